@@ -1,0 +1,206 @@
+"""Pins the CPU oracle (oracle/neube_oracle.py) against golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  CPU only; never reads /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+from oracle import neube_oracle as orc
+from conftest import load_golden
+
+T = torch.from_numpy
+
+
+def close(a, b, tol):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    err = float(np.abs(a.astype(np.float64) - np.asarray(b, np.float64)).max())
+    assert err <= tol, f"max abs err {err} > {tol}"
+
+
+def test_bias_act_kats(ops_kat):
+    k = ops_kat
+    x, b = T(k["ba_x"]), T(k["ba_b"])
+    for act in ("lrelu", "linear", "tanh"):
+        close(orc.bias_act(x, b, act=act), k[f"ba_{act}_n"], 1e-6)
+        close(orc.bias_act(x, b, act=act, clamp=1.5), k[f"ba_{act}_c"], 1e-6)
+    close(orc.bias_act(x, b, act="lrelu", gain=np.sqrt(2) * 0.5, clamp=128.0), k["ba_lrelu_gain"], 1e-6)
+    close(orc.bias_act(T(k["ba2_x"]), T(k["ba2_b"]), dim=1, act="tanh"), k["ba2_tanh"], 1e-6)
+
+
+def test_upfirdn2d_kats(ops_kat):
+    k = ops_kat
+    f = orc.setup_filter((1, 3, 3, 1))
+    close(f, k["fir_f"], 0)
+    x = T(k["fir_x"])
+    close(orc.upfirdn2d(x, f, padding=(1, 1, 1, 1), gain=4), k["fir_pad1_gain4"], 1e-6)
+    close(orc.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4), k["fir_up2"], 1e-6)
+    close(orc.upfirdn2d(x, f, down=2, padding=(1, 1, 1, 1)), k["fir_down2"], 1e-6)
+    close(orc.upfirdn2d(x, T(k["fir_f_ragged"]), padding=(1, 0, 2, -1), flip_filter=True, gain=1.5),
+          k["fir_ragged_flip"], 1e-6)
+
+
+def test_modulated_conv2d_kats(ops_kat):
+    k = ops_kat
+    x, w, s = T(k["mc_x"]), T(k["mc_w"]), T(k["mc_s"])
+    f = orc.setup_filter((1, 3, 3, 1))
+    for up in (1, 2):
+        noise = T(k[f"mc_noise_up{up}"])
+        for demod in (True, False):
+            for use_noise in (True, False):
+                for fused in (True, False):
+                    y = orc.modulated_conv2d(x, w, s, noise=noise if use_noise else None, up=up, padding=1,
+                                             resample_filter=f, demodulate=demod, flip_weight=(up == 1),
+                                             fused_modconv=fused)
+                    close(y, k[f"mc_up{up}_d{int(demod)}_n{int(use_noise)}_f{int(fused)}"], 2e-5)
+    close(orc.modulated_conv2d(x, T(k["mc_w1x1"]), s, demodulate=False), k["mc_1x1_nodemod"], 1e-5)
+
+
+def test_direct_loops_agree_with_reference(ops_kat):
+    """The torch-free float64 loop evaluation of SURVEY note A equals the reference's outputs."""
+    k = ops_kat
+    for up in (1, 2):
+        y = orc.direct_modconv_numpy(k["mc_x"], k["mc_w"], k["mc_s"], up=up, demodulate=True, f=k["fir_f"])
+        close(y, k[f"mc_up{up}_d1_n0_f1"], 2e-5)
+
+
+def test_fc_and_normalize(ops_kat):
+    k = ops_kat
+    x = T(k["fc_x"])
+    close(orc.fully_connected(x, T(k["fc_lrelu_w"]), T(k["fc_lrelu_b"]), "lrelu", 0.01), k["fc_lrelu_y"], 1e-6)
+    close(orc.fully_connected(x, T(k["fc_lin_w"]), T(k["fc_lin_b"]), "linear", 1.0), k["fc_lin_y"], 1e-6)
+    close(orc.normalize_2nd_moment(x), k["n2m_y"], 1e-6)
+
+
+def test_shifted_noise_matches_grid_sample(ops_kat):
+    k = ops_kat
+    R = int(k["ns_R"])
+    pos = T(k["ns_pos"])
+    normp = (pos % R) / (R - 1)
+    close(orc.shifted_const_noise(T(k["ns_noise"]), T(k["ns_grid"]), normp), k["ns_out"], 1e-6)
+    # and against torch's own grid_sample on a fresh random case at another resolution
+    rs = np.random.RandomState(0)
+    r, R = 16, 256
+    noise = T(rs.randn(r, r).astype(np.float32))
+    grid = T(wmod.make_noise_grid(r))
+    pos = T(rs.randint(0, 4096, (7, 2)))
+    normp = (pos % R) / (R - 1)
+    want = torch.nn.functional.grid_sample(noise[None, None].expand(7, -1, -1, -1),
+                                           ((grid + normp.unsqueeze(1).unsqueeze(1)) % 1) * 2 - 1,
+                                           padding_mode="reflection", align_corners=True)
+    close(orc.shifted_const_noise(noise, grid, normp), want.numpy(), 1e-6)
+
+
+def _tiny():
+    g = load_golden("gen_tiny.npz")
+    cfg = cfgmod.tiny_config(32)
+    sd = wmod.random_state_dict(cfg, seed=int(g["weights_seed"]))
+    geom = synthetic.geom_features(cfg, 3, seed=int(g["geom_seed"]))
+    return g, cfg, orc.OracleGenerator(cfg, sd), geom
+
+
+def test_generator_tiny_case_A_all_layers():
+    g, cfg, G, geom = _tiny()
+    taps = {}
+    img, dbg = G(g["z"], None, geom, positions=g["positions"], return_debug_data=True, return_features=[16], taps=taps)
+    close(dbg["ws"], g["A_ws"], 1e-5)
+    for l in cfg.layers:
+        close(taps[f"{l.name}.out"], g[f"A_{l.name}.out"], 1e-4)
+    close(taps["torgb.logits"], g["A_torgb.logits"], 2e-4)
+    close(dbg["colors"], g["A_colors"], 1e-5)
+    close(dbg["uvs"], g["A_uvs"], 2e-5)
+    close(img, g["A_img"], 2e-5)
+    close(dbg["features16"], g["A_features16"], 1e-4)
+    close(dbg["features16_preblend"], g["A_features16_preblend"], 1e-4)
+
+
+def test_generator_tiny_other_cases():
+    g, cfg, G, geom = _tiny()
+    close(G(g["z"], None, geom), g["B_img"], 2e-5)
+    nb = {k[len("C_nb_"):]: g[k] for k in g if k.startswith("C_nb_")}
+    img, dbg = G.forward_pre_mapped(g["C_ws"], geom, positions=g["positions"][::-1].copy(), return_debug_data=True,
+                                    noise_buffers=nb)
+    close(img, g["C_img"], 2e-5)
+    close(dbg["uvs"], g["C_uvs"], 2e-5)
+    close(dbg["colors"], g["C_colors"], 1e-5)
+    geom1 = [x[:1] for x in geom]
+    img, dbg = G(g["z"][:1], None, geom1, positions=g["positions"][:1], return_debug_data=True, return_features=[16],
+                 blended_features={16: {"features": g["D_feat"], "alpha": g["D_alpha"]}})
+    close(img, g["D_img"], 2e-5)
+    close(dbg["features16"], g["D_features16"], 1e-4)
+    close(dbg["features16_preblend"], g["D_features16_preblend"], 1e-4)
+    img, dbg = G(g["z"][:1], None, geom1, return_features=[32], truncation_psi=0.7,
+                 blended_features={32: {"features": g["E_feat"], "alpha": g["E_alpha"]}})
+    close(img, g["E_img"], 2e-5)
+    close(dbg["uvs"], g["E_uvs"], 2e-5)
+    close(dbg["features32"], g["E_features32"], 1e-4)
+
+
+def test_fused_and_nonfused_agree_tiny():
+    g, cfg, G, geom = _tiny()
+    a = G(g["z"], None, geom, positions=g["positions"], fused_modconv=True)
+    b = G(g["z"], None, geom, positions=g["positions"], fused_modconv=False)
+    close(a, b.numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("res", [128])
+def test_generator_full_shapes(res):
+    """style1 shapes at R=128 (as shipped).  R=256 takes ~1 min on CPU and is checked in the GPU suite
+    (HIP vs the same fixture) plus tests/test_oracle_golden_r256 when NEUBE_SLOW=1."""
+    _check_full(res)
+
+
+def _check_full(res):
+    g = load_golden(f"gen_r{res}.npz")
+    cfg = cfgmod.style1_config(res)
+    sd = wmod.random_state_dict(cfg, seed=int(g["weights_seed"]))
+    geom = synthetic.geom_features(cfg, 2, seed=int(g["geom_seed"]))
+    G = orc.OracleGenerator(cfg, sd)
+    taps = {}
+    half = res // 2
+    img, dbg = G(g["z"], None, geom, positions=g["positions"], return_debug_data=True, return_features=[half], taps=taps)
+    step = int(g["step"])
+    close(dbg["ws"], g["ws"], 1e-5)
+    close(dbg["colors"], g["colors"], 1e-5)
+
+    def chk(name, full, tol):
+        full = full.numpy()
+        s = 1 if full.shape[-1] <= 16 else step
+        got = full[..., ::s, ::s] if full.shape[1] <= 4 else full[:, ::8, ::s, ::s]
+        close(got, g[f"{name}.sub"], tol)
+        st = g[f"{name}.stats"]
+        f64 = full.astype(np.float64)
+        assert abs(f64.sum() - st[0]) <= 1e-5 * max(1.0, np.sqrt(st[1] * f64.size))
+        assert abs((f64 * f64).sum() - st[1]) <= 1e-5 * st[1]
+
+    for l in cfg.layers:
+        chk(f"{l.name}.out", taps[f"{l.name}.out"], 2e-4)
+    chk("logits", taps["torgb.logits"], 5e-4)
+    chk("uvs", dbg["uvs"], 5e-5)
+    chk("img", img, 5e-5)
+    chk(f"features{half}", dbg[f"features{half}"], 2e-4)
+    close(dbg["uvs"].numpy()[:, :, res // 3, :], g["uvs.row"], 5e-5)
+
+
+def test_generator_full_shapes_256_slow():
+    import os
+    if os.environ.get("NEUBE_SLOW") != "1":
+        pytest.skip("set NEUBE_SLOW=1 (about a minute of CPU)")
+    _check_full(256)
+
+
+def test_triad_composite_semantics():
+    rs = np.random.RandomState(3)
+    uvs = torch.softmax(T(rs.randn(2, 3, 5, 5).astype(np.float32)), dim=1)
+    colors = torch.tanh(T(rs.randn(2, 3, 3).astype(np.float32)))
+    rgba = orc.triad_composite(uvs, colors, "clear")
+    assert rgba.shape == (2, 4, 5, 5)
+    close(rgba[:, 3], (uvs[:, 0] + uvs[:, 1]).numpy(), 1e-6)
+    c01 = (colors + 1) / 2
+    want = sum(uvs[:, k][:, None] * c01[:, :, k][:, :, None, None] for k in range(3))
+    close(rgba[:, :3], want.numpy(), 1e-6)
+    full = orc.triad_composite(uvs, colors, "full")
+    assert float(full[:, 3].min()) == 1.0
+    with pytest.raises(RuntimeError):
+        orc.triad_composite(uvs, colors, "bogus")
+    u8 = orc.rgba_to_uint8(rgba)
+    assert u8.dtype == torch.uint8
