@@ -1,0 +1,96 @@
+"""ctypes binding of ``csrc/libneube_hip.so`` (the C ABI declared in ``include/neube_hip.h``).
+
+There is no CPU fallback: if the library is missing or a symbol cannot be resolved this raises, and
+every product-path op goes through :func:`lib`.  (The reference silently falls back to slow
+``_ref`` ops when its plugin build fails, ``torch_utils/ops/bias_act.py:47-50``; this build must not.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+# torch MUST be imported before the library is dlopen'ed: the torch wheel bundles its own HIP runtime
+# (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  Loaded first, it satisfies this library's
+# NEEDED libamdhip64.so.7, so kernels, device pointers and streams all live in ONE runtime.  Loaded
+# second, /opt/rocm's copy would come in beside it and launches fail with "no ROCm-capable device".
+import torch  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+f32p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class NbLayerDesc(C.Structure):
+    """Mirror of ``struct NbLayerDesc`` (include/neube_hip.h)."""
+    _fields_ = [
+        ("affine_w", C.c_uint64), ("affine_b", C.c_uint64), ("wsq", C.c_uint64), ("styles", C.c_uint64),
+        ("dcoefs", C.c_uint64), ("noise_const", C.c_uint64), ("noise_lin", C.c_uint64), ("noise_out", C.c_uint64),
+        ("noise_strength", C.c_uint64),
+        ("c_aff", C.c_int32), ("n_plain", C.c_int32), ("c_out", C.c_int32), ("w_index", C.c_int32),
+        ("res", C.c_int32), ("style_scale", C.c_float), ("pad_", C.c_int32 * 2),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/neube_hip.h
+PROTOTYPES = {
+    "nb_last_error": (C.c_char_p, []),
+    "nb_abi_version": (C.c_int, []),
+    "nb_bias_act_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
+    "nb_upfirdn2d_f32": (C.c_int, [vp, vp, vp] + [C.c_int] * 14 + [C.c_float, vp]),
+    "nb_mapping_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "nb_styles_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_demod_coefs_f32": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_noise_f32": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "nb_modconv3x3_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
+    "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, vp, vp,
+                                     C.c_int, C.c_int, C.c_int, vp]),
+    "nb_blend_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_pack_conv_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+}
+
+
+class NeubeHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NeubeHipError(
+                f"HIP kernel library not found at {LIB_PATH}. Build it with "
+                f"`python -m brushstroke_engine_amd.build` (needs hipcc, gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:
+                raise NeubeHipError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+            fn.restype = res
+            fn.argtypes = args
+        v = l.nb_abi_version()
+        if v != ABI_VERSION:
+            raise NeubeHipError(f"ABI version mismatch: library {v}, python {ABI_VERSION}; rebuild the library")
+        _lib = l
+        return _lib
+
+
+def check(code: int, what: str) -> None:
+    """Translate a negative NB_E* return code into the exception type the reference would raise
+    (TORCH_CHECK failures surface as RuntimeError, bias_act.cpp:35-52)."""
+    if code != 0:
+        msg = lib().nb_last_error().decode("utf-8", "replace")
+        raise NeubeHipError(f"{what} failed ({code}): {msg}")

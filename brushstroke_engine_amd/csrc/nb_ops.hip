@@ -1,0 +1,484 @@
+// Non-contraction kernels of the NeuBE generator path for gfx950: bias_act, upfirdn2d (standalone
+// operator parity with the reference plugins), mapping network, per-layer styles + demodulation
+// coefficients, constant-noise resampling, triad ToRGB epilogue, feature blending.
+// All are HBM- or latency-bound; they use 64-wide waves, 16-byte accesses where the layout allows,
+// and LDS only for per-block constants.
+#include "nb_common.h"
+#include <cmath>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void nb_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* nb_last_error(void) { return g_err; }
+extern "C" int nb_abi_version(void) { return NB_ABI_VERSION; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// bias_act  (reference: torch_utils/ops/bias_act.cu:23-147, forward, fp32)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nb_act(float x, int act, float alpha) {
+    switch (act) {
+        case NB_ACT_RELU: return x > 0.f ? x : 0.f;
+        case NB_ACT_LRELU: return x > 0.f ? x : x * alpha;
+        case NB_ACT_TANH: return tanhf(x);
+        case NB_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        default: return x;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                                       float* __restrict__ y, long long size_x, int size_b,
+                                                       int step_b, int act, float alpha, float gain, float clamp) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (VEC) {
+        const long long n4 = size_x >> 2;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+            const float bb = size_b ? b[((i << 2) / step_b) % size_b] : 0.f;   // step_b % 4 == 0: one bias per vector
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = nb_act(v[j] + bb, act, alpha) * gain;
+                if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
+                v[j] = t;
+            }
+            reinterpret_cast<f32x4*>(y)[i] = v;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < size_x; i += stride) {
+            const float bb = size_b ? b[(i / step_b) % size_b] : 0.f;
+            float t = nb_act(x[i] + bb, act, alpha) * gain;
+            if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
+            y[i] = t;
+        }
+    }
+}
+
+extern "C" int nb_bias_act_f32(const float* x, const float* b, float* y, int64_t size_x, int size_b, int step_b,
+                               int act, float alpha, float gain, float clamp, void* stream) {
+    NB_REQUIRE(x && y, "bias_act: null pointer");
+    NB_REQUIRE(size_x >= 0, "bias_act: negative size");
+    NB_REQUIRE(size_b == 0 || (b && step_b >= 1), "bias_act: bias given without a valid step");
+    NB_REQUIRE(act >= NB_ACT_LINEAR && act <= NB_ACT_SIGMOID, "bias_act: unsupported activation %d", act);
+    if (size_x == 0) return NB_OK;
+    const bool vec = (size_x % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0) && (size_b == 0 || step_b % 4 == 0);
+    const long long work = vec ? size_x / 4 : size_x;
+    int grid = (int)((work + 255) / 256);
+    if (grid > 2048 * 4) grid = 2048 * 4;
+    if (vec)
+        hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, b, y, (long long)size_x, size_b, step_b, act, alpha, gain, clamp);
+    else
+        hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, b, y, (long long)size_x, size_b, step_b, act, alpha, gain, clamp);
+    NB_CHECK_LAUNCH("bias_act");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// upfirdn2d  (reference: torch_utils/ops/upfirdn2d.cu:29-92 generic kernel semantics, fp32, NCHW)
+// ------------------------------------------------------------------------------------------------
+struct UpfirdnParams {
+    const float* x; const float* f; float* y;
+    int major, in_h, in_w, out_h, out_w, f_h, f_w, upx, upy, downx, downy, padx0, pady0, flip;
+    float gain;
+};
+
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirdnParams p) {
+    extern __shared__ float sf[];
+    for (int i = threadIdx.x; i < p.f_h * p.f_w; i += blockDim.x) {
+        // store the filter so that tap (fy, fx) below is always "filter as correlated with the padded input"
+        const int fy = i / p.f_w, fx = i % p.f_w;
+        const int sy = p.flip ? fy : p.f_h - 1 - fy, sx = p.flip ? fx : p.f_w - 1 - fx;
+        sf[i] = p.f[sy * p.f_w + sx] * p.gain;
+    }
+    __syncthreads();
+    const long long total = (long long)p.major * p.out_h * p.out_w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % p.out_w);
+        const int oy = (int)((idx / p.out_w) % p.out_h);
+        const int m = (int)(idx / ((long long)p.out_w * p.out_h));
+        // position of the window's first tap in the upsampled (zero-stuffed), un-padded image
+        const int ux0 = ox * p.downx - p.padx0, uy0 = oy * p.downy - p.pady0;
+        const float* xm = p.x + (size_t)m * p.in_h * p.in_w;
+        float v = 0.f;
+        for (int fy = 0; fy < p.f_h; ++fy) {
+            const int uy = uy0 + fy;
+            if (uy < 0 || uy % p.upy != 0) continue;
+            const int iy = uy / p.upy;
+            if (iy >= p.in_h) continue;
+            for (int fx = 0; fx < p.f_w; ++fx) {
+                const int ux = ux0 + fx;
+                if (ux < 0 || ux % p.upx != 0) continue;
+                const int ix = ux / p.upx;
+                if (ix >= p.in_w) continue;
+                v += xm[iy * p.in_w + ix] * sf[fy * p.f_w + fx];
+            }
+        }
+        p.y[idx] = v;
+    }
+}
+
+extern "C" int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int major, int in_h, int in_w, int f_h,
+                                int f_w, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
+                                int pady1, int flip, float gain, void* stream) {
+    NB_REQUIRE(x && f && y, "upfirdn2d: null pointer");
+    NB_REQUIRE(major >= 1 && in_h >= 1 && in_w >= 1, "upfirdn2d: empty input");
+    NB_REQUIRE(f_h >= 1 && f_w >= 1 && f_h * f_w <= 1024, "upfirdn2d: filter must be between 1x1 and 1024 taps");
+    NB_REQUIRE(upx >= 1 && upy >= 1, "upfirdn2d: upsampling factor must be at least 1");
+    NB_REQUIRE(downx >= 1 && downy >= 1, "upfirdn2d: downsampling factor must be at least 1");
+    UpfirdnParams p;
+    p.x = x; p.f = f; p.y = y; p.major = major; p.in_h = in_h; p.in_w = in_w; p.f_h = f_h; p.f_w = f_w;
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0; p.flip = flip; p.gain = gain;
+    p.out_w = (in_w * upx + padx0 + padx1 - f_w + downx) / downx;
+    p.out_h = (in_h * upy + pady0 + pady1 - f_h + downy) / downy;
+    NB_REQUIRE(p.out_w >= 1 && p.out_h >= 1, "upfirdn2d: output must be at least 1x1");
+    const long long total = (long long)major * p.out_h * p.out_w;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid), dim3(256), f_h * f_w * sizeof(float), (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("upfirdn2d");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mapping network  (reference: training/networks.py:255-290, :109-122, :24-26)
+// one workgroup per latent; activations ping-pong through LDS; one output feature per thread
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mapping_kernel(const float* __restrict__ z, const float* __restrict__ fc_w,
+                                                      const float* __restrict__ fc_b, float* __restrict__ w_out,
+                                                      int z_dim, int w_dim, int num_layers, float lr_mul) {
+    __shared__ float xa[512], xb[512], red[8];
+    const int n = blockIdx.x, t = threadIdx.x;
+    // normalize_2nd_moment
+    float v = t < z_dim ? z[(size_t)n * z_dim + t] : 0.f;
+    float sq = v * v;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((t & 63) == 0) red[t >> 6] = sq;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < 8; ++i) tot += red[i];
+    xa[t] = v * rsqrtf(tot / (float)z_dim + 1e-8f);
+    __syncthreads();
+    float* cur = xa; float* nxt = xb;
+    const float* wl = fc_w;
+    for (int l = 0; l < num_layers; ++l) {
+        const int in = l == 0 ? z_dim : w_dim;
+        const float wg = lr_mul / sqrtf((float)in);
+        if (t < w_dim) {
+            const float* wr = wl + (size_t)t * in;
+            float acc = 0.f;
+            for (int i = 0; i < in; ++i) acc += cur[i] * (wr[i] * wg);
+            acc += fc_b[l * w_dim + t] * lr_mul;
+            acc = (acc > 0.f ? acc : acc * 0.2f) * 1.41421356237309515f;
+            nxt[t] = acc;
+        }
+        __syncthreads();
+        wl += (size_t)w_dim * in;
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (t < w_dim) w_out[(size_t)n * w_dim + t] = cur[t];
+}
+
+extern "C" int nb_mapping_f32(const float* z, const float* fc_w, const float* fc_b, float* w_out, int n, int z_dim,
+                              int w_dim, int num_layers, float lr_mul, void* stream) {
+    NB_REQUIRE(z && fc_w && fc_b && w_out, "mapping: null pointer");
+    NB_REQUIRE(n >= 1, "mapping: empty batch");
+    NB_REQUIRE(z_dim >= 1 && z_dim <= 512 && w_dim >= 1 && w_dim <= 512, "mapping: z_dim/w_dim must be in [1,512]");
+    NB_REQUIRE(num_layers >= 1, "mapping: need at least one layer");
+    hipLaunchKernelGGL(mapping_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, z, fc_w, fc_b, w_out, z_dim, w_dim, num_layers, lr_mul);
+    NB_CHECK_LAUNCH("mapping");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-layer styles (affine) + demodulation coefficients, all layers in one launch
+// grid = (n_layers, n); reference: networks.py:366 (affine), :59-62 (dcoefs), :458-460 (ToRGB split/scale)
+// ------------------------------------------------------------------------------------------------
+#define NB_MAX_AFF 1024
+__global__ __launch_bounds__(256) void styles_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ ws,
+                                                     int num_ws, int w_dim) {
+    __shared__ float wv[512];
+    __shared__ float s2[NB_MAX_AFF];
+    const NbLayerDesc L = layers[blockIdx.x];
+    const int n = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < w_dim; i += 256) wv[i] = ws[((size_t)n * num_ws + L.w_index) * w_dim + i];
+    __syncthreads();
+    const float wg = 1.f / sqrtf((float)w_dim);
+    for (int c = t; c < L.c_aff; c += 256) {
+        const float* wr = L.affine_w + (size_t)c * w_dim;
+        float acc = 0.f;
+        for (int i = 0; i < w_dim; ++i) acc += wv[i] * (wr[i] * wg);
+        acc += L.affine_b[c];
+        if (c >= L.n_plain) acc *= L.style_scale;
+        L.styles[(size_t)n * L.c_aff + c] = acc;
+        s2[c] = acc * acc;
+    }
+    __syncthreads();
+    if (L.wsq) {
+        const int c_in = L.c_aff - L.n_plain;
+        for (int o = t; o < L.c_out; o += 256) {
+            float acc = 0.f;
+            for (int i = 0; i < c_in; ++i) acc += s2[L.n_plain + i] * L.wsq[(size_t)i * L.c_out + o];
+            L.dcoefs[(size_t)n * L.c_out + o] = rsqrtf(acc + 1e-8f);
+        }
+    }
+}
+
+extern "C" int nb_styles_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim, int n,
+                             void* stream) {
+    NB_REQUIRE(layers_dev && ws, "styles: null pointer");
+    NB_REQUIRE(n_layers >= 1 && n >= 1 && n <= 65535, "styles: bad sizes");
+    NB_REQUIRE(w_dim >= 1 && w_dim <= 512, "styles: w_dim must be in [1,512]");
+    hipLaunchKernelGGL(styles_kernel, dim3(n_layers, n), dim3(256), 0, (hipStream_t)stream, layers_dev, ws, num_ws, w_dim);
+    NB_CHECK_LAUNCH("styles");
+    return NB_OK;
+}
+
+// standalone demodulation coefficients (networks.py:59-62): d[n,o] = rsqrt(sum_i s[n,i]^2 * wsq[i,o] + 1e-8)
+__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq,
+                                                    float* __restrict__ dcoefs, int c_in, int c_out) {
+    const int n = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= c_out) return;
+    float acc = 0.f;
+    for (int i = 0; i < c_in; ++i) {
+        const float s = styles[(size_t)n * c_in + i];
+        acc += (s * s) * wsq[(size_t)i * c_out + o];
+    }
+    dcoefs[(size_t)n * c_out + o] = rsqrtf(acc + 1e-8f);
+}
+
+extern "C" int nb_demod_coefs_f32(const float* styles, const float* wsq, float* dcoefs, int n, int c_in, int c_out,
+                                  void* stream) {
+    NB_REQUIRE(styles && wsq && dcoefs, "demod_coefs: null pointer");
+    NB_REQUIRE(n >= 1 && n <= 65535 && c_in >= 1 && c_out >= 1, "demod_coefs: bad sizes");
+    hipLaunchKernelGGL(demod_kernel, dim3(nb_cdiv(c_out, 256), n), dim3(256), 0, (hipStream_t)stream, styles, wsq, dcoefs, c_in, c_out);
+    NB_CHECK_LAUNCH("demod_coefs");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// constant noise, optionally position-shifted (networks.py:371-382, SURVEY note C), all layers at once
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ norm_pos,
+                                                    const long long* __restrict__ positions, int img_res) {
+    const NbLayerDesc L = layers[blockIdx.y];
+    if (!L.noise_const) return;
+    const int r = L.res, n = blockIdx.z;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= r * r) return;
+    const float strength = L.noise_strength[0];
+    if (!norm_pos && !positions) {
+        L.noise_out[idx] = L.noise_const[idx] * strength;
+        return;
+    }
+    const int i = idx / r, j = idx - i * r;
+    float np0, np1;
+    if (positions) {
+        // networks_modified.py:351-353: (positions % R) / (R - 1), python-style modulo, IEEE float32 division
+        // (done here, not with a torch GPU op: torch's device division is not correctly rounded and the
+        // wrap `% 1` below is discontinuous, so a 1-ulp difference moves whole noise rows)
+        const long long R = img_res;
+        const long long p0 = ((positions[2 * n + 0] % R) + R) % R, p1 = ((positions[2 * n + 1] % R) + R) % R;
+        np0 = (float)p0 / (float)(img_res - 1);
+        np1 = (float)p1 / (float)(img_res - 1);
+    } else {
+        np0 = norm_pos[2 * n + 0];
+        np1 = norm_pos[2 * n + 1];
+    }
+    // grid[i,j] = (lin[i] + pos0, lin[j] + pos1); channel 0 is the COLUMN coordinate, channel 1 the ROW
+    const float g0 = fmodf(L.noise_lin[i] + np0, 1.f) * 2.f - 1.f;
+    const float g1 = fmodf(L.noise_lin[j] + np1, 1.f) * 2.f - 1.f;
+    const float cx = ((g0 + 1.f) / 2.f) * (float)(r - 1);
+    const float cy = ((g1 + 1.f) / 2.f) * (float)(r - 1);
+    const float x0 = floorf(cx), y0 = floorf(cy);
+    const int x0i = (int)x0, y0i = (int)y0, x1i = x0i + 1, y1i = y0i + 1;
+    const float wx1 = cx - x0, wy1 = cy - y0, wx0 = (x0 + 1.f) - cx, wy0 = (y0 + 1.f) - cy;
+    auto tap = [&](int yi, int xi) -> float {
+        return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? L.noise_const[yi * r + xi] : 0.f;
+    };
+    float v = tap(y0i, x0i) * (wx0 * wy0);
+    v += tap(y0i, x1i) * (wx1 * wy0);
+    v += tap(y1i, x0i) * (wx0 * wy1);
+    v += tap(y1i, x1i) * (wx1 * wy1);
+    L.noise_out[(size_t)n * r * r + idx] = v * strength;
+}
+
+extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max_res, const float* norm_pos,
+                            const int64_t* positions, int img_resolution, int n, void* stream) {
+    NB_REQUIRE(layers_dev, "noise: null pointer");
+    NB_REQUIRE(n_layers >= 1 && n_layers <= 65535 && max_res >= 1 && n >= 1 && n <= 65535, "noise: bad sizes");
+    NB_REQUIRE(!(norm_pos && positions), "noise: pass either norm_pos or positions, not both");
+    NB_REQUIRE(!positions || img_resolution >= 2, "noise: positions need img_resolution >= 2");
+    dim3 grid(nb_cdiv(max_res * max_res, 256), n_layers, (norm_pos || positions) ? n : 1);
+    hipLaunchKernelGGL(noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, layers_dev, norm_pos,
+                       (const long long*)positions, img_resolution);
+    NB_CHECK_LAUNCH("noise");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// triad ToRGB epilogue (networks.py:451-485) + paint-engine compositing (forger/ui/brush.py:763-792)
+// HBM-bound: reads x once (16 B per lane per channel), writes the 3-channel results.
+// ------------------------------------------------------------------------------------------------
+struct TorgbParams {
+    const float* x; const float* styles; const float* w; const float* bias; const float* color_bias;
+    float* logits; float* uvs; float* img; float* colors_out; const float* user_colors; float* rgba_f32; uint8_t* rgba_u8;
+    int styles_stride_n, c, hw, render_mode;
+    float clamp;
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
+    extern __shared__ float sw[];          // [3][c] modulated weights, then 9 colors, 9 col01
+    float* scol = sw + 3 * p.c;
+    float* scol01 = scol + 9;
+    const int n = blockIdx.y, t = threadIdx.x;
+    const float* st = p.styles + (size_t)n * p.styles_stride_n;
+    for (int i = t; i < 3 * p.c; i += 256) {
+        const int o = i / p.c, ch = i - o * p.c;
+        sw[i] = p.w[o * p.c + ch] * st[9 + ch];
+    }
+    if (t < 9) {
+        const float col = tanhf(st[t] + p.color_bias[t]);
+        scol[t] = col;
+        float c01 = (col + 1.f) / 2.f;
+        if (p.user_colors) {
+            const float u = p.user_colors[n * 9 + t];
+            if (!(u != u)) c01 = u;
+        }
+        scol01[t] = c01;
+        if (p.colors_out && blockIdx.x == 0) p.colors_out[n * 9 + t] = col;
+    }
+    __syncthreads();
+    const int pix = (blockIdx.x * 256 + t) * V;
+    if (pix >= p.hw) return;
+    float a0[V], a1[V], a2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a0[j] = a1[j] = a2[j] = 0.f;
+    const float* xp = p.x + (size_t)n * p.c * p.hw + pix;
+#pragma unroll 8
+    for (int ch = 0; ch < p.c; ++ch) {
+        float xv[V];
+        if constexpr (V == 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(xp + (size_t)ch * p.hw);
+            xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2]; xv[3] = q[3];
+        } else {
+            xv[0] = xp[(size_t)ch * p.hw];
+        }
+        const float w0 = sw[ch], w1 = sw[p.c + ch], w2 = sw[2 * p.c + ch];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a0[j] += xv[j] * w0; a1[j] += xv[j] * w1; a2[j] += xv[j] * w2; }
+    }
+    const float b0 = p.bias[0], b1 = p.bias[1], b2 = p.bias[2];
+    float lg[3][V], uv[3][V], im[3][V], rg[4][V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        float l0 = a0[j] + b0, l1 = a1[j] + b1, l2 = a2[j] + b2;
+        if (p.clamp >= 0.f) {
+            l0 = fminf(fmaxf(l0, -p.clamp), p.clamp); l1 = fminf(fmaxf(l1, -p.clamp), p.clamp); l2 = fminf(fmaxf(l2, -p.clamp), p.clamp);
+        }
+        const float m = fmaxf(l0, fmaxf(l1, l2));
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+        const float inv = 1.f / (e0 + e1 + e2);
+        const float u = e0 * inv, v = e1 * inv, s = e2 * inv;
+        lg[0][j] = l0; lg[1][j] = l1; lg[2][j] = l2;
+        uv[0][j] = u; uv[1][j] = v; uv[2][j] = s;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            im[ch][j] = u * scol[ch * 3 + 0] + v * scol[ch * 3 + 1] + s * scol[ch * 3 + 2];
+            rg[ch][j] = u * scol01[ch * 3 + 0] + v * scol01[ch * 3 + 1] + s * scol01[ch * 3 + 2];
+        }
+        rg[3][j] = p.render_mode == 0 ? u + v : 1.f;
+    }
+    auto put = [&](float* base, int nch, int ch, const float (&vals)[V]) {
+        float* dst = base + ((size_t)n * nch + ch) * p.hw + pix;
+        if constexpr (V == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{vals[0], vals[1], vals[2], vals[3]};
+        else dst[0] = vals[0];
+    };
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        if (p.logits) put(p.logits, 3, ch, lg[ch]);
+        if (p.uvs) put(p.uvs, 3, ch, uv[ch]);
+        if (p.img) put(p.img, 3, ch, im[ch]);
+    }
+    if (p.rgba_f32) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) put(p.rgba_f32, 4, ch, rg[ch]);
+    }
+    if (p.rgba_u8) {
+        uint32_t pk[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            pk[j] = 0;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float q = fminf(fmaxf(rg[ch][j] * 255.f, 0.f), 255.f);   // (x*255).clip(0,255).to(uint8): truncation
+                pk[j] |= ((uint32_t)q & 0xffu) << (8 * ch);
+            }
+        }
+        uint32_t* dst = reinterpret_cast<uint32_t*>(p.rgba_u8) + (size_t)n * p.hw + pix;    // [n][hw][4] bytes (HWC)
+        if constexpr (V == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        else dst[0] = pk[0];
+    }
+}
+
+extern "C" int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n, const float* w,
+                                  const float* bias, const float* color_bias, float clamp, float* logits, float* uvs,
+                                  float* img, float* colors_out, const float* user_colors, int render_mode,
+                                  float* rgba_f32, uint8_t* rgba_u8, int n, int c, int hw, void* stream) {
+    NB_REQUIRE(x && styles && w && bias && color_bias, "torgb_triad: null pointer");
+    NB_REQUIRE(n >= 1 && n <= 65535 && c >= 1 && c <= 4096 && hw >= 1, "torgb_triad: bad sizes");
+    NB_REQUIRE(styles_stride_n >= c + 9, "torgb_triad: styles rows must hold 9 color scalars + c styles");
+    NB_REQUIRE(render_mode == 0 || render_mode == 1, "Unknown render mode for TriadGanPaintEngine: %d", render_mode);
+    TorgbParams p;
+    p.x = x; p.styles = styles; p.w = w; p.bias = bias; p.color_bias = color_bias; p.logits = logits; p.uvs = uvs; p.img = img;
+    p.colors_out = colors_out; p.user_colors = user_colors; p.rgba_f32 = rgba_f32; p.rgba_u8 = rgba_u8;
+    p.styles_stride_n = styles_stride_n; p.c = c; p.hw = hw; p.render_mode = render_mode; p.clamp = clamp;
+    const size_t lds = (size_t)(3 * c + 18) * sizeof(float);
+    const bool vec = (hw % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    if (vec) {
+        dim3 grid(nb_cdiv(hw, 1024), n);
+        hipLaunchKernelGGL(torgb_triad_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    } else {
+        dim3 grid(nb_cdiv(hw, 256), n);
+        hipLaunchKernelGGL(torgb_triad_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    }
+    NB_CHECK_LAUNCH("torgb_triad");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature blending (forger/train/stitching.py:24-25)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ feat, int nf, const float* __restrict__ alpha,
+                                                    int na, const float* __restrict__ x, float* __restrict__ y,
+                                                    int c, int hw, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int pix = (int)(i % hw);
+        const long long nc = i / hw;
+        const int ch = (int)(nc % c);
+        const int n = (int)(nc / c);
+        const float a = alpha[(size_t)(na == 1 ? 0 : n) * hw + pix];
+        const float f = feat[((size_t)(nf == 1 ? 0 : n) * c + ch) * hw + pix];
+        y[i] = a * f + (1.f - a) * x[i];
+    }
+}
+
+extern "C" int nb_blend_f32(const float* features, int nf, const float* alpha, int na, const float* x, float* y, int n,
+                            int c, int hw, void* stream) {
+    NB_REQUIRE(features && alpha && x && y, "blend: null pointer");
+    NB_REQUIRE(n >= 1 && c >= 1 && hw >= 1, "blend: bad sizes");
+    NB_REQUIRE((nf == 1 || nf == n) && (na == 1 || na == n), "blend: features/alpha batch must be 1 or n");
+    const long long total = (long long)n * c * hw;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(blend_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, features, nf, alpha, na, x, y, c, hw, total);
+    NB_CHECK_LAUNCH("blend");
+    return NB_OK;
+}

@@ -1,0 +1,501 @@
+"""MI355X-native NeuBE generator behind the reference's ``Generator`` API.
+
+Drop-in for the object the reference stores as ``engine.G`` (``forger/ui/brush.py:631-633``):
+same attributes (``z_dim c_dim w_dim img_resolution img_channels num_ws mapping synthesis``,
+``synthesis.block_resolutions``, ``synthesis.b{res}.conv{0,1}.noise_const`` ...), the same
+keyword-exact call signatures and return conventions as
+``thirdparty/stylegan2_ada_pytorch/training/networks_modified.py:123-124, 346-348, 367-368`` and the
+same ``state_dict()`` key names, so ``TriadGanPaintEngine._render_stroke_torch`` (brush.py:731-805),
+``StyleUVSMapper`` (forger/ui/mapper.py:80-92) and ``PaintStrokeGenerator`` (forger/metrics/util.py)
+can call it unmodified.
+
+All arithmetic runs in the hand-written gfx950 kernels of ``csrc/`` through the C ABI of
+``include/neube_hip.h``; PyTorch only owns device memory and the stream.  Per forward pass:
+1 mapping launch, 1 launch for every layer's affine + demodulation coefficients, 1 launch for every
+layer's (position-shifted) constant noise, then one fused modulated-conv launch per layer
+(13 at R=128, 15 at R=256) and one fused ToRGB/softmax/triad launch.  (The reference issues ~100
+launches per patch: SURVEY 3.3.)
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .config import GeneratorConfig, LayerSpec
+from .weights import StateDict, random_state_dict, validate_state_dict
+
+_p = ops._p
+
+
+def _assert_shape(t: torch.Tensor, ref_shape) -> None:
+    """``torch_utils/misc.py:80-93`` assert_shape: AssertionError on mismatch, None = wildcard."""
+    if t.ndim != len(ref_shape):
+        raise AssertionError(f"Wrong number of dimensions: got {t.ndim}, expected {len(ref_shape)}")
+    for idx, (size, ref) in enumerate(zip(t.shape, ref_shape)):
+        if ref is not None and size != ref:
+            raise AssertionError(f"Wrong size for dimension {idx}: got {size}, expected {ref}")
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    """Parameter holder for ``networks.py:92-122``; evaluated inside nb_mapping_f32 / nb_styles_f32."""
+
+    def __init__(self, in_features, out_features, lr_multiplier=1.0):
+        super().__init__()
+        self.register_buffer("weight", torch.zeros([out_features, in_features]))
+        self.register_buffer("bias", torch.zeros([out_features]))
+        self.weight_gain = lr_multiplier / math.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+
+class MappingNetwork(torch.nn.Module):
+    """``networks.py:214-290`` for c_dim = 0 (eval mode)."""
+
+    def __init__(self, cfg: GeneratorConfig):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws = cfg.z_dim, cfg.c_dim, cfg.w_dim, cfg.num_ws
+        self.num_layers = cfg.mapping_layers
+        self.lr_multiplier = cfg.mapping_lr_multiplier
+        for i in range(self.num_layers):
+            setattr(self, f"fc{i}", FullyConnectedLayer(cfg.z_dim if i == 0 else cfg.w_dim, cfg.w_dim,
+                                                        cfg.mapping_lr_multiplier))
+        self.register_buffer("w_avg", torch.zeros([cfg.w_dim]))
+        self._packed = None
+
+    def _pack(self):
+        if self._packed is None:
+            w = torch.cat([getattr(self, f"fc{i}").weight.reshape(-1) for i in range(self.num_layers)]).contiguous()
+            b = torch.cat([getattr(self, f"fc{i}").bias for i in range(self.num_layers)]).contiguous()
+            self._packed = (w, b)
+        return self._packed
+
+    def forward(self, z, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+        _assert_shape(z, [None, self.z_dim])
+        w, b = self._pack()
+        if z.device != w.device:
+            raise RuntimeError(f"z is on {z.device} but the generator is on {w.device}")
+        z32 = z.to(torch.float32).contiguous()                      # networks.py:261
+        n = z32.shape[0]
+        x = torch.empty([n, self.w_dim], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.lib().nb_mapping_f32(_p(z32), _p(w), _p(b), _p(x), n, self.z_dim, self.w_dim,
+                                                 self.num_layers, self.lr_multiplier, ops._stream(x)), "mapping")
+        x = x.unsqueeze(1).repeat([1, self.num_ws, 1])              # networks.py:278-280
+        if truncation_psi != 1:                                     # networks.py:283-289 (not used by the engine)
+            if truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class SynthesisLayer(torch.nn.Module):
+    """Parameter holder for ``networks.py:302-391``.  The arithmetic is one nb_modconv3x3_f32 launch."""
+
+    def __init__(self, spec: LayerSpec, w_dim: int, conv_clamp):
+        super().__init__()
+        self.spec = spec
+        self.resolution, self.up = spec.block_res, spec.up
+        self.conv_clamp = conv_clamp
+        self.act_gain = math.sqrt(2)
+        self.affine = FullyConnectedLayer(w_dim, spec.in_channels)
+        self.register_buffer("weight", torch.zeros([spec.out_channels, spec.in_channels, 3, 3]))
+        self.register_buffer("noise_strength", torch.zeros([]))
+        self.register_buffer("bias", torch.zeros([spec.out_channels]))
+        self.register_buffer("noise_grid", torch.zeros([1, spec.block_res, spec.block_res, 2]))
+        self.register_buffer("resample_filter", torch.zeros([4, 4]))
+        self.register_buffer("noise_const", torch.zeros([spec.block_res, spec.block_res]))
+
+
+class ToRGBColorTriadLayer(torch.nn.Module):
+    """Parameter holder for ``networks.py:415-485`` (color_w_channels = 0, 'triad')."""
+
+    def __init__(self, in_channels: int, w_dim: int, conv_clamp):
+        super().__init__()
+        self.conv_clamp = conv_clamp
+        self.color_w_channels = 0
+        self.color_format = "triad"
+        self.affine = FullyConnectedLayer(w_dim, in_channels + 9)
+        self.register_buffer("weight", torch.zeros([3, in_channels, 1, 1]))
+        self.register_buffer("bias", torch.zeros([3]))
+        self.register_buffer("color_bias", torch.zeros([9]))
+        self.weight_gain = 1 / math.sqrt(in_channels)
+
+
+class SynthesisBlock(torch.nn.Module):
+    """``networks.py:539-680`` for architecture='orig'."""
+
+    def __init__(self, cfg: GeneratorConfig, res: int, layers: Dict[str, LayerSpec]):
+        super().__init__()
+        self.resolution = res
+        self.is_last = res == cfg.img_resolution
+        self.architecture = "orig"
+        self.use_fp16 = False
+        self.num_conv = 0
+        self.num_torgb = 0
+        self.register_buffer("resample_filter", torch.zeros([4, 4]))
+        if res == 4:
+            self.in_channels = 0
+            self.register_buffer("const", torch.zeros([cfg.channels(4), 4, 4]))
+        else:
+            spec = layers[f"synthesis.b{res}.conv0"]
+            self.in_channels = spec.in_channels
+            self.conv0 = SynthesisLayer(spec, cfg.w_dim, cfg.conv_clamp)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(layers[f"synthesis.b{res}.conv1"], cfg.w_dim, cfg.conv_clamp)
+        self.num_conv += 1
+        if self.is_last:
+            self.torgb = ToRGBColorTriadLayer(cfg.channels(res), cfg.w_dim, cfg.conv_clamp)
+            self.num_torgb += 1
+
+
+class _Plan:
+    """Device-side layer table (NbLayerDesc[]) + workspaces for a maximum batch size."""
+
+    def __init__(self, syn: "SynthesisNetwork", n_max: int, device):
+        cfg = syn.cfg
+        specs = cfg.layers
+        self.n_max = n_max
+        self.device = device
+        c_aff = [s.in_channels for s in specs] + [cfg.channels(cfg.img_resolution) + 9]
+        c_out = [s.out_channels for s in specs] + [3]
+        self.styles = [torch.empty([n_max, c], dtype=torch.float32, device=device) for c in c_aff]
+        self.dcoefs = [torch.empty([n_max, c], dtype=torch.float32, device=device) for c in c_out[:-1]]
+        self.noise = [torch.empty([n_max, s.block_res, s.block_res], dtype=torch.float32, device=device) for s in specs]
+        self.max_res = max(s.block_res for s in specs)
+        descs = (_lib.NbLayerDesc * (len(specs) + 1))()
+        for i, s in enumerate(specs):
+            layer = syn.layer_module(s)
+            pk = syn.packed[s.name]
+            d = descs[i]
+            d.affine_w, d.affine_b = layer.affine.weight.data_ptr(), layer.affine.bias.data_ptr()
+            d.wsq = pk["wsq"].data_ptr()
+            d.styles, d.dcoefs = self.styles[i].data_ptr(), self.dcoefs[i].data_ptr()
+            d.noise_const = layer.noise_const.data_ptr()
+            d.noise_lin = pk["noise_lin"].data_ptr()
+            d.noise_out = self.noise[i].data_ptr()
+            d.noise_strength = layer.noise_strength.data_ptr()
+            d.c_aff, d.n_plain, d.c_out, d.w_index, d.res = s.in_channels, 0, s.out_channels, s.w_index, s.block_res
+            d.style_scale = 1.0
+        t = syn.last_block().torgb
+        d = descs[len(specs)]
+        d.affine_w, d.affine_b = t.affine.weight.data_ptr(), t.affine.bias.data_ptr()
+        d.wsq = 0
+        d.styles, d.dcoefs = self.styles[-1].data_ptr(), 0
+        d.noise_const = d.noise_lin = d.noise_out = d.noise_strength = 0
+        d.c_aff, d.n_plain, d.c_out, d.w_index, d.res = c_aff[-1], 9, 3, cfg.torgb_w_index, 0
+        d.style_scale = float(t.weight_gain)
+        self.host_descs = descs
+        self.n_layers = len(specs) + 1
+        self.table = self._upload(descs)
+
+    def _upload(self, descs) -> torch.Tensor:
+        raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
+        return torch.from_numpy(raw).to(self.device)
+
+    def table_with_noise_overrides(self, syn, noise_buffers) -> torch.Tensor:
+        """Reference noise_buffers (networks_modified.py:163-165): per-call replacement of noise_const."""
+        descs = (_lib.NbLayerDesc * self.n_layers)()
+        ctypes.memmove(descs, self.host_descs, ctypes.sizeof(descs))
+        keep = []
+        for i, s in enumerate(syn.cfg.layers):
+            key = f"b{s.block_res}.conv{0 if s.up == 2 else 1}.noise_const"
+            buf = noise_buffers.get(key)
+            if buf is not None:
+                if not torch.is_tensor(buf):
+                    buf = torch.from_numpy(np.asarray(buf))
+                buf = buf.to(device=self.device, dtype=torch.float32).contiguous()
+                _assert_shape(buf, [s.block_res, s.block_res])
+                keep.append(buf)
+                descs[i].noise_const = buf.data_ptr()
+        return self._upload(descs), keep
+
+
+class SynthesisNetwork(torch.nn.Module):
+    """``networks_modified.py:28-223`` on the HIP kernels."""
+
+    def __init__(self, cfg: GeneratorConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.w_dim = cfg.w_dim
+        self.img_resolution = cfg.img_resolution
+        self.img_resolution_log2 = int(math.log2(cfg.img_resolution))
+        self.img_channels = cfg.img_channels
+        self.block_resolutions = cfg.block_resolutions
+        self.geom_feature_resolutions = list(cfg.geom_feature_resolutions)
+        self.geom_feature_channels = list(cfg.geom_feature_channels)
+        self.geom_linear = None
+        self.pos_encoding_channels = 0
+        self.pos_encoding_feature_resolutions = []
+        self.pos_encoding_injection_mode = "cat"
+        self.num_ws = cfg.num_ws
+        layers = {l.name: l for l in cfg.layers}
+        for res in self.block_resolutions:
+            setattr(self, f"b{res}", SynthesisBlock(cfg, res, layers))
+        self.packed: Dict[str, Dict[str, torch.Tensor]] = {}
+        self._plan: Optional[_Plan] = None
+
+    # -- helpers --
+    def get_last_block(self):
+        return getattr(self, f"b{self.block_resolutions[-1]}")
+
+    last_block = get_last_block
+
+    def layer_module(self, spec: LayerSpec) -> SynthesisLayer:
+        return getattr(getattr(self, f"b{spec.block_res}"), "conv0" if spec.up == 2 else "conv1")
+
+    def invalidate(self):
+        self.packed = {}
+        self._plan = None
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def _ensure_packed(self):
+        if self.packed:
+            return
+        for s in self.cfg.layers:
+            layer = self.layer_module(s)
+            wpk, wsq = ops.pack_conv_weight(layer.weight)
+            self.packed[s.name] = {"wpk": wpk, "wsq": wsq,
+                                   "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous()}
+        t = self.get_last_block().torgb
+        self.packed["torgb"] = {"w": t.weight.reshape(3, -1).contiguous()}
+
+    def _get_plan(self, n: int, device) -> _Plan:
+        self._ensure_packed()
+        if self._plan is None or self._plan.n_max < n or self._plan.device != device:
+            n_max = max(n, 1 if self._plan is None else self._plan.n_max)
+            self._plan = _Plan(self, n_max, device)
+        return self._plan
+
+    # -- forward --
+    def forward(self, ws, geom_feature, pos_encoding=None, return_debug_data=False, return_features=None,
+                blended_features=None, noise_buffers=None, **block_kwargs):
+        cfg = self.cfg
+        return_features = [] if return_features is None else return_features
+        blended_features = {} if blended_features is None else blended_features
+        noise_mode = block_kwargs.pop("noise_mode", "random")      # SynthesisLayer default, networks.py:362
+        norm_noise_positions = block_kwargs.pop("norm_noise_positions", None)
+        int_positions = block_kwargs.pop("_positions", None)   # integer (y,x) positions: normalised in-kernel
+        block_kwargs.pop("force_fp32", None)       # always fp32 here (SURVEY note B)
+        block_kwargs.pop("fused_modconv", None)    # one arithmetic form (csrc/nb_modconv.hip)
+        extra = block_kwargs.pop("_extra_outputs", None)
+        if block_kwargs:
+            raise TypeError(f"unexpected synthesis kwargs: {sorted(block_kwargs)}")
+        if noise_mode not in ("random", "const", "none"):
+            raise AssertionError(f"noise_mode {noise_mode!r}")
+        if pos_encoding is not None:
+            raise RuntimeError("positional encodings are not part of the shipped configuration (SG/train.py:680)")
+        _assert_shape(ws, [None, self.num_ws, self.w_dim])          # networks_modified.py:145
+        device = self.get_last_block().conv1.weight.device
+        if ws.device != device:
+            raise RuntimeError(f"ws is on {ws.device} but the generator is on {device}")
+        ws = ws.to(torch.float32).contiguous()
+        n = ws.shape[0]
+        plan = self._get_plan(n, device)
+        lib = _lib.lib()
+        geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
+        keep_alive = []
+        with torch.cuda.device(device):
+            stream = ops._stream(ws)
+            _lib.check(lib.nb_styles_f32(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, n, stream),
+                       "styles")
+            noise_stride = {}
+            if noise_mode == "const":
+                table = plan.table
+                if noise_buffers:
+                    table, keep = plan.table_with_noise_overrides(self, noise_buffers)
+                    keep_alive += [table] + keep
+                npos = ipos = None
+                if int_positions is not None:
+                    ipos = int_positions.to(device=device, dtype=torch.int64).contiguous()
+                    _assert_shape(ipos, [n, 2])
+                    keep_alive.append(ipos)
+                elif norm_noise_positions is not None:
+                    npos = norm_noise_positions.to(device=device, dtype=torch.float32).contiguous()
+                    _assert_shape(npos, [n, 2])
+                    keep_alive.append(npos)
+                _lib.check(lib.nb_noise_f32(_p(table), plan.n_layers, plan.max_res, _p(npos), _p(ipos),
+                                            self.img_resolution, n, stream), "noise")
+                shared = npos is None and ipos is None
+
+            debug_data = {}
+            x = img = None
+            x2 = None
+            geo_idx = 0
+            specs = {s.name: (i, s) for i, s in enumerate(cfg.layers)}
+            for res in self.block_resolutions:
+                block = getattr(self, f"b{res}")
+                names = ([f"synthesis.b{res}.conv0"] if res > 4 else []) + [f"synthesis.b{res}.conv1"]
+                if res == 4:
+                    x = block.const.unsqueeze(0).expand(n, -1, -1, -1).contiguous()     # networks.py:641-643
+                else:
+                    _assert_shape(x, [None, block.in_channels - (0 if x2 is None else x2.shape[1]), res // 2, res // 2])
+                for name in names:
+                    i, s = specs[name]
+                    layer = self.layer_module(s)
+                    pk = self.packed[name]
+                    c1 = x.shape[1]
+                    c2 = 0 if x2 is None else x2.shape[1]
+                    if c1 + c2 != s.in_channels:
+                        raise AssertionError(f"{name}: got {c1}+{c2} input channels, expected {s.in_channels}")
+                    noise_ptr, nstride = None, 0
+                    if noise_mode == "const":
+                        noise_ptr = plan.noise[i].data_ptr()
+                        nstride = 0 if shared else s.block_res * s.block_res
+                    elif noise_mode == "random":
+                        rnd = torch.randn([n, s.block_res, s.block_res], device=device) * layer.noise_strength
+                        keep_alive.append(rnd)
+                        noise_ptr, nstride = rnd.data_ptr(), s.block_res * s.block_res
+                    y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                    clamp = -1.0 if layer.conv_clamp is None else float(layer.conv_clamp)
+                    _lib.check(lib.nb_modconv3x3_f32(
+                        _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
+                        nstride, _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, s.up, 0.2,
+                        layer.act_gain, clamp, stream), name)
+                    keep_alive += [x, x2]
+                    x, x2 = y, None
+
+                if block.is_last:
+                    img, triad = self._torgb(plan, x, n, stream, extra)
+                    if return_debug_data:
+                        debug_data.update(triad)
+                if res in return_features:
+                    debug_data["features%d_preblend" % res] = x
+                if res in blended_features:
+                    bf = blended_features[res]
+                    x = ops.blend(bf.features.to(device=device, dtype=torch.float32),
+                                  bf.alpha.to(device=device, dtype=torch.float32), x)
+                    if block.is_last:                                   # networks_modified.py:182-185
+                        img, triad = self._torgb(plan, x, n, stream, extra)
+                        debug_data.update(triad)
+                if res in return_features:
+                    debug_data["features%d" % res] = x
+                if res in self.geom_feature_resolutions:
+                    g = geom_feature[geo_idx]
+                    geo_idx += 1
+                    if g.device != device:
+                        raise RuntimeError(f"geom_feature is on {g.device} but the generator is on {device}")
+                    x2 = g.to(torch.float32).contiguous()
+                    _assert_shape(x2, [n, self.geom_feature_channels[self.geom_feature_resolutions.index(res)], res, res])
+        if len(debug_data) > 0:
+            return img, debug_data
+        return img
+
+    def _torgb(self, plan: _Plan, x, n, stream, extra):
+        cfg = self.cfg
+        block = self.get_last_block()
+        t = block.torgb
+        r = cfg.img_resolution
+        c = x.shape[1]
+        dev = x.device
+        uvs = torch.empty([n, 3, r, r], dtype=torch.float32, device=dev)
+        img = torch.empty([n, 3, r, r], dtype=torch.float32, device=dev)
+        colors = torch.empty([n, 3, 3], dtype=torch.float32, device=dev)
+        logits = rgba = rgba8 = user = None
+        mode = 0
+        if extra is not None:
+            if extra.get("logits"):
+                logits = torch.empty([n, 3, r, r], dtype=torch.float32, device=dev)
+            if extra.get("rgba"):
+                rgba = torch.empty([n, 4, r, r], dtype=torch.float32, device=dev)
+            if extra.get("rgba_u8"):
+                rgba8 = torch.empty([n, r, r, 4], dtype=torch.uint8, device=dev)
+            user = extra.get("user_colors")
+            if user is not None:
+                user = user.to(device=dev, dtype=torch.float32).contiguous()
+                _assert_shape(user, [n, 3, 3])
+            mode = {"clear": 0, "full": 1}.get(extra.get("render_mode", "clear"), -1)
+            if mode < 0:
+                raise RuntimeError("Unknown render mode for TriadGanPaintEngine: {}".format(extra.get("render_mode")))
+        clamp = -1.0 if t.conv_clamp is None else float(t.conv_clamp)
+        _lib.check(_lib.lib().nb_torgb_triad_f32(
+            _p(x), _p(plan.styles[-1]), c + 9, _p(self.packed["torgb"]["w"]), _p(t.bias), _p(t.color_bias), clamp,
+            _p(logits), _p(uvs), _p(img), _p(colors), _p(user), mode, _p(rgba), _p(rgba8), n, c, r * r, stream),
+            "torgb_triad")
+        if extra is not None:
+            extra["out"] = {"logits": logits, "rgba": rgba, "rgba_u8": rgba8}
+        return img, {"colors": colors, "uvs": uvs}
+
+
+class Generator(torch.nn.Module):
+    """``networks_modified.py:227-400``."""
+
+    def __init__(self, cfg: GeneratorConfig = None, state_dict: Optional[StateDict] = None, **kwargs):
+        super().__init__()
+        if cfg is None:
+            cfg = GeneratorConfig(**kwargs)
+        self.cfg = cfg
+        self.z_dim, self.c_dim, self.w_dim = cfg.z_dim, cfg.c_dim, cfg.w_dim
+        self.img_resolution, self.img_channels = cfg.img_resolution, cfg.img_channels
+        self.positional_encoder = None
+        self.synthesis = SynthesisNetwork(cfg)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(cfg)
+        self.geom_inject = True
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+        if state_dict is not None:
+            self.load_numpy_state_dict(state_dict)
+        self.eval().requires_grad_(False)
+
+    def _invalidate(self):
+        self.synthesis.invalidate()
+        self.mapping._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_numpy_state_dict(self, sd: StateDict):
+        validate_state_dict(self.cfg, sd)
+        self.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32))) for k, v in sd.items()},
+                             strict=True)
+        return self
+
+    @staticmethod
+    def from_random(cfg: GeneratorConfig, seed: int = 0, device="cuda") -> "Generator":
+        return Generator(cfg, random_state_dict(cfg, seed)).to(device)
+
+    def forward_pre_mapped(self, ws, geom_feature, positions=None, return_debug_data=False, return_features=None,
+                           blended_features=None, noise_buffers=None, **synthesis_kwargs):
+        # networks_modified.py:351-353 normalises positions here; this build hands the integer positions to
+        # nb_noise_f32, which does the same (positions % R)/(R-1) in correctly rounded fp32 (see neube_hip.h)
+        syn_res = self.synthesis(ws, geom_feature, pos_encoding=None, return_debug_data=return_debug_data,
+                                 return_features=return_features, blended_features=blended_features,
+                                 **synthesis_kwargs, _positions=positions, noise_buffers=noise_buffers)
+        if return_debug_data or return_features:
+            img, debug_data = syn_res
+            if return_debug_data:
+                debug_data["ws"] = ws
+            return img, debug_data
+        return syn_res
+
+    def forward(self, z, c, geom_feature, positions=None, noise_buffers=None, truncation_psi=1, truncation_cutoff=None,
+                return_debug_data=False, return_features=None, blended_features=None, style_mixing_prob=0,
+                **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        if style_mixing_prob > 0:
+            raise RuntimeError("style mixing is a training-time feature (networks_modified.py:385-394); not in this build")
+        return self.forward_pre_mapped(ws, geom_feature, positions=positions, return_debug_data=return_debug_data,
+                                       return_features=return_features, blended_features=blended_features,
+                                       noise_buffers=noise_buffers, **synthesis_kwargs)
+
+    def render_triad(self, z=None, ws=None, geom_feature=None, positions=None, render_mode="clear", user_colors=None,
+                     want_u8=True, want_f32=False, **kw):
+        """Generator + the paint engine's compositing (brush.py:763-792) fused into the ToRGB launch.
+        Returns (rgba_u8 [N,R,R,4] | None, rgba_f32 [N,4,R,R] | None, debug dict with uvs/colors)."""
+        extra = {"rgba_u8": want_u8, "rgba": want_f32, "render_mode": render_mode, "user_colors": user_colors}
+        kw.setdefault("noise_mode", "const")
+        if ws is None:
+            img, dbg = self.forward(z, None, geom_feature, positions=positions, return_debug_data=True,
+                                    _extra_outputs=extra, **kw)
+        else:
+            img, dbg = self.forward_pre_mapped(ws, geom_feature, positions=positions, return_debug_data=True,
+                                               _extra_outputs=extra, **kw)
+        return extra["out"]["rgba_u8"], extra["out"]["rgba"], dbg

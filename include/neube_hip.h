@@ -1,0 +1,158 @@
+/*
+ * neube_hip.h -- C ABI of the MI355X (gfx950) NeuBE generator kernels.
+ *
+ * This is the drop-in boundary for the reference's native plugin layer.  In the reference the
+ * generator's arithmetic bottoms out in two pybind11/CUDA plugins plus cuDNN:
+ *
+ *   bias_act_plugin.bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)
+ *       thirdparty/stylegan2_ada_pytorch/torch_utils/ops/bias_act.cpp:32-91  (kernel bias_act.cu:23-147)
+ *   upfirdn2d_plugin.upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)
+ *       thirdparty/stylegan2_ada_pytorch/torch_utils/ops/upfirdn2d.cpp:16-94 (kernels upfirdn2d.cu:29-200)
+ *   torch.nn.functional.conv2d / conv_transpose2d (cuDNN) via
+ *       thirdparty/stylegan2_ada_pytorch/torch_utils/ops/conv2d_gradfix.py:35-43
+ *   loaded lazily by torch_utils/custom_ops.py:46-124 (JIT nvcc build).
+ *
+ * Here they are replaced by one ahead-of-time hipcc-built shared library with plain-C entry
+ * points: raw device pointers, integer sizes, scalar parameters and the HIP stream to launch on.
+ * No torch types cross this boundary.  All tensors are dense, contiguous, float32, NCHW.
+ * Outputs are caller-allocated.  Every function returns 0 on success and a negative NB_E* code on
+ * failure; nb_last_error() then returns a thread-local message.  Functions only enqueue work on
+ * `stream` (no allocation, no synchronisation) and are therefore capturable into a hipGraph.
+ *
+ * `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ */
+#ifndef NEUBE_HIP_H
+#define NEUBE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_OK            0
+#define NB_EINVAL       -1   /* bad argument (shape, null pointer, unsupported mode) */
+#define NB_ELAUNCH      -2   /* the HIP runtime rejected a launch */
+#define NB_EUNSUPPORTED -3
+
+/* activation codes = the reference's cuda_idx (bias_act.py:22-32) */
+#define NB_ACT_LINEAR  1
+#define NB_ACT_RELU    2
+#define NB_ACT_LRELU   3
+#define NB_ACT_TANH    4
+#define NB_ACT_SIGMOID 5
+
+const char* nb_last_error(void);
+int nb_abi_version(void);
+
+/* ---- standalone operator parity with the reference plugins ------------------------------- */
+
+/* y = clamp(act(x + b[(i / step_b) % size_b]) * gain, +-clamp); forward (grad=0) of
+ * bias_act.cpp:32-91.  size_b = 0 -> no bias.  clamp < 0 -> no clamping.  x and y may alias. */
+int nb_bias_act_f32(const float* x, const float* b, float* y, int64_t size_x, int size_b, int step_b,
+                    int act, float alpha, float gain, float clamp, void* stream);
+
+/* upfirdn2d.cpp:16-94 forward on a contiguous [major, in_h, in_w] stack of planes (major = N*C):
+ * zero-insert by (upx,upy), pad/crop, correlate with f[f_h,f_w] (flipped unless `flip`), scale by
+ * gain, keep every (downx,downy)-th sample.  y is [major, out_h, out_w] with
+ * out_w = (in_w*upx + padx0 + padx1 - f_w + downx) / downx (same for h). */
+int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int major, int in_h, int in_w,
+                     int f_h, int f_w, int upx, int upy, int downx, int downy,
+                     int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
+
+/* ---- generator path ---------------------------------------------------------------------- */
+
+/* MappingNetwork.forward (training/networks.py:255-290) for c_dim = 0, without the broadcast:
+ * w[n,:] = FC_{L-1}(...FC_0(z * rsqrt(mean(z^2)+1e-8))), each FC = lrelu(x W^T * lr_mul/sqrt(in) + b*lr_mul)*sqrt2.
+ * fc_w: layer 0 [w_dim, z_dim] followed by layers 1.. [w_dim, w_dim]; fc_b: [L, w_dim].
+ * z_dim, w_dim <= 512. */
+int nb_mapping_f32(const float* z, const float* fc_w, const float* fc_b, float* w_out, int n, int z_dim,
+                   int w_dim, int num_layers, float lr_mul, void* stream);
+
+/* One entry of the per-layer table consumed by nb_styles_f32 / nb_noise_f32 (device memory, built
+ * once when weights are packed).  Pointers are device addresses. */
+typedef struct NbLayerDesc {
+    const float* affine_w;   /* [c_aff, w_dim]  FullyConnectedLayer.weight of the layer's affine */
+    const float* affine_b;   /* [c_aff] */
+    const float* wsq;        /* [c_in, c_out]   sum_k W[o,i,k]^2 (transposed), NULL -> no demodulation */
+    float*       styles;     /* out [n_max, c_aff]  affine(w) * style_scale (entries < n_plain are NOT scaled) */
+    float*       dcoefs;     /* out [n_max, c_out]  rsqrt(sum_i (styles^2 * wsq) + 1e-8), unused when wsq NULL */
+    const float* noise_const;/* [res, res] or NULL */
+    const float* noise_lin;  /* [res] = noise_grid[0, :, 0, 0] (torch.linspace(0,1,res)) */
+    float*       noise_out;  /* out [n_max or 1, res, res] = (shifted) noise_const * noise_strength */
+    const float* noise_strength; /* [1] */
+    int32_t c_aff;           /* affine outputs (= c_in, or c_in + 9 for the triad ToRGB) */
+    int32_t n_plain;         /* leading affine outputs that are not styles (9 color scalars for ToRGB, else 0) */
+    int32_t c_out;
+    int32_t w_index;         /* which ws[:, w_index, :] feeds this layer */
+    int32_t res;             /* output resolution of the layer (noise size) */
+    float   style_scale;     /* 1 for conv layers, 1/sqrt(c_in) for ToRGB (networks.py:460) */
+    int32_t pad_[2];
+} NbLayerDesc;
+
+/* For every layer l < n_layers and sample n: styles = affine_l(ws[n, w_index_l]) (weight_gain
+ * 1/sqrt(w_dim), bias_gain 1: networks.py:106-118) and the demodulation coefficients
+ * (networks.py:59-62 in the algebraically equal form d = rsqrt(sum_i s_i^2 * sum_k W_oik^2 + 1e-8)). */
+int nb_styles_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim, int n,
+                  void* stream);
+
+/* Stand-alone demodulation coefficients for one layer (networks.py:59-62 in the form above):
+ * dcoefs[n,o] = rsqrt(sum_i styles[n,i]^2 * wsq[i,o] + 1e-8); styles [n,c_in], wsq [c_in,c_out]. */
+int nb_demod_coefs_f32(const float* styles, const float* wsq, float* dcoefs, int n, int c_in, int c_out,
+                       void* stream);
+
+/* Constant-noise inputs of all layers in one launch (networks.py:371-382).
+ *   norm_pos == NULL && positions == NULL: noise_out[0] = noise_const * strength (shared by the batch).
+ *   positions != NULL: [n,2] int64 (y,x) patch positions; the kernel forms the reference's
+ *       (positions % img_resolution) / (img_resolution - 1) (networks_modified.py:351-353) itself, with
+ *       python-style modulo and correctly rounded float32 division, so that it is bit-identical to the
+ *       reference's CPU arithmetic (the wrapped coordinate is discontinuous: 1 ulp moves a noise row).
+ *   norm_pos != NULL: [n,2] float32 already-normalised positions (the `norm_noise_positions` kwarg).
+ * noise_out[n] is the bilinear, wrapped resampling of SURVEY note C.  Layers whose noise_const is
+ * NULL are skipped.  max_res = largest `res` in the table.  The reference's noise_buffers override
+ * (networks_modified.py:163-165) is expressed by passing a table with replaced noise_const pointers. */
+int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max_res, const float* norm_pos,
+                 const int64_t* positions, int img_resolution, int n, void* stream);
+
+/* Modulated 3x3 convolution + fused epilogue = SynthesisLayer.forward (networks.py:362-391) after
+ * the affine:  y = clamp(lrelu(conv(x * s) * d + noise + bias, alpha) * gain, +-clamp)
+ *   up = 1: cross-correlation, zero padding 1 (conv2d_resample.py:145-147)
+ *   up = 2: stride-2 transposed convolution (true convolution, 2H+1) followed by the 4x4
+ *           [1,3,3,1]x[1,3,3,1]/64 FIR with padding 1 and gain 4 (conv2d_resample.py:124-142)
+ * The input is the channel-concatenation of x1 [n,c1,h,w] and (optionally) x2 [n,c2,h,w] -- the
+ * geometry feature -- so no torch.cat copy is needed (networks_modified.py:218-219).
+ * wpk is the packed weight [c1+c2][9][c_out] (tap = ky*3+kx) produced by nb_pack_conv_weight.
+ * noise is [n or 1, h*up, w*up] with sample stride noise_stride_n (0 = shared), or NULL.
+ * y is [n, c_out, h*up, w*up].  c_out must be a multiple of 4; h and w powers of two. */
+int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c2, const float* wpk, const float* styles,
+                      const float* dcoefs, const float* noise, int64_t noise_stride_n, const float* bias,
+                      float* y, int n, int h, int w, int c_out, int up, float alpha, float gain, float clamp,
+                      void* stream);
+
+/* ToRGBColorTriadLayer.forward (networks.py:451-485) after its affine, on x [n,c,hw]:
+ *   logits_o = clamp(sum_c x_c * styles[n,c] * w[o,c] + bias[o]);  uvs = softmax_o(logits)
+ *   img[n,ch] = sum_k uvs_k * colors[n,ch,k]            (colors = tanh(affine[:, :9] + color_bias))
+ * plus, optionally, the paint engine's compositing (forger/ui/brush.py:763-792):
+ *   rgba[:3] = sum_k uvs_k * col01[n,:,k], rgba[3] = u+v ('clear', render_mode 0) or 1 ('full', 1)
+ *   with col01 = user_colors (where not NaN) else (colors+1)/2; rgba_f32 is [n,4,hw];
+ *   rgba_u8 = trunc(clip(rgba*255, 0, 255)) is [n,hw,4] bytes (HWC, as brush.py:377 hands it out).
+ * colors_raw is the [n, c_aff] affine output whose first 9 entries are the un-biased color scalars.
+ * Any of logits / uvs / img / colors_out / rgba_f32 / rgba_u8 may be NULL. */
+int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n, const float* w, const float* bias,
+                       const float* color_bias, float clamp, float* logits, float* uvs, float* img,
+                       float* colors_out, const float* user_colors, int render_mode, float* rgba_f32,
+                       uint8_t* rgba_u8, int n, int c, int hw, void* stream);
+
+/* BlendedFeatures.blend (forger/train/stitching.py:24-25): y = alpha*F + (1-alpha)*x over
+ * x [n,c,hw]; F is [nf,c,hw] and alpha [na,1,hw] with nf, na in {1, n} (broadcast). */
+int nb_blend_f32(const float* features, int nf, const float* alpha, int na, const float* x, float* y, int n, int c,
+                 int hw, void* stream);
+
+/* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into wpk[c_in][9][c_out] and
+ * wsq[c_in][c_out] = sum_k W^2.  Either output may be NULL. */
+int nb_pack_conv_weight(const float* w, int c_out, int c_in, float* wpk, float* wsq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUBE_HIP_H */

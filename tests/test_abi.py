@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol that include/neube_hip.h declares (no kernels are launched here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from brushstroke_engine_amd import _lib, build
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def library():
+    build.build()          # no-op when up to date; hipcc cross-compiles without a GPU
+    return _lib.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "neube_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(library):
+    names = declared_symbols()
+    assert len(names) >= 12
+    assert sorted(_lib.PROTOTYPES) == names
+    for n in names:
+        assert hasattr(library, n), n
+
+
+def test_abi_version_and_error_string(library):
+    assert library.nb_abi_version() == _lib.ABI_VERSION
+    # argument validation happens on the host before any launch: usable without a GPU
+    rc = library.nb_bias_act_f32(None, None, None, 4, 0, 1, 3, 0.2, 1.0, -1.0, None)
+    assert rc == -1
+    assert b"null pointer" in library.nb_last_error()
+    with pytest.raises(_lib.NeubeHipError):
+        _lib.check(rc, "bias_act")
+
+
+def test_layer_desc_layout_matches_header(library):
+    # 9 pointers + 5 int32 + 1 float + 2 pad int32 = 72 + 32 = 104 bytes, 8-byte aligned
+    assert ctypes.sizeof(_lib.NbLayerDesc) == 104
+
+
+def test_pack_conv_weight_host_helper(library):
+    rs = np.random.RandomState(0)
+    w = rs.randn(8, 5, 3, 3).astype(np.float32)
+    wpk = np.zeros((5, 9, 8), np.float32)
+    wsq = np.zeros((5, 8), np.float32)
+    rc = library.nb_pack_conv_weight(w.ctypes.data, 8, 5, wpk.ctypes.data, wsq.ctypes.data)
+    assert rc == 0
+    np.testing.assert_array_equal(wpk, w.transpose(1, 2, 3, 0).reshape(5, 9, 8))
+    np.testing.assert_allclose(wsq, (w ** 2).sum(axis=(2, 3)).T, rtol=1e-6)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.NeubeHipError, match="no CPU fallback"):
+        _lib.lib()
