@@ -1,0 +1,213 @@
+"""Headline benchmark: stylized 256x256 stroke patches / second at batch 32 on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--res 256] [--batch 32] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (mapping -> styles/noise -> 15 fused modulated-conv launches ->
+fused ToRGB/softmax/triad + paint-engine compositing to uint8 RGBA) over one batch of 32 synthetic
+patches per GPU (BASELINE.json configs[1]: random z, random stroke-geometry features, random patch
+positions, style1 checkpoint shapes at R=256, fp32).  Inputs are resident in HBM before the timed
+region.  With N > 1 every rank renders its own batch (weak scaling, replicated weights) and the
+uint8 RGBA tiles are gathered to rank 0 over RCCL inside the step, overlapped with the next batch.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel,
+algorithmic FLOPs / HIP-event time on the launch stream, against the fp32 matrix peak of
+MI355X_MICROARCH.md) and `cpu_baseline` (the CPU oracle = port of the reference path, timed on this
+box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2/16x16x4, 64 FLOP/clk/SIMD (spec)
+
+
+def layer_flops(spec, batch):
+    """Algorithmic FLOPs of one modulated-conv launch (2 x MACs; up-layers at their
+    non-zero transposed-conv MACs + the 4x4 FIR)."""
+    if spec.up == 2:
+        macs = spec.in_res ** 2 * spec.out_channels * spec.in_channels * 9 + spec.block_res ** 2 * spec.out_channels * 16
+    else:
+        macs = spec.block_res ** 2 * spec.out_channels * spec.in_channels * 9
+    return 2.0 * macs * batch
+
+
+def kernel_label(spec):
+    return f"modconv3x3_up{spec.up}[{spec.in_channels}->{spec.out_channels}@{spec.block_res}]"
+
+
+def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=4):
+    """The CPU oracle (oracle/neube_oracle.py, a port of the reference path onto plain torch CPU ops)
+    timed on this box's host cores.  Bounded sample: `n_sample` patches per pass, repeated until
+    ~seconds_budget of CPU time is spent.  This is a reported baseline, not the thing shipped."""
+    from oracle import neube_oracle as orc
+    from brushstroke_engine_amd import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    O = orc.OracleGenerator(cfg, sd)
+    z = synthetic.batch_z(cfg, n_sample, 0)
+    geom = synthetic.geom_features(cfg, n_sample, seed=0)
+    pos = synthetic.positions(cfg, n_sample, seed=0)
+
+    def one():
+        img, dbg = O(z, None, geom, positions=pos, return_debug_data=True)
+        rgba = orc.rgba_to_uint8(orc.triad_composite(dbg["uvs"], dbg["colors"], "clear"))
+        return rgba
+
+    one()                                   # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds_budget or reps >= 50:
+            break
+    return {"value": round(reps * n_sample / el, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} passes of batch {n_sample} at {cfg.img_resolution}x{cfg.img_resolution} "
+                      f"(oracle = torch-CPU port of the reference generator + compositing, fp32, {el:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    from brushstroke_engine_amd.sharding import TileGatherer
+
+    cfg = cfgmod.style1_config(args.res)
+    sd = wmod.random_state_dict(cfg, seed=0)
+    G = Generator(cfg, sd).to(dev)
+    B = args.batch
+    # synthetic inputs, resident in HBM before anything is timed (different per rank)
+    z = torch.from_numpy(synthetic.batch_z(cfg, B, first_seed=rank * B)).to(dev)
+    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, seed=rank)]
+    pos = torch.from_numpy(synthetic.positions(cfg, B, seed=rank)).to(dev)
+    gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if (world > 1 and not args.no_gather) else None
+
+    def step():
+        u8, _, _ = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear")
+        if gatherer is not None:
+            gatherer.finish()           # previous step's gather must be done before its buffer is reused
+            gatherer.start(u8)
+        return u8
+
+    for _ in range(args.warmup):
+        step()
+    if gatherer is not None:
+        gatherer.finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    G.synthesis.layer_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if gatherer is not None:
+        gatherer.finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events = G.synthesis.layer_events
+    G.synthesis.layer_events = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch durations from the HIP events recorded on the launch stream during the timed steps
+    per_layer = {}
+    for name, e0, e1 in events:
+        per_layer.setdefault(name, []).append(e0.elapsed_time(e1))
+    specs = {s.name: s for s in cfg.layers}
+    rows = []
+    for name, ts in per_layer.items():
+        ms = float(np.mean(ts))
+        if name in specs:
+            fl = layer_flops(specs[name], B)
+            rows.append((ms, name, fl, kernel_label(specs[name])))
+    rows.sort(reverse=True)
+    conv_ms = sum(r[0] for r in rows)
+    conv_fl = sum(r[2] for r in rows)
+    dom = rows[0]
+    achieved = dom[2] / (dom[0] * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom[3])
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": dom[3], "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+                "launch_ms": round(dom[0], 4), "flops_per_launch": dom[2],
+                "all_conv_launches": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                      "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+                                      "ms_per_step": round(conv_ms, 4)},
+                "layers_ms": {r[3]: round(r[0], 4) for r in rows},
+                "other_ms": {k: round(float(np.mean(v)), 4) for k, v in per_layer.items() if k not in specs}}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        out = {
+            "metric": "stylized 256x256 stroke patches/sec at batch=32" if args.res == 256 and B == 32
+                      else f"stylized {args.res}x{args.res} stroke patches/sec at batch={B}",
+            "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch={B} random-z {args.res}x{args.res} patches through the HIP SynthesisNetwork, "
+                                   f"style1 checkpoint shapes (BASELINE.json configs[1]); generator + triad compositing "
+                                   f"to uint8 RGBA; geometry features precomputed",
+                       "batch_per_gpu": B, "resolution": args.res, "gflop_per_patch": round(2 * cfg.macs_per_patch() / 1e9, 3),
+                       "parallelism": f"patch-parallel x{world}" + (" + RCCL gather of RGBA tiles to rank 0" if gatherer else "")},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
     }
     const float* sty = p.styles + (size_t)n * p.c_in;
 
-    float xreg[KC][XE];
+    float xreg[KC][XE], sreg[KC];
     f32x4 wreg[WE];
 
     auto load_chunk = [&](int c0) {
@@ -109,10 +109,11 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
                 src = ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW;
                 s = sty[ch];
             }
+            sreg[k] = s;      // the style multiply happens at store_chunk, so no wait on these loads sits before the MFMAs
 #pragma unroll
             for (int i = 0; i < XE; ++i) {
                 float v = 0.f;
-                if (chv && xoff[i] >= 0) v = src[xoff[i]] * s;
+                if (chv && xoff[i] >= 0) v = src[xoff[i]];
                 xreg[k][i] = v;
             }
         }
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
         for (int k = 0; k < KC; ++k)
 #pragma unroll
             for (int i = 0; i < XE; ++i)
-                if (xlds[i] >= 0) xd[k * plane + xlds[i]] = xreg[k][i];
+                if (xlds[i] >= 0) xd[k * plane + xlds[i]] = xreg[k][i] * sreg[k];
         float* wd = wsm + buf * WBUF;
 #pragma unroll
         for (int i = 0; i < WE; ++i) {
@@ -172,22 +173,33 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
         if (ck + 1 < nchunks) load_chunk((ck + 1) * KC);
         const float* xb = xs + buf * XBUF + lh * plane;
         const float* wb = wsm + buf * WBUF + lh * 9 * CO_WG + l31;
+        // software pipeline: the fragments of step s+1 are read from LDS right after the first MFMA of
+        // step s has issued, so their latency rides under the remaining MB*NBW-1 MFMAs (64 cycles each)
+        constexpr int STEPS = (KC / 2) * 9;
+        float af[2][MB], bfr[2][NBW];
+        auto fetch = [&](int step, float (&a)[MB], float (&b)[NBW]) {
+            const int kk = step / 9, tap = step - kk * 9;
+            const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
+            for (int mb = 0; mb < MB; ++mb) a[mb] = wb[(kk * 2 * 9 + tap) * CO_WG + mb * 32];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap - ky * 3;
-                float a[MB], bf[NBW];
+            for (int nb = 0; nb < NBW; ++nb) b[nb] = xb[kk * 2 * plane + boff[nb] + ky * XS + kx];
+        };
+        fetch(0, af[0], bfr[0]);
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) a[mb] = wb[(kk * 2 * 9 + tap) * CO_WG + mb * 32];
+        for (int step = 0; step < STEPS; ++step) {
+            const int cur = step & 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bfr[cur][0], acc[0][0], 0, 0, 0);
+            if (step + 1 < STEPS) fetch(step + 1, af[cur ^ 1], bfr[cur ^ 1]);
 #pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) bf[nb] = xb[kk * 2 * plane + boff[nb] + ky * XS + kx];
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bf[nb], acc[mb][nb], 0, 0, 0);
-            }
+                for (int nb = 0; nb < NBW; ++nb)
+                    if (mb + nb > 0)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mb], bfr[cur][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (step + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, MB + NBW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW - 1, 0);
         }
         if (ck + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
     }
     const float* sty = p.styles + (size_t)n * p.c_in;
 
-    float xreg[KC][XE];
+    float xreg[KC][XE], sreg[KC];
     float wreg[(WBUF + 255) / 256];
     constexpr int WE = (WBUF + 255) / 256;
 
@@ -295,10 +307,11 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
                 src = ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW;
                 s = sty[ch];
             }
+            sreg[k] = s;      // the style multiply happens at store_chunk, so no wait on these loads sits before the MFMAs
 #pragma unroll
             for (int i = 0; i < XE; ++i) {
                 float v = 0.f;
-                if (chv && xoff[i] >= 0) v = src[xoff[i]] * s;
+                if (chv && xoff[i] >= 0) v = src[xoff[i]];
                 xreg[k][i] = v;
             }
         }
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
         for (int k = 0; k < KC; ++k)
 #pragma unroll
             for (int i = 0; i < XE; ++i)
-                if (xlds[i] >= 0) xd[k * plane + xlds[i]] = xreg[k][i];
+                if (xlds[i] >= 0) xd[k * plane + xlds[i]] = xreg[k][i] * sreg[k];
         float* wd = wsm + buf * WBUF;
 #pragma unroll
         for (int i = 0; i < WE; ++i) {
@@ -354,27 +367,48 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
         if (ck + 1 < nchunks) load_chunk((ck + 1) * KC);
         const float* xb = xs + buf * XBUF + lq * plane;
         const float* wb = wsm + buf * WBUF + lq * 9 * CO_WG + l15;
-#pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {
-            float a[9];
+        // software pipeline over (k-step, position block): block j+1's four B fragments (and, at the last
+        // block of a k-step, the next k-step's nine A fragments) are read right after block j's first MFMA
+        constexpr int KS = KC / 4;
+        float af[2][9], xf[2][4];
+        auto fetchA = [&](int ks, float (&a)[9]) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) a[tap] = wb[(ks * 4 * 9 + tap) * CO_WG];
+        };
+        auto fetchB = [&](int ks, int j, float (&x)[4]) {
+            const float* xp = xb + ks * 4 * plane + boff[j];
+            x[3] = xp[0];            // X(r, c)
+            x[2] = xp[1];            // X(r, c+1)
+            x[1] = xp[XS];           // X(r+1, c)
+            x[0] = xp[XS + 1];       // X(r+1, c+1)
+        };
+        fetchA(0, af[0]);
+        fetchB(0, 0, xf[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int j = 0; j < NBP; ++j) {
-                const float* xp = xb + ks * 4 * plane + boff[j];
-                const float x11 = xp[0];            // X(r, c)
-                const float x10 = xp[1];            // X(r, c+1)
-                const float x01 = xp[XS];           // X(r+1, c)
-                const float x00 = xp[XS + 1];       // X(r+1, c+1)
+                const int it = ks * NBP + j;
+                const int cb = it & 1, ca = ks & 1;
+                const float x00 = xf[cb][0], x01 = xf[cb][1], x10 = xf[cb][2], x11 = xf[cb][3];
+                const float(&a)[9] = af[ca];
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x00, acc[j][0], 0, 0, 0);
+                int nreads = 0;
+                if (j + 1 < NBP) { fetchB(ks, j + 1, xf[cb ^ 1]); nreads = 4; }
+                else if (ks + 1 < KS) { fetchA(ks + 1, af[ca ^ 1]); fetchB(ks + 1, 0, xf[cb ^ 1]); nreads = 13; }
+                // accumulator order keeps consecutive MFMAs on different accumulators (40-cycle dependent latency)
                 acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x01, acc[j][1], 0, 0, 0);
                 acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], x10, acc[j][2], 0, 0, 0);
-                acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4], x11, acc[j][3], 0, 0, 0);
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], x01, acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[7], x11, acc[j][1], 0, 0, 0);
-                acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[5], x11, acc[j][2], 0, 0, 0);
+                acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4], x11, acc[j][3], 0, 0, 0);
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[6], x10, acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[7], x11, acc[j][1], 0, 0, 0);
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8], x11, acc[j][0], 0, 0, 0);
+                acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[5], x11, acc[j][2], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (nreads == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                if (nreads == 13) __builtin_amdgcn_sched_group_barrier(0x100, 13, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         }
         if (ck + 1 < nchunks) store_chunk(buf ^ 1);

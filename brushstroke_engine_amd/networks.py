@@ -274,6 +274,21 @@ class SynthesisNetwork(torch.nn.Module):
             self._plan = _Plan(self, n_max, device)
         return self._plan
 
+    # -- optional per-launch HIP-event timing (bench.py): events are recorded on the launch stream --
+    layer_events = None      # set to a list to collect (name, start_event, end_event)
+
+    def _begin_event(self, name):
+        if self.layer_events is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, e0, e1)
+
+    def _end_event(self, ev):
+        if ev is not None:
+            ev[2].record()
+            self.layer_events.append(ev)
+
     # -- forward --
     def forward(self, ws, geom_feature, pos_encoding=None, return_debug_data=False, return_features=None,
                 blended_features=None, noise_buffers=None, **block_kwargs):
@@ -355,10 +370,12 @@ class SynthesisNetwork(torch.nn.Module):
                         noise_ptr, nstride = rnd.data_ptr(), s.block_res * s.block_res
                     y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
                     clamp = -1.0 if layer.conv_clamp is None else float(layer.conv_clamp)
+                    ev = self._begin_event(name)
                     _lib.check(lib.nb_modconv3x3_f32(
                         _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
                         nstride, _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, s.up, 0.2,
                         layer.act_gain, clamp, stream), name)
+                    self._end_event(ev)
                     keep_alive += [x, x2]
                     x, x2 = y, None
 
@@ -415,10 +432,12 @@ class SynthesisNetwork(torch.nn.Module):
             if mode < 0:
                 raise RuntimeError("Unknown render mode for TriadGanPaintEngine: {}".format(extra.get("render_mode")))
         clamp = -1.0 if t.conv_clamp is None else float(t.conv_clamp)
+        ev = self._begin_event("torgb")
         _lib.check(_lib.lib().nb_torgb_triad_f32(
             _p(x), _p(plan.styles[-1]), c + 9, _p(self.packed["torgb"]["w"]), _p(t.bias), _p(t.color_bias), clamp,
             _p(logits), _p(uvs), _p(img), _p(colors), _p(user), mode, _p(rgba), _p(rgba8), n, c, r * r, stream),
             "torgb_triad")
+        self._end_event(ev)
         if extra is not None:
             extra["out"] = {"logits": logits, "rgba": rgba, "rgba_u8": rgba8}
         return img, {"colors": colors, "uvs": uvs}
