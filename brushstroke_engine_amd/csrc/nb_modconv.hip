@@ -6,17 +6,24 @@
 // i.e. the "scale activations, shared weights, scale outputs" form (networks.py:67-76), which is
 // algebraically the fused per-sample-weight form (networks.py:55-64, 78-88) but turns the whole
 // batch into ONE implicit GEMM against a single shared weight matrix:
-//     A = weights  [M = c_out]            (MFMA A operand, from LDS, layout [k][tap][c_out])
-//     B = s-scaled activations [N = pixels] (MFMA B operand, from an LDS halo tile [k][row][col])
+//     A = weights  [M = c_out]              (MFMA A operand, LDS image [k][tap][c_out], filled by LDS-DMA)
+//     B = s-scaled activations [N = pixels] (MFMA B operand, LDS halo tile [k][row][col], 16-byte staged)
 //     K = c_in x taps, walked in chunks of KC input channels that are double-buffered in LDS.
 // Output D[c_out, pixel] has the pixel on the lane, so NCHW stores are 128-B contiguous per row.
 //
-// up = 1 kernel: v_mfma_f32_32x32x2_f32, 4 waves, wave tile = (MB x 32 c_out) x (NBW x 32 pixels).
+// up = 1 kernel: v_mfma_f32_32x32x2_f32, NW waves, wave tile = (MB x 32 c_out) x (NBW x 32 pixels).
 // up = 2 kernel: the stride-2 transposed convolution is evaluated as its 4 output phases
 //     (even/odd row x even/odd col; 4+2+2+1 = 9 non-zero taps, so no multiply by stuffed zeros),
 //     on a quad grid with a one-quad halo, v_mfma_f32_16x16x4_f32; the phase images y1 are then
 //     passed through LDS to the fused 4x4 FIR ([1,3,3,1]x[1,3,3,1]/64 * 4, evaluated separably,
 //     polyphase) + epilogue, so the (2H+1)^2 intermediate never reaches HBM.
+//
+// Staging: the activation halo tile is laid out so that LDS column u <-> image column X0 - 4 + u; every
+// 16-byte group is then aligned in global memory AND in LDS (one global_load_dwordx4 + one
+// ds_write_b128 per 4 pixels, style multiply in between).  Loads for chunk k+1 are issued before the
+// MFMA loop of chunk k and consumed after it.  Weights are zero-padded on the host to
+// [ceil8(c_in)][9][ceil32(c_out)] so their chunk is a pure linear copy done by global_load_lds_dwordx4
+// (no VGPRs, no ds_write).  LDS fragment reads are software-pipelined one k-step ahead of the MFMAs.
 #include "nb_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -25,14 +32,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ModconvParams {
     const float* x1;
     const float* x2;
-    const float* wpk;      // [c_in][9][c_out]
+    const float* wpk;      // [c_in_pad][9][c_out_ld]
     const float* styles;   // [n][c_in]
     const float* dcoefs;   // [n][c_out]
     const float* noise;    // [n or 1][Hout][Wout] or null
     const float* bias;     // [c_out]
     float* y;              // [n][c_out][Hout][Wout]
     long long noise_stride_n;
-    int c1, c2, c_in, c_out;
+    int c1, c2, c_in, c_out, c_out_ld;
     int h, w;              // input resolution
     int log2_tw;           // up1: tile width = 1 << log2_tw
     int th;                // up1: tile rows actually staged (<= h); up2: quad rows per tile
@@ -49,25 +56,100 @@ __device__ __forceinline__ float nb_epilogue(float v, float bias, float alpha, f
     return v;
 }
 
+// LDS floats reserved for one weight chunk: whole 1-KiB LDS-DMA pieces (tail lanes of the last piece re-copy
+// the last element, so the piece must lie inside the buffer)
+__host__ __device__ constexpr int nb_wbuf_floats(int kc, int co_wg) { return ((kc * 9 * co_wg / 4 + 63) / 64) * 256; }
+
+#define NB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define NB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// Activation halo tile staging, shared by both kernels.  ROWS x XS floats per channel, XS % 4 == 0,
+// LDS column u <-> image column X0 - 4 + u, LDS row t <-> image row Y0 - 1 + t.
+template <int KC, int NT, int XE4>
+struct XStage {
+    int sp[XE4];      // spatial offset gy*W + gx of the 16-byte group, -1 = zero fill (outside the image)
+    int lds[XE4];     // float offset inside the LDS x buffer, -1 = no element for this thread
+    int kk[XE4];      // channel of the chunk this element belongs to
+    f32x4 v[XE4];
+    float s[XE4];
+
+    __device__ __forceinline__ void init(int tid, int rows, int XS, int plane, int Y0, int X0, int H, int W) {
+        const int G = XS >> 2, plane4 = rows * G;
+#pragma unroll
+        for (int i = 0; i < XE4; ++i) {
+            const int e = tid + i * NT;
+            sp[i] = -1; lds[i] = -1; kk[i] = 0;
+            if (e < KC * plane4) {
+                const int k = e / plane4, rem = e - k * plane4;
+                const int r = rem / G, g = rem - r * G;
+                const int gy = Y0 - 1 + r, gx = X0 - 4 + 4 * g;
+                kk[i] = k;
+                lds[i] = k * plane + r * XS + 4 * g;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) sp[i] = gy * W + gx;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const ModconvParams& p, int n, int c0, int HW) {
+#pragma unroll
+        for (int i = 0; i < XE4; ++i) {
+            const int ch = c0 + kk[i];
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            float sv = 0.f;
+            if (sp[i] >= 0 && ch < p.c_in) {
+                const float* base = ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW
+                                              : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW;
+                t = *reinterpret_cast<const f32x4*>(base + sp[i]);
+                sv = p.styles[(size_t)n * p.c_in + ch];
+            }
+            v[i] = t; s[i] = sv;     // the style multiply happens at store(): no wait on these loads before the MFMAs
+        }
+    }
+    __device__ __forceinline__ void store(float* xd) const {
+#pragma unroll
+        for (int i = 0; i < XE4; ++i)
+            if (lds[i] >= 0) *reinterpret_cast<f32x4*>(xd + lds[i]) = v[i] * s[i];
+    }
+};
+
+// Weight chunk: rows (k*9+tap) of CO_WG floats, copied global -> LDS by LDS-DMA, 1 KiB per wave-instruction.
+template <int KC, int CO_WG, int NW>
+__device__ __forceinline__ void stage_weights_dma(const ModconvParams& p, float* wd, int c0, int co0, int wv, int lane) {
+    constexpr int NE4 = KC * 9 * CO_WG / 4;            // 16-byte elements in the chunk
+    constexpr int NINST = (NE4 + 63) / 64;
+#pragma unroll
+    for (int q0 = 0; q0 < NINST; q0 += NW) {
+        const int q = q0 + wv;
+        if (q < NINST) {
+            int e4 = q * 64 + lane;
+            if (e4 >= NE4) e4 = NE4 - 1;                // tail lanes re-copy the last element (harmless)
+            const int row = e4 / (CO_WG / 4), j4 = e4 - row * (CO_WG / 4);
+            const float* src = p.wpk + ((size_t)c0 * 9 + row) * p.c_out_ld + co0 + j4 * 4;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(wd + q * 256), 16, 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // up = 1
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NBW, int KC>
-__global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams p) {
+template <int NW, int MB, int NBW, int KC>
+__global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvParams p) {
+    constexpr int NT = NW * 64;
     constexpr int CO_WG = MB * 32;
-    constexpr int XPLANE_MAX = 352;                 // >= (th+2)*(tw+2) for every tile shape (10x34 = 340, 18x18 = 324)
+    constexpr int PIX_WG = NW * NBW * 32;
+    constexpr int XPLANE_A = (PIX_WG / 32 + 2) * 40;                 // tile width 32: (rows+2) x (32+8)
+    constexpr int XPLANE_MAX = XPLANE_A > 18 * 24 ? XPLANE_A : 18 * 24;   // narrower (whole-image) tiles: <= 18 x 24
     constexpr int XBUF = KC * XPLANE_MAX;
-    constexpr int WBUF = KC * 9 * CO_WG;
-    constexpr int XE = (XPLANE_MAX + 255) / 256;    // halo elements per thread per channel
-    constexpr int WE = (WBUF / 4 + 255) / 256;      // float4 weight elements per thread per chunk
+    constexpr int WBUF = nb_wbuf_floats(KC, CO_WG);
+    constexpr int XE4 = (KC * XPLANE_MAX / 4 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                 // [2][KC][plane]
     float* wsm = smem + 2 * XBUF;     // [2][KC][9][CO_WG]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6, lh = lane >> 5, l31 = lane & 31;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
     const int H = p.h, W = p.w;
-    const int TW = 1 << p.log2_tw, XS = TW + 2;
+    const int TW = 1 << p.log2_tw, XS = TW + 8;
     const int th = p.th;
     const int plane = (th + 2) * XS;
 
@@ -79,73 +161,10 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
     const int co0 = slice * CO_WG;
     const int HW = H * W;
 
-    // ---- per-thread staging geometry (identical for every channel chunk) ----
-    int xoff[XE];      // offset inside one channel plane of the global image, -1 = zero fill
-    int xlds[XE];      // offset inside one channel plane of the LDS tile, -1 = not mine
-#pragma unroll
-    for (int i = 0; i < XE; ++i) {
-        const int e = tid + i * 256;
-        xoff[i] = -1; xlds[i] = -1;
-        if (e < plane) {
-            const int r = e / XS, c = e - r * XS;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            xlds[i] = e;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xoff[i] = gy * W + gx;
-        }
-    }
-    const float* sty = p.styles + (size_t)n * p.c_in;
+    XStage<KC, NT, XE4> xst;
+    xst.init(tid, th + 2, XS, plane, y0, x0, H, W);
 
-    float xreg[KC][XE], sreg[KC];
-    f32x4 wreg[WE];
-
-    auto load_chunk = [&](int c0) {
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const int ch = c0 + k;
-            const bool chv = ch < p.c_in;
-            const float* src = nullptr;
-            float s = 0.f;
-            if (chv) {
-                src = ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW;
-                s = sty[ch];
-            }
-            sreg[k] = s;      // the style multiply happens at store_chunk, so no wait on these loads sits before the MFMAs
-#pragma unroll
-            for (int i = 0; i < XE; ++i) {
-                float v = 0.f;
-                if (chv && xoff[i] >= 0) v = src[xoff[i]];
-                xreg[k][i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WE; ++i) {
-            const int e4 = tid + i * 256;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e4 < WBUF / 4) {
-                const int row = e4 / (CO_WG / 4), j4 = e4 - row * (CO_WG / 4);   // row = k*9 + tap
-                const int ch = c0 + row / 9;
-                if (ch < p.c_in && co0 + j4 * 4 < p.c_out)
-                    v = *reinterpret_cast<const f32x4*>(p.wpk + ((size_t)c0 * 9 + row) * p.c_out + co0 + j4 * 4);
-            }
-            wreg[i] = v;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-        float* xd = xs + buf * XBUF;
-#pragma unroll
-        for (int k = 0; k < KC; ++k)
-#pragma unroll
-            for (int i = 0; i < XE; ++i)
-                if (xlds[i] >= 0) xd[k * plane + xlds[i]] = xreg[k][i] * sreg[k];
-        float* wd = wsm + buf * WBUF;
-#pragma unroll
-        for (int i = 0; i < WE; ++i) {
-            const int e4 = tid + i * 256;
-            if (e4 < WBUF / 4) *reinterpret_cast<f32x4*>(wd + e4 * 4) = wreg[i];
-        }
-    };
-
-    // ---- B-fragment base offsets (pixel -> halo tile position) ----
+    // ---- B-fragment base offsets (pixel -> halo tile position; +3: column u = tx + kx + 3) ----
     int boff[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -153,7 +172,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
         int ty = q >> p.log2_tw;
         const int tx = q & (TW - 1);
         ty = ty < th ? ty : th - 1;       // rows past the tile are computed on clamped data and never stored
-        boff[nb] = ty * XS + tx;
+        boff[nb] = ty * XS + tx + 3;
     }
 
     f32x16 acc[MB][NBW];
@@ -165,25 +184,29 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
     const int nchunks = (p.c_in + KC - 1) / KC;
-    load_chunk(0);
-    store_chunk(0);
+    xst.load(p, n, 0, HW);
+    stage_weights_dma<KC, CO_WG, NW>(p, wsm, 0, co0, wv, lane);
+    xst.store(xs);
     __syncthreads();
     for (int ck = 0; ck < nchunks; ++ck) {
         const int buf = ck & 1;
-        if (ck + 1 < nchunks) load_chunk((ck + 1) * KC);
+        if (ck + 1 < nchunks) {
+            xst.load(p, n, (ck + 1) * KC, HW);
+            stage_weights_dma<KC, CO_WG, NW>(p, wsm + (buf ^ 1) * WBUF, (ck + 1) * KC, co0, wv, lane);
+        }
         const float* xb = xs + buf * XBUF + lh * plane;
         const float* wb = wsm + buf * WBUF + lh * 9 * CO_WG + l31;
         // software pipeline: the fragments of step s+1 are read from LDS right after the first MFMA of
         // step s has issued, so their latency rides under the remaining MB*NBW-1 MFMAs (64 cycles each)
         constexpr int STEPS = (KC / 2) * 9;
         float af[2][MB], bfr[2][NBW];
-        auto fetch = [&](int step, float (&a)[MB], float (&b)[NBW]) {
+        auto fetch = [&](int step, float (&a)[MB], float (&bb)[NBW]) {
             const int kk = step / 9, tap = step - kk * 9;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) a[mb] = wb[(kk * 2 * 9 + tap) * CO_WG + mb * 32];
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) b[nb] = xb[kk * 2 * plane + boff[nb] + ky * XS + kx];
+            for (int nb = 0; nb < NBW; ++nb) bb[nb] = xb[kk * 2 * plane + boff[nb] + ky * XS + kx];
         };
         fetch(0, af[0], bfr[0]);
 #pragma unroll
@@ -199,9 +222,9 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mb], bfr[cur][nb], acc[mb][nb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (step + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, MB + NBW, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW - 1, 0);
+            if (MB * NBW > 1) __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW - 1, 0);
         }
-        if (ck + 1 < nchunks) store_chunk(buf ^ 1);
+        if (ck + 1 < nchunks) xst.store(xs + (buf ^ 1) * XBUF);
         __syncthreads();
     }
 
@@ -249,11 +272,12 @@ __global__ __launch_bounds__(256) void modconv3x3_up1_kernel(const ModconvParams
 // ------------------------------------------------------------------------------------------------
 template <int NBP, int KC>
 __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams p) {
+    constexpr int NW = 4, NT = 256;
     constexpr int CO_WG = 16;
-    constexpr int XPLANE_MAX = 19 * 35;             // (TQH+3)*(TQW+3) for TQ = 16 x 32
+    constexpr int XPLANE_MAX = 19 * 40;             // (TQH+3) x (TQW+8) for TQ = 16 x 32
     constexpr int XBUF = KC * XPLANE_MAX;
-    constexpr int WBUF = KC * 9 * CO_WG;
-    constexpr int XE = (XPLANE_MAX + 255) / 256;
+    constexpr int WBUF = nb_wbuf_floats(KC, CO_WG);
+    constexpr int XE4 = (KC * XPLANE_MAX / 4 + NT - 1) / NT;
     constexpr int NPOS_MAX = 4 * NBP * 16;
     constexpr int Y1_PHASE = NPOS_MAX;               // floats per phase image
     constexpr int Y1_SLOT = 4 * Y1_PHASE + 16;       // +16: keep the 4 c_out slots on different banks
@@ -263,11 +287,11 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
     float* y1s = smem;                // epilogue reuse: [4 slots][4 phases][NPOS_MAX]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6, lq = lane >> 4, l15 = lane & 15;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lq = lane >> 4, l15 = lane & 15;
     const int H = p.h, W = p.w;
     const int TQH = p.th, TQW = p.tw;
     const int PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;
-    const int XS = TQW + 3;
+    const int XS = TQW + 8;
     const int plane = (TQH + 3) * XS;
 
     int b = blockIdx.x;
@@ -278,78 +302,17 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
     const int co0 = slice * CO_WG;
     const int HW = H * W;
 
-    int xoff[XE], xlds[XE];
-#pragma unroll
-    for (int i = 0; i < XE; ++i) {
-        const int e = tid + i * 256;
-        xoff[i] = -1; xlds[i] = -1;
-        if (e < plane) {
-            const int r = e / XS, c = e - r * XS;
-            const int gy = I0 - 1 + r, gx = J0 - 1 + c;
-            xlds[i] = e;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xoff[i] = gy * W + gx;
-        }
-    }
-    const float* sty = p.styles + (size_t)n * p.c_in;
+    XStage<KC, NT, XE4> xst;
+    xst.init(tid, TQH + 3, XS, plane, I0, J0, H, W);
 
-    float xreg[KC][XE], sreg[KC];
-    float wreg[(WBUF + 255) / 256];
-    constexpr int WE = (WBUF + 255) / 256;
-
-    auto load_chunk = [&](int c0) {
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const int ch = c0 + k;
-            const bool chv = ch < p.c_in;
-            const float* src = nullptr;
-            float s = 0.f;
-            if (chv) {
-                src = ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW;
-                s = sty[ch];
-            }
-            sreg[k] = s;      // the style multiply happens at store_chunk, so no wait on these loads sits before the MFMAs
-#pragma unroll
-            for (int i = 0; i < XE; ++i) {
-                float v = 0.f;
-                if (chv && xoff[i] >= 0) v = src[xoff[i]];
-                xreg[k][i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WE; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < WBUF) {
-                const int row = e >> 4, j = e & 15;            // row = k*9 + tap
-                const int ch = c0 + row / 9;
-                if (ch < p.c_in && co0 + j < p.c_out) v = p.wpk[((size_t)c0 * 9 + row) * p.c_out + co0 + j];
-            }
-            wreg[i] = v;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-        float* xd = xs + buf * XBUF;
-#pragma unroll
-        for (int k = 0; k < KC; ++k)
-#pragma unroll
-            for (int i = 0; i < XE; ++i)
-                if (xlds[i] >= 0) xd[k * plane + xlds[i]] = xreg[k][i] * sreg[k];
-        float* wd = wsm + buf * WBUF;
-#pragma unroll
-        for (int i = 0; i < WE; ++i) {
-            const int e = tid + i * 256;
-            if (e < WBUF) wd[e] = wreg[i];
-        }
-    };
-
-    // position blocks of this wave: block index wv*NBP + j, 16 positions each
+    // position blocks of this wave: block index wv*NBP + j, 16 positions each; X(r,c) sits at column c + 3
     int boff[NBP];
 #pragma unroll
     for (int j = 0; j < NBP; ++j) {
         int pidx = (wv * NBP + j) * 16 + l15;
         pidx = pidx < NPOS ? pidx : NPOS - 1;
         const int r = pidx / PW, c = pidx - r * PW;
-        boff[j] = r * XS + c;
+        boff[j] = r * XS + c + 3;
     }
 
     f32x4 acc[NBP][4];
@@ -359,12 +322,16 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
         for (int ph = 0; ph < 4; ++ph) acc[j][ph] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = (p.c_in + KC - 1) / KC;
-    load_chunk(0);
-    store_chunk(0);
+    xst.load(p, n, 0, HW);
+    stage_weights_dma<KC, CO_WG, NW>(p, wsm, 0, co0, wv, lane);
+    xst.store(xs);
     __syncthreads();
     for (int ck = 0; ck < nchunks; ++ck) {
         const int buf = ck & 1;
-        if (ck + 1 < nchunks) load_chunk((ck + 1) * KC);
+        if (ck + 1 < nchunks) {
+            xst.load(p, n, (ck + 1) * KC, HW);
+            stage_weights_dma<KC, CO_WG, NW>(p, wsm + (buf ^ 1) * WBUF, (ck + 1) * KC, co0, wv, lane);
+        }
         const float* xb = xs + buf * XBUF + lq * plane;
         const float* wb = wsm + buf * WBUF + lq * 9 * CO_WG + l15;
         // software pipeline over (k-step, position block): block j+1's four B fragments (and, at the last
@@ -411,7 +378,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         }
-        if (ck + 1 < nchunks) store_chunk(buf ^ 1);
+        if (ck + 1 < nchunks) xst.store(xs + (buf ^ 1) * XBUF);
         __syncthreads();
     }
 
@@ -486,19 +453,26 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NBW, int KC>
+template <int NW, int MB, int NBW, int KC>
 static int launch_up1(ModconvParams p, int n, hipStream_t st) {
-    constexpr int PIX_WG = 4 * NBW * 32;
+    constexpr int PIX_WG = NW * NBW * 32;
+    constexpr int XPLANE_A = (PIX_WG / 32 + 2) * 40;
+    constexpr int XPLANE_MAX = XPLANE_A > 18 * 24 ? XPLANE_A : 18 * 24;
     const int TW = p.w < 32 ? p.w : 32;
     int l2 = 0; while ((1 << l2) < TW) ++l2;
     p.log2_tw = l2;
     int th = PIX_WG / TW; if (th > p.h) th = p.h;
     p.th = th;
-    if ((th + 2) * (TW + 2) > 352) { nb_set_error("modconv up1: tile %dx%d does not fit the LDS plane", th, TW); return NB_EINVAL; }
+    if ((th + 2) * (TW + 8) > XPLANE_MAX) { nb_set_error("modconv up1: tile %dx%d does not fit the LDS plane", th, TW); return NB_EINVAL; }
     p.tiles_x = p.w / TW; p.tiles_y = nb_cdiv(p.h, th); p.slices = nb_cdiv(p.c_out, MB * 32);
-    const size_t lds = (size_t)(2 * KC * 352 + 2 * KC * 9 * MB * 32) * sizeof(float);
+    const size_t lds = (size_t)(2 * KC * XPLANE_MAX + 2 * nb_wbuf_floats(KC, MB * 32)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_kernel<NW, MB, NBW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_kernel<MB, NBW, KC>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_kernel<NW, MB, NBW, KC>), grid, dim3(NW * 64), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1");
     return NB_OK;
 }
@@ -506,9 +480,14 @@ static int launch_up1(ModconvParams p, int n, hipStream_t st) {
 template <int NBP, int KC>
 static int launch_up2(ModconvParams p, int n, hipStream_t st) {
     p.slices = nb_cdiv(p.c_out, 16);
-    const size_t lds_main = (size_t)(2 * KC * 19 * 35 + 2 * KC * 9 * 16) * sizeof(float);
+    const size_t lds_main = (size_t)(2 * KC * 19 * 40 + 2 * nb_wbuf_floats(KC, 16)) * sizeof(float);
     const size_t lds_epi = (size_t)(4 * (4 * 4 * NBP * 16 + 16)) * sizeof(float);
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_kernel<NBP, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
     hipLaunchKernelGGL((modconv3x3_up2_kernel<NBP, KC>), grid, dim3(256), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up2");
@@ -522,43 +501,48 @@ extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c
     NB_REQUIRE(x1 && wpk && styles && dcoefs && bias && y, "modconv3x3: null pointer");
     NB_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0 || x2), "modconv3x3: bad channel split c1=%d c2=%d", c1, c2);
     NB_REQUIRE(n > 0 && n <= 65535, "modconv3x3: batch %d out of range", n);
-    NB_REQUIRE(h >= 1 && w >= 1 && (w & (w - 1)) == 0 && (h & (h - 1)) == 0, "modconv3x3: h,w must be powers of two (got %dx%d)", h, w);
-    NB_REQUIRE(c_out > 0 && c_out % 4 == 0, "modconv3x3: c_out=%d must be a multiple of 4", c_out);
+    NB_REQUIRE(h >= 4 && w >= 4 && (w & (w - 1)) == 0 && (h & (h - 1)) == 0, "modconv3x3: h,w must be powers of two >= 4 (got %dx%d)", h, w);
+    NB_REQUIRE(c_out > 0, "modconv3x3: c_out=%d", c_out);
     NB_REQUIRE(up == 1 || up == 2, "modconv3x3: up=%d unsupported", up);
+    NB_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)wpk | (uintptr_t)y) % 16 == 0, "modconv3x3: x1, x2, wpk and y must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     ModconvParams p;
     p.x1 = x1; p.x2 = x2; p.wpk = wpk; p.styles = styles; p.dcoefs = dcoefs; p.noise = noise; p.bias = bias; p.y = y;
     p.noise_stride_n = noise_stride_n;
-    p.c1 = c1; p.c2 = c2; p.c_in = c1 + c2; p.c_out = c_out; p.h = h; p.w = w;
+    p.c1 = c1; p.c2 = c2; p.c_in = c1 + c2; p.c_out = c_out; p.c_out_ld = (c_out + 31) / 32 * 32; p.h = h; p.w = w;
     p.log2_tw = 0; p.th = 0; p.tw = 0; p.tiles_x = p.tiles_y = p.slices = 1;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     if (up == 1) {
         // pick the c_out slice / pixels per workgroup so that small layers still give >= ~2 workgroups per CU
         const long pixels = (long)n * h * w;
-        if (c_out % 128 == 0 && pixels >= 512L * 256) return launch_up1<4, 2, 4>(p, n, st);
-        if (c_out % 64 == 0 && pixels >= 256L * 256) return launch_up1<2, 2, 4>(p, n, st);
-        if (pixels >= 64L * 256) return launch_up1<1, 2, 4>(p, n, st);
-        return launch_up1<1, 1, 4>(p, n, st);
+        if (c_out > 64 && pixels >= 512L * 256) return launch_up1<8, 4, 1, 8>(p, n, st);
+        if (c_out > 32 && pixels >= 512L * 256) return launch_up1<8, 2, 2, 8>(p, n, st);
+        if (c_out > 32 && pixels >= 128L * 256) return launch_up1<4, 2, 2, 8>(p, n, st);
+        if (pixels >= 64L * 256) return launch_up1<4, 1, 2, 8>(p, n, st);
+        return launch_up1<4, 1, 1, 8>(p, n, st);
     }
     const int tqw = w < 32 ? w : 32, tqh = h < 16 ? h : 16;
     p.th = tqh; p.tw = tqw; p.tiles_x = w / tqw; p.tiles_y = h / tqh;
     const int nblk = nb_cdiv((tqh + 2) * (tqw + 2), 16);
     const int nbp = nb_cdiv(nblk, 4);
-    if (nbp <= 1) return launch_up2<1, 4>(p, n, st);
-    if (nbp <= 2) return launch_up2<2, 4>(p, n, st);
+    if (nbp <= 1) return launch_up2<1, 8>(p, n, st);
+    if (nbp <= 2) return launch_up2<2, 8>(p, n, st);
     if (nbp <= 6) return launch_up2<6, 4>(p, n, st);
     return launch_up2<10, 4>(p, n, st);
 }
 
+// Host-side repack: W[c_out,c_in,3,3] -> wpk[ceil8(c_in)][9][ceil32(c_out)] (zero padded), wsq[c_in][c_out] = sum_k W^2
 extern "C" int nb_pack_conv_weight(const float* w, int c_out, int c_in, float* wpk, float* wsq) {
     NB_REQUIRE(w && c_out > 0 && c_in > 0, "pack_conv_weight: bad arguments");
+    const int ci_pad = (c_in + 7) / 8 * 8, co_ld = (c_out + 31) / 32 * 32;
+    if (wpk) for (size_t i = 0; i < (size_t)ci_pad * 9 * co_ld; ++i) wpk[i] = 0.f;
     for (int o = 0; o < c_out; ++o)
         for (int i = 0; i < c_in; ++i) {
             float sq = 0.f;
             for (int t = 0; t < 9; ++t) {
                 const float v = w[((size_t)o * c_in + i) * 9 + t];
                 sq += v * v;
-                if (wpk) wpk[((size_t)i * 9 + t) * c_out + o] = v;
+                if (wpk) wpk[((size_t)i * 9 + t) * co_ld + o] = v;
             }
             if (wsq) wsq[(size_t)i * c_out + o] = sq;
         }

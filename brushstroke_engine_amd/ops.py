@@ -113,11 +113,14 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
 
 
 def pack_conv_weight(weight: torch.Tensor):
-    """[O,I,3,3] -> (wpk [I,9,O], wsq [I,O]) in the kernels' layout (see nb_pack_conv_weight)."""
+    """[O,I,3,3] -> (wpk [ceil8(I), 9, ceil32(O)] zero padded, wsq [I,O]) in the kernels' layout
+    (same as the host helper nb_pack_conv_weight)."""
     o, i, kh, kw = weight.shape
     assert kh == 3 and kw == 3
     w = weight.detach().to(torch.float32)
-    wpk = w.permute(1, 2, 3, 0).reshape(i, 9, o).contiguous()
+    ip, op = (i + 7) // 8 * 8, (o + 31) // 32 * 32
+    wpk = torch.zeros([ip, 9, op], dtype=torch.float32, device=w.device)
+    wpk[:i, :, :o] = w.permute(1, 2, 3, 0).reshape(i, 9, o)
     wsq = w.square().sum(dim=[2, 3]).t().contiguous()
     return wpk, wsq
 

@@ -121,9 +121,10 @@ int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max_res, const
  *           [1,3,3,1]x[1,3,3,1]/64 FIR with padding 1 and gain 4 (conv2d_resample.py:124-142)
  * The input is the channel-concatenation of x1 [n,c1,h,w] and (optionally) x2 [n,c2,h,w] -- the
  * geometry feature -- so no torch.cat copy is needed (networks_modified.py:218-219).
- * wpk is the packed weight [c1+c2][9][c_out] (tap = ky*3+kx) produced by nb_pack_conv_weight.
+ * wpk is the packed, zero-padded weight [ceil8(c1+c2)][9][ceil32(c_out)] (tap = ky*3+kx) produced by
+ * nb_pack_conv_weight.  x1, x2, wpk and y must be 16-byte aligned.
  * noise is [n or 1, h*up, w*up] with sample stride noise_stride_n (0 = shared), or NULL.
- * y is [n, c_out, h*up, w*up].  c_out must be a multiple of 4; h and w powers of two. */
+ * y is [n, c_out, h*up, w*up].  h and w must be powers of two >= 4. */
 int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c2, const float* wpk, const float* styles,
                       const float* dcoefs, const float* noise, int64_t noise_stride_n, const float* bias,
                       float* y, int n, int h, int w, int c_out, int up, float alpha, float gain, float clamp,
@@ -148,8 +149,8 @@ int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n,
 int nb_blend_f32(const float* features, int nf, const float* alpha, int na, const float* x, float* y, int n, int c,
                  int hw, void* stream);
 
-/* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into wpk[c_in][9][c_out] and
- * wsq[c_in][c_out] = sum_k W^2.  Either output may be NULL. */
+/* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into the zero-padded
+ * wpk[ceil8(c_in)][9][ceil32(c_out)] and wsq[c_in][c_out] = sum_k W^2.  Either output may be NULL. */
 int nb_pack_conv_weight(const float* w, int c_out, int c_in, float* wpk, float* wsq);
 
 #ifdef __cplusplus

@@ -50,11 +50,12 @@ def test_layer_desc_layout_matches_header(library):
 def test_pack_conv_weight_host_helper(library):
     rs = np.random.RandomState(0)
     w = rs.randn(8, 5, 3, 3).astype(np.float32)
-    wpk = np.zeros((5, 9, 8), np.float32)
+    wpk = np.full((8, 9, 32), 7.0, np.float32)        # padded to [ceil8(c_in)][9][ceil32(c_out)]
     wsq = np.zeros((5, 8), np.float32)
     rc = library.nb_pack_conv_weight(w.ctypes.data, 8, 5, wpk.ctypes.data, wsq.ctypes.data)
     assert rc == 0
-    np.testing.assert_array_equal(wpk, w.transpose(1, 2, 3, 0).reshape(5, 9, 8))
+    np.testing.assert_array_equal(wpk[:5, :, :8], w.transpose(1, 2, 3, 0).reshape(5, 9, 8))
+    assert float(np.abs(wpk[5:]).max()) == 0.0 and float(np.abs(wpk[:, :, 8:]).max()) == 0.0
     np.testing.assert_allclose(wsq, (w ** 2).sum(axis=(2, 3)).T, rtol=1e-6)
 
 
