@@ -38,6 +38,7 @@ struct ModconvParams {
     const float* noise;    // [n or 1][Hout][Wout] or null
     const float* bias;     // [c_out]
     float* y;              // [n][c_out][Hout][Wout]
+    const float* zeros;    // >= 16 bytes of zeros in device memory (LDS-DMA source for out-of-image halo groups)
     long long noise_stride_n;
     int c1, c2, c_in, c_out, c_out_ld;
     int h, w;              // input resolution
@@ -194,6 +195,8 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
             xst.load(p, n, (ck + 1) * KC, HW);
             stage_weights_dma<KC, CO_WG, NW>(p, wsm + (buf ^ 1) * WBUF, (ck + 1) * KC, co0, wv, lane);
         }
+        // nothing may sink below this point: the loads / LDS-DMA copies above must be in flight during the MFMA loop
+        __builtin_amdgcn_sched_barrier(0);
         const float* xb = xs + buf * XBUF + lh * plane;
         const float* wb = wsm + buf * WBUF + lh * 9 * CO_WG + l31;
         // software pipeline: the fragments of step s+1 are read from LDS right after the first MFMA of
@@ -270,29 +273,40 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
 //   y[2i]   = .25*o[ti]  + .75*e[ti]   + .75*o[ti+1] + .25*e[ti+1]
 //   y[2i+1] = .25*e[ti]  + .75*o[ti+1] + .75*e[ti+1] + .25*o[ti+2]         (i = I0 + ti)
 // ------------------------------------------------------------------------------------------------
+// LDS geometry of the up=2 kernel (shared by kernel and launcher)
+__host__ __device__ constexpr int nb_up2_ppc(int nbp) { return nbp <= 2 ? 1 : (nbp <= 6 ? 2 : 3); }   // 1-KiB pieces per channel
+__host__ __device__ constexpr int nb_up2_xch(int nbp) { return nb_up2_ppc(nbp) * 256 + 16; }            // floats per channel (+16: k and k+1 on different banks)
+__host__ __device__ constexpr int nb_up2_stage_floats(int nbp, int kc) { return kc * nb_up2_xch(nbp) + nb_wbuf_floats(kc, 16); }
+#define NB_UP2_STAGES 3
+#define NB_STY_MAX 1024
+
 template <int NBP, int KC>
 __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams p) {
-    constexpr int NW = 4, NT = 256;
+    constexpr int NW = 4;
     constexpr int CO_WG = 16;
-    constexpr int XPLANE_MAX = 19 * 40;             // (TQH+3) x (TQW+8) for TQ = 16 x 32
-    constexpr int XBUF = KC * XPLANE_MAX;
-    constexpr int WBUF = nb_wbuf_floats(KC, CO_WG);
-    constexpr int XE4 = (KC * XPLANE_MAX / 4 + NT - 1) / NT;
+    constexpr int PPC = nb_up2_ppc(NBP);
+    constexpr int XCH = nb_up2_xch(NBP);
+    constexpr int NXP = KC * PPC;                    // activation pieces per chunk
+    constexpr int NXPW = (NXP + NW - 1) / NW;        // ... issued per wave
+    constexpr int NWP = nb_wbuf_floats(KC, CO_WG) / 256;   // weight pieces per chunk
+    constexpr int NWPW = (NWP + NW - 1) / NW;
+    constexpr int NPW = NXPW + NWPW;                 // LDS-DMA instructions per wave per chunk (same for every wave)
+    constexpr int STAGE = nb_up2_stage_floats(NBP, KC);
     constexpr int NPOS_MAX = 4 * NBP * 16;
     constexpr int Y1_PHASE = NPOS_MAX;               // floats per phase image
     constexpr int Y1_SLOT = 4 * Y1_PHASE + 16;       // +16: keep the 4 c_out slots on different banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                 // [2][KC][plane]
-    float* wsm = smem + 2 * XBUF;     // [2][KC][9][16]
-    float* y1s = smem;                // epilogue reuse: [4 slots][4 phases][NPOS_MAX]
+    float* sty = smem;                // [NB_STY_MAX] styles of this sample (zero padded)
+    float* ring = smem + NB_STY_MAX;  // [3 stages][ x: KC channels x XCH | w: KC x 9 x 16 ]
+    float* y1s = ring;                // epilogue reuse: [4 slots][4 phases][NPOS_MAX]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lq = lane >> 4, l15 = lane & 15;
     const int H = p.h, W = p.w;
     const int TQH = p.th, TQW = p.tw;
     const int PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;
-    const int XS = TQW + 8;
-    const int plane = (TQH + 3) * XS;
+    const int XS = TQW + 8, G = XS >> 2;
+    const int plane4 = (TQH + 3) * G;                // 16-byte groups per channel of the halo tile
 
     int b = blockIdx.x;
     const int slice = b % p.slices; b /= p.slices;
@@ -302,8 +316,49 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
     const int co0 = slice * CO_WG;
     const int HW = H * W;
 
-    XStage<KC, NT, XE4> xst;
-    xst.init(tid, TQH + 3, XS, plane, I0, J0, H, W);
+    // styles of this sample -> LDS (the A fragments are modulated on their way from LDS to the MFMA)
+    for (int i = tid; i < NB_STY_MAX; i += 256) sty[i] = i < p.c_in ? p.styles[(size_t)n * p.c_in + i] : 0.f;
+
+    // ---- LDS-DMA descriptors of this wave's activation pieces (fixed for all chunks) ----
+    // piece q = i*NW + wv  ->  channel k = q / PPC of the chunk, part = q % PPC; lane l copies the 16-byte group
+    // e4 = part*64 + l of that channel's halo tile (row r = e4 / G, group g = e4 % G), or zeros outside the image.
+    int xsp[NXPW], xk[NXPW], xdst[NXPW];
+#pragma unroll
+    for (int i = 0; i < NXPW; ++i) {
+        int q = i * NW + wv;
+        q = q < NXP ? q : NXP - 1;
+        const int k = q / PPC, part = q - k * PPC;
+        const int e4 = part * 64 + lane;
+        xk[i] = k;
+        xdst[i] = k * XCH + part * 256;
+        xsp[i] = -1;
+        if (e4 < plane4) {
+            const int r = e4 / G, g = e4 - r * G;
+            const int gy = I0 - 1 + r, gx = J0 - 4 + 4 * g;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xsp[i] = gy * W + gx;
+        }
+    }
+    auto issue = [&](int ck, float* st) {
+        const int c0 = ck * KC;
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            const int ch = c0 + xk[i];
+            const float* src = p.zeros;
+            if (xsp[i] >= 0 && ch < p.c_in)
+                src = (ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW) + xsp[i];
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + xdst[i]), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NWPW; ++i) {
+            int q = i * NW + wv;
+            q = q < NWP ? q : NWP - 1;
+            int e4 = q * 64 + lane;
+            e4 = e4 < KC * 9 * CO_WG / 4 ? e4 : KC * 9 * CO_WG / 4 - 1;
+            const int row = e4 / (CO_WG / 4), j4 = e4 - row * (CO_WG / 4);
+            const float* src = p.wpk + ((size_t)c0 * 9 + row) * p.c_out_ld + co0 + j4 * 4;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + KC * XCH + q * 256), 16, 0, 0);
+        }
+    };
 
     // position blocks of this wave: block index wv*NBP + j, 16 positions each; X(r,c) sits at column c + 3
     int boff[NBP];
@@ -322,47 +377,58 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
         for (int ph = 0; ph < 4; ++ph) acc[j][ph] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = (p.c_in + KC - 1) / KC;
-    xst.load(p, n, 0, HW);
-    stage_weights_dma<KC, CO_WG, NW>(p, wsm, 0, co0, wv, lane);
-    xst.store(xs);
-    __syncthreads();
+    // 3-stage ring: chunk ck+2 is in flight while chunk ck is multiplied.  A chunk is complete for this wave when
+    // all but its NPW youngest LDS-DMA operations have retired (counted vmcnt), and for the workgroup after the
+    // barrier that follows.  Raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
+    issue(0, ring);
+    if (nchunks > 1) issue(1, ring + STAGE);
+    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
     for (int ck = 0; ck < nchunks; ++ck) {
-        const int buf = ck & 1;
-        if (ck + 1 < nchunks) {
-            xst.load(p, n, (ck + 1) * KC, HW);
-            stage_weights_dma<KC, CO_WG, NW>(p, wsm + (buf ^ 1) * WBUF, (ck + 1) * KC, co0, wv, lane);
+        if (ck + 2 < nchunks) {
+            const int nxt = cur >= 1 ? cur - 1 : 2;       // (cur + 2) % 3
+            issue(ck + 2, ring + nxt * STAGE);
         }
-        const float* xb = xs + buf * XBUF + lq * plane;
-        const float* wb = wsm + buf * WBUF + lq * 9 * CO_WG + l15;
+        __builtin_amdgcn_sched_barrier(0);
+        const float* xb = ring + cur * STAGE + lq * XCH;
+        const float* wb = ring + cur * STAGE + KC * XCH + lq * 9 * CO_WG + l15;
+        const float* sb = sty + ck * KC + lq;
         // software pipeline over (k-step, position block): block j+1's four B fragments (and, at the last
-        // block of a k-step, the next k-step's nine A fragments) are read right after block j's first MFMA
+        // block of a k-step, the next k-step's nine A fragments + style) are read right after block j's first MFMA
         constexpr int KS = KC / 4;
-        float af[2][9], xf[2][4];
-        auto fetchA = [&](int ks, float (&a)[9]) {
+        float af[2][9], sv[2], xf[2][4];
+        auto fetchA = [&](int ks, float (&a)[9], float& s) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) a[tap] = wb[(ks * 4 * 9 + tap) * CO_WG];
+            s = sb[ks * 4];
         };
         auto fetchB = [&](int ks, int j, float (&x)[4]) {
-            const float* xp = xb + ks * 4 * plane + boff[j];
+            const float* xp = xb + ks * 4 * XCH + boff[j];
             x[3] = xp[0];            // X(r, c)
             x[2] = xp[1];            // X(r, c+1)
             x[1] = xp[XS];           // X(r+1, c)
             x[0] = xp[XS + 1];       // X(r+1, c+1)
         };
-        fetchA(0, af[0]);
+        fetchA(0, af[0], sv[0]);
         fetchB(0, 0, xf[0]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            const int ca = ks & 1;
+            float a[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) a[tap] = af[ca][tap] * sv[ca];     // weight modulation (networks.py:59-60)
 #pragma unroll
             for (int j = 0; j < NBP; ++j) {
                 const int it = ks * NBP + j;
-                const int cb = it & 1, ca = ks & 1;
+                const int cb = it & 1;
                 const float x00 = xf[cb][0], x01 = xf[cb][1], x10 = xf[cb][2], x11 = xf[cb][3];
-                const float(&a)[9] = af[ca];
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x00, acc[j][0], 0, 0, 0);
                 int nreads = 0;
                 if (j + 1 < NBP) { fetchB(ks, j + 1, xf[cb ^ 1]); nreads = 4; }
-                else if (ks + 1 < KS) { fetchA(ks + 1, af[ca ^ 1]); fetchB(ks + 1, 0, xf[cb ^ 1]); nreads = 13; }
+                else if (ks + 1 < KS) { fetchA(ks + 1, af[ca ^ 1], sv[ca ^ 1]); fetchB(ks + 1, 0, xf[cb ^ 1]); nreads = 14; }
                 // accumulator order keeps consecutive MFMAs on different accumulators (40-cycle dependent latency)
                 acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x01, acc[j][1], 0, 0, 0);
                 acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], x10, acc[j][2], 0, 0, 0);
@@ -374,12 +440,16 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
                 acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[5], x11, acc[j][2], 0, 0, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (nreads == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                if (nreads == 13) __builtin_amdgcn_sched_group_barrier(0x100, 13, 0);
+                if (nreads == 14) __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         }
-        if (ck + 1 < nchunks) xst.store(xs + (buf ^ 1) * XBUF);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // chunk ck+1 must have landed (this wave's share) before the barrier publishes it to the workgroup
+        if (ck + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
     }
 
     // ---- epilogue: 4 rounds of 4 c_out (accumulator register g <-> c_out rows {g, 4+g, 8+g, 12+g}) ----
@@ -480,9 +550,10 @@ static int launch_up1(ModconvParams p, int n, hipStream_t st) {
 template <int NBP, int KC>
 static int launch_up2(ModconvParams p, int n, hipStream_t st) {
     p.slices = nb_cdiv(p.c_out, 16);
-    const size_t lds_main = (size_t)(2 * KC * 19 * 40 + 2 * nb_wbuf_floats(KC, 16)) * sizeof(float);
+    if (p.c_in > NB_STY_MAX) { nb_set_error("modconv up2: c_in=%d exceeds %d", p.c_in, NB_STY_MAX); return NB_EINVAL; }
+    const size_t lds_main = (size_t)(NB_UP2_STAGES * nb_up2_stage_floats(NBP, KC)) * sizeof(float);
     const size_t lds_epi = (size_t)(4 * (4 * 4 * NBP * 16 + 16)) * sizeof(float);
-    const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    const size_t lds = NB_STY_MAX * sizeof(float) + (lds_main > lds_epi ? lds_main : lds_epi);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         (void)hipFuncSetAttribute((const void*)modconv3x3_up2_kernel<NBP, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -492,6 +563,21 @@ static int launch_up2(ModconvParams p, int n, hipStream_t st) {
     hipLaunchKernelGGL((modconv3x3_up2_kernel<NBP, KC>), grid, dim3(256), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up2");
     return NB_OK;
+}
+
+// Lazily created per-device page of zeros (256 B): the LDS-DMA source for halo groups outside the image.
+// Created on the first call for a device (outside any stream capture: run one warm-up call before capturing).
+static const float* nb_zero_page() {
+    static float* pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        float* ptr = nullptr;
+        if (hipMalloc((void**)&ptr, 256) != hipSuccess) return nullptr;
+        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = ptr;
+    }
+    return pages[dev];
 }
 
 extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c2, const float* wpk,
@@ -509,14 +595,16 @@ extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c
     ModconvParams p;
     p.x1 = x1; p.x2 = x2; p.wpk = wpk; p.styles = styles; p.dcoefs = dcoefs; p.noise = noise; p.bias = bias; p.y = y;
     p.noise_stride_n = noise_stride_n;
+    p.zeros = nb_zero_page();
+    NB_REQUIRE(p.zeros, "modconv3x3: could not allocate the zero page");
     p.c1 = c1; p.c2 = c2; p.c_in = c1 + c2; p.c_out = c_out; p.c_out_ld = (c_out + 31) / 32 * 32; p.h = h; p.w = w;
     p.log2_tw = 0; p.th = 0; p.tw = 0; p.tiles_x = p.tiles_y = p.slices = 1;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     if (up == 1) {
         // pick the c_out slice / pixels per workgroup so that small layers still give >= ~2 workgroups per CU
         const long pixels = (long)n * h * w;
-        if (c_out > 64 && pixels >= 512L * 256) return launch_up1<8, 4, 1, 8>(p, n, st);
-        if (c_out > 32 && pixels >= 512L * 256) return launch_up1<8, 2, 2, 8>(p, n, st);
+        if (c_out > 64 && pixels >= 512L * 256) return launch_up1<8, 4, 1, 4>(p, n, st);
+        if (c_out > 32 && pixels >= 512L * 256) return launch_up1<8, 2, 2, 4>(p, n, st);
         if (c_out > 32 && pixels >= 128L * 256) return launch_up1<4, 2, 2, 8>(p, n, st);
         if (pixels >= 64L * 256) return launch_up1<4, 1, 2, 8>(p, n, st);
         return launch_up1<4, 1, 1, 8>(p, n, st);
