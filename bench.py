@@ -48,14 +48,19 @@ def kernel_label(spec):
     return f"modconv3x3_up{spec.up}[{spec.in_channels}->{spec.out_channels}@{spec.block_res}]"
 
 
-def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=4):
-    """The CPU oracle (oracle/neube_oracle.py, a port of the reference path onto plain torch CPU ops)
-    timed on this box's host cores.  Bounded sample: `n_sample` patches per pass, repeated until
-    ~seconds_budget of CPU time is spent.  This is a reported baseline, not the thing shipped."""
+def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16):
+    """The CPU oracle (oracle/neube_oracle.py, a port of the reference path onto plain torch CPU ops, fused
+    modulated conv = the reference's eval-mode fp32 default) timed on this box's host cores.  Bounded
+    sample: `n_sample` patches per pass, repeated until ~seconds_budget of CPU time is spent.  16 threads:
+    measured on the MI355X host (256 logical CPUs) the oracle peaks at 16 torch threads (8: 5.7, 16: 6.1,
+    32: 4.9, 64: 2.5, 128: 1.6 patches/s; tools/cpu_threads_scan.py).  A reported baseline, not the target."""
     from oracle import neube_oracle as orc
     from brushstroke_engine_amd import synthetic
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(threads, avail)))
     O = orc.OracleGenerator(cfg, sd)
     z = synthetic.batch_z(cfg, n_sample, 0)
     geom = synthetic.geom_features(cfg, n_sample, seed=0)
@@ -63,8 +68,7 @@ def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=4):
 
     def one():
         img, dbg = O(z, None, geom, positions=pos, return_debug_data=True)
-        rgba = orc.rgba_to_uint8(orc.triad_composite(dbg["uvs"], dbg["colors"], "clear"))
-        return rgba
+        return orc.rgba_to_uint8(orc.triad_composite(dbg["uvs"], dbg["colors"], "clear"))
 
     one()                                   # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
@@ -77,7 +81,8 @@ def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=4):
             break
     return {"value": round(reps * n_sample / el, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} passes of batch {n_sample} at {cfg.img_resolution}x{cfg.img_resolution} "
-                      f"(oracle = torch-CPU port of the reference generator + compositing, fp32, {el:.1f} s)"}
+                      f"(oracle = torch-CPU port of the reference generator + compositing, fp32, {el:.1f} s, "
+                      f"{torch.get_num_threads()} of {avail} host CPUs)"}
 
 
 def main():

@@ -1,0 +1,83 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a tile list, 'render' their shard with a
+deterministic stand-in, gather the uint8 RGBA tiles to rank 0 and assemble the canvas."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def fake_render(tile_ids, size):
+    """Stand-in for the generator: tile i is filled with a pattern that depends only on i."""
+    out = torch.empty([len(tile_ids), size, size, 4], dtype=torch.uint8)
+    for j, i in enumerate(tile_ids):
+        base = torch.arange(size * size * 4, dtype=torch.int64).reshape(size, size, 4)
+        out[j] = ((base * 7 + i * 13) % 251).to(torch.uint8)
+    return out
+
+
+def _worker(rank, world, port, n_tiles, size, tmp):
+    sys.path.insert(0, REPO)
+    from brushstroke_engine_amd.sharding import TileGatherer, paste_tiles, shard_bounds, shard_sizes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(n_tiles, rank, world)
+        n_max = max(shard_sizes(n_tiles, world))
+        mine = fake_render(list(range(lo, hi)), size)
+        padded = torch.zeros([n_max, size, size, 4], dtype=torch.uint8)
+        padded[: hi - lo] = mine
+        g = TileGatherer([n_max, size, size, 4], torch.uint8, "cpu")
+        for _ in range(2):                       # two back-to-back steps reuse the receive buffers
+            g.start(padded)
+            got = g.finish()
+        if rank == 0:
+            cols = 3
+            canvas = torch.zeros([((n_tiles + cols - 1) // cols) * size, cols * size, 4], dtype=torch.uint8)
+            for r in range(world):
+                a, b = shard_bounds(n_tiles, r, world)
+                coords = [((i // cols) * size, (i % cols) * size) for i in range(a, b)]
+                paste_tiles(canvas, got[r][: b - a], coords)
+            np.save(os.path.join(tmp, "canvas.npy"), canvas.numpy())
+        else:
+            assert got is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    from brushstroke_engine_amd.sharding import shard_bounds, shard_sizes
+    for n in (0, 1, 7, 8, 12, 60, 361):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sz = shard_sizes(n, w)
+            assert max(sz) - min(sz) <= 1 and sum(sz) == n
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gather_assembles_canvas(tmp_path):
+    n_tiles, size, world = 7, 8, 2           # ragged: 4 + 3 tiles
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_tiles, size, str(tmp_path)), nprocs=world, join=True)
+    canvas = np.load(tmp_path / "canvas.npy")
+    want = fake_render(list(range(n_tiles)), size).numpy()
+    cols = 3
+    for i in range(n_tiles):
+        y, x = (i // cols) * size, (i % cols) * size
+        np.testing.assert_array_equal(canvas[y:y + size, x:x + size], want[i])
