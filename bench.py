@@ -85,6 +85,34 @@ def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16):
                       f"{torch.get_num_threads()} of {avail} host CPUs)"}
 
 
+def latency_batch1(G, cfg, dev, geom, pos, iters=300):
+    """BASELINE.json config 4 / second half of the metric: per-stroke latency of ONE patch through the
+    hipGraph-captured generator step (inputs on device -> uint8 RGBA on device), wall-clock per replay
+    including the launch and a stream sync, plus the D2H copy of the tile measured separately."""
+    from brushstroke_engine_amd.graphed import GraphedTriadRender
+    gr = GraphedTriadRender(G, batch=1)
+    gr.set_inputs(z=torch.randn(1, cfg.z_dim, device=dev), geom_feature=[g[:1] for g in geom], positions=pos[:1])
+    for _ in range(20):
+        gr.replay()
+    torch.cuda.synchronize()
+    ts, ts_d2h = [], []
+    host = torch.empty_like(gr.out_u8, device="cpu").pin_memory()
+    for i in range(iters):
+        t0 = time.perf_counter()
+        gr.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        host.copy_(gr.out_u8, non_blocking=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ts.append((t1 - t0) * 1e3)
+        ts_d2h.append((t2 - t0) * 1e3)
+    q = lambda a, p: round(float(np.percentile(a, p)), 4)
+    return {"unit": "ms", "p50": q(ts, 50), "p99": q(ts, 99), "mean": round(float(np.mean(ts)), 4),
+            "p50_incl_d2h": q(ts_d2h, 50), "p99_incl_d2h": q(ts_d2h, 99), "iters": iters,
+            "what": "batch=1 256x256 patch, hipGraph replay of the 19-launch generator step + stream sync"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +121,7 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 hipGraph latency leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
     args = ap.parse_args()
 
@@ -206,6 +235,8 @@ def main():
                        "parallelism": f"patch-parallel x{world}" + (" + RCCL gather of RGBA tiles to rank 0" if gatherer else "")},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_latency:
+            out["latency_batch1"] = latency_batch1(G, cfg, dev, geom, pos)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(out), flush=True)

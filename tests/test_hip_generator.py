@@ -176,3 +176,21 @@ def test_linearity_and_determinism_full_size(dev):
     idx = [5, 17, 31]
     c = G(z[idx], None, [x[idx] for x in geom], positions=pos[idx], noise_mode="const")
     assert torch.equal(c, a[idx])
+
+
+def test_graphed_batch1_matches_eager(dev):
+    """Config 4: the hipGraph-captured batch-1 step reproduces the eager result bit for bit, also after
+    its inputs have been overwritten in place."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic
+    from brushstroke_engine_amd.graphed import GraphedTriadRender
+    cfg = cfgmod.style1_config(64)
+    G, _ = build(cfg, 5, dev)
+    gr = GraphedTriadRender(G, batch=1, want_f32=True)
+    for seed in (1, 2):
+        z = D(synthetic.batch_z(cfg, 1, seed), dev).to(torch.float32)
+        geom = [D(x, dev) for x in synthetic.geom_features(cfg, 1, seed=seed)]
+        pos = D(synthetic.positions(cfg, 1, seed=seed), dev)
+        u8, f32, dbg = gr(z=z, geom_feature=geom, positions=pos)
+        e8, ef32, edbg = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
+        torch.cuda.synchronize()
+        assert torch.equal(u8, e8) and torch.equal(f32, ef32) and torch.equal(dbg["uvs"], edbg["uvs"])
