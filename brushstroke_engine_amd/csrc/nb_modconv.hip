@@ -25,6 +25,7 @@
 // [ceil8(c_in)][9][ceil32(c_out)] so their chunk is a pure linear copy done by global_load_lds_dwordx4
 // (no VGPRs, no ds_write).  LDS fragment reads are software-pipelined one k-step ahead of the MFMAs.
 #include "nb_common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,6 +42,8 @@ struct ModconvParams {
     const float* zeros;    // >= 16 bytes of zeros in device memory (LDS-DMA source for out-of-image halo groups)
     long long noise_stride_n;
     int c1, c2, c_in, c_out, c_out_ld;
+    int dbg;               // developer ablation flags (env NB_DEBUG): 1 = no output stores, 2 = no LDS-DMA in the K loop
+    int sty_floats;        // LDS floats reserved for the styles of one sample (c_in rounded up to the chunk grid)
     int h, w;              // input resolution
     int log2_tw;           // up1: tile width = 1 << log2_tw
     int th;                // up1: tile rows actually staged (<= h); up2: quad rows per tile
@@ -64,95 +67,43 @@ __host__ __device__ constexpr int nb_wbuf_floats(int kc, int co_wg) { return ((k
 #define NB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define NB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// Activation halo tile staging, shared by both kernels.  ROWS x XS floats per channel, XS % 4 == 0,
-// LDS column u <-> image column X0 - 4 + u, LDS row t <-> image row Y0 - 1 + t.
-template <int KC, int NT, int XE4>
-struct XStage {
-    int sp[XE4];      // spatial offset gy*W + gx of the 16-byte group, -1 = zero fill (outside the image)
-    int lds[XE4];     // float offset inside the LDS x buffer, -1 = no element for this thread
-    int kk[XE4];      // channel of the chunk this element belongs to
-    f32x4 v[XE4];
-    float s[XE4];
-
-    __device__ __forceinline__ void init(int tid, int rows, int XS, int plane, int Y0, int X0, int H, int W) {
-        const int G = XS >> 2, plane4 = rows * G;
-#pragma unroll
-        for (int i = 0; i < XE4; ++i) {
-            const int e = tid + i * NT;
-            sp[i] = -1; lds[i] = -1; kk[i] = 0;
-            if (e < KC * plane4) {
-                const int k = e / plane4, rem = e - k * plane4;
-                const int r = rem / G, g = rem - r * G;
-                const int gy = Y0 - 1 + r, gx = X0 - 4 + 4 * g;
-                kk[i] = k;
-                lds[i] = k * plane + r * XS + 4 * g;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) sp[i] = gy * W + gx;
-            }
-        }
-    }
-    __device__ __forceinline__ void load(const ModconvParams& p, int n, int c0, int HW) {
-#pragma unroll
-        for (int i = 0; i < XE4; ++i) {
-            const int ch = c0 + kk[i];
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            float sv = 0.f;
-            if (sp[i] >= 0 && ch < p.c_in) {
-                const float* base = ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW
-                                              : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW;
-                t = *reinterpret_cast<const f32x4*>(base + sp[i]);
-                sv = p.styles[(size_t)n * p.c_in + ch];
-            }
-            v[i] = t; s[i] = sv;     // the style multiply happens at store(): no wait on these loads before the MFMAs
-        }
-    }
-    __device__ __forceinline__ void store(float* xd) const {
-#pragma unroll
-        for (int i = 0; i < XE4; ++i)
-            if (lds[i] >= 0) *reinterpret_cast<f32x4*>(xd + lds[i]) = v[i] * s[i];
-    }
-};
-
-// Weight chunk: rows (k*9+tap) of CO_WG floats, copied global -> LDS by LDS-DMA, 1 KiB per wave-instruction.
-template <int KC, int CO_WG, int NW>
-__device__ __forceinline__ void stage_weights_dma(const ModconvParams& p, float* wd, int c0, int co0, int wv, int lane) {
-    constexpr int NE4 = KC * 9 * CO_WG / 4;            // 16-byte elements in the chunk
-    constexpr int NINST = (NE4 + 63) / 64;
-#pragma unroll
-    for (int q0 = 0; q0 < NINST; q0 += NW) {
-        const int q = q0 + wv;
-        if (q < NINST) {
-            int e4 = q * 64 + lane;
-            if (e4 >= NE4) e4 = NE4 - 1;                // tail lanes re-copy the last element (harmless)
-            const int row = e4 / (CO_WG / 4), j4 = e4 - row * (CO_WG / 4);
-            const float* src = p.wpk + ((size_t)c0 * 9 + row) * p.c_out_ld + co0 + j4 * 4;
-            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(wd + q * 256), 16, 0, 0);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // up = 1
 // ------------------------------------------------------------------------------------------------
-template <int NW, int MB, int NBW, int KC>
+// LDS geometry of the up=1 kernel (shared by kernel and launcher): 16-byte groups of the largest halo tile
+__host__ __device__ constexpr int nb_imin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ constexpr int nb_imax(int a, int b) { return a > b ? a : b; }
+__host__ __device__ constexpr int nb_up1_plane4(int pix_wg) {
+    return nb_imax(nb_imax((pix_wg / 32 + 2) * 10, (nb_imin(pix_wg / 16, 16) + 2) * 6),
+                   nb_imax((nb_imin(pix_wg / 8, 8) + 2) * 4, 6 * 3));
+}
+__host__ __device__ constexpr int nb_up1_ppc(int pix_wg) { return (nb_up1_plane4(pix_wg) + 63) / 64; }   // 1-KiB pieces per channel
+__host__ __device__ constexpr int nb_up1_stage_floats(int pix_wg, int kc, int co_wg) {
+    return kc * nb_up1_ppc(pix_wg) * 256 + nb_wbuf_floats(kc, co_wg);
+}
+
+template <int NW, int MB, int NBW, int KC, int NST>
 __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvParams p) {
-    constexpr int NT = NW * 64;
     constexpr int CO_WG = MB * 32;
     constexpr int PIX_WG = NW * NBW * 32;
-    constexpr int XPLANE_A = (PIX_WG / 32 + 2) * 40;                 // tile width 32: (rows+2) x (32+8)
-    constexpr int XPLANE_MAX = XPLANE_A > 18 * 24 ? XPLANE_A : 18 * 24;   // narrower (whole-image) tiles: <= 18 x 24
-    constexpr int XBUF = KC * XPLANE_MAX;
-    constexpr int WBUF = nb_wbuf_floats(KC, CO_WG);
-    constexpr int XE4 = (KC * XPLANE_MAX / 4 + NT - 1) / NT;
+    constexpr int PPC = nb_up1_ppc(PIX_WG);
+    constexpr int XCH = PPC * 256;                   // floats per channel of the halo tile (lanes 0-31 / 32-63 read k / k+1 in separate LDS passes)
+    constexpr int NXP = KC * PPC;                    // activation pieces per chunk
+    constexpr int NXPW = (NXP + NW - 1) / NW;
+    constexpr int NWP = nb_wbuf_floats(KC, CO_WG) / 256;
+    constexpr int NWPW = (NWP + NW - 1) / NW;
+    constexpr int NPW = NXPW + NWPW;                 // LDS-DMA instructions per wave per chunk (same for every wave)
+    constexpr int STAGE = nb_up1_stage_floats(PIX_WG, KC, CO_WG);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                 // [2][KC][plane]
-    float* wsm = smem + 2 * XBUF;     // [2][KC][9][CO_WG]
+    float* sty = smem;                // [sty_floats] styles of this sample (zero padded to the chunk grid)
+    float* ring = smem + p.sty_floats;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
     const int H = p.h, W = p.w;
-    const int TW = 1 << p.log2_tw, XS = TW + 8;
+    const int TW = 1 << p.log2_tw, XS = TW + 8, G = XS >> 2;
     const int th = p.th;
-    const int plane = (th + 2) * XS;
+    const int plane4 = (th + 2) * G;
 
     int b = blockIdx.x;
     const int slice = b % p.slices; b /= p.slices;
@@ -162,8 +113,46 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
     const int co0 = slice * CO_WG;
     const int HW = H * W;
 
-    XStage<KC, NT, XE4> xst;
-    xst.init(tid, th + 2, XS, plane, y0, x0, H, W);
+    for (int i = tid; i < p.sty_floats; i += NW * 64) sty[i] = i < p.c_in ? p.styles[(size_t)n * p.c_in + i] : 0.f;
+
+    // ---- LDS-DMA descriptors of this wave's activation pieces (fixed for all chunks), see the up=2 kernel ----
+    int xsp[NXPW], xk[NXPW], xdst[NXPW];
+#pragma unroll
+    for (int i = 0; i < NXPW; ++i) {
+        int q = i * NW + wv;
+        q = q < NXP ? q : NXP - 1;
+        const int k = q / PPC, part = q - k * PPC;
+        const int e4 = part * 64 + lane;
+        xk[i] = k;
+        xdst[i] = k * XCH + part * 256;
+        xsp[i] = -1;
+        if (e4 < plane4) {
+            const int r = e4 / G, g = e4 - r * G;
+            const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * g;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xsp[i] = gy * W + gx;
+        }
+    }
+    auto issue = [&](int ck, float* st) {
+        const int c0 = ck * KC;
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            const int ch = c0 + xk[i];
+            const float* src = p.zeros;
+            if (xsp[i] >= 0 && ch < p.c_in)
+                src = (ch < p.c1 ? p.x1 + ((size_t)n * p.c1 + ch) * HW : p.x2 + ((size_t)n * p.c2 + (ch - p.c1)) * HW) + xsp[i];
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + xdst[i]), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NWPW; ++i) {
+            int q = i * NW + wv;
+            q = q < NWP ? q : NWP - 1;
+            int e4 = q * 64 + lane;
+            e4 = e4 < KC * 9 * CO_WG / 4 ? e4 : KC * 9 * CO_WG / 4 - 1;
+            const int row = e4 / (CO_WG / 4), j4 = e4 - row * (CO_WG / 4);
+            const float* src = p.wpk + ((size_t)c0 * 9 + row) * p.c_out_ld + co0 + j4 * 4;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + KC * XCH + q * 256), 16, 0, 0);
+        }
+    };
 
     // ---- B-fragment base offsets (pixel -> halo tile position; +3: column u = tx + kx + 3) ----
     int boff[NBW];
@@ -185,50 +174,76 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
     const int nchunks = (p.c_in + KC - 1) / KC;
-    xst.load(p, n, 0, HW);
-    stage_weights_dma<KC, CO_WG, NW>(p, wsm, 0, co0, wv, lane);
-    xst.store(xs);
-    __syncthreads();
+    // NST-stage ring: chunks ck+1 .. ck+NST-1 are in flight while chunk ck is multiplied.  A chunk is complete
+    // for this wave when all but the (chunks still allowed in flight) x NPW youngest LDS-DMA operations have retired
+    // (counted vmcnt), and for the workgroup after the raw s_barrier that follows (__syncthreads() would drain the queue).
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nchunks) issue(st, ring + st * STAGE);
+    {
+        // wait for chunk 0: at most min(nchunks, NST-1) - 1 younger chunks may stay in flight
+        const int younger = (nchunks < NST - 1 ? nchunks : NST - 1) - 1;
+#pragma unroll
+        for (int v = NST - 2; v >= 0; --v)
+            if (younger == v) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v * NPW) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
     for (int ck = 0; ck < nchunks; ++ck) {
-        const int buf = ck & 1;
-        if (ck + 1 < nchunks) {
-            xst.load(p, n, (ck + 1) * KC, HW);
-            stage_weights_dma<KC, CO_WG, NW>(p, wsm + (buf ^ 1) * WBUF, (ck + 1) * KC, co0, wv, lane);
+        if (ck + NST - 1 < nchunks && !(p.dbg & 2)) {
+            const int nxt = cur == 0 ? NST - 1 : cur - 1;       // (cur + NST - 1) % NST
+            issue(ck + NST - 1, ring + nxt * STAGE);
         }
-        // nothing may sink below this point: the loads / LDS-DMA copies above must be in flight during the MFMA loop
         __builtin_amdgcn_sched_barrier(0);
-        const float* xb = xs + buf * XBUF + lh * plane;
-        const float* wb = wsm + buf * WBUF + lh * 9 * CO_WG + l31;
+        const float* xb = ring + cur * STAGE + lh * XCH;
+        const float* wb = ring + cur * STAGE + KC * XCH + lh * 9 * CO_WG + l31;
+        const float* sb = sty + ck * KC + lh;
         // software pipeline: the fragments of step s+1 are read from LDS right after the first MFMA of
-        // step s has issued, so their latency rides under the remaining MB*NBW-1 MFMAs (64 cycles each)
+        // step s has issued, so their latency rides under the remaining MB*NBW-1 MFMAs (64 cycles each).
+        // The style modulates the weight fragments on their way from LDS to the MFMA (networks.py:59-60).
         constexpr int STEPS = (KC / 2) * 9;
-        float af[2][MB], bfr[2][NBW];
-        auto fetch = [&](int step, float (&a)[MB], float (&bb)[NBW]) {
+        float af[2][MB], bfr[2][NBW], sv[2];
+        auto fetch = [&](int step, float (&a)[MB], float (&bb)[NBW], float& s) {
             const int kk = step / 9, tap = step - kk * 9;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) a[mb] = wb[(kk * 2 * 9 + tap) * CO_WG + mb * 32];
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) bb[nb] = xb[kk * 2 * plane + boff[nb] + ky * XS + kx];
+            for (int nb = 0; nb < NBW; ++nb) bb[nb] = xb[kk * 2 * XCH + boff[nb] + ky * XS + kx];
+            s = sb[kk * 2];
         };
-        fetch(0, af[0], bfr[0]);
+        fetch(0, af[0], bfr[0], sv[0]);
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
-            const int cur = step & 1;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bfr[cur][0], acc[0][0], 0, 0, 0);
-            if (step + 1 < STEPS) fetch(step + 1, af[cur ^ 1], bfr[cur ^ 1]);
+            const int cur_f = step & 1;
+            float a[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a[mb] = af[cur_f][mb] * sv[cur_f];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bfr[cur_f][0], acc[0][0], 0, 0, 0);
+            if (step + 1 < STEPS) fetch(step + 1, af[cur_f ^ 1], bfr[cur_f ^ 1], sv[cur_f ^ 1]);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb)
                     if (mb + nb > 0)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mb], bfr[cur][nb], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bfr[cur_f][nb], acc[mb][nb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (step + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, MB + NBW, 0);
+            if (step + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, MB + NBW + 1, 0);
             if (MB * NBW > 1) __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW - 1, 0);
         }
-        if (ck + 1 < nchunks) xst.store(xs + (buf ^ 1) * XBUF);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // chunk ck+1 must have landed: chunks ck+2 .. min(nchunks-1, ck+NST-1) may stay in flight
+            const int last = nchunks - 1 < ck + NST - 1 ? nchunks - 1 : ck + NST - 1;
+            const int younger = last - (ck + 1);
+#pragma unroll
+            for (int v = NST - 2; v >= 1; --v)
+                if (younger == v) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v * NPW) : "memory");
+            if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        cur = cur == NST - 1 ? 0 : cur + 1;
     }
 
     // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp; D[row = c_out, col = pixel] ----
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ok && co < p.c_out) {
+                if (ok && co < p.c_out && !(p.dbg & 1)) {
                     float v = acc[mb][nb][r] * dco[co] + nz;
                     v = nb_epilogue(v, p.bias[co], p.alpha, p.gain, p.clamp);
                     p.y[((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox] = v;
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
     __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int ck = 0; ck < nchunks; ++ck) {
-        if (ck + 2 < nchunks) {
+        if (ck + 2 < nchunks && !(p.dbg & 2)) {
             const int nxt = cur >= 1 ? cur - 1 : 2;       // (cur + 2) % 3
             issue(ck + 2, ring + nxt * STAGE);
         }
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
             out[1][0] = 0.25f * vo1[0] + 0.75f * ve1[0] + 0.75f * vo1[1] + 0.25f * ve1[1];
             out[1][1] = 0.25f * ve1[0] + 0.75f * vo1[1] + 0.75f * ve1[1] + 0.25f * vo1[2];
             const int qi = I0 + ti, qj = J0 + tj;
-            if (qi < H && qj < W && co < p.c_out) {
+            if (qi < H && qj < W && co < p.c_out && !(p.dbg & 1)) {
                 const float d = dco[co], bs = p.bias[co];
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
@@ -523,26 +538,26 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int NW, int MB, int NBW, int KC>
+template <int NW, int MB, int NBW, int KC, int NST>
 static int launch_up1(ModconvParams p, int n, hipStream_t st) {
     constexpr int PIX_WG = NW * NBW * 32;
-    constexpr int XPLANE_A = (PIX_WG / 32 + 2) * 40;
-    constexpr int XPLANE_MAX = XPLANE_A > 18 * 24 ? XPLANE_A : 18 * 24;
     const int TW = p.w < 32 ? p.w : 32;
     int l2 = 0; while ((1 << l2) < TW) ++l2;
     p.log2_tw = l2;
     int th = PIX_WG / TW; if (th > p.h) th = p.h;
     p.th = th;
-    if ((th + 2) * (TW + 8) > XPLANE_MAX) { nb_set_error("modconv up1: tile %dx%d does not fit the LDS plane", th, TW); return NB_EINVAL; }
+    if ((th + 2) * ((TW + 8) / 4) > nb_up1_ppc(PIX_WG) * 64) { nb_set_error("modconv up1: tile %dx%d does not fit the LDS plane", th, TW); return NB_EINVAL; }
     p.tiles_x = p.w / TW; p.tiles_y = nb_cdiv(p.h, th); p.slices = nb_cdiv(p.c_out, MB * 32);
-    const size_t lds = (size_t)(2 * KC * XPLANE_MAX + 2 * nb_wbuf_floats(KC, MB * 32)) * sizeof(float);
+    p.sty_floats = (p.c_in + 31) / 32 * 32;
+    const size_t lds = (size_t)(p.sty_floats + NST * nb_up1_stage_floats(PIX_WG, KC, MB * 32)) * sizeof(float);
+    if (lds > 160 * 1024) { nb_set_error("modconv up1: c_in=%d needs %zu bytes of LDS", p.c_in, lds); return NB_EINVAL; }
     static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_kernel<NW, MB, NBW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_kernel<NW, MB, NBW, KC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_kernel<NW, MB, NBW, KC>), grid, dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_kernel<NW, MB, NBW, KC, NST>), grid, dim3(NW * 64), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1");
     return NB_OK;
 }
@@ -598,16 +613,17 @@ extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c
     p.zeros = nb_zero_page();
     NB_REQUIRE(p.zeros, "modconv3x3: could not allocate the zero page");
     p.c1 = c1; p.c2 = c2; p.c_in = c1 + c2; p.c_out = c_out; p.c_out_ld = (c_out + 31) / 32 * 32; p.h = h; p.w = w;
-    p.log2_tw = 0; p.th = 0; p.tw = 0; p.tiles_x = p.tiles_y = p.slices = 1;
+    { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    p.sty_floats = 0; p.log2_tw = 0; p.th = 0; p.tw = 0; p.tiles_x = p.tiles_y = p.slices = 1;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     if (up == 1) {
         // pick the c_out slice / pixels per workgroup so that small layers still give >= ~2 workgroups per CU
         const long pixels = (long)n * h * w;
-        if (c_out > 64 && pixels >= 512L * 256) return launch_up1<8, 4, 1, 4>(p, n, st);
-        if (c_out > 32 && pixels >= 512L * 256) return launch_up1<8, 2, 2, 4>(p, n, st);
-        if (c_out > 32 && pixels >= 128L * 256) return launch_up1<4, 2, 2, 8>(p, n, st);
-        if (pixels >= 64L * 256) return launch_up1<4, 1, 2, 8>(p, n, st);
-        return launch_up1<4, 1, 1, 8>(p, n, st);
+        if (c_out > 64 && pixels >= 512L * 256) return launch_up1<8, 4, 1, 4, 3>(p, n, st);
+        if (c_out > 32 && pixels >= 512L * 256) return launch_up1<8, 2, 2, 4, 3>(p, n, st);
+        if (c_out > 32 && pixels >= 128L * 256) return launch_up1<4, 2, 2, 8, 4>(p, n, st);
+        if (pixels >= 64L * 256) return launch_up1<4, 1, 2, 8, 4>(p, n, st);
+        return launch_up1<4, 1, 1, 8, 4>(p, n, st);
     }
     const int tqw = w < 32 ? w : 32, tqh = h < 16 ? h : 16;
     p.th = tqh; p.tw = tqw; p.tiles_x = w / tqw; p.tiles_y = h / tqh;
