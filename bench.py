@@ -188,34 +188,49 @@ def main():
         elapsed = float(t.item())
 
     # per-launch durations from the HIP events recorded on the launch stream during the timed steps
+    import ctypes
+    from brushstroke_engine_amd import _lib
     per_layer = {}
     for name, e0, e1 in events:
         per_layer.setdefault(name, []).append(e0.elapsed_time(e1))
     specs = {s.name: s for s in cfg.layers}
-    rows = []
+    rows, kernels = [], {}
     for name, ts in per_layer.items():
+        if name not in specs:
+            continue
+        sp = specs[name]
         ms = float(np.mean(ts))
-        if name in specs:
-            fl = layer_flops(specs[name], B)
-            rows.append((ms, name, fl, kernel_label(specs[name])))
+        fl = layer_flops(sp, B)
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().nb_modconv3x3_variant(B, sp.in_res, sp.in_res, sp.out_channels, sp.up, buf, 128), "variant")
+        kname = buf.value.decode()
+        rows.append((ms, name, fl, kernel_label(sp), kname))
+        k = kernels.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        k["ms"] += ms; k["flops"] += fl; k["launches"] += 1
     rows.sort(reverse=True)
     conv_ms = sum(r[0] for r in rows)
     conv_fl = sum(r[2] for r in rows)
-    dom = rows[0]
-    achieved = dom[2] / (dom[0] * 1e-3) / 1e12
+    # dominant kernel = the kernel symbol (as rocprofv3 names it) with the largest share of the step; its average
+    # launch duration is over all of its launches in the timed steps, exactly what `rocprofv3 --stats` averages
+    dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
+    dom = kernels[dom_name]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom[3])
+            traffic = json.load(open(tpath)).get(dom_name)
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "kernel": dom[3], "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
+    roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
-                "launch_ms": round(dom[0], 4), "flops_per_launch": dom[2],
+                "launch_ms": round(dom["ms"] / dom["launches"], 4), "launches_per_step": dom["launches"],
+                "flops_per_launch": dom["flops"] / dom["launches"],
                 "all_conv_launches": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                       "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
                                       "ms_per_step": round(conv_ms, 4)},
+                "kernels": {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
+                                "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in kernels.items()},
                 "layers_ms": {r[3]: round(r[0], 4) for r in rows},
                 "other_ms": {k: round(float(np.mean(v)), 4) for k, v in per_layer.items() if k not in specs}}
 

@@ -82,10 +82,15 @@ __host__ __device__ constexpr int nb_up1_stage_floats(int pix_wg, int kc, int co
     return kc * nb_up1_ppc(pix_wg) * 256 + nb_wbuf_floats(kc, co_wg);
 }
 
-template <int NW, int MB, int NBW, int KC, int NST>
+// SK = split-K: all NW waves work on the SAME (MB x 32 c_out) x (NBW x 32 pixel) tile, wave w taking the k-pairs
+// kk = w (mod NW) of every chunk; the partial accumulators are summed through LDS before the epilogue.  This is for
+// the small layers / the batch-1 configuration, where the length of one wave's dependent MFMA chain (not the
+// chip's MFMA rate) bounds the launch.
+template <int NW, int MB, int NBW, int KC, int NST, bool SK>
 __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvParams p) {
     constexpr int CO_WG = MB * 32;
-    constexpr int PIX_WG = NW * NBW * 32;
+    constexpr int PIX_WG = (SK ? 1 : NW) * NBW * 32;
+    static_assert(!SK || (KC / 2) % NW == 0, "split-K needs a whole number of k-pairs per wave");
     constexpr int PPC = nb_up1_ppc(PIX_WG);
     constexpr int XCH = PPC * 256;                   // floats per channel of the halo tile (lanes 0-31 / 32-63 read k / k+1 in separate LDS passes)
     constexpr int NXP = KC * PPC;                    // activation pieces per chunk
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
     int boff[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-        const int q = (wv * NBW + nb) * 32 + l31;
+        const int q = ((SK ? 0 : wv) * NBW + nb) * 32 + l31;
         int ty = q >> p.log2_tw;
         const int tx = q & (TW - 1);
         ty = ty < th ? ty : th - 1;       // rows past the tile are computed on clamped data and never stored
@@ -202,10 +207,11 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
         // software pipeline: the fragments of step s+1 are read from LDS right after the first MFMA of
         // step s has issued, so their latency rides under the remaining MB*NBW-1 MFMAs (64 cycles each).
         // The style modulates the weight fragments on their way from LDS to the MFMA (networks.py:59-60).
-        constexpr int STEPS = (KC / 2) * 9;
+        constexpr int STEPS = (KC / 2) / (SK ? NW : 1) * 9;
         float af[2][MB], bfr[2][NBW], sv[2];
         auto fetch = [&](int step, float (&a)[MB], float (&bb)[NBW], float& s) {
-            const int kk = step / 9, tap = step - kk * 9;
+            const int kq = step / 9, tap = step - kq * 9;
+            const int kk = SK ? kq * NW + wv : kq;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) a[mb] = wb[(kk * 2 * 9 + tap) * CO_WG + mb * 32];
@@ -246,12 +252,36 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
         cur = cur == NST - 1 ? 0 : cur + 1;
     }
 
+    // ---- split-K: sum the NW partial accumulators through LDS; wave w then owns registers r with (r >> 2) == w ----
+    if constexpr (SK) {
+        static_assert(!SK || NW == 4, "split-K register ownership assumes 4 waves");
+        float* red = ring;                                   // [NW][MB*NBW*16][64]; the ring is idle now
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(wv * (MB * NBW * 16) + (mb * NBW + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; ++w2) sum += red[(w2 * (MB * NBW * 16) + (mb * NBW + nb) * 16 + r) * 64 + lane];
+                    acc[mb][nb][r] = sum;
+                }
+    }
+
     // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp; D[row = c_out, col = pixel] ----
     const int Wo = W, Ho = H;
     const float* dco = p.dcoefs + (size_t)n * p.c_out;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-        const int q = (wv * NBW + nb) * 32 + l31;
+        const int q = ((SK ? 0 : wv) * NBW + nb) * 32 + l31;
         const int ty = q >> p.log2_tw, tx = q & (TW - 1);
         const int oy = y0 + ty, ox = x0 + tx;
         const bool ok = ty < th && oy < Ho;
@@ -261,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                if (SK && (r >> 2) != wv) continue;          // split-K: each wave stores a quarter of the rows
                 const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (ok && co < p.c_out && !(p.dbg & 1)) {
                     float v = acc[mb][nb][r] * dco[co] + nz;
@@ -538,9 +569,9 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int NW, int MB, int NBW, int KC, int NST>
+template <int NW, int MB, int NBW, int KC, int NST, bool SK = false>
 static int launch_up1(ModconvParams p, int n, hipStream_t st) {
-    constexpr int PIX_WG = NW * NBW * 32;
+    constexpr int PIX_WG = (SK ? 1 : NW) * NBW * 32;
     const int TW = p.w < 32 ? p.w : 32;
     int l2 = 0; while ((1 << l2) < TW) ++l2;
     p.log2_tw = l2;
@@ -549,15 +580,17 @@ static int launch_up1(ModconvParams p, int n, hipStream_t st) {
     if ((th + 2) * ((TW + 8) / 4) > nb_up1_ppc(PIX_WG) * 64) { nb_set_error("modconv up1: tile %dx%d does not fit the LDS plane", th, TW); return NB_EINVAL; }
     p.tiles_x = p.w / TW; p.tiles_y = nb_cdiv(p.h, th); p.slices = nb_cdiv(p.c_out, MB * 32);
     p.sty_floats = (p.c_in + 31) / 32 * 32;
-    const size_t lds = (size_t)(p.sty_floats + NST * nb_up1_stage_floats(PIX_WG, KC, MB * 32)) * sizeof(float);
+    size_t ring_floats = (size_t)NST * nb_up1_stage_floats(PIX_WG, KC, MB * 32);
+    if (SK && ring_floats < (size_t)NW * MB * NBW * 16 * 64) ring_floats = (size_t)NW * MB * NBW * 16 * 64;
+    const size_t lds = (p.sty_floats + ring_floats) * sizeof(float);
     if (lds > 160 * 1024) { nb_set_error("modconv up1: c_in=%d needs %zu bytes of LDS", p.c_in, lds); return NB_EINVAL; }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_kernel<NW, MB, NBW, KC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_kernel<NW, MB, NBW, KC, NST, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_kernel<NW, MB, NBW, KC, NST>), grid, dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_kernel<NW, MB, NBW, KC, NST, SK>), grid, dim3(NW * 64), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1");
     return NB_OK;
 }
@@ -578,6 +611,49 @@ static int launch_up2(ModconvParams p, int n, hipStream_t st) {
     hipLaunchKernelGGL((modconv3x3_up2_kernel<NBP, KC>), grid, dim3(256), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up2");
     return NB_OK;
+}
+
+// Kernel variant selection.  Preference order = efficiency order; a less efficient (smaller-tile) variant is
+// taken when the preferred one would leave the chip under-filled (< ~1.5 workgroups per CU), which is what
+// matters for the small layers and for the batch-1 interactive configuration.
+static const char* const kVariantNames[] = {
+    "modconv3x3_up1_kernel<8, 4, 1, 4, 3, false>", "modconv3x3_up1_kernel<8, 2, 2, 4, 3, false>", "modconv3x3_up1_kernel<4, 2, 2, 8, 4, false>",
+    "modconv3x3_up1_kernel<4, 1, 2, 8, 4, false>", "modconv3x3_up1_kernel<4, 1, 1, 8, 4, false>",
+    "modconv3x3_up2_kernel<10, 4>", "modconv3x3_up2_kernel<6, 4>", "modconv3x3_up2_kernel<3, 8>",
+    "modconv3x3_up2_kernel<2, 8>", "modconv3x3_up2_kernel<1, 8>", "modconv3x3_up1_kernel<4, 1, 1, 8, 4, true>"};
+static const int kUp2Tiles[5][2] = {{16, 32}, {16, 16}, {8, 16}, {8, 8}, {4, 4}};      // quad rows x cols per workgroup
+
+static int nb_select_variant(int n, int h, int w, int c_out, int up, int* tq = nullptr) {
+    const long target = 384;
+    if (up == 1) {
+        static const int cand[6][2] = {{128, 256}, {64, 512}, {64, 256}, {32, 256}, {32, 128}, {32, 32}};   // c_out x pixels per workgroup (last: split-K)
+        const long hw = (long)h * w;
+        int best = 4; long best_wgs = -1;
+        for (int i = 0; i < 6; ++i) {
+            const int co_wg = cand[i][0], pix = cand[i][1];
+            if (i == 0 && c_out <= 64) continue;
+            if (i == 1 && (c_out <= 32 || c_out > 64)) continue;
+            if (i == 2 && c_out <= 32) continue;
+            const long wgs = (long)n * ((hw + pix - 1) / pix) * ((c_out + co_wg - 1) / co_wg);
+            if (wgs >= target) return i == 5 ? 10 : i;
+            if (wgs > best_wgs) { best_wgs = wgs; best = i == 5 ? 10 : i; }
+        }
+        return best;
+    }
+    int best = 9; long best_wgs = -1;
+    for (int i = 0; i < 5; ++i) {
+        const int tqh = kUp2Tiles[i][0] < h ? kUp2Tiles[i][0] : h, tqw = kUp2Tiles[i][1] < w ? kUp2Tiles[i][1] : w;
+        const int nbp = ((tqh + 2) * (tqw + 2) + 63) / 64;          // 16-position blocks per wave (4 waves)
+        const int v = nbp > 6 ? 5 : nbp > 3 ? 6 : nbp > 2 ? 7 : nbp > 1 ? 8 : 9;
+        const long wgs = (long)n * (h / tqh) * (w / tqw) * ((c_out + 15) / 16);
+        if (tq) { tq[0] = tqh; tq[1] = tqw; }
+        if (wgs >= target) return v;
+        if (wgs > best_wgs) { best_wgs = wgs; best = v; }
+    }
+    if (tq) {      // nothing reached the target: the last (smallest) candidate has the most workgroups
+        tq[0] = kUp2Tiles[4][0] < h ? kUp2Tiles[4][0] : h; tq[1] = kUp2Tiles[4][1] < w ? kUp2Tiles[4][1] : w;
+    }
+    return best;
 }
 
 // Lazily created per-device page of zeros (256 B): the LDS-DMA source for halo groups outside the image.
@@ -616,23 +692,33 @@ extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.sty_floats = 0; p.log2_tw = 0; p.th = 0; p.tw = 0; p.tiles_x = p.tiles_y = p.slices = 1;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
-    if (up == 1) {
-        // pick the c_out slice / pixels per workgroup so that small layers still give >= ~2 workgroups per CU
-        const long pixels = (long)n * h * w;
-        if (c_out > 64 && pixels >= 512L * 256) return launch_up1<8, 4, 1, 4, 3>(p, n, st);
-        if (c_out > 32 && pixels >= 512L * 256) return launch_up1<8, 2, 2, 4, 3>(p, n, st);
-        if (c_out > 32 && pixels >= 128L * 256) return launch_up1<4, 2, 2, 8, 4>(p, n, st);
-        if (pixels >= 64L * 256) return launch_up1<4, 1, 2, 8, 4>(p, n, st);
-        return launch_up1<4, 1, 1, 8, 4>(p, n, st);
+    int tq[2] = {0, 0};
+    const int v = nb_select_variant(n, h, w, c_out, up, tq);
+    switch (v) {
+        case 0: return launch_up1<8, 4, 1, 4, 3>(p, n, st);
+        case 1: return launch_up1<8, 2, 2, 4, 3>(p, n, st);
+        case 2: return launch_up1<4, 2, 2, 8, 4>(p, n, st);
+        case 3: return launch_up1<4, 1, 2, 8, 4>(p, n, st);
+        case 4: return launch_up1<4, 1, 1, 8, 4>(p, n, st);
+        case 10: return launch_up1<4, 1, 1, 8, 4, true>(p, n, st);
+        default: break;
     }
-    const int tqw = w < 32 ? w : 32, tqh = h < 16 ? h : 16;
-    p.th = tqh; p.tw = tqw; p.tiles_x = w / tqw; p.tiles_y = h / tqh;
-    const int nblk = nb_cdiv((tqh + 2) * (tqw + 2), 16);
-    const int nbp = nb_cdiv(nblk, 4);
-    if (nbp <= 1) return launch_up2<1, 8>(p, n, st);
-    if (nbp <= 2) return launch_up2<2, 8>(p, n, st);
-    if (nbp <= 6) return launch_up2<6, 4>(p, n, st);
-    return launch_up2<10, 4>(p, n, st);
+    p.th = tq[0]; p.tw = tq[1];
+    p.tiles_x = w / p.tw; p.tiles_y = h / p.th;
+    switch (v) {
+        case 5: return launch_up2<10, 4>(p, n, st);
+        case 6: return launch_up2<6, 4>(p, n, st);
+        case 7: return launch_up2<3, 8>(p, n, st);
+        case 8: return launch_up2<2, 8>(p, n, st);
+        default: return launch_up2<1, 8>(p, n, st);
+    }
+}
+
+extern "C" int nb_modconv3x3_variant(int n, int h, int w, int c_out, int up, char* buf, int buflen) {
+    NB_REQUIRE(buf && buflen > 0, "modconv3x3_variant: bad buffer");
+    NB_REQUIRE(n > 0 && h >= 4 && w >= 4 && c_out > 0 && (up == 1 || up == 2), "modconv3x3_variant: bad shape");
+    snprintf(buf, buflen, "%s", kVariantNames[nb_select_variant(n, h, w, c_out, up)]);
+    return NB_OK;
 }
 
 // Host-side repack: W[c_out,c_in,3,3] -> wpk[ceil8(c_in)][9][ceil32(c_out)] (zero padded), wsq[c_in][c_out] = sum_k W^2

@@ -130,6 +130,10 @@ int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c2, const fl
                       float* y, int n, int h, int w, int c_out, int up, float alpha, float gain, float clamp,
                       void* stream);
 
+/* Name of the kernel template instance nb_modconv3x3_f32 launches for this problem shape (the name
+ * rocprofv3 reports), so that a benchmark can attribute its per-launch timings to kernels. */
+int nb_modconv3x3_variant(int n, int h, int w, int c_out, int up, char* buf, int buflen);
+
 /* ToRGBColorTriadLayer.forward (networks.py:451-485) after its affine, on x [n,c,hw]:
  *   logits_o = clamp(sum_c x_c * styles[n,c] * w[o,c] + bias[o]);  uvs = softmax_o(logits)
  *   img[n,ch] = sum_k uvs_k * colors[n,ch,k]            (colors = tanh(affine[:, :9] + color_bias))

@@ -3,6 +3,10 @@ import sys
 
 import numpy as np
 import pytest
+import torch
+
+# the CPU oracle is slowest with one thread per logical CPU on big hosts (tools/cpu_threads_scan.py)
+torch.set_num_threads(min(16, torch.get_num_threads()))
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:

@@ -174,8 +174,10 @@ def test_linearity_and_determinism_full_size(dev):
     s = torch.sum(da["uvs"], dim=1)
     assert float((s - 1).abs().max()) <= 1e-5                     # softmax over u,v,s
     idx = [5, 17, 31]
+    # a sub-batch may run other kernel variants (tile shapes / split-K are chosen by problem size), i.e. another
+    # summation order: equal to fp32 rounding, not bitwise
     c = G(z[idx], None, [x[idx] for x in geom], positions=pos[idx], noise_mode="const")
-    assert torch.equal(c, a[idx])
+    assert err(c, a[idx]) <= 2e-5
 
 
 def test_graphed_batch1_matches_eager(dev):
