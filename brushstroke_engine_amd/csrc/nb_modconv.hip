@@ -39,6 +39,7 @@ struct ModconvParams {
     const float* noise;    // [n or 1][Hout][Wout] or null
     const float* bias;     // [c_out]
     float* y;              // [n][c_out][Hout][Wout]
+    const float* out_scale;// H2 output mode: [n][c_out] per-channel scale applied after the epilogue (the consumer's styles), or null
     const float* zeros;    // >= 16 bytes of zeros in device memory (LDS-DMA source for out-of-image halo groups)
     long long noise_stride_n;
     int c1, c2, c_in, c_out, c_out_ld;
@@ -326,7 +327,9 @@ __host__ __device__ constexpr int nb_up2_stage_floats(int nbp, int kc) { return 
 #define NB_UP2_STAGES 3
 #define NB_STY_MAX 1024
 
-template <int NBP, int KC>
+// H2OUT: write the output in the split-f16 "H2" activation format of nb_modconv_h3.hip ([N][C/8][hi,lo][H][W][8] f16,
+// multiplied by out_scale = the consuming layer's styles) instead of fp32 NCHW.
+template <int NBP, int KC, bool H2OUT>
 __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams p) {
     constexpr int NW = 4;
     constexpr int CO_WG = 16;
@@ -498,67 +501,128 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
         cur = cur == 2 ? 0 : cur + 1;
     }
 
-    // ---- epilogue: 4 rounds of 4 c_out (accumulator register g <-> c_out rows {g, 4+g, 8+g, 12+g}) ----
+    // ---- epilogue: 4 rounds of 4 c_out through LDS -> polyphase FIR -> bias/lrelu/clamp -> store ----
+    // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15 (position), row = 4*(lane>>4) + reg (c_out).
+    // fp32 NCHW output: round g publishes accumulator register g of every lane (c_out rows {g, 4+g, 8+g, 12+g}).
+    // H2 output:        round g publishes all 4 registers of lane group g (c_out rows 4g .. 4g+3, consecutive),
+    //                   so that one thread owns 4 consecutive channels of a pixel = one 8-byte f16x4 store.
     const int Wo = 2 * W, Ho = 2 * H;
     const float* dco = p.dcoefs + (size_t)n * p.c_out;
     const int nquads = TQH * TQW;
+    auto fir_quad = [&](const float* base, float (&out)[2][2]) {
+        const float* ee = base;
+        const float* eo = base + 1 * Y1_PHASE;
+        const float* oe = base + 2 * Y1_PHASE;
+        const float* oo = base + 3 * Y1_PHASE;
+        // vertical pass -> 2 output rows x (even cols c..c+1, odd cols c..c+2)
+        float ve0[2], ve1[2], vo0[3], vo1[3];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float e0 = ee[c], e1 = ee[PW + c];
+            const float o0 = oe[c], o1 = oe[PW + c], o2 = oe[2 * PW + c];
+            ve0[c] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
+            ve1[c] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e0 = eo[c], e1 = eo[PW + c];
+            const float o0 = oo[c], o1 = oo[PW + c], o2 = oo[2 * PW + c];
+            vo0[c] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
+            vo1[c] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
+        }
+        out[0][0] = 0.25f * vo0[0] + 0.75f * ve0[0] + 0.75f * vo0[1] + 0.25f * ve0[1];
+        out[0][1] = 0.25f * ve0[0] + 0.75f * vo0[1] + 0.75f * ve0[1] + 0.25f * vo0[2];
+        out[1][0] = 0.25f * vo1[0] + 0.75f * ve1[0] + 0.75f * vo1[1] + 0.25f * ve1[1];
+        out[1][1] = 0.25f * ve1[0] + 0.75f * vo1[1] + 0.75f * ve1[1] + 0.25f * vo1[2];
+    };
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15 (position), row = 4*(lane>>4) + reg (c_out)
+        if constexpr (H2OUT) {
+            if (lq == g) {
 #pragma unroll
-        for (int j = 0; j < NBP; ++j) {
-            const int pidx = (wv * NBP + j) * 16 + l15;
+                for (int j = 0; j < NBP; ++j) {
+                    const int pidx = (wv * NBP + j) * 16 + l15;
 #pragma unroll
-            for (int ph = 0; ph < 4; ++ph) {
-                y1s[lq * Y1_SLOT + ph * Y1_PHASE + pidx] = acc[j][ph][g];
+                    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y1s[r * Y1_SLOT + ph * Y1_PHASE + pidx] = acc[j][ph][r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBP; ++j) {
+                const int pidx = (wv * NBP + j) * 16 + l15;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) y1s[lq * Y1_SLOT + ph * Y1_PHASE + pidx] = acc[j][ph][g];
             }
         }
         __syncthreads();
-        // slot s <-> c_out row 4*s + g
-        for (int it = tid; it < 4 * nquads; it += 256) {
-            const int s = it / nquads, qd = it - s * nquads;
-            const int ti = qd / TQW, tj = qd - ti * TQW;
-            const int co = co0 + 4 * s + g;
-            const float* ee = y1s + s * Y1_SLOT + 0 * Y1_PHASE + ti * PW + tj;
-            const float* eo = y1s + s * Y1_SLOT + 1 * Y1_PHASE + ti * PW + tj;
-            const float* oe = y1s + s * Y1_SLOT + 2 * Y1_PHASE + ti * PW + tj;
-            const float* oo = y1s + s * Y1_SLOT + 3 * Y1_PHASE + ti * PW + tj;
-            // vertical pass -> 2 output rows x (even cols c..c+1, odd cols c..c+2)
-            float ve0[2], ve1[2], vo0[3], vo1[3];
+        if constexpr (H2OUT) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const int cb = co0 + 4 * g;                          // 4 consecutive channels cb .. cb+3
+            const int c8o = (p.c_out + 7) >> 3;
+            for (int qd = tid; qd < nquads; qd += 256) {
+                const int ti = qd / TQW, tj = qd - ti * TQW;
+                const int qi = I0 + ti, qj = J0 + tj;
+                float o[4][2][2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float e0 = ee[c], e1 = ee[PW + c];
-                const float o0 = oe[c], o1 = oe[PW + c], o2 = oe[2 * PW + c];
-                ve0[c] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
-                ve1[c] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
-            }
+                for (int s4 = 0; s4 < 4; ++s4) fir_quad(y1s + s4 * Y1_SLOT + ti * PW + tj, o[s4]);
+                if (qi < H && qj < W && cb < p.c_out && !(p.dbg & 1)) {
+                    float d4[4], b4[4], sc4[4];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float e0 = eo[c], e1 = eo[PW + c];
-                const float o0 = oo[c], o1 = oo[PW + c], o2 = oo[2 * PW + c];
-                vo0[c] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
-                vo1[c] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
-            }
-            float out[2][2];
-            out[0][0] = 0.25f * vo0[0] + 0.75f * ve0[0] + 0.75f * vo0[1] + 0.25f * ve0[1];
-            out[0][1] = 0.25f * ve0[0] + 0.75f * vo0[1] + 0.75f * ve0[1] + 0.25f * vo0[2];
-            out[1][0] = 0.25f * vo1[0] + 0.75f * ve1[0] + 0.75f * vo1[1] + 0.25f * ve1[1];
-            out[1][1] = 0.25f * ve1[0] + 0.75f * vo1[1] + 0.75f * ve1[1] + 0.25f * vo1[2];
-            const int qi = I0 + ti, qj = J0 + tj;
-            if (qi < H && qj < W && co < p.c_out && !(p.dbg & 1)) {
-                const float d = dco[co], bs = p.bias[co];
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int oy = 2 * qi + dy, ox = 2 * qj;
-                    float n0 = 0.f, n1 = 0.f;
-                    if (p.noise) {
-                        const float* np_ = p.noise + (size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox;
-                        n0 = np_[0]; n1 = np_[1];
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int co = cb + s4;
+                        const bool v = co < p.c_out;
+                        d4[s4] = v ? dco[co] : 0.f;
+                        b4[s4] = v ? p.bias[co] : 0.f;
+                        sc4[s4] = v ? (p.out_scale ? p.out_scale[(size_t)n * p.c_out + co] : 1.f) : 0.f;
                     }
-                    float2 o;
-                    o.x = nb_epilogue(out[dy][0] * d + n0, bs, p.alpha, p.gain, p.clamp);
-                    o.y = nb_epilogue(out[dy][1] * d + n1, bs, p.alpha, p.gain, p.clamp);
-                    *reinterpret_cast<float2*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = o;
+                    _Float16* ob = reinterpret_cast<_Float16*>(p.y) + (((size_t)n * c8o + (cb >> 3)) * 2) * ((size_t)Ho * Wo * 8) + (cb & 7);
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int oy = 2 * qi + dy, ox = 2 * qj + dx;
+                            float nz = 0.f;
+                            if (p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox];
+                            h4 hi, lo;
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                const float v = nb_epilogue(o[s4][dy][dx] * d4[s4] + nz, b4[s4], p.alpha, p.gain, p.clamp) * sc4[s4];
+                                const _Float16 hh = (_Float16)v;
+                                hi[s4] = hh;
+                                lo[s4] = (_Float16)(v - (float)hh);
+                            }
+                            _Float16* op = ob + ((size_t)oy * Wo + ox) * 8;
+                            *reinterpret_cast<h4*>(op) = hi;
+                            *reinterpret_cast<h4*>(op + (size_t)Ho * Wo * 8) = lo;
+                        }
+                }
+            }
+        } else {
+            // slot s <-> c_out row 4*s + g
+            for (int it = tid; it < 4 * nquads; it += 256) {
+                const int s = it / nquads, qd = it - s * nquads;
+                const int ti = qd / TQW, tj = qd - ti * TQW;
+                const int co = co0 + 4 * s + g;
+                float out[2][2];
+                fir_quad(y1s + s * Y1_SLOT + ti * PW + tj, out);
+                const int qi = I0 + ti, qj = J0 + tj;
+                if (qi < H && qj < W && co < p.c_out && !(p.dbg & 1)) {
+                    const float d = dco[co], bs = p.bias[co];
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int oy = 2 * qi + dy, ox = 2 * qj;
+                        float n0 = 0.f, n1 = 0.f;
+                        if (p.noise) {
+                            const float* np_ = p.noise + (size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox;
+                            n0 = np_[0]; n1 = np_[1];
+                        }
+                        float2 o;
+                        o.x = nb_epilogue(out[dy][0] * d + n0, bs, p.alpha, p.gain, p.clamp);
+                        o.y = nb_epilogue(out[dy][1] * d + n1, bs, p.alpha, p.gain, p.clamp);
+                        *reinterpret_cast<float2*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = o;
+                    }
                 }
             }
         }
@@ -595,7 +659,7 @@ static int launch_up1(ModconvParams p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int NBP, int KC>
+template <int NBP, int KC, bool H2OUT = false>
 static int launch_up2(ModconvParams p, int n, hipStream_t st) {
     p.slices = nb_cdiv(p.c_out, 16);
     if (p.c_in > NB_STY_MAX) { nb_set_error("modconv up2: c_in=%d exceeds %d", p.c_in, NB_STY_MAX); return NB_EINVAL; }
@@ -604,11 +668,11 @@ static int launch_up2(ModconvParams p, int n, hipStream_t st) {
     const size_t lds = NB_STY_MAX * sizeof(float) + (lds_main > lds_epi ? lds_main : lds_epi);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_kernel<NBP, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_kernel<NBP, KC, H2OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up2_kernel<NBP, KC>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up2_kernel<NBP, KC, H2OUT>), grid, dim3(256), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up2");
     return NB_OK;
 }
@@ -658,7 +722,7 @@ static int nb_select_variant(int n, int h, int w, int c_out, int up, int* tq = n
 
 // Lazily created per-device page of zeros (256 B): the LDS-DMA source for halo groups outside the image.
 // Created on the first call for a device (outside any stream capture: run one warm-up call before capturing).
-static const float* nb_zero_page() {
+extern "C" const float* nb_zero_page_ptr(void) {
     static float* pages[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -671,10 +735,11 @@ static const float* nb_zero_page() {
     return pages[dev];
 }
 
-extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c2, const float* wpk,
-                                 const float* styles, const float* dcoefs, const float* noise,
-                                 int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w,
-                                 int c_out, int up, float alpha, float gain, float clamp, void* stream) {
+static int nb_modconv3x3_impl(const float* x1, int c1, const float* x2, int c2, const float* wpk,
+                             const float* styles, const float* dcoefs, const float* noise,
+                             int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w,
+                             int c_out, int up, float alpha, float gain, float clamp, void* stream,
+                             bool h2out, const float* out_scale) {
     NB_REQUIRE(x1 && wpk && styles && dcoefs && bias && y, "modconv3x3: null pointer");
     NB_REQUIRE(c1 > 0 && c2 >= 0 && (c2 == 0 || x2), "modconv3x3: bad channel split c1=%d c2=%d", c1, c2);
     NB_REQUIRE(n > 0 && n <= 65535, "modconv3x3: batch %d out of range", n);
@@ -686,7 +751,8 @@ extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c
     ModconvParams p;
     p.x1 = x1; p.x2 = x2; p.wpk = wpk; p.styles = styles; p.dcoefs = dcoefs; p.noise = noise; p.bias = bias; p.y = y;
     p.noise_stride_n = noise_stride_n;
-    p.zeros = nb_zero_page();
+    p.out_scale = out_scale;
+    p.zeros = nb_zero_page_ptr();
     NB_REQUIRE(p.zeros, "modconv3x3: could not allocate the zero page");
     p.c1 = c1; p.c2 = c2; p.c_in = c1 + c2; p.c_out = c_out; p.c_out_ld = (c_out + 31) / 32 * 32; p.h = h; p.w = w;
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
@@ -705,6 +771,15 @@ extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c
     }
     p.th = tq[0]; p.tw = tq[1];
     p.tiles_x = w / p.tw; p.tiles_y = h / p.th;
+    if (h2out) {
+        switch (v) {
+            case 5: return launch_up2<10, 4, true>(p, n, st);
+            case 6: return launch_up2<6, 4, true>(p, n, st);
+            case 7: return launch_up2<3, 8, true>(p, n, st);
+            case 8: return launch_up2<2, 8, true>(p, n, st);
+            default: return launch_up2<1, 8, true>(p, n, st);
+        }
+    }
     switch (v) {
         case 5: return launch_up2<10, 4>(p, n, st);
         case 6: return launch_up2<6, 4>(p, n, st);
@@ -712,6 +787,23 @@ extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c
         case 8: return launch_up2<2, 8>(p, n, st);
         default: return launch_up2<1, 8>(p, n, st);
     }
+}
+
+extern "C" int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c2, const float* wpk,
+                                 const float* styles, const float* dcoefs, const float* noise,
+                                 int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w,
+                                 int c_out, int up, float alpha, float gain, float clamp, void* stream) {
+    return nb_modconv3x3_impl(x1, c1, x2, c2, wpk, styles, dcoefs, noise, noise_stride_n, bias, y, n, h, w, c_out, up,
+                              alpha, gain, clamp, stream, false, nullptr);
+}
+
+extern "C" int nb_modconv3x3_up2_f32_h2(const float* x1, int c1, const float* x2, int c2, const float* wpk,
+                                        const float* styles, const float* dcoefs, const float* noise,
+                                        int64_t noise_stride_n, const float* bias, const float* out_scale, void* y_h2,
+                                        int n, int h, int w, int c_out, float alpha, float gain, float clamp,
+                                        void* stream) {
+    return nb_modconv3x3_impl(x1, c1, x2, c2, wpk, styles, dcoefs, noise, noise_stride_n, bias, (float*)y_h2, n, h, w,
+                              c_out, 2, alpha, gain, clamp, stream, true, out_scale);
 }
 
 extern "C" int nb_modconv3x3_variant(int n, int h, int w, int c_out, int up, char* buf, int buflen) {

@@ -1,0 +1,315 @@
+// Split-f16 ("h3") modulated 3x3 convolution, up = 1, for gfx950: fp32-accurate products on the f16 matrix
+// cores at ~5x the fp32-MFMA rate.
+//
+// Every fp32 operand v is carried as two halves  v = hi + lo,  hi = f16(v), lo = f16(v - hi)  (22 significant
+// bits); a product is evaluated as  x*w ~= xh*wh + xl*wh + xh*wl  with three v_mfma_f32_32x32x16_f16 (products
+// of two f16 are exact in fp32, accumulation is fp32); the dropped xl*wl term is 2^-22 relative.  End to end
+// (14 stacked layers, R=128) this differs from the all-fp32 evaluation by 5e-6 on pixels, against 3e-3 for a
+// plain single-f16 evaluation (tools/split_precision_check.py) -- far inside the 1e-3 parity budget.
+//
+// The style modulation is applied by the PRODUCER of the activation tensor (x * s[n,c] is what gets split and
+// stored), so the weights are static and pre-split once at load time; the demodulation d[n,o] stays in the
+// fp32 epilogue.  Reference arithmetic: training/networks.py:67-76 (non-fused form of modulated_conv2d).
+//
+// Activation format "H2":  _Float16 [N][C/8][2 (hi, lo)][H][W][8]   -- 8 channels of one pixel = 16 bytes =
+// one lane's MFMA fragment (k = 8 consecutive channels), so halo-tile rows are contiguous 16-byte slots in HBM
+// and LDS and every staging transfer is a global_load_lds_dwordx4 (no VGPRs, no alignment games).
+// Weight format:  _Float16 [C_in/16][ky 3][kx 3][cg 2][hi/lo 2][C_out_ld][8].
+//
+// Workgroup = 8 waves as MW (c_out) x 8/MW (pixels), wave tile 64 c_out x 64 pixels (2x2 MFMA tiles, 64
+// accumulator registers), i.e. 128 x 256 (MW=2) or 64 x 512 (MW=1) per workgroup; pixel blocks are image rows
+// of 32.  K loop: 16-channel chunks x 3 tap rows; the weights of one (chunk, tap row) form a 4-deep LDS ring,
+// the activation halo tile of a chunk is double buffered; counted vmcnt + raw s_barrier keep 2 sub-chunks of
+// LDS-DMA in flight behind the MFMAs.
+#include "nb_common.h"
+#include <cstdlib>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define NB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct H3Params {
+    const _Float16* x;      // H2 [n][c8][2][H][W][8], already multiplied by this layer's styles
+    const _Float16* wts;    // [nchunks][3][3][2][2][co_ld][8]
+    const float* dcoefs;    // [n][c_out]
+    const float* noise;     // [n or 1][H][W] or null
+    const float* bias;      // [c_out]
+    float* y;               // fp32 NCHW [n][c_out][H][W] or null
+    const float* zeros;
+    long long noise_stride_n;
+    int c8, nchunks, c_out, co_ld, h, w;
+    int tiles_x, tiles_y, slices, dbg;
+    float alpha, gain, clamp;
+};
+
+__device__ __forceinline__ float nb_h3_epilogue(float v, float bias, float alpha, float gain, float clamp) {
+    v += bias;
+    v = v < 0.f ? v * alpha : v;
+    v *= gain;
+    if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
+    return v;
+}
+
+template <int MW>
+__global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
+    constexpr int NW = 8, NWN = NW / MW;          // waves along pixels
+    constexpr int MB = 2, NBW = 2;                // 32x32 MFMA tiles per wave: 64 c_out x 64 pixels
+    constexpr int CO_WG = MW * 64, TH = NWN * NBW, TWP = 34;     // tile rows (32 pixels each), halo tile width
+    constexpr int SLOTS = (TH + 2) * TWP;         // 16-byte slots of one (cgroup, hi/lo) plane of the halo tile
+    constexpr int PP = (SLOTS + 63) / 64;         // 1-KiB DMA pieces per plane
+    constexpr int XPL = PP * 64;                  // slots reserved per plane
+    constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;      // activation pieces per chunk / per wave
+    constexpr int WSLOTS = 12 * CO_WG;            // slots of one (chunk, tap row) weight sub-chunk: [kx][cg][hl][c_out]
+    constexpr int NWP = WSLOTS / 64, NWPW = (NWP + NW - 1) / NW;
+    constexpr int WST = 4;                        // weight ring depth
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
+    h8* xbuf = reinterpret_cast<h8*>(smem_h3);                    // [2][4 planes][XPL]
+    h8* wring = xbuf + 2 * 4 * XPL;                               // [WST][WSLOTS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
+    const int wm = wv / NWN, wn = wv - wm * NWN;  // wave coordinates (c_out, pixel rows)
+    const int H = p.h, W = p.w;
+    int b = blockIdx.x;
+    const int slice = b % p.slices; b /= p.slices;
+    const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
+    const int n = blockIdx.y;
+    const int y0 = tile_y * TH, x0 = tile_x * 32;
+    const int co0 = slice * CO_WG;
+    const size_t HW8 = (size_t)H * W * 8;
+    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+
+    // ---- DMA descriptors of this wave's activation pieces ----
+    int xsp[NXPW], xpl[NXPW], xdst[NXPW];
+#pragma unroll
+    for (int i = 0; i < NXPW; ++i) {
+        int q = i * NW + wv;
+        q = q < NXP ? q : NXP - 1;
+        const int pl = q / PP, part = q - pl * PP;      // pl = cg_local*2 + hi/lo
+        const int e = part * 64 + lane;
+        xpl[i] = pl;
+        xdst[i] = pl * XPL + part * 64;
+        xsp[i] = -1;
+        if (e < SLOTS) {
+            const int r = e / TWP, c = e - r * TWP;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xsp[i] = (gy * W + gx) * 8;
+        }
+    }
+    auto issue_x = [&](int c, h8* dst) {
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            const int cg = 2 * c + (xpl[i] >> 1);
+            const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
+            if (xsp[i] >= 0 && cg < p.c8) src = xn + (size_t)(4 * c + xpl[i]) * HW8 + xsp[i];
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(dst + xdst[i]), 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int t, h8* dst) {          // t = chunk*3 + ky
+#pragma unroll
+        for (int i = 0; i < NWPW; ++i) {
+            int q = i * NW + wv;
+            q = q < NWP ? q : NWP - 1;
+            const int e = q * 64 + lane;
+            const int row = e / CO_WG, j = e - row * CO_WG;     // row = kx*4 + cg*2 + hl
+            const _Float16* src = p.wts + (((size_t)t * 12 + row) * p.co_ld + co0 + j) * 8;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(dst + q * 64), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    const int NC = p.nchunks, T = NC * 3;
+    auto clampt = [&](int t) { return t < T ? t : T - 1; };
+    // prologue: chunk 0's halo tile and the first three weight sub-chunks
+    issue_x(0, xbuf);
+    issue_w(0, wring);
+    issue_w(clampt(1), wring + WSLOTS);
+    issue_w(clampt(2), wring + 2 * WSLOTS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses (in 16-byte slots)
+    const int a_base = lh * 2 * CO_WG + wm * 64 + l31;           // + kx*4*CO_WG + hl*CO_WG + mb*32
+    const int b_base = lh * 2 * XPL + (wn * NBW) * TWP + l31;    // + hl*XPL + (nb + ky)*TWP + kx
+
+    for (int c = 0; c < NC; ++c) {
+        const h8* xb = xbuf + (c & 1) * 4 * XPL;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int t = c * 3 + ky;
+            // keep the LDS-DMA stream 3 sub-chunks ahead (past the end: harmless re-copies keep the counts uniform)
+            if (!(p.dbg & 2)) {
+                issue_w(clampt(t + 3), wring + ((t + 3) & 3) * WSLOTS);
+                if (ky == 0) issue_x(c + 1 < NC ? c + 1 : NC - 1, xbuf + ((c + 1) & 1) * 4 * XPL);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const h8* wb = wring + (t & 3) * WSLOTS;
+            h8 ah[2][MB], al[2][MB], bh[2][NBW], bl[2][NBW];
+            auto fetch = [&](int kx, h8 (&fah)[MB], h8 (&fal)[MB], h8 (&fbh)[NBW], h8 (&fbl)[NBW]) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    fah[mb] = wb[a_base + kx * 4 * CO_WG + mb * 32];
+                    fal[mb] = wb[a_base + kx * 4 * CO_WG + CO_WG + mb * 32];
+                }
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    fbh[nb] = xb[b_base + (nb + ky) * TWP + kx];
+                    fbl[nb] = xb[b_base + XPL + (nb + ky) * TWP + kx];
+                }
+            };
+            fetch(0, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int cu = kx & 1;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][0], bh[cu][0], acc[0][0], 0, 0, 0);
+                if (kx + 1 < 3) fetch(kx + 1, ah[cu ^ 1], al[cu ^ 1], bh[cu ^ 1], bl[cu ^ 1]);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) {
+                        if (mb + nb > 0)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][mb], bh[cu][nb], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][mb], bl[cu][nb], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cu][mb], bh[cu][nb], acc[mb][nb], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kx + 1 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB + 2 * NBW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MB * NBW - 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // everything issued before sub-chunk t-1 must have landed (it is what sub-chunk t+1 reads)
+            if (ky == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW + NXPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail re-copies before the LDS is released
+
+    // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp -> fp32 NCHW; D[row = c_out, col = pixel] ----
+    const float* dco = p.dcoefs + (size_t)n * p.c_out;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int oy = y0 + wn * NBW + nb, ox = x0 + l31;
+        float nz = 0.f;
+        if (p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * W + ox];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.c_out && !(p.dbg & 1)) {
+                    float v = acc[mb][nb][r] * dco[co] + nz;
+                    v = nb_h3_epilogue(v, p.bias[co], p.alpha, p.gain, p.clamp);
+                    p.y[((size_t)n * p.c_out + co) * ((size_t)H * W) + (size_t)oy * W + ox] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MW>
+static int launch_h3(H3Params p, int n, hipStream_t st) {
+    constexpr int NWN = 8 / MW, TH = NWN * 2, CO_WG = MW * 64;
+    constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
+    const size_t lds = (size_t)(2 * 4 * XPL + 4 * 12 * CO_WG) * 16;
+    p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW>), grid, dim3(512), lds, st, p);
+    NB_CHECK_LAUNCH("modconv3x3_up1_h3");
+    return NB_OK;
+}
+
+extern "C" const float* nb_zero_page_ptr(void);
+
+extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                                    int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                                    float alpha, float gain, float clamp, void* stream) {
+    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && y, "modconv3x3_up1_h3: null pointer");
+    NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up1_h3: bad sizes");
+    NB_REQUIRE(w % 32 == 0 && h % 16 == 0, "modconv3x3_up1_h3: needs w %% 32 == 0 and h %% 16 == 0 (got %dx%d)", h, w);
+    NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up1_h3: pointers must be 16-byte aligned");
+    H3Params p;
+    p.x = (const _Float16*)x_h2; p.wts = (const _Float16*)w_h3; p.dcoefs = dcoefs; p.noise = noise; p.bias = bias; p.y = y;
+    p.zeros = nb_zero_page_ptr();
+    NB_REQUIRE(p.zeros, "modconv3x3_up1_h3: could not allocate the zero page");
+    p.noise_stride_n = noise_stride_n;
+    p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
+    { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    if (c_out > 64) return launch_h3<2>(p, n, (hipStream_t)stream);
+    return launch_h3<1>(p, n, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 NCHW -> H2 packing (optionally x two concatenated inputs, x per-(n,c) scale = the consumer's styles)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_h2_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,
+                                                      const float* __restrict__ scale, _Float16* __restrict__ out, int c8, int hw) {
+    const int n = blockIdx.z, cg = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const int c_in = c1 + c2;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cg * 8 + j;
+        float v = 0.f;
+        if (ch < c_in) {
+            v = ch < c1 ? x1[((size_t)n * c1 + ch) * hw + pix] : x2[((size_t)n * c2 + (ch - c1)) * hw + pix];
+            if (scale) v *= scale[(size_t)n * c_in + ch];
+        }
+        const _Float16 hh = (_Float16)v;
+        hi[j] = hh;
+        lo[j] = (_Float16)(v - (float)hh);
+    }
+    h8* o = reinterpret_cast<h8*>(out) + ((size_t)(n * c8 + cg) * 2) * hw + pix;
+    o[0] = hi;
+    o[hw] = lo;
+}
+
+extern "C" int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out_h2, int n,
+                              int hw, void* stream) {
+    NB_REQUIRE(x1 && out_h2 && c1 > 0 && c2 >= 0 && (c2 == 0 || x2) && n > 0 && n <= 65535 && hw > 0, "pack_h2: bad arguments");
+    const int c8 = (c1 + c2 + 7) / 8;
+    dim3 grid((hw + 255) / 256, c8, n);
+    hipLaunchKernelGGL(pack_h2_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, c1, x2, c2, scale, (_Float16*)out_h2, c8, hw);
+    NB_CHECK_LAUNCH("pack_h2");
+    return NB_OK;
+}
+
+// Host-side weight packing: W[c_out][c_in][3][3] fp32 -> hi/lo f16 [ceil16(c_in)/16][3][3][2][2][ceil64(c_out)][8]
+extern "C" int nb_pack_conv_weight_h3(const float* w, int c_out, int c_in, void* out) {
+    NB_REQUIRE(w && out && c_out > 0 && c_in > 0, "pack_conv_weight_h3: bad arguments");
+    const int nch = (c_in + 15) / 16, co_ld = (c_out + 63) / 64 * 64;
+    _Float16* o = (_Float16*)out;
+    const size_t total = (size_t)nch * 9 * 4 * co_ld * 8;
+    for (size_t i = 0; i < total; ++i) o[i] = (_Float16)0.f;
+    for (int co = 0; co < c_out; ++co)
+        for (int ci = 0; ci < c_in; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const float v = w[((size_t)co * c_in + ci) * 9 + t];
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const int ch = ci / 16, cg = (ci % 16) / 8, j = ci % 8;
+                const size_t base = ((((size_t)ch * 9 + t) * 2 + cg) * 2) * co_ld;
+                o[(base + co) * 8 + j] = hi;
+                o[(base + co_ld + co) * 8 + j] = lo;
+            }
+    return NB_OK;
+}

@@ -238,6 +238,11 @@ class SynthesisNetwork(torch.nn.Module):
             setattr(self, f"b{res}", SynthesisBlock(cfg, res, layers))
         self.packed: Dict[str, Dict[str, torch.Tensor]] = {}
         self._plan: Optional[_Plan] = None
+        # "h3": large conv1 layers on the f16 matrix cores as hi/lo split products (fp32-grade, ~5x the fp32 MFMA
+        # rate); "f32": every layer on the exact-fp32 MFMA kernels.
+        self.conv_mode = "h3"
+        self.h2_fused_epilogue = False    # True: the up=2 kernel writes H2 itself (slower epilogue at present)
+        self.layer_kernels: Dict[str, str] = {}
 
     # -- helpers --
     def get_last_block(self):
@@ -264,8 +269,21 @@ class SynthesisNetwork(torch.nn.Module):
             wpk, wsq = ops.pack_conv_weight(layer.weight)
             self.packed[s.name] = {"wpk": wpk, "wsq": wsq,
                                    "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous()}
+            if self._h3_eligible(s):
+                self.packed[s.name]["w_h3"] = ops.pack_conv_weight_h3(layer.weight)
         t = self.get_last_block().torgb
         self.packed["torgb"] = {"w": t.weight.reshape(3, -1).contiguous()}
+
+    def _h3_eligible(self, s: LayerSpec) -> bool:
+        """conv1 layers that run as 3-pass split-f16 MFMA (csrc/nb_modconv_h3.hip): the kernel needs rows of 32
+        pixels and 16-row tiles, and a conv_clamp so that activations are bounded inside the f16 range."""
+        return (self.conv_mode == "h3" and s.up == 1 and s.block_res >= 32 and s.block_res % 32 == 0
+                and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
+
+    def _variant_name(self, n: int, s: LayerSpec) -> str:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().nb_modconv3x3_variant(n, s.in_res, s.in_res, s.out_channels, s.up, buf, 128), "variant")
+        return buf.value.decode()
 
     def _get_plan(self, n: int, device) -> _Plan:
         self._ensure_packed()
@@ -343,6 +361,7 @@ class SynthesisNetwork(torch.nn.Module):
             debug_data = {}
             x = img = None
             x2 = None
+            x_h2 = None
             geo_idx = 0
             specs = {s.name: (i, s) for i, s in enumerate(cfg.layers)}
             for res in self.block_resolutions:
@@ -356,7 +375,7 @@ class SynthesisNetwork(torch.nn.Module):
                     i, s = specs[name]
                     layer = self.layer_module(s)
                     pk = self.packed[name]
-                    c1 = x.shape[1]
+                    c1 = s.in_channels if x is None else x.shape[1]
                     c2 = 0 if x2 is None else x2.shape[1]
                     if c1 + c2 != s.in_channels:
                         raise AssertionError(f"{name}: got {c1}+{c2} input channels, expected {s.in_channels}")
@@ -368,14 +387,46 @@ class SynthesisNetwork(torch.nn.Module):
                         rnd = torch.randn([n, s.block_res, s.block_res], device=device) * layer.noise_strength
                         keep_alive.append(rnd)
                         noise_ptr, nstride = rnd.data_ptr(), s.block_res * s.block_res
-                    y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
                     clamp = -1.0 if layer.conv_clamp is None else float(layer.conv_clamp)
                     ev = self._begin_event(name)
-                    _lib.check(lib.nb_modconv3x3_f32(
-                        _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
-                        nstride, _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, s.up, 0.2,
-                        layer.act_gain, clamp, stream), name)
+                    if s.up == 1 and x_h2 is not None:
+                        # conv1 on the f16 matrix cores: input arrives pre-modulated in H2 format from conv0
+                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                        _lib.check(lib.nb_modconv3x3_up1_h3(
+                            _p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                            _p(layer.bias), _p(y), n, s.block_res, s.block_res, s.out_channels, 0.2, layer.act_gain,
+                            clamp, stream), name)
+                        self.layer_kernels[name] = "modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
+                        keep_alive.append(x_h2)
+                        x_h2 = None
+                    elif s.up == 2 and self.h2_fused_epilogue and self._h3_eligible(specs[f"synthesis.b{res}.conv1"][1]):
+                        # conv0 writes its output directly in H2 format, multiplied by conv1's styles
+                        i1 = specs[f"synthesis.b{res}.conv1"][0]
+                        x_h2 = torch.empty(ops.h2_shape(n, s.out_channels, s.block_res, s.block_res), dtype=torch.float16,
+                                           device=device)
+                        _lib.check(lib.nb_modconv3x3_up2_f32_h2(
+                            _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
+                            nstride, _p(layer.bias), _p(plan.styles[i1]), _p(x_h2), n, s.in_res, s.in_res,
+                            s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
+                        self.layer_kernels[name] = self._variant_name(n, s) + " [H2 out]"
+                        y = None
+                    else:
+                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                        _lib.check(lib.nb_modconv3x3_f32(
+                            _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
+                            nstride, _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, s.up, 0.2,
+                            layer.act_gain, clamp, stream), name)
+                        self.layer_kernels[name] = self._variant_name(n, s)
                     self._end_event(ev)
+                    if s.up == 2 and y is not None and self._h3_eligible(specs[f"synthesis.b{res}.conv1"][1]):
+                        # hand conv1 its input in H2 format: fp32 NCHW * conv1's styles -> hi/lo f16, channel-blocked
+                        i1 = specs[f"synthesis.b{res}.conv1"][0]
+                        ev = self._begin_event("pack_h2")
+                        x_h2 = torch.empty(ops.h2_shape(n, s.out_channels, s.block_res, s.block_res), dtype=torch.float16,
+                                           device=device)
+                        _lib.check(lib.nb_pack_h2_f32(_p(y), s.out_channels, None, 0, _p(plan.styles[i1]), _p(x_h2), n,
+                                                      s.block_res * s.block_res, stream), "pack_h2")
+                        self._end_event(ev)
                     keep_alive += [x, x2]
                     x, x2 = y, None
 
@@ -446,8 +497,11 @@ class SynthesisNetwork(torch.nn.Module):
 class Generator(torch.nn.Module):
     """``networks_modified.py:227-400``."""
 
-    def __init__(self, cfg: GeneratorConfig = None, state_dict: Optional[StateDict] = None, **kwargs):
+    def __init__(self, cfg: GeneratorConfig = None, state_dict: Optional[StateDict] = None, conv_mode: str = "h3",
+                 **kwargs):
         super().__init__()
+        if conv_mode not in ("h3", "f32"):
+            raise RuntimeError(f"unknown conv_mode {conv_mode!r}")
         if cfg is None:
             cfg = GeneratorConfig(**kwargs)
         self.cfg = cfg
@@ -455,6 +509,7 @@ class Generator(torch.nn.Module):
         self.img_resolution, self.img_channels = cfg.img_resolution, cfg.img_channels
         self.positional_encoder = None
         self.synthesis = SynthesisNetwork(cfg)
+        self.synthesis.conv_mode = conv_mode
         self.num_ws = self.synthesis.num_ws
         self.mapping = MappingNetwork(cfg)
         self.geom_inject = True
@@ -462,6 +517,14 @@ class Generator(torch.nn.Module):
         if state_dict is not None:
             self.load_numpy_state_dict(state_dict)
         self.eval().requires_grad_(False)
+
+    def set_conv_mode(self, conv_mode: str):
+        """'h3' (default): large conv1 layers as split-f16 MFMA; 'f32': all layers on the exact-fp32 MFMA kernels."""
+        if conv_mode not in ("h3", "f32"):
+            raise RuntimeError(f"unknown conv_mode {conv_mode!r}")
+        self.synthesis.conv_mode = conv_mode
+        self._invalidate()
+        return self
 
     def _invalidate(self):
         self.synthesis.invalidate()

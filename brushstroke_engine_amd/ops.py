@@ -197,3 +197,62 @@ def blend(features, alpha, x):
         _lib.check(_lib.lib().nb_blend_f32(_p(features.contiguous()), features.shape[0], _p(alpha.contiguous()), na,
                                            _p(x), _p(y), n, c, h * w, _stream(x)), "blend")
     return y
+
+
+# ----------------------------------------------------------------------------------------------
+# split-f16 ("h3") fast path (csrc/nb_modconv_h3.hip)
+# ----------------------------------------------------------------------------------------------
+
+def pack_conv_weight_h3(weight: torch.Tensor) -> torch.Tensor:
+    """[O,I,3,3] fp32 -> static hi/lo f16 weights [ceil(I/16), 3, 3, 2(cg), 2(hi,lo), ceil64(O), 8] (device)."""
+    o, i, kh, kw = weight.shape
+    assert kh == 3 and kw == 3
+    w = weight.detach().to(torch.float32)
+    nch, op = (i + 15) // 16, (o + 63) // 64 * 64
+    wp = torch.zeros([nch * 16, 3, 3, op], dtype=torch.float32, device=w.device)
+    wp[:i, :, :, :o] = w.permute(1, 2, 3, 0)
+    hi = wp.to(torch.float16)
+    lo = (wp - hi.to(torch.float32)).to(torch.float16)
+    both = torch.stack([hi, lo], dim=0)                                   # [hl, c, ky, kx, o]
+    both = both.reshape(2, nch, 2, 8, 3, 3, op)                           # [hl, chunk, cg, j, ky, kx, o]
+    return both.permute(1, 4, 5, 2, 0, 6, 3).contiguous()                 # [chunk, ky, kx, cg, hl, o, j]
+
+
+def h2_shape(n, c, h, w):
+    return [n, (c + 7) // 8, 2, h, w, 8]
+
+
+def pack_h2(x, scale=None, x2=None):
+    """fp32 NCHW (optionally the channel concatenation of x and x2) * scale[n,c] -> H2 f16 tensor."""
+    _dev(x, "x")
+    n, c1, h, w = x.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    out = torch.empty(h2_shape(n, c1 + c2, h, w), dtype=torch.float16, device=x.device)
+    sc = None if scale is None else scale.contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nb_pack_h2_f32(_p(x.contiguous()), c1, _p(None if x2 is None else x2.contiguous()), c2,
+                                             _p(sc), _p(out), n, h * w, _stream(x)), "pack_h2")
+    return out
+
+
+def unpack_h2(xh2, c):
+    """H2 -> fp32 NCHW (hi + lo); a test/debug helper built from torch ops."""
+    n, c8, _, h, w, _ = xh2.shape
+    v = xh2[:, :, 0].to(torch.float32) + xh2[:, :, 1].to(torch.float32)    # [n, c8, h, w, 8]
+    return v.permute(0, 1, 4, 2, 3).reshape(n, c8 * 8, h, w)[:, :c].contiguous()
+
+
+def modconv_up1_h3(x_h2, c_in, w_h3, dcoefs, noise, bias, c_out, act_gain=math.sqrt(2), act_clamp=None, alpha=0.2):
+    """conv1-type layer on the f16 matrix cores: H2 input (already style-modulated) -> fp32 NCHW output."""
+    n, _, _, h, w, _ = x_h2.shape
+    y = torch.empty([n, c_out, h, w], dtype=torch.float32, device=x_h2.device)
+    ns = 0
+    if noise is not None:
+        noise = noise.contiguous()
+        ns = h * w if noise.numel() == n * h * w and n > 1 else 0
+    with torch.cuda.device(x_h2.device):
+        _lib.check(_lib.lib().nb_modconv3x3_up1_h3(_p(x_h2), c_in, _p(w_h3), _p(dcoefs.contiguous()), _p(noise), ns,
+                                                   _p(bias.contiguous()), _p(y), n, h, w, c_out, alpha, float(act_gain),
+                                                   float(-1 if act_clamp is None else act_clamp), _stream(x_h2)),
+                   "modconv3x3_up1_h3")
+    return y

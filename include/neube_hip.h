@@ -134,6 +134,34 @@ int nb_modconv3x3_f32(const float* x1, int c1, const float* x2, int c2, const fl
  * rocprofv3 reports), so that a benchmark can attribute its per-launch timings to kernels. */
 int nb_modconv3x3_variant(int n, int h, int w, int c_out, int up, char* buf, int buflen);
 
+/* ---- split-f16 ("h3") fast path for the large conv1 layers (csrc/nb_modconv_h3.hip) ----------------
+ * Every fp32 operand is carried as hi + lo f16 halves and a product is three f16 MFMAs (xh*wh + xl*wh +
+ * xh*wl, fp32 accumulate): fp32-grade results (5e-6 on pixels end to end) at ~5x the fp32-MFMA rate.
+ * Activation format H2: _Float16 [n][ceil(c/8)][2 (hi,lo)][h][w][8], ALREADY multiplied by the consuming
+ * layer's styles.  Weight format: produced by nb_pack_conv_weight_h3 (static, not modulated). */
+
+/* fp32 NCHW (x1 [n,c1,hw] ++ x2 [n,c2,hw]) * scale[n, c1+c2] (or NULL) -> H2 */
+int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out_h2, int n,
+                   int hw, void* stream);
+
+/* Host helper: W[c_out,c_in,3,3] fp32 -> hi/lo f16 [ceil(c_in/16)][3][3][2][2][ceil64(c_out)][8]
+ * (bytes: ceil(c_in/16)*9*4*ceil64(c_out)*16). */
+int nb_pack_conv_weight_h3(const float* w, int c_out, int c_in, void* out);
+
+/* SynthesisLayer.forward with up = 1 (networks.py:362-391) on an H2 input:
+ * y[n,c_out,h,w] (fp32 NCHW) = clamp(lrelu(conv3x3(x_h2, W) * dcoefs + noise + bias, alpha) * gain).
+ * Needs w % 32 == 0 and h % 16 == 0 (the large layers); smaller layers use nb_modconv3x3_f32. */
+int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                         int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                         float alpha, float gain, float clamp, void* stream);
+
+/* nb_modconv3x3_f32 with up = 2 whose fused epilogue writes the result in H2 format, multiplied by
+ * out_scale[n, c_out] (the styles of the conv1 layer that consumes it; NULL = 1), instead of fp32 NCHW. */
+int nb_modconv3x3_up2_f32_h2(const float* x1, int c1, const float* x2, int c2, const float* wpk,
+                             const float* styles, const float* dcoefs, const float* noise,
+                             int64_t noise_stride_n, const float* bias, const float* out_scale, void* y_h2,
+                             int n, int h, int w, int c_out, float alpha, float gain, float clamp, void* stream);
+
 /* ToRGBColorTriadLayer.forward (networks.py:451-485) after its affine, on x [n,c,hw]:
  *   logits_o = clamp(sum_c x_c * styles[n,c] * w[o,c] + bias[o]);  uvs = softmax_o(logits)
  *   img[n,ch] = sum_k uvs_k * colors[n,ch,k]            (colors = tanh(affine[:, :9] + color_bias))
