@@ -55,6 +55,8 @@ PROTOTYPES = {
     "nb_pack_conv_weight_h3": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "nb_modconv3x3_up1_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_float, C.c_float, vp]),
+    "nb_modconv3x3_up2_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_float, C.c_float, C.c_float, vp]),
     "nb_modconv3x3_up2_f32_h2": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp, vp,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
     "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, vp, vp,

@@ -257,6 +257,231 @@ extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3
 }
 
 // ------------------------------------------------------------------------------------------------
+// up = 2 on the f16 matrix cores: the 4-phase transposed convolution + fused polyphase FIR of
+// nb_modconv.hip (same math, same quad grid: see the comment block there), with split-f16 products.
+//
+// Workgroup = 8 waves, one 12 x 32 quad tile (14 x 34 = 476 halo'd positions = 15 MFMA column blocks of 32, two
+// per wave) x 32 c_out.  All four phases share the staged halo tile (9 taps per staged byte), so every wave
+// carries 2 blocks x 4 phases x 16 = 128 accumulator registers; the A/B fragments are streamed per tap.
+// (12 rows do not divide the image height: the last tile row overhangs and is masked.)  Input H2 (pre-modulated), weights [chunk][tap 9][cg 2][hi/lo 2][c_out_ld][8], output fp32 NCHW.
+// ------------------------------------------------------------------------------------------------
+#define NB_H3_TQH 12
+struct H3Up2Params {
+    const _Float16* x;      // H2 [n][c8][2][H][W][8]
+    const _Float16* wts;    // [nchunks][9][2][2][co_ld][8]
+    const float* dcoefs; const float* noise; const float* bias; float* y; const float* zeros;
+    long long noise_stride_n;
+    int c8, nchunks, c_out, co_ld, h, w;
+    int tiles_x, tiles_y, slices, dbg;
+    float alpha, gain, clamp;
+};
+
+__global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
+    constexpr int NW = 8, TQH = NB_H3_TQH, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
+    constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
+    constexpr int NBJ = (NBLK + NW - 1) / NW;         // blocks per wave (2)
+    constexpr int XR = TQH + 3, XS = TQW + 3;         // halo tile 15 x 35 input pixels
+    constexpr int SLOTS = XR * XS, PP = (SLOTS + 63) / 64, XPL = PP * 64;       // 525 -> 9 pieces
+    constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;                     // 36 -> 5 per wave
+    constexpr int WSLOTS = 36 * 32, NWP = WSLOTS / 64, NWPW = (NWP + NW - 1) / NW;   // 18 -> 3 per wave
+    constexpr int STAGE = 4 * XPL + WSLOTS;           // 16-byte slots per stage
+    constexpr int Y1_PHASE = NBLK * 32, Y1_SLOT = 4 * Y1_PHASE + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
+    h8* ring = reinterpret_cast<h8*>(smem_h3);        // [2][ x: 4 planes x XPL | w: 36 rows x 32 ]
+    float* y1s = reinterpret_cast<float*>(smem_h3);   // epilogue reuse: [2 slots][4 phases][640]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
+    const int H = p.h, W = p.w;
+    int b = blockIdx.x;
+    const int slice = b % p.slices; b /= p.slices;
+    const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
+    const int n = blockIdx.y;
+    const int I0 = tile_y * TQH, J0 = tile_x * TQW;
+    const int co0 = slice * 32;
+    const size_t HW8 = (size_t)H * W * 8;
+    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+    const int nblk = wv < NBLK - (NBJ - 1) * NW ? NBJ : NBJ - 1;      // blocks wv, wv+8 (< 15)
+
+    int xsp[NXPW], xpl[NXPW], xdst[NXPW];
+#pragma unroll
+    for (int i = 0; i < NXPW; ++i) {
+        int q = i * NW + wv;
+        q = q < NXP ? q : NXP - 1;
+        const int pl = q / PP, part = q - pl * PP;
+        const int e = part * 64 + lane;
+        xpl[i] = pl;
+        xdst[i] = pl * XPL + part * 64;
+        xsp[i] = -1;
+        if (e < SLOTS) {
+            const int r = e / XS, c = e - r * XS;
+            const int gy = I0 - 1 + r, gx = J0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xsp[i] = (gy * W + gx) * 8;
+        }
+    }
+    auto issue = [&](int c, h8* st) {
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            const int cg = 2 * c + (xpl[i] >> 1);
+            const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
+            if (xsp[i] >= 0 && cg < p.c8) src = xn + (size_t)(4 * c + xpl[i]) * HW8 + xsp[i];
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + xdst[i]), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NWPW; ++i) {
+            int q = i * NW + wv;
+            q = q < NWP ? q : NWP - 1;
+            const int e = q * 64 + lane;
+            const int row = e >> 5, j = e & 31;           // row = tap*4 + cg*2 + hl
+            const _Float16* src = p.wts + (((size_t)c * 36 + row) * p.co_ld + co0 + j) * 8;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + 4 * XPL + q * 64), 16, 0, 0);
+        }
+    };
+
+    // B-fragment base slots: position (r, c) of block (wv + 8j); X(r, c) = slot r*XS + c of plane (lh*2 + hl)
+    int boff[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+        int pidx = (wv + NW * j) * 32 + l31;
+        pidx = pidx < NPOS ? pidx : NPOS - 1;
+        const int r = pidx / PW, c = pidx - r * PW;
+        boff[j] = lh * 2 * XPL + r * XS + c;
+    }
+    const int aoff = 4 * XPL + lh * 2 * 32 + l31;     // + tap*128 + hl*32
+
+    f32x16 acc[NBJ][4];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][ph][r] = 0.f;
+
+    const int NC = p.nchunks;
+    issue(0, ring);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // tap -> (delta slot offset, phase): x11 = X(r,c), x10 = X(r,c+1), x01 = X(r+1,c), x00 = X(r+1,c+1)
+    constexpr int kTapDelta[9] = {XS + 1, XS, XS, 1, 0, 0, 1, 0, 0};      // taps 0..8 = (a,b) row-major
+    constexpr int kTapPhase[9] = {0, 1, 0, 2, 3, 2, 0, 1, 0};
+    for (int c = 0; c < NC; ++c) {
+        h8* st = ring + (c & 1) * STAGE;
+        if (c + 1 < NC && !(p.dbg & 2)) issue(c + 1, ring + ((c + 1) & 1) * STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const h8 ah = st[aoff + tap * 128], al = st[aoff + tap * 128 + 32];
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) {
+                if (j < nblk) {
+                    const h8 bh = st[boff[j] + kTapDelta[tap]], bl = st[boff[j] + XPL + kTapDelta[tap]];
+                    f32x16& a = acc[j][kTapPhase[tap]];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a, 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: 16 rounds of 2 c_out (accumulator register rho <-> c_out rows (rho&3) + 8(rho>>2) + 4*lh) ----
+    const int Wo = 2 * W, Ho = 2 * H;
+    const float* dco = p.dcoefs + (size_t)n * p.c_out;
+    constexpr int nquads = TQH * TQW;
+#pragma unroll
+    for (int rho = 0; rho < 16; ++rho) {
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+            if (j < nblk) {
+                const int pidx = (wv + NW * j) * 32 + l31;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) y1s[lh * Y1_SLOT + ph * Y1_PHASE + pidx] = acc[j][ph][rho];
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < 2 * nquads; it += 512) {
+            const int s = it / nquads, qd = it - s * nquads;
+            const int ti = qd / TQW, tj = qd - ti * TQW;
+            const int co = co0 + (rho & 3) + 8 * (rho >> 2) + 4 * s;
+            const float* ee = y1s + s * Y1_SLOT + ti * PW + tj;
+            const float* eo = ee + 1 * Y1_PHASE;
+            const float* oe = ee + 2 * Y1_PHASE;
+            const float* oo = ee + 3 * Y1_PHASE;
+            float ve0[2], ve1[2], vo0[3], vo1[3];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const float e0 = ee[cc], e1 = ee[PW + cc];
+                const float o0 = oe[cc], o1 = oe[PW + cc], o2 = oe[2 * PW + cc];
+                ve0[cc] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
+                ve1[cc] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float e0 = eo[cc], e1 = eo[PW + cc];
+                const float o0 = oo[cc], o1 = oo[PW + cc], o2 = oo[2 * PW + cc];
+                vo0[cc] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
+                vo1[cc] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
+            }
+            float out[2][2];
+            out[0][0] = 0.25f * vo0[0] + 0.75f * ve0[0] + 0.75f * vo0[1] + 0.25f * ve0[1];
+            out[0][1] = 0.25f * ve0[0] + 0.75f * vo0[1] + 0.75f * ve0[1] + 0.25f * vo0[2];
+            out[1][0] = 0.25f * vo1[0] + 0.75f * ve1[0] + 0.75f * vo1[1] + 0.25f * ve1[1];
+            out[1][1] = 0.25f * ve1[0] + 0.75f * vo1[1] + 0.75f * ve1[1] + 0.25f * vo1[2];
+            const int qi = I0 + ti, qj = J0 + tj;
+            if (co < p.c_out && qi < H && !(p.dbg & 1)) {
+                const float d = dco[co], bs = p.bias[co];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int oy = 2 * qi + dy, ox = 2 * qj;
+                    float n0 = 0.f, n1 = 0.f;
+                    if (p.noise) {
+                        const float* np_ = p.noise + (size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox;
+                        n0 = np_[0]; n1 = np_[1];
+                    }
+                    float2 o;
+                    o.x = nb_h3_epilogue(out[dy][0] * d + n0, bs, p.alpha, p.gain, p.clamp);
+                    o.y = nb_h3_epilogue(out[dy][1] * d + n1, bs, p.alpha, p.gain, p.clamp);
+                    *reinterpret_cast<float2*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                                    int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                                    float alpha, float gain, float clamp, void* stream) {
+    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && y, "modconv3x3_up2_h3: null pointer");
+    NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up2_h3: bad sizes");
+    NB_REQUIRE(w % 32 == 0 && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0 (got %dx%d)", h, w);
+    NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up2_h3: pointers must be 16-byte aligned");
+    H3Up2Params p;
+    p.x = (const _Float16*)x_h2; p.wts = (const _Float16*)w_h3; p.dcoefs = dcoefs; p.noise = noise; p.bias = bias; p.y = y;
+    p.zeros = nb_zero_page_ptr();
+    NB_REQUIRE(p.zeros, "modconv3x3_up2_h3: could not allocate the zero page");
+    p.noise_stride_n = noise_stride_n;
+    p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
+    { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.tiles_x = w / 32; p.tiles_y = (h + NB_H3_TQH - 1) / NB_H3_TQH; p.slices = (c_out + 31) / 32;
+    constexpr int XPL = (((NB_H3_TQH + 3) * 35 + 63) / 64) * 64;
+    const size_t lds = (size_t)2 * (4 * XPL + 36 * 32) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
+    hipLaunchKernelGGL(modconv3x3_up2_h3_kernel, grid, dim3(512), lds, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("modconv3x3_up2_h3");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 NCHW -> H2 packing (optionally x two concatenated inputs, x per-(n,c) scale = the consumer's styles)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_h2_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,

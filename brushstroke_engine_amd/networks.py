@@ -269,7 +269,7 @@ class SynthesisNetwork(torch.nn.Module):
             wpk, wsq = ops.pack_conv_weight(layer.weight)
             self.packed[s.name] = {"wpk": wpk, "wsq": wsq,
                                    "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous()}
-            if self._h3_eligible(s):
+            if self._h3_eligible(s) or self._h3_up2_eligible(s):
                 self.packed[s.name]["w_h3"] = ops.pack_conv_weight_h3(layer.weight)
         t = self.get_last_block().torgb
         self.packed["torgb"] = {"w": t.weight.reshape(3, -1).contiguous()}
@@ -278,6 +278,11 @@ class SynthesisNetwork(torch.nn.Module):
         """conv1 layers that run as 3-pass split-f16 MFMA (csrc/nb_modconv_h3.hip): the kernel needs rows of 32
         pixels and 16-row tiles, and a conv_clamp so that activations are bounded inside the f16 range."""
         return (self.conv_mode == "h3" and s.up == 1 and s.block_res >= 32 and s.block_res % 32 == 0
+                and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
+
+    def _h3_up2_eligible(self, s: LayerSpec) -> bool:
+        """conv0 (up=2) layers that run on the split-f16 4-phase kernel: input rows must be multiples of 32 pixels."""
+        return (self.conv_mode == "h3" and s.up == 2 and s.in_res >= 32 and s.in_res % 32 == 0
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _variant_name(self, n: int, s: LayerSpec) -> str:
@@ -399,6 +404,22 @@ class SynthesisNetwork(torch.nn.Module):
                         self.layer_kernels[name] = "modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
                         keep_alive.append(x_h2)
                         x_h2 = None
+                    elif s.up == 2 and self._h3_up2_eligible(s):
+                        # conv0 on the f16 matrix cores: (x ++ geometry) * styles -> H2, then the 4-phase split-f16 kernel
+                        evp = self._begin_event("pack_h2")
+                        xin_h2 = torch.empty(ops.h2_shape(n, s.in_channels, s.in_res, s.in_res), dtype=torch.float16,
+                                             device=device)
+                        _lib.check(lib.nb_pack_h2_f32(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(xin_h2), n,
+                                                      s.in_res * s.in_res, stream), "pack_h2")
+                        self._end_event(evp)
+                        ev = self._begin_event(name)
+                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                        _lib.check(lib.nb_modconv3x3_up2_h3(
+                            _p(xin_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                            _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp,
+                            stream), name)
+                        self.layer_kernels[name] = "modconv3x3_up2_h3_kernel"
+                        keep_alive.append(xin_h2)
                     elif s.up == 2 and self.h2_fused_epilogue and self._h3_eligible(specs[f"synthesis.b{res}.conv1"][1]):
                         # conv0 writes its output directly in H2 format, multiplied by conv1's styles
                         i1 = specs[f"synthesis.b{res}.conv1"][0]

@@ -256,3 +256,19 @@ def modconv_up1_h3(x_h2, c_in, w_h3, dcoefs, noise, bias, c_out, act_gain=math.s
                                                    float(-1 if act_clamp is None else act_clamp), _stream(x_h2)),
                    "modconv3x3_up1_h3")
     return y
+
+
+def modconv_up2_h3(x_h2, c_in, w_h3, dcoefs, noise, bias, c_out, act_gain=math.sqrt(2), act_clamp=None, alpha=0.2):
+    """conv0-type (up=2) layer on the f16 matrix cores: H2 input [n,c_in,h,w] -> fp32 NCHW output [n,c_out,2h,2w]."""
+    n, _, _, h, w, _ = x_h2.shape
+    y = torch.empty([n, c_out, 2 * h, 2 * w], dtype=torch.float32, device=x_h2.device)
+    ns = 0
+    if noise is not None:
+        noise = noise.contiguous()
+        ns = 4 * h * w if noise.numel() == n * 4 * h * w and n > 1 else 0
+    with torch.cuda.device(x_h2.device):
+        _lib.check(_lib.lib().nb_modconv3x3_up2_h3(_p(x_h2), c_in, _p(w_h3), _p(dcoefs.contiguous()), _p(noise), ns,
+                                                   _p(bias.contiguous()), _p(y), n, h, w, c_out, alpha, float(act_gain),
+                                                   float(-1 if act_clamp is None else act_clamp), _stream(x_h2)),
+                   "modconv3x3_up2_h3")
+    return y

@@ -155,6 +155,13 @@ int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const flo
                          int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
                          float alpha, float gain, float clamp, void* stream);
 
+/* SynthesisLayer.forward with up = 2 (stride-2 transposed conv as 4 phases + fused 4x4 FIR, as in
+ * nb_modconv3x3_f32) with split-f16 products: x_h2 is the H2 input [n, c_in, h, w] (already multiplied by this
+ * layer's styles), y the fp32 NCHW output [n, c_out, 2h, 2w].  Needs w % 32 == 0. */
+int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                         int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                         float alpha, float gain, float clamp, void* stream);
+
 /* nb_modconv3x3_f32 with up = 2 whose fused epilogue writes the result in H2 format, multiplied by
  * out_scale[n, c_out] (the styles of the conv1 layer that consumes it; NULL = 1), instead of fp32 NCHW. */
 int nb_modconv3x3_up2_f32_h2(const float* x1, int c1, const float* x2, int c2, const float* wpk,

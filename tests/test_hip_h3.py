@@ -89,3 +89,27 @@ def test_up2_h2_output_vs_oracle(dev, shape):
     _lib.check(rc, "up2_h2")
     got = ops.unpack_h2(out, oc)
     assert maxerr(got, want) <= 5e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 144, 128, 32, 32), (1, 384, 128, 64, 64), (1, 128, 64, 128, 128), (2, 40, 48, 16, 32)])
+def test_up2_h3_vs_oracle(dev, shape):
+    from brushstroke_engine_amd import ops
+    from oracle import neube_oracle as orc
+    n, ic, oc, h, w = shape
+    rs = np.random.RandomState(ic + oc + h)
+    x = rs.randn(n, ic, h, w).astype(np.float32)
+    wt = rs.randn(oc, ic, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(n, ic)).astype(np.float32)
+    b = (0.1 * rs.randn(oc)).astype(np.float32)
+    noise = (0.1 * rs.randn(n, 1, 2 * h, 2 * w)).astype(np.float32)
+    T = torch.from_numpy
+    want = orc.modulated_conv2d(T(x), T(wt), T(s), noise=T(noise), up=2, padding=1, resample_filter=orc.setup_filter(),
+                                flip_weight=False)
+    want = orc.bias_act(want, T(b), act="lrelu", gain=np.sqrt(2), clamp=256.0)
+    wd = D(wt, dev)
+    c2 = 16 if ic > 64 else 0
+    xh2 = ops.pack_h2(D(x[:, :ic - c2], dev), D(s, dev), D(x[:, ic - c2:], dev) if c2 else None)
+    wsq = wd.square().sum(dim=[2, 3]).t().contiguous()
+    d = (D(s, dev).square() @ wsq + 1e-8).rsqrt()
+    got = ops.modconv_up2_h3(xh2, ic, ops.pack_conv_weight_h3(wd), d, D(noise, dev), D(b, dev), oc, act_clamp=256.0)
+    assert maxerr(got, want) <= 5e-5
