@@ -299,9 +299,10 @@ class SynthesisNetwork(torch.nn.Module):
 
     # -- optional per-launch HIP-event timing (bench.py): events are recorded on the launch stream --
     layer_events = None      # set to a list to collect (name, start_event, end_event)
+    event_filter = None      # optional set of names: record only these (every recorded pair costs ~10 us of stream time)
 
     def _begin_event(self, name):
-        if self.layer_events is None:
+        if self.layer_events is None or (self.event_filter is not None and name not in self.event_filter):
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
