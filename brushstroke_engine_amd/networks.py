@@ -241,6 +241,8 @@ class SynthesisNetwork(torch.nn.Module):
         # "h3": large conv1 layers on the f16 matrix cores as hi/lo split products (fp32-grade, ~5x the fp32 MFMA
         # rate); "f32": every layer on the exact-fp32 MFMA kernels.
         self.conv_mode = "h3"
+        self.h3_min_batch = 4             # below this the launch-bound fp32 path (fewer launches, no pack passes) is faster
+        self._h3_batch_ok = True
         self.h2_fused_epilogue = False    # True: the up=2 kernel writes H2 itself (slower epilogue at present)
         self.layer_kernels: Dict[str, str] = {}
 
@@ -269,7 +271,7 @@ class SynthesisNetwork(torch.nn.Module):
             wpk, wsq = ops.pack_conv_weight(layer.weight)
             self.packed[s.name] = {"wpk": wpk, "wsq": wsq,
                                    "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous()}
-            if self._h3_eligible(s) or self._h3_up2_eligible(s):
+            if self.conv_mode == "h3" and self.cfg.conv_clamp is not None:
                 self.packed[s.name]["w_h3"] = ops.pack_conv_weight_h3(layer.weight)
         t = self.get_last_block().torgb
         self.packed["torgb"] = {"w": t.weight.reshape(3, -1).contiguous()}
@@ -277,12 +279,12 @@ class SynthesisNetwork(torch.nn.Module):
     def _h3_eligible(self, s: LayerSpec) -> bool:
         """conv1 layers that run as 3-pass split-f16 MFMA (csrc/nb_modconv_h3.hip): the kernel needs rows of 32
         pixels and 16-row tiles, and a conv_clamp so that activations are bounded inside the f16 range."""
-        return (self.conv_mode == "h3" and s.up == 1 and s.block_res >= 32 and s.block_res % 32 == 0
-                and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
+        return (self.conv_mode == "h3" and self._h3_batch_ok and s.up == 1 and s.block_res >= 32
+                and s.block_res % 32 == 0 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _h3_up2_eligible(self, s: LayerSpec) -> bool:
         """conv0 (up=2) layers that run on the split-f16 4-phase kernel: input rows must be multiples of 32 pixels."""
-        return (self.conv_mode == "h3" and s.up == 2 and s.in_res >= 32 and s.in_res % 32 == 0
+        return (self.conv_mode == "h3" and self._h3_batch_ok and s.up == 2 and s.in_res >= 32 and s.in_res % 32 == 0
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _variant_name(self, n: int, s: LayerSpec) -> str:
@@ -337,6 +339,7 @@ class SynthesisNetwork(torch.nn.Module):
             raise RuntimeError(f"ws is on {ws.device} but the generator is on {device}")
         ws = ws.to(torch.float32).contiguous()
         n = ws.shape[0]
+        self._h3_batch_ok = n >= self.h3_min_batch
         plan = self._get_plan(n, device)
         lib = _lib.lib()
         geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]

@@ -9,7 +9,7 @@ for r in csv.DictReader(open(f)):
     meta[key] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["VGPR_Count"], r["Accum_VGPR_Count"], r["LDS_Block_Size"], r["Grid_Size"], r["Workgroup_Size"])
 last = {}
 for (k, d), v in agg.items():
-    if "modconv" in k or "torgb" in k:
+    if "modconv" in k or "torgb" in k or "pack_h2" in k:
         last[(k, meta[(k, d)][4])] = (d, v, meta[(k, d)])
 for (k, g), (d, v, m) in sorted(last.items(), key=lambda t: -t[1][2][0]):
     dur, vg, ag, lds, grid, wg = m
