@@ -42,7 +42,7 @@ struct H3Params {
     const float* zeros;
     long long noise_stride_n;
     int c8, nchunks, c_out, co_ld, h, w;
-    int tiles_x, tiles_y, slices, dbg;
+    int tiles_x, tiles_y, slices, dbg, stagger_ticks;
     float alpha, gain, clamp;
 };
 
@@ -54,8 +54,22 @@ __device__ __forceinline__ float nb_h3_epilogue(float v, float bias, float alpha
     return v;
 }
 
+// De-synchronise the chip: without this every CU runs the same tile schedule in lockstep, so all epilogue store
+// bursts (and all prologue DMA bursts) hit HBM at the same moments while the matrix pipes idle.  The workgroups of
+// the first dispatch round (one per CU) start `phase/16` of a tile time apart; later workgroups inherit the offsets
+// as slots free up.  `stagger_ticks` = tile time / 16 in 100 MHz s_memrealtime ticks (0 = off).
+__device__ __forceinline__ void nb_stagger(int stagger_ticks, int first_round) {
+    const int bid = blockIdx.x + blockIdx.y * gridDim.x;
+    if (stagger_ticks > 0 && bid < first_round) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)(bid & 15) * stagger_ticks;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 template <int MW>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
+    nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = 8, NWN = NW / MW;          // waves along pixels
     constexpr int MB = 2, NBW = 2;                // 32x32 MFMA tiles per wave: 64 c_out x 64 pixels
     constexpr int CO_WG = MW * 64, TH = NWN * NBW, TWP = 34;     // tile rows (32 pixels each), halo tile width
@@ -197,22 +211,40 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail re-copies before the LDS is released
 
     // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp -> fp32 NCHW; D[row = c_out, col = pixel] ----
+    // The finished values go through LDS (the staging buffers are dead now) as an [c_out][pixel] image so that each
+    // lane can store 16 bytes (4 consecutive pixels of one channel row): 4x fewer store instructions than storing
+    // the accumulator registers directly, and whole 512-byte row segments per wave-instruction.
+    constexpr int PIX_WG = TH * 32;
+    float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG] floats (<= 128 KiB)
     const float* dco = p.dcoefs + (size_t)n * p.c_out;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-        const int oy = y0 + wn * NBW + nb, ox = x0 + l31;
+        const int trow = wn * NBW + nb;
+        const int oy = y0 + trow, ox = x0 + l31;
         float nz = 0.f;
         if (p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * W + ox];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < p.c_out && !(p.dbg & 1)) {
-                    float v = acc[mb][nb][r] * dco[co] + nz;
-                    v = nb_h3_epilogue(v, p.bias[co], p.alpha, p.gain, p.clamp);
-                    p.y[((size_t)n * p.c_out + co) * ((size_t)H * W) + (size_t)oy * W + ox] = v;
-                }
+                const int col = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // c_out within the workgroup
+                const int co = co0 + col;
+                float v = 0.f;
+                if (co < p.c_out) v = nb_h3_epilogue(acc[mb][nb][r] * dco[co] + nz, p.bias[co], p.alpha, p.gain, p.clamp);
+                ot[col * PIX_WG + trow * 32 + l31] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (!(p.dbg & 1)) {
+        constexpr int V4_PER_ROW = PIX_WG / 4;                   // float4 per c_out row
+        for (int e = tid; e < CO_WG * V4_PER_ROW; e += 512) {
+            const int col = e / V4_PER_ROW, q4 = e - col * V4_PER_ROW;
+            const int co = co0 + col;
+            if (co < p.c_out) {
+                const int trow = q4 >> 3, px = (q4 & 7) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ot + col * PIX_WG + q4 * 4);
+                *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)H * W) + (size_t)(y0 + trow) * W + x0 + px) = v;
             }
         }
     }
@@ -251,6 +283,7 @@ extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3
     p.noise_stride_n = noise_stride_n;
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     if (c_out > 64) return launch_h3<2>(p, n, (hipStream_t)stream);
     return launch_h3<1>(p, n, (hipStream_t)stream);
@@ -272,11 +305,12 @@ struct H3Up2Params {
     const float* dcoefs; const float* noise; const float* bias; float* y; const float* zeros;
     long long noise_stride_n;
     int c8, nchunks, c_out, co_ld, h, w;
-    int tiles_x, tiles_y, slices, dbg;
+    int tiles_x, tiles_y, slices, dbg, stagger_ticks;
     float alpha, gain, clamp;
 };
 
 __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
+    nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = 8, TQH = NB_H3_TQH, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
     constexpr int NBJ = (NBLK + NW - 1) / NW;         // blocks per wave (2)
@@ -466,6 +500,7 @@ extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3
     p.noise_stride_n = noise_stride_n;
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tiles_x = w / 32; p.tiles_y = (h + NB_H3_TQH - 1) / NB_H3_TQH; p.slices = (c_out + 31) / 32;
     constexpr int XPL = (((NB_H3_TQH + 3) * 35 + 63) / 64) * 64;
