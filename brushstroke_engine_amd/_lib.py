@@ -62,6 +62,10 @@ PROTOTYPES = {
     "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, vp, vp,
                                      C.c_int, C.c_int, C.c_int, vp]),
     "nb_blend_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_geom_tiles_f32": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
+    "nb_canvas_replay_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                       vp, vp, vp]),
+    "nb_paste_tiles_u8": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     "nb_pack_conv_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
 }
 

@@ -327,6 +327,10 @@ class SynthesisNetwork(torch.nn.Module):
         block_kwargs.pop("force_fp32", None)       # always fp32 here (SURVEY note B)
         block_kwargs.pop("fused_modconv", None)    # one arithmetic form (csrc/nb_modconv.hip)
         extra = block_kwargs.pop("_extra_outputs", None)
+        # split entry for the tiled-canvas schedule (painting.py): `_stop_after=res` returns the output of block
+        # `res` before any blending; `_resume=(res, x)` continues after block `res` from (blended) features x
+        stop_after = block_kwargs.pop("_stop_after", None)
+        resume = block_kwargs.pop("_resume", None)
         if block_kwargs:
             raise TypeError(f"unexpected synthesis kwargs: {sorted(block_kwargs)}")
         if noise_mode not in ("random", "const", "none"):
@@ -375,6 +379,15 @@ class SynthesisNetwork(torch.nn.Module):
             specs = {s.name: (i, s) for i, s in enumerate(cfg.layers)}
             for res in self.block_resolutions:
                 block = getattr(self, f"b{res}")
+                if resume is not None and res <= resume[0]:
+                    if res == resume[0]:
+                        x = resume[1].to(device=device, dtype=torch.float32).contiguous()
+                        _assert_shape(x, [n, cfg.channels(res), res, res])
+                    if res in self.geom_feature_resolutions:
+                        if res == resume[0]:
+                            x2 = geom_feature[geo_idx].to(torch.float32).contiguous()
+                        geo_idx += 1
+                    continue
                 names = ([f"synthesis.b{res}.conv0"] if res > 4 else []) + [f"synthesis.b{res}.conv1"]
                 if res == 4:
                     x = block.const.unsqueeze(0).expand(n, -1, -1, -1).contiguous()     # networks.py:641-643
@@ -455,6 +468,8 @@ class SynthesisNetwork(torch.nn.Module):
                     keep_alive += [x, x2]
                     x, x2 = y, None
 
+                if stop_after is not None and res == stop_after:
+                    return x
                 if block.is_last:
                     img, triad = self._torgb(plan, x, n, stream, extra)
                     if return_debug_data:

@@ -188,6 +188,38 @@ int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n,
 int nb_blend_f32(const float* features, int nf, const float* alpha, int na, const float* x, float* y, int n, int c,
                  int hw, void* stream);
 
+/* ---- canvas side of the painting engine (SURVEY 8 rows e / f2) ---------------------------------------------
+ * Cells: the canvas is cut into NB_CELL_H x NB_CELL_W pixel cells (row-major, ceil(w/NB_CELL_W) per row);
+ * cell_off [ncells+1] / cell_tiles is a CSR list of the tiles whose rectangle touches each cell, in ascending
+ * tile order (= the reference's sequential paint order).  All pointers are device pointers. */
+#define NB_CELL_H 4
+#define NB_CELL_W 64
+
+/* Geometry tiles for the encoder: out[t,0,y,x] = 1 - (255 - geom[ty+y, tx+x]) / 255  (outside the image: 1), i.e.
+ * forger/viz/paint_image_main.py:162 (`255 - geom[y:y+P, x:x+P]`) followed by GanPaintEngine.prepare_geom_input
+ * (forger/ui/brush.py:672-681).  geom is [gh,gw] uint8 (255 = background), tile_yx [t,2] int32. */
+int nb_geom_tiles_f32(const uint8_t* geom, int gh, int gw, const int32_t* tile_yx, int t, int r, float* out,
+                      void* stream);
+
+/* Feature-canvas blending for a SEQUENCE of full tiles in one launch.  Replaces, for tiles 0..t-1 in order,
+ * PaintingHelper._get_blended_features (forger/ui/brush.py:190-227) + BlendedFeatures.blend (forger/train/
+ * stitching.py:24-25, applied in networks_modified.py:176-181) + FeatureCanvas.set_features (brush.py:82-92):
+ *   upd = alpha0 > 0.99 | (mask & alpha0 > 0), cleared inside the `crop` border;  a = 1 - (mask ? alpha0 : 1);
+ *   tiles[t] = a * canvas + (1 - a) * tiles[t];  canvas[upd] = tiles[t][upd];  mask |= upd.
+ * tiles [t,c,hw,hw] holds the block output before blending on entry and the blended features on return;
+ * tile_yx [t,2] are tile origins on the feature canvas; alpha0 [hw,hw] is generate_dirty_area_alpha
+ * (brush.py:159-187) for a full tile; canvas [c,hc,wc] / mask_in / mask_out [hc,wc] are the FeatureCanvas state
+ * (mask_out must not alias mask_in).  Cells are taken over the feature canvas. */
+int nb_canvas_replay_f32(float* tiles, int t, int c, int hw, const int32_t* tile_yx, const float* alpha0, int crop,
+                         float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
+                         const int32_t* cell_off, const int32_t* cell_tiles, void* stream);
+
+/* Paste RGBA8 tiles [t,r,r,4] into canvas [h,w,4]: the interior [crop, r-crop)^2 of tile i lands at
+ * dst_yx[i] + crop (brush.py:369-374 crop + out_meta, paint_image_main.py:173-177 paste); later tiles
+ * overwrite earlier ones.  Cells are taken over the RGBA canvas from the interior rectangles. */
+int nb_paste_tiles_u8(const uint8_t* tiles, int t, int r, const int32_t* dst_yx, int crop, uint8_t* canvas, int h, int w,
+                      const int32_t* cell_off, const int32_t* cell_tiles, void* stream);
+
 /* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into the zero-padded
  * wpk[ceil8(c_in)][9][ceil32(c_out)] and wsq[c_in][c_out] = sum_k W^2.  Either output may be NULL. */
 int nb_pack_conv_weight(const float* w, int c_out, int c_in, float* wpk, float* wsq);

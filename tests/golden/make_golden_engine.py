@@ -1,0 +1,132 @@
+"""Golden vectors for the painting-engine rows: run the REFERENCE
+PaintEngineFactory / PaintingHelper (forger/ui/brush.py) on CPU over a small tiled canvas with feature
+blending level 2, exactly as forger/viz/paint_image_main.py:157-177 drives it.  Build container only.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_engine.py
+"""
+import argparse
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+# stubs for modules the reference imports but this container lacks
+sk, skio = types.ModuleType("skimage"), types.ModuleType("skimage.io")
+skio.imread = lambda p: np.array(__import__("PIL.Image").Image.open(p))
+skio.imsave = lambda p, a: None
+sk.io = skio
+skf = types.ModuleType("skimage.filters")
+skf.threshold_otsu = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("not available"))
+skf.threshold_local = skf.threshold_otsu
+sk.filters = skf
+sys.modules.update({"skimage": sk, "skimage.io": skio, "skimage.filters": skf, "torchvision": types.ModuleType("torchvision")})
+import matplotlib  # noqa: E402
+matplotlib.use("Agg")
+import thirdparty.stylegan2_ada_pytorch  # noqa: E402,F401
+import thirdparty.stylegan2_ada_pytorch.dnnlib as dnnlib  # noqa: E402
+from thirdparty.stylegan2_ada_pytorch.training.networks_modified import Generator  # noqa: E402
+from thirdparty.stylegan2_ada_pytorch.training.networks import Discriminator  # noqa: E402
+import forger.experimental.autoenc.simple_autoencoder as sa  # noqa: E402
+import forger.ui.brush as brush  # noqa: E402
+import forger.viz.style_transfer as style_transfer  # noqa: E402
+
+from brushstroke_engine_amd import config as cfgmod, weights as wmod  # noqa: E402
+from brushstroke_engine_amd import encoder as encmod  # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    R = 128
+    cfg = cfgmod.style1_config(R)
+    sd = wmod.random_state_dict(cfg, seed=0)
+    ap = argparse.ArgumentParser()
+    sa.add_model_flags(ap)
+    ea = ap.parse_args([])
+    ea.encoder_in_channels = ea.decoder_out_channels = 1
+    ea.model_name = "sauto"
+    ea.preproc_type = None
+    ea.widths = "256,128,64"
+    enc = sa.model_from_flags(ea)
+    esd = encmod.random_encoder_state_dict(seed=5)
+    missing = set(enc.state_dict().keys()) ^ set(esd.keys())
+    assert not missing, sorted(missing)[:5]
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in esd.items()}, strict=True)
+    inj = [0, 1]
+    G = Generator(z_dim=64, c_dim=0, w_dim=64, img_resolution=R, img_channels=3,
+                  mapping_kwargs=dnnlib.EasyDict(num_layers=4),
+                  synthesis_kwargs=dnnlib.EasyDict(channel_base=16384, channel_max=128, num_fp16_res=0, conv_clamp=256,
+                                                   architecture="orig", color_format="triad", color_w_channels=0,
+                                                   enable_geom_linear=False,
+                                                   geom_feature_channels=[enc.feature_channels(i) for i in inj],
+                                                   geom_feature_resolutions=[enc.featuremap_resolution(R, i) for i in inj])
+                  ).eval().requires_grad_(False)
+    G.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    D = Discriminator(c_dim=0, img_resolution=R, img_channels=3, architecture="orig", channel_base=16384, channel_max=128)
+    snap = dict(G=G, D=D, G_ema=G, training_set_kwargs=None, augment_pipe=None,
+                args=argparse.Namespace(color_format="triad", geom_inject_resolutions=inj),
+                encoder={"args": ea, "model_state": enc.state_dict()})
+    path = "/tmp/neube_snap.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(snap, f)
+    eng = brush.PaintEngineFactory.create(gan_checkpoint=path, device=torch.device("cpu"))
+
+    # synthetic line drawing: 255 = background, 0 = stroke (what _read_any_geo hands out, paint_image_main.py:28-55)
+    rs = np.random.RandomState(42)
+    H0, W0 = 250, 200
+    geom = np.full((H0, W0, 1), 255, np.uint8)
+    for _ in range(14):
+        y, x = rs.randint(5, H0 - 5), rs.randint(5, W0 - 5)
+        dy, dx = rs.randint(-60, 60), rs.randint(-60, 60)
+        for t in np.linspace(0, 1, 200):
+            yy, xx = int(y + t * dy), int(x + t * dx)
+            if 1 <= yy < H0 - 1 and 1 <= xx < W0 - 1:
+                geom[yy - 1:yy + 2, xx - 1:xx + 2] = 0
+    crop_margin = 10
+    out = {"geom": geom[..., 0], "crop_margin": np.int64(crop_margin), "style_seed": np.int64(594),
+           "weights_seed": np.int64(0), "encoder_seed": np.int64(5), "resolution": np.int64(R)}
+    # paint_image_main.py:58-61 pad_geo, :148-151 crops
+    gp = np.ones((geom.shape[0] + crop_margin, geom.shape[1] + crop_margin, 1), np.uint8) * 255
+    gp[crop_margin:, crop_margin:] = geom
+    crops, gpad = style_transfer.generate_stitching_crops(gp, R, mode="all", overlap_margin=crop_margin * 2)
+    out["crops"] = np.array([c[:2] for c in crops], np.int64)
+    out["geom_padded"] = gpad[..., 0]
+    for level in (0, 2):
+        for mode in ("clear",):
+            helper = brush.PaintingHelper(eng, style_seed=0)
+            helper.make_new_canvas(gpad.shape[0], gpad.shape[1], feature_blending=level)
+            helper.set_render_mode(mode)
+            opts = brush.GanBrushOptions()
+            opts.set_style(eng.random_style(594), 594)
+            result = np.zeros((gpad.shape[0], gpad.shape[1], 4), np.uint8)
+            with torch.no_grad():
+                for (y, x, _, _) in crops:
+                    opts.set_position(x, y)
+                    patch = 255 - gpad[y:y + R, x:x + R, :]
+                    res, _, meta = helper.render_stroke(patch, None, opts, meta={"x": x, "y": y, "crop_margin": crop_margin})
+                    result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+            out[f"canvas_level{level}_{mode}"] = result
+            if level == 2:
+                out["feature_canvas_stats"] = np.array([float(helper.feature_canvas.features.double().sum()),
+                                                        float(helper.feature_canvas.features.double().square().sum()),
+                                                        float(helper.feature_canvas.mask.sum())])
+                out["feature_canvas_sub"] = helper.feature_canvas.features[0, ::16, ::4, ::4].numpy()
+    # encoder KAT: features for the first tile
+    y, x = crops[0][:2]
+    g0 = eng.prepare_geom_input(255 - gpad[y:y + R, x:x + R, :])
+    feats = eng.encoder.encode(g0)
+    out["enc_in"] = g0.numpy()
+    out["enc_f0"], out["enc_f1"] = feats[0].detach().numpy(), feats[1].detach().numpy()[:, ::8]
+    np.savez_compressed(os.path.join(HERE, "engine_r128.npz"), **out)
+    print("engine_r128.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,244 @@
+"""CPU tests of the painting-engine rows (SURVEY 8 e/f1/f2): the oracle against the reference-generated canvases,
+the host logic of brushstroke_engine_amd.painting, and the three-phase (sharded) schedule with an oracle-backed
+device stand-in -- world size 1 and world size 2 over gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden, REPO
+from brushstroke_engine_amd import config as cfgmod, weights as wmod, encoder as encmod, painting
+from oracle import neube_oracle as no, painting_oracle as po
+from oracle_tile_ops import OracleTileOps, sequential_replay
+
+
+@pytest.fixture(scope="module")
+def eng():
+    g = load_golden("engine_r128.npz")
+    cfg = cfgmod.style1_config(int(g["resolution"]))
+    sd = wmod.random_state_dict(cfg, seed=int(g["weights_seed"]))
+    esd = encmod.random_encoder_state_dict(int(g["encoder_seed"]))
+    z = np.random.RandomState(int(g["style_seed"])).randn(1, cfg.z_dim)
+    return dict(g=g, cfg=cfg, sd=sd, esd=esd, z=z)
+
+
+def _canvas_close(a, b, max_frac=2e-4):
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    assert d.max() <= 1, d.max()                    # fp32 reassociation can flip a uint8 truncation
+    assert (d > 0).mean() <= max_frac, (d > 0).sum()
+
+
+# ---------------------------------------------------------------- oracle pinned by the reference
+def test_oracle_encoder_matches_reference(eng):
+    g = eng["g"]
+    f = po.encoder_encode(eng["esd"], torch.from_numpy(g["enc_in"]))
+    np.testing.assert_allclose(f[0].numpy(), g["enc_f0"], atol=1e-6)
+    np.testing.assert_allclose(f[1].numpy()[:, ::8], g["enc_f1"], atol=1e-6)
+
+
+@pytest.mark.parametrize("level", [0, 2])
+def test_oracle_painter_matches_reference_canvas(eng, level):
+    g = eng["g"]
+    P = po.OraclePainter(no.OracleGenerator(eng["cfg"], eng["sd"]), eng["esd"])
+    out, full, crops, padded = P.paint_image(g["geom"][..., None], z=eng["z"], crop_margin=int(g["crop_margin"]),
+                                             feature_blending=level)
+    assert np.array_equal(np.array([c[:2] for c in crops]), g["crops"])
+    assert np.array_equal(padded[..., 0], g["geom_padded"])
+    _canvas_close(full, g[f"canvas_level{level}_clear"])
+    assert out.shape == (g["geom"].shape[0], g["geom"].shape[1], 4)
+    if level == 2:
+        st = g["feature_canvas_stats"]
+        assert float(P.mask.sum()) == st[2]
+        np.testing.assert_allclose(float(P.features.double().sum()), st[0], rtol=1e-6)
+        np.testing.assert_allclose(P.features[0, ::16, ::4, ::4].numpy(), g["feature_canvas_sub"], atol=2e-5)
+
+
+# ---------------------------------------------------------------- host logic
+@pytest.mark.parametrize("width,margin,crop", [(64, 8, 5), (128, 16, 10), (128, 8, 0), (32, 4, 2), (64, 8, 0)])
+def test_dirty_area_alpha_bitwise(width, margin, crop):
+    a = painting.dirty_area_alpha(width, margin, crop)
+    b = po.dirty_area_alpha(width, margin, crop).numpy()
+    assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert a.max() == 1 and a.min() == 0 and a[width // 2, width // 2] == 1
+
+
+def test_tiling_matches_reference(eng):
+    g = eng["g"]
+    m = int(g["crop_margin"])
+    crops, padded = painting.generate_stitching_crops(painting.pad_geo(g["geom"][..., None], m), 128, "all", 2 * m)
+    assert np.array_equal(np.array([c[:2] for c in crops]), g["crops"])
+    assert np.array_equal(padded[..., 0], g["geom_padded"])
+    full_only, _ = painting.generate_stitching_crops(painting.pad_geo(g["geom"][..., None], m), 128, "full", 2 * m)
+    assert 0 < len(full_only) <= len(crops)
+    empty = np.full((40, 50, 1), 255, np.uint8)                       # ragged: image smaller than one patch
+    c2, p2 = painting.generate_stitching_crops(empty, 128, "all", 20)
+    assert c2 == [(0, 0, 128, 128)] and p2.shape == (88 + 128, 88 + 128, 1)
+    assert painting.generate_stitching_crops(empty, 128, "full", 20)[0] == []
+
+
+def test_build_cells_bruteforce():
+    rs = np.random.RandomState(0)
+    h, w = 37, 150
+    rects = []
+    for _ in range(12):
+        y0, x0 = rs.randint(-5, h), rs.randint(-5, w)
+        rects.append((y0, x0, y0 + rs.randint(1, 30), x0 + rs.randint(1, 90)))
+    rects.append((0, 0, 0, 0))                                         # padding row
+    off, lst = painting.build_cells(np.array(rects), h, w)
+    ncx = -(-w // painting.CELL_W)
+    for cy in range(-(-h // painting.CELL_H)):
+        for cx in range(ncx):
+            want = [t for t, (y0, x0, y1, x1) in enumerate(rects)
+                    if max(y0, cy * painting.CELL_H, 0) < min(y1, (cy + 1) * painting.CELL_H, h)
+                    and max(x0, cx * painting.CELL_W, 0) < min(x1, (cx + 1) * painting.CELL_W, w)]
+            c = cy * ncx + cx
+            assert list(lst[off[c]:off[c + 1]]) == want
+
+
+def test_otsu_and_geometry_preparation():
+    rs = np.random.RandomState(1)
+    img = np.where(rs.rand(64, 64) < 0.3, rs.randint(10, 40, (64, 64)), rs.randint(180, 250, (64, 64))).astype(np.uint8)
+    t = painting.threshold_otsu(img)
+    assert 39 <= t < 180                                               # any cut between the two modes is optimal
+    # exhaustive between-class variance maximisation
+    best = max(range(int(img.min()), int(img.max())),
+               key=lambda k: (img <= k).sum() * (img > k).sum() * (img[img <= k].mean() - img[img > k].mean()) ** 2)
+    assert t == best
+    rgba = np.zeros((32, 32, 4), np.uint8)
+    rgba[8:12, :, 3] = 255                                             # an opaque black line on transparent
+    g = painting.prepare_geometry_image(rgba)
+    assert g.shape == (32, 32, 1) and set(np.unique(g)) == {0, 255} and (g[8:12] == 0).all() and (g[:8] == 255).all()
+    assert (painting.prepare_geometry_image(255 - rgba[..., 3]) == g).all()      # gray input, same drawing
+
+
+def test_encoder_module_matches_reference(eng):
+    g = eng["g"]
+    m = encmod.build_encoder(eng["esd"], device="cpu")
+    f = m.encode(torch.from_numpy(g["enc_in"]))
+    np.testing.assert_allclose(f[0].numpy(), g["enc_f0"], atol=1e-6)
+    np.testing.assert_allclose(f[1].numpy()[:, ::8], g["enc_f1"], atol=1e-6)
+    assert m.feature_channels(0) == 16 and m.feature_channels(1) == 256
+    assert m.featuremap_resolution(128, 0) == 16 and m.featuremap_resolution(128, 1) == 32
+    with pytest.raises(RuntimeError):
+        encmod.GeometryEncoder(preproc_type="bogus").encode(torch.zeros(1, 1, 32, 32))
+
+
+def test_tile_ops_needs_gpu(eng):
+    class FakeG:
+        img_resolution = 128
+        cfg = eng["cfg"]
+    with pytest.raises(RuntimeError):
+        painting.TileOps(FakeG(), None, device="cpu")
+
+
+# ---------------------------------------------------------------- the schedule on CPU (oracle stand-in)
+def _paint(eng, level, batch=4, group=None):
+    ops = OracleTileOps(eng["cfg"], eng["sd"], eng["esd"])
+    helper = painting.PaintingHelper(ops, batch=batch, group=group)
+    helper.set_feature_blending(level)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    res = helper.paint_image(eng["g"]["geom"], opts, crop_margin=int(eng["g"]["crop_margin"]), return_full=True)
+    return helper, res
+
+
+@pytest.mark.parametrize("level", [0, 2])
+def test_three_phase_schedule_matches_reference_canvas(eng, level):
+    helper, (out, full, crops, padded) = _paint(eng, level)
+    _canvas_close(full, eng["g"][f"canvas_level{level}_clear"])
+    if level == 2:
+        st = eng["g"]["feature_canvas_stats"]
+        assert float(helper.mask.sum()) == st[2]
+        np.testing.assert_allclose(helper.features[0, ::16, ::4, ::4].numpy(), eng["g"]["feature_canvas_sub"], atol=2e-5)
+
+
+def test_render_stroke_sequence_equals_batched_schedule(eng):
+    """The reference contract (one render_stroke per tile, canvas state in between) == one render_tiles call."""
+    g = eng["g"]
+    m = int(g["crop_margin"])
+    ops = OracleTileOps(eng["cfg"], eng["sd"], eng["esd"])
+    helper = painting.PaintingHelper(ops)
+    padded = g["geom_padded"]
+    helper.make_new_canvas(padded.shape[0], padded.shape[1], feature_blending=2)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    result = np.zeros(padded.shape + (4,), np.uint8)
+    for y, x in g["crops"][:5].tolist():
+        opts.set_position(x, y)
+        patch = (255 - padded[y:y + 128, x:x + 128])[..., None]
+        res, _, meta = helper.render_stroke(patch, None, opts, meta={"x": x, "y": y, "crop_margin": m})
+        assert res.shape == (128 - 2 * m, 128 - 2 * m, 4) and meta == {"x": x + m, "y": y + m}
+        result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+    h2 = painting.PaintingHelper(ops)
+    h2.make_new_canvas(padded.shape[0], padded.shape[1], feature_blending=2)
+    batched = h2.render_tiles(padded, g["crops"][:5], opts, crop_margin=m).numpy()
+    _canvas_close(result, batched)
+    assert torch.equal(helper.mask, h2.mask)
+    np.testing.assert_allclose(helper.features.numpy(), h2.features.numpy(), atol=1e-5)
+    with pytest.raises(RuntimeError):
+        helper.render_stroke(np.zeros((64, 64, 1), np.uint8), None, opts)
+    with pytest.raises(RuntimeError):
+        helper.set_render_mode("bogus")
+
+
+def test_user_colors_and_full_mode(eng):
+    g = eng["g"]
+    ops = OracleTileOps(eng["cfg"], eng["sd"], eng["esd"])
+    helper = painting.PaintingHelper(ops)
+    helper.set_render_mode("full")
+    opts = painting.GanBrushOptions(primary_color=np.array([255, 0, 0], np.uint8))
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    padded = g["geom_padded"]
+    out = helper.render_tiles(padded, g["crops"][:2], opts, crop_margin=0).numpy()
+    assert (out[:128, :128, 3] == 255).all()
+    P = po.OraclePainter(no.OracleGenerator(eng["cfg"], eng["sd"]), eng["esd"])
+    P.render_mode = "full"
+    y, x = g["crops"][1].tolist()
+    ref, _ = P.render_stroke((255 - padded[y:y + 128, x:x + 128])[..., None], z=eng["z"], x=x, y=y, position=(y, x),
+                             user_colors=opts.user_colors())
+    _canvas_close(out[y:y + 128, x:x + 128], ref)
+
+
+# ---------------------------------------------------------------- world size 2 (gloo)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    torch.set_num_threads(4)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("engine_r128.npz")
+        cfg = cfgmod.style1_config(128)
+        e = dict(g=g, cfg=cfg, sd=wmod.random_state_dict(cfg, seed=0), esd=encmod.random_encoder_state_dict(5),
+                 z=np.random.RandomState(594).randn(1, cfg.z_dim))
+        for level in (0, 2):
+            helper, res = _paint(e, level, batch=2)
+            if rank == 0:
+                np.save(os.path.join(tmp, f"full{level}.npy"), res[1])
+                if level == 2:
+                    np.save(os.path.join(tmp, "mask.npy"), helper.mask.numpy())
+            else:
+                assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_schedule_world2_gloo(eng, tmp_path):
+    """9 tiles over 2 ranks (5 + 4, padded all_gather of phase-1 features, padded RGBA gather)."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for level in (0, 2):
+        _canvas_close(np.load(tmp_path / f"full{level}.npy"), eng["g"][f"canvas_level{level}_clear"])
+    assert float(np.load(tmp_path / "mask.npy").sum()) == eng["g"]["feature_canvas_stats"][2]
