@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -59,7 +59,7 @@ PROTOTYPES = {
                                        C.c_float, C.c_float, C.c_float, vp]),
     "nb_modconv3x3_up2_f32_h2": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp, vp,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
-    "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int, vp, vp,
+    "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp,
                                      C.c_int, C.c_int, C.c_int, vp]),
     "nb_blend_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "nb_geom_tiles_f32": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]),

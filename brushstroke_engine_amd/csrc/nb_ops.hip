@@ -328,7 +328,7 @@ extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max
 // ------------------------------------------------------------------------------------------------
 struct TorgbParams {
     const float* x; const float* styles; const float* w; const float* bias; const float* color_bias;
-    float* logits; float* uvs; float* img; float* colors_out; const float* user_colors; float* rgba_f32; uint8_t* rgba_u8;
+    float* logits; float* uvs; float* img; float* colors_out; const float* user_colors; const float* sfactor; float* rgba_f32; uint8_t* rgba_u8;
     int styles_stride_n, c, hw, render_mode;
     float clamp;
 };
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
         for (int j = 0; j < V; ++j) { a0[j] += xv[j] * w0; a1[j] += xv[j] * w1; a2[j] += xv[j] * w2; }
     }
     const float b0 = p.bias[0], b1 = p.bias[1], b2 = p.bias[2];
+    const float sf = p.sfactor ? p.sfactor[n] : 0.f;
     float lg[3][V], uv[3][V], im[3][V], rg[4][V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -389,12 +390,21 @@ __global__ __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
         const float u = e0 * inv, v = e1 * inv, s = e2 * inv;
         lg[0][j] = l0; lg[1][j] = l1; lg[2][j] = l2;
         uv[0][j] = u; uv[1][j] = v; uv[2][j] = s;
+        // StyleUVSMapper._map_style_s (forger/ui/mapper.py:52-72): stretch the background weight S so that clear
+        // background becomes fully transparent, rescale U, V to keep the triple on the simplex
+        float um = u, vm = v, sm = s;
+        if (p.sfactor) {
+            sm = fminf(sf * s, 1.f);
+            const float delta = 1.f - sm;
+            const float f = delta <= 0.000001f ? 0.f : delta / (u + v);
+            um = f * u; vm = f * v;
+        }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             im[ch][j] = u * scol[ch * 3 + 0] + v * scol[ch * 3 + 1] + s * scol[ch * 3 + 2];
-            rg[ch][j] = u * scol01[ch * 3 + 0] + v * scol01[ch * 3 + 1] + s * scol01[ch * 3 + 2];
+            rg[ch][j] = um * scol01[ch * 3 + 0] + vm * scol01[ch * 3 + 1] + sm * scol01[ch * 3 + 2];
         }
-        rg[3][j] = p.render_mode == 0 ? u + v : 1.f;
+        rg[3][j] = p.render_mode == 0 ? um + vm : 1.f;
     }
     auto put = [&](float* base, int nch, int ch, const float (&vals)[V]) {
         float* dst = base + ((size_t)n * nch + ch) * p.hw + pix;
@@ -430,15 +440,15 @@ __global__ __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
 
 extern "C" int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n, const float* w,
                                   const float* bias, const float* color_bias, float clamp, float* logits, float* uvs,
-                                  float* img, float* colors_out, const float* user_colors, int render_mode,
-                                  float* rgba_f32, uint8_t* rgba_u8, int n, int c, int hw, void* stream) {
+                                  float* img, float* colors_out, const float* user_colors, const float* sfactor,
+                                  int render_mode, float* rgba_f32, uint8_t* rgba_u8, int n, int c, int hw, void* stream) {
     NB_REQUIRE(x && styles && w && bias && color_bias, "torgb_triad: null pointer");
     NB_REQUIRE(n >= 1 && n <= 65535 && c >= 1 && c <= 4096 && hw >= 1, "torgb_triad: bad sizes");
     NB_REQUIRE(styles_stride_n >= c + 9, "torgb_triad: styles rows must hold 9 color scalars + c styles");
     NB_REQUIRE(render_mode == 0 || render_mode == 1, "Unknown render mode for TriadGanPaintEngine: %d", render_mode);
     TorgbParams p;
     p.x = x; p.styles = styles; p.w = w; p.bias = bias; p.color_bias = color_bias; p.logits = logits; p.uvs = uvs; p.img = img;
-    p.colors_out = colors_out; p.user_colors = user_colors; p.rgba_f32 = rgba_f32; p.rgba_u8 = rgba_u8;
+    p.colors_out = colors_out; p.user_colors = user_colors; p.sfactor = sfactor; p.rgba_f32 = rgba_f32; p.rgba_u8 = rgba_u8;
     p.styles_stride_n = styles_stride_n; p.c = c; p.hw = hw; p.render_mode = render_mode; p.clamp = clamp;
     const size_t lds = (size_t)(3 * c + 18) * sizeof(float);
     const bool vec = (hw % 4 == 0) && ((uintptr_t)x % 16 == 0);

@@ -506,7 +506,7 @@ class SynthesisNetwork(torch.nn.Module):
         uvs = torch.empty([n, 3, r, r], dtype=torch.float32, device=dev)
         img = torch.empty([n, 3, r, r], dtype=torch.float32, device=dev)
         colors = torch.empty([n, 3, 3], dtype=torch.float32, device=dev)
-        logits = rgba = rgba8 = user = None
+        logits = rgba = rgba8 = user = sfac = None
         mode = 0
         if extra is not None:
             if extra.get("logits"):
@@ -519,6 +519,11 @@ class SynthesisNetwork(torch.nn.Module):
             if user is not None:
                 user = user.to(device=dev, dtype=torch.float32).contiguous()
                 _assert_shape(user, [n, 3, 3])
+            sfac = extra.get("sfactor")
+            if sfac is not None:
+                sfac = torch.as_tensor(sfac, dtype=torch.float32, device=dev).reshape(-1)
+                sfac = (sfac.expand(n) if sfac.numel() == 1 else sfac).contiguous()
+                _assert_shape(sfac, [n])
             mode = {"clear": 0, "full": 1}.get(extra.get("render_mode", "clear"), -1)
             if mode < 0:
                 raise RuntimeError("Unknown render mode for TriadGanPaintEngine: {}".format(extra.get("render_mode")))
@@ -526,7 +531,7 @@ class SynthesisNetwork(torch.nn.Module):
         ev = self._begin_event("torgb")
         _lib.check(_lib.lib().nb_torgb_triad_f32(
             _p(x), _p(plan.styles[-1]), c + 9, _p(self.packed["torgb"]["w"]), _p(t.bias), _p(t.color_bias), clamp,
-            _p(logits), _p(uvs), _p(img), _p(colors), _p(user), mode, _p(rgba), _p(rgba8), n, c, r * r, stream),
+            _p(logits), _p(uvs), _p(img), _p(colors), _p(user), _p(sfac), mode, _p(rgba), _p(rgba8), n, c, r * r, stream),
             "torgb_triad")
         self._end_event(ev)
         if extra is not None:
@@ -609,10 +614,11 @@ class Generator(torch.nn.Module):
                                        noise_buffers=noise_buffers, **synthesis_kwargs)
 
     def render_triad(self, z=None, ws=None, geom_feature=None, positions=None, render_mode="clear", user_colors=None,
-                     want_u8=True, want_f32=False, **kw):
+                     want_u8=True, want_f32=False, sfactor=None, **kw):
         """Generator + the paint engine's compositing (brush.py:763-792) fused into the ToRGB launch.
         Returns (rgba_u8 [N,R,R,4] | None, rgba_f32 [N,4,R,R] | None, debug dict with uvs/colors)."""
-        extra = {"rgba_u8": want_u8, "rgba": want_f32, "render_mode": render_mode, "user_colors": user_colors}
+        extra = {"rgba_u8": want_u8, "rgba": want_f32, "render_mode": render_mode, "user_colors": user_colors,
+                 "sfactor": sfactor}
         kw.setdefault("noise_mode", "const")
         if ws is None:
             img, dbg = self.forward(z, None, geom_feature, positions=positions, return_debug_data=True,

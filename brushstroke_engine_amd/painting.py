@@ -255,15 +255,20 @@ class TileOps:
     def head(self, ws, geom_feats, positions, stop_res: int) -> torch.Tensor:
         return self.G.forward_pre_mapped(ws, geom_feats, positions=positions, noise_mode="const", _stop_after=stop_res)
 
-    def tail(self, ws, feats, geom_feats, positions, resume_res: int, render_mode, user_colors) -> torch.Tensor:
+    def tail(self, ws, feats, geom_feats, positions, resume_res: int, render_mode, user_colors, sfactor=None) -> torch.Tensor:
         u8, _, _ = self.G.render_triad(ws=ws, geom_feature=geom_feats, positions=positions, render_mode=render_mode,
-                                       user_colors=user_colors, _resume=(resume_res, feats))
+                                       user_colors=user_colors, sfactor=sfactor, _resume=(resume_res, feats))
         return u8
 
-    def full(self, ws, geom_feats, positions, render_mode, user_colors) -> torch.Tensor:
+    def full(self, ws, geom_feats, positions, render_mode, user_colors, sfactor=None) -> torch.Tensor:
         u8, _, _ = self.G.render_triad(ws=ws, geom_feature=geom_feats, positions=positions, render_mode=render_mode,
-                                       user_colors=user_colors)
+                                       user_colors=user_colors, sfactor=sfactor)
         return u8
+
+    def background_weight(self, ws, geom_feats) -> torch.Tensor:
+        """S = uvs[:, 2:3] of an un-positioned render (what StyleUVSMapper calibrates on, mapper.py:74-87)."""
+        _, dbg = self.G.forward_pre_mapped(ws, geom_feats, return_debug_data=True, noise_mode="const")
+        return dbg["uvs"][:, 2:3]
 
     # -- canvas kernels --
     def new_feature_canvas(self, c, hc, wc):
@@ -290,6 +295,44 @@ class TileOps:
 
 
 # ------------------------------------------------------------------------------------------------
+# clear-background mapping (reference: StyleUVSMapper, forger/ui/mapper.py:16-72, 117-135)
+# ------------------------------------------------------------------------------------------------
+class StyleUVSMapper:
+    """Per-style scale ``sfactor`` that stretches the background weight S of the triad so that clear background
+    renders fully transparent; the remap itself (``_map_style_s``) is fused into the ToRGB launch
+    (``nb_torgb_triad_f32(sfactor=...)``).  The reference calibrates on five bundled drawings at two stroke widths
+    (``*_rad016.png`` / ``*_rad025.png``); they are data files of the reference, so the caller supplies them."""
+
+    def __init__(self, ops, cal_medium: Optional[np.ndarray] = None, cal_thick: Optional[np.ndarray] = None):
+        self.ops = ops
+        self.sfactors: Dict = {}
+        self.geom_feature = self.bmask = None
+        if cal_medium is not None:
+            self.set_calibration(cal_medium, cal_thick)
+
+    def set_calibration(self, cal_medium: np.ndarray, cal_thick: np.ndarray):
+        """[k,R,R] uint8 drawings, 0 = stroke: medium strokes are rendered, thick ones define "surely background"."""
+        geo = (self.ops.to_device(np.asarray(cal_medium, np.uint8)).to(torch.float32) / 255).unsqueeze(1)
+        self.geom_feature = self.ops.encode(geo)
+        self.bmask = (self.ops.to_device(np.asarray(cal_thick, np.uint8)).to(torch.float32) / 255).unsqueeze(1) > 0.99
+        self.sfactors = {}
+
+    def get_sfactor(self, opts) -> torch.Tensor:
+        if opts.style_id is not None and opts.style_id in self.sfactors:
+            return self.sfactors[opts.style_id]
+        if self.geom_feature is None:
+            raise RuntimeError("StyleUVSMapper: no calibration drawings set (set_calibration)")
+        n = self.geom_feature[0].shape[0]
+        ws = self.ops.map_style(z=opts.style_z, ws=opts.style_ws).expand(n, -1, -1).contiguous()
+        S = self.ops.background_weight(ws, self.geom_feature)
+        val = torch.stack([torch.topk(S[i][self.bmask[i]], k=15)[0].min() for i in range(n)]).min()
+        sfactor = 1 / val
+        if opts.style_id is not None:
+            self.sfactors[opts.style_id] = sfactor
+        return sfactor
+
+
+# ------------------------------------------------------------------------------------------------
 # the painting helper
 # ------------------------------------------------------------------------------------------------
 class PaintingHelper:
@@ -300,8 +343,9 @@ class PaintingHelper:
 
     feature_blending_margin = 16
 
-    def __init__(self, ops: TileOps, batch: int = 32, group=None):
+    def __init__(self, ops: TileOps, batch: int = 32, group=None, uvs_mapper: Optional[StyleUVSMapper] = None):
         self.ops = ops
+        self.uvs_mapper = uvs_mapper
         self.batch = int(batch)
         self.group = group
         self.patch_width = ops.patch_width
@@ -358,6 +402,11 @@ class PaintingHelper:
         geom_dev = ops.to_device(np.ascontiguousarray(geom_img))
         ws1 = ops.map_style(z=opts.style_z, ws=opts.style_ws)                  # one brush style for all tiles
         user = opts.user_colors()
+        sfac = None
+        if opts.enable_uvs_mapping:                                            # brush.py:773-774
+            if self.uvs_mapper is None:
+                raise RuntimeError("opts.enable_uvs_mapping needs a StyleUVSMapper (PaintingHelper(uvs_mapper=...))")
+            sfac = self.uvs_mapper.get_sfactor(opts)
         own_yx = ops.to_device(geom_yx[t0:t1].astype(np.int32)) if n_own else None
         own_pos = ops.to_device(positions[t0:t1].astype(np.int64)) if (positions is not None and n_own) else None
 
@@ -378,7 +427,7 @@ class PaintingHelper:
         if level == 0:
             for b0, b1 in batches():
                 g = ops.geom_tiles(geom_dev, own_yx[b0:b1])
-                outs.append(ops.full(style(b1 - b0), ops.encode(g), pos(b0, b1), self.render_mode, colors(b1 - b0)))
+                outs.append(ops.full(style(b1 - b0), ops.encode(g), pos(b0, b1), self.render_mode, colors(b1 - b0), sfac))
         else:
             bres = R // df
             C = ops.cfg.channels(bres)
@@ -413,7 +462,7 @@ class PaintingHelper:
             # phase 3: last block(s) + ToRGB + compositing on the blended features, own tiles
             for i, (b0, b1) in enumerate(batches()):
                 outs.append(ops.tail(style(b1 - b0), mine[b0:b1], geom_feats_own[i], pos(b0, b1), bres,
-                                     self.render_mode, colors(b1 - b0)))
+                                     self.render_mode, colors(b1 - b0), sfac))
         rgba_own = torch.cat(outs) if outs else None
         if world == 1:
             return rgba_own

@@ -174,14 +174,16 @@ int nb_modconv3x3_up2_f32_h2(const float* x1, int c1, const float* x2, int c2, c
  *   img[n,ch] = sum_k uvs_k * colors[n,ch,k]            (colors = tanh(affine[:, :9] + color_bias))
  * plus, optionally, the paint engine's compositing (forger/ui/brush.py:763-792):
  *   rgba[:3] = sum_k uvs_k * col01[n,:,k], rgba[3] = u+v ('clear', render_mode 0) or 1 ('full', 1)
- *   with col01 = user_colors (where not NaN) else (colors+1)/2; rgba_f32 is [n,4,hw];
+ *   with col01 = user_colors (where not NaN) else (colors+1)/2; if sfactor [n] is given, (u,v,s) are first remapped
+ *   per StyleUVSMapper._map_style_s (forger/ui/mapper.py:52-72; brush.py:773-774): s' = min(sfactor*s, 1),
+ *   (u',v') = (u,v) * (1-s')/(u+v) (0 where 1-s' <= 1e-6) -- only in the RGBA outputs; rgba_f32 is [n,4,hw];
  *   rgba_u8 = trunc(clip(rgba*255, 0, 255)) is [n,hw,4] bytes (HWC, as brush.py:377 hands it out).
  * colors_raw is the [n, c_aff] affine output whose first 9 entries are the un-biased color scalars.
  * Any of logits / uvs / img / colors_out / rgba_f32 / rgba_u8 may be NULL. */
 int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n, const float* w, const float* bias,
                        const float* color_bias, float clamp, float* logits, float* uvs, float* img,
-                       float* colors_out, const float* user_colors, int render_mode, float* rgba_f32,
-                       uint8_t* rgba_u8, int n, int c, int hw, void* stream);
+                       float* colors_out, const float* user_colors, const float* sfactor, int render_mode,
+                       float* rgba_f32, uint8_t* rgba_u8, int n, int c, int hw, void* stream);
 
 /* BlendedFeatures.blend (forger/train/stitching.py:24-25): y = alpha*F + (1-alpha)*x over
  * x [n,c,hw]; F is [nf,c,hw] and alpha [na,1,hw] with nf, na in {1, n} (broadcast). */

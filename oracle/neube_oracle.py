@@ -370,7 +370,17 @@ class OracleGenerator:
 # Engine compositing (L3, row a15)
 # ----------------------------------------------------------------------------------------------
 
-def triad_composite(uvs, colors, render_mode="clear", user_colors=None):
+def map_style_s(sfactor, uvs):
+    """``StyleUVSMapper._map_style_s`` (forger/ui/mapper.py:52-72): S' = min(sfactor*S, 1); (U', V') = (U, V) scaled
+    so that U'+V'+S' = 1 (zero where 1-S' <= 1e-6)."""
+    U, V, S = uvs[:, 0:1], uvs[:, 1:2], uvs[:, 2:3]
+    Sp = torch.clamp(sfactor * S, max=1.0)
+    delta = 1 - Sp
+    f = torch.where(delta <= 0.000001, torch.zeros_like(delta), delta / (U + V))
+    return torch.cat([f * U, f * V, Sp], dim=1)
+
+
+def triad_composite(uvs, colors, render_mode="clear", user_colors=None, sfactor=None):
     """``forger/ui/brush.py:763-792`` (TriadGanPaintEngine._render_stroke_torch, enable_uvs_mapping=False).
 
     default_colors = (colors+1)/2 [N,3(rgb),3(k)]; ``user_colors`` (same layout, NaN = keep default)
@@ -378,6 +388,8 @@ def triad_composite(uvs, colors, render_mode="clear", user_colors=None):
     'full': alpha = 1.  Returns RGBA float [N,4,R,R] in [0,1].
     """
     default_colors = (colors + 1) / 2.0
+    if sfactor is not None:                        # brush.py:773-774, enable_uvs_mapping
+        uvs = map_style_s(sfactor, uvs)
     if user_colors is not None:
         uc = _t(user_colors, colors.dtype)
         default_colors = torch.where(torch.isnan(uc), default_colors, uc)

@@ -118,6 +118,23 @@ class OraclePainter:
         self.level = 0
         self.features = self.mask = None
         self.render_mode = "clear"
+        self.sfactor = None            # set to enable UVS mapping (brush.py:773-774)
+
+    def compute_sfactor(self, cal_medium: np.ndarray, cal_thick: np.ndarray, z=None, ws=None):
+        """``StyleUVSMapper.get_sfactor`` (forger/ui/mapper.py:117-135) on caller-provided calibration drawings
+        [5,R,R] uint8 (medium / thick strokes, 0 = stroke): 1 / (min over drawings of the 15th largest background
+        weight S among the pixels that are background even in the thick version)."""
+        geo = (torch.from_numpy(cal_medium).to(torch.float32) / 255).unsqueeze(1)
+        bmask = (torch.from_numpy(cal_thick).to(torch.float32) / 255).unsqueeze(1) > 0.99
+        feats = encoder_encode(self.esd, geo, self.preproc)
+        n = geo.shape[0]
+        if ws is not None:
+            _, dbg = self.G.forward_pre_mapped(torch.as_tensor(ws).expand(n, -1, -1), feats, return_debug_data=True)
+        else:
+            _, dbg = self.G.forward(np.repeat(np.asarray(z), n, axis=0), None, feats, return_debug_data=True)
+        S = dbg["uvs"][:, 2:3]
+        val = torch.stack([torch.topk(S[i][bmask[i]], k=15)[0].min() for i in range(n)]).min()
+        return 1 / val
 
     def make_new_canvas(self, rows, cols, feature_blending=0):
         self.level = feature_blending
@@ -160,7 +177,7 @@ class OraclePainter:
             _, dbg = self.G.forward_pre_mapped(ws, feats, positions=pos, return_debug_data=True, **kw)
         else:
             _, dbg = self.G.forward(z, None, feats, positions=pos, return_debug_data=True, **kw)
-        rgba = no.triad_composite(dbg["uvs"], dbg["colors"], self.render_mode, user_colors)
+        rgba = no.triad_composite(dbg["uvs"], dbg["colors"], self.render_mode, user_colors, self.sfactor)
         if self.level > 0:
             fnew = dbg[f"features{bres}"]
             if self.features is None:

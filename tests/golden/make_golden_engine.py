@@ -118,6 +118,42 @@ def main():
                                                         float(helper.feature_canvas.features.double().square().sum()),
                                                         float(helper.feature_canvas.mask.sum())])
                 out["feature_canvas_sub"] = helper.feature_canvas.features[0, ::16, ::4, ::4].numpy()
+    # StyleUVSMapper (forger/ui/mapper.py:46-72, 117-135): the bundled calibration drawings need torchvision to be
+    # resized, so synthetic stand-ins (five strokes at two thicknesses) are installed the way _init_geometry would
+    cal = np.full((2, 5, R, R), 255, np.uint8)
+    for i in range(5):
+        for thick, half in ((0, 3), (1, 6)):                # [0] medium, [1] thick
+            for t in np.linspace(0, 1, 400):
+                yy = int(R * (0.2 + 0.6 * t))
+                xx = int(R * (0.5 + 0.3 * np.sin(t * (i + 1) * 1.7 + i)))
+                cal[thick, i, max(yy - half, 0):yy + half, max(xx - half, 0):xx + half] = 0
+    out["uvs_cal_medium"], out["uvs_cal_thick"] = cal[0], cal[1]
+    mapper = eng.uvs_mapper
+    geo_input = (torch.from_numpy(cal[0]).to(torch.float32) / 255).unsqueeze(1)
+    mapper.geom_feature = eng.encoder.encode(geo_input)
+    mapper.fmask = geo_input < 0.01
+    mapper.bmask = (torch.from_numpy(cal[1]).to(torch.float32) / 255).unsqueeze(1) > 0.99
+    opts = brush.GanBrushOptions()
+    opts.set_style(eng.random_style(594), 594)
+    opts.enable_uvs_mapping = True
+    with torch.no_grad():
+        out["uvs_sfactor"] = np.float32(mapper.get_sfactor(opts))
+        helper = brush.PaintingHelper(eng, style_seed=0)
+        helper.make_new_canvas(gpad.shape[0], gpad.shape[1], feature_blending=2)
+        helper.set_render_mode("clear")
+        result = np.zeros((gpad.shape[0], gpad.shape[1], 4), np.uint8)
+        for (y, x, _, _) in crops:
+            opts.set_position(x, y)
+            res, _, meta = helper.render_stroke(255 - gpad[y:y + R, x:x + R, :], None, opts,
+                                                meta={"x": x, "y": y, "crop_margin": crop_margin})
+            result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+        out["canvas_level2_clear_uvsmap"] = result
+    # _map_style_s known-answer (pointwise), including the S' >= 1 and delta <= EPS branches
+    rs2 = np.random.RandomState(7)
+    lg = torch.from_numpy(rs2.randn(2, 3, 16, 16).astype(np.float32) * 3)
+    uvs_in = torch.softmax(lg, dim=1)
+    out["uvsmap_in"] = uvs_in.numpy()
+    out["uvsmap_out"] = mapper._map_style_s(torch.tensor(np.float32(1.7)), uvs_in).numpy()
     # encoder KAT: features for the first tile
     y, x = crops[0][:2]
     g0 = eng.prepare_geom_input(255 - gpad[y:y + R, x:x + R, :])

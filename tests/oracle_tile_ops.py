@@ -36,17 +36,21 @@ class OracleTileOps:
         _, dbg = self.G.forward_pre_mapped(ws, geom_feats, positions=positions, return_features=[stop_res])
         return dbg[f"features{stop_res}_preblend"]
 
-    def tail(self, ws, feats, geom_feats, positions, resume_res, render_mode, user_colors):
+    def tail(self, ws, feats, geom_feats, positions, resume_res, render_mode, user_colors, sfactor=None):
         one = torch.ones([1, 1, resume_res, resume_res])
         _, dbg = self.G.forward_pre_mapped(ws, geom_feats, positions=positions, return_debug_data=True,
                                            blended_features={resume_res: {"features": feats, "alpha": one}})
-        rgba = no.triad_composite(dbg["uvs"], dbg["colors"], render_mode, user_colors)
+        rgba = no.triad_composite(dbg["uvs"], dbg["colors"], render_mode, user_colors, sfactor)
         return no.rgba_to_uint8(rgba).permute(0, 2, 3, 1).contiguous()
 
-    def full(self, ws, geom_feats, positions, render_mode, user_colors):
+    def full(self, ws, geom_feats, positions, render_mode, user_colors, sfactor=None):
         _, dbg = self.G.forward_pre_mapped(ws, geom_feats, positions=positions, return_debug_data=True)
-        rgba = no.triad_composite(dbg["uvs"], dbg["colors"], render_mode, user_colors)
+        rgba = no.triad_composite(dbg["uvs"], dbg["colors"], render_mode, user_colors, sfactor)
         return no.rgba_to_uint8(rgba).permute(0, 2, 3, 1).contiguous()
+
+    def background_weight(self, ws, geom_feats):
+        _, dbg = self.G.forward_pre_mapped(ws, geom_feats, return_debug_data=True)
+        return dbg["uvs"][:, 2:3]
 
     def new_feature_canvas(self, c, hc, wc):
         return torch.zeros([1, c, hc, wc]), torch.zeros([hc, wc], dtype=torch.uint8)

@@ -150,3 +150,28 @@ def test_encoder_on_gpu_matches_reference(eng):
     f = eng["ops"].encode(torch.from_numpy(g["enc_in"]).cuda())
     np.testing.assert_allclose(f[0].cpu().numpy(), g["enc_f0"], atol=2e-5)
     np.testing.assert_allclose(f[1].cpu().numpy()[:, ::8], g["enc_f1"], atol=2e-5)
+
+
+def test_uvs_mapping_on_gpu(eng):
+    """enable_uvs_mapping: sfactor calibration + the remap fused into the ToRGB launch, against the reference."""
+    g = eng["g"]
+    from oracle import neube_oracle as no
+    mapper = painting.StyleUVSMapper(eng["ops"], g["uvs_cal_medium"], g["uvs_cal_thick"])
+    helper = painting.PaintingHelper(eng["ops"], batch=4, uvs_mapper=mapper)
+    helper.set_feature_blending(2)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    opts.enable_uvs_mapping = True
+    _, full, _, _ = helper.paint_image(g["geom"], opts, crop_margin=int(g["crop_margin"]), return_full=True)
+    np.testing.assert_allclose(float(mapper.get_sfactor(opts)), float(g["uvs_sfactor"]), rtol=1e-4)
+    _canvas_close(full, g["canvas_level2_clear_uvsmap"], max_frac=2e-3)
+    # pointwise remap, float outputs
+    G, cfg = eng["G"], eng["cfg"]
+    from brushstroke_engine_amd import synthetic
+    n = 2
+    ws = G.mapping(torch.from_numpy(synthetic.batch_z(cfg, n)).cuda(), None)
+    gf = [torch.from_numpy(a).cuda() for a in synthetic.geom_features(cfg, n, seed=2)]
+    _, rgba, dbg = G.render_triad(ws=ws, geom_feature=gf, want_f32=True, sfactor=torch.tensor([1.7, 1.2]))
+    for i, sf in enumerate((1.7, 1.2)):
+        ref = no.triad_composite(dbg["uvs"][i:i + 1].cpu(), dbg["colors"][i:i + 1].cpu(), "clear", None, torch.tensor(np.float32(sf)))
+        np.testing.assert_allclose(rgba[i:i + 1].cpu().numpy(), ref.numpy(), atol=2e-6)

@@ -242,3 +242,33 @@ def test_sharded_schedule_world2_gloo(eng, tmp_path):
     for level in (0, 2):
         _canvas_close(np.load(tmp_path / f"full{level}.npy"), eng["g"][f"canvas_level{level}_clear"])
     assert float(np.load(tmp_path / "mask.npy").sum()) == eng["g"]["feature_canvas_stats"][2]
+
+
+# ---------------------------------------------------------------- clear-background (UVS) mapping
+def test_oracle_uvs_mapping_matches_reference(eng):
+    g = eng["g"]
+    out = no.map_style_s(torch.tensor(np.float32(1.7)), torch.from_numpy(g["uvsmap_in"]))
+    np.testing.assert_array_equal(out.numpy(), g["uvsmap_out"])
+    assert (out.sum(dim=1) - 1).abs().max() < 1e-5 or (out[:, 2] == 1).any()
+    P = po.OraclePainter(no.OracleGenerator(eng["cfg"], eng["sd"]), eng["esd"])
+    sf = P.compute_sfactor(g["uvs_cal_medium"], g["uvs_cal_thick"], z=eng["z"])
+    np.testing.assert_allclose(float(sf), float(g["uvs_sfactor"]), rtol=1e-5)
+    P.sfactor = sf
+    _, full, _, _ = P.paint_image(g["geom"][..., None], z=eng["z"], crop_margin=int(g["crop_margin"]), feature_blending=2)
+    _canvas_close(full, g["canvas_level2_clear_uvsmap"])
+
+
+def test_schedule_with_uvs_mapping(eng):
+    g = eng["g"]
+    ops = OracleTileOps(eng["cfg"], eng["sd"], eng["esd"])
+    mapper = painting.StyleUVSMapper(ops, g["uvs_cal_medium"], g["uvs_cal_thick"])
+    helper = painting.PaintingHelper(ops, batch=4, uvs_mapper=mapper)
+    helper.set_feature_blending(2)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    opts.enable_uvs_mapping = True
+    _, full, _, _ = helper.paint_image(g["geom"], opts, crop_margin=int(g["crop_margin"]), return_full=True)
+    np.testing.assert_allclose(float(mapper.get_sfactor(opts)), float(g["uvs_sfactor"]), rtol=1e-5)
+    _canvas_close(full, g["canvas_level2_clear_uvsmap"])
+    with pytest.raises(RuntimeError):
+        painting.PaintingHelper(ops).render_tiles(g["geom_padded"], g["crops"][:1], opts)
