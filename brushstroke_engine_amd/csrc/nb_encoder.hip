@@ -1,0 +1,434 @@
+// Geometry encoder of the painting engine for gfx950.
+//
+// Reference: forger/experimental/autoenc/simple_autoencoder.py:88-121, 155-199, 251-261 -- a stack of
+//   conv (reflect padding) -> eval-mode BatchNorm -> LeakyReLU(0.01):
+//   stem 1->64 7x7 | 64->128, 128->256, 256->256 3x3 stride 2 | 256->32, 32->16 3x3 | bilinear x2 + 16->256 3x3.
+// BatchNorm is folded into the conv weights / bias on the host, so every layer is conv + bias + LeakyReLU.
+//
+// Three kernels:
+//   enc_stem7x7_kernel   C_in = 1: no channel contraction to feed the f16 matrix cores with, so the 49 taps are the
+//                        K dimension of v_mfma_f32_32x32x2_f32 (exact fp32); all weights of a wave live in 50
+//                        registers, B operands are single-dword LDS reads of the reflect-padded image tile.
+//   enc_conv3x3_h3_kernel  3x3, stride 1 or 2, split-f16 products (see nb_modconv_h3.hip for the arithmetic and
+//                        the H2 activation format).  K loop = (16-channel chunk, tap row); per step the activation
+//                        rows that tap row needs are gathered by LDS-DMA with per-lane source addresses -- for
+//                        stride 2 the even and odd input columns land in two planes, so every MFMA B fragment is a
+//                        stride-1 ds_read_b128 whatever the conv stride, and reflect padding is just address
+//                        arithmetic in the gather.  Steps are double buffered (DMA of step t+1 under the MFMAs of t).
+//   enc_upsample2x_h2_kernel  bilinear x2, align_corners=True, fp32 NCHW -> H2 (input of the decoder conv).
+// Layer outputs go out as H2 (next layer's input) or fp32 NCHW (what the generator consumes).
+#include "nb_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define NB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+extern "C" const float* nb_zero_page_ptr(void);
+
+__device__ __forceinline__ int nb_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__device__ __forceinline__ float nb_lrelu(float v, float slope) { return v < 0.f ? v * slope : v; }
+
+// ------------------------------------------------------------------------------------------------
+// stem: 1 -> 64 channels, 7x7, reflect padding 3; fp32 [n,1,h,w] -> H2 [n,8,2,h,w,8]
+// ------------------------------------------------------------------------------------------------
+struct StemParams {
+    const float* x; const float* w50; const float* bias; _Float16* y;
+    int h, w, tiles_x, preproc;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
+    constexpr int TR = 16, TC = 32, PR = TR + 6, PC = TC + 6, NBW = 4, KS = 25, CP = 72;   // CP: padded channel pitch (halves)
+    __shared__ float tile[PR * PC];
+    __shared__ __attribute__((aligned(16))) _Float16 stage[4][2][32 * CP];                   // per wave: [hi/lo][pixel][channel]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lh = lane >> 5, l31 = lane & 31;
+    const int n = blockIdx.y;
+    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
+    const int y0 = ty * TR, x0 = tx * TC;
+    const float* xn = p.x + (size_t)n * p.h * p.w;
+    for (int e = tid; e < PR * PC; e += 256) {
+        const int r = e / PC, c = e - r * PC;
+        float v = xn[(size_t)nb_reflect(y0 + r - 3, p.h) * p.w + nb_reflect(x0 + c - 3, p.w)];
+        if (p.preproc == 1) v = (1.f - v) * 2.f - 1.f;          // '-11inverse' (autoenc/base.py:30-52)
+        else if (p.preproc == 2) v = 1.f - v;                   // 'inverse'
+        tile[e] = v;
+    }
+    // A fragments: lane (row = c_out l31, k = lh) of k-step s holds w[c_out][tap 2s + lh]  (taps 49.. are zero)
+    float wa[2][KS];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wa[mb][s] = p.w50[(mb * 32 + l31) * 50 + 2 * s + lh];
+    __syncthreads();
+
+    f32x16 acc[2][NBW];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    const float* tb = tile + (wv * NBW) * PC + l31;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t0 = 2 * s, t1 = 2 * s + 1 < 49 ? 2 * s + 1 : 48;
+        const int off = lh ? (t1 / 7) * PC + (t1 % 7) : (t0 / 7) * PC + (t0 % 7);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const float b = tb[nb * PC + off];
+            acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], b, acc[0][nb], 0, 0, 0);
+            acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], b, acc[1][nb], 0, 0, 0);
+        }
+    }
+    // epilogue: bias, LeakyReLU, hi/lo split, transpose through LDS to 16-byte H2 slots
+    _Float16* sh = stage[wv][0];
+    _Float16* sl = stage[wv][1];
+    const size_t HW8 = (size_t)p.h * p.w * 8;
+    _Float16* yn = p.y + (size_t)n * 8 * 2 * HW8;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = mb * 32 + 8 * g + 4 * lh;
+                h4 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = nb_lrelu(acc[mb][nb][4 * g + j] + p.bias[co + j], p.slope);
+                    const _Float16 hi = (_Float16)v;
+                    vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                }
+                *reinterpret_cast<h4*>(sh + l31 * CP + co) = vh;
+                *reinterpret_cast<h4*>(sl + l31 * CP + co) = vl;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes are done (wave-private stage)
+        const int oy = y0 + wv * NBW + nb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = i * 64 + lane;             // 512 slots: [cg 8][hl 2][px 32]
+            const int cg = q >> 6, hl = (q >> 5) & 1, px = q & 31;
+            const h8 v = *reinterpret_cast<const h8*>((hl ? sl : sh) + px * CP + cg * 8);
+            *reinterpret_cast<h8*>(yn + (size_t)(cg * 2 + hl) * HW8 + ((size_t)oy * p.w + x0 + px) * 8) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
+extern "C" int nb_enc_stem7x7_f32_h2(const float* x, const float* w50, const float* bias, void* y_h2, int n, int h, int w,
+                                     int preproc, float slope, void* stream) {
+    NB_REQUIRE(x && w50 && bias && y_h2, "enc_stem7x7: null pointer");
+    NB_REQUIRE(n >= 1 && n <= 65535 && h % 16 == 0 && w % 32 == 0 && h >= 16 && w >= 32,
+               "enc_stem7x7: needs h %% 16 == 0 and w %% 32 == 0 (got %dx%d)", h, w);
+    NB_REQUIRE(preproc >= 0 && preproc <= 2, "Unknown preprocessing type %d", preproc);
+    NB_REQUIRE((uintptr_t)y_h2 % 16 == 0, "enc_stem7x7: output must be 16-byte aligned");
+    StemParams p{x, w50, bias, (_Float16*)y_h2, h, w, w / 32, preproc, slope};
+    hipLaunchKernelGGL(enc_stem7x7_kernel, dim3((w / 32) * (h / 16), n), dim3(256), 0, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("enc_stem7x7");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv, stride 1 or 2, reflect padding 1, split-f16
+// ------------------------------------------------------------------------------------------------
+struct EncConvParams {
+    const _Float16* x;      // H2 [n][c8][2][hin][win][8]
+    const _Float16* wts;    // [nchunks][3][3][2][2][co_ld][8], co_ld % 128 == 0
+    const float* bias;      // [c_out]
+    float* y32;             // fp32 NCHW [n][c_out][hout][wout]      (OUT == 0)
+    _Float16* yh2;          // H2 [n][c_out/8][2][hout][wout][8]     (OUT == 1)
+    const float* zeros;
+    int c8, nchunks, c_out, co_ld, hin, win, hout, wout, tiles_x, tiles_y, slices;
+    float slope;
+};
+
+template <int STRIDE, int LW, int OUT>
+__global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams p) {
+    constexpr int NW = 8, NWN = 4, MB = 2, NBW = 2, CO_WG = 128;
+    constexpr int WT = 1 << LW, RPB = 32 / WT, TH = NWN * NBW * RPB, PW = WT + 2;      // output tile TH x WT = 256 pixels
+    constexpr int SLOTS = STRIDE * TH * PW;             // 16-byte slots of one (cgroup, hi/lo) plane of a step
+    constexpr int PP = (SLOTS + 63) / 64, XPL = PP * 64;
+    constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;
+    constexpr int WSLOTS = 12 * CO_WG, NWP = WSLOTS / 64, NWPW = NWP / NW;
+    constexpr int KX0 = STRIDE == 2 ? TH * PW : 0, KX1 = STRIDE == 2 ? 0 : 1, KX2 = STRIDE == 2 ? TH * PW + 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_enc[];
+    h8* xbuf = reinterpret_cast<h8*>(smem_enc);         // [2][4][XPL]
+    h8* wbuf = xbuf + 2 * 4 * XPL;                      // [2][WSLOTS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
+    const int wm = wv / NWN, wn = wv - wm * NWN;
+    int b = blockIdx.x;
+    const int slice = b % p.slices; b /= p.slices;
+    const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
+    const int n = blockIdx.y;
+    const int y0 = tile_y * TH, x0 = tile_x * WT, co0 = slice * CO_WG;
+    const size_t HW8 = (size_t)p.hin * p.win * 8;
+    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+
+    // gather descriptors of this wave's activation pieces
+    int xcol[NXPW], xrow[NXPW], xpl[NXPW], xdst[NXPW];
+#pragma unroll
+    for (int i = 0; i < NXPW; ++i) {
+        int q = i * NW + wv;
+        q = q < NXP ? q : NXP - 1;
+        const int pl4 = q / PP, part = q - pl4 * PP;
+        const int e = part * 64 + lane;
+        xpl[i] = pl4;
+        xdst[i] = pl4 * XPL + part * 64;
+        bool valid = e < SLOTS;
+        int r, ix;
+        if (STRIDE == 1) {
+            r = e / PW;
+            ix = nb_reflect(x0 + (e - r * PW) - 1, p.win);
+            xrow[i] = y0 + r - 1;
+        } else {
+            const int pl = e / (TH * PW), rem = e - pl * (TH * PW);
+            r = rem / PW;
+            const int c = rem - r * PW;
+            ix = pl ? nb_reflect(2 * (x0 + c) - 1, p.win) : 2 * (x0 + c);        // odd columns 2j-1 | even columns 2j
+            valid = valid && (pl ? c <= WT : c < WT);
+            xrow[i] = 2 * (y0 + r) - 1;
+        }
+        xcol[i] = valid ? ix * 8 : -1;
+    }
+    auto issue = [&](int t, int buf) {                   // t = chunk * 3 + ky
+        const int c = t / 3, ky = t - 3 * c;
+        h8* xd = xbuf + buf * 4 * XPL;
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            const int cg = 2 * c + (xpl[i] >> 1);
+            const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
+            if (xcol[i] >= 0 && cg < p.c8)
+                src = xn + (size_t)(4 * c + xpl[i]) * HW8 + (size_t)nb_reflect(xrow[i] + ky, p.hin) * p.win * 8 + xcol[i];
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(xd + xdst[i]), 16, 0, 0);
+        }
+        h8* wd = wbuf + buf * WSLOTS;
+#pragma unroll
+        for (int i = 0; i < NWPW; ++i) {
+            const int e = (i * NW + wv) * 64 + lane;
+            const int row = e / CO_WG, j = e - row * CO_WG;                      // row = kx*4 + cg*2 + hl
+            const _Float16* src = p.wts + (((size_t)t * 12 + row) * p.co_ld + co0 + j) * 8;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(wd + (i * NW + wv) * 64), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    const int T = p.nchunks * 3;
+    const int a_base = lh * 2 * CO_WG + wm * 64 + l31;
+    const int b_base = lh * 2 * XPL + ((wn * NBW) * RPB + (l31 >> LW)) * PW + (l31 & (WT - 1));
+    issue(0, 0);
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my share of step t has landed
+        __builtin_amdgcn_s_barrier();                             // ... everybody's has, and step t-1 is fully consumed
+        issue(t + 1 < T ? t + 1 : T - 1, (t + 1) & 1);            // past the end: a harmless re-copy keeps the flow uniform
+        __builtin_amdgcn_sched_barrier(0);
+        const h8* xb = xbuf + (t & 1) * 4 * XPL;
+        const h8* wb = wbuf + (t & 1) * WSLOTS;
+        h8 ah[2][MB], al[2][MB], bh[2][NBW], bl[2][NBW];
+        auto fetch = [&](int kx, h8 (&fah)[MB], h8 (&fal)[MB], h8 (&fbh)[NBW], h8 (&fbl)[NBW]) {
+            const int ko = kx == 0 ? KX0 : (kx == 1 ? KX1 : KX2);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                fah[mb] = wb[a_base + kx * 4 * CO_WG + mb * 32];
+                fal[mb] = wb[a_base + kx * 4 * CO_WG + CO_WG + mb * 32];
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                fbh[nb] = xb[b_base + nb * RPB * PW + ko];
+                fbl[nb] = xb[b_base + XPL + nb * RPB * PW + ko];
+            }
+        };
+        fetch(0, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int cu = kx & 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][0], bh[cu][0], acc[0][0], 0, 0, 0);
+            if (kx + 1 < 3) fetch(kx + 1, ah[cu ^ 1], al[cu ^ 1], bh[cu ^ 1], bl[cu ^ 1]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    if (mb + nb > 0)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][mb], bh[cu][nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][mb], bl[cu][nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cu][mb], bh[cu][nb], acc[mb][nb], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (kx + 1 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB + 2 * NBW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MB * NBW - 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                              // staging buffers are dead from here on
+
+    // ---- epilogue: + bias, LeakyReLU; D[row = c_out, col = pixel]; tile pixel index = block * 32 + l31 ----
+    if (OUT == 0) {
+        constexpr int PIX_WG = 256;
+        float* ot = reinterpret_cast<float*>(smem_enc);           // [CO_WG][PIX_WG]
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int co = co0 + col;
+                    float v = 0.f;
+                    if (co < p.c_out) v = nb_lrelu(acc[mb][nb][r] + p.bias[co], p.slope);
+                    ot[col * PIX_WG + (wn * NBW + nb) * 32 + l31] = v;
+                }
+        __syncthreads();
+        for (int e = tid; e < CO_WG * (PIX_WG / 4); e += 512) {
+            const int col = e / (PIX_WG / 4), q4 = e - col * (PIX_WG / 4);
+            const int co = co0 + col;
+            if (co < p.c_out) {
+                const int pix = q4 * 4, row = pix >> LW, cx = pix & (WT - 1);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ot + col * PIX_WG + pix);
+                *reinterpret_cast<f32x4*>(p.y32 + (((size_t)n * p.c_out + co) * p.hout + y0 + row) * p.wout + x0 + cx) = v;
+            }
+        }
+    } else {
+        constexpr int CP = CO_WG + 8;                             // padded channel pitch (halves): 2-way conflicts at most
+        _Float16* sh = reinterpret_cast<_Float16*>(smem_enc);     // [256 pixels][CP] hi, then lo
+        _Float16* sl = sh + 256 * CP;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int pix = (wn * NBW + nb) * 32 + l31;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wm * 64 + mb * 32 + 8 * g + 4 * lh;
+                    h4 vh, vl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = co0 + col + j;
+                        float v = 0.f;
+                        if (co < p.c_out) v = nb_lrelu(acc[mb][nb][4 * g + j] + p.bias[co], p.slope);
+                        const _Float16 hi = (_Float16)v;
+                        vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                    }
+                    *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
+                    *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                }
+        }
+        __syncthreads();
+        const int c8o = (p.c_out + 7) / 8;
+        const size_t OHW8 = (size_t)p.hout * p.wout * 8;
+        _Float16* yn = p.yh2 + (size_t)n * c8o * 2 * OHW8;
+        for (int e = tid; e < (CO_WG / 8) * 2 * 256; e += 512) {  // [cg 16][hl 2][pixel 256]
+            const int pix = e & 255, hl = (e >> 8) & 1, cgl = e >> 9;
+            const int cg = co0 / 8 + cgl;
+            if (cg < c8o) {
+                const int row = pix >> LW, cx = pix & (WT - 1);
+                const h8 v = *reinterpret_cast<const h8*>((hl ? sl : sh) + pix * CP + cgl * 8);
+                *reinterpret_cast<h8*>(yn + (size_t)(cg * 2 + hl) * OHW8 + ((size_t)(y0 + row) * p.wout + x0 + cx) * 8) = v;
+            }
+        }
+    }
+}
+
+template <int STRIDE, int LW, int OUT>
+static int launch_enc_conv(EncConvParams p, int n, hipStream_t st) {
+    constexpr int WT = 1 << LW, TH = 8 * (32 / WT), PW = WT + 2, SLOTS = STRIDE * TH * PW, XPL = ((SLOTS + 63) / 64) * 64;
+    constexpr size_t staging = (size_t)(2 * 4 * XPL + 2 * 12 * 128) * 16;
+    constexpr size_t epi = OUT == 0 ? (size_t)128 * 256 * 4 : (size_t)2 * 256 * (128 + 8) * 2;
+    constexpr size_t lds = staging > epi ? staging : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    p.tiles_x = p.wout / WT; p.tiles_y = p.hout / TH; p.slices = (p.c_out + 127) / 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)enc_conv3x3_h3_kernel<STRIDE, LW, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((enc_conv3x3_h3_kernel<STRIDE, LW, OUT>), dim3(p.tiles_x * p.tiles_y * p.slices, n), dim3(512), lds, st, p);
+    NB_CHECK_LAUNCH("enc_conv3x3_h3");
+    return NB_OK;
+}
+
+extern "C" int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2,
+                                 int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
+    NB_REQUIRE(x_h2 && w_h3 && bias && ((y_f32 != nullptr) != (y_h2 != nullptr)), "enc_conv3x3_h3: need x, w, bias and exactly one output");
+    NB_REQUIRE(n >= 1 && n <= 65535 && c_in >= 1 && c_out >= 1 && (stride == 1 || stride == 2), "enc_conv3x3_h3: bad sizes");
+    NB_REQUIRE(h_in % stride == 0 && w_in % stride == 0 && h_in >= 2 && w_in >= 2, "enc_conv3x3_h3: bad input size %dx%d", h_in, w_in);
+    const int ho = h_in / stride, wo = w_in / stride;
+    const bool wide = wo % 32 == 0 && ho % 8 == 0, narrow = wo == 16 && ho % 16 == 0;
+    NB_REQUIRE(wide || narrow, "enc_conv3x3_h3: output must be 16 wide (rows %% 16 == 0) or a multiple of 32 wide (rows %% 8 == 0), got %dx%d", ho, wo);
+    NB_REQUIRE(y_f32 || c_out % 8 == 0, "enc_conv3x3_h3: H2 output needs c_out %% 8 == 0");
+    NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y_f32 | (uintptr_t)y_h2) % 16 == 0, "enc_conv3x3_h3: pointers must be 16-byte aligned");
+    EncConvParams p;
+    p.x = (const _Float16*)x_h2; p.wts = (const _Float16*)w_h3; p.bias = bias; p.y32 = y_f32; p.yh2 = (_Float16*)y_h2;
+    p.zeros = nb_zero_page_ptr();
+    NB_REQUIRE(p.zeros, "enc_conv3x3_h3: could not allocate the zero page");
+    p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 127) / 128 * 128;
+    p.hin = h_in; p.win = w_in; p.hout = ho; p.wout = wo; p.slope = slope;
+    hipStream_t st = (hipStream_t)stream;
+    const int key = (stride == 2 ? 4 : 0) | (wide ? 2 : 0) | (y_h2 ? 1 : 0);
+    switch (key) {
+        case 0: return launch_enc_conv<1, 4, 0>(p, n, st);
+        case 1: return launch_enc_conv<1, 4, 1>(p, n, st);
+        case 2: return launch_enc_conv<1, 5, 0>(p, n, st);
+        case 3: return launch_enc_conv<1, 5, 1>(p, n, st);
+        case 4: return launch_enc_conv<2, 4, 0>(p, n, st);
+        case 5: return launch_enc_conv<2, 4, 1>(p, n, st);
+        case 6: return launch_enc_conv<2, 5, 0>(p, n, st);
+        default: return launch_enc_conv<2, 5, 1>(p, n, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear x2 upsampling, align_corners=True (nn.Upsample in ScaleUp, simple_autoencoder.py:106-121):
+// fp32 NCHW [n,c,h,w] -> H2 [n,c/8,2,2h,2w,8]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_upsample2x_h2_kernel(const float* __restrict__ x, _Float16* __restrict__ y,
+                                                                int c, int h, int w, long long total) {
+    const int oh = 2 * h, ow = 2 * w, c8 = c / 8;
+    const float sy = (float)(h - 1) / (float)(oh - 1), sx = (float)(w - 1) / (float)(ow - 1);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % ow);
+        long long r = i / ow;
+        const int oy = (int)(r % oh); r /= oh;
+        const int cg = (int)(r % c8);
+        const int n = (int)(r / c8);
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        h8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* xp = x + ((size_t)n * c + cg * 8 + j) * ((size_t)h * w);
+            const float v = hy * (hx * xp[y0 * w + x0] + lx * xp[y0 * w + x1]) + ly * (hx * xp[y1 * w + x0] + lx * xp[y1 * w + x1]);
+            const _Float16 hi = (_Float16)v;
+            vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+        }
+        _Float16* yp = y + ((size_t)(n * c8 + cg) * 2) * ((size_t)oh * ow * 8) + ((size_t)oy * ow + ox) * 8;
+        *reinterpret_cast<h8*>(yp) = vh;
+        *reinterpret_cast<h8*>(yp + (size_t)oh * ow * 8) = vl;
+    }
+}
+
+extern "C" int nb_enc_upsample2x_h2(const float* x, void* y_h2, int n, int c, int h, int w, void* stream) {
+    NB_REQUIRE(x && y_h2, "enc_upsample2x: null pointer");
+    NB_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && h >= 2 && w >= 2, "enc_upsample2x: bad sizes (c must be a multiple of 8)");
+    NB_REQUIRE((uintptr_t)y_h2 % 16 == 0, "enc_upsample2x: output must be 16-byte aligned");
+    const long long total = (long long)n * (c / 8) * 4 * h * w;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(enc_upsample2x_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y_h2, c, h, w, total);
+    NB_CHECK_LAUNCH("enc_upsample2x");
+    return NB_OK;
+}

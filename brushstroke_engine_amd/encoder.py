@@ -139,3 +139,99 @@ def build_encoder(state_dict: Dict[str, np.ndarray], preproc_type=None, device="
     m = GeometryEncoder(preproc_type=preproc_type)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_dict.items()}, strict=True)
     return m.to(device).eval()
+
+
+# ------------------------------------------------------------------------------------------------
+# hand-written HIP path (csrc/nb_encoder.hip)
+# ------------------------------------------------------------------------------------------------
+def _fold_bn(sd, prefix: str):
+    """conv + eval BatchNorm -> conv' : w' = w*s, b' = (b - mean)*s + beta, s = gamma / sqrt(var + 1e-5)."""
+    g = lambda k: np.asarray(sd[prefix + k], np.float64)
+    s = g(".conv.1.weight") / np.sqrt(g(".conv.1.running_var") + 1e-5)
+    w = g(".conv.0.weight") * s[:, None, None, None]
+    b = (g(".conv.0.bias") - g(".conv.1.running_mean")) * s + g(".conv.1.bias")
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+def pack_enc_weight_h3(w: np.ndarray) -> np.ndarray:
+    """[O,I,3,3] fp32 -> hi/lo f16 [ceil(I/16)][ky][kx][cg 2][hi/lo 2][ceil128(O)][8] (include/neube_hip.h)."""
+    o, i = w.shape[:2]
+    nch, co_ld = -(-i // 16), -(-o // 128) * 128
+    wp = np.zeros([nch * 16, 3, 3, co_ld], np.float32)
+    wp[:i, :, :, :o] = w.transpose(1, 2, 3, 0)
+    hi = wp.astype(np.float16)
+    lo = (wp - hi.astype(np.float32)).astype(np.float16)
+    a = np.stack([hi, lo], axis=0).reshape(2, nch, 2, 8, 3, 3, co_ld)       # [hl][chunk][cg][8][ky][kx][co]
+    return np.ascontiguousarray(a.transpose(1, 4, 5, 2, 0, 6, 3))           # [chunk][ky][kx][cg][hl][co][8]
+
+
+class HipGeometryEncoder:
+    """``AutoEncoder.encode(geom, res=[0, 1])`` on the hand-written gfx950 kernels: 8 launches per batch
+    (stem, 3 stride-2 convs, 2 bottleneck convs, bilinear x2, decoder conv), BatchNorm folded on the host.
+    Same interface as ``GeometryEncoder``.  Patch sizes the kernels do not tile (R % 128 != 0) raise."""
+
+    _PRE = {None: 0, "none": 0, "-11inverse": 1, "inverse": 2}
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], preproc_type=None, device="cuda"):
+        from . import _lib
+        if preproc_type not in self._PRE:
+            raise RuntimeError(f'Unknown preprocessing type "{preproc_type}"')
+        self._lib = _lib
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NeubeHipError("HipGeometryEncoder needs a GPU (no CPU path in this build)")
+        self.preproc_type = preproc_type
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        w, b = _fold_bn(state_dict, "encoder.model.0")
+        w50 = np.zeros([64, 50], np.float32)
+        w50[:, :49] = w.reshape(64, 49)
+        self.stem = (dev(w50), dev(b))
+        self.convs = []                                   # (packed weight, bias, c_in, c_out, stride)
+        for prefix, stride in (("encoder.model.1", 2), ("encoder.model.2", 2), ("encoder.model.3", 2),
+                               ("encoder.model.4", 1), ("encoder.model.5", 1), ("decoder.model.0.conv", 1)):
+            w, b = _fold_bn(state_dict, prefix)
+            self.convs.append((dev(pack_enc_weight_h3(w)).view(torch.float16), dev(b), w.shape[1], w.shape[0], stride))
+
+    def feature_channels(self, res=0):
+        return [16, 256, 128, 64][res]
+
+    def featuremap_resolution(self, input_res, res=0):
+        return (input_res // 8) * (2 ** res)
+
+    @staticmethod
+    def supports(resolution: int) -> bool:
+        return resolution >= 128 and resolution % 128 == 0
+
+    @torch.no_grad()
+    def encode(self, geom: torch.Tensor, res=None) -> List[torch.Tensor]:
+        if res is not None and list(res) != [0, 1]:
+            raise RuntimeError("HipGeometryEncoder evaluates the shipped configuration: res=[0, 1]")
+        lib, check = self._lib.lib(), self._lib.check
+        n, c, h, w = geom.shape
+        if c != 1 or not self.supports(h) or h != w:
+            raise RuntimeError(f"HipGeometryEncoder: unsupported geometry shape {tuple(geom.shape)} (square, R % 128 == 0)")
+        x = geom.to(self.device, torch.float32).contiguous()
+        f16 = lambda ch, r: torch.empty([n, ch // 8, 2, r, r, 8], dtype=torch.float16, device=self.device)
+        f32 = lambda ch, r: torch.empty([n, ch, r, r], dtype=torch.float32, device=self.device)
+        P = lambda t: t.data_ptr()
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            a = f16(64, h)
+            check(lib.nb_enc_stem7x7_f32_h2(P(x), P(self.stem[0]), P(self.stem[1]), P(a), n, h, w,
+                                            self._PRE[self.preproc_type], 0.01, st), "enc_stem")
+            r = h
+            for i in range(4):                               # three stride-2 stages + 256 -> 32
+                wt, b, ci, co, stride = self.convs[i]
+                r_out = r // stride
+                y = f16(co, r_out)
+                check(lib.nb_enc_conv3x3_h3(P(a), ci, P(wt), P(b), None, P(y), n, r, r, co, stride, 0.01, st), "enc_conv")
+                a, r = y, r_out
+            wt, b, ci, co, stride = self.convs[4]            # 32 -> 16: the bottleneck the generator consumes
+            enc = f32(co, r)
+            check(lib.nb_enc_conv3x3_h3(P(a), ci, P(wt), P(b), P(enc), None, n, r, r, co, 1, 0.01, st), "enc_conv")
+            up = f16(co, 2 * r)
+            check(lib.nb_enc_upsample2x_h2(P(enc), P(up), n, co, r, r, st), "enc_upsample")
+            wt, b, ci, co, stride = self.convs[5]            # first decoder stage, 16 -> 256
+            dec = f32(co, 2 * r)
+            check(lib.nb_enc_conv3x3_h3(P(up), ci, P(wt), P(b), P(dec), None, n, 2 * r, 2 * r, co, 1, 0.01, st), "enc_conv")
+        return [enc, dec]

@@ -222,6 +222,27 @@ int nb_canvas_replay_f32(float* tiles, int t, int c, int hw, const int32_t* tile
 int nb_paste_tiles_u8(const uint8_t* tiles, int t, int r, const int32_t* dst_yx, int crop, uint8_t* canvas, int h, int w,
                       const int32_t* cell_off, const int32_t* cell_tiles, void* stream);
 
+/* ---- geometry encoder (forger/experimental/autoenc/simple_autoencoder.py:88-121, 155-199,
+ * 251-261).  Every layer is conv(reflect padding) + bias + LeakyReLU(slope) with eval-mode BatchNorm folded into
+ * the weights and bias by the caller.  Activations between layers travel in the H2 format of the split-f16 convs. */
+
+/* Stem: 1 -> 64 channels, 7x7, reflect padding 3.  x fp32 [n,1,h,w] (h % 16 == 0, w % 32 == 0), w50 [64][50] =
+ * folded weights [c_out][ky*7+kx] padded with one zero, y_h2 = H2 [n,8,2,h,w,8].  preproc (autoenc/base.py:30-52):
+ * 0 none, 1 '-11inverse' (1-x)*2-1, 2 'inverse' 1-x.  Exact fp32 products (v_mfma_f32_32x32x2_f32). */
+int nb_enc_stem7x7_f32_h2(const float* x, const float* w50, const float* bias, void* y_h2, int n, int h, int w,
+                          int preproc, float slope, void* stream);
+
+/* 3x3 conv, stride 1 or 2, reflect padding 1, split-f16 products.  x_h2: H2 [n, c_in, h_in, w_in]; w_h3: hi/lo f16
+ * [ceil(c_in/16)][3][3][2][2][ceil128(c_out)][8]; exactly one of y_f32 (fp32 NCHW [n,c_out,h_in/stride,w_in/stride])
+ * and y_h2 (H2, c_out % 8 == 0) is non-NULL.  Output must be 16 wide (rows % 16 == 0) or a multiple of 32 wide
+ * (rows % 8 == 0). */
+int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2, int n,
+                      int h_in, int w_in, int c_out, int stride, float slope, void* stream);
+
+/* Bilinear x2, align_corners=True (nn.Upsample in ScaleUp, simple_autoencoder.py:106-121): fp32 NCHW [n,c,h,w]
+ * (c % 8 == 0) -> H2 [n, c, 2h, 2w]. */
+int nb_enc_upsample2x_h2(const float* x, void* y_h2, int n, int c, int h, int w, void* stream);
+
 /* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into the zero-padded
  * wpk[ceil8(c_in)][9][ceil32(c_out)] and wsq[c_in][c_out] = sum_k W^2.  Either output may be NULL. */
 int nb_pack_conv_weight(const float* w, int c_out, int c_in, float* wpk, float* wsq);

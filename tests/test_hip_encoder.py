@@ -1,0 +1,115 @@
+"""GPU parity of the hand-written geometry encoder (csrc/nb_encoder.hip) against the reference's encoder outputs
+(tests/golden/engine_r128.npz) and the oracle restatement on seeded inputs; tolerance 2e-4 on O(1) feature values
+(split-f16 products + BatchNorm folding; the generator's pixel budget is 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from brushstroke_engine_amd import encoder as encmod, _lib
+from oracle import painting_oracle as po
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+def _h2_to_nchw(t):
+    n, c8, _, h, w, _ = t.shape
+    v = t.float()
+    return (v[:, :, 0] + v[:, :, 1]).permute(0, 1, 4, 2, 3).reshape(n, c8 * 8, h, w)
+
+
+def _nchw_to_h2(x):
+    n, c, h, w = x.shape
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    return torch.stack([hi, lo], 1).reshape(n, 2, c // 8, 8, h, w).permute(0, 2, 1, 4, 5, 3).contiguous()
+
+
+def test_encoder_matches_reference_golden():
+    g = load_golden("engine_r128.npz")
+    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(int(g["encoder_seed"])))
+    f = enc.encode(torch.from_numpy(g["enc_in"]).cuda())
+    np.testing.assert_allclose(f[0].cpu().numpy(), g["enc_f0"], atol=TOL)
+    np.testing.assert_allclose(f[1].cpu().numpy()[:, ::8], g["enc_f1"], atol=TOL)
+
+
+@pytest.mark.parametrize("res,n,pre", [(128, 3, None), (256, 2, None), (128, 1, "-11inverse"), (256, 1, "inverse")])
+def test_encoder_matches_oracle(res, n, pre):
+    rs = np.random.RandomState(res + n)
+    esd = encmod.random_encoder_state_dict(11)
+    geom = (rs.rand(n, 1, res, res) > 0.1).astype(np.float32)
+    geom[:, :, ::7, :] = rs.rand(n, 1, len(range(0, res, 7)), res).astype(np.float32)      # gray levels too
+    enc = encmod.HipGeometryEncoder(esd, preproc_type=pre)
+    f = enc.encode(torch.from_numpy(geom).cuda())
+    ref = po.encoder_encode(esd, torch.from_numpy(geom), pre)
+    assert f[0].shape == ref[0].shape and f[1].shape == ref[1].shape
+    for a, b in zip(f, ref):
+        assert float((a.cpu() - b).abs().max()) <= TOL, float((a.cpu() - b).abs().max())
+
+
+@pytest.mark.parametrize("stride,ci,co,h,w,h2out", [(1, 16, 256, 32, 32, False), (2, 64, 128, 64, 64, True),
+                                                     (2, 256, 256, 32, 32, True), (1, 32, 16, 16, 16, False),
+                                                     (1, 256, 32, 16, 16, True), (2, 128, 256, 64, 128, False)])
+def test_enc_conv_layer(stride, ci, co, h, w, h2out):
+    """One layer against torch fp64 (reflect pad, cross-correlation), both output formats, both tile shapes."""
+    rs = np.random.RandomState(ci + co)
+    n = 2
+    x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32))
+    wt = (rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rs.randn(co).astype(np.float32)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(
+        torch.nn.functional.pad(x.double(), (1, 1, 1, 1), mode="reflect"), torch.from_numpy(wt).double(),
+        torch.from_numpy(b).double(), stride=stride), 0.01)
+    ho, wo = h // stride, w // stride
+    xd = _nchw_to_h2(x).cuda()
+    wd = torch.from_numpy(encmod.pack_enc_weight_h3(wt)).cuda()
+    bd = torch.from_numpy(b).cuda()
+    if h2out:
+        y = torch.empty([n, co // 8, 2, ho, wo, 8], dtype=torch.float16, device="cuda")
+        _lib.check(_lib.lib().nb_enc_conv3x3_h3(_p(xd), ci, _p(wd), _p(bd), None, _p(y), n, h, w, co, stride, 0.01,
+                                                torch.cuda.current_stream().cuda_stream), "enc_conv")
+        out = _h2_to_nchw(y).cpu()
+    else:
+        y = torch.empty([n, co, ho, wo], dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib().nb_enc_conv3x3_h3(_p(xd), ci, _p(wd), _p(bd), _p(y), None, n, h, w, co, stride, 0.01,
+                                                torch.cuda.current_stream().cuda_stream), "enc_conv")
+        out = y.cpu()
+    assert float((out.double() - ref).abs().max()) <= 2e-5
+
+
+def test_enc_stem_and_upsample():
+    rs = np.random.RandomState(0)
+    n, h, w = 2, 32, 64
+    x = torch.from_numpy(rs.rand(n, 1, h, w).astype(np.float32))
+    wt = (rs.randn(64, 1, 7, 7) / 7).astype(np.float32)
+    b = rs.randn(64).astype(np.float32)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(
+        torch.nn.functional.pad(x.double(), (3, 3, 3, 3), mode="reflect"), torch.from_numpy(wt).double(),
+        torch.from_numpy(b).double()), 0.01)
+    w50 = np.zeros([64, 50], np.float32)
+    w50[:, :49] = wt.reshape(64, 49)
+    y = torch.empty([n, 8, 2, h, w, 8], dtype=torch.float16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    xd, wd, bd = x.cuda(), torch.from_numpy(w50).cuda(), torch.from_numpy(b).cuda()      # keep the device buffers alive
+    _lib.check(_lib.lib().nb_enc_stem7x7_f32_h2(_p(xd), _p(wd), _p(bd), _p(y), n, h, w, 0, 0.01, st), "stem")
+    assert float((_h2_to_nchw(y).cpu().double() - ref).abs().max()) <= 1e-5
+    xs = torch.from_numpy(rs.randn(n, 16, 16, 32).astype(np.float32))
+    up = torch.empty([n, 2, 2, 32, 64, 8], dtype=torch.float16, device="cuda")
+    xsd = xs.cuda()
+    _lib.check(_lib.lib().nb_enc_upsample2x_h2(_p(xsd), _p(up), n, 16, 16, 32, st), "upsample")
+    ref = torch.nn.functional.interpolate(xs, scale_factor=2, mode="bilinear", align_corners=True)
+    assert float((_h2_to_nchw(up).cpu() - ref).abs().max()) <= 2e-6
+
+
+def test_encoder_rejects_unsupported():
+    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(1))
+    with pytest.raises(RuntimeError):
+        enc.encode(torch.zeros(1, 1, 64, 64).cuda())
+    with pytest.raises(RuntimeError):
+        encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(1), preproc_type="bogus")
+    assert _lib.lib().nb_enc_conv3x3_h3(None, 16, None, None, None, None, 1, 16, 16, 16, 1, 0.01, None) < 0

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--conv-mode", default="h3")
     ap.add_argument("--breakdown", action="store_true")
+    ap.add_argument("--encoder", default="hip", choices=["hip", "torch"])
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -55,7 +56,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     cfg = cfgmod.style1_config(a.res)
     G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode=a.conv_mode).to("cuda")
-    enc = encmod.build_encoder(encmod.random_encoder_state_dict(5), device="cuda")
+    if a.encoder == "hip":
+        enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5))
+    else:
+        enc = encmod.build_encoder(encmod.random_encoder_state_dict(5), device="cuda")
     ops = painting.TileOps(G, enc)
     helper = painting.PaintingHelper(ops, batch=a.batch)
     helper.set_feature_blending(a.level)
@@ -87,7 +91,7 @@ def main():
         line = {"metric": "tiled canvas stylization, tiles/s (end to end: host tiling + H2D + encoder + generator + "
                           "paste + D2H)", "value": n_tiles / t, "unit": "tiles/s", "n_gpus": world, "seconds": t,
                 "tiles": n_tiles, "canvas": [a.size, a.size], "res": a.res, "feature_blending_level": a.level,
-                "crop_margin": a.crop_margin, "batch": a.batch, "conv_mode": a.conv_mode, "steps": a.steps,
+                "crop_margin": a.crop_margin, "batch": a.batch, "conv_mode": a.conv_mode, "encoder": a.encoder, "steps": a.steps,
                 "stroke_fraction": float((geom == 0).mean())}
         if _TIMES:
             torch.cuda.synchronize()
