@@ -209,6 +209,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail re-copies before the LDS is released
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
 
     // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp -> fp32 NCHW; D[row = c_out, col = pixel] ----
     // The finished values go through LDS (the staging buffers are dead now) as an [c_out][pixel] image so that each
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         __builtin_amdgcn_s_barrier();
     }
 
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
     // ---- epilogue: 16 rounds of 2 c_out (accumulator register rho <-> c_out rows (rho&3) + 8(rho>>2) + 4*lh) ----
     const int Wo = 2 * W, Ho = 2 * H;
     const float* dco = p.dcoefs + (size_t)n * p.c_out;

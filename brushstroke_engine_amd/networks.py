@@ -302,11 +302,16 @@ class SynthesisNetwork(torch.nn.Module):
     # -- optional per-launch HIP-event timing (bench.py): events are recorded on the launch stream --
     layer_events = None      # set to a list to collect (name, start_event, end_event)
     event_filter = None      # optional set of names: record only these (every recorded pair costs ~10 us of stream time)
+    event_pool = None        # optional list of pre-created (and once-recorded) timing events to draw from: creating
+                             # events inside a timed region costs milliseconds per step in a fresh process
 
     def _begin_event(self, name):
         if self.layer_events is None or (self.event_filter is not None and name not in self.event_filter):
             return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if self.event_pool:
+            e0, e1 = self.event_pool.pop(), self.event_pool.pop()
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         return (name, e0, e1)
 
