@@ -44,7 +44,18 @@ struct H3Params {
     int c8, nchunks, c_out, co_ld, h, w;
     int tiles_x, tiles_y, slices, dbg, stagger_ticks;
     float alpha, gain, clamp;
+    unsigned long long* tstamps;   // debug: per-workgroup phase timestamps (nb_debug_set_timestamps), else null
 };
+
+static unsigned long long* g_tstamps = nullptr;
+static int g_tstamps_cap = 0;
+// Debug hook (not part of the product ABI): phase timestamps [workgroup][8] of the next h3 launches, s_memrealtime ticks
+extern "C" void nb_debug_set_timestamps(void* buf, int capacity_workgroups) { g_tstamps = (unsigned long long*)buf; g_tstamps_cap = capacity_workgroups; }
+
+#define NB_TSTAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (p.tstamps && threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 __device__ __forceinline__ float nb_h3_epilogue(float v, float bias, float alpha, float gain, float clamp) {
     v += bias;
@@ -69,6 +80,7 @@ __device__ __forceinline__ void nb_stagger(int stagger_ticks, int first_round) {
 
 template <int MW>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
+    NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = 8, NWN = NW / MW;          // waves along pixels
     constexpr int MB = 2, NBW = 2;                // 32x32 MFMA tiles per wave: 64 c_out x 64 pixels
@@ -96,6 +108,19 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     const int co0 = slice * CO_WG;
     const size_t HW8 = (size_t)H * W * 8;
     const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+
+    // epilogue operands are fetched now, under the prologue DMA: per-channel demodulation / bias into LDS, the
+    // lane's noise values into registers (fetching them in the epilogue costs ~10 us of exposed latency per tile)
+    __shared__ float s_dco[CO_WG], s_bias[CO_WG];
+    if (tid < CO_WG) {
+        const int co = co0 + tid;
+        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
+        s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
+    }
+    float nzr[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+        nzr[nb] = p.noise ? p.noise[(size_t)n * p.noise_stride_n + (size_t)(y0 + wn * NBW + nb) * W + x0 + l31] : 0.f;
 
     // ---- DMA descriptors of this wave's activation pieces ----
     int xsp[NXPW], xpl[NXPW], xdst[NXPW];
@@ -152,6 +177,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     issue_w(clampt(2), wring + 2 * WSLOTS);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    NB_TSTAMP(1);
 
     // fragment addresses (in 16-byte slots)
     const int a_base = lh * 2 * CO_WG + wm * 64 + l31;           // + kx*4*CO_WG + hl*CO_WG + mb*32
@@ -209,6 +235,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail re-copies before the LDS is released
+    NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
 
     // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp -> fp32 NCHW; D[row = c_out, col = pixel] ----
@@ -217,26 +244,22 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     // the accumulator registers directly, and whole 512-byte row segments per wave-instruction.
     constexpr int PIX_WG = TH * 32;
     float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG] floats (<= 128 KiB)
-    const float* dco = p.dcoefs + (size_t)n * p.c_out;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int trow = wn * NBW + nb;
-        const int oy = y0 + trow, ox = x0 + l31;
-        float nz = 0.f;
-        if (p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * W + ox];
+        const float nz = nzr[nb];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // c_out within the workgroup
-                const int co = co0 + col;
-                float v = 0.f;
-                if (co < p.c_out) v = nb_h3_epilogue(acc[mb][nb][r] * dco[co] + nz, p.bias[co], p.alpha, p.gain, p.clamp);
-                ot[col * PIX_WG + trow * 32 + l31] = v;
+                // (channels past c_out carry dco = bias = 0 and are never stored)
+                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_epilogue(acc[mb][nb][r] * s_dco[col] + nz, s_bias[col], p.alpha, p.gain, p.clamp);
             }
         }
     }
     __syncthreads();
+    NB_TSTAMP(3);
     if (!(p.dbg & 1)) {
         constexpr int V4_PER_ROW = PIX_WG / 4;                   // float4 per c_out row
         for (int e = tid; e < CO_WG * V4_PER_ROW; e += 512) {
@@ -249,6 +272,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             }
         }
     }
+    NB_TSTAMP(4);
+    if (p.tstamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NB_TSTAMP(5);
+    }
 }
 
 template <int MW>
@@ -259,7 +287,7 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
@@ -286,6 +314,11 @@ extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.tstamps = nullptr;
+    if (g_tstamps) {
+        const long long wgs = (long long)(w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64)) * n;
+        if (wgs <= g_tstamps_cap) p.tstamps = g_tstamps;
+    }
     if (c_out > 64) return launch_h3<2>(p, n, (hipStream_t)stream);
     return launch_h3<1>(p, n, (hipStream_t)stream);
 }
@@ -308,9 +341,11 @@ struct H3Up2Params {
     int c8, nchunks, c_out, co_ld, h, w;
     int tiles_x, tiles_y, slices, dbg, stagger_ticks;
     float alpha, gain, clamp;
+    unsigned long long* tstamps;
 };
 
 __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
+    NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = 8, TQH = NB_H3_TQH, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
@@ -337,6 +372,20 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     const size_t HW8 = (size_t)H * W * 8;
     const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
     const int nblk = wv < NBLK - (NBJ - 1) * NW ? NBJ : NBJ - 1;      // blocks wv, wv+8 (< 15)
+
+    // epilogue operands fetched under the prologue DMA: demodulation / bias per channel and the tile's noise
+    __shared__ float s_dco[32], s_bias[32];
+    __shared__ float s_noise[2 * TQH * 2 * TQW];
+    if (tid < 32) {
+        const int co = co0 + tid;
+        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
+        s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
+    }
+    for (int e = tid; e < 2 * TQH * 2 * TQW; e += 512) {
+        const int r = e / (2 * TQW), c = e - r * (2 * TQW);
+        const int oy = 2 * I0 + r, ox = 2 * J0 + c;
+        s_noise[e] = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
+    }
 
     int xsp[NXPW], xpl[NXPW], xdst[NXPW];
 #pragma unroll
@@ -396,6 +445,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     issue(0, ring);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    NB_TSTAMP(1);
     // tap -> (delta slot offset, phase): x11 = X(r,c), x10 = X(r,c+1), x01 = X(r+1,c), x00 = X(r+1,c+1)
     constexpr int kTapDelta[9] = {XS + 1, XS, XS, 1, 0, 0, 1, 0, 0};      // taps 0..8 = (a,b) row-major
     constexpr int kTapPhase[9] = {0, 1, 0, 2, 3, 2, 0, 1, 0};
@@ -422,26 +472,34 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         __builtin_amdgcn_s_barrier();
     }
 
+    NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
-    // ---- epilogue: 16 rounds of 2 c_out (accumulator register rho <-> c_out rows (rho&3) + 8(rho>>2) + 4*lh) ----
+    // ---- epilogue: 4 rounds of 4 accumulator registers = 8 c_out each (register rho <-> c_out rows
+    //      (rho&3) + 8(rho>>2) + 4*lh): phases -> LDS, polyphase FIR, demodulate, noise, bias, lrelu, store ----
     const int Wo = 2 * W, Ho = 2 * H;
-    const float* dco = p.dcoefs + (size_t)n * p.c_out;
     constexpr int nquads = TQH * TQW;
+    constexpr int RPR = 4;                            // accumulator registers per round
 #pragma unroll
-    for (int rho = 0; rho < 16; ++rho) {
+    for (int round = 0; round < 16 / RPR; ++round) {
 #pragma unroll
-        for (int j = 0; j < NBJ; ++j) {
-            if (j < nblk) {
-                const int pidx = (wv + NW * j) * 32 + l31;
+        for (int rr = 0; rr < RPR; ++rr) {
+            const int rho = round * RPR + rr;
 #pragma unroll
-                for (int ph = 0; ph < 4; ++ph) y1s[lh * Y1_SLOT + ph * Y1_PHASE + pidx] = acc[j][ph][rho];
+            for (int j = 0; j < NBJ; ++j) {
+                if (j < nblk) {
+                    const int pidx = (wv + NW * j) * 32 + l31;
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) y1s[(rr * 2 + lh) * Y1_SLOT + ph * Y1_PHASE + pidx] = acc[j][ph][rho];
+                }
             }
         }
         __syncthreads();
-        for (int it = tid; it < 2 * nquads; it += 512) {
+        for (int it = tid; it < RPR * 2 * nquads; it += 512) {
             const int s = it / nquads, qd = it - s * nquads;
             const int ti = qd / TQW, tj = qd - ti * TQW;
-            const int co = co0 + (rho & 3) + 8 * (rho >> 2) + 4 * s;
+            const int rho = round * RPR + (s >> 1);
+            const int col = (rho & 3) + 8 * (rho >> 2) + 4 * (s & 1);
+            const int co = co0 + col;
             const float* ee = y1s + s * Y1_SLOT + ti * PW + tj;
             const float* eo = ee + 1 * Y1_PHASE;
             const float* oe = ee + 2 * Y1_PHASE;
@@ -468,15 +526,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             out[1][1] = 0.25f * ve1[0] + 0.75f * vo1[1] + 0.75f * ve1[1] + 0.25f * vo1[2];
             const int qi = I0 + ti, qj = J0 + tj;
             if (co < p.c_out && qi < H && !(p.dbg & 1)) {
-                const float d = dco[co], bs = p.bias[co];
+                const float d = s_dco[col], bs = s_bias[col];
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const int oy = 2 * qi + dy, ox = 2 * qj;
-                    float n0 = 0.f, n1 = 0.f;
-                    if (p.noise) {
-                        const float* np_ = p.noise + (size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox;
-                        n0 = np_[0]; n1 = np_[1];
-                    }
+                    const float n0 = s_noise[(2 * ti + dy) * (2 * TQW) + 2 * tj], n1 = s_noise[(2 * ti + dy) * (2 * TQW) + 2 * tj + 1];
                     float2 o;
                     o.x = nb_h3_epilogue(out[dy][0] * d + n0, bs, p.alpha, p.gain, p.clamp);
                     o.y = nb_h3_epilogue(out[dy][1] * d + n1, bs, p.alpha, p.gain, p.clamp);
@@ -485,6 +539,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             }
         }
         __syncthreads();
+    }
+    NB_TSTAMP(4);
+    if (p.tstamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NB_TSTAMP(5);
     }
 }
 
@@ -505,11 +564,12 @@ extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3
     { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tiles_x = w / 32; p.tiles_y = (h + NB_H3_TQH - 1) / NB_H3_TQH; p.slices = (c_out + 31) / 32;
+    p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
     constexpr int XPL = (((NB_H3_TQH + 3) * 35 + 63) / 64) * 64;
     const size_t lds = (size_t)2 * (4 * XPL + 36 * 32) * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);

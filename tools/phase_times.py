@@ -1,0 +1,74 @@
+"""Per-workgroup phase timeline of the split-f16 conv kernels (debug hook nb_debug_set_timestamps): where a
+workgroup's time goes -- prologue DMA, K loop, epilogue through LDS, store issue, store drain.
+
+    python tools/phase_times.py            # on the GPU box
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from brushstroke_engine_amd import _lib, ops  # noqa: E402
+
+
+def run(kind, n, ci, co, res):
+    lib = _lib.lib()
+    lib.nb_debug_set_timestamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.nb_debug_set_timestamps.restype = None
+    rs = np.random.RandomState(0)
+    hin = res if kind == "up1" else res // 2
+    x = torch.from_numpy(rs.randn(n, ci, hin, hin).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    styles = torch.ones(n, ci, device="cuda")
+    dco = torch.ones(n, co, device="cuda")
+    bias = torch.zeros(co, device="cuda")
+    xh = ops.pack_h2(x, styles)
+    wp = ops.pack_conv_weight_h3(w)
+    cap = 1 << 16
+    ts = torch.zeros([cap, 8], dtype=torch.int64, device="cuda")
+    y = torch.empty([n, co, res, res], device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    fn = lib.nb_modconv3x3_up1_h3 if kind == "up1" else lib.nb_modconv3x3_up2_h3
+
+    def launch():
+        _lib.check(fn(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(), n, hin, hin,
+                      co, 0.2, 1.4142135, 256.0, st), kind)
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); launch(); e1.record(); torch.cuda.synchronize()
+    plain = e0.elapsed_time(e1)
+    lib.nb_debug_set_timestamps(ts.data_ptr(), cap)
+    e0.record(); launch(); e1.record(); torch.cuda.synchronize()
+    lib.nb_debug_set_timestamps(None, 0)
+    t = ts.cpu().numpy().astype(np.float64)
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    us = (t - t0) / 100.0                                    # 100 MHz ticks -> us
+    d = np.diff(us[:, :6], axis=1)
+    names = ["prologue", "k-loop", "epilogue(LDS)", "store issue", "store drain"]
+    print(f"{kind} {ci}->{co}@{res} n={n}: {t.shape[0]} workgroups, kernel {plain:.3f} ms (instrumented {e0.elapsed_time(e1):.3f} ms), "
+          f"span {us[:, 5].max() / 1e3:.3f} ms, workgroup mean {(us[:, 5] - us[:, 0]).mean():.1f} us")
+    for i, nm in enumerate(names):
+        print(f"    {nm:14s} mean {d[:, i].mean():7.2f} us   p10 {np.percentile(d[:, i], 10):7.2f}   p90 {np.percentile(d[:, i], 90):7.2f}")
+    # how many workgroups are in each phase at a time (sampled)
+    grid = np.linspace(0, us[:, 5].max(), 400)
+    occ = np.zeros((len(names), len(grid)))
+    for i in range(len(names)):
+        occ[i] = ((us[:, i, None] <= grid[None]) & (grid[None] < us[:, i + 1, None])).sum(0)
+    print("    mean workgroups in phase:", {nm: round(float(occ[i].mean()), 1) for i, nm in enumerate(names)},
+          " max storing at once:", int((occ[3] + occ[4]).max()))
+    # gaps between a CU slot finishing and the next workgroup starting cannot be seen directly; estimate idle from totals
+    busy = (us[:, 5] - us[:, 0]).sum()
+    print(f"    sum of workgroup times / (256 CUs x span) = {busy / (256 * us[:, 5].max()):.2f}")
+
+
+if __name__ == "__main__":
+    run("up1", 32, 64, 64, 256)
+    run("up1", 32, 128, 128, 128)
+    run("up2", 32, 128, 64, 256)
+    run("up2", 32, 384, 128, 128)
