@@ -183,6 +183,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     const int a_base = lh * 2 * CO_WG + wm * 64 + l31;           // + kx*4*CO_WG + hl*CO_WG + mb*32
     const int b_base = lh * 2 * XPL + (wn * NBW) * TWP + l31;    // + hl*XPL + (nb + ky)*TWP + kx
 
+    unsigned long long t_dma = 0, t_bar = 0;
+    const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
     for (int c = 0; c < NC; ++c) {
         const h8* xb = xbuf + (c & 1) * 4 * XPL;
 #pragma unroll
@@ -228,11 +230,19 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * MB * NBW - 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tw0 = 0;
+            if (p.tstamps) tw0 = __builtin_amdgcn_s_memtime();
             // everything issued before sub-chunk t-1 must have landed (it is what sub-chunk t+1 reads)
             if (ky == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW + NXPW) : "memory");
+            if (p.tstamps) { const unsigned long long tw1 = __builtin_amdgcn_s_memtime(); t_dma += tw1 - tw0; tw0 = tw1; }
             __builtin_amdgcn_s_barrier();
+            if (p.tstamps) t_bar += __builtin_amdgcn_s_memtime() - tw0;
         }
+    }
+    if (p.tstamps && tid == 0) {
+        unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        ts[6] = t_dma; ts[7] = t_bar | ((__builtin_amdgcn_s_memtime() - t_loop0) << 32);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail re-copies before the LDS is released
     NB_TSTAMP(2);
@@ -364,6 +374,9 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
     const int H = p.h, W = p.w;
     int b = blockIdx.x;
+    // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the c_out
+    // slices of one input tile -- which re-read the same activations -- are renumbered to share an XCD
+    if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int slice = b % p.slices; b /= p.slices;
     const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
     const int n = blockIdx.y;
@@ -446,26 +459,52 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     NB_TSTAMP(1);
-    // tap -> (delta slot offset, phase): x11 = X(r,c), x10 = X(r,c+1), x01 = X(r+1,c), x00 = X(r+1,c+1)
-    constexpr int kTapDelta[9] = {XS + 1, XS, XS, 1, 0, 0, 1, 0, 0};      // taps 0..8 = (a,b) row-major
-    constexpr int kTapPhase[9] = {0, 1, 0, 2, 3, 2, 0, 1, 0};
+    // tap (a,b) row-major -> (slot offset of its input pixel, output phase): x11 = X(r,c), x10 = X(r,c+1),
+    // x01 = X(r+1,c), x00 = X(r+1,c+1).  Only four distinct offsets occur, so the taps are walked grouped by offset:
+    // one pair of B fragments (hi, lo) per block serves up to four taps, and the A fragments of the next tap (and the
+    // B fragments of the next group) are fetched under the six MFMAs of the current tap.
+    constexpr int kOrd[9] = {4, 5, 7, 8, 3, 6, 1, 2, 0};
+    constexpr int kDel[9] = {0, 0, 0, 0, 1, 1, XS, XS, XS + 1};          // slot offset, in walk order
+    constexpr int kGrp[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+    constexpr int kPha[9] = {3, 2, 1, 0, 2, 0, 1, 0, 0};                 // kTapPhase[kOrd[i]]
     for (int c = 0; c < NC; ++c) {
         h8* st = ring + (c & 1) * STAGE;
         if (c + 1 < NC && !(p.dbg & 2)) issue(c + 1, ring + ((c + 1) & 1) * STAGE);
         __builtin_amdgcn_sched_barrier(0);
+        h8 ah[2], al[2], bh[2][NBJ], bl[2][NBJ];
+        ah[0] = st[aoff + kOrd[0] * 128]; al[0] = st[aoff + kOrd[0] * 128 + 32];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const h8 ah = st[aoff + tap * 128], al = st[aoff + tap * 128 + 32];
+        for (int j = 0; j < NBJ; ++j) { bh[0][j] = st[boff[j] + kDel[0]]; bl[0][j] = st[boff[j] + XPL + kDel[0]]; }
 #pragma unroll
-            for (int j = 0; j < NBJ; ++j) {
-                if (j < nblk) {
-                    const h8 bh = st[boff[j] + kTapDelta[tap]], bl = st[boff[j] + XPL + kTapDelta[tap]];
-                    f32x16& a = acc[j][kTapPhase[tap]];
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a, 0, 0, 0);
+        for (int i = 0; i < 9; ++i) {
+            const int ca = i & 1, cb = kGrp[i] & 1;
+            f32x16& a0 = acc[0][kPha[i]];
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][0], a0, 0, 0, 0);
+            int nfetch = 0;
+            if (i + 1 < 9) {
+                ah[ca ^ 1] = st[aoff + kOrd[i + 1] * 128]; al[ca ^ 1] = st[aoff + kOrd[i + 1] * 128 + 32];
+                nfetch = 2;
+                if (kGrp[i + 1] != kGrp[i]) {
+#pragma unroll
+                    for (int j = 0; j < NBJ; ++j) {
+                        bh[cb ^ 1][j] = st[boff[j] + kDel[i + 1]]; bl[cb ^ 1][j] = st[boff[j] + XPL + kDel[i + 1]];
+                    }
+                    nfetch += 2 * NBJ;
                 }
             }
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][0], a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][0], a0, 0, 0, 0);
+#pragma unroll
+            for (int j = 1; j < NBJ; ++j) {
+                f32x16& aj = acc[j][kPha[i]];
+                aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][j], aj, 0, 0, 0);
+                aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][j], aj, 0, 0, 0);
+                aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][j], aj, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (nfetch == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (nfetch) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NBJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ - 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
