@@ -45,6 +45,11 @@ struct H3Params {
     int tiles_x, tiles_y, slices, dbg, stagger_ticks;
     float alpha, gain, clamp;
     unsigned long long* tstamps;   // debug: per-workgroup phase timestamps (nb_debug_set_timestamps), else null
+    // H2 output (y == null): the result, multiplied by the CONSUMER's styles, goes straight into the consumer's H2
+    // input tensor [n][c8_next][2][H][W][8] (channel groups 0 .. c_out/8-1), so no separate packing pass is needed
+    _Float16* yh2;
+    const float* next_styles;      // [n][next_stride]
+    int next_stride, c8_next;
 };
 
 static unsigned long long* g_tstamps = nullptr;
@@ -111,11 +116,12 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 
     // epilogue operands are fetched now, under the prologue DMA: per-channel demodulation / bias into LDS, the
     // lane's noise values into registers (fetching them in the epilogue costs ~10 us of exposed latency per tile)
-    __shared__ float s_dco[CO_WG], s_bias[CO_WG];
+    __shared__ float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
     if (tid < CO_WG) {
         const int co = co0 + tid;
         s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
         s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
+        s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
     float nzr[NBW];
 #pragma unroll
@@ -253,6 +259,47 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     // lane can store 16 bytes (4 consecutive pixels of one channel row): 4x fewer store instructions than storing
     // the accumulator registers directly, and whole 512-byte row segments per wave-instruction.
     constexpr int PIX_WG = TH * 32;
+    if (p.yh2) {
+        // H2 epilogue: [pixel][channel] hi and lo images in LDS (pitch +8 halves), then 16-byte slot stores
+        constexpr int CP = CO_WG + 8;
+        _Float16* sh = reinterpret_cast<_Float16*>(smem_h3);
+        _Float16* sl = sh + PIX_WG * CP;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int pix = (wn * NBW + nb) * 32 + l31;
+            const float nz = nzr[nb];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wm * 64 + mb * 32 + 8 * g + 4 * lh;
+                    h4 vh, vl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = nb_h3_epilogue(acc[mb][nb][4 * g + j] * s_dco[col + j] + nz, s_bias[col + j], p.alpha, p.gain, p.clamp) * s_nst[col + j];
+                        const _Float16 hi = (_Float16)v;
+                        vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                    }
+                    *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
+                    *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                }
+        }
+        __syncthreads();
+        NB_TSTAMP(3);
+        _Float16* yn = p.yh2 + (size_t)n * p.c8_next * 2 * HW8;
+        if (!(p.dbg & 1)) {
+            for (int e = tid; e < (CO_WG / 8) * 2 * PIX_WG; e += 512) {
+                const int pix = e % PIX_WG, hl = (e / PIX_WG) & 1, cgl = e / (2 * PIX_WG);
+                const int cg = co0 / 8 + cgl;
+                if (cg * 8 < p.c_out) {
+                    const h8 v = *reinterpret_cast<const h8*>((hl ? sl : sh) + pix * CP + cgl * 8);
+                    *reinterpret_cast<h8*>(yn + (size_t)(cg * 2 + hl) * HW8 + ((size_t)(y0 + (pix >> 5)) * W + x0 + (pix & 31)) * 8) = v;
+                }
+            }
+        }
+        NB_TSTAMP(4);
+        return;
+    }
     float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG] floats (<= 128 KiB)
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -293,7 +340,8 @@ template <int MW>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * 2, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
-    const size_t lds = (size_t)(2 * 4 * XPL + 4 * 12 * CO_WG) * 16;
+    constexpr size_t lds_stage = (size_t)(2 * 4 * XPL + 4 * 12 * CO_WG) * 16, lds_h2 = (size_t)2 * TH * 32 * (CO_WG + 8) * 2;
+    const size_t lds = lds_stage > lds_h2 ? lds_stage : lds_h2;
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -308,10 +356,13 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
 
 extern "C" const float* nb_zero_page_ptr(void);
 
-extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
-                                    int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
-                                    float alpha, float gain, float clamp, void* stream) {
-    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && y, "modconv3x3_up1_h3: null pointer");
+static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                          int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
+                          int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
+                          void* stream) {
+    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && ((y != nullptr) != (y_h2 != nullptr)), "modconv3x3_up1_h3: null pointer");
+    NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
+               "modconv3x3_up1_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up1_h3: bad sizes");
     NB_REQUIRE(w % 32 == 0 && h % 16 == 0, "modconv3x3_up1_h3: needs w %% 32 == 0 and h %% 16 == 0 (got %dx%d)", h, w);
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up1_h3: pointers must be 16-byte aligned");
@@ -324,6 +375,7 @@ extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.tstamps = nullptr;
     if (g_tstamps) {
         const long long wgs = (long long)(w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64)) * n;
@@ -331,6 +383,21 @@ extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3
     }
     if (c_out > 64) return launch_h3<2>(p, n, (hipStream_t)stream);
     return launch_h3<1>(p, n, (hipStream_t)stream);
+}
+
+extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                                    int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                                    float alpha, float gain, float clamp, void* stream) {
+    return nb_up1_h3_impl(x_h2, c_in, w_h3, dcoefs, noise, noise_stride_n, bias, y, nullptr, nullptr, 0, 0, n, h, w, c_out,
+                          alpha, gain, clamp, stream);
+}
+
+extern "C" int nb_modconv3x3_up1_h3_h2(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                                       int64_t noise_stride_n, const float* bias, const float* next_styles, int next_stride,
+                                       void* y_h2, int c_next, int n, int h, int w, int c_out, float alpha, float gain,
+                                       float clamp, void* stream) {
+    return nb_up1_h3_impl(x_h2, c_in, w_h3, dcoefs, noise, noise_stride_n, bias, nullptr, y_h2, next_styles, next_stride,
+                          c_next, n, h, w, c_out, alpha, gain, clamp, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,6 +419,7 @@ struct H3Up2Params {
     int tiles_x, tiles_y, slices, dbg, stagger_ticks;
     float alpha, gain, clamp;
     unsigned long long* tstamps;
+    _Float16* yh2; const float* next_styles; int next_stride, c8_next;      // H2 output (see H3Params)
 };
 
 __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
@@ -387,12 +455,13 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     const int nblk = wv < NBLK - (NBJ - 1) * NW ? NBJ : NBJ - 1;      // blocks wv, wv+8 (< 15)
 
     // epilogue operands fetched under the prologue DMA: demodulation / bias per channel and the tile's noise
-    __shared__ float s_dco[32], s_bias[32];
+    __shared__ float s_dco[32], s_bias[32], s_nst[32];
     __shared__ float s_noise[2 * TQH * 2 * TQW];
     if (tid < 32) {
         const int co = co0 + tid;
         s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
         s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
+        s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
     for (int e = tid; e < 2 * TQH * 2 * TQW; e += 512) {
         const int r = e / (2 * TQW), c = e - r * (2 * TQW);
@@ -518,6 +587,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     const int Wo = 2 * W, Ho = 2 * H;
     constexpr int nquads = TQH * TQW;
     constexpr int RPR = 4;                            // accumulator registers per round
+    constexpr int OPIX = 4 * nquads;                  // output pixels of the tile
+    _Float16* obuf = reinterpret_cast<_Float16*>(y1s + RPR * 2 * Y1_SLOT);      // H2 output: [hi/lo][OPIX][8]
 #pragma unroll
     for (int round = 0; round < 16 / RPR; ++round) {
 #pragma unroll
@@ -564,8 +635,22 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             out[1][0] = 0.25f * vo1[0] + 0.75f * ve1[0] + 0.75f * vo1[1] + 0.25f * ve1[1];
             out[1][1] = 0.25f * ve1[0] + 0.75f * vo1[1] + 0.75f * ve1[1] + 0.25f * vo1[2];
             const int qi = I0 + ti, qj = J0 + tj;
-            if (co < p.c_out && qi < H && !(p.dbg & 1)) {
-                const float d = s_dco[col], bs = s_bias[col];
+            const float d = s_dco[col], bs = s_bias[col];
+            if (p.yh2) {
+                // the round's 8 channels are exactly channel group co0/8 + round: collect [hi/lo][pixel][8] slots in LDS
+                const float ns = s_nst[col];
+                const int ch = col & 7;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int opix = (2 * ti + dy) * (2 * TQW) + 2 * tj + dx;
+                        const float v = nb_h3_epilogue(out[dy][dx] * d + s_noise[opix], bs, p.alpha, p.gain, p.clamp) * ns;
+                        const _Float16 hi = (_Float16)v;
+                        obuf[opix * 8 + ch] = hi;
+                        obuf[(OPIX + opix) * 8 + ch] = (_Float16)(v - (float)hi);
+                    }
+            } else if (co < p.c_out && qi < H && !(p.dbg & 1)) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const int oy = 2 * qi + dy, ox = 2 * qj;
@@ -578,6 +663,19 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             }
         }
         __syncthreads();
+        if (p.yh2) {
+            const int cg = co0 / 8 + round;
+            if (cg * 8 < p.c_out && !(p.dbg & 1)) {
+                const size_t OHW8 = (size_t)Ho * Wo * 8;
+                _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
+                for (int e = tid; e < 2 * OPIX; e += 512) {
+                    const int hl = e / OPIX, opix = e - hl * OPIX;
+                    const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
+                    if (oy < Ho)
+                        *reinterpret_cast<h8*>(yn + (size_t)hl * OHW8 + ((size_t)oy * Wo + ox) * 8) = *reinterpret_cast<const h8*>(obuf + (size_t)e * 8);
+                }
+            }
+        }
     }
     NB_TSTAMP(4);
     if (p.tstamps) {
@@ -586,10 +684,13 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     }
 }
 
-extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
-                                    int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
-                                    float alpha, float gain, float clamp, void* stream) {
-    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && y, "modconv3x3_up2_h3: null pointer");
+static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                          int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
+                          int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
+                          void* stream) {
+    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && ((y != nullptr) != (y_h2 != nullptr)), "modconv3x3_up2_h3: null pointer");
+    NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
+               "modconv3x3_up2_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up2_h3: bad sizes");
     NB_REQUIRE(w % 32 == 0 && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0 (got %dx%d)", h, w);
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up2_h3: pointers must be 16-byte aligned");
@@ -603,9 +704,13 @@ extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3
     { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tiles_x = w / 32; p.tiles_y = (h + NB_H3_TQH - 1) / NB_H3_TQH; p.slices = (c_out + 31) / 32;
+    p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
     constexpr int XPL = (((NB_H3_TQH + 3) * 35 + 63) / 64) * 64;
-    const size_t lds = (size_t)2 * (4 * XPL + 36 * 32) * 16;
+    constexpr int NBLK_ = ((NB_H3_TQH + 2) * 34 + 31) / 32;
+    constexpr size_t lds_stage = (size_t)2 * (4 * XPL + 36 * 32) * 16;
+    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)2 * 4 * NB_H3_TQH * 32 * 16;   // FIR slots + H2 slots
+    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -615,6 +720,21 @@ extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3
     hipLaunchKernelGGL(modconv3x3_up2_h3_kernel, grid, dim3(512), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2_h3");
     return NB_OK;
+}
+
+extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                                    int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                                    float alpha, float gain, float clamp, void* stream) {
+    return nb_up2_h3_impl(x_h2, c_in, w_h3, dcoefs, noise, noise_stride_n, bias, y, nullptr, nullptr, 0, 0, n, h, w, c_out,
+                          alpha, gain, clamp, stream);
+}
+
+extern "C" int nb_modconv3x3_up2_h3_h2(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                                       int64_t noise_stride_n, const float* bias, const float* next_styles, int next_stride,
+                                       void* y_h2, int c_next, int n, int h, int w, int c_out, float alpha, float gain,
+                                       float clamp, void* stream) {
+    return nb_up2_h3_impl(x_h2, c_in, w_h3, dcoefs, noise, noise_stride_n, bias, nullptr, y_h2, next_styles, next_stride,
+                          c_next, n, h, w, c_out, alpha, gain, clamp, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,6 +771,40 @@ extern "C" int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, 
     dim3 grid((hw + 255) / 256, c8, n);
     hipLaunchKernelGGL(pack_h2_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, c1, x2, c2, scale, (_Float16*)out_h2, c8, hw);
     NB_CHECK_LAUNCH("pack_h2");
+    return NB_OK;
+}
+
+// Pack c channels of an fp32 NCHW tensor into channel groups cg0.. of an H2 tensor with c8_total groups (the geometry
+// features that the consumer concatenates behind a producer that wrote its own groups directly)
+__global__ __launch_bounds__(256) void pack_h2_part_kernel(const float* __restrict__ x, int c, const float* __restrict__ scale,
+                                                           int scale_stride, _Float16* __restrict__ out, int c8_total, int cg0, int hw) {
+    const int n = blockIdx.z, cgl = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cgl * 8 + j;
+        float v = 0.f;
+        if (ch < c) {
+            v = x[((size_t)n * c + ch) * hw + pix];
+            if (scale) v *= scale[(size_t)n * scale_stride + ch];
+        }
+        const _Float16 hh = (_Float16)v;
+        hi[j] = hh;
+        lo[j] = (_Float16)(v - (float)hh);
+    }
+    h8* o = reinterpret_cast<h8*>(out) + ((size_t)(n * c8_total + cg0 + cgl) * 2) * hw + pix;
+    o[0] = hi;
+    o[hw] = lo;
+}
+
+extern "C" int nb_pack_h2_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out_h2, int c8_total,
+                                   int cg0, int n, int hw, void* stream) {
+    NB_REQUIRE(x && out_h2 && c > 0 && n > 0 && n <= 65535 && hw > 0 && cg0 >= 0 && cg0 + (c + 7) / 8 <= c8_total, "pack_h2_part: bad arguments");
+    dim3 grid((hw + 255) / 256, (c + 7) / 8, n);
+    hipLaunchKernelGGL(pack_h2_part_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c, scale, scale_stride, (_Float16*)out_h2, c8_total, cg0, hw);
+    NB_CHECK_LAUNCH("pack_h2_part");
     return NB_OK;
 }
 

@@ -243,7 +243,8 @@ class SynthesisNetwork(torch.nn.Module):
         self.conv_mode = "h3"
         self.h3_min_batch = 4             # below this the launch-bound fp32 path (fewer launches, no pack passes) is faster
         self._h3_batch_ok = True
-        self.h2_fused_epilogue = False    # True: the up=2 kernel writes H2 itself (slower epilogue at present)
+        self.h2_fused_epilogue = False    # (fp32 up=2 kernel writing H2: superseded by h2_handoff)
+        self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
         self.layer_kernels: Dict[str, str] = {}
 
     # -- helpers --
@@ -396,14 +397,14 @@ class SynthesisNetwork(torch.nn.Module):
                 names = ([f"synthesis.b{res}.conv0"] if res > 4 else []) + [f"synthesis.b{res}.conv1"]
                 if res == 4:
                     x = block.const.unsqueeze(0).expand(n, -1, -1, -1).contiguous()     # networks.py:641-643
-                else:
+                elif x is not None:                  # (None: the previous block handed its output over in H2 format)
                     _assert_shape(x, [None, block.in_channels - (0 if x2 is None else x2.shape[1]), res // 2, res // 2])
                 for name in names:
                     i, s = specs[name]
                     layer = self.layer_module(s)
                     pk = self.packed[name]
-                    c1 = s.in_channels if x is None else x.shape[1]
                     c2 = 0 if x2 is None else x2.shape[1]
+                    c1 = s.in_channels - c2 if x is None else x.shape[1]
                     if c1 + c2 != s.in_channels:
                         raise AssertionError(f"{name}: got {c1}+{c2} input channels, expected {s.in_channels}")
                     noise_ptr, nstride = None, 0
@@ -415,61 +416,56 @@ class SynthesisNetwork(torch.nn.Module):
                         keep_alive.append(rnd)
                         noise_ptr, nstride = rnd.data_ptr(), s.block_res * s.block_res
                     clamp = -1.0 if layer.conv_clamp is None else float(layer.conv_clamp)
-                    ev = self._begin_event(name)
-                    if s.up == 1 and x_h2 is not None:
-                        # conv1 on the f16 matrix cores: input arrives pre-modulated in H2 format from conv0
-                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                        _lib.check(lib.nb_modconv3x3_up1_h3(
-                            _p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
-                            _p(layer.bias), _p(y), n, s.block_res, s.block_res, s.out_channels, 0.2, layer.act_gain,
-                            clamp, stream), name)
-                        self.layer_kernels[name] = "modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
-                        keep_alive.append(x_h2)
-                        x_h2 = None
-                    elif s.up == 2 and self._h3_up2_eligible(s):
-                        # conv0 on the f16 matrix cores: (x ++ geometry) * styles -> H2, then the 4-phase split-f16 kernel
-                        evp = self._begin_event("pack_h2")
-                        xin_h2 = torch.empty(ops.h2_shape(n, s.in_channels, s.in_res, s.in_res), dtype=torch.float16,
-                                             device=device)
-                        _lib.check(lib.nb_pack_h2_f32(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(xin_h2), n,
-                                                      s.in_res * s.in_res, stream), "pack_h2")
-                        self._end_event(evp)
+                    # split-f16 layers hand activations over in H2 format (pre-multiplied by the consumer's styles).
+                    # `x_h2` is this layer's complete H2 input if the previous layer produced it; `next_h2` is the
+                    # consumer's input tensor this layer writes into directly when both ends are split-f16 kernels
+                    # and nothing taps the fp32 activations in between (feature taps, blending, ToRGB, stop_after).
+                    nxt = cfg.layers[i + 1] if i + 1 < len(cfg.layers) else None
+                    at_block_end = s.up == 1
+                    tapped = at_block_end and (block.is_last or res in return_features or res in blended_features
+                                               or stop_after == res)
+                    me_h3 = self._h3_up2_eligible(s) if s.up == 2 else self._h3_eligible(s)
+                    nxt_h3 = nxt is not None and (self._h3_eligible(nxt) if nxt.up == 1 else self._h3_up2_eligible(nxt))
+                    fuse_out = (self.h2_handoff and me_h3 and nxt_h3 and not tapped and s.out_channels % 8 == 0)
+                    y = next_h2 = None
+                    if me_h3:
+                        if x_h2 is None:
+                            # producer was not a split-f16 kernel: (x ++ geometry) * styles -> H2
+                            evp = self._begin_event("pack_h2")
+                            x_h2 = torch.empty(ops.h2_shape(n, s.in_channels, s.in_res, s.in_res), dtype=torch.float16,
+                                               device=device)
+                            _lib.check(lib.nb_pack_h2_f32(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(x_h2), n,
+                                                          s.in_res * s.in_res, stream), "pack_h2")
+                            self._end_event(evp)
                         ev = self._begin_event(name)
-                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                        _lib.check(lib.nb_modconv3x3_up2_h3(
-                            _p(xin_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
-                            _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp,
-                            stream), name)
-                        self.layer_kernels[name] = "modconv3x3_up2_h3_kernel"
-                        keep_alive.append(xin_h2)
-                    elif s.up == 2 and self.h2_fused_epilogue and self._h3_eligible(specs[f"synthesis.b{res}.conv1"][1]):
-                        # conv0 writes its output directly in H2 format, multiplied by conv1's styles
-                        i1 = specs[f"synthesis.b{res}.conv1"][0]
-                        x_h2 = torch.empty(ops.h2_shape(n, s.out_channels, s.block_res, s.block_res), dtype=torch.float16,
-                                           device=device)
-                        _lib.check(lib.nb_modconv3x3_up2_f32_h2(
-                            _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
-                            nstride, _p(layer.bias), _p(plan.styles[i1]), _p(x_h2), n, s.in_res, s.in_res,
-                            s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
-                        self.layer_kernels[name] = self._variant_name(n, s) + " [H2 out]"
-                        y = None
+                        fn = {(1, False): lib.nb_modconv3x3_up1_h3, (2, False): lib.nb_modconv3x3_up2_h3,
+                              (1, True): lib.nb_modconv3x3_up1_h3_h2, (2, True): lib.nb_modconv3x3_up2_h3_h2}[(s.up, fuse_out)]
+                        if fuse_out:
+                            next_h2 = torch.empty(ops.h2_shape(n, nxt.in_channels, s.block_res, s.block_res),
+                                                  dtype=torch.float16, device=device)
+                            _lib.check(fn(_p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                                          _p(layer.bias), _p(plan.styles[i + 1]), nxt.in_channels, _p(next_h2),
+                                          nxt.in_channels, n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain,
+                                          clamp, stream), name)
+                        else:
+                            y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                            _lib.check(fn(_p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                                          _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2,
+                                          layer.act_gain, clamp, stream), name)
+                        self.layer_kernels[name] = ("modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
+                                                    if s.up == 1 else "modconv3x3_up2_h3_kernel")
+                        keep_alive.append(x_h2)
+                        self._end_event(ev)
                     else:
+                        ev = self._begin_event(name)
                         y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
                         _lib.check(lib.nb_modconv3x3_f32(
                             _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
                             nstride, _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, s.up, 0.2,
                             layer.act_gain, clamp, stream), name)
                         self.layer_kernels[name] = self._variant_name(n, s)
-                    self._end_event(ev)
-                    if s.up == 2 and y is not None and self._h3_eligible(specs[f"synthesis.b{res}.conv1"][1]):
-                        # hand conv1 its input in H2 format: fp32 NCHW * conv1's styles -> hi/lo f16, channel-blocked
-                        i1 = specs[f"synthesis.b{res}.conv1"][0]
-                        ev = self._begin_event("pack_h2")
-                        x_h2 = torch.empty(ops.h2_shape(n, s.out_channels, s.block_res, s.block_res), dtype=torch.float16,
-                                           device=device)
-                        _lib.check(lib.nb_pack_h2_f32(_p(y), s.out_channels, None, 0, _p(plan.styles[i1]), _p(x_h2), n,
-                                                      s.block_res * s.block_res, stream), "pack_h2")
                         self._end_event(ev)
+                    x_h2 = next_h2
                     keep_alive += [x, x2]
                     x, x2 = y, None
 
@@ -497,6 +493,18 @@ class SynthesisNetwork(torch.nn.Module):
                         raise RuntimeError(f"geom_feature is on {g.device} but the generator is on {device}")
                     x2 = g.to(torch.float32).contiguous()
                     _assert_shape(x2, [n, self.geom_feature_channels[self.geom_feature_resolutions.index(res)], res, res])
+                    if x_h2 is not None:
+                        # the block's last layer already wrote its channels into the consumer's H2 input: add the
+                        # geometry channels (x the consumer's styles) behind them
+                        inext, snext = specs[f"synthesis.b{2 * res}.conv0"]
+                        c_prod = snext.in_channels - x2.shape[1]
+                        evp = self._begin_event("pack_h2")
+                        _lib.check(lib.nb_pack_h2_part_f32(_p(x2), x2.shape[1], plan.styles[inext].data_ptr() + 4 * c_prod,
+                                                           snext.in_channels, _p(x_h2), (snext.in_channels + 7) // 8,
+                                                           c_prod // 8, n, res * res, stream), "pack_h2_part")
+                        self._end_event(evp)
+                        keep_alive.append(x2)
+                        x2 = None
         if len(debug_data) > 0:
             return img, debug_data
         return img

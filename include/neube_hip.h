@@ -190,6 +190,24 @@ int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n,
 int nb_blend_f32(const float* features, int nf, const float* alpha, int na, const float* x, float* y, int n, int c,
                  int hw, void* stream);
 
+/* The two split-f16 convolutions with the output written straight into the CONSUMER's H2 input tensor
+ * y_h2 = H2 [n, c_next, h_out, w_out] (channel groups 0 .. c_out/8-1; c_out % 8 == 0), already multiplied by the
+ * consumer's styles next_styles[n*next_stride + c] -- the fused form of SynthesisLayer.forward followed by the next
+ * layer's `x * styles` (networks.py:67, 362-391).  Removes the separate nb_pack_h2_f32 pass between two such layers. */
+int nb_modconv3x3_up1_h3_h2(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                            int64_t noise_stride_n, const float* bias, const float* next_styles, int next_stride,
+                            void* y_h2, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
+                            void* stream);
+int nb_modconv3x3_up2_h3_h2(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                            int64_t noise_stride_n, const float* bias, const float* next_styles, int next_stride,
+                            void* y_h2, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
+                            void* stream);
+
+/* fp32 NCHW x [n,c,hw] * scale[n*scale_stride + ch] (or NULL) -> channel groups cg0.. of an H2 tensor with c8_total
+ * groups: the geometry features concatenated behind a producer that wrote its groups itself (NM:218-219). */
+int nb_pack_h2_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out_h2, int c8_total, int cg0,
+                        int n, int hw, void* stream);
+
 /* ---- canvas side of the painting engine (SURVEY 8 rows e / f2) ---------------------------------------------
  * Cells: the canvas is cut into NB_CELL_H x NB_CELL_W pixel cells (row-major, ceil(w/NB_CELL_W) per row);
  * cell_off [ncells+1] / cell_tiles is a CSR list of the tiles whose rectangle touches each cell, in ascending

@@ -113,3 +113,67 @@ def test_up2_h3_vs_oracle(dev, shape):
     d = (D(s, dev).square() @ wsq + 1e-8).rsqrt()
     got = ops.modconv_up2_h3(xh2, ic, ops.pack_conv_weight_h3(wd), d, D(noise, dev), D(b, dev), oc, act_clamp=256.0)
     assert maxerr(got, want) <= 5e-5
+
+
+# ---------------------------------------------------------------- fused H2 hand-off between split-f16 layers
+@pytest.mark.parametrize("up,ci,co,res,c_next", [(1, 64, 64, 64, 64), (1, 128, 128, 32, 384), (2, 128, 64, 64, 64),
+                                                  (2, 144, 128, 64, 128)])
+def test_h2_handoff_kernels(up, ci, co, res, c_next):
+    """nb_modconv3x3_up{1,2}_h3_h2 == the fp32-output kernel followed by nb_pack_h2_f32 with the consumer's styles."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(ci + co + up)
+    n = 3
+    hin = res if up == 1 else res // 2
+    x = torch.from_numpy(rs.randn(n, ci, hin, hin).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    nst = torch.from_numpy(rs.uniform(0.5, 1.5, (n, c_next)).astype(np.float32)).cuda()
+    dco = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32)).cuda()
+    noise = torch.from_numpy(rs.randn(n, res, res).astype(np.float32)).cuda()
+    xh, wp = ops.pack_h2(x, st), ops.pack_conv_weight_h3(w)
+    lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    y = torch.empty([n, co, res, res], device="cuda")
+    f32 = lib.nb_modconv3x3_up1_h3 if up == 1 else lib.nb_modconv3x3_up2_h3
+    h2 = lib.nb_modconv3x3_up1_h3_h2 if up == 1 else lib.nb_modconv3x3_up2_h3_h2
+    _lib.check(f32(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), noise.data_ptr(), res * res, bias.data_ptr(), y.data_ptr(),
+                   n, hin, hin, co, 0.2, 1.4142135, 256.0, S), "f32")
+    out = torch.zeros(ops.h2_shape(n, c_next, res, res), dtype=torch.float16, device="cuda")
+    _lib.check(h2(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), noise.data_ptr(), res * res, bias.data_ptr(), nst.data_ptr(),
+                  c_next, out.data_ptr(), c_next, n, hin, hin, co, 0.2, 1.4142135, 256.0, S), "h2")
+    ref = ops.pack_h2(y, nst[:, :co].contiguous())
+    # same value; the hi/lo split may differ where y*style is an exact f16 tie (the fused kernel rounds the product
+    # once, the two-pass path twice), so compare hi+lo, which carries 22 bits either way
+    got, want = ops.unpack_h2(out[:, :co // 8].contiguous(), co), ops.unpack_h2(ref, co)
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    assert (out[:, :co // 8] != ref).float().mean() < 1e-3
+    assert not out[:, co // 8:].any()                       # channel groups of the geometry features are left alone
+    if c_next > co:
+        g = torch.from_numpy(rs.randn(n, c_next - co, res, res).astype(np.float32)).cuda()
+        _lib.check(lib.nb_pack_h2_part_f32(g.data_ptr(), c_next - co, nst.data_ptr() + 4 * co, c_next, out.data_ptr(),
+                                           (c_next + 7) // 8, co // 8, n, res * res, S), "part")
+        full = ops.pack_h2(y, nst, g)
+        assert torch.equal(out[:, co // 8:], full[:, co // 8:])
+
+
+def test_generator_h2_handoff_equals_pack_path():
+    """End to end: the fused hand-off changes no bit of the output."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod
+    from brushstroke_engine_amd.networks import Generator
+    cfg = cfgmod.style1_config(256)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0)).to("cuda")
+    from brushstroke_engine_amd import synthetic
+    n = 4
+    z = torch.from_numpy(synthetic.batch_z(cfg, n)).cuda()
+    gf = [torch.from_numpy(a).cuda() for a in synthetic.geom_features(cfg, n, seed=1)]
+    pos = torch.from_numpy(synthetic.positions(cfg, n, seed=1)).cuda()
+    G.synthesis.h2_handoff = True
+    a, _, da = G.render_triad(z=z, geom_feature=gf, positions=pos)
+    G.synthesis.h2_handoff = False
+    b, _, db = G.render_triad(z=z, geom_feature=gf, positions=pos)
+    assert float((da["uvs"] - db["uvs"]).abs().max()) < 2e-6        # 22-bit hand-off either way
+    assert int((a.int() - b.int()).abs().max()) <= 1 and float((a != b).float().mean()) < 1e-4
+    # taps still work with the hand-off enabled (fp32 features at the blending resolution)
+    G.synthesis.h2_handoff = True
+    _, _, dc = G.render_triad(z=z, geom_feature=gf, positions=pos, return_features=[128])
+    assert float((dc["uvs"] - da["uvs"]).abs().max()) < 2e-6 and dc["features128"].shape == (n, 128, 128, 128)

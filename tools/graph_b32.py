@@ -21,3 +21,12 @@ for _ in range(3): gr.replay()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): gr.replay()
 torch.cuda.synchronize(); print("graph ms/step", (time.perf_counter() - t0) / 20 * 1e3)
+# host-side enqueue time of one eager step (no GPU wait): is the eager path host-bound?
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    G.render_triad(z=z, geom_feature=geom, positions=pos)
+    ts.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+print("host enqueue ms/step (eager)", sorted(ts)[len(ts) // 2])
