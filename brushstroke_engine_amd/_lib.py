@@ -62,6 +62,8 @@ PROTOTYPES = {
     "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp,
                                      C.c_int, C.c_int, C.c_int, vp]),
     "nb_blend_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_modconv3x3_up1_h3_torgb": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_float, C.c_float, C.c_float, vp, vp]),
     "nb_modconv3x3_up1_h3_h2": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
     "nb_modconv3x3_up2_h3_h2": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,
@@ -76,6 +78,13 @@ PROTOTYPES = {
     "nb_enc_upsample2x_h2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "nb_pack_conv_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
 }
+
+
+class NbTorgbArgs(C.Structure):
+    """``struct NbTorgbArgs`` of include/neube_hip.h."""
+    _fields_ = [("styles", vp), ("w", vp), ("bias", vp), ("color_bias", vp), ("logits", vp), ("uvs", vp), ("img", vp),
+                ("colors_out", vp), ("user_colors", vp), ("sfactor", vp), ("rgba_f32", vp), ("rgba_u8", vp),
+                ("styles_stride_n", C.c_int), ("render_mode", C.c_int), ("clamp", C.c_float)]
 
 
 class NeubeHipError(RuntimeError):

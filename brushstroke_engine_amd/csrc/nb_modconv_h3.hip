@@ -22,6 +22,7 @@
 // the activation halo tile of a chunk is double buffered; counted vmcnt + raw s_barrier keep 2 sub-chunks of
 // LDS-DMA in flight behind the MFMAs.
 #include "nb_common.h"
+#include "nb_torgb.h"
 #include <cstdlib>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -50,6 +51,9 @@ struct H3Params {
     _Float16* yh2;
     const float* next_styles;      // [n][next_stride]
     int next_stride, c8_next;
+    // fused triad ToRGB (last layer; the workgroup holds all c_out channels of its pixels): tg.c != 0 enables it,
+    // y may then be null (the fp32 activations are only needed when somebody taps them)
+    TorgbParams tg;
 };
 
 static unsigned long long* g_tstamps = nullptr;
@@ -123,6 +127,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
         s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
+    __shared__ float s_tw[3 * CO_WG], s_tcol[9], s_tcol01[9];
+    if (p.tg.c) nb_torgb_setup(p.tg, n, s_tw, s_tcol, s_tcol01, tid, 512, blockIdx.x == 0);
     float nzr[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
@@ -317,6 +323,19 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     }
     __syncthreads();
     NB_TSTAMP(3);
+    if (p.tg.c) {
+        // ToRGB on the tile while it sits in LDS: 3 dot products over the channels per pixel, then the triad tail
+        for (int pix = tid; pix < PIX_WG; pix += 512) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+            for (int ch = 0; ch < p.c_out; ++ch) {
+                const float xv = ot[ch * PIX_WG + pix];
+                a0 += xv * s_tw[ch]; a1 += xv * s_tw[p.c_out + ch]; a2 += xv * s_tw[2 * p.c_out + ch];
+            }
+            nb_torgb_pixel(p.tg, n, (y0 + (pix >> 5)) * W + x0 + (pix & 31), a0, a1, a2, s_tcol, s_tcol01);
+        }
+        if (!p.y) return;
+    }
     if (!(p.dbg & 1)) {
         constexpr int V4_PER_ROW = PIX_WG / 4;                   // float4 per c_out row
         for (int e = tid; e < CO_WG * V4_PER_ROW; e += 512) {
@@ -359,8 +378,8 @@ extern "C" const float* nb_zero_page_ptr(void);
 static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
-                          void* stream) {
-    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && ((y != nullptr) != (y_h2 != nullptr)), "modconv3x3_up1_h3: null pointer");
+                          void* stream, const TorgbParams* tg = nullptr) {
+    NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && (tg ? !y_h2 : ((y != nullptr) != (y_h2 != nullptr))), "modconv3x3_up1_h3: null pointer");
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
                "modconv3x3_up1_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up1_h3: bad sizes");
@@ -376,6 +395,8 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
+    p.tg = TorgbParams{};
+    if (tg) p.tg = *tg;
     p.tstamps = nullptr;
     if (g_tstamps) {
         const long long wgs = (long long)(w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64)) * n;
@@ -390,6 +411,22 @@ extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3
                                     float alpha, float gain, float clamp, void* stream) {
     return nb_up1_h3_impl(x_h2, c_in, w_h3, dcoefs, noise, noise_stride_n, bias, y, nullptr, nullptr, 0, 0, n, h, w, c_out,
                           alpha, gain, clamp, stream);
+}
+
+extern "C" int nb_modconv3x3_up1_h3_torgb(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                                          int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                                          float alpha, float gain, float clamp, const NbTorgbArgs* t, void* stream) {
+    NB_REQUIRE(t && t->styles && t->w && t->bias && t->color_bias, "modconv3x3_up1_h3_torgb: null pointer");
+    NB_REQUIRE(c_out <= 128, "modconv3x3_up1_h3_torgb: the fused ToRGB needs all channels in one workgroup (c_out <= 128)");
+    NB_REQUIRE(t->styles_stride_n >= c_out + 9, "torgb_triad: styles rows must hold 9 color scalars + c styles");
+    NB_REQUIRE(t->render_mode == 0 || t->render_mode == 1, "Unknown render mode for TriadGanPaintEngine: %d", t->render_mode);
+    TorgbParams tg;
+    tg.x = nullptr; tg.styles = t->styles; tg.w = t->w; tg.bias = t->bias; tg.color_bias = t->color_bias;
+    tg.logits = t->logits; tg.uvs = t->uvs; tg.img = t->img; tg.colors_out = t->colors_out; tg.user_colors = t->user_colors;
+    tg.sfactor = t->sfactor; tg.rgba_f32 = t->rgba_f32; tg.rgba_u8 = t->rgba_u8;
+    tg.styles_stride_n = t->styles_stride_n; tg.c = c_out; tg.hw = h * w; tg.render_mode = t->render_mode; tg.clamp = t->clamp;
+    return nb_up1_h3_impl(x_h2, c_in, w_h3, dcoefs, noise, noise_stride_n, bias, y, nullptr, nullptr, 0, 0, n, h, w, c_out,
+                          alpha, gain, clamp, stream, &tg);
 }
 
 extern "C" int nb_modconv3x3_up1_h3_h2(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,

@@ -4,6 +4,7 @@
 // All are HBM- or latency-bound; they use 64-wide waves, 16-byte accesses where the layout allows,
 // and LDS only for per-block constants.
 #include "nb_common.h"
+#include "nb_torgb.h"
 #include <cmath>
 #include <cstring>
 
@@ -326,13 +327,6 @@ extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max
 // triad ToRGB epilogue (networks.py:451-485) + paint-engine compositing (forger/ui/brush.py:763-792)
 // HBM-bound: reads x once (16 B per lane per channel), writes the 3-channel results.
 // ------------------------------------------------------------------------------------------------
-struct TorgbParams {
-    const float* x; const float* styles; const float* w; const float* bias; const float* color_bias;
-    float* logits; float* uvs; float* img; float* colors_out; const float* user_colors; const float* sfactor; float* rgba_f32; uint8_t* rgba_u8;
-    int styles_stride_n, c, hw, render_mode;
-    float clamp;
-};
-
 template <int V>
 __global__ __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
     extern __shared__ float sw[];          // [3][c] modulated weights, then 9 colors, 9 col01

@@ -245,6 +245,7 @@ class SynthesisNetwork(torch.nn.Module):
         self._h3_batch_ok = True
         self.h2_fused_epilogue = False    # (fp32 up=2 kernel writing H2: superseded by h2_handoff)
         self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
+        self.fuse_torgb = True            # last conv1 + ToRGB + compositing in one launch (split-f16 path)
         self.layer_kernels: Dict[str, str] = {}
 
     # -- helpers --
@@ -428,6 +429,7 @@ class SynthesisNetwork(torch.nn.Module):
                     nxt_h3 = nxt is not None and (self._h3_eligible(nxt) if nxt.up == 1 else self._h3_up2_eligible(nxt))
                     fuse_out = (self.h2_handoff and me_h3 and nxt_h3 and not tapped and s.out_channels % 8 == 0)
                     y = next_h2 = None
+                    fused_rgb = None
                     if me_h3:
                         if x_h2 is None:
                             # producer was not a split-f16 kernel: (x ++ geometry) * styles -> H2
@@ -440,7 +442,21 @@ class SynthesisNetwork(torch.nn.Module):
                         ev = self._begin_event(name)
                         fn = {(1, False): lib.nb_modconv3x3_up1_h3, (2, False): lib.nb_modconv3x3_up2_h3,
                               (1, True): lib.nb_modconv3x3_up1_h3_h2, (2, True): lib.nb_modconv3x3_up2_h3_h2}[(s.up, fuse_out)]
-                        if fuse_out:
+                        fuse_rgb = (self.fuse_torgb and block.is_last and s.up == 1 and s.out_channels <= 128
+                                    and res not in blended_features)
+                        if fuse_rgb:
+                            # last conv + ToRGB + compositing in one launch; the fp32 activations are only written
+                            # when a caller taps them
+                            tg = self._torgb_setup(plan, n, device, extra)
+                            targs = self._torgb_args(plan, tg, s.out_channels)
+                            if res in return_features or stop_after == res:
+                                y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                            _lib.check(lib.nb_modconv3x3_up1_h3_torgb(
+                                _p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                                _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp,
+                                ctypes.byref(targs), stream), name)
+                            fused_rgb = self._torgb_finish(tg, extra)
+                        elif fuse_out:
                             next_h2 = torch.empty(ops.h2_shape(n, nxt.in_channels, s.block_res, s.block_res),
                                                   dtype=torch.float16, device=device)
                             _lib.check(fn(_p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
@@ -472,7 +488,7 @@ class SynthesisNetwork(torch.nn.Module):
                 if stop_after is not None and res == stop_after:
                     return x
                 if block.is_last:
-                    img, triad = self._torgb(plan, x, n, stream, extra)
+                    img, triad = fused_rgb if fused_rgb is not None else self._torgb(plan, x, n, stream, extra)
                     if return_debug_data:
                         debug_data.update(triad)
                 if res in return_features:
@@ -509,13 +525,11 @@ class SynthesisNetwork(torch.nn.Module):
             return img, debug_data
         return img
 
-    def _torgb(self, plan: _Plan, x, n, stream, extra):
+    def _torgb_setup(self, plan: _Plan, n, dev, extra):
+        """Allocate the ToRGB outputs and collect the launch arguments (shared by the standalone and fused forms)."""
         cfg = self.cfg
-        block = self.get_last_block()
-        t = block.torgb
+        t = self.get_last_block().torgb
         r = cfg.img_resolution
-        c = x.shape[1]
-        dev = x.device
         uvs = torch.empty([n, 3, r, r], dtype=torch.float32, device=dev)
         img = torch.empty([n, 3, r, r], dtype=torch.float32, device=dev)
         colors = torch.empty([n, 3, 3], dtype=torch.float32, device=dev)
@@ -541,15 +555,33 @@ class SynthesisNetwork(torch.nn.Module):
             if mode < 0:
                 raise RuntimeError("Unknown render mode for TriadGanPaintEngine: {}".format(extra.get("render_mode")))
         clamp = -1.0 if t.conv_clamp is None else float(t.conv_clamp)
+        return dict(t=t, uvs=uvs, img=img, colors=colors, logits=logits, rgba=rgba, rgba8=rgba8, user=user, sfac=sfac,
+                    mode=mode, clamp=clamp, r=r)
+
+    def _torgb_finish(self, o, extra):
+        if extra is not None:
+            extra["out"] = {"logits": o["logits"], "rgba": o["rgba"], "rgba_u8": o["rgba8"]}
+        return o["img"], {"colors": o["colors"], "uvs": o["uvs"]}
+
+    def _torgb_args(self, plan: _Plan, o, c) -> "_lib.NbTorgbArgs":
+        a = _lib.NbTorgbArgs()
+        a.styles, a.w, a.bias, a.color_bias = _p(plan.styles[-1]), _p(self.packed["torgb"]["w"]), _p(o["t"].bias), _p(o["t"].color_bias)
+        a.logits, a.uvs, a.img, a.colors_out = _p(o["logits"]), _p(o["uvs"]), _p(o["img"]), _p(o["colors"])
+        a.user_colors, a.sfactor, a.rgba_f32, a.rgba_u8 = _p(o["user"]), _p(o["sfac"]), _p(o["rgba"]), _p(o["rgba8"])
+        a.styles_stride_n, a.render_mode, a.clamp = c + 9, o["mode"], o["clamp"]
+        return a
+
+    def _torgb(self, plan: _Plan, x, n, stream, extra):
+        c = x.shape[1]
+        o = self._torgb_setup(plan, n, x.device, extra)
+        r = o["r"]
         ev = self._begin_event("torgb")
         _lib.check(_lib.lib().nb_torgb_triad_f32(
-            _p(x), _p(plan.styles[-1]), c + 9, _p(self.packed["torgb"]["w"]), _p(t.bias), _p(t.color_bias), clamp,
-            _p(logits), _p(uvs), _p(img), _p(colors), _p(user), _p(sfac), mode, _p(rgba), _p(rgba8), n, c, r * r, stream),
-            "torgb_triad")
+            _p(x), _p(plan.styles[-1]), c + 9, _p(self.packed["torgb"]["w"]), _p(o["t"].bias), _p(o["t"].color_bias),
+            o["clamp"], _p(o["logits"]), _p(o["uvs"]), _p(o["img"]), _p(o["colors"]), _p(o["user"]), _p(o["sfac"]),
+            o["mode"], _p(o["rgba"]), _p(o["rgba8"]), n, c, r * r, stream), "torgb_triad")
         self._end_event(ev)
-        if extra is not None:
-            extra["out"] = {"logits": logits, "rgba": rgba, "rgba_u8": rgba8}
-        return img, {"colors": colors, "uvs": uvs}
+        return self._torgb_finish(o, extra)
 
 
 class Generator(torch.nn.Module):

@@ -190,6 +190,28 @@ int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n,
 int nb_blend_f32(const float* features, int nf, const float* alpha, int na, const float* x, float* y, int n, int c,
                  int hw, void* stream);
 
+/* Arguments of the triad ToRGB epilogue when it is fused into the last conv (same meaning as the parameters of
+ * nb_torgb_triad_f32; any output pointer may be NULL). */
+struct NbTorgbArgs {
+    const float* styles;      /* [n, styles_stride_n]: 9 color scalars then c styles (affine output) */
+    const float* w;           /* [3, c] */
+    const float* bias;        /* [3] */
+    const float* color_bias;  /* [9] */
+    float* logits; float* uvs; float* img; float* colors_out;
+    const float* user_colors; /* [n,3,3] or NULL */
+    const float* sfactor;     /* [n] or NULL */
+    float* rgba_f32; uint8_t* rgba_u8;
+    int styles_stride_n, render_mode;
+    float clamp;
+};
+
+/* Last SynthesisLayer (up = 1) + ToRGBColorTriadLayer + compositing in one launch: nb_modconv3x3_up1_h3 followed by
+ * nb_torgb_triad_f32 on the tile while it is still in LDS (c_out <= 128).  y (the fp32 activations) may be NULL:
+ * nothing but ToRGB reads them unless a caller taps the features. */
+int nb_modconv3x3_up1_h3_torgb(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
+                               int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                               float alpha, float gain, float clamp, const struct NbTorgbArgs* t, void* stream);
+
 /* The two split-f16 convolutions with the output written straight into the CONSUMER's H2 input tensor
  * y_h2 = H2 [n, c_next, h_out, w_out] (channel groups 0 .. c_out/8-1; c_out % 8 == 0), already multiplied by the
  * consumer's styles next_styles[n*next_stride + c] -- the fused form of SynthesisLayer.forward followed by the next

@@ -177,3 +177,27 @@ def test_generator_h2_handoff_equals_pack_path():
     G.synthesis.h2_handoff = True
     _, _, dc = G.render_triad(z=z, geom_feature=gf, positions=pos, return_features=[128])
     assert float((dc["uvs"] - da["uvs"]).abs().max()) < 2e-6 and dc["features128"].shape == (n, 128, 128, 128)
+
+
+@pytest.mark.parametrize("res", [128, 256])
+def test_fused_torgb_equals_standalone(res):
+    """Last conv1 + ToRGB + compositing in one launch == the two-launch form (same arithmetic order), all outputs."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    cfg = cfgmod.style1_config(res)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0)).to("cuda")
+    n = 5
+    z = torch.from_numpy(synthetic.batch_z(cfg, n)).cuda()
+    gf = [torch.from_numpy(a).cuda() for a in synthetic.geom_features(cfg, n, seed=1)]
+    pos = torch.from_numpy(synthetic.positions(cfg, n, seed=1)).cuda()
+    user = torch.full([n, 3, 3], float("nan")); user[1, :, 0] = torch.tensor([1.0, 0.0, 0.25])
+    kw = dict(z=z, geom_feature=gf, positions=pos, want_f32=True, user_colors=user, sfactor=torch.tensor(1.3), render_mode="clear")
+    outs = {}
+    for fused in (True, False):
+        G.synthesis.fuse_torgb = fused
+        u8, f32, dbg = G.render_triad(**kw)
+        img, dbg2 = G(z, None, gf, positions=pos, noise_mode="const", return_debug_data=True, return_features=[res])
+        outs[fused] = (u8, f32, dbg["uvs"], dbg["colors"], img, dbg2[f"features{res}"])
+    for a, b in zip(outs[True][1:], outs[False][1:]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[True][0], outs[False][0])
