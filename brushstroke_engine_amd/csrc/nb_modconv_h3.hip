@@ -29,6 +29,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define NB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define NB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
 
     // epilogue operands fetched under the prologue DMA: demodulation / bias per channel and the tile's noise
     __shared__ float s_dco[32], s_bias[32], s_nst[32];
-    __shared__ float s_noise[2 * TQH * 2 * TQW];
+    __shared__ __attribute__((aligned(16))) float s_noise[2 * TQH * 2 * TQW];
     if (tid < 32) {
         const int co = co0 + tid;
         s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
@@ -641,9 +642,15 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             }
         }
         __syncthreads();
-        for (int it = tid; it < RPR * 2 * nquads; it += 512) {
-            const int s = it / nquads, qd = it - s * nquads;
-            const int ti = qd / TQW, tj = qd - ti * TQW;
+        // FIR + activation: one item = one channel x one row of quads x 2 adjacent quads (2 x 4 output pixels).
+        // Column pairs are evaluated with packed fp32 math; the expressions keep the operand order of the reference
+        // polyphase form  0.25 a + 0.75 b + 0.75 c + 0.25 d  (left to right).
+        for (int it = tid; it < RPR * 2 * TQH * (TQW / 2); it += 512) {
+            // lanes of a wave span the round's 8 channels x 8 quad pairs: the 2-byte H2 writes below then fall into 16
+            // different LDS banks (pixel slots are 16 bytes, so one channel alone would hit only 4)
+            const int s = it % (RPR * 2);
+            const int rr_ = it / (RPR * 2);
+            const int p2 = rr_ % (TQW / 2), ti = rr_ / (TQW / 2), tj = 2 * p2;
             const int rho = round * RPR + (s >> 1);
             const int col = (rho & 3) + 8 * (rho >> 2) + 4 * (s & 1);
             const int co = co0 + col;
@@ -651,26 +658,28 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             const float* eo = ee + 1 * Y1_PHASE;
             const float* oe = ee + 2 * Y1_PHASE;
             const float* oo = ee + 3 * Y1_PHASE;
-            float ve0[2], ve1[2], vo0[3], vo1[3];
+            auto ld2 = [](const float* q) { return *reinterpret_cast<const f32x2*>(q); };
+            auto fv0 = [](auto o0, auto e0, auto o1, auto e1) { return 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1; };
+            auto fv1 = [](auto e0, auto o1, auto e1, auto o2) { return 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2; };
+            // even output columns come from (ee, oe) at quad columns tj..tj+2, odd ones from (eo, oo) at tj..tj+3
+            const f32x2 eeA0 = ld2(ee), eeA1 = ld2(ee + PW), oeA0 = ld2(oe), oeA1 = ld2(oe + PW), oeA2 = ld2(oe + 2 * PW);
+            const float eeB0 = ee[2], eeB1 = ee[PW + 2], oeB0 = oe[2], oeB1 = oe[PW + 2], oeB2 = oe[2 * PW + 2];
+            const f32x2 eoA0 = ld2(eo), eoA1 = ld2(eo + PW), ooA0 = ld2(oo), ooA1 = ld2(oo + PW), ooA2 = ld2(oo + 2 * PW);
+            const f32x2 eoC0 = ld2(eo + 2), eoC1 = ld2(eo + PW + 2), ooC0 = ld2(oo + 2), ooC1 = ld2(oo + PW + 2), ooC2 = ld2(oo + 2 * PW + 2);
+            const f32x2 ve0A = fv0(oeA0, eeA0, oeA1, eeA1), ve1A = fv1(eeA0, oeA1, eeA1, oeA2);
+            const float ve0B = fv0(oeB0, eeB0, oeB1, eeB1), ve1B = fv1(eeB0, oeB1, eeB1, oeB2);
+            const f32x2 vo0A = fv0(ooA0, eoA0, ooA1, eoA1), vo1A = fv1(eoA0, ooA1, eoA1, ooA2);
+            const f32x2 vo0C = fv0(ooC0, eoC0, ooC1, eoC1), vo1C = fv1(eoC0, ooC1, eoC1, ooC2);
+            const float ve[2][3] = {{ve0A[0], ve0A[1], ve0B}, {ve1A[0], ve1A[1], ve1B}};
+            const float vo[2][4] = {{vo0A[0], vo0A[1], vo0C[0], vo0C[1]}, {vo1A[0], vo1A[1], vo1C[0], vo1C[1]}};
+            float out[2][4];
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const float e0 = ee[cc], e1 = ee[PW + cc];
-                const float o0 = oe[cc], o1 = oe[PW + cc], o2 = oe[2 * PW + cc];
-                ve0[cc] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
-                ve1[cc] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
-            }
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                const float e0 = eo[cc], e1 = eo[PW + cc];
-                const float o0 = oo[cc], o1 = oo[PW + cc], o2 = oo[2 * PW + cc];
-                vo0[cc] = 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1;
-                vo1[cc] = 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2;
-            }
-            float out[2][2];
-            out[0][0] = 0.25f * vo0[0] + 0.75f * ve0[0] + 0.75f * vo0[1] + 0.25f * ve0[1];
-            out[0][1] = 0.25f * ve0[0] + 0.75f * vo0[1] + 0.75f * ve0[1] + 0.25f * vo0[2];
-            out[1][0] = 0.25f * vo1[0] + 0.75f * ve1[0] + 0.75f * vo1[1] + 0.25f * ve1[1];
-            out[1][1] = 0.25f * ve1[0] + 0.75f * vo1[1] + 0.75f * ve1[1] + 0.25f * vo1[2];
+                for (int q = 0; q < 2; ++q) {
+                    out[dy][2 * q] = 0.25f * vo[dy][q] + 0.75f * ve[dy][q] + 0.75f * vo[dy][q + 1] + 0.25f * ve[dy][q + 1];
+                    out[dy][2 * q + 1] = 0.25f * ve[dy][q] + 0.75f * vo[dy][q + 1] + 0.75f * ve[dy][q + 1] + 0.25f * vo[dy][q + 2];
+                }
             const int qi = I0 + ti, qj = J0 + tj;
             const float d = s_dco[col], bs = s_bias[col];
             if (p.yh2) {
@@ -678,24 +687,26 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 const float ns = s_nst[col];
                 const int ch = col & 7;
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int opix0 = (2 * ti + dy) * (2 * TQW) + 2 * tj;
+                    const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + opix0);
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int opix = (2 * ti + dy) * (2 * TQW) + 2 * tj + dx;
-                        const float v = nb_h3_epilogue(out[dy][dx] * d + s_noise[opix], bs, p.alpha, p.gain, p.clamp) * ns;
+                    for (int dx = 0; dx < 4; ++dx) {
+                        const float v = nb_h3_epilogue(out[dy][dx] * d + nz[dx], bs, p.alpha, p.gain, p.clamp) * ns;
                         const _Float16 hi = (_Float16)v;
-                        obuf[opix * 8 + ch] = hi;
-                        obuf[(OPIX + opix) * 8 + ch] = (_Float16)(v - (float)hi);
+                        obuf[(opix0 + dx) * 8 + ch] = hi;
+                        obuf[(OPIX + opix0 + dx) * 8 + ch] = (_Float16)(v - (float)hi);
                     }
+                }
             } else if (co < p.c_out && qi < H && !(p.dbg & 1)) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const int oy = 2 * qi + dy, ox = 2 * qj;
-                    const float n0 = s_noise[(2 * ti + dy) * (2 * TQW) + 2 * tj], n1 = s_noise[(2 * ti + dy) * (2 * TQW) + 2 * tj + 1];
-                    float2 o;
-                    o.x = nb_h3_epilogue(out[dy][0] * d + n0, bs, p.alpha, p.gain, p.clamp);
-                    o.y = nb_h3_epilogue(out[dy][1] * d + n1, bs, p.alpha, p.gain, p.clamp);
-                    *reinterpret_cast<float2*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = o;
+                    const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + (2 * ti + dy) * (2 * TQW) + 2 * tj);
+                    f32x4 o;
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx) o[dx] = nb_h3_epilogue(out[dy][dx] * d + nz[dx], bs, p.alpha, p.gain, p.clamp);
+                    *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = o;
                 }
             }
         }
