@@ -136,23 +136,24 @@ def dirty_area_alpha(width: int, margin: int, crop_margin: int = 0) -> np.ndarra
 
 def build_cells(rects: np.ndarray, h: int, w: int) -> Tuple[np.ndarray, np.ndarray]:
     """CSR list of the rectangles (y0, x0, y1, x1; end-exclusive) touching each CELL_H x CELL_W cell of an h x w
-    grid, in ascending rectangle order (include/neube_hip.h, "Cells")."""
+    grid, in ascending rectangle order (include/neube_hip.h, "Cells").  Vectorised: canvases have thousands of tiles."""
     ncx, ncy = -(-w // CELL_W), -(-h // CELL_H)
-    cells, tiles = [], []
-    for t, (y0, x0, y1, x1) in enumerate(np.asarray(rects, np.int64).reshape(-1, 4)):
-        y0, x0, y1, x1 = max(int(y0), 0), max(int(x0), 0), min(int(y1), h), min(int(x1), w)
-        if y1 <= y0 or x1 <= x0:
-            continue
-        cy = np.arange(y0 // CELL_H, (y1 - 1) // CELL_H + 1)
-        cx = np.arange(x0 // CELL_W, (x1 - 1) // CELL_W + 1)
-        ids = (cy[:, None] * ncx + cx[None, :]).ravel()
-        cells.append(ids)
-        tiles.append(np.full(ids.shape, t, np.int64))
+    r = np.asarray(rects, np.int64).reshape(-1, 4)
+    y0, x0 = np.maximum(r[:, 0], 0), np.maximum(r[:, 1], 0)
+    y1, x1 = np.minimum(r[:, 2], h), np.minimum(r[:, 3], w)
+    ok = (y1 > y0) & (x1 > x0)
     off = np.zeros(ncx * ncy + 1, np.int32)
-    if not cells:
+    if not ok.any():
         return off, np.zeros(1, np.int32)
-    cells, tiles = np.concatenate(cells), np.concatenate(tiles)
-    order = np.lexsort((tiles, cells))                    # by cell, then ascending tile index
+    t_idx = np.nonzero(ok)[0]
+    cy0, cx0 = y0[ok] // CELL_H, x0[ok] // CELL_W
+    ny, nx = (y1[ok] - 1) // CELL_H - cy0 + 1, (x1[ok] - 1) // CELL_W - cx0 + 1
+    cnt = ny * nx
+    rep = np.repeat(np.arange(len(t_idx)), cnt)                       # which rectangle each (cell, tile) pair belongs to
+    local = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    cells = (cy0[rep] + local // nx[rep]) * ncx + cx0[rep] + local % nx[rep]
+    tiles = t_idx[rep]
+    order = np.lexsort((tiles, cells))                                # by cell, then ascending tile index
     np.cumsum(np.bincount(cells, minlength=ncx * ncy), out=off[1:])
     return off, tiles[order].astype(np.int32)
 
@@ -233,6 +234,13 @@ class TileOps:
     # -- inputs --
     def to_device(self, a: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=True)
+
+    def to_host(self, t: torch.Tensor) -> np.ndarray:
+        """Device tensor -> numpy through a pinned buffer (the caching host allocator recycles it once the array dies)."""
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return host.numpy()
 
     def geom_tiles(self, geom_dev: torch.Tensor, tile_yx: torch.Tensor) -> torch.Tensor:
         gh, gw = geom_dev.shape
@@ -537,10 +545,16 @@ class PaintingHelper:
         canvas = self.render_tiles(padded[..., 0], crops, opts, crop_margin=crop_margin)
         if canvas is None:
             return None
-        full = canvas.cpu().numpy()
-        result = full
+        m, (h0, w0) = crop_margin, geom.shape[:2]
+        to_host = getattr(self.ops, "to_host", lambda t: t.cpu().numpy())
+        result = canvas[m:m + h0, m:m + w0]                          # crop on the device: only the answer crosses PCIe
         if on_white:                                                # paint_image_main.py:179-183 (3 channels out)
-            a = result[..., 3:].astype(np.float32) / 255
-            result = (result[..., :3].astype(np.float32) * a + 255 * (1 - a)).clip(0, 255).astype(np.uint8)
-        out = result[crop_margin:crop_margin + geom.shape[0], crop_margin:crop_margin + geom.shape[1], :]
+            # alpha = a / 255 through a host-computed table: device division is not correctly rounded
+            lut = self.ops.to_device(np.arange(256, dtype=np.float32) / np.float32(255))
+            a = lut[result[..., 3:].to(torch.int64)]
+            result = (result[..., :3].to(torch.float32) * a + 255 * (1 - a)).clip(0, 255).to(torch.uint8)
+        out = to_host(result.contiguous())
+        if not return_full:
+            return out
+        full = to_host(canvas)
         return (out, full, crops, padded) if return_full else out

@@ -272,3 +272,19 @@ def test_schedule_with_uvs_mapping(eng):
     _canvas_close(full, g["canvas_level2_clear_uvsmap"])
     with pytest.raises(RuntimeError):
         painting.PaintingHelper(ops).render_tiles(g["geom_padded"], g["crops"][:1], opts)
+
+
+def test_on_white_matches_reference_formula(eng):
+    """--on_white (paint_image_main.py:179-183): float32 compositing over white, 3 channels out."""
+    helper, (out, full, crops, padded) = _paint(eng, 2)
+    ops = OracleTileOps(eng["cfg"], eng["sd"], eng["esd"])
+    h2 = painting.PaintingHelper(ops, batch=4)
+    h2.set_feature_blending(2)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    m = int(eng["g"]["crop_margin"])
+    white = h2.paint_image(eng["g"]["geom"], opts, crop_margin=m, on_white=True)
+    alpha = full[..., 3:].astype(np.float32) / 255
+    ref = (full[..., :3].astype(np.float32) * alpha + 255 * (1 - alpha)).clip(0, 255).astype(np.uint8)
+    h0, w0 = eng["g"]["geom"].shape
+    assert np.array_equal(white, ref[m:m + h0, m:m + w0]) and white.shape == (h0, w0, 3)

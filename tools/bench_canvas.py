@@ -74,7 +74,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = helper.paint_image(geom, opts, crop_margin=a.crop_margin, return_full=True)
+        out = helper.paint_image(geom, opts, crop_margin=a.crop_margin)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -86,7 +86,7 @@ def main():
         elif a.breakdown and world == 1:
             _TIMES.clear()
     if rank == 0:
-        n_tiles = len(out[2])
+        n_tiles = len(painting.generate_stitching_crops(painting.pad_geo(geom, a.crop_margin), a.res, 'all', 2 * a.crop_margin)[0])
         t = float(np.mean(times))
         line = {"metric": "tiled canvas stylization, tiles/s (end to end: host tiling + H2D + encoder + generator + "
                           "paste + D2H)", "value": n_tiles / t, "unit": "tiles/s", "n_gpus": world, "seconds": t,
