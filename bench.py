@@ -137,12 +137,20 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    # test hooks for a 1-GPU box: NB_BENCH_SHARE_GPU=1 puts every rank on device 0, NB_BENCH_BACKEND=gloo swaps RCCL out
+    # (exercises the N>1 control flow; numbers from such a run mean nothing)
+    if os.environ.get("NB_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
     from brushstroke_engine_amd.networks import Generator
@@ -157,6 +165,21 @@ def main():
     geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, seed=rank)]
     pos = torch.from_numpy(synthetic.positions(cfg, B, seed=rank)).to(dev)
     gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if (world > 1 and not args.no_gather) else None
+    gather_note = ""
+    if gatherer is not None:
+        # pre-flight: one small RCCL gather; if the fabric refuses it the bench still measures the sharded compute
+        try:
+            probe = TileGatherer([4, 8, 8, 4], torch.uint8, dev)
+            probe.start(torch.full([4, 8, 8, 4], rank, dtype=torch.uint8, device=dev))
+            got = probe.finish()
+            torch.cuda.synchronize()
+            ok = torch.tensor([1.0 if (rank != 0 or all(int(g.flatten()[0]) == r for r, g in enumerate(got))) else 0.0], device=dev)
+        except Exception as e:                                     # noqa: BLE001
+            print(f"[bench] rank {rank}: RCCL gather pre-flight failed: {e}", file=sys.stderr, flush=True)
+            ok = torch.tensor([0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1:
+            gatherer, gather_note = None, " (RCCL gather of RGBA tiles disabled: pre-flight failed)"
 
     def step():
         u8, _, _ = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear")
@@ -315,7 +338,7 @@ def main():
                                    f"style1 checkpoint shapes (BASELINE.json configs[1]); generator + triad compositing "
                                    f"to uint8 RGBA; geometry features precomputed",
                        "batch_per_gpu": B, "resolution": args.res, "gflop_per_patch": round(2 * cfg.macs_per_patch() / 1e9, 3),
-                       "parallelism": f"patch-parallel x{world}" + (" + RCCL gather of RGBA tiles to rank 0" if gatherer else "")},
+                       "parallelism": f"patch-parallel x{world}" + (" + RCCL gather of RGBA tiles to rank 0" if gatherer else "") + gather_note},
             "roofline": roofline,
             "rehearsal_ms_per_step": round(rehearsal_ms, 4),
             "burn_in_ms_per_step": [round(b, 3) for b in burn_in[:6]] + (["..."] if len(burn_in) > 7 else []) + [round(b, 3) for b in burn_in[6:][-1:]],
