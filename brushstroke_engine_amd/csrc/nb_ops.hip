@@ -267,47 +267,51 @@ extern "C" int nb_demod_coefs_f32(const float* styles, const float* wsq, float* 
 // constant noise, optionally position-shifted (networks.py:371-382, SURVEY note C), all layers at once
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ norm_pos,
-                                                    const long long* __restrict__ positions, int img_res) {
+                                                    const long long* __restrict__ positions, int img_res, int n_total) {
     const NbLayerDesc L = layers[blockIdx.y];
     if (!L.noise_const) return;
-    const int r = L.res, n = blockIdx.z;
+    const int r = L.res;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= r * r) return;
+    if (idx >= r * r) return;          // (most blocks of the small layers: the grid is sized for the largest one)
     const float strength = L.noise_strength[0];
     if (!norm_pos && !positions) {
-        L.noise_out[idx] = L.noise_const[idx] * strength;
+        if (blockIdx.z == 0) L.noise_out[idx] = L.noise_const[idx] * strength;
         return;
     }
     const int i = idx / r, j = idx - i * r;
-    float np0, np1;
-    if (positions) {
-        // networks_modified.py:351-353: (positions % R) / (R - 1), python-style modulo, IEEE float32 division
-        // (done here, not with a torch GPU op: torch's device division is not correctly rounded and the
-        // wrap `% 1` below is discontinuous, so a 1-ulp difference moves whole noise rows)
-        const long long R = img_res;
-        const long long p0 = ((positions[2 * n + 0] % R) + R) % R, p1 = ((positions[2 * n + 1] % R) + R) % R;
-        np0 = (float)p0 / (float)(img_res - 1);
-        np1 = (float)p1 / (float)(img_res - 1);
-    } else {
-        np0 = norm_pos[2 * n + 0];
-        np1 = norm_pos[2 * n + 1];
+    const float li = L.noise_lin[i], lj = L.noise_lin[j];
+    // a block walks the samples (grid.z is small): 4x fewer, fatter blocks than one block per (tile, layer, sample)
+    for (int n = blockIdx.z; n < n_total; n += gridDim.z) {
+        float np0, np1;
+        if (positions) {
+            // networks_modified.py:351-353: (positions % R) / (R - 1), python-style modulo, IEEE float32 division
+            // (done here, not with a torch GPU op: torch's device division is not correctly rounded and the
+            // wrap `% 1` below is discontinuous, so a 1-ulp difference moves whole noise rows)
+            const long long R = img_res;
+            const long long p0 = ((positions[2 * n + 0] % R) + R) % R, p1 = ((positions[2 * n + 1] % R) + R) % R;
+            np0 = (float)p0 / (float)(img_res - 1);
+            np1 = (float)p1 / (float)(img_res - 1);
+        } else {
+            np0 = norm_pos[2 * n + 0];
+            np1 = norm_pos[2 * n + 1];
+        }
+        // grid[i,j] = (lin[i] + pos0, lin[j] + pos1); channel 0 is the COLUMN coordinate, channel 1 the ROW
+        const float g0 = fmodf(li + np0, 1.f) * 2.f - 1.f;
+        const float g1 = fmodf(lj + np1, 1.f) * 2.f - 1.f;
+        const float cx = ((g0 + 1.f) / 2.f) * (float)(r - 1);
+        const float cy = ((g1 + 1.f) / 2.f) * (float)(r - 1);
+        const float x0 = floorf(cx), y0 = floorf(cy);
+        const int x0i = (int)x0, y0i = (int)y0, x1i = x0i + 1, y1i = y0i + 1;
+        const float wx1 = cx - x0, wy1 = cy - y0, wx0 = (x0 + 1.f) - cx, wy0 = (y0 + 1.f) - cy;
+        auto tap = [&](int yi, int xi) -> float {
+            return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? L.noise_const[yi * r + xi] : 0.f;
+        };
+        float v = tap(y0i, x0i) * (wx0 * wy0);
+        v += tap(y0i, x1i) * (wx1 * wy0);
+        v += tap(y1i, x0i) * (wx0 * wy1);
+        v += tap(y1i, x1i) * (wx1 * wy1);
+        L.noise_out[(size_t)n * r * r + idx] = v * strength;
     }
-    // grid[i,j] = (lin[i] + pos0, lin[j] + pos1); channel 0 is the COLUMN coordinate, channel 1 the ROW
-    const float g0 = fmodf(L.noise_lin[i] + np0, 1.f) * 2.f - 1.f;
-    const float g1 = fmodf(L.noise_lin[j] + np1, 1.f) * 2.f - 1.f;
-    const float cx = ((g0 + 1.f) / 2.f) * (float)(r - 1);
-    const float cy = ((g1 + 1.f) / 2.f) * (float)(r - 1);
-    const float x0 = floorf(cx), y0 = floorf(cy);
-    const int x0i = (int)x0, y0i = (int)y0, x1i = x0i + 1, y1i = y0i + 1;
-    const float wx1 = cx - x0, wy1 = cy - y0, wx0 = (x0 + 1.f) - cx, wy0 = (y0 + 1.f) - cy;
-    auto tap = [&](int yi, int xi) -> float {
-        return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? L.noise_const[yi * r + xi] : 0.f;
-    };
-    float v = tap(y0i, x0i) * (wx0 * wy0);
-    v += tap(y0i, x1i) * (wx1 * wy0);
-    v += tap(y1i, x0i) * (wx0 * wy1);
-    v += tap(y1i, x1i) * (wx1 * wy1);
-    L.noise_out[(size_t)n * r * r + idx] = v * strength;
 }
 
 extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max_res, const float* norm_pos,
@@ -316,9 +320,9 @@ extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max
     NB_REQUIRE(n_layers >= 1 && n_layers <= 65535 && max_res >= 1 && n >= 1 && n <= 65535, "noise: bad sizes");
     NB_REQUIRE(!(norm_pos && positions), "noise: pass either norm_pos or positions, not both");
     NB_REQUIRE(!positions || img_resolution >= 2, "noise: positions need img_resolution >= 2");
-    dim3 grid(nb_cdiv(max_res * max_res, 256), n_layers, (norm_pos || positions) ? n : 1);
+    dim3 grid(nb_cdiv(max_res * max_res, 256), n_layers, (norm_pos || positions) ? (n < 4 ? n : 4) : 1);
     hipLaunchKernelGGL(noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, layers_dev, norm_pos,
-                       (const long long*)positions, img_resolution);
+                       (const long long*)positions, img_resolution, n);
     NB_CHECK_LAUNCH("noise");
     return NB_OK;
 }

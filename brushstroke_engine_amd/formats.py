@@ -140,11 +140,23 @@ class SeedBrushLibrary(BrushLibrary):
                                 style_id=_interp_style_id(style_id1, style_id2, alpha))
 
 
-class RandomBrushLibrary(SeedBrushLibrary):
-    """``rand<N>``: accepts any integer style id; lists N random ones."""
+class RandomBrushLibrary(BrushLibrary):
+    """``rand<N>`` (library.py:237-251): ids ``rand0..rand<N-1>``; every ``set_style`` draws a fresh UNIFORM [0,1) latent from
+    a torch generator seeded with 1 (``forger/metrics/util.py:77-89``, ``RandomState(0)``), whatever the id."""
 
-    def __init__(self, nseeds, zdim):
-        super().__init__([random.randint(0, 10000) for _ in range(nseeds)], zdim)
+    def __init__(self, num, zdim, seed=0):
+        self.num, self.zdim = num, zdim
+        self.tgenerator = torch.Generator()
+        self.tgenerator.manual_seed(seed + 1)
+
+    def get_style_ids(self):
+        return ["rand" + str(x) for x in range(self.num)]
+
+    def set_style(self, style_id, brush_options):
+        brush_options.set_style(torch.rand((1, self.zdim), dtype=torch.float32, generator=self.tgenerator))
+
+    def set_interpolated_style(self, style_id1, style_id2, alpha, brush_options):
+        self.set_style(style_id1, brush_options)
 
 
 class WBrushLibrary(BrushLibrary):

@@ -84,7 +84,11 @@ def test_seed_and_w_libraries(tmp_path):
     lib.set_style("594", opts)
     assert opts.style_id == "594" and opts.style_ws is None
     assert np.array_equal(opts.style_z.numpy(), np.random.RandomState(594).randn(1, 64))
-    assert formats.BrushLibrary.from_arg("rand5", 64).zdim == 64 and len(formats.BrushLibrary.from_arg("rand5").zs) == 5
+    rl = formats.BrushLibrary.from_arg("rand5", 64)
+    assert rl.get_style_ids() == ["rand0", "rand1", "rand2", "rand3", "rand4"]
+    rl.set_style("rand3", opts)
+    g = torch.Generator(); g.manual_seed(1)
+    assert torch.equal(opts.style_z, torch.rand((1, 64), generator=g)) and opts.style_id is None
     assert formats.BrushLibrary.from_arg("3,1,2").get_style_ids() == ["1", "2", "3"]
     assert len(formats.BrushLibrary.from_arg("4").zs) == 4
     lib.set_interpolated_style("594", "7", 0.25, opts)

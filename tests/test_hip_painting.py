@@ -176,3 +176,24 @@ def test_uvs_mapping_on_gpu(eng):
     for i, sf in enumerate((1.7, 1.2)):
         ref = no.triad_composite(dbg["uvs"][i:i + 1].cpu(), dbg["colors"][i:i + 1].cpu(), "clear", None, torch.tensor(np.float32(sf)))
         np.testing.assert_allclose(rgba[i:i + 1].cpu().numpy(), ref.numpy(), atol=2e-6)
+
+
+def test_paint_image_main_cli(eng, tmp_path):
+    """The paint_image_main counterpart end to end: snapshot container + PNG in, stylized PNG out (== paint_image)."""
+    from PIL import Image
+    from brushstroke_engine_amd import formats, paint_image_main
+    g = eng["g"]
+    snap = str(tmp_path / "engine.npz")
+    formats.save_engine_snapshot(snap, eng["cfg"], eng["sd"], eng["esd"], preproc_type=None)
+    png = str(tmp_path / "drawing.png")
+    Image.fromarray(g["geom"]).save(png)
+    out = paint_image_main.main(["--gan_checkpoint", snap, "--geom_image", png, "--output_file_prefix", str(tmp_path / "o" / "res"),
+                                 "--style_id", "594", "--library", "594,12", "--feature_blending_level", "2", "--no_uvs_mapping"])
+    assert out.endswith("res_clear_594.png")
+    img = np.array(Image.open(out))
+    m = int(g["crop_margin"])
+    h0, w0 = g["geom"].shape
+    _canvas_close(img, g["canvas_level2_clear"][m:m + h0, m:m + w0])
+    out2 = paint_image_main.main(["--gan_checkpoint", snap, "--geom_image", png, "--output_file_prefix", str(tmp_path / "o" / "w"),
+                                  "--style_id", "594", "--library", "594,12", "--on_white", "--color_mode", "255,0,0;;", "--no_uvs_mapping"])
+    assert np.array(Image.open(out2)).shape == (h0, w0, 3)
