@@ -692,6 +692,7 @@ static int nb_select_variant(int n, int h, int w, int c_out, int up, int* tq = n
     if (up == 1) {
         static const int cand[6][2] = {{128, 256}, {64, 512}, {64, 256}, {32, 256}, {32, 128}, {32, 32}};   // c_out x pixels per workgroup (last: split-K)
         const long hw = (long)h * w;
+        if (hw <= 32) return 10;       // 4x4 images: one 32-pixel block per sample, latency-bound -> split K over the waves
         int best = 4; long best_wgs = -1;
         for (int i = 0; i < 6; ++i) {
             const int co_wg = cand[i][0], pix = cand[i][1];
