@@ -356,6 +356,222 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-workgroup form of the same layer: 4 waves, 64 c_out x 256 px, <= 75 KB of LDS, so TWO workgroups share a
+// CU and one's prologue / epilogue (DMA latency, VALU, stores) runs under the other's MFMAs.  K loop = (16-channel
+// chunk, tap row) steps, double buffered: the rows a step needs are gathered by LDS-DMA (zero page outside the
+// image), the next step's DMA is in flight under the current step's MFMAs (the scheme of nb_encoder.hip).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Params p) {
+    constexpr int NW = 4, MB = 2, NBW = 2, CO_WG = 64, TH = NW * NBW, PW = 34, PIX_WG = TH * 32;
+    constexpr int SLOTS = TH * PW, PP = (SLOTS + 63) / 64, XPL = PP * 64, NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;
+    constexpr int WSLOTS = 12 * CO_WG, NWP = WSLOTS / 64, NWPW = NWP / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
+    h8* xbuf = reinterpret_cast<h8*>(smem_h3);                    // [2][4][XPL]
+    h8* wbuf = xbuf + 2 * 4 * XPL;                                // [2][WSLOTS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
+    const int H = p.h, W = p.w;
+    int b = blockIdx.x;
+    if (gridDim.x % 8 == 0 && p.slices > 1) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);       // slices of a tile share an XCD
+    const int slice = b % p.slices; b /= p.slices;
+    const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
+    const int n = blockIdx.y;
+    const int y0 = tile_y * TH, x0 = tile_x * 32, co0 = slice * CO_WG;
+    const size_t HW8 = (size_t)H * W * 8;
+    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+
+    __shared__ float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
+    __shared__ float s_tw[3 * 128], s_tcol[9], s_tcol01[9];
+    if (tid < CO_WG) {
+        const int co = co0 + tid;
+        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
+        s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
+        s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
+    }
+    if (p.tg.c) nb_torgb_setup(p.tg, n, s_tw, s_tcol, s_tcol01, tid, 256, blockIdx.x == 0);
+    float nzr[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+        nzr[nb] = p.noise ? p.noise[(size_t)n * p.noise_stride_n + (size_t)(y0 + wn * NBW + nb) * W + x0 + l31] : 0.f;
+
+    int xcol[NXPW], xrow[NXPW], xpl[NXPW], xdst[NXPW];
+#pragma unroll
+    for (int i = 0; i < NXPW; ++i) {
+        const int q = i * NW + wn;                    // NXP = NW * NXPW exactly
+        const int pl4 = q / PP, part = q - pl4 * PP;
+        const int e = part * 64 + lane;
+        const int r = e / PW, c = e - r * PW;
+        const int gx = x0 - 1 + c;
+        xpl[i] = pl4;
+        xdst[i] = pl4 * XPL + part * 64;
+        xrow[i] = y0 - 1 + r;
+        xcol[i] = (e < SLOTS && gx >= 0 && gx < W) ? gx * 8 : -1;
+    }
+    auto issue = [&](int t, int buf) {                // t = chunk * 3 + ky
+        const int c = t / 3, ky = t - 3 * c;
+        h8* xd = xbuf + buf * 4 * XPL;
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            const int cg = 2 * c + (xpl[i] >> 1), gy = xrow[i] + ky;
+            const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
+            if (xcol[i] >= 0 && gy >= 0 && gy < H && cg < p.c8)
+                src = xn + (size_t)(4 * c + xpl[i]) * HW8 + (size_t)gy * W * 8 + xcol[i];
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(xd + xdst[i]), 16, 0, 0);
+        }
+        h8* wd = wbuf + buf * WSLOTS;
+#pragma unroll
+        for (int i = 0; i < NWPW; ++i) {
+            const int e = (i * NW + wn) * 64 + lane;
+            const int row = e / CO_WG, j = e - row * CO_WG;                      // row = kx*4 + cg*2 + hl
+            const _Float16* src = p.wts + (((size_t)t * 12 + row) * p.co_ld + co0 + j) * 8;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(wd + (i * NW + wn) * 64), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    const int T = p.nchunks * 3;
+    const int a_base = lh * 2 * CO_WG + l31;
+    const int b_base = lh * 2 * XPL + (wn * NBW) * PW + l31;
+    issue(0, 0);
+    for (int t = 0; t < T; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(t + 1 < T ? t + 1 : T - 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const h8* xb = xbuf + (t & 1) * 4 * XPL;
+        const h8* wb = wbuf + (t & 1) * WSLOTS;
+        h8 ah[2][MB], al[2][MB], bh[2][NBW], bl[2][NBW];
+        auto fetch = [&](int kx, h8 (&fah)[MB], h8 (&fal)[MB], h8 (&fbh)[NBW], h8 (&fbl)[NBW]) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                fah[mb] = wb[a_base + kx * 4 * CO_WG + mb * 32];
+                fal[mb] = wb[a_base + kx * 4 * CO_WG + CO_WG + mb * 32];
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                fbh[nb] = xb[b_base + nb * PW + kx];
+                fbl[nb] = xb[b_base + XPL + nb * PW + kx];
+            }
+        };
+        fetch(0, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int cu = kx & 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][0], bh[cu][0], acc[0][0], 0, 0, 0);
+            if (kx + 1 < 3) fetch(kx + 1, ah[cu ^ 1], al[cu ^ 1], bh[cu ^ 1], bl[cu ^ 1]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    if (mb + nb > 0)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][mb], bh[cu][nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu][mb], bl[cu][nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cu][mb], bh[cu][nb], acc[mb][nb], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (kx + 1 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB + 2 * NBW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MB * NBW - 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // staging buffers are dead from here on
+
+    if (p.yh2) {
+        constexpr int CP = CO_WG + 8;
+        _Float16* sh = reinterpret_cast<_Float16*>(smem_h3);
+        _Float16* sl = sh + PIX_WG * CP;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int pix = (wn * NBW + nb) * 32 + l31;
+            const float nz = nzr[nb];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = mb * 32 + 8 * g + 4 * lh;
+                    h4 vh, vl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = nb_h3_epilogue(acc[mb][nb][4 * g + j] * s_dco[col + j] + nz, s_bias[col + j], p.alpha, p.gain, p.clamp) * s_nst[col + j];
+                        const _Float16 hi = (_Float16)v;
+                        vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                    }
+                    *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
+                    *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                }
+        }
+        __syncthreads();
+        _Float16* yn = p.yh2 + (size_t)n * p.c8_next * 2 * HW8;
+        for (int e = tid; e < (CO_WG / 8) * 2 * PIX_WG; e += 256) {
+            const int pix = e % PIX_WG, hl = (e / PIX_WG) & 1, cgl = e / (2 * PIX_WG);
+            const int cg = co0 / 8 + cgl;
+            if (cg * 8 < p.c_out) {
+                const h8 v = *reinterpret_cast<const h8*>((hl ? sl : sh) + pix * CP + cgl * 8);
+                *reinterpret_cast<h8*>(yn + (size_t)(cg * 2 + hl) * HW8 + ((size_t)(y0 + (pix >> 5)) * W + x0 + (pix & 31)) * 8) = v;
+            }
+        }
+        return;
+    }
+    float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG]
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int trow = wn * NBW + nb;
+        const float nz = nzr[nb];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_epilogue(acc[mb][nb][r] * s_dco[col] + nz, s_bias[col], p.alpha, p.gain, p.clamp);
+            }
+    }
+    __syncthreads();
+    if (p.tg.c) {
+        for (int pix = tid; pix < PIX_WG; pix += 256) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+            for (int ch = 0; ch < p.c_out; ++ch) {
+                const float xv = ot[ch * PIX_WG + pix];
+                a0 += xv * s_tw[ch]; a1 += xv * s_tw[p.c_out + ch]; a2 += xv * s_tw[2 * p.c_out + ch];
+            }
+            nb_torgb_pixel(p.tg, n, (y0 + (pix >> 5)) * W + x0 + (pix & 31), a0, a1, a2, s_tcol, s_tcol01);
+        }
+        if (!p.y) return;
+    }
+    constexpr int V4_PER_ROW = PIX_WG / 4;
+    for (int e = tid; e < CO_WG * V4_PER_ROW; e += 256) {
+        const int col = e / V4_PER_ROW, q4 = e - col * V4_PER_ROW;
+        const int co = co0 + col;
+        if (co < p.c_out) {
+            const int trow = q4 >> 3, px = (q4 & 7) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ot + col * PIX_WG + q4 * 4);
+            *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)H * W) + (size_t)(y0 + trow) * W + x0 + px) = v;
+        }
+    }
+}
+
+static int launch_h3s(H3Params p, int n, hipStream_t st) {
+    constexpr size_t lds_stage = (size_t)2 * (4 * 320 + 12 * 64) * 16, lds_h2 = (size_t)2 * 256 * 72 * 2;
+    const size_t lds = p.yh2 ? lds_h2 : lds_stage;
+    p.tiles_x = p.w / 32; p.tiles_y = p.h / 8; p.slices = (p.c_out + 63) / 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h2);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(modconv3x3_up1_h3s_kernel, dim3(p.tiles_x * p.tiles_y * p.slices, n), dim3(256), lds, st, p);
+    NB_CHECK_LAUNCH("modconv3x3_up1_h3s");
+    return NB_OK;
+}
+
 template <int MW>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * 2, CO_WG = MW * 64;
@@ -403,6 +619,11 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
         const long long wgs = (long long)(w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64)) * n;
         if (wgs <= g_tstamps_cap) p.tstamps = g_tstamps;
     }
+    // the 4-wave / 2-workgroups-per-CU form wins on small images (fewer, larger workgroups leave CUs idle there); on the
+    // large layers both forms run at the same rate -- the chip is power-limited in these loops, not latency-limited
+    { const char* e = getenv("NB_UP1_SMALL");
+      const bool small = e ? atoi(e) != 0 : (h * w <= 32 * 32);
+      if (small && (!tg || c_out <= 64)) return launch_h3s(p, n, (hipStream_t)stream); }
     if (c_out > 64) return launch_h3<2>(p, n, (hipStream_t)stream);
     return launch_h3<1>(p, n, (hipStream_t)stream);
 }
