@@ -669,7 +669,12 @@ extern "C" int nb_modconv3x3_up1_h3_h2(const void* x_h2, int c_in, const void* w
 // carries 2 blocks x 4 phases x 16 = 128 accumulator registers; the A/B fragments are streamed per tap.
 // (12 rows do not divide the image height: the last tile row overhangs and is masked.)  Input H2 (pre-modulated), weights [chunk][tap 9][cg 2][hi/lo 2][c_out_ld][8], output fp32 NCHW.
 // ------------------------------------------------------------------------------------------------
+#ifndef NB_H3_TQH
 #define NB_H3_TQH 12
+#endif
+#ifndef NB_H3_STAGES
+#define NB_H3_STAGES 2          // LDS-DMA stages of the up=2 kernel.  3 (needs NB_H3_TQH <= 10 to fit the LDS) was measured:
+#endif                           // no faster -- the K loop is not DMA-latency bound
 struct H3Up2Params {
     const _Float16* x;      // H2 [n][c8][2][H][W][8]
     const _Float16* wts;    // [nchunks][9][2][2][co_ld][8]
@@ -784,8 +789,14 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             for (int r = 0; r < 16; ++r) acc[j][ph][r] = 0.f;
 
     const int NC = p.nchunks;
+    constexpr int NST = NB_H3_STAGES;
     issue(0, ring);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NST == 3) {
+        issue(NC > 1 ? 1 : 0, ring + STAGE);                       // (single-chunk layers: a harmless second copy)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXPW + NWPW) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     NB_TSTAMP(1);
     // tap (a,b) row-major -> (slot offset of its input pixel, output phase): x11 = X(r,c), x10 = X(r,c+1),
@@ -797,8 +808,14 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int kGrp[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
     constexpr int kPha[9] = {3, 2, 1, 0, 2, 0, 1, 0, 0};                 // kTapPhase[kOrd[i]]
     for (int c = 0; c < NC; ++c) {
-        h8* st = ring + (c & 1) * STAGE;
-        if (c + 1 < NC && !(p.dbg & 2)) issue(c + 1, ring + ((c + 1) & 1) * STAGE);
+        h8* st = ring + (c % NST) * STAGE;
+        if (NST == 3) {
+            // two chunks of LDS-DMA in flight: chunk c+2 goes into the stage chunk c-1 just left (past the end: a
+            // harmless re-copy of the last chunk keeps the vmcnt bookkeeping uniform)
+            issue(c + 2 < NC ? c + 2 : NC - 1, ring + ((c + 2) % NST) * STAGE);
+        } else if (c + 1 < NC && !(p.dbg & 2)) {
+            issue(c + 1, ring + ((c + 1) & 1) * STAGE);
+        }
         __builtin_amdgcn_sched_barrier(0);
         h8 ah[2], al[2], bh[2][NBJ], bl[2][NBJ];
         ah[0] = st[aoff + kOrd[0] * 128]; al[0] = st[aoff + kOrd[0] * 128 + 32];
@@ -836,9 +853,13 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ - 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // chunk c+1 must have landed; with 3 stages the DMA of chunk c+2 may stay in flight
+        if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXPW + NWPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain before the staging LDS is reused
+    __builtin_amdgcn_s_barrier();
 
     NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
@@ -978,7 +999,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
     constexpr int XPL = (((NB_H3_TQH + 3) * 35 + 63) / 64) * 64;
     constexpr int NBLK_ = ((NB_H3_TQH + 2) * 34 + 31) / 32;
-    constexpr size_t lds_stage = (size_t)2 * (4 * XPL + 36 * 32) * 16;
+    constexpr size_t lds_stage = (size_t)NB_H3_STAGES * (4 * XPL + 36 * 32) * 16;
     constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)2 * 4 * NB_H3_TQH * 32 * 16;   // FIR slots + H2 slots
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_set = false;
