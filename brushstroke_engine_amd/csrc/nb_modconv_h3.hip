@@ -807,6 +807,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int kDel[9] = {0, 0, 0, 0, 1, 1, XS, XS, XS + 1};          // slot offset, in walk order
     constexpr int kGrp[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
     constexpr int kPha[9] = {3, 2, 1, 0, 2, 0, 1, 0, 0};                 // kTapPhase[kOrd[i]]
+    unsigned long long t_dma = 0, t_bar = 0;
+    const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
     for (int c = 0; c < NC; ++c) {
         h8* st = ring + (c % NST) * STAGE;
         if (NST == 3) {
@@ -847,16 +849,25 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][j], aj, 0, 0, 0);
                 aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][j], aj, 0, 0, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            // next tap's fragment reads go out BEFORE this tap's six MFMAs (their registers are free: the previous tap
+            // has issued), which gives the LDS the whole tap to answer
             if (nfetch == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             else if (nfetch) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NBJ, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ - 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         // chunk c+1 must have landed; with 3 stages the DMA of chunk c+2 may stay in flight
+        unsigned long long tw0 = 0;
+        if (p.tstamps) tw0 = __builtin_amdgcn_s_memtime();
         if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXPW + NWPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.tstamps) { const unsigned long long tw1 = __builtin_amdgcn_s_memtime(); t_dma += tw1 - tw0; tw0 = tw1; }
         __builtin_amdgcn_s_barrier();
+        if (p.tstamps) t_bar += __builtin_amdgcn_s_memtime() - tw0;
+    }
+    if (p.tstamps && tid == 0) {
+        unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        ts[6] = t_dma; ts[7] = t_bar | ((__builtin_amdgcn_s_memtime() - t_loop0) << 32);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // drain before the staging LDS is reused
     __builtin_amdgcn_s_barrier();

@@ -63,12 +63,12 @@ def run(kind, n, ci, co, res):
     print("    mean workgroups in phase:", {nm: round(float(occ[i].mean()), 1) for i, nm in enumerate(names)},
           " max storing at once:", int((occ[3] + occ[4]).max()))
     # gaps between a CU slot finishing and the next workgroup starting cannot be seen directly; estimate idle from totals
-    if kind == "up1":
+    if True:
         raw = ts.cpu().numpy()[: t.shape[0]]
         dma, bar, loop = raw[:, 6].astype(np.float64), (raw[:, 7] & 0xffffffff).astype(np.float64), (raw[:, 7] >> 32).astype(np.float64)
         print(f"    wave 0 inside the k-loop (shader cycles): total {loop.mean():.0f}, parked on vmcnt {dma.mean():.0f} "
               f"({dma.mean() / loop.mean() * 100:.1f}%), parked on the barrier {bar.mean():.0f} ({bar.mean() / loop.mean() * 100:.1f}%); "
-              f"clock {loop.mean() / (d[:, 1].mean() * 1e-6) / 1e9:.2f} GHz")
+              f"s_memtime ticks per us {loop.mean() / d[:, 1].mean():.0f}")
     busy = (us[:, 5] - us[:, 0]).sum()
     print(f"    sum of workgroup times / (256 CUs x span) = {busy / (256 * us[:, 5].max()):.2f}")
 
