@@ -241,7 +241,7 @@ class SynthesisNetwork(torch.nn.Module):
         # "h3": large conv1 layers on the f16 matrix cores as hi/lo split products (fp32-grade, ~5x the fp32 MFMA
         # rate); "f32": every layer on the exact-fp32 MFMA kernels.
         self.conv_mode = "h3"
-        self.h3_min_batch = 4             # below this the launch-bound fp32 path (fewer launches, no pack passes) is faster
+        self.h3_min_batch = 2             # batch 1: the fp32 path is as fast (R=256) or faster (R=128), measured with tools/latency_b1.py
         self._h3_batch_ok = True
         self.h2_fused_epilogue = False    # (fp32 up=2 kernel writing H2: superseded by h2_handoff)
         self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
