@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -243,7 +243,6 @@ class SynthesisNetwork(torch.nn.Module):
         self.conv_mode = "h3"
         self.h3_min_batch = 2             # batch 1: the fp32 path is as fast (R=256) or faster (R=128), measured with tools/latency_b1.py
         self._h3_batch_ok = True
-        self.h2_fused_epilogue = False    # (fp32 up=2 kernel writing H2: superseded by h2_handoff)
         self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
         self.fuse_torgb = True            # last conv1 + ToRGB + compositing in one launch (split-f16 path)
         self.layer_kernels: Dict[str, str] = {}

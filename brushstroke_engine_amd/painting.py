@@ -22,7 +22,6 @@ tests inject an oracle-backed ``TileOps`` stand-in to check the host logic and t
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np

@@ -21,7 +21,7 @@ against outputs of the reference itself, generated in the build container by imp
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Sequence
 
 import numpy as np
 import torch

@@ -20,7 +20,7 @@ Reference:
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 import torch
