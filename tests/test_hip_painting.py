@@ -197,3 +197,48 @@ def test_paint_image_main_cli(eng, tmp_path):
     out2 = paint_image_main.main(["--gan_checkpoint", snap, "--geom_image", png, "--output_file_prefix", str(tmp_path / "o" / "w"),
                                   "--style_id", "594", "--library", "594,12", "--on_white", "--color_mode", "255,0,0;;", "--no_uvs_mapping"])
     assert np.array(Image.open(out2)).shape == (h0, w0, 3)
+
+
+def test_r256_batched_equals_sequential_and_full_mode():
+    """BASELINE resolution: a ragged 600x450 drawing at R=256 -- the batched three-phase schedule against one
+    render_stroke per tile on the same HIP kernels, and stitching_mode='full' (only tiles that contain strokes)."""
+    from brushstroke_engine_amd.networks import Generator
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_canvas import synthetic_drawing
+    cfg = cfgmod.style1_config(256)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0)).to("cuda")
+    ops = painting.TileOps(G, encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5)))
+    geom = synthetic_drawing(600, 450, seed=3, n_lines=6)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(np.random.RandomState(7).randn(1, cfg.z_dim)), 7)
+    m = 10
+    helper = painting.PaintingHelper(ops, batch=5)
+    helper.set_feature_blending(2)
+    out, full, crops, padded = helper.paint_image(geom, opts, crop_margin=m, return_full=True)
+    assert out.shape == (600, 450, 4) and len(crops) == (610 // 216 + 1) * (460 // 216 + 1)
+    seq = painting.PaintingHelper(ops)
+    seq.make_new_canvas(padded.shape[0], padded.shape[1], feature_blending=2)
+    result = np.zeros(padded.shape[:2] + (4,), np.uint8)
+    for (y, x, _, _) in crops:
+        opts.set_position(x, y)
+        res, _, meta = seq.render_stroke(255 - padded[y:y + 256, x:x + 256], None, opts, meta={"x": x, "y": y, "crop_margin": m})
+        result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+    _canvas_close(result, full, max_frac=2e-3)        # batch-1 calls take the fp32 kernels, the batched ones split-f16
+    assert torch.equal(seq.mask, helper.mask)
+    np.testing.assert_allclose(seq.features.cpu().numpy(), helper.features.cpu().numpy(), atol=2e-4)
+    # 'full': fewer tiles, untouched regions stay transparent black, painted regions equal the 'all' result where
+    # the same tiles (and the same blending history) are involved -- check the weaker, order-independent property
+    h2 = painting.PaintingHelper(ops, batch=5)
+    h2.set_feature_blending(0)
+    all0 = h2.paint_image(geom, opts, crop_margin=m)
+    full0 = h2.paint_image(geom, opts, crop_margin=m, stitching_mode="full")
+    kept, _ = painting.generate_stitching_crops(painting.pad_geo(geom, m), 256, "full", 2 * m)
+    assert 0 < len(kept) < len(crops)
+    covered = np.zeros(painting.pad_geo(geom, m).shape[:2], bool)
+    covered = np.pad(covered, ((0, 512), (0, 512)))
+    for (y, x, _, _) in kept:
+        covered[y + m:y + 256 - m, x + m:x + 256 - m] = True
+    covered = covered[m:m + 600, m:m + 450]
+    assert (full0[~covered] == 0).all() and (full0[covered][:, 3] > 0).any()
+    assert (full0 == all0).all(axis=-1).mean() > 0.3            # where no skipped tile would have painted later

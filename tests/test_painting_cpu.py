@@ -236,6 +236,43 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
+def _worker_one_tile(rank, world, port, tmp):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    torch.set_num_threads(4)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("engine_r128.npz")
+        cfg = cfgmod.style1_config(128)
+        ops = OracleTileOps(cfg, wmod.random_state_dict(cfg, seed=0), encmod.random_encoder_state_dict(5))
+        helper = painting.PaintingHelper(ops, batch=2)
+        helper.make_new_canvas(g["geom_padded"].shape[0], g["geom_padded"].shape[1], feature_blending=2)
+        opts = painting.GanBrushOptions()
+        opts.set_style(torch.from_numpy(np.random.RandomState(594).randn(1, cfg.z_dim)), 594)
+        out = helper.render_tiles(g["geom_padded"], g["crops"][:1], opts, crop_margin=10)      # 1 tile, 2 ranks
+        if rank == 0:
+            np.save(os.path.join(tmp, "one.npy"), out.numpy())
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fewer_tiles_than_ranks_gloo(eng, tmp_path):
+    """A rank without tiles still takes part in the all_gather / gather (padded, empty shard)."""
+    mp.spawn(_worker_one_tile, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ops = OracleTileOps(eng["cfg"], eng["sd"], eng["esd"])
+    helper = painting.PaintingHelper(ops)
+    helper.make_new_canvas(eng["g"]["geom_padded"].shape[0], eng["g"]["geom_padded"].shape[1], feature_blending=2)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    ref = helper.render_tiles(eng["g"]["geom_padded"], eng["g"]["crops"][:1], opts, crop_margin=10).numpy()
+    assert np.array_equal(np.load(tmp_path / "one.npy"), ref)
+
+
 def test_sharded_schedule_world2_gloo(eng, tmp_path):
     """9 tiles over 2 ranks (5 + 4, padded all_gather of phase-1 features, padded RGBA gather)."""
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
