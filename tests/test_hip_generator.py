@@ -196,3 +196,26 @@ def test_graphed_batch1_matches_eager(dev):
         e8, ef32, edbg = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
         torch.cuda.synchronize()
         assert torch.equal(u8, e8) and torch.equal(f32, ef32) and torch.equal(dbg["uvs"], edbg["uvs"])
+
+
+@pytest.mark.parametrize("res,cmax,cbase,geom", [(64, 96, 4096, (8, 24)), (128, 72, 8192, (16, 40)), (64, 160, 16384, (16, 256)),
+                                                 (64, 100, 6400, (5, 21))])
+def test_odd_channel_counts_vs_oracle(res, cmax, cbase, geom):
+    """Channel counts that are not powers of two (ragged c_out slices, partial 16-channel K chunks, geometry channel
+    counts that are not multiples of 16) through both conv modes, against the oracle."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    from oracle import neube_oracle as orc
+    cfg = cfgmod.GeneratorConfig(z_dim=64, w_dim=64, img_resolution=res, channel_base=cbase, channel_max=cmax,
+                                 geom_feature_channels=geom)
+    sd = wmod.random_state_dict(cfg, seed=2)
+    n = 3
+    z, gf, pos = synthetic.batch_z(cfg, n, 5), synthetic.geom_features(cfg, n, seed=4), synthetic.positions(cfg, n, seed=4)
+    _, want = orc.OracleGenerator(cfg, sd)(z, None, gf, positions=pos, return_debug_data=True, return_features=[res // 2])
+    G = Generator(cfg, sd).to("cuda")
+    for mode in ("h3", "f32"):
+        G.set_conv_mode(mode)
+        _, got = G(torch.from_numpy(z).cuda(), None, [torch.from_numpy(a).cuda() for a in gf], positions=torch.from_numpy(pos).cuda(),
+                   return_debug_data=True, return_features=[res // 2], noise_mode="const")
+        assert float((got["uvs"].cpu() - want["uvs"]).abs().max()) <= 1e-4, mode
+        assert float((got[f"features{res // 2}"].cpu() - want[f"features{res // 2}"]).abs().max()) <= 5e-4, mode
