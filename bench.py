@@ -182,11 +182,13 @@ def main():
             gatherer, gather_note = None, " (RCCL gather of RGBA tiles disabled: pre-flight failed)"
 
     def step():
-        u8, _, _ = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear")
+        # without a gather the step is enqueued without joining the generator's two sub-batch streams, so consecutive
+        # steps overlap across them (the timed region ends with a device-wide synchronize)
+        res = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=gatherer is not None)
         if gatherer is not None:
+            u8 = res[0]
             gatherer.finish()           # previous step's gather must be done before its buffer is reused
             gatherer.start(u8)
-        return u8
 
     # Burn-in (untimed, before the W warmup steps): a fresh process on a fresh box runs its first steps well below
     # steady state (host-side first-touch costs: lazily loaded code objects, allocator growth, cold Python paths, clock
@@ -278,13 +280,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # after the timed region: the dominant kernel once more with the whole batch on ONE stream (3 steps), so that its
+    # launch duration is also known without another stream's kernels sharing the chip
+    iso = {}
+    if G.sub_streams > 1:
+        keep = G.sub_streams
+        G.sub_streams = 1
+        G.synthesis.layer_events, G.synthesis.event_filter = [], dom_layers
+        for _ in range(3):
+            step()
+        if gatherer is not None:
+            gatherer.finish()
+        torch.cuda.synchronize()
+        for name, e0, e1 in G.synthesis.layer_events:
+            iso.setdefault(name, []).append(e0.elapsed_time(e1))
+        G.synthesis.layer_events, G.synthesis.event_filter = None, None
+        G.sub_streams = keep
+
     # dominant kernel: algorithmic FLOPs / HIP-event time of its launches inside the timed region (launch stream)
     specs = {sp.name: sp for sp in cfg.layers}
     timed = {}
     for name, e0, e1 in events:
         timed.setdefault(name, []).append(e0.elapsed_time(e1))
-    dom_ms = sum(float(np.mean(ts)) for ts in timed.values())            # per step, summed over the kernel's layers
-    dom_fl = sum(layer_flops(specs[name], B) for name in timed)
+    # a layer is launched once per sub-batch (the generator runs the batch as `sub` sub-batches on separate streams):
+    # every launch is bracketed on its own stream and carries batch/sub patches
+    sub = max(1, round(len(next(iter(timed.values()))) / args.steps))
+    dom_ms = sum(float(np.mean(ts)) for ts in timed.values())            # mean launch duration, summed over the kernel's layers
+    dom_fl = sum(layer_flops(specs[name], B / sub) for name in timed)
     dom_launches = len(timed)
     dom_peak = PEAK_F16_MATRIX_TFLOPS if "_h3_" in dom_name else PEAK_F32_MATRIX_TFLOPS
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12
@@ -294,7 +316,7 @@ def main():
         if name not in specs:
             continue
         ms = float(np.mean(ts))
-        fl = layer_flops(specs[name], B)
+        fl = layer_flops(specs[name], B / max(1, round(len(ts) / 3)))
         kname = layer_kernels[name]
         rows.append((ms, kernel_label(specs[name]), fl, kname))
         k = kernels.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0,
@@ -316,7 +338,17 @@ def main():
                                    "what": "f16 MFMA FLOPs actually executed for the algorithmic ones (3 products per fp32 "
                                            "product; halo / block-rounding overhead of the up=2 kernel not included)"}
                                   if "_h3_" in dom_name else None),
-                "launch_ms": round(dom_ms / dom_launches, 4), "launches_per_step": dom_launches,
+                "launch_ms": round(dom_ms / dom_launches, 4), "launches_per_step": dom_launches * sub,
+                "patches_per_launch": B // sub,
+                "concurrency": (f"{sub} sub-batches in flight on {sub} HIP streams: launch durations are measured while "
+                                f"the other stream's kernels share the chip") if sub > 1 else "single stream",
+                "isolated": ({"what": f"same kernel, whole batch of {B} on one stream (3 untimed steps after the timed region)",
+                              "launch_ms": round(sum(float(np.mean(t)) for t in iso.values()) / len(iso), 4),
+                              "achieved": round(sum(layer_flops(specs[nm], B) for nm in iso)
+                                                / (sum(float(np.mean(t)) for t in iso.values()) * 1e-3) / 1e12, 2),
+                              "frac": round(sum(layer_flops(specs[nm], B) for nm in iso)
+                                            / (sum(float(np.mean(t)) for t in iso.values()) * 1e-3) / 1e12 / dom_peak, 4)}
+                             if iso else None),
                 "flops_per_launch": dom_fl / dom_launches,
                 "note": "split-f16 (h3) kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
                         if "_h3_" in dom_name else "fp32 MFMA",

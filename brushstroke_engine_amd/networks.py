@@ -237,7 +237,7 @@ class SynthesisNetwork(torch.nn.Module):
         for res in self.block_resolutions:
             setattr(self, f"b{res}", SynthesisBlock(cfg, res, layers))
         self.packed: Dict[str, Dict[str, torch.Tensor]] = {}
-        self._plan: Optional[_Plan] = None
+        self._plans: Dict[int, _Plan] = {}      # per-batch workspaces, one per concurrent sub-batch (slot)
         # "h3": large conv1 layers on the f16 matrix cores as hi/lo split products (fp32-grade, ~5x the fp32 MFMA
         # rate); "f32": every layer on the exact-fp32 MFMA kernels.
         self.conv_mode = "h3"
@@ -258,7 +258,7 @@ class SynthesisNetwork(torch.nn.Module):
 
     def invalidate(self):
         self.packed = {}
-        self._plan = None
+        self._plans = {}
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -293,12 +293,13 @@ class SynthesisNetwork(torch.nn.Module):
         _lib.check(_lib.lib().nb_modconv3x3_variant(n, s.in_res, s.in_res, s.out_channels, s.up, buf, 128), "variant")
         return buf.value.decode()
 
-    def _get_plan(self, n: int, device) -> _Plan:
+    def _get_plan(self, n: int, device, slot: int = 0) -> _Plan:
         self._ensure_packed()
-        if self._plan is None or self._plan.n_max < n or self._plan.device != device:
-            n_max = max(n, 1 if self._plan is None else self._plan.n_max)
-            self._plan = _Plan(self, n_max, device)
-        return self._plan
+        plan = self._plans.get(slot)
+        if plan is None or plan.n_max < n or plan.device != device:
+            plan = _Plan(self, max(n, 1 if plan is None else plan.n_max), device)
+            self._plans[slot] = plan
+        return plan
 
     # -- optional per-launch HIP-event timing (bench.py): events are recorded on the launch stream --
     layer_events = None      # set to a list to collect (name, start_event, end_event)
@@ -337,6 +338,7 @@ class SynthesisNetwork(torch.nn.Module):
         # `res` before any blending; `_resume=(res, x)` continues after block `res` from (blended) features x
         stop_after = block_kwargs.pop("_stop_after", None)
         resume = block_kwargs.pop("_resume", None)
+        plan_slot = block_kwargs.pop("_plan_slot", 0)      # workspace to use (concurrent sub-batches on separate streams)
         if block_kwargs:
             raise TypeError(f"unexpected synthesis kwargs: {sorted(block_kwargs)}")
         if noise_mode not in ("random", "const", "none"):
@@ -350,7 +352,7 @@ class SynthesisNetwork(torch.nn.Module):
         ws = ws.to(torch.float32).contiguous()
         n = ws.shape[0]
         self._h3_batch_ok = n >= self.h3_min_batch
-        plan = self._get_plan(n, device)
+        plan = self._get_plan(n, device, plan_slot)
         lib = _lib.lib()
         geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
         keep_alive = []
@@ -583,6 +585,39 @@ class SynthesisNetwork(torch.nn.Module):
         return self._torgb_finish(o, extra)
 
 
+class _SplitForward:
+    """Results of a forward that runs as sub-batches on side streams (``Generator._forward_split``).  ``join()`` makes
+    the caller's stream wait for them and returns what the unsplit call returns; until then the parts are only valid
+    on their own streams (a throughput loop can keep enqueueing steps and synchronise the device once at the end)."""
+
+    def __init__(self, G, main, parts, extras, extra, ws):
+        self.G, self.main, self.parts, self.extras, self.extra, self.ws = G, main, parts, extras, extra, ws
+
+    def join(self):
+        main = self.main
+        for st in self.G._side_streams:
+            main.wait_stream(st)
+
+        def cat(ts):
+            if ts[0] is None:
+                return None
+            with torch.cuda.stream(main):
+                out = torch.cat(ts)
+            for t in ts:
+                t.record_stream(main)                 # produced on a side stream, read on the main one
+            return out
+        if self.extra is not None:
+            self.extra["out"] = {k: cat([e["out"][k] for e in self.extras]) for k in self.extras[0]["out"]}
+        parts = self.parts
+        if isinstance(parts[0], tuple):
+            img = cat([p[0] for p in parts])
+            dbg = {k: cat([p[1][k] for p in parts]) for k in parts[0][1]}
+            if self.ws is not None:
+                dbg["ws"] = self.ws
+            return img, dbg
+        return cat(list(parts))
+
+
 class Generator(torch.nn.Module):
     """``networks_modified.py:227-400``."""
 
@@ -602,6 +637,7 @@ class Generator(torch.nn.Module):
         self.num_ws = self.synthesis.num_ws
         self.mapping = MappingNetwork(cfg)
         self.geom_inject = True
+        self._side_streams = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
         if state_dict is not None:
             self.load_numpy_state_dict(state_dict)
@@ -637,6 +673,11 @@ class Generator(torch.nn.Module):
                            blended_features=None, noise_buffers=None, **synthesis_kwargs):
         # networks_modified.py:351-353 normalises positions here; this build hands the integer positions to
         # nb_noise_f32, which does the same (positions % R)/(R-1) in correctly rounded fp32 (see neube_hip.h)
+        n = ws.shape[0]
+        if (self.sub_streams > 1 and n >= self.sub_stream_min_batch and not blended_features and not noise_buffers
+                and "_plan_slot" not in synthesis_kwargs and ws.is_cuda and not torch.cuda.is_current_stream_capturing()):
+            return self._forward_split(ws, geom_feature, positions, return_debug_data, return_features, synthesis_kwargs)
+        synthesis_kwargs.pop("_join", None)
         syn_res = self.synthesis(ws, geom_feature, pos_encoding=None, return_debug_data=return_debug_data,
                                  return_features=return_features, blended_features=blended_features,
                                  **synthesis_kwargs, _positions=positions, noise_buffers=noise_buffers)
@@ -646,6 +687,50 @@ class Generator(torch.nn.Module):
                 debug_data["ws"] = ws
             return img, debug_data
         return syn_res
+
+    # Two sub-batches in flight on two HIP streams: every launch of a layer ends with a partially filled last round
+    # of workgroups and the next layer cannot start before it drains; with a second, independent chain of launches
+    # the CUs that fall idle at one chain's kernel boundary pick up the other chain's workgroups (+7.6 % at batch 32).
+    sub_streams = 2
+    sub_stream_min_batch = 16
+
+    def _forward_split(self, ws, geom_feature, positions, return_debug_data, return_features, kw):
+        n = ws.shape[0]
+        dev = ws.device
+        geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
+        kw = dict(kw)
+        extra = kw.pop("_extra_outputs", None)
+        resume = kw.pop("_resume", None)
+        npos = kw.pop("norm_noise_positions", None)
+        kw_join = kw.pop("_join", True)
+        if self._side_streams is None or self._side_streams[0].device != dev:
+            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(self.sub_streams)]
+        main = torch.cuda.current_stream(dev)
+        bounds = [(i * n // self.sub_streams, (i + 1) * n // self.sub_streams) for i in range(self.sub_streams)]
+        sl = lambda t, a, b: None if t is None else (t[a:b] if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == n) else t)
+        parts, extras = [], []
+        for i, (a, b) in enumerate(bounds):
+            st = self._side_streams[i]
+            st.wait_stream(main)
+            ex = None
+            if extra is not None:
+                ex = {k: (sl(torch.as_tensor(v), a, b) if k in ("user_colors", "sfactor") and v is not None else v)
+                      for k, v in extra.items() if k != "out"}
+            for t in [ws, positions, npos, None if resume is None else resume[1]] + geom_feature:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(st)               # allocated on the caller's stream, read on this one
+            with torch.cuda.stream(st):
+                res = self.synthesis(ws[a:b], [g[a:b] for g in geom_feature], pos_encoding=None,
+                                     return_debug_data=return_debug_data, return_features=return_features, **kw,
+                                     _positions=sl(positions, a, b), norm_noise_positions=sl(npos, a, b),
+                                     _resume=None if resume is None else (resume[0], resume[1][a:b]),
+                                     _extra_outputs=ex, _plan_slot=i + 1)
+            parts.append(res)
+            extras.append(ex)
+        pending = _SplitForward(self, main, parts, extras, extra, ws if return_debug_data else None)
+        if kw_join is False:
+            return pending                            # caller joins (or synchronises the device) before using the outputs
+        return pending.join()
 
     def forward(self, z, c, geom_feature, positions=None, noise_buffers=None, truncation_psi=1, truncation_cutoff=None,
                 return_debug_data=False, return_features=None, blended_features=None, style_mixing_prob=0,
@@ -658,16 +743,24 @@ class Generator(torch.nn.Module):
                                        noise_buffers=noise_buffers, **synthesis_kwargs)
 
     def render_triad(self, z=None, ws=None, geom_feature=None, positions=None, render_mode="clear", user_colors=None,
-                     want_u8=True, want_f32=False, sfactor=None, **kw):
+                     want_u8=True, want_f32=False, sfactor=None, join=True, **kw):
         """Generator + the paint engine's compositing (brush.py:763-792) fused into the ToRGB launch.
-        Returns (rgba_u8 [N,R,R,4] | None, rgba_f32 [N,4,R,R] | None, debug dict with uvs/colors)."""
+        Returns (rgba_u8 [N,R,R,4] | None, rgba_f32 [N,4,R,R] | None, debug dict with uvs/colors).
+        ``join=False`` (throughput loops): when the batch runs as sub-batches on side streams, returns a callable that
+        joins and yields that tuple; steps enqueued without joining overlap across the streams."""
         extra = {"rgba_u8": want_u8, "rgba": want_f32, "render_mode": render_mode, "user_colors": user_colors,
                  "sfactor": sfactor}
         kw.setdefault("noise_mode", "const")
         if ws is None:
-            img, dbg = self.forward(z, None, geom_feature, positions=positions, return_debug_data=True,
-                                    _extra_outputs=extra, **kw)
+            res = self.forward(z, None, geom_feature, positions=positions, return_debug_data=True,
+                               _extra_outputs=extra, _join=join, **kw)
         else:
-            img, dbg = self.forward_pre_mapped(ws, geom_feature, positions=positions, return_debug_data=True,
-                                               _extra_outputs=extra, **kw)
+            res = self.forward_pre_mapped(ws, geom_feature, positions=positions, return_debug_data=True,
+                                          _extra_outputs=extra, _join=join, **kw)
+        if isinstance(res, _SplitForward):
+            def finish():
+                _, dbg = res.join()
+                return extra["out"]["rgba_u8"], extra["out"]["rgba"], dbg
+            return finish
+        img, dbg = res
         return extra["out"]["rgba_u8"], extra["out"]["rgba"], dbg

@@ -226,6 +226,8 @@ class TileOps:
             raise _lib.NeubeHipError("the painting engine needs the generator on a GPU (no CPU path in this build)")
         self.patch_width = G.img_resolution
         self.cfg = G.cfg
+        self._streams = None
+        self._forked = set()
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -259,18 +261,47 @@ class TileOps:
         return self.G.mapping(z.to(self.device), None)
 
     # -- generator halves --
-    def head(self, ws, geom_feats, positions, stop_res: int) -> torch.Tensor:
-        return self.G.forward_pre_mapped(ws, geom_feats, positions=positions, noise_mode="const", _stop_after=stop_res)
+    # ``slot``: which of the generator's per-batch workspaces to use -- consecutive batches alternate between two HIP
+    # streams (``stream``/``join_streams``), each with its own workspace, so that one batch's kernel tails and small
+    # launches are covered by the other batch's work
+    def head(self, ws, geom_feats, positions, stop_res: int, slot: int = 0) -> torch.Tensor:
+        return self.G.forward_pre_mapped(ws, geom_feats, positions=positions, noise_mode="const", _stop_after=stop_res,
+                                         _plan_slot=slot)
 
-    def tail(self, ws, feats, geom_feats, positions, resume_res: int, render_mode, user_colors, sfactor=None) -> torch.Tensor:
+    def tail(self, ws, feats, geom_feats, positions, resume_res: int, render_mode, user_colors, sfactor=None,
+             slot: int = 0) -> torch.Tensor:
         u8, _, _ = self.G.render_triad(ws=ws, geom_feature=geom_feats, positions=positions, render_mode=render_mode,
-                                       user_colors=user_colors, sfactor=sfactor, _resume=(resume_res, feats))
+                                       user_colors=user_colors, sfactor=sfactor, _resume=(resume_res, feats), _plan_slot=slot)
         return u8
 
-    def full(self, ws, geom_feats, positions, render_mode, user_colors, sfactor=None) -> torch.Tensor:
+    def full(self, ws, geom_feats, positions, render_mode, user_colors, sfactor=None, slot: int = 0) -> torch.Tensor:
         u8, _, _ = self.G.render_triad(ws=ws, geom_feature=geom_feats, positions=positions, render_mode=render_mode,
-                                       user_colors=user_colors, sfactor=sfactor)
+                                       user_colors=user_colors, sfactor=sfactor, _plan_slot=slot)
         return u8
+
+    n_streams = 2
+
+    def stream(self, k: int):
+        """Context manager: work of batch k goes to side stream k % n_streams (which first waits for the caller's)."""
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)]
+            self._forked = set()
+        st = self._streams[k % self.n_streams]
+        if k % self.n_streams not in self._forked:
+            st.wait_stream(torch.cuda.current_stream(self.device))
+            self._forked.add(k % self.n_streams)
+        return torch.cuda.stream(st)
+
+    def join_streams(self, tensors=()):
+        """The caller's stream waits for the side streams; ``tensors`` produced there are about to be read here."""
+        main = torch.cuda.current_stream(self.device)
+        if self._streams is not None:
+            for st in self._streams:
+                main.wait_stream(st)
+            self._forked = set()
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
 
     def background_weight(self, ws, geom_feats) -> torch.Tensor:
         """S = uvs[:, 2:3] of an un-positioned render (what StyleUVSMapper calibrates on, mapper.py:74-87)."""
@@ -424,17 +455,25 @@ class PaintingHelper:
         def style(n):
             return ws1.expand(n, -1, -1).contiguous()
 
-        def colors(n):
-            return None if user is None else user.expand(n, -1, -1).contiguous().to(ops.device)
-
         def pos(b0, b1):
             return None if own_pos is None else own_pos[b0:b1]
 
+        import contextlib
+        on_stream = getattr(ops, "stream", lambda k: contextlib.nullcontext())      # (CPU stand-ins have no streams)
+        join = getattr(ops, "join_streams", lambda tensors=(): None)
+        plan_slot = lambda k: 1 + k % getattr(ops, "n_streams", 1)
+        if n_own <= self.batch:                      # a single batch (interactive strokes): nothing to overlap with
+            on_stream, join, plan_slot = (lambda k: contextlib.nullcontext()), (lambda tensors=(): None), (lambda k: 0)
+        user_dev = None if user is None else user.to(ops.device)
+        colors = lambda n_: None if user_dev is None else user_dev.expand(n_, -1, -1).contiguous()
         outs = []
         if level == 0:
-            for b0, b1 in batches():
-                g = ops.geom_tiles(geom_dev, own_yx[b0:b1])
-                outs.append(ops.full(style(b1 - b0), ops.encode(g), pos(b0, b1), self.render_mode, colors(b1 - b0), sfac))
+            for k, (b0, b1) in enumerate(batches()):
+                with on_stream(k):
+                    g = ops.geom_tiles(geom_dev, own_yx[b0:b1])
+                    outs.append(ops.full(style(b1 - b0), ops.encode(g), pos(b0, b1), self.render_mode, colors(b1 - b0), sfac,
+                                         slot=plan_slot(k)))
+            join(outs)
         else:
             bres = R // df
             C = ops.cfg.channels(bres)
@@ -443,10 +482,12 @@ class PaintingHelper:
             feats_all = torch.empty([world * n_pad, C, bres, bres], dtype=torch.float32, device=ops.device)
             mine = feats_all[rank * n_pad: rank * n_pad + n_own]
             geom_feats_own = []
-            for b0, b1 in batches():
-                gf = ops.encode(ops.geom_tiles(geom_dev, own_yx[b0:b1]))
-                geom_feats_own.append(gf)
-                mine[b0:b1] = ops.head(style(b1 - b0), gf, pos(b0, b1), bres)
+            for k, (b0, b1) in enumerate(batches()):
+                with on_stream(k):
+                    gf = ops.encode(ops.geom_tiles(geom_dev, own_yx[b0:b1]))
+                    geom_feats_own.append(gf)
+                    mine[b0:b1] = ops.head(style(b1 - b0), gf, pos(b0, b1), bres, slot=plan_slot(k))
+            join()
             if world > 1:
                 if n_own < n_pad:
                     feats_all[rank * n_pad + n_own: (rank + 1) * n_pad].zero_()
@@ -468,8 +509,10 @@ class PaintingHelper:
                                    self.features, self.mask, ops.to_device(off), ops.to_device(lst))
             # phase 3: last block(s) + ToRGB + compositing on the blended features, own tiles
             for i, (b0, b1) in enumerate(batches()):
-                outs.append(ops.tail(style(b1 - b0), mine[b0:b1], geom_feats_own[i], pos(b0, b1), bres,
-                                     self.render_mode, colors(b1 - b0), sfac))
+                with on_stream(i):
+                    outs.append(ops.tail(style(b1 - b0), mine[b0:b1], geom_feats_own[i], pos(b0, b1), bres,
+                                         self.render_mode, colors(b1 - b0), sfac, slot=plan_slot(i)))
+            join(outs)
         rgba_own = torch.cat(outs) if outs else None
         if world == 1:
             return rgba_own

@@ -32,18 +32,18 @@ class OracleTileOps:
     def map_style(self, z=None, ws=None):
         return ws.to(torch.float32) if ws is not None else self.G.mapping(z, None)
 
-    def head(self, ws, geom_feats, positions, stop_res):
+    def head(self, ws, geom_feats, positions, stop_res, slot=0):
         _, dbg = self.G.forward_pre_mapped(ws, geom_feats, positions=positions, return_features=[stop_res])
         return dbg[f"features{stop_res}_preblend"]
 
-    def tail(self, ws, feats, geom_feats, positions, resume_res, render_mode, user_colors, sfactor=None):
+    def tail(self, ws, feats, geom_feats, positions, resume_res, render_mode, user_colors, sfactor=None, slot=0):
         one = torch.ones([1, 1, resume_res, resume_res])
         _, dbg = self.G.forward_pre_mapped(ws, geom_feats, positions=positions, return_debug_data=True,
                                            blended_features={resume_res: {"features": feats, "alpha": one}})
         rgba = no.triad_composite(dbg["uvs"], dbg["colors"], render_mode, user_colors, sfactor)
         return no.rgba_to_uint8(rgba).permute(0, 2, 3, 1).contiguous()
 
-    def full(self, ws, geom_feats, positions, render_mode, user_colors, sfactor=None):
+    def full(self, ws, geom_feats, positions, render_mode, user_colors, sfactor=None, slot=0):
         _, dbg = self.G.forward_pre_mapped(ws, geom_feats, positions=positions, return_debug_data=True)
         rgba = no.triad_composite(dbg["uvs"], dbg["colors"], render_mode, user_colors, sfactor)
         return no.rgba_to_uint8(rgba).permute(0, 2, 3, 1).contiguous()

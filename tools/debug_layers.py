@@ -28,7 +28,7 @@ syn = G.synthesis
 feats = [r for r in cfg.block_resolutions]
 img, dbg = G.forward_pre_mapped(ws, [D(g) for g in geom], positions=D(pos), return_debug_data=True,
                                 return_features=feats, noise_mode="const", _extra_outputs=(ex := {"logits": True}))
-plan = syn._plan
+plan = syn._plans[0]
 for i, s in enumerate(cfg.layers):
     st = plan.styles[i][:n].cpu()
     npos = (torch.from_numpy(pos) % cfg.img_resolution) / (cfg.img_resolution - 1)
