@@ -164,6 +164,9 @@ def main():
     z = torch.from_numpy(synthetic.batch_z(cfg, B, first_seed=rank * B)).to(dev)
     geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, seed=rank)]
     pos = torch.from_numpy(synthetic.positions(cfg, B, seed=rank)).to(dev)
+    # the generator runs a batch as `sub` sub-batches on separate HIP streams; with N>1 each part's RGBA tiles are
+    # gathered from the part's own stream, so steps keep overlapping across the streams at any N
+    sub = G.sub_streams if B >= G.sub_stream_min_batch else 1
     gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if (world > 1 and not args.no_gather) else None
     gather_note = ""
     if gatherer is not None:
@@ -180,15 +183,30 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() < 1:
             gatherer, gather_note = None, " (RCCL gather of RGBA tiles disabled: pre-flight failed)"
+    part_gatherers = []
+    if gatherer is not None and sub > 1:
+        bounds = [(i * B // sub, (i + 1) * B // sub) for i in range(sub)]
+        part_gatherers = [TileGatherer([b - a, args.res, args.res, 4], torch.uint8, dev) for a, b in bounds]
+
+    def finish_gathers():
+        if gatherer is not None:
+            gatherer.finish()
+            for g_ in part_gatherers:
+                g_.finish()
 
     def step():
         # without a gather the step is enqueued without joining the generator's two sub-batch streams, so consecutive
         # steps overlap across them (the timed region ends with a device-wide synchronize)
-        res = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=gatherer is not None)
+        res = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False)
         if gatherer is not None:
-            u8 = res[0]
-            gatherer.finish()           # previous step's gather must be done before its buffer is reused
-            gatherer.start(u8)
+            if callable(res):           # sub-batches: one gather per part, enqueued from the part's stream
+                for g_, st_, u8_ in zip(part_gatherers, res.streams, res.parts_u8):
+                    with torch.cuda.stream(st_):
+                        g_.finish()     # previous step's gather must be done before its buffer is reused
+                        g_.start(u8_)
+            else:
+                gatherer.finish()
+                gatherer.start(res[0])
 
     # Burn-in (untimed, before the W warmup steps): a fresh process on a fresh box runs its first steps well below
     # steady state (host-side first-touch costs: lazily loaded code objects, allocator growth, cold Python paths, clock
@@ -200,8 +218,7 @@ def main():
         tb = time.perf_counter()
         for _ in range(5):
             step()
-        if gatherer is not None:
-            gatherer.finish()
+        finish_gathers()
         torch.cuda.synchronize()
         burn_in.append((time.perf_counter() - tb) / 5 * 1e3)
         spent = time.perf_counter() - t_burn
@@ -215,8 +232,7 @@ def main():
             break
     for _ in range(args.warmup):
         step()
-    if gatherer is not None:
-        gatherer.finish()
+    finish_gathers()
     torch.cuda.synchronize()
 
     # Calibration (untimed): 3 steps with a HIP-event pair around EVERY launch give the per-layer table and name the
@@ -225,8 +241,7 @@ def main():
     G.synthesis.layer_events, G.synthesis.event_filter = [], None
     for _ in range(3):
         step()
-    if gatherer is not None:
-        gatherer.finish()
+    finish_gathers()
     torch.cuda.synchronize()
     cal_events = G.synthesis.layer_events
     layer_kernels = dict(G.synthesis.layer_kernels)
@@ -254,8 +269,7 @@ def main():
     t_reh = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if gatherer is not None:
-        gatherer.finish()
+    finish_gathers()
     torch.cuda.synchronize()
     rehearsal_ms = (time.perf_counter() - t_reh) / args.steps * 1e3
     G.synthesis.event_pool = make_pool()
@@ -266,8 +280,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if gatherer is not None:
-        gatherer.finish()
+    finish_gathers()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -289,8 +302,7 @@ def main():
         G.synthesis.layer_events, G.synthesis.event_filter = [], dom_layers
         for _ in range(3):
             step()
-        if gatherer is not None:
-            gatherer.finish()
+        finish_gathers()
         torch.cuda.synchronize()
         for name, e0, e1 in G.synthesis.layer_events:
             iso.setdefault(name, []).append(e0.elapsed_time(e1))

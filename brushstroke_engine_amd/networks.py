@@ -761,6 +761,9 @@ class Generator(torch.nn.Module):
             def finish():
                 _, dbg = res.join()
                 return extra["out"]["rgba_u8"], extra["out"]["rgba"], dbg
+            # per sub-batch results, each valid on its own stream (e.g. to start a gather of a part from that stream)
+            finish.streams = list(self._side_streams)
+            finish.parts_u8 = [e["out"]["rgba_u8"] for e in res.extras]
             return finish
         img, dbg = res
         return extra["out"]["rgba_u8"], extra["out"]["rgba"], dbg
