@@ -299,6 +299,10 @@ def main():
     if G.sub_streams > 1:
         keep = G.sub_streams
         G.sub_streams = 1
+        for _ in range(2):                           # (first single-stream steps build that workspace: not measured)
+            step()
+        finish_gathers()
+        torch.cuda.synchronize()
         G.synthesis.layer_events, G.synthesis.event_filter = [], dom_layers
         for _ in range(3):
             step()
