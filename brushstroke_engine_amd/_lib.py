@@ -62,6 +62,9 @@ PROTOTYPES = {
     "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp,
                                      C.c_int, C.c_int, C.c_int, vp]),
     "nb_blend_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_modconv3x3_up1_h3f8": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, vp]),
+    "nb_pack_h2f8_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_modconv3x3_up1_h3_torgb": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_float, C.c_float, C.c_float, vp, vp]),
     "nb_modconv3x3_up1_h3_h2": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,

@@ -88,7 +88,23 @@ __device__ __forceinline__ void nb_stagger(int stagger_ticks, int first_round) {
     }
 }
 
-template <int MW>
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// "f8" operand format (F8 = true): the two correction products run on ONE block-scaled fp8 MFMA per tap pair.
+//   activations: the (cg, lo) slots of a 16-channel chunk hold, instead of the f16 low halves,
+//       (cg 2k,   lo) = fp8 e4m3( xl * 2^9 ) of the chunk's 16 channels     (xl = x - f16(x))
+//       (cg 2k+1, lo) = fp8 e4m3( x / 4 )    of the chunk's 16 channels
+//   weights likewise: (cg 0, lo) = fp8(w), (cg 1, lo) = fp8((w - f16(w)) * 2^11)
+//   v_mfma_scale_f32_32x32x64_f8f6f4: lane half lh = 0 contracts  fp8(w) . fp8(xl 2^9) * 2^-9,  lh = 1 contracts
+//   fp8(wl 2^11) 2^-11 . fp8(x/4) 2^2; its K = 64 = 2 taps x 16 channels x 2 terms (the third tap of a row rides alone).
+// Same containers, same staging, same fragment reads as the f16 lo halves; 5 instead of 9 matrix instructions per tap row.
+__device__ __forceinline__ i32x8 nb_cat8(h8 a, h8 b) {
+    const i32x4 x = __builtin_bit_cast(i32x4, a), y = __builtin_bit_cast(i32x4, b);
+    return i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+}
+
+template <int MW, bool F8 = false>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
     NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
@@ -224,6 +240,47 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 }
             };
             fetch(0, ah[0], al[0], bh[0], bl[0]);
+            if (F8) {
+                // block scales (E8M0) of this lane's 32-element K block: lh = 0 -> fp8(w) * fp8(xl 2^9), lh = 1 -> fp8(wl 2^11) * fp8(x/4)
+                const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
+                const h8 z8 = {};
+                // tap 0: main products; tap 1's fragments arrive meanwhile
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][mb], bh[0][nb], acc[mb][nb], 0, 0, 0);
+                        if (mb + nb == 0) fetch(1, ah[1], al[1], bh[1], bl[1]);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB + 2 * NBW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW - 1, 0);
+                // taps 0+1: corrections (one fp8 MFMA per tile), then tap 1's main products; tap 2's fragments replace tap 0's
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(al[0][mb], al[1][mb]), nb_cat8(bl[0][nb], bl[1][nb]),
+                                                                                      acc[mb][nb], 0, 0, 0, sa, 0, sb);
+                fetch(2, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][mb], bh[1][nb], acc[mb][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB + 2 * NBW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW, 0);
+                // tap 2: main products and its corrections (second half of the fp8 K block empty)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][mb], bh[0][nb], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(al[0][mb], z8), nb_cat8(bl[0][nb], z8),
+                                                                                      acc[mb][nb], 0, 0, 0, sa, 0, sb);
+                    }
+            } else {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int cu = kx & 1;
@@ -241,6 +298,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (kx + 1 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB + 2 * NBW, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * MB * NBW - 1, 0);
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
             unsigned long long tw0 = 0;
@@ -573,7 +631,7 @@ static int launch_h3s(H3Params p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int MW>
+template <int MW, bool F8 = false>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * 2, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
@@ -582,11 +640,11 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
 }
@@ -596,8 +654,9 @@ extern "C" const float* nb_zero_page_ptr(void);
 static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
-                          void* stream, const TorgbParams* tg = nullptr) {
+                          void* stream, const TorgbParams* tg = nullptr, bool f8 = false) {
     NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && (tg ? !y_h2 : ((y != nullptr) != (y_h2 != nullptr))), "modconv3x3_up1_h3: null pointer");
+    NB_REQUIRE(!f8 || c_in % 16 == 0, "modconv3x3_up1_h3: the f8 operand format needs c_in %% 16 == 0 (got %d)", c_in);
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
                "modconv3x3_up1_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up1_h3: bad sizes");
@@ -624,9 +683,17 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     // large layers both forms run at the same rate -- the chip is power-limited in these loops, not latency-limited
     { const char* e = getenv("NB_UP1_SMALL");
       const bool small = e ? atoi(e) != 0 : (h * w <= 32 * 32);
-      if (small && (!tg || c_out <= 64)) return launch_h3s(p, n, (hipStream_t)stream); }
+      if (small && !f8 && (!tg || c_out <= 64)) return launch_h3s(p, n, (hipStream_t)stream); }
+    if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, (hipStream_t)stream) : launch_h3<1, true>(p, n, (hipStream_t)stream);
     if (c_out > 64) return launch_h3<2>(p, n, (hipStream_t)stream);
     return launch_h3<1>(p, n, (hipStream_t)stream);
+}
+
+extern "C" int nb_modconv3x3_up1_h3f8(const void* x_f8, int c_in, const void* w_f8, const float* dcoefs, const float* noise,
+                                      int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                                      float alpha, float gain, float clamp, void* stream) {
+    return nb_up1_h3_impl(x_f8, c_in, w_f8, dcoefs, noise, noise_stride_n, bias, y, nullptr, nullptr, 0, 0, n, h, w, c_out,
+                          alpha, gain, clamp, stream, nullptr, true);
 }
 
 extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
@@ -1073,6 +1140,65 @@ extern "C" int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, 
     dim3 grid((hw + 255) / 256, c8, n);
     hipLaunchKernelGGL(pack_h2_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, c1, x2, c2, scale, (_Float16*)out_h2, c8, hw);
     NB_CHECK_LAUNCH("pack_h2");
+    return NB_OK;
+}
+
+// fp32 NCHW (x1 ++ x2) * scale -> the "f8" activation format (see modconv3x3_up1_h3_kernel): per 16-channel chunk the
+// f16 high halves of both channel groups, fp8(xl * 2^9) and fp8(x / 4)
+__device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float d) {
+    auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+    return (unsigned)w;
+}
+
+__global__ __launch_bounds__(256) void pack_h2f8_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,
+                                                        const float* __restrict__ scale, _Float16* __restrict__ out, int c8, int hw) {
+    const int n = blockIdx.z, chunk = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const int c_in = c1 + c2;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ch = chunk * 16 + j;
+        float t = 0.f;
+        if (ch < c_in) {
+            t = ch < c1 ? x1[((size_t)n * c1 + ch) * hw + pix] : x2[((size_t)n * c2 + (ch - c1)) * hw + pix];
+            if (scale) t *= scale[(size_t)n * c_in + ch];
+        }
+        v[j] = t;
+    }
+    h8 hi0, hi1;
+    float xl[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const _Float16 hh = (_Float16)v[j];
+        if (j < 8) hi0[j & 7] = hh; else hi1[j & 7] = hh;
+        xl[j] = (v[j] - (float)hh) * 512.f;
+    }
+    i32x4 l8, h8v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        l8[q] = (int)nb_pk4_fp8(xl[4 * q], xl[4 * q + 1], xl[4 * q + 2], xl[4 * q + 3]);
+        h8v[q] = (int)nb_pk4_fp8(v[4 * q] * 0.25f, v[4 * q + 1] * 0.25f, v[4 * q + 2] * 0.25f, v[4 * q + 3] * 0.25f);
+    }
+    h8* o = reinterpret_cast<h8*>(out) + ((size_t)(n * c8 + 2 * chunk) * 2) * hw + pix;
+    o[0] = hi0;
+    o[hw] = __builtin_bit_cast(h8, l8);
+    o[2 * (size_t)hw] = hi1;
+    o[3 * (size_t)hw] = __builtin_bit_cast(h8, h8v);
+}
+
+extern "C" int nb_pack_h2f8_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out, int n, int hw,
+                                void* stream) {
+    NB_REQUIRE(x1 && out && c1 > 0 && c2 >= 0 && (c2 == 0 || x2) && n > 0 && n <= 65535 && hw > 0, "pack_h2f8: bad arguments");
+    NB_REQUIRE((c1 + c2) % 16 == 0, "pack_h2f8: the f8 operand format needs a multiple of 16 channels (got %d)", c1 + c2);
+    const int c8 = (c1 + c2) / 8;
+    dim3 grid((hw + 255) / 256, c8 / 2, n);
+    hipLaunchKernelGGL(pack_h2f8_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, c1, x2, c2, scale, (_Float16*)out, c8, hw);
+    NB_CHECK_LAUNCH("pack_h2f8");
     return NB_OK;
 }
 

@@ -218,6 +218,39 @@ def pack_conv_weight_h3(weight: torch.Tensor) -> torch.Tensor:
     return both.permute(1, 4, 5, 2, 0, 6, 3).contiguous()                 # [chunk, ky, kx, cg, hl, o, j]
 
 
+def pack_conv_weight_h3f8(weight: torch.Tensor) -> torch.Tensor:
+    """[O,I,3,3] fp32 -> the "f8" weight format: container of pack_conv_weight_h3 with the lo slots holding
+    fp8 e4m3 (w) [cg 0] and fp8((w - f16(w)) * 2^11) [cg 1] of the chunk's 16 channels (include/neube_hip.h)."""
+    o, i, kh, kw = weight.shape
+    assert kh == 3 and kw == 3
+    w = weight.detach().to(torch.float32)
+    nch, op = (i + 15) // 16, (o + 63) // 64 * 64
+    wp = torch.zeros([nch * 16, 3, 3, op], dtype=torch.float32, device=w.device)
+    wp[:i, :, :, :o] = w.permute(1, 2, 3, 0)
+    hi = wp.to(torch.float16)
+    lo = wp - hi.to(torch.float32)
+    f8 = lambda t: t.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    out = torch.empty([nch, 3, 3, 2, 2, op, 16], dtype=torch.uint8, device=w.device)
+    hi_b = hi.reshape(nch, 2, 8, 3, 3, op).permute(0, 3, 4, 1, 5, 2).contiguous().view(torch.uint8)      # [chunk,ky,kx,cg,o,16]
+    out[:, :, :, :, 0] = hi_b.reshape(nch, 3, 3, 2, op, 16)
+    out[:, :, :, 0, 1] = f8(wp).reshape(nch, 16, 3, 3, op).permute(0, 2, 3, 4, 1)
+    out[:, :, :, 1, 1] = f8(lo * 2048.0).reshape(nch, 16, 3, 3, op).permute(0, 2, 3, 4, 1)
+    return out.view(torch.float16).reshape(nch, 3, 3, 2, 2, op, 8)
+
+
+def pack_h2f8(x, scale=None, x2=None):
+    """fp32 NCHW (x ++ x2) * scale[n,c] -> the "f8" activation format (same container as H2)."""
+    _dev(x, "x")
+    n, c1, h, w = x.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    out = torch.empty(h2_shape(n, c1 + c2, h, w), dtype=torch.float16, device=x.device)
+    sc = None if scale is None else scale.contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nb_pack_h2f8_f32(_p(x.contiguous()), c1, _p(None if x2 is None else x2.contiguous()), c2,
+                                               _p(sc), _p(out), n, h * w, _stream(x)), "pack_h2f8")
+    return out
+
+
 def h2_shape(n, c, h, w):
     return [n, (c + 7) // 8, 2, h, w, 8]
 

@@ -190,6 +190,16 @@ int nb_torgb_triad_f32(const float* x, const float* styles, int styles_stride_n,
 int nb_blend_f32(const float* features, int nf, const float* alpha, int na, const float* x, float* y, int n, int c,
                  int hw, void* stream);
 
+/* ---- "f8" operand format of the split-f16 convolutions: the two correction products on one block-scaled fp8 MFMA per
+ * tap pair (csrc/nb_modconv_h3.hip).  Same containers as H2 / nb_pack_conv_weight_h3, but the (cg, lo) slots of a
+ * 16-channel chunk hold fp8 e4m3 values: activations (cg 2k, lo) = fp8(xl*2^9), (cg 2k+1, lo) = fp8(x/4); weights
+ * (cg 0, lo) = fp8(w), (cg 1, lo) = fp8((w - f16(w))*2^11).  c_in % 16 == 0.  End-to-end pixel error ~1e-4 (H2: 5e-6). */
+int nb_pack_h2f8_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out, int n, int hw,
+                     void* stream);
+int nb_modconv3x3_up1_h3f8(const void* x_f8, int c_in, const void* w_f8, const float* dcoefs, const float* noise,
+                           int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
+                           float alpha, float gain, float clamp, void* stream);
+
 /* Arguments of the triad ToRGB epilogue when it is fused into the last conv (same meaning as the parameters of
  * nb_torgb_triad_f32; any output pointer may be NULL). */
 struct NbTorgbArgs {
