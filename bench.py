@@ -124,8 +124,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 hipGraph latency leg")
-    ap.add_argument("--conv-mode", default="h3", choices=["h3", "f32"],
-                    help="h3: large conv1 layers as 3-pass split-f16 MFMA (fp32-grade results); f32: all layers fp32 MFMA")
+    ap.add_argument("--conv-mode", default="f8", choices=["h3", "f8", "f32"],
+                    help="f8 (default): split-f16 MFMA with the two correction products on block-scaled fp8 MFMAs (pixels within "
+                         "1e-4 of fp32; budget 1e-3); h3: all three products in f16 (5e-6); f32: all layers on the fp32 MFMA kernels")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
     args = ap.parse_args()
 
@@ -384,7 +385,10 @@ def main():
                       else f"stylized {args.res}x{args.res} stroke patches/sec at batch={B}",
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_mode == "f32" else "f32 (conv1 layers: 3-pass split-f16 MFMA, fp32-equivalent)",
+            "dtype": {"f32": "f32",
+                      "h3": "f32 (layers >= 32x32: 3-pass split-f16 MFMA, within 5e-6 of fp32 on pixels)",
+                      "f8": "f32 (layers >= 32x32: split-f16 MFMA, correction products on block-scaled fp8 MFMA; within 1e-4 of "
+                            "fp32 on pixels, north_star budget 1e-3)"}[args.conv_mode],
             "data": "synthetic",
             "config": {"workload": f"batch={B} random-z {args.res}x{args.res} patches through the HIP SynthesisNetwork, "
                                    f"style1 checkpoint shapes (BASELINE.json configs[1]); generator + triad compositing "

@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lock = threading.Lock()
 _lib = None
@@ -62,8 +62,11 @@ PROTOTYPES = {
     "nb_torgb_triad_f32": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp,
                                      C.c_int, C.c_int, C.c_int, vp]),
     "nb_blend_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-    "nb_modconv3x3_up1_h3f8": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                         C.c_float, C.c_float, C.c_float, vp]),
+    "nb_modconv3x3_up1_h3_ex": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
+    "nb_modconv3x3_up2_h3_ex": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
+    "nb_pack_h2f8_part_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "nb_pack_h2f8_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_modconv3x3_up1_h3_torgb": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_float, C.c_float, C.c_float, vp, vp]),

@@ -52,6 +52,7 @@ struct H3Params {
     _Float16* yh2;
     const float* next_styles;      // [n][next_stride]
     int next_stride, c8_next;
+    int out_f8;                    // H2 output in the "f8" operand format (the consumer's corrections run on fp8 MFMAs)
     // fused triad ToRGB (last layer; the workgroup holds all c_out channels of its pixels): tg.c != 0 enables it,
     // y may then be null (the fp32 activations are only needed when somebody taps them)
     TorgbParams tg;
@@ -102,6 +103,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x8 nb_cat8(h8 a, h8 b) {
     const i32x4 x = __builtin_bit_cast(i32x4, a), y = __builtin_bit_cast(i32x4, b);
     return i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+}
+
+__device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float d) {
+    auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+    return (unsigned)w;
 }
 
 template <int MW, bool F8 = false>
@@ -339,14 +348,23 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 for (int g = 0; g < 4; ++g) {
                     const int col = wm * 64 + mb * 32 + 8 * g + 4 * lh;
                     h4 vh, vl;
+                    float vv[4], xl[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = nb_h3_epilogue(acc[mb][nb][4 * g + j] * s_dco[col + j] + nz, s_bias[col + j], p.alpha, p.gain, p.clamp) * s_nst[col + j];
                         const _Float16 hi = (_Float16)v;
-                        vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                        vv[j] = v; xl[j] = v - (float)hi;
+                        vh[j] = hi; vl[j] = (_Float16)xl[j];
                     }
                     *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
-                    *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                    if (p.out_f8) {
+                        // lo image as bytes: per 16-channel chunk 16 x fp8(xl 2^9) then 16 x fp8(v/4) (= the chunk's two lo slots)
+                        unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)pix * (CP * 2) + (col >> 4) * 32 + (col & 15);
+                        *reinterpret_cast<unsigned*>(sb) = nb_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
+                        *reinterpret_cast<unsigned*>(sb + 16) = nb_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
+                    } else {
+                        *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                    }
                 }
         }
         __syncthreads();
@@ -557,14 +575,22 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
                 for (int g = 0; g < 4; ++g) {
                     const int col = mb * 32 + 8 * g + 4 * lh;
                     h4 vh, vl;
+                    float vv[4], xl[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v = nb_h3_epilogue(acc[mb][nb][4 * g + j] * s_dco[col + j] + nz, s_bias[col + j], p.alpha, p.gain, p.clamp) * s_nst[col + j];
                         const _Float16 hi = (_Float16)v;
-                        vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                        vv[j] = v; xl[j] = v - (float)hi;
+                        vh[j] = hi; vl[j] = (_Float16)xl[j];
                     }
                     *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
-                    *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                    if (p.out_f8) {
+                        unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)pix * (CP * 2) + (col >> 4) * 32 + (col & 15);
+                        *reinterpret_cast<unsigned*>(sb) = nb_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
+                        *reinterpret_cast<unsigned*>(sb + 16) = nb_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
+                    } else {
+                        *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                    }
                 }
         }
         __syncthreads();
@@ -654,7 +680,9 @@ extern "C" const float* nb_zero_page_ptr(void);
 static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
-                          void* stream, const TorgbParams* tg = nullptr, bool f8 = false) {
+                          void* stream, const TorgbParams* tg = nullptr, bool f8 = false, int out_fmt = 0) {
+    NB_REQUIRE(out_fmt == 0 || (out_fmt == 1 && y_h2 && c_out % 16 == 0 && c_next % 16 == 0),
+               "modconv3x3_up1_h3: f8 output needs an H2 destination and c_out, c_next %% 16 == 0");
     NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && (tg ? !y_h2 : ((y != nullptr) != (y_h2 != nullptr))), "modconv3x3_up1_h3: null pointer");
     NB_REQUIRE(!f8 || c_in % 16 == 0, "modconv3x3_up1_h3: the f8 operand format needs c_in %% 16 == 0 (got %d)", c_in);
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
@@ -672,6 +700,7 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
+    p.out_f8 = out_fmt;
     p.tg = TorgbParams{};
     if (tg) p.tg = *tg;
     p.tstamps = nullptr;
@@ -689,11 +718,26 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     return launch_h3<1>(p, n, (hipStream_t)stream);
 }
 
-extern "C" int nb_modconv3x3_up1_h3f8(const void* x_f8, int c_in, const void* w_f8, const float* dcoefs, const float* noise,
-                                      int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
-                                      float alpha, float gain, float clamp, void* stream) {
-    return nb_up1_h3_impl(x_f8, c_in, w_f8, dcoefs, noise, noise_stride_n, bias, y, nullptr, nullptr, 0, 0, n, h, w, c_out,
-                          alpha, gain, clamp, stream, nullptr, true);
+extern "C" int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts, const float* dcoefs, const float* noise,
+                                      int64_t noise_stride_n, const float* bias, float* y_f32, void* y_h2,
+                                      const float* next_styles, int next_stride, int c_next, const NbTorgbArgs* t, int in_fmt,
+                                      int out_fmt, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
+                                      void* stream) {
+    NB_REQUIRE(in_fmt == 0 || in_fmt == 1, "modconv3x3_up1_h3: operand format must be 0 (H2) or 1 (f8)");
+    if (!t)
+        return nb_up1_h3_impl(x, c_in, wts, dcoefs, noise, noise_stride_n, bias, y_f32, y_h2, next_styles, next_stride, c_next,
+                              n, h, w, c_out, alpha, gain, clamp, stream, nullptr, in_fmt == 1, out_fmt);
+    NB_REQUIRE(t->styles && t->w && t->bias && t->color_bias && !y_h2, "modconv3x3_up1_h3_ex: bad ToRGB arguments");
+    NB_REQUIRE(c_out <= 128, "modconv3x3_up1_h3_ex: the fused ToRGB needs all channels in one workgroup (c_out <= 128)");
+    NB_REQUIRE(t->styles_stride_n >= c_out + 9, "torgb_triad: styles rows must hold 9 color scalars + c styles");
+    NB_REQUIRE(t->render_mode == 0 || t->render_mode == 1, "Unknown render mode for TriadGanPaintEngine: %d", t->render_mode);
+    TorgbParams tg;
+    tg.x = nullptr; tg.styles = t->styles; tg.w = t->w; tg.bias = t->bias; tg.color_bias = t->color_bias;
+    tg.logits = t->logits; tg.uvs = t->uvs; tg.img = t->img; tg.colors_out = t->colors_out; tg.user_colors = t->user_colors;
+    tg.sfactor = t->sfactor; tg.rgba_f32 = t->rgba_f32; tg.rgba_u8 = t->rgba_u8;
+    tg.styles_stride_n = t->styles_stride_n; tg.c = c_out; tg.hw = h * w; tg.render_mode = t->render_mode; tg.clamp = t->clamp;
+    return nb_up1_h3_impl(x, c_in, wts, dcoefs, noise, noise_stride_n, bias, y_f32, nullptr, nullptr, 0, 0, n, h, w, c_out,
+                          alpha, gain, clamp, stream, &tg, in_fmt == 1, 0);
 }
 
 extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
@@ -751,9 +795,10 @@ struct H3Up2Params {
     int tiles_x, tiles_y, slices, dbg, stagger_ticks;
     float alpha, gain, clamp;
     unsigned long long* tstamps;
-    _Float16* yh2; const float* next_styles; int next_stride, c8_next;      // H2 output (see H3Params)
+    _Float16* yh2; const float* next_styles; int next_stride, c8_next, out_f8;      // H2 output (see H3Params)
 };
 
+template <bool F8>
 __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
@@ -886,6 +931,42 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             issue(c + 1, ring + ((c + 1) & 1) * STAGE);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (F8) {
+            // "f8" operands (see modconv3x3_up1_h3_kernel): one f16 MFMA per tap for the main product, and the two
+            // correction products of a PAIR of taps that feed the same output phase on one block-scaled fp8 MFMA:
+            //   phase 0 (ee): taps (8,6) and (2,0)   phase 1 (eo): (7,1)   phase 2 (oe): (5,3)   phase 3 (oo): 4 alone
+            // walked so that the B fragments of input offsets 0 and 1 are loaded once and those of XS / XS+1 replace them.
+            const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
+            const h8 z8 = {};
+            h8 b0h[NBJ], b0l[NBJ], b1h[NBJ], b1l[NBJ], b2h[NBJ], b2l[NBJ];
+            h8 a1h, a1l, a2h, a2l, n1h, n1l, n2h, n2l;
+#define NB_LDA(tap, hi, lo) { hi = st[aoff + (tap) * 128]; lo = st[aoff + (tap) * 128 + 32]; }
+#define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) { hi[j] = st[boff[j] + (del)]; lo[j] = st[boff[j] + XPL + (del)]; } }
+#define NB_PAIR(ph, ah_a, al_a, bha, bla, ah_b, al_b, bhb, blb)                                                                   \
+            { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) {                                                                    \
+                f32x16& a_ = acc[j][ph];                                                                                           \
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_a, bha[j], a_, 0, 0, 0);                                            \
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_b, bhb[j], a_, 0, 0, 0);                                            \
+                a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(al_a, al_b), nb_cat8(bla[j], blb[j]), a_, 0, 0, 0, sa, 0, sb); } }
+            NB_LDB(0, b0h, b0l); NB_LDB(1, b1h, b1l); NB_LDA(8, a1h, a1l); NB_LDA(6, a2h, a2l);
+            NB_LDA(5, n1h, n1l); NB_LDA(3, n2h, n2l);
+            NB_PAIR(0, a1h, a1l, b0h, b0l, a2h, a2l, b1h, b1l);                   // taps 8, 6
+            NB_LDA(4, a1h, a1l);
+            NB_PAIR(2, n1h, n1l, b0h, b0l, n2h, n2l, b1h, b1l);                   // taps 5, 3
+            NB_LDB(XS, b1h, b1l); NB_LDA(7, n1h, n1l); NB_LDA(1, n2h, n2l);
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) {                                       // tap 4 alone
+                f32x16& a_ = acc[j][3];
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h[j], a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(a1l, z8), nb_cat8(b0l[j], z8), a_, 0, 0, 0, sa, 0, sb);
+            }
+            NB_LDB(XS + 1, b2h, b2l); NB_LDA(2, a1h, a1l); NB_LDA(0, a2h, a2l);
+            NB_PAIR(1, n1h, n1l, b0h, b0l, n2h, n2l, b1h, b1l);                   // taps 7, 1
+            NB_PAIR(0, a1h, a1l, b1h, b1l, a2h, a2l, b2h, b2l);                   // taps 2, 0
+#undef NB_LDA
+#undef NB_LDB
+#undef NB_PAIR
+        } else {
         h8 ah[2], al[2], bh[2][NBJ], bl[2][NBJ];
         ah[0] = st[aoff + kOrd[0] * 128]; al[0] = st[aoff + kOrd[0] * 128 + 32];
 #pragma unroll
@@ -921,6 +1002,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             if (nfetch == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             else if (nfetch) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NBJ, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ, 0);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         // chunk c+1 must have landed; with 3 stages the DMA of chunk c+2 may stay in flight
@@ -1016,7 +1098,15 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                         const float v = nb_h3_epilogue(out[dy][dx] * d + nz[dx], bs, p.alpha, p.gain, p.clamp) * ns;
                         const _Float16 hi = (_Float16)v;
                         obuf[(opix0 + dx) * 8 + ch] = hi;
-                        obuf[(OPIX + opix0 + dx) * 8 + ch] = (_Float16)(v - (float)hi);
+                        if (p.out_f8) {
+                            // the chunk's two lo slots (16 x fp8(xl 2^9), 16 x fp8(v/4)) fill up over two rounds
+                            const unsigned pk = nb_pk4_fp8((v - (float)hi) * 512.f, v * 0.25f, 0.f, 0.f);
+                            unsigned char* ob = reinterpret_cast<unsigned char*>(obuf + (size_t)OPIX * 8);
+                            ob[(opix0 + dx) * 16 + (round & 1) * 8 + ch] = (unsigned char)(pk & 0xff);
+                            ob[(OPIX + opix0 + dx) * 16 + (round & 1) * 8 + ch] = (unsigned char)((pk >> 8) & 0xff);
+                        } else {
+                            obuf[(OPIX + opix0 + dx) * 8 + ch] = (_Float16)(v - (float)hi);
+                        }
                     }
                 }
             } else if (co < p.c_out && qi < H && !(p.dbg & 1)) {
@@ -1037,11 +1127,27 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             if (cg * 8 < p.c_out && !(p.dbg & 1)) {
                 const size_t OHW8 = (size_t)Ho * Wo * 8;
                 _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
-                for (int e = tid; e < 2 * OPIX; e += 512) {
-                    const int hl = e / OPIX, opix = e - hl * OPIX;
-                    const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
-                    if (oy < Ho)
-                        *reinterpret_cast<h8*>(yn + (size_t)hl * OHW8 + ((size_t)oy * Wo + ox) * 8) = *reinterpret_cast<const h8*>(obuf + (size_t)e * 8);
+                if (!p.out_f8) {
+                    for (int e = tid; e < 2 * OPIX; e += 512) {
+                        const int hl = e / OPIX, opix = e - hl * OPIX;
+                        const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
+                        if (oy < Ho)
+                            *reinterpret_cast<h8*>(yn + (size_t)hl * OHW8 + ((size_t)oy * Wo + ox) * 8) = *reinterpret_cast<const h8*>(obuf + (size_t)e * 8);
+                    }
+                } else {
+                    // hi slot of this round's channel group; after the chunk's second round also its two lo slots
+                    // ((cg-1, lo) = fp8(xl 2^9) of the 16 channels, (cg, lo) = fp8(v/4))
+                    const int nsl = (round & 1) ? 3 : 1;
+                    for (int e = tid; e < nsl * OPIX; e += 512) {
+                        const int k = e / OPIX, opix = e - k * OPIX;
+                        const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
+                        if (oy < Ho) {
+                            const size_t pixo = ((size_t)oy * Wo + ox) * 8;
+                            if (k == 0) *reinterpret_cast<h8*>(yn + pixo) = *reinterpret_cast<const h8*>(obuf + (size_t)opix * 8);
+                            else if (k == 1) *reinterpret_cast<h8*>(yn - OHW8 + pixo) = *reinterpret_cast<const h8*>(obuf + (size_t)(OPIX + opix) * 8);
+                            else *reinterpret_cast<h8*>(yn + OHW8 + pixo) = *reinterpret_cast<const h8*>(obuf + (size_t)(2 * OPIX + opix) * 8);
+                        }
+                    }
                 }
             }
         }
@@ -1056,7 +1162,10 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
 static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
-                          void* stream) {
+                          void* stream, int in_fmt = 0, int out_fmt = 0) {
+    NB_REQUIRE((in_fmt == 0 || in_fmt == 1) && (out_fmt == 0 || out_fmt == 1), "modconv3x3_up2_h3: operand format must be 0 (H2) or 1 (f8)");
+    NB_REQUIRE(in_fmt == 0 || c_in % 16 == 0, "modconv3x3_up2_h3: the f8 operand format needs c_in %% 16 == 0 (got %d)", c_in);
+    NB_REQUIRE(out_fmt == 0 || (y_h2 && c_out % 16 == 0 && c_next % 16 == 0), "modconv3x3_up2_h3: f8 output needs an H2 destination and c_out, c_next %% 16 == 0");
     NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && ((y != nullptr) != (y_h2 != nullptr)), "modconv3x3_up2_h3: null pointer");
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
                "modconv3x3_up2_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
@@ -1074,19 +1183,22 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tiles_x = w / 32; p.tiles_y = (h + NB_H3_TQH - 1) / NB_H3_TQH; p.slices = (c_out + 31) / 32;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
+    p.out_f8 = out_fmt;
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
     constexpr int XPL = (((NB_H3_TQH + 3) * 35 + 63) / 64) * 64;
     constexpr int NBLK_ = ((NB_H3_TQH + 2) * 34 + 31) / 32;
     constexpr size_t lds_stage = (size_t)NB_H3_STAGES * (4 * XPL + 36 * 32) * 16;
-    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)2 * 4 * NB_H3_TQH * 32 * 16;   // FIR slots + H2 slots
+    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * NB_H3_TQH * 32 * 16;   // FIR slots + H2 slots (hi, 2 x lo)
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL(modconv3x3_up2_h3_kernel, grid, dim3(512), lds, (hipStream_t)stream, p);
+    if (in_fmt) hipLaunchKernelGGL(modconv3x3_up2_h3_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(modconv3x3_up2_h3_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2_h3");
     return NB_OK;
 }
@@ -1096,6 +1208,14 @@ extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3
                                     float alpha, float gain, float clamp, void* stream) {
     return nb_up2_h3_impl(x_h2, c_in, w_h3, dcoefs, noise, noise_stride_n, bias, y, nullptr, nullptr, 0, 0, n, h, w, c_out,
                           alpha, gain, clamp, stream);
+}
+
+extern "C" int nb_modconv3x3_up2_h3_ex(const void* x, int c_in, const void* wts, const float* dcoefs, const float* noise,
+                                      int64_t noise_stride_n, const float* bias, float* y_f32, void* y_h2,
+                                      const float* next_styles, int next_stride, int c_next, int in_fmt, int out_fmt, int n,
+                                      int h, int w, int c_out, float alpha, float gain, float clamp, void* stream) {
+    return nb_up2_h3_impl(x, c_in, wts, dcoefs, noise, noise_stride_n, bias, y_f32, y_h2, next_styles, next_stride, c_next,
+                          n, h, w, c_out, alpha, gain, clamp, stream, in_fmt, out_fmt);
 }
 
 extern "C" int nb_modconv3x3_up2_h3_h2(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
@@ -1145,14 +1265,6 @@ extern "C" int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, 
 
 // fp32 NCHW (x1 ++ x2) * scale -> the "f8" activation format (see modconv3x3_up1_h3_kernel): per 16-channel chunk the
 // f16 high halves of both channel groups, fp8(xl * 2^9) and fp8(x / 4)
-__device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float d) {
-    auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
-    return (unsigned)w;
-}
-
 __global__ __launch_bounds__(256) void pack_h2f8_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,
                                                         const float* __restrict__ scale, _Float16* __restrict__ out, int c8, int hw) {
     const int n = blockIdx.z, chunk = blockIdx.y;
@@ -1225,6 +1337,48 @@ __global__ __launch_bounds__(256) void pack_h2_part_kernel(const float* __restri
     h8* o = reinterpret_cast<h8*>(out) + ((size_t)(n * c8_total + cg0 + cgl) * 2) * hw + pix;
     o[0] = hi;
     o[hw] = lo;
+}
+
+__global__ __launch_bounds__(256) void pack_h2f8_part_kernel(const float* __restrict__ x, int c, const float* __restrict__ scale,
+                                                             int scale_stride, _Float16* __restrict__ out, int c8_total, int cg0, int hw) {
+    const int n = blockIdx.z, chunk = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    float v[16], xl[16];
+    h8 hi0, hi1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ch = chunk * 16 + j;
+        float t = 0.f;
+        if (ch < c) {
+            t = x[((size_t)n * c + ch) * hw + pix];
+            if (scale) t *= scale[(size_t)n * scale_stride + ch];
+        }
+        const _Float16 hh = (_Float16)t;
+        if (j < 8) hi0[j & 7] = hh; else hi1[j & 7] = hh;
+        v[j] = t; xl[j] = (t - (float)hh) * 512.f;
+    }
+    i32x4 l8, h8v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        l8[q] = (int)nb_pk4_fp8(xl[4 * q], xl[4 * q + 1], xl[4 * q + 2], xl[4 * q + 3]);
+        h8v[q] = (int)nb_pk4_fp8(v[4 * q] * 0.25f, v[4 * q + 1] * 0.25f, v[4 * q + 2] * 0.25f, v[4 * q + 3] * 0.25f);
+    }
+    h8* o = reinterpret_cast<h8*>(out) + ((size_t)(n * c8_total + cg0 + 2 * chunk) * 2) * hw + pix;
+    o[0] = hi0;
+    o[hw] = __builtin_bit_cast(h8, l8);
+    o[2 * (size_t)hw] = hi1;
+    o[3 * (size_t)hw] = __builtin_bit_cast(h8, h8v);
+}
+
+extern "C" int nb_pack_h2f8_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out, int c8_total,
+                                     int cg0, int n, int hw, void* stream) {
+    NB_REQUIRE(x && out && c > 0 && c % 16 == 0 && cg0 % 2 == 0 && n > 0 && n <= 65535 && hw > 0 && cg0 >= 0 && cg0 + c / 8 <= c8_total,
+               "pack_h2f8_part: bad arguments (whole 16-channel chunks only)");
+    dim3 grid((hw + 255) / 256, c / 16, n);
+    hipLaunchKernelGGL(pack_h2f8_part_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c, scale, scale_stride, (_Float16*)out, c8_total, cg0, hw);
+    NB_CHECK_LAUNCH("pack_h2f8_part");
+    return NB_OK;
 }
 
 extern "C" int nb_pack_h2_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out_h2, int c8_total,

@@ -272,21 +272,28 @@ class SynthesisNetwork(torch.nn.Module):
             wpk, wsq = ops.pack_conv_weight(layer.weight)
             self.packed[s.name] = {"wpk": wpk, "wsq": wsq,
                                    "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous()}
-            if self.conv_mode == "h3" and self.cfg.conv_clamp is not None:
+            if self.conv_mode in ("h3", "f8") and self.cfg.conv_clamp is not None:
                 self.packed[s.name]["w_h3"] = ops.pack_conv_weight_h3(layer.weight)
+                if self.conv_mode == "f8" and s.in_channels % 16 == 0:
+                    self.packed[s.name]["w_f8"] = ops.pack_conv_weight_h3f8(layer.weight)
         t = self.get_last_block().torgb
         self.packed["torgb"] = {"w": t.weight.reshape(3, -1).contiguous()}
 
     def _h3_eligible(self, s: LayerSpec) -> bool:
         """conv1 layers that run as 3-pass split-f16 MFMA (csrc/nb_modconv_h3.hip): the kernel needs rows of 32
         pixels and 16-row tiles, and a conv_clamp so that activations are bounded inside the f16 range."""
-        return (self.conv_mode == "h3" and self._h3_batch_ok and s.up == 1 and s.block_res >= 32
+        return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 1 and s.block_res >= 32
                 and s.block_res % 32 == 0 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _h3_up2_eligible(self, s: LayerSpec) -> bool:
         """conv0 (up=2) layers that run on the split-f16 4-phase kernel: input rows must be multiples of 32 pixels."""
-        return (self.conv_mode == "h3" and self._h3_batch_ok and s.up == 2 and s.in_res >= 32 and s.in_res % 32 == 0
+        return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 2 and s.in_res >= 32 and s.in_res % 32 == 0
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
+
+    def _operand_fmt(self, s: Optional[LayerSpec]) -> int:
+        """Operand format of a split-f16 layer's input: 1 = "f8" (correction products on block-scaled fp8 MFMAs; whole
+        16-channel chunks only), 0 = H2 (hi/lo f16)."""
+        return 1 if (s is not None and self.conv_mode == "f8" and s.in_channels % 16 == 0) else 0
 
     def _variant_name(self, n: int, s: LayerSpec) -> str:
         buf = ctypes.create_string_buffer(128)
@@ -428,23 +435,29 @@ class SynthesisNetwork(torch.nn.Module):
                                                or stop_after == res)
                     me_h3 = self._h3_up2_eligible(s) if s.up == 2 else self._h3_eligible(s)
                     nxt_h3 = nxt is not None and (self._h3_eligible(nxt) if nxt.up == 1 else self._h3_up2_eligible(nxt))
-                    fuse_out = (self.h2_handoff and me_h3 and nxt_h3 and not tapped and s.out_channels % 8 == 0)
+                    in_fmt = self._operand_fmt(s)                       # 0 = H2 (hi/lo f16), 1 = f8 corrections
+                    out_fmt = self._operand_fmt(nxt) if nxt_h3 else 0
+                    geo_after = (self.geom_feature_channels[self.geom_feature_resolutions.index(res)]
+                                 if at_block_end and res in self.geom_feature_resolutions else 0)
+                    fuse_out = (self.h2_handoff and me_h3 and nxt_h3 and not tapped and s.out_channels % 8 == 0
+                                and (out_fmt == 0 or (s.out_channels % 16 == 0 and geo_after % 16 == 0)))
                     y = next_h2 = None
                     fused_rgb = None
                     if me_h3:
                         if x_h2 is None:
-                            # producer was not a split-f16 kernel: (x ++ geometry) * styles -> H2
+                            # producer was not a split-f16 kernel: (x ++ geometry) * styles -> H2 / f8 operands
                             evp = self._begin_event("pack_h2")
                             x_h2 = torch.empty(ops.h2_shape(n, s.in_channels, s.in_res, s.in_res), dtype=torch.float16,
                                                device=device)
-                            _lib.check(lib.nb_pack_h2_f32(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(x_h2), n,
-                                                          s.in_res * s.in_res, stream), "pack_h2")
+                            pack = lib.nb_pack_h2f8_f32 if in_fmt else lib.nb_pack_h2_f32
+                            _lib.check(pack(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(x_h2), n, s.in_res * s.in_res, stream),
+                                       "pack_h2")
                             self._end_event(evp)
                         ev = self._begin_event(name)
-                        fn = {(1, False): lib.nb_modconv3x3_up1_h3, (2, False): lib.nb_modconv3x3_up2_h3,
-                              (1, True): lib.nb_modconv3x3_up1_h3_h2, (2, True): lib.nb_modconv3x3_up2_h3_h2}[(s.up, fuse_out)]
+                        wts = pk["w_f8"] if in_fmt else pk["w_h3"]
                         fuse_rgb = (self.fuse_torgb and block.is_last and s.up == 1 and s.out_channels <= 128
                                     and res not in blended_features)
+                        targs = None
                         if fuse_rgb:
                             # last conv + ToRGB + compositing in one launch; the fp32 activations are only written
                             # when a caller taps them
@@ -452,23 +465,26 @@ class SynthesisNetwork(torch.nn.Module):
                             targs = self._torgb_args(plan, tg, s.out_channels)
                             if res in return_features or stop_after == res:
                                 y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                            _lib.check(lib.nb_modconv3x3_up1_h3_torgb(
-                                _p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
-                                _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp,
-                                ctypes.byref(targs), stream), name)
-                            fused_rgb = self._torgb_finish(tg, extra)
                         elif fuse_out:
                             next_h2 = torch.empty(ops.h2_shape(n, nxt.in_channels, s.block_res, s.block_res),
                                                   dtype=torch.float16, device=device)
-                            _lib.check(fn(_p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
-                                          _p(layer.bias), _p(plan.styles[i + 1]), nxt.in_channels, _p(next_h2),
-                                          nxt.in_channels, n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain,
-                                          clamp, stream), name)
                         else:
                             y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                            _lib.check(fn(_p(x_h2), s.in_channels, _p(pk["w_h3"]), _p(plan.dcoefs[i]), noise_ptr, nstride,
-                                          _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2,
-                                          layer.act_gain, clamp, stream), name)
+                        nst = _p(plan.styles[i + 1]) if next_h2 is not None else None
+                        c_next = nxt.in_channels if next_h2 is not None else 0
+                        if s.up == 1:
+                            _lib.check(lib.nb_modconv3x3_up1_h3_ex(
+                                _p(x_h2), s.in_channels, _p(wts), _p(plan.dcoefs[i]), noise_ptr, nstride, _p(layer.bias),
+                                _p(y), _p(next_h2), nst, c_next, c_next, None if targs is None else ctypes.byref(targs),
+                                in_fmt, out_fmt if next_h2 is not None else 0, n, s.in_res, s.in_res, s.out_channels, 0.2,
+                                layer.act_gain, clamp, stream), name)
+                        else:
+                            _lib.check(lib.nb_modconv3x3_up2_h3_ex(
+                                _p(x_h2), s.in_channels, _p(wts), _p(plan.dcoefs[i]), noise_ptr, nstride, _p(layer.bias),
+                                _p(y), _p(next_h2), nst, c_next, c_next, in_fmt, out_fmt if next_h2 is not None else 0, n,
+                                s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
+                        if fuse_rgb:
+                            fused_rgb = self._torgb_finish(tg, extra)
                         self.layer_kernels[name] = ("modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
                                                     if s.up == 1 else "modconv3x3_up2_h3_kernel")
                         keep_alive.append(x_h2)
@@ -516,9 +532,10 @@ class SynthesisNetwork(torch.nn.Module):
                         inext, snext = specs[f"synthesis.b{2 * res}.conv0"]
                         c_prod = snext.in_channels - x2.shape[1]
                         evp = self._begin_event("pack_h2")
-                        _lib.check(lib.nb_pack_h2_part_f32(_p(x2), x2.shape[1], plan.styles[inext].data_ptr() + 4 * c_prod,
-                                                           snext.in_channels, _p(x_h2), (snext.in_channels + 7) // 8,
-                                                           c_prod // 8, n, res * res, stream), "pack_h2_part")
+                        part = lib.nb_pack_h2f8_part_f32 if self._operand_fmt(snext) else lib.nb_pack_h2_part_f32
+                        _lib.check(part(_p(x2), x2.shape[1], plan.styles[inext].data_ptr() + 4 * c_prod, snext.in_channels,
+                                        _p(x_h2), (snext.in_channels + 7) // 8, c_prod // 8, n, res * res, stream),
+                                   "pack_h2_part")
                         self._end_event(evp)
                         keep_alive.append(x2)
                         x2 = None
@@ -624,7 +641,7 @@ class Generator(torch.nn.Module):
     def __init__(self, cfg: GeneratorConfig = None, state_dict: Optional[StateDict] = None, conv_mode: str = "h3",
                  **kwargs):
         super().__init__()
-        if conv_mode not in ("h3", "f32"):
+        if conv_mode not in ("h3", "f8", "f32"):
             raise RuntimeError(f"unknown conv_mode {conv_mode!r}")
         if cfg is None:
             cfg = GeneratorConfig(**kwargs)
@@ -644,8 +661,9 @@ class Generator(torch.nn.Module):
         self.eval().requires_grad_(False)
 
     def set_conv_mode(self, conv_mode: str):
-        """'h3' (default): large conv1 layers as split-f16 MFMA; 'f32': all layers on the exact-fp32 MFMA kernels."""
-        if conv_mode not in ("h3", "f32"):
+        """'h3': layers >= 32x32 as 3-pass split-f16 MFMA (5e-6 from fp32); 'f8': the two correction passes on one
+        block-scaled fp8 MFMA per tap pair (1e-4 from fp32, ~1.4x faster layers); 'f32': exact-fp32 MFMA kernels."""
+        if conv_mode not in ("h3", "f8", "f32"):
             raise RuntimeError(f"unknown conv_mode {conv_mode!r}")
         self.synthesis.conv_mode = conv_mode
         self._invalidate()

@@ -196,9 +196,9 @@ int nb_blend_f32(const float* features, int nf, const float* alpha, int na, cons
  * (cg 0, lo) = fp8(w), (cg 1, lo) = fp8((w - f16(w))*2^11).  c_in % 16 == 0.  End-to-end pixel error ~1e-4 (H2: 5e-6). */
 int nb_pack_h2f8_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out, int n, int hw,
                      void* stream);
-int nb_modconv3x3_up1_h3f8(const void* x_f8, int c_in, const void* w_f8, const float* dcoefs, const float* noise,
-                           int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
-                           float alpha, float gain, float clamp, void* stream);
+/* c % 16 == 0 channels into the 16-channel chunks starting at channel group cg0 (even) of an f8-format tensor */
+int nb_pack_h2f8_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out, int c8_total, int cg0,
+                          int n, int hw, void* stream);
 
 /* Arguments of the triad ToRGB epilogue when it is fused into the last conv (same meaning as the parameters of
  * nb_torgb_triad_f32; any output pointer may be NULL). */
@@ -221,6 +221,19 @@ struct NbTorgbArgs {
 int nb_modconv3x3_up1_h3_torgb(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                                int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
                                float alpha, float gain, float clamp, const struct NbTorgbArgs* t, void* stream);
+
+/* General forms of the two split-f16 convolutions.  in_fmt / out_fmt: 0 = H2 (hi/lo f16), 1 = "f8" (hi f16 + fp8
+ * correction operands, above); the weights must be packed for in_fmt (nb_pack_conv_weight_h3 or the f8 layout).
+ * Exactly one destination: y_f32 (fp32 NCHW; out_fmt ignored), y_h2 (the consumer's input tensor [n, c_next, ...] in
+ * out_fmt, multiplied by next_styles), or -- up1 only, t != NULL -- the fused ToRGB outputs (y_f32 optional). */
+int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts, const float* dcoefs, const float* noise,
+                            int64_t noise_stride_n, const float* bias, float* y_f32, void* y_h2, const float* next_styles,
+                            int next_stride, int c_next, const struct NbTorgbArgs* t, int in_fmt, int out_fmt, int n, int h,
+                            int w, int c_out, float alpha, float gain, float clamp, void* stream);
+int nb_modconv3x3_up2_h3_ex(const void* x, int c_in, const void* wts, const float* dcoefs, const float* noise,
+                            int64_t noise_stride_n, const float* bias, float* y_f32, void* y_h2, const float* next_styles,
+                            int next_stride, int c_next, int in_fmt, int out_fmt, int n, int h, int w, int c_out,
+                            float alpha, float gain, float clamp, void* stream);
 
 /* The two split-f16 convolutions with the output written straight into the CONSUMER's H2 input tensor
  * y_h2 = H2 [n, c_next, h_out, w_out] (channel groups 0 .. c_out/8-1; c_out % 8 == 0), already multiplied by the

@@ -1,0 +1,144 @@
+"""GPU parity of the "f8" conv mode (correction products of the split-f16 scheme on block-scaled fp8 MFMAs):
+kernels against float64 / the h3 kernels, the generator against the REFERENCE outputs (tests/golden/gen_r*.npz) and the
+tiled canvas against the reference-painted canvas.  north_star tolerance: 1e-3 max abs on pixels; asserted: 3e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+PIX_TOL_F8 = 3e-4
+
+
+def _conv_ref(x, w, st, up):
+    xm = (x * st[:, :, None, None]).double().cpu()
+    if up == 1:
+        return torch.nn.functional.conv2d(xm, w.double().cpu(), padding=1)
+    from oracle import neube_oracle as orc
+    f = orc.setup_filter([1, 3, 3, 1], dtype=torch.float64)
+    return orc.conv2d_resample(xm, w.double().cpu(), f=f, up=2, padding=1, flip_weight=False)
+
+
+@pytest.mark.parametrize("up,ci,co,res", [(1, 64, 64, 64), (1, 128, 128, 32), (1, 144, 96, 64), (2, 128, 64, 64),
+                                           (2, 384, 128, 64), (2, 144, 128, 64)])
+def test_f8_kernels_vs_float64(up, ci, co, res):
+    """One layer, f8 operands, fp32 output: error against float64 at the level of the fp8 correction terms
+    (2^-11 * 2^-4 relative per product), ~20x the h3 error and ~30x below a plain f16 evaluation."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(up * 1000 + ci + co)
+    n = 2
+    hin = res if up == 1 else res // 2
+    x = torch.from_numpy((rs.randn(n, ci, hin, hin) * 2).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    dco, bias = torch.ones(n, co, device="cuda"), torch.zeros(co, device="cuda")
+    ref = _conv_ref(x, w, st, up)
+    S = torch.cuda.current_stream().cuda_stream
+    errs = {}
+    for fmt, pack_x, pack_w in ((0, ops.pack_h2, ops.pack_conv_weight_h3), (1, ops.pack_h2f8, ops.pack_conv_weight_h3f8)):
+        xh, wp = pack_x(x, st), pack_w(w)
+        y = torch.empty([n, co, res, res], device="cuda")
+        if up == 1:
+            rc = _lib.lib().nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(),
+                                                    y.data_ptr(), None, None, 0, 0, None, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
+        else:
+            rc = _lib.lib().nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(),
+                                                    y.data_ptr(), None, None, 0, 0, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
+        _lib.check(rc, "conv")
+        errs[fmt] = float((y.cpu().double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert errs[0] <= 2e-6 * scale and errs[1] <= 4e-5 * scale, (errs, scale)
+
+
+@pytest.mark.parametrize("up,ci,co,res,c_next", [(1, 64, 64, 64, 64), (1, 128, 128, 32, 384), (2, 128, 64, 64, 64), (2, 144, 128, 64, 128)])
+def test_f8_handoff_equals_pack(up, ci, co, res, c_next):
+    """f8-format output of a producer == fp32 output followed by nb_pack_h2f8_f32 with the consumer's styles
+    (same value; the fp8 bytes may differ where the product is an exact tie, so the decoded planes are compared)."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(ci + co + up)
+    n = 3
+    hin = res if up == 1 else res // 2
+    x = torch.from_numpy(rs.randn(n, ci, hin, hin).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    nst = torch.from_numpy(rs.uniform(0.5, 1.5, (n, c_next)).astype(np.float32)).cuda()
+    dco = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32)).cuda()
+    noise = torch.from_numpy(rs.randn(n, res, res).astype(np.float32)).cuda()
+    xh, wp = ops.pack_h2f8(x, st), ops.pack_conv_weight_h3f8(w)
+    lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    y = torch.empty([n, co, res, res], device="cuda")
+    out = torch.zeros(ops.h2_shape(n, c_next, res, res), dtype=torch.float16, device="cuda")
+    common = (dco.data_ptr(), noise.data_ptr(), res * res, bias.data_ptr())
+    if up == 1:
+        _lib.check(lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, y.data_ptr(), None, None, 0, 0, None, 1, 0,
+                                               n, hin, hin, co, 0.2, 1.4142135, 256.0, S), "f32")
+        _lib.check(lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, None, out.data_ptr(), nst.data_ptr(), c_next,
+                                               c_next, None, 1, 1, n, hin, hin, co, 0.2, 1.4142135, 256.0, S), "f8out")
+    else:
+        _lib.check(lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, y.data_ptr(), None, None, 0, 0, 1, 0,
+                                               n, hin, hin, co, 0.2, 1.4142135, 256.0, S), "f32")
+        _lib.check(lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, None, out.data_ptr(), nst.data_ptr(), c_next,
+                                               c_next, 1, 1, n, hin, hin, co, 0.2, 1.4142135, 256.0, S), "f8out")
+    ref = ops.pack_h2f8(y, nst[:, :co].contiguous())
+
+    def decode(t, c):
+        """f8-format tensor -> (hi f32 [n,c,h,w], xl8 f32, xh8 f32)"""
+        nn, c8, _, h, w_, _ = t.shape
+        hi = t[:, :, 0].float().permute(0, 1, 4, 2, 3).reshape(nn, c8 * 8, h, w_)[:, :c]
+        lo = t[:, :, 1].contiguous().view(torch.uint8).view(torch.float8_e4m3fn).float()      # [n, c8, h, w, 16]
+        xl = lo[:, 0::2].permute(0, 1, 4, 2, 3).reshape(nn, c8 * 8, h, w_)[:, :c]
+        xh = lo[:, 1::2].permute(0, 1, 4, 2, 3).reshape(nn, c8 * 8, h, w_)[:, :c]
+        return hi, xl, xh
+    got, want = decode(out[:, :co // 8].contiguous(), co), decode(ref, co)
+    v_got = got[0] + got[1] / 512
+    v_want = want[0] + want[1] / 512
+    assert float((v_got - v_want).abs().max()) <= 2e-5 * float(v_want.abs().max())        # hi + xl: ~15 bits either way
+    assert float((got[2] - want[2]).abs().max()) <= 0.07 * float(want[2].abs().max())      # fp8(v/4): one fp8 step at most
+    assert (out[:, :co // 8] != ref).float().mean() < 2e-3
+    assert not out[:, co // 8:].any()
+    if c_next > co:
+        g = torch.from_numpy(rs.randn(n, c_next - co, res, res).astype(np.float32)).cuda()
+        _lib.check(lib.nb_pack_h2f8_part_f32(g.data_ptr(), c_next - co, nst.data_ptr() + 4 * co, c_next, out.data_ptr(),
+                                             c_next // 8, co // 8, n, res * res, S), "part")
+        full = ops.pack_h2f8(y, nst, g)
+        assert torch.equal(out[:, co // 8:], full[:, co // 8:])
+
+
+@pytest.mark.parametrize("res", [128, 256])
+def test_f8_generator_vs_reference_golden(res):
+    """style1 shapes against the reference's outputs in the f8 mode: pixels within 3e-4 (budget 1e-3)."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic, weights as wmod
+    from brushstroke_engine_amd.networks import Generator
+    g = load_golden(f"gen_r{res}.npz")
+    cfg = cfgmod.style1_config(res)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=int(g["weights_seed"])), conv_mode="f8").to("cuda")
+    geom = [torch.from_numpy(x).cuda() for x in synthetic.geom_features(cfg, 2, seed=int(g["geom_seed"]))]
+    z = torch.from_numpy(np.concatenate([g["z"]] * 2)).cuda()              # batch 4 so that the split-f16 path is taken
+    geom = [torch.cat([x, x]) for x in geom]
+    pos = torch.from_numpy(np.concatenate([g["positions"]] * 2)).cuda()
+    img, dbg = G(z, None, geom, positions=pos, return_debug_data=True, noise_mode="const")
+    assert any("_h3" in k for k in G.synthesis.layer_kernels.values())
+    step = int(g["step"])
+    for name, full in (("uvs", dbg["uvs"]), ("img", img)):
+        got = full[:2].cpu().numpy()[..., ::step, ::step]
+        assert float(np.abs(got - g[f"{name}.sub"]).max()) <= PIX_TOL_F8, name
+    assert float(np.abs(dbg["uvs"][:2, :, res // 3, :].cpu().numpy() - g["uvs.row"]).max()) <= PIX_TOL_F8
+    assert torch.equal(img[:2], img[2:])                                    # batch-composition independence, bitwise
+
+
+def test_f8_tiled_canvas_matches_reference():
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, encoder as encmod, painting
+    from brushstroke_engine_amd.networks import Generator
+    g = load_golden("engine_r128.npz")
+    cfg = cfgmod.style1_config(128)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode="f8").to("cuda")
+    ops = painting.TileOps(G, encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5)))
+    helper = painting.PaintingHelper(ops, batch=4)
+    helper.set_feature_blending(2)
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(np.random.RandomState(594).randn(1, cfg.z_dim)), 594)
+    _, full, _, _ = helper.paint_image(g["geom"], opts, crop_margin=int(g["crop_margin"]), return_full=True)
+    d = np.abs(full.astype(np.int32) - g["canvas_level2_clear"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() <= 5e-3, (d.max(), (d > 0).mean())
