@@ -33,7 +33,8 @@ import torch.distributed as dist
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2/16x16x4, 64 FLOP/clk/SIMD (spec)
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA (spec, no sparsity); the split-f16 kernels
-                                    # execute 3 MFMA FLOPs per algorithmic FLOP, so their frac is capped at 1/3
+                                    # execute 3 (h3) or the time-equivalent of 2 (f8) MFMA FLOPs per algorithmic FLOP
+PEAK_FP8_MATRIX_TFLOPS = 5000.0     # dense fp8 MFMA (same guide)
 
 
 def layer_flops(spec, batch):
@@ -351,9 +352,15 @@ def main():
             traffic = None
     roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": dom_peak,
                 "unit": "TFLOP/s", "frac": round(achieved / dom_peak, 4), "traffic": traffic,
-                "executed_mfma": ({"tflops": round(3 * achieved, 1), "frac": round(3 * achieved / dom_peak, 4),
-                                   "what": "f16 MFMA FLOPs actually executed for the algorithmic ones (3 products per fp32 "
-                                           "product; halo / block-rounding overhead of the up=2 kernel not included)"}
+                "executed_mfma": (({"tflops": round(3 * achieved, 1), "frac": round(3 * achieved / dom_peak, 4),
+                                    "what": "f16 MFMA FLOPs actually executed for the algorithmic ones (3 products per fp32 "
+                                            "product; halo / block-rounding overhead of the up=2 kernel not included)"}
+                                   if args.conv_mode == "h3" else
+                                   {"f16_tflops": round(achieved, 1), "fp8_tflops": round(2 * achieved, 1),
+                                    "frac": round(achieved / PEAK_F16_MATRIX_TFLOPS + 2 * achieved / PEAK_FP8_MATRIX_TFLOPS, 4),
+                                    "what": "matrix work actually executed per algorithmic FLOP: 1 f16 MFMA FLOP (main product) + "
+                                            "2 fp8 MFMA FLOPs (both correction products in one K=64 block-scaled instruction per "
+                                            "tap pair); frac = share of the matrix pipes' time (f16 peak 2500, fp8 peak 5000 TFLOP/s)"})
                                   if "_h3_" in dom_name else None),
                 "launch_ms": round(dom_ms / dom_launches, 4), "launches_per_step": dom_launches * sub,
                 "patches_per_launch": B // sub,
@@ -367,8 +374,11 @@ def main():
                                             / (sum(float(np.mean(t)) for t in iso.values()) * 1e-3) / 1e12 / dom_peak, 4)}
                              if iso else None),
                 "flops_per_launch": dom_fl / dom_launches,
-                "note": "split-f16 (h3) kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
-                        if "_h3_" in dom_name else "fp32 MFMA",
+                "note": ("fp32 MFMA" if "_h3_" not in dom_name else
+                         "split-f16 kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
+                         if args.conv_mode == "h3" else
+                         "split-f16 + fp8-correction kernels spend 2 f16-MFMA-equivalents of matrix time per algorithmic fp32 FLOP: "
+                         "frac (against the f16 peak) <= 1/2 by construction"),
                 "calibration": {"what": "untimed pass with every launch bracketed by HIP events",
                                 "all_conv_launches": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4)},
                                 "kernels": {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],

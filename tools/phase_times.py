@@ -14,6 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib, ops  # noqa: E402
 
 
+F8 = os.environ.get("NB_PHASE_F8") == "1"
+
+
 def run(kind, n, ci, co, res):
     lib = _lib.lib()
     lib.nb_debug_set_timestamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -25,17 +28,20 @@ def run(kind, n, ci, co, res):
     styles = torch.ones(n, ci, device="cuda")
     dco = torch.ones(n, co, device="cuda")
     bias = torch.zeros(co, device="cuda")
-    xh = ops.pack_h2(x, styles)
-    wp = ops.pack_conv_weight_h3(w)
+    xh = (ops.pack_h2f8 if F8 else ops.pack_h2)(x, styles)
+    wp = (ops.pack_conv_weight_h3f8 if F8 else ops.pack_conv_weight_h3)(w)
     cap = 1 << 16
     ts = torch.zeros([cap, 8], dtype=torch.int64, device="cuda")
     y = torch.empty([n, co, res, res], device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    fn = lib.nb_modconv3x3_up1_h3 if kind == "up1" else lib.nb_modconv3x3_up2_h3
-
     def launch():
-        _lib.check(fn(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(), n, hin, hin,
-                      co, 0.2, 1.4142135, 256.0, st), kind)
+        if kind == "up1":
+            rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(),
+                                             None, None, 0, 0, None, int(F8), 0, n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
+        else:
+            rc = lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(),
+                                             None, None, 0, 0, int(F8), 0, n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
+        _lib.check(rc, kind)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
