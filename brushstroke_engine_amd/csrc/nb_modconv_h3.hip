@@ -105,6 +105,14 @@ __device__ __forceinline__ i32x8 nb_cat8(h8 a, h8 b) {
     return i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
 }
 
+// two values -> two fp8 bytes (low 16 bits).  CLAMP: saturate to the e4m3 range first (needed for x/4 when |x| > 1792;
+// xl * 2^9 = (x - f16(x)) * 512 <= |x| / 4 is covered by the same bound and is clamped as well where x is not)
+template <bool CLAMP>
+__device__ __forceinline__ unsigned nb_pk2_fp8(float a, float b) {
+    if (CLAMP) { a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f); }
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+
 __device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float d) {
     auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
     int w = 0;
@@ -1093,19 +1101,24 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 for (int dy = 0; dy < 2; ++dy) {
                     const int opix0 = (2 * ti + dy) * (2 * TQW) + 2 * tj;
                     const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + opix0);
+                    float vv[4], xl[4];
 #pragma unroll
                     for (int dx = 0; dx < 4; ++dx) {
                         const float v = nb_h3_epilogue(out[dy][dx] * d + nz[dx], bs, p.alpha, p.gain, p.clamp) * ns;
                         const _Float16 hi = (_Float16)v;
                         obuf[(opix0 + dx) * 8 + ch] = hi;
-                        if (p.out_f8) {
-                            // the chunk's two lo slots (16 x fp8(xl 2^9), 16 x fp8(v/4)) fill up over two rounds
-                            const unsigned pk = nb_pk4_fp8((v - (float)hi) * 512.f, v * 0.25f, 0.f, 0.f);
-                            unsigned char* ob = reinterpret_cast<unsigned char*>(obuf + (size_t)OPIX * 8);
-                            ob[(opix0 + dx) * 16 + (round & 1) * 8 + ch] = (unsigned char)(pk & 0xff);
-                            ob[(OPIX + opix0 + dx) * 16 + (round & 1) * 8 + ch] = (unsigned char)((pk >> 8) & 0xff);
-                        } else {
-                            obuf[(OPIX + opix0 + dx) * 8 + ch] = (_Float16)(v - (float)hi);
+                        vv[dx] = v; xl[dx] = v - (float)hi;
+                        if (!p.out_f8) obuf[(OPIX + opix0 + dx) * 8 + ch] = (_Float16)xl[dx];
+                    }
+                    if (p.out_f8 && !(p.dbg & 32)) {
+                        // the chunk's two lo slots (16 x fp8(xl 2^9), 16 x fp8(v/4)) fill up over two rounds
+                        unsigned char* ob = reinterpret_cast<unsigned char*>(obuf + (size_t)OPIX * 8) + (size_t)opix0 * 16 + (round & 1) * 8 + ch;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const unsigned pl = nb_pk2_fp8<true>(xl[2 * q] * 512.f, xl[2 * q + 1] * 512.f);
+                            const unsigned ph = nb_pk2_fp8<true>(vv[2 * q] * 0.25f, vv[2 * q + 1] * 0.25f);
+                            ob[(2 * q) * 16] = (unsigned char)pl; ob[(2 * q + 1) * 16] = (unsigned char)(pl >> 8);
+                            ob[(size_t)OPIX * 16 + (2 * q) * 16] = (unsigned char)ph; ob[(size_t)OPIX * 16 + (2 * q + 1) * 16] = (unsigned char)(ph >> 8);
                         }
                     }
                 }

@@ -15,6 +15,7 @@ from brushstroke_engine_amd import _lib, ops  # noqa: E402
 
 
 F8 = os.environ.get("NB_PHASE_F8") == "1"
+H2OUT = os.environ.get("NB_PHASE_H2OUT") == "1"          # write the consumer's H2 / f8 tensor instead of fp32 NCHW
 
 
 def run(kind, n, ci, co, res):
@@ -34,13 +35,17 @@ def run(kind, n, ci, co, res):
     ts = torch.zeros([cap, 8], dtype=torch.int64, device="cuda")
     y = torch.empty([n, co, res, res], device="cuda")
     st = torch.cuda.current_stream().cuda_stream
+    yh2 = torch.empty(ops.h2_shape(n, co, res, res), dtype=torch.float16, device="cuda") if H2OUT else None
+    nst = torch.ones(n, co, device="cuda")
+    yp, hp, sp, cn = (None, yh2.data_ptr(), nst.data_ptr(), co) if H2OUT else (y.data_ptr(), None, None, 0)
+
     def launch():
         if kind == "up1":
-            rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(),
-                                             None, None, 0, 0, None, int(F8), 0, n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
+            rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), yp,
+                                             hp, sp, cn, cn, None, int(F8), int(F8 and H2OUT), n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
         else:
-            rc = lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(),
-                                             None, None, 0, 0, int(F8), 0, n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
+            rc = lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), yp,
+                                             hp, sp, cn, cn, int(F8), int(F8 and H2OUT), n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
         _lib.check(rc, kind)
     for _ in range(3):
         launch()
