@@ -213,9 +213,9 @@ def test_odd_channel_counts_vs_oracle(res, cmax, cbase, geom):
     z, gf, pos = synthetic.batch_z(cfg, n, 5), synthetic.geom_features(cfg, n, seed=4), synthetic.positions(cfg, n, seed=4)
     _, want = orc.OracleGenerator(cfg, sd)(z, None, gf, positions=pos, return_debug_data=True, return_features=[res // 2])
     G = Generator(cfg, sd).to("cuda")
-    for mode in ("h3", "f32"):
+    for mode, tol in (("h3", 1e-4), ("f32", 1e-4), ("f8", 3e-4)):      # f8: layers whose c_in is not a multiple of 16 stay on H2 operands
         G.set_conv_mode(mode)
         _, got = G(torch.from_numpy(z).cuda(), None, [torch.from_numpy(a).cuda() for a in gf], positions=torch.from_numpy(pos).cuda(),
                    return_debug_data=True, return_features=[res // 2], noise_mode="const")
-        assert float((got["uvs"].cpu() - want["uvs"]).abs().max()) <= 1e-4, mode
-        assert float((got[f"features{res // 2}"].cpu() - want[f"features{res // 2}"]).abs().max()) <= 5e-4, mode
+        assert float((got["uvs"].cpu() - want["uvs"]).abs().max()) <= tol, mode
+        assert float((got[f"features{res // 2}"].cpu() - want[f"features{res // 2}"]).abs().max()) <= 5 * tol, mode

@@ -8,7 +8,7 @@ from brushstroke_engine_amd.graphed import GraphedTriadRender
 dev = torch.device("cuda:0")
 for res in (256, 128):
     cfg = cfgmod.style1_config(res)
-    G = Generator(cfg, wmod.random_state_dict(cfg, 0)).to(dev)
+    G = Generator(cfg, wmod.random_state_dict(cfg, 0), conv_mode=os.environ.get("NB_MODE", "h3")).to(dev)
     for B in (1, 2, 4):
         for minb in (1, 4, 64):
             G.synthesis.h3_min_batch = minb
