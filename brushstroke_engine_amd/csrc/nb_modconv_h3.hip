@@ -1038,8 +1038,10 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int RPR = 4;                            // accumulator registers per round
     constexpr int OPIX = 4 * nquads;                  // output pixels of the tile
     _Float16* obuf = reinterpret_cast<_Float16*>(y1s + RPR * 2 * Y1_SLOT);      // H2 output: [hi/lo][OPIX][8]
+    unsigned long long te_w = 0, te_f = 0, te_s = 0, te0 = 0;     // debug: cycles in (phase write + sync), (FIR stage + sync), (store stage)
 #pragma unroll
     for (int round = 0; round < 16 / RPR; ++round) {
+        if (p.tstamps) te0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int rr = 0; rr < RPR; ++rr) {
             const int rho = round * RPR + rr;
@@ -1053,15 +1055,25 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             }
         }
         __syncthreads();
+        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_w += t_ - te0; te0 = t_; }
         // FIR + activation: one item = one channel x one row of quads x 2 adjacent quads (2 x 4 output pixels).
         // Column pairs are evaluated with packed fp32 math; the expressions keep the operand order of the reference
         // polyphase form  0.25 a + 0.75 b + 0.75 c + 0.25 d  (left to right).
         for (int it = tid; it < RPR * 2 * TQH * (TQW / 2); it += 512) {
             // lanes of a wave span the round's 8 channels x 8 quad pairs: the 2-byte H2 writes below then fall into 16
             // different LDS banks (pixel slots are 16 bytes, so one channel alone would hit only 4)
-            const int s = it % (RPR * 2);
-            const int rr_ = it / (RPR * 2);
-            const int p2 = rr_ % (TQW / 2), ti = rr_ / (TQW / 2), tj = 2 * p2;
+            // (fp32 output has no such writes: there the lanes walk the quad pairs, whose phase reads are conflict-free)
+            int s, p2, ti;
+            if (p.yh2 && !(p.dbg & 64)) {
+                s = it % (RPR * 2);
+                const int rr_ = it / (RPR * 2);
+                p2 = rr_ % (TQW / 2); ti = rr_ / (TQW / 2);
+            } else {
+                p2 = it % (TQW / 2);
+                const int rr_ = it / (TQW / 2);
+                ti = rr_ % TQH; s = rr_ / TQH;
+            }
+            const int tj = 2 * p2;
             const int rho = round * RPR + (s >> 1);
             const int col = (rho & 3) + 8 * (rho >> 2) + 4 * (s & 1);
             const int co = co0 + col;
@@ -1070,8 +1082,16 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             const float* oe = ee + 2 * Y1_PHASE;
             const float* oo = ee + 3 * Y1_PHASE;
             auto ld2 = [](const float* q) { return *reinterpret_cast<const f32x2*>(q); };
-            auto fv0 = [](auto o0, auto e0, auto o1, auto e1) { return 0.25f * o0 + 0.75f * e0 + 0.75f * o1 + 0.25f * e1; };
-            auto fv1 = [](auto e0, auto o1, auto e1, auto o2) { return 0.25f * e0 + 0.75f * o1 + 0.75f * e1 + 0.25f * o2; };
+            // 4-tap polyphase FIR 0.25 a + 0.75 b + 0.75 c + 0.25 d as one multiply + three fused multiply-adds (the
+            // reference's upfirdn2d is a convolution whose summation order and fusing are the backend's; the epilogue is
+            // VALU-bound, so the 4-instead-of-7 instructions per tap row matter)
+            auto fir4 = [](auto a, auto b, auto c, auto d) {
+                decltype(a) q75 = a, q25 = a;
+                q75 = 0.75f; q25 = 0.25f;
+                return __builtin_elementwise_fma(q25, d, __builtin_elementwise_fma(q75, c, __builtin_elementwise_fma(q75, b, 0.25f * a)));
+            };
+            auto fv0 = [&](auto o0, auto e0, auto o1, auto e1) { return fir4(o0, e0, o1, e1); };
+            auto fv1 = [&](auto e0, auto o1, auto e1, auto o2) { return fir4(e0, o1, e1, o2); };
             // even output columns come from (ee, oe) at quad columns tj..tj+2, odd ones from (eo, oo) at tj..tj+3
             const f32x2 eeA0 = ld2(ee), eeA1 = ld2(ee + PW), oeA0 = ld2(oe), oeA1 = ld2(oe + PW), oeA2 = ld2(oe + 2 * PW);
             const float eeB0 = ee[2], eeB1 = ee[PW + 2], oeB0 = oe[2], oeB1 = oe[PW + 2], oeB2 = oe[2 * PW + 2];
@@ -1088,8 +1108,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    out[dy][2 * q] = 0.25f * vo[dy][q] + 0.75f * ve[dy][q] + 0.75f * vo[dy][q + 1] + 0.25f * ve[dy][q + 1];
-                    out[dy][2 * q + 1] = 0.25f * ve[dy][q] + 0.75f * vo[dy][q + 1] + 0.75f * ve[dy][q + 1] + 0.25f * vo[dy][q + 2];
+                    out[dy][2 * q] = fir4(vo[dy][q], ve[dy][q], vo[dy][q + 1], ve[dy][q + 1]);
+                    out[dy][2 * q + 1] = fir4(ve[dy][q], vo[dy][q + 1], ve[dy][q + 1], vo[dy][q + 2]);
                 }
             const int qi = I0 + ti, qj = J0 + tj;
             const float d = s_dco[col], bs = s_bias[col];
@@ -1135,6 +1155,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             }
         }
         __syncthreads();
+        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_f += t_ - te0; te0 = t_; }
         if (p.yh2) {
             const int cg = co0 / 8 + round;
             if (cg * 8 < p.c_out && !(p.dbg & 1)) {
@@ -1164,11 +1185,13 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 }
             }
         }
+        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_s += t_ - te0; }
     }
     NB_TSTAMP(4);
     if (p.tstamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NB_TSTAMP(5);
+        if (threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 3] = (te_w & 0x1fffff) | ((te_f & 0x1fffff) << 21) | ((te_s & 0x1fffff) << 42);
     }
 }
 

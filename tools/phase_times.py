@@ -80,6 +80,12 @@ def run(kind, n, ci, co, res):
         print(f"    wave 0 inside the k-loop (shader cycles): total {loop.mean():.0f}, parked on vmcnt {dma.mean():.0f} "
               f"({dma.mean() / loop.mean() * 100:.1f}%), parked on the barrier {bar.mean():.0f} ({bar.mean() / loop.mean() * 100:.1f}%); "
               f"s_memtime ticks per us {loop.mean() / d[:, 1].mean():.0f}")
+    if kind == "up2":
+        raw3 = ts.cpu().numpy()[: t.shape[0], 3]
+        w_, f_, s_ = (raw3 & 0x1fffff).astype(np.float64), ((raw3 >> 21) & 0x1fffff).astype(np.float64), ((raw3 >> 42) & 0x1fffff).astype(np.float64)
+        tot = (w_ + f_ + s_).mean()
+        print(f"    epilogue of wave 0 (s_memtime ticks, 4 rounds): phases->LDS + sync {w_.mean():.0f} ({w_.mean() / tot * 100:.0f}%), "
+              f"FIR/activation/convert + sync {f_.mean():.0f} ({f_.mean() / tot * 100:.0f}%), slot stores {s_.mean():.0f} ({s_.mean() / tot * 100:.0f}%)")
     busy = (us[:, 5] - us[:, 0]).sum()
     print(f"    sum of workgroup times / (256 CUs x span) = {busy / (256 * us[:, 5].max()):.2f}")
 
