@@ -1060,19 +1060,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         // Column pairs are evaluated with packed fp32 math; the expressions keep the operand order of the reference
         // polyphase form  0.25 a + 0.75 b + 0.75 c + 0.25 d  (left to right).
         for (int it = tid; it < RPR * 2 * TQH * (TQW / 2); it += 512) {
-            // lanes of a wave span the round's 8 channels x 8 quad pairs: the 2-byte H2 writes below then fall into 16
-            // different LDS banks (pixel slots are 16 bytes, so one channel alone would hit only 4)
-            // (fp32 output has no such writes: there the lanes walk the quad pairs, whose phase reads are conflict-free)
-            int s, p2, ti;
-            if (p.yh2 && !(p.dbg & 64)) {
-                s = it % (RPR * 2);
-                const int rr_ = it / (RPR * 2);
-                p2 = rr_ % (TQW / 2); ti = rr_ / (TQW / 2);
-            } else {
-                p2 = it % (TQW / 2);
-                const int rr_ = it / (TQW / 2);
-                ti = rr_ % TQH; s = rr_ / TQH;
-            }
+            // lanes walk the quad pairs of one channel (conflict-free phase reads); the H2 / f8 results are staged
+            // channel-planar so that the lane's 4 consecutive pixels go out as one 8- / 4-byte LDS write
+            const int p2 = it % (TQW / 2);
+            const int rr_ = it / (TQW / 2);
+            const int ti = rr_ % TQH, s = rr_ / TQH;
             const int tj = 2 * p2;
             const int rho = round * RPR + (s >> 1);
             const int col = (rho & 3) + 8 * (rho >> 2) + 4 * (s & 1);
@@ -1114,7 +1106,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             const int qi = I0 + ti, qj = J0 + tj;
             const float d = s_dco[col], bs = s_bias[col];
             if (p.yh2) {
-                // the round's 8 channels are exactly channel group co0/8 + round: collect [hi/lo][pixel][8] slots in LDS
+                // the round's 8 channels are exactly channel group co0/8 + round.  Staging (after the phase slots):
+                //   hi plane [ch 8][OPIX] f16 | H2: lo plane [ch 8][OPIX] f16 | f8: [16][OPIX] fp8(xl 2^9), [16][OPIX] fp8(v/4)
                 const float ns = s_nst[col];
                 const int ch = col & 7;
 #pragma unroll
@@ -1122,24 +1115,20 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                     const int opix0 = (2 * ti + dy) * (2 * TQW) + 2 * tj;
                     const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + opix0);
                     float vv[4], xl[4];
+                    h4 vh, vl;
 #pragma unroll
                     for (int dx = 0; dx < 4; ++dx) {
                         const float v = nb_h3_epilogue(out[dy][dx] * d + nz[dx], bs, p.alpha, p.gain, p.clamp) * ns;
                         const _Float16 hi = (_Float16)v;
-                        obuf[(opix0 + dx) * 8 + ch] = hi;
-                        vv[dx] = v; xl[dx] = v - (float)hi;
-                        if (!p.out_f8) obuf[(OPIX + opix0 + dx) * 8 + ch] = (_Float16)xl[dx];
+                        vh[dx] = hi; vv[dx] = v; xl[dx] = v - (float)hi; vl[dx] = (_Float16)xl[dx];
                     }
-                    if (p.out_f8 && !(p.dbg & 32)) {
-                        // the chunk's two lo slots (16 x fp8(xl 2^9), 16 x fp8(v/4)) fill up over two rounds
-                        unsigned char* ob = reinterpret_cast<unsigned char*>(obuf + (size_t)OPIX * 8) + (size_t)opix0 * 16 + (round & 1) * 8 + ch;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const unsigned pl = nb_pk2_fp8<true>(xl[2 * q] * 512.f, xl[2 * q + 1] * 512.f);
-                            const unsigned ph = nb_pk2_fp8<true>(vv[2 * q] * 0.25f, vv[2 * q + 1] * 0.25f);
-                            ob[(2 * q) * 16] = (unsigned char)pl; ob[(2 * q + 1) * 16] = (unsigned char)(pl >> 8);
-                            ob[(size_t)OPIX * 16 + (2 * q) * 16] = (unsigned char)ph; ob[(size_t)OPIX * 16 + (2 * q + 1) * 16] = (unsigned char)(ph >> 8);
-                        }
+                    *reinterpret_cast<h4*>(obuf + (size_t)ch * OPIX + opix0) = vh;
+                    if (!p.out_f8) {
+                        *reinterpret_cast<h4*>(obuf + (size_t)(8 + ch) * OPIX + opix0) = vl;
+                    } else if (!(p.dbg & 32)) {
+                        unsigned char* ob = reinterpret_cast<unsigned char*>(obuf + (size_t)8 * OPIX) + (size_t)((round & 1) * 8 + ch) * OPIX + opix0;
+                        *reinterpret_cast<unsigned*>(ob) = nb_pk2_fp8<true>(xl[0] * 512.f, xl[1] * 512.f) | (nb_pk2_fp8<true>(xl[2] * 512.f, xl[3] * 512.f) << 16);
+                        *reinterpret_cast<unsigned*>(ob + (size_t)16 * OPIX) = nb_pk2_fp8<true>(vv[0] * 0.25f, vv[1] * 0.25f) | (nb_pk2_fp8<true>(vv[2] * 0.25f, vv[3] * 0.25f) << 16);
                     }
                 }
             } else if (co < p.c_out && qi < H && !(p.dbg & 1)) {
@@ -1161,25 +1150,51 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             if (cg * 8 < p.c_out && !(p.dbg & 1)) {
                 const size_t OHW8 = (size_t)Ho * Wo * 8;
                 _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
-                if (!p.out_f8) {
-                    for (int e = tid; e < 2 * OPIX; e += 512) {
-                        const int hl = e / OPIX, opix = e - hl * OPIX;
-                        const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
-                        if (oy < Ho)
-                            *reinterpret_cast<h8*>(yn + (size_t)hl * OHW8 + ((size_t)oy * Wo + ox) * 8) = *reinterpret_cast<const h8*>(obuf + (size_t)e * 8);
+                // planar staging -> 16-byte slots: a task transposes 4 consecutive pixels x 8 channels (f16) resp. x 16
+                // channels (fp8) in registers and stores the 4 slots (64 contiguous bytes per lane)
+                const int nf16 = p.out_f8 ? 1 : 2;                                  // f16 planes sets: hi (+ lo for H2)
+                for (int e = tid; e < nf16 * (OPIX / 4); e += 512) {
+                    const int k = e / (OPIX / 4), t4 = e - k * (OPIX / 4);
+                    const int opix = 4 * t4;
+                    const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
+                    if (oy < Ho) {
+                        h4 pl[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) pl[c] = *reinterpret_cast<const h4*>(obuf + (size_t)(k * 8 + c) * OPIX + opix);
+                        _Float16* dst = yn + (size_t)k * OHW8 + ((size_t)oy * Wo + ox) * 8;
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) {
+                            h8 sl8;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) sl8[c] = pl[c][px];
+                            *reinterpret_cast<h8*>(dst + px * 8) = sl8;
+                        }
                     }
-                } else {
-                    // hi slot of this round's channel group; after the chunk's second round also its two lo slots
-                    // ((cg-1, lo) = fp8(xl 2^9) of the 16 channels, (cg, lo) = fp8(v/4))
-                    const int nsl = (round & 1) ? 3 : 1;
-                    for (int e = tid; e < nsl * OPIX; e += 512) {
-                        const int k = e / OPIX, opix = e - k * OPIX;
+                }
+                if (p.out_f8 && (round & 1)) {
+                    // the chunk's two lo slots: (cg-1, lo) = fp8(xl 2^9) of its 16 channels, (cg, lo) = fp8(v/4)
+                    for (int e = tid; e < 2 * (OPIX / 4); e += 512) {
+                        const int k = e / (OPIX / 4), t4 = e - k * (OPIX / 4);
+                        const int opix = 4 * t4;
                         const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
                         if (oy < Ho) {
-                            const size_t pixo = ((size_t)oy * Wo + ox) * 8;
-                            if (k == 0) *reinterpret_cast<h8*>(yn + pixo) = *reinterpret_cast<const h8*>(obuf + (size_t)opix * 8);
-                            else if (k == 1) *reinterpret_cast<h8*>(yn - OHW8 + pixo) = *reinterpret_cast<const h8*>(obuf + (size_t)(OPIX + opix) * 8);
-                            else *reinterpret_cast<h8*>(yn + OHW8 + pixo) = *reinterpret_cast<const h8*>(obuf + (size_t)(2 * OPIX + opix) * 8);
+                            const unsigned char* src = reinterpret_cast<const unsigned char*>(obuf + (size_t)8 * OPIX) + (size_t)k * 16 * OPIX + opix;
+                            unsigned r[16];
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const unsigned*>(src + (size_t)c * OPIX);
+                            _Float16* dst = (k == 0 ? yn - OHW8 : yn + OHW8) + ((size_t)oy * Wo + ox) * 8;
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) {
+                                i32x4 sl4;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    // bytes px of r[4q .. 4q+3] -> one dword (v_perm_b32: selector bytes 0-3 pick from the 2nd operand, 4-7 from the 1st)
+                                    const unsigned lo2 = __builtin_amdgcn_perm(r[4 * q + 1], r[4 * q], 0x0c0c0400u + px * 0x0101u);
+                                    const unsigned hi2 = __builtin_amdgcn_perm(r[4 * q + 3], r[4 * q + 2], 0x0c0c0400u + px * 0x0101u);
+                                    sl4[q] = (int)((lo2 & 0xffffu) | (hi2 << 16));
+                                }
+                                *reinterpret_cast<i32x4*>(dst + px * 8) = sl4;
+                            }
                         }
                     }
                 }
