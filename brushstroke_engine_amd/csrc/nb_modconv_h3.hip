@@ -221,7 +221,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     issue_w(0, wring);
     issue_w(clampt(1), wring + WSLOTS);
     issue_w(clampt(2), wring + 2 * WSLOTS);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // step 0 needs the halo tile and sub-chunk 0 only: sub-chunks 1 and 2 may still be in flight (the loop's invariant)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
     __builtin_amdgcn_s_barrier();
     NB_TSTAMP(1);
 
