@@ -149,10 +149,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)            # a wedged collective should fail the run, not hang it
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
     from brushstroke_engine_amd.networks import Generator
