@@ -113,7 +113,7 @@ def latency_batch1(G, cfg, dev, geom, pos, iters=300):
     q = lambda a, p: round(float(np.percentile(a, p)), 4)
     return {"unit": "ms", "p50": q(ts, 50), "p99": q(ts, 99), "mean": round(float(np.mean(ts)), 4),
             "p50_incl_d2h": q(ts_d2h, 50), "p99_incl_d2h": q(ts_d2h, 99), "iters": iters,
-            "what": "batch=1 256x256 patch, hipGraph replay of the 19-launch generator step + stream sync"}
+            "what": "batch=1 256x256 patch, hipGraph replay of the whole generator step (mapping ... fused ToRGB) + stream sync"}
 
 
 def main():

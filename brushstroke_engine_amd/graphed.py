@@ -3,7 +3,8 @@
 The interactive path of the reference renders ONE patch per websocket request
 (``forger/ui/util.py:175-195`` -> ``PaintingHelper.render_stroke``), where ~100 tiny launches per patch
 make it launch-latency bound.  Here the whole step -- mapping, styles, noise, 15 fused conv
-launches, fused ToRGB + compositing -- is 19 launches, captured once into a hipGraph (static shapes;
+launches (the >= 128x128 layers on the split-f16 kernels, the small ones on the fp32 split-K kernels), ToRGB +
+compositing fused into the last one -- is about 20 launches, captured once into a hipGraph (static shapes;
 z / ws, geometry features, positions and user colors are graph inputs that are overwritten in place)
 and replayed with a single ``hipGraphLaunch``.
 """

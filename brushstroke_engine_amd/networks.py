@@ -241,8 +241,13 @@ class SynthesisNetwork(torch.nn.Module):
         # "h3": large conv1 layers on the f16 matrix cores as hi/lo split products (fp32-grade, ~5x the fp32 MFMA
         # rate); "f32": every layer on the exact-fp32 MFMA kernels.
         self.conv_mode = "h3"
-        self.h3_min_batch = 2             # batch 1: the fp32 path is as fast (R=256) or faster (R=128), measured with tools/latency_b1.py
+        # a layer takes the split-f16 kernels when it has enough output pixels to fill the chip with their (large)
+        # workgroups: below ~64 workgroups the fp32 kernels (smaller tiles, split-K) have the lower latency
+        # (tools/layers_b1.py: at batch 1 the >= 128x128 layers gain 25-65 %, the <= 64x64 layers lose 40-100 %)
+        self.h3_min_pixels = 128 * 128
+        self.h3_min_batch = 1
         self._h3_batch_ok = True
+        self._n = 1
         self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
         self.fuse_torgb = True            # last conv1 + ToRGB + compositing in one launch (split-f16 path)
         self.layer_kernels: Dict[str, str] = {}
@@ -283,11 +288,12 @@ class SynthesisNetwork(torch.nn.Module):
         """conv1 layers that run as 3-pass split-f16 MFMA (csrc/nb_modconv_h3.hip): the kernel needs rows of 32
         pixels and 16-row tiles, and a conv_clamp so that activations are bounded inside the f16 range."""
         return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 1 and s.block_res >= 32
-                and s.block_res % 32 == 0 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
+                and self._n * s.block_res ** 2 >= self.h3_min_pixels and s.block_res % 32 == 0 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _h3_up2_eligible(self, s: LayerSpec) -> bool:
         """conv0 (up=2) layers that run on the split-f16 4-phase kernel: input rows must be multiples of 32 pixels."""
         return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 2 and s.in_res >= 32 and s.in_res % 32 == 0
+                and self._n * s.block_res ** 2 >= self.h3_min_pixels
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _operand_fmt(self, s: Optional[LayerSpec]) -> int:
@@ -359,6 +365,7 @@ class SynthesisNetwork(torch.nn.Module):
         ws = ws.to(torch.float32).contiguous()
         n = ws.shape[0]
         self._h3_batch_ok = n >= self.h3_min_batch
+        self._n = n
         plan = self._get_plan(n, device, plan_slot)
         lib = _lib.lib()
         geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
