@@ -51,7 +51,7 @@ def kernel_label(spec):
     return f"modconv3x3_up{spec.up}[{spec.in_channels}->{spec.out_channels}@{spec.block_res}]"
 
 
-def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16):
+def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16, G=None, dev=None):
     """The CPU oracle (oracle/neube_oracle.py, a port of the reference path onto plain torch CPU ops, fused
     modulated conv = the reference's eval-mode fp32 default) timed on this box's host cores.  Bounded
     sample: `n_sample` patches per pass, repeated until ~seconds_budget of CPU time is spent.  16 threads:
@@ -69,11 +69,15 @@ def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16):
     geom = synthetic.geom_features(cfg, n_sample, seed=0)
     pos = synthetic.positions(cfg, n_sample, seed=0)
 
+    last = {}
+
     def one():
         img, dbg = O(z, None, geom, positions=pos, return_debug_data=True)
-        return orc.rgba_to_uint8(orc.triad_composite(dbg["uvs"], dbg["colors"], "clear"))
+        last["rgba"] = orc.triad_composite(dbg["uvs"], dbg["colors"], "clear")
+        last["uvs"] = dbg["uvs"]
+        return orc.rgba_to_uint8(last["rgba"])
 
-    one()                                   # warm-up (thread pool, allocator)
+    u8_ref = one()                          # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
     reps = 0
     while True:
@@ -82,10 +86,23 @@ def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16):
         el = time.perf_counter() - t0
         if el >= seconds_budget or reps >= 50:
             break
-    return {"value": round(reps * n_sample / el, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} passes of batch {n_sample} at {cfg.img_resolution}x{cfg.img_resolution} "
-                      f"(oracle = torch-CPU port of the reference generator + compositing, fp32, {el:.1f} s, "
-                      f"{torch.get_num_threads()} of {avail} host CPUs)"}
+    out = {"value": round(reps * n_sample / el, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{reps} passes of batch {n_sample} at {cfg.img_resolution}x{cfg.img_resolution} "
+                     f"(oracle = torch-CPU port of the reference generator + compositing, fp32, {el:.1f} s, "
+                     f"{torch.get_num_threads()} of {avail} host CPUs)"}
+    if G is not None:
+        # the oracle as the checker: the same sample through the benchmarked HIP generator (same conv mode), compared
+        # with the oracle's fp32 result at the full 256x256 size
+        u8, rgba, dbg = G.render_triad(z=torch.from_numpy(z).to(dev), geom_feature=[torch.from_numpy(g).to(dev) for g in geom],
+                                       positions=torch.from_numpy(pos).to(dev), render_mode="clear", want_f32=True)
+        torch.cuda.synchronize()
+        to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+        out["parity"] = {"max_abs_rgba_vs_oracle": float(np.abs(to_np(rgba) - to_np(last["rgba"])).max()),
+                         "max_abs_uvs_vs_oracle": float(np.abs(to_np(dbg["uvs"]) - to_np(last["uvs"])).max()),
+                         "max_u8_diff": int(np.abs(to_np(u8).astype(np.int32) - to_np(u8_ref).transpose(0, 2, 3, 1).astype(np.int32)).max()),
+                         "tolerance": 1e-3, "patches": n_sample,
+                         "what": "HIP generator (the benchmarked conv mode) vs the fp32 CPU oracle on the cpu_baseline sample"}
+    return out
 
 
 def latency_batch1(G, cfg, dev, geom, pos, iters=300):
@@ -414,7 +431,7 @@ def main():
         if world == 1 and not args.no_latency:
             out["latency_batch1"] = latency_batch1(G, cfg, dev, geom, pos)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, G=G, dev=dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
