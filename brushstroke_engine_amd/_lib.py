@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None
@@ -43,6 +43,8 @@ PROTOTYPES = {
     "nb_last_error": (C.c_char_p, []),
     "nb_abi_version": (C.c_int, []),
     "nb_bias_act_f32": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
+    "nb_bias_act_grad_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       C.c_float, C.c_float, vp]),
     "nb_upfirdn2d_f32": (C.c_int, [vp, vp, vp] + [C.c_int] * 14 + [C.c_float, vp]),
     "nb_mapping_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_styles_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),

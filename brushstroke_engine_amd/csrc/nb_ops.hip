@@ -22,63 +22,138 @@ extern "C" int nb_abi_version(void) { return NB_ABI_VERSION; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-// bias_act  (reference: torch_utils/ops/bias_act.cu:23-147, forward, fp32)
+// bias_act  (reference: torch_utils/ops/bias_act.cu:23-147; forward and the two gradient modes, fp32)
+//   grad 0: y = clamp(act(x + b) * gain)
+//   grad 1: x carries the incoming gradient; y = x * act'(.) * gain, zero where the forward clamped
+//   grad 2: x carries the gradient w.r.t. the grad-1 output, dy the original gradient;
+//           y = x * dy * act''(.) * gain, zero where the forward clamped
+//   act' / act'' are expressed through yref (= forward output, divided by gain) for every activation but
+//   swish, which needs xref (+ b) instead - exactly the tensors the reference saves (bias_act.py:22-32 `ref`).
+// HBM-bound streaming kernels: 16-byte accesses when sizes / alignment / bias step allow.
 // ------------------------------------------------------------------------------------------------
+#define NB_SELU_SCALE 1.0507009873554804934193349852946f
+#define NB_SELU_ALPHA 1.6732632423543772848170429916717f
+
 __device__ __forceinline__ float nb_act(float x, int act, float alpha) {
     switch (act) {
         case NB_ACT_RELU: return x > 0.f ? x : 0.f;
         case NB_ACT_LRELU: return x > 0.f ? x : x * alpha;
         case NB_ACT_TANH: return tanhf(x);
         case NB_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        case NB_ACT_ELU: return x >= 0.f ? x : expm1f(x);
+        case NB_ACT_SELU: return x >= 0.f ? NB_SELU_SCALE * x : (NB_SELU_SCALE * NB_SELU_ALPHA) * expm1f(x);
+        case NB_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+        case NB_ACT_SWISH: return x / (1.f + expf(-x));
         default: return x;
     }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
-                                                       float* __restrict__ y, long long size_x, int size_b,
-                                                       int step_b, int act, float alpha, float gain, float clamp) {
+// one element of the gradient modes: g = incoming gradient, yy = forward output / gain, xr = xref + b
+template <int G>
+__device__ __forceinline__ float nb_act_grad(float g, float yy, float xr, int act, float alpha) {
+    switch (act) {
+        case NB_ACT_LINEAR: return G == 1 ? g : 0.f;
+        case NB_ACT_RELU: return G == 1 ? (yy > 0.f ? g : 0.f) : 0.f;
+        case NB_ACT_LRELU: return G == 1 ? (yy > 0.f ? g : g * alpha) : 0.f;
+        case NB_ACT_TANH: { const float d = g * (1.f - yy * yy); return G == 1 ? d : d * (-2.f * yy); }
+        case NB_ACT_SIGMOID: { const float d = g * yy * (1.f - yy); return G == 1 ? d : d * (1.f - 2.f * yy); }
+        case NB_ACT_ELU: return yy >= 0.f ? (G == 1 ? g : 0.f) : g * (yy + 1.f);
+        case NB_ACT_SELU: return yy >= 0.f ? (G == 1 ? g * NB_SELU_SCALE : 0.f) : g * (yy + NB_SELU_SCALE * NB_SELU_ALPHA);
+        case NB_ACT_SOFTPLUS: { const float c = expf(-yy); return G == 1 ? g * (1.f - c) : g * c * (1.f - c); }
+        case NB_ACT_SWISH: {
+            if (xr > 40.f) return G == 1 ? g : 0.f;
+            const float c = expf(xr), d = c + 1.f;
+            return G == 1 ? g * c * (xr + d) / (d * d) : g * c * (xr * (2.f - d) + 2.f * d) / (d * d * d);
+        }
+        default: return 0.f;
+    }
+}
+
+struct BiasActParams {
+    const float* x; const float* b; const float* xref; const float* yref; const float* dy; float* y;
+    long long size_x; int size_b, step_b, act; float alpha, gain, clamp;
+};
+
+template <int G>
+__device__ __forceinline__ float nb_bias_act_elem(const BiasActParams& p, float x, float bb, float xref, float yref, float dy) {
+    float y;
+    if (G == 0) {
+        y = nb_act(x + bb, p.act, p.alpha) * p.gain;
+        if (p.clamp >= 0.f) y = fminf(fmaxf(y, -p.clamp), p.clamp);
+        return y;
+    }
+    const float xr = xref + bb;
+    const float yy = p.gain != 0.f ? yref / p.gain : 0.f;
+    y = nb_act_grad<G>(x, yy, xr, p.act, p.alpha) * (p.gain * dy);
+    if (p.clamp >= 0.f) {
+        // where did the forward clamp?  swish saves x, not y: recompute its forward output
+        const float yf = p.act == NB_ACT_SWISH ? nb_act(xr, NB_ACT_SWISH, 0.f) * p.gain : yref;
+        if (!(yf > -p.clamp && yf < p.clamp)) y = 0.f;
+    }
+    return y;
+}
+
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     if (VEC) {
-        const long long n4 = size_x >> 2;
+        const long long n4 = p.size_x >> 2;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-            f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-            const float bb = size_b ? b[((i << 2) / step_b) % size_b] : 0.f;   // step_b % 4 == 0: one bias per vector
+            f32x4 v = reinterpret_cast<const f32x4*>(p.x)[i];
+            f32x4 xr = {0.f, 0.f, 0.f, 0.f}, yr = xr, dv = {1.f, 1.f, 1.f, 1.f};
+            if (G > 0 && p.xref) xr = reinterpret_cast<const f32x4*>(p.xref)[i];
+            if (G > 0 && p.yref) yr = reinterpret_cast<const f32x4*>(p.yref)[i];
+            if (G > 0 && p.dy) dv = reinterpret_cast<const f32x4*>(p.dy)[i];
+            const float bb = p.size_b ? p.b[((i << 2) / p.step_b) % p.size_b] : 0.f;   // step_b % 4 == 0: one bias per vector
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = nb_act(v[j] + bb, act, alpha) * gain;
-                if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
-                v[j] = t;
-            }
-            reinterpret_cast<f32x4*>(y)[i] = v;
+            for (int j = 0; j < 4; ++j) v[j] = nb_bias_act_elem<G>(p, v[j], bb, xr[j], yr[j], dv[j]);
+            reinterpret_cast<f32x4*>(p.y)[i] = v;
         }
     } else {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < size_x; i += stride) {
-            const float bb = size_b ? b[(i / step_b) % size_b] : 0.f;
-            float t = nb_act(x[i] + bb, act, alpha) * gain;
-            if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
-            y[i] = t;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.size_x; i += stride) {
+            const float bb = p.size_b ? p.b[(i / p.step_b) % p.size_b] : 0.f;
+            p.y[i] = nb_bias_act_elem<G>(p, p.x[i], bb, (G > 0 && p.xref) ? p.xref[i] : 0.f,
+                                         (G > 0 && p.yref) ? p.yref[i] : 0.f, (G > 0 && p.dy) ? p.dy[i] : 1.f);
         }
     }
 }
 
-extern "C" int nb_bias_act_f32(const float* x, const float* b, float* y, int64_t size_x, int size_b, int step_b,
-                               int act, float alpha, float gain, float clamp, void* stream) {
+extern "C" int nb_bias_act_grad_f32(const float* x, const float* b, const float* xref, const float* yref, const float* dy,
+                                    float* y, int64_t size_x, int size_b, int step_b, int grad, int act, float alpha,
+                                    float gain, float clamp, void* stream) {
     NB_REQUIRE(x && y, "bias_act: null pointer");
     NB_REQUIRE(size_x >= 0, "bias_act: negative size");
     NB_REQUIRE(size_b == 0 || (b && step_b >= 1), "bias_act: bias given without a valid step");
-    NB_REQUIRE(act >= NB_ACT_LINEAR && act <= NB_ACT_SIGMOID, "bias_act: unsupported activation %d", act);
+    NB_REQUIRE(act >= NB_ACT_LINEAR && act <= NB_ACT_SWISH, "bias_act: unsupported activation %d", act);
+    NB_REQUIRE(grad >= 0 && grad <= 2, "bias_act: grad must be 0, 1 or 2");
+    if (grad > 0) {
+        const bool needs_x = act == NB_ACT_SWISH;
+        const bool needs_y = !needs_x && (act != NB_ACT_LINEAR || clamp >= 0.f);
+        NB_REQUIRE(!needs_x || xref, "bias_act: grad >= 1 of swish needs xref");
+        NB_REQUIRE(!needs_y || yref, "bias_act: grad >= 1 of this activation / clamp needs yref");
+    }
     if (size_x == 0) return NB_OK;
-    const bool vec = (size_x % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0) && (size_b == 0 || step_b % 4 == 0);
+    uintptr_t al = (uintptr_t)x | (uintptr_t)y;
+    if (grad > 0) al |= (uintptr_t)xref | (uintptr_t)yref | (uintptr_t)dy;          // null pointers do not disturb the test
+    const bool vec = (size_x % 4 == 0) && (al % 16 == 0) && (size_b == 0 || step_b % 4 == 0);
     const long long work = vec ? size_x / 4 : size_x;
     int grid = (int)((work + 255) / 256);
     if (grid > 2048 * 4) grid = 2048 * 4;
-    if (vec)
-        hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, b, y, (long long)size_x, size_b, step_b, act, alpha, gain, clamp);
-    else
-        hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, b, y, (long long)size_x, size_b, step_b, act, alpha, gain, clamp);
+    BiasActParams p;
+    p.x = x; p.b = size_b ? b : nullptr; p.xref = xref; p.yref = yref; p.dy = dy; p.y = y; p.size_x = size_x;
+    p.size_b = size_b; p.step_b = step_b; p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    hipStream_t st = (hipStream_t)stream;
+#define NB_BA_LAUNCH(G) do { if (vec) hipLaunchKernelGGL((bias_act_kernel<G, true>), dim3(grid), dim3(256), 0, st, p); \
+                             else hipLaunchKernelGGL((bias_act_kernel<G, false>), dim3(grid), dim3(256), 0, st, p); } while (0)
+    if (grad == 0) NB_BA_LAUNCH(0); else if (grad == 1) NB_BA_LAUNCH(1); else NB_BA_LAUNCH(2);
+#undef NB_BA_LAUNCH
     NB_CHECK_LAUNCH("bias_act");
     return NB_OK;
+}
+
+extern "C" int nb_bias_act_f32(const float* x, const float* b, float* y, int64_t size_x, int size_b, int step_b,
+                               int act, float alpha, float gain, float clamp, void* stream) {
+    return nb_bias_act_grad_f32(x, b, nullptr, nullptr, nullptr, y, size_x, size_b, step_b, 0, act, alpha, gain, clamp, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

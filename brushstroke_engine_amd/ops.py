@@ -2,7 +2,8 @@
 
 Same function names, argument meaning and error behaviour as the reference ops
 (``bias_act.bias_act``, ``upfirdn2d.upfirdn2d`` / ``setup_filter``, ``networks.modulated_conv2d``),
-forward only, fp32, device tensors only.  Every function launches hand-written gfx950 kernels
+fp32, device tensors only; ``bias_act`` and ``upfirdn2d`` also carry the reference's gradients (first and second
+order, as autograd Functions whose every evaluation is a HIP launch), the rest is forward only.  Every function launches hand-written gfx950 kernels
 through :mod:`brushstroke_engine_amd._lib` on torch's current HIP stream; nothing here computes on
 the CPU or falls back to torch ops.
 """
@@ -16,9 +17,20 @@ import torch
 
 from . import _lib
 
-ACT_CODES = {"linear": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5}   # = cuda_idx, bias_act.py:22-32
-ACT_DEFAULTS = {"linear": (0.0, 1.0), "relu": (0.0, math.sqrt(2)), "lrelu": (0.2, math.sqrt(2)),
-                "tanh": (0.0, 1.0), "sigmoid": (0.0, 1.0)}
+# name -> (cuda_idx, default alpha, default gain, tensors the gradient needs, has a 2nd-order term); bias_act.py:22-32
+ACT_SPECS = {
+    "linear":   (1, 0.0, 1.0, "", False),
+    "relu":     (2, 0.0, math.sqrt(2), "y", False),
+    "lrelu":    (3, 0.2, math.sqrt(2), "y", False),
+    "tanh":     (4, 0.0, 1.0, "y", True),
+    "sigmoid":  (5, 0.0, 1.0, "y", True),
+    "elu":      (6, 0.0, 1.0, "y", True),
+    "selu":     (7, 0.0, 1.0, "y", True),
+    "softplus": (8, 0.0, 1.0, "y", True),
+    "swish":    (9, 0.0, math.sqrt(2), "x", True),
+}
+ACT_CODES = {k: v[0] for k, v in ACT_SPECS.items()}
+ACT_DEFAULTS = {k: (v[1], v[2]) for k, v in ACT_SPECS.items()}
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -38,41 +50,107 @@ def _dev(x: torch.Tensor, name: str) -> None:
         raise RuntimeError(f"{name} must be float32 (got {x.dtype})")
 
 
+def _bias_act_launch(x, b, xref, yref, dy, grad, dim, cfg):
+    """One launch of the plugin entry ``bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)``
+    (bias_act.cpp:32) on contiguous fp32 device tensors."""
+    act, alpha, gain, clamp = cfg
+    size_b, step_b = (b.shape[0], x.stride(dim)) if b is not None else (0, 1)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nb_bias_act_grad_f32(_p(x), _p(b), _p(xref), _p(yref), _p(dy), _p(y), x.numel(), size_b, step_b,
+                                                   grad, ACT_CODES[act], alpha, gain, clamp, _stream(x)), "bias_act")
+    return y
+
+
+class _BiasActGrad(torch.autograd.Function):
+    """dx = dy * act'(x + b) * gain (clamped region zeroed); differentiable once more
+    (``BiasActCudaGrad``, bias_act.py:173-204)."""
+
+    @staticmethod
+    def forward(ctx, dy, x, b, y, dim, cfg):
+        dy = dy.contiguous()
+        ctx.dim, ctx.cfg = dim, cfg
+        ctx.save_for_backward(dy if ACT_SPECS[cfg[0]][4] else None, x, b, y)
+        return _bias_act_launch(dy, b, x, y, None, 1, dim, cfg)
+
+    @staticmethod
+    def backward(ctx, d_dx):
+        d_dx = d_dx.contiguous()
+        dy, x, b, y = ctx.saved_tensors
+        dim, cfg = ctx.dim, ctx.cfg
+        d_dy = d_x = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_dy = _BiasActGrad.apply(d_dx, x, b, y, dim, cfg)
+        if ACT_SPECS[cfg[0]][4] and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            d_x = _bias_act_launch(d_dx, b, x, y, dy, 2, dim, cfg)
+            if ctx.needs_input_grad[2]:
+                d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+        return d_dy, d_x, d_b, None, None, None
+
+
+class _BiasAct(torch.autograd.Function):
+    """``BiasActCuda`` (bias_act.py:145-171): saves x/b only when the gradient formula needs them."""
+
+    @staticmethod
+    def forward(ctx, x, b, dim, cfg):
+        y = _bias_act_launch(x, b, None, None, None, 0, dim, cfg)
+        ref, second = ACT_SPECS[cfg[0]][3], ACT_SPECS[cfg[0]][4]
+        keep_x = "x" in ref or second
+        ctx.dim, ctx.cfg = dim, cfg
+        ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if "y" in ref or cfg[3] >= 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, b, y = ctx.saved_tensors
+        dim, (act, alpha, gain, clamp) = ctx.dim, ctx.cfg
+        dx = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx = dy
+            if act != "linear" or gain != 1 or clamp >= 0:
+                dx = _BiasActGrad.apply(dy, x, b, y, dim, ctx.cfg)
+        if ctx.needs_input_grad[1]:
+            db = dx.sum([i for i in range(dx.ndim) if i != dim])
+        return dx, db, None, None
+
+
 def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None):
-    """Fused bias + activation + gain + clamp.  Mirrors ``bias_act.bias_act`` (bias_act.py:55-89)."""
+    """Fused bias + activation + gain + clamp with gradients of first and second order.
+    Mirrors ``bias_act.bias_act`` (bias_act.py:55-89) and its autograd functions (:145-204): every
+    evaluation - forward, d/dx, d2/dx2 - is one launch of the HIP kernel."""
     _dev(x, "x")
     if act not in ACT_CODES:
         raise AssertionError(f"unknown activation {act!r}")
     assert clamp is None or clamp >= 0
     d_alpha, d_gain = ACT_DEFAULTS[act]
-    alpha = float(d_alpha if alpha is None else alpha)
-    gain = float(d_gain if gain is None else gain)
-    clamp = float(-1 if clamp is None else clamp)
+    cfg = (act, float(d_alpha if alpha is None else alpha), float(d_gain if gain is None else gain),
+           float(-1 if clamp is None else clamp))
     x = x.contiguous()
-    size_b, step_b = 0, 1
     if b is not None:
         _dev(b, "b")
         assert b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]
         b = b.contiguous()
-        size_b, step_b = b.shape[0], x.stride(dim)
-    y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().nb_bias_act_f32(_p(x), _p(b), _p(y), x.numel(), size_b, step_b, ACT_CODES[act], alpha,
-                                              gain, clamp, _stream(x)), "bias_act")
-    return y
+    if torch.is_grad_enabled() and (x.requires_grad or (b is not None and b.requires_grad)):
+        return _BiasAct.apply(x, b, dim, cfg)
+    return _bias_act_launch(x, b, None, None, None, 0, dim, cfg)
 
 
-def setup_filter(f: Sequence[float] = (1, 3, 3, 1), device=None, normalize=True, flip_filter=False, gain=1):
-    """``upfirdn2d.setup_filter`` (upfirdn2d.py:72-116) for tap lists shorter than 8 (non-separable 2-D)."""
-    f = torch.as_tensor(f, dtype=torch.float32)
-    assert f.ndim in (1, 2) and f.numel() > 0
-    if f.ndim == 1:
-        assert f.numel() < 8, "separable filters are not used on the generator path"
+def setup_filter(f: Sequence[float] = (1, 3, 3, 1), device=None, normalize=True, flip_filter=False, gain=1, separable=None):
+    """``upfirdn2d.setup_filter`` (upfirdn2d.py:72-116): tap lists shorter than 8 become a 2-D outer product,
+    longer ones stay 1-D (separable) unless ``separable`` says otherwise."""
+    f = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    assert f.ndim in (0, 1, 2) and f.numel() > 0
+    if f.ndim == 0:
+        f = f[None]
+    if separable is None:
+        separable = f.ndim == 1 and f.numel() >= 8
+    if f.ndim == 1 and not separable:
         f = f.ger(f)
+    assert f.ndim == (1 if separable else 2)
     if normalize:
         f = f / f.sum()
     if flip_filter:
-        f = f.flip([0, 1])
+        f = f.flip(list(range(f.ndim)))
     f = f * (gain ** (f.ndim / 2))
     return f.to(device=device) if device is not None else f
 
@@ -87,29 +165,118 @@ def _parse_padding(padding):
     return padding
 
 
+def _parse_scaling(s):
+    if isinstance(s, int):
+        s = [s, s]
+    assert isinstance(s, (list, tuple)) and all(isinstance(v, int) for v in s)
+    sx, sy = s
+    assert sx >= 1 and sy >= 1
+    return sx, sy
+
+
+def _upfirdn2d_launch(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain):
+    """One launch of the plugin entry ``upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1,
+    flip, gain)`` (upfirdn2d.cpp:16) on a contiguous NCHW fp32 tensor."""
+    n, c, h, w = x.shape
+    fh, fw = f2d.shape
+    ow = (w * upx + px0 + px1 - fw + downx) // downx
+    oh = (h * upy + py0 + py1 - fh + downy) // downy
+    x = x.contiguous()
+    f2d = f2d.contiguous()
+    y = torch.empty([n, c, max(oh, 0), max(ow, 0)], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nb_upfirdn2d_f32(_p(x), _p(f2d), _p(y), n * c, h, w, fh, fw, upx, upy, downx, downy,
+                                               px0, px1, py0, py1, int(bool(flip)), float(gain), _stream(x)),
+                   "upfirdn2d")
+    return y
+
+
+def _upfirdn2d_apply(x, f, cfg):
+    upx, upy, downx, downy, px0, px1, py0, py1, flip, gain = cfg
+    if f.ndim == 2:
+        return _upfirdn2d_launch(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain)
+    # separable taps: a row pass then a column pass, sqrt(gain) each (upfirdn2d.py:234-236)
+    y = _upfirdn2d_launch(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip, math.sqrt(gain))
+    return _upfirdn2d_launch(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip, math.sqrt(gain))
+
+
+class _Upfirdn2d(torch.autograd.Function):
+    """``Upfirdn2dCuda`` (upfirdn2d.py:223-264): the gradient w.r.t. x is another upfirdn2d with up and down
+    swapped, the filter flipped the other way and padding that maps the output grid back onto the input;
+    differentiable to any order because the backward is the same Function.  No gradient w.r.t. f."""
+
+    @staticmethod
+    def forward(ctx, x, f, cfg):
+        ctx.cfg, ctx.x_shape = cfg, x.shape
+        ctx.save_for_backward(f)
+        return _upfirdn2d_apply(x, f, cfg)
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, = ctx.saved_tensors
+        upx, upy, downx, downy, px0, px1, py0, py1, flip, gain = ctx.cfg
+        _, _, ih, iw = ctx.x_shape
+        _, _, oh, ow = dy.shape
+        fw, fh = f.shape[-1], f.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            back = (downx, downy, upx, upy,
+                    fw - px0 - 1, iw * upx - ow * downx + px0 - upx + 1,
+                    fh - py0 - 1, ih * upy - oh * downy + py0 - upy + 1, not flip, gain)
+            dx = _Upfirdn2d.apply(dy.contiguous(), f, back)
+        assert not ctx.needs_input_grad[1], "upfirdn2d has no gradient with respect to the filter"
+        return dx, None, None
+
+
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
-    """Pad, upsample, FIR-filter, downsample.  Mirrors ``upfirdn2d.upfirdn2d`` (upfirdn2d.py:120-164)."""
+    """Pad, upsample, FIR-filter, downsample, with gradients of any order w.r.t. x.  Mirrors
+    ``upfirdn2d.upfirdn2d`` (upfirdn2d.py:120-164): ``f`` is [fh, fw] (non-separable), [taps] (separable) or None."""
     _dev(x, "x")
     assert x.ndim == 4
     if f is None:
         f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
     _dev(f, "f")
-    assert f.ndim == 2, "f must be rank 2"
-    upx, upy = (up, up) if isinstance(up, int) else up
-    downx, downy = (down, down) if isinstance(down, int) else down
+    assert f.ndim in (1, 2), "f must be rank 1 or 2"
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
     px0, px1, py0, py1 = _parse_padding(padding)
-    n, c, h, w = x.shape
-    fh, fw = f.shape
-    ow = (w * upx + px0 + px1 - fw + downx) // downx
-    oh = (h * upy + py0 + py1 - fh + downy) // downy
-    x = x.contiguous()
-    f = f.contiguous()
-    y = torch.empty([n, c, max(oh, 0), max(ow, 0)], dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().nb_upfirdn2d_f32(_p(x), _p(f), _p(y), n * c, h, w, fh, fw, upx, upy, downx, downy,
-                                               px0, px1, py0, py1, int(bool(flip_filter)), float(gain), _stream(x)),
-                   "upfirdn2d")
-    return y
+    cfg = (upx, upy, downx, downy, px0, px1, py0, py1, bool(flip_filter), float(gain))
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _Upfirdn2d.apply(x, f, cfg)
+    return _upfirdn2d_apply(x, f, cfg)
+
+
+def _filter_size(f):
+    if f is None:
+        return 1, 1
+    assert isinstance(f, torch.Tensor) and f.ndim in (1, 2)
+    return int(f.shape[-1]), int(f.shape[0])
+
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1):
+    """``upfirdn2d.filter2d`` (upfirdn2d.py:268-301): FIR filter, output padded to the input's shape."""
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _filter_size(f)
+    p = [px0 + fw // 2, px1 + (fw - 1) // 2, py0 + fh // 2, py1 + (fh - 1) // 2]
+    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain)
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1):
+    """``upfirdn2d.upsample2d`` (upfirdn2d.py:305-340): output is ``up`` times the input, gain scaled by up_x*up_y."""
+    upx, upy = _parse_scaling(up)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _filter_size(f)
+    p = [px0 + (fw + upx - 1) // 2, px1 + (fw - upx) // 2, py0 + (fh + upy - 1) // 2, py1 + (fh - upy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy)
+
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1):
+    """``upfirdn2d.downsample2d`` (upfirdn2d.py:344-379): output is the input divided by ``down``."""
+    downx, downy = _parse_scaling(down)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _filter_size(f)
+    p = [px0 + (fw - downx + 1) // 2, px1 + (fw - downx) // 2, py0 + (fh - downy + 1) // 2, py1 + (fh - downy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain)
 
 
 def pack_conv_weight(weight: torch.Tensor):

@@ -41,6 +41,10 @@ extern "C" {
 #define NB_ACT_LRELU   3
 #define NB_ACT_TANH    4
 #define NB_ACT_SIGMOID 5
+#define NB_ACT_ELU      6
+#define NB_ACT_SELU     7
+#define NB_ACT_SOFTPLUS 8
+#define NB_ACT_SWISH    9
 
 const char* nb_last_error(void);
 int nb_abi_version(void);
@@ -51,6 +55,19 @@ int nb_abi_version(void);
  * bias_act.cpp:32-91.  size_b = 0 -> no bias.  clamp < 0 -> no clamping.  x and y may alias. */
 int nb_bias_act_f32(const float* x, const float* b, float* y, int64_t size_x, int size_b, int step_b,
                     int act, float alpha, float gain, float clamp, void* stream);
+
+/* The plugin's full entry (bias_act.cpp:32 `bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)`,
+ * kernel bias_act.cu:23-147) with the gradient modes the reference's autograd functions call
+ * (bias_act.py:155-204):
+ *   grad 0: forward as above (xref, yref, dy ignored).
+ *   grad 1: x = incoming gradient, returns x * act'(.) * gain, zero where the forward output was clamped.
+ *   grad 2: x = gradient w.r.t. the grad-1 result, dy = the original incoming gradient; returns
+ *           x * dy * act''(.) * gain (identically zero for linear / relu / lrelu).
+ * yref = the forward output (needed by every activation but linear-without-clamp and swish),
+ * xref = the forward input, bias not yet added (needed by swish only); unused ones may be NULL. */
+int nb_bias_act_grad_f32(const float* x, const float* b, const float* xref, const float* yref, const float* dy,
+                         float* y, int64_t size_x, int size_b, int step_b, int grad, int act, float alpha,
+                         float gain, float clamp, void* stream);
 
 /* upfirdn2d.cpp:16-94 forward on a contiguous [major, in_h, in_w] stack of planes (major = N*C):
  * zero-insert by (upx,upy), pad/crop, correlate with f[f_h,f_w] (flipped unless `flip`), scale by

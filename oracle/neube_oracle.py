@@ -43,11 +43,16 @@ def _t(a, dtype):
 def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None):
     """``SG/torch_utils/ops/bias_act.py:93-123`` (_bias_act_ref): +bias -> act -> *gain -> clamp.
 
-    Defaults per ``activation_funcs`` (bias_act.py:22-32): linear(gain 1), lrelu(alpha .2, gain sqrt2),
-    tanh(gain 1).  Native twin: ``bias_act.cu:23-147`` (same order, fp32 internal).
+    Defaults per ``activation_funcs`` (bias_act.py:22-32).  Native twin: ``bias_act.cu:23-147`` (same order,
+    fp32 internal).  Plain torch ops, so torch.autograd supplies the first- and second-order gradients the
+    reference's ``BiasActCuda`` / ``BiasActCudaGrad`` (bias_act.py:145-204) compute in closed form.
+    (One deliberate difference from the reference's *CUDA* gradient: for act='linear' with a clamp the CUDA
+    path passes no ``yref`` and so never masks the clamped region, bias_act.py:165 + bias_act.cu:137-138; the
+    ``_ref`` path - followed here and by the golden vectors - does mask it.)
     """
     spec = {"linear": (0.0, 1.0), "relu": (0.0, SQRT2), "lrelu": (0.2, SQRT2), "tanh": (0.0, 1.0),
-            "sigmoid": (0.0, 1.0)}[act]
+            "sigmoid": (0.0, 1.0), "elu": (0.0, 1.0), "selu": (0.0, 1.0), "softplus": (0.0, 1.0),
+            "swish": (0.0, SQRT2)}[act]
     alpha = float(spec[0] if alpha is None else alpha)
     gain = float(spec[1] if gain is None else gain)
     clamp = float(-1 if clamp is None else clamp)
@@ -62,6 +67,14 @@ def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None):
         x = torch.tanh(x)
     elif act == "sigmoid":
         x = torch.sigmoid(x)
+    elif act == "elu":
+        x = F.elu(x)
+    elif act == "selu":
+        x = F.selu(x)
+    elif act == "softplus":
+        x = F.softplus(x)
+    elif act == "swish":
+        x = torch.sigmoid(x) * x
     if gain != 1:
         x = x * gain
     if clamp >= 0:
@@ -80,22 +93,30 @@ def setup_filter(taps: Sequence[float] = (1, 3, 3, 1), dtype=torch.float32):
 def upfirdn2d(x, f, up=1, down=1, padding=(0, 0, 0, 0), flip_filter=False, gain=1.0):
     """``SG/torch_utils/ops/upfirdn2d.py:168-208`` (_upfirdn2d_ref): zero-stuff, pad/crop, FIR, decimate.
 
-    ``padding`` = [x0, x1, y0, y1].  Native twin: ``upfirdn2d.cu:97-200`` (small kernel) /
-    ``:29-92`` (large kernel).
+    ``padding`` = [x0, x1, y0, y1]; ``up`` / ``down`` an int or (x, y); ``f`` 2-D, or 1-D = separable taps
+    (row pass then column pass, :200-203).  Native twin: ``upfirdn2d.cu:97-200`` (small kernel) / ``:29-92``
+    (large kernel).  Plain torch ops: autograd gives the gradient the reference obtains by a second upfirdn2d
+    (upfirdn2d.py:245-264).
     """
     n, c, h, w = x.shape
+    upx, upy = (up, up) if isinstance(up, int) else up
+    downx, downy = (down, down) if isinstance(down, int) else down
     px0, px1, py0, py1 = padding
     x = x.reshape(n, c, h, 1, w, 1)
-    x = F.pad(x, [0, up - 1, 0, 0, 0, up - 1])
-    x = x.reshape(n, c, h * up, w * up)
+    x = F.pad(x, [0, upx - 1, 0, 0, 0, upy - 1])
+    x = x.reshape(n, c, h * upy, w * upx)
     x = F.pad(x, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
     x = x[:, :, max(-py0, 0): x.shape[2] - max(-py1, 0), max(-px0, 0): x.shape[3] - max(-px1, 0)]
     f = f * (gain ** (f.ndim / 2))
     f = f.to(x.dtype)
     if not flip_filter:
-        f = f.flip([0, 1])
-    x = F.conv2d(x, f[None, None].repeat(c, 1, 1, 1), groups=c)
-    return x[:, :, ::down, ::down]
+        f = f.flip(list(range(f.ndim)))
+    if f.ndim == 2:
+        x = F.conv2d(x, f[None, None].repeat(c, 1, 1, 1), groups=c)
+    else:
+        x = F.conv2d(x, f[None, None, None, :].repeat(c, 1, 1, 1), groups=c)
+        x = F.conv2d(x, f[None, None, :, None].repeat(c, 1, 1, 1), groups=c)
+    return x[:, :, ::downy, ::downx]
 
 
 def conv2d_resample(x, w, f=None, up=1, padding=0, groups=1, flip_weight=True):

@@ -1,0 +1,131 @@
+"""GPU parity (row f4, first slice): the HIP bias_act / upfirdn2d operators with the reference's gradient modes -
+forward, dx/db and the second-order terms - against the reference-generated golden vectors
+(tests/golden/ops_grads.npz) and against the CPU oracle under torch.autograd on seeded inputs.
+fp32 tolerances are written at each check."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+ACTS = ["linear", "relu", "lrelu", "tanh", "sigmoid", "elu", "selu", "softplus", "swish"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def k():
+    return load_golden("ops_grads.npz")
+
+
+def D(a, dev, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(grad)
+
+
+def close(got, want, tol):
+    got = np.zeros_like(want) if got is None else got.detach().cpu().numpy()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = float(np.abs(got.astype(np.float64) - np.asarray(want, np.float64)).max())
+    assert err <= tol, f"max abs err {err} > {tol}"
+
+
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("tag,clamp", [("n", None), ("c", 0.8)])
+def test_bias_act_grads_golden(dev, k, act, tag, clamp):
+    from brushstroke_engine_amd import ops
+    x, b, dy = D(k["ba_x"], dev, True), D(k["ba_b"], dev, True), D(k["ba_dy"], dev, True)
+    y = ops.bias_act(x, b, dim=1, act=act, clamp=clamp)
+    dx, db = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+    d_dy, d_x, d_b = torch.autograd.grad((dx * D(k["ba_ddx"], dev)).sum(), [dy, x, b], allow_unused=True)
+    p = f"ba_{act}_{tag}"
+    close(y, k[p + "_y"], 2e-6)
+    close(dx, k[p + "_dx"], 4e-6)
+    close(db, k[p + "_db"], 4e-5)          # sum over 84 elements
+    close(d_dy, k[p + "_ddy"], 4e-6)
+    close(d_x, k[p + "_d2x"], 4e-6)
+    close(d_b, k[p + "_d2b"], 4e-5)
+
+
+def test_bias_act_last_dim_and_no_grad(dev, k):
+    from brushstroke_engine_amd import ops
+    x, b = D(k["ba2_x"], dev, True), D(k["ba2_b"], dev, True)
+    y = ops.bias_act(x, b, dim=1, act="lrelu", gain=0.7, alpha=0.1)
+    dx, db = torch.autograd.grad(y, [x, b], D(k["ba2_dy"], dev))
+    close(y, k["ba2_y"], 2e-6); close(dx, k["ba2_dx"], 2e-6); close(db, k["ba2_db"], 2e-5)
+    with torch.no_grad():
+        assert not ops.bias_act(x, b, act="lrelu").requires_grad
+    # gradient only w.r.t. the bias
+    y = ops.bias_act(x.detach(), b, dim=1, act="tanh")
+    db2, = torch.autograd.grad(y.sum(), [b])
+    want = (1 - torch.tanh(x.detach() + b.detach()) ** 2).sum(0)
+    close(db2, want.cpu().numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_bias_act_grads_oracle_large(dev, act):
+    """Odd sizes (scalar path) and a 16-byte friendly shape (vector path) vs the oracle under autograd."""
+    from brushstroke_engine_amd import ops
+    from oracle import neube_oracle as orc
+    rng = np.random.RandomState(5)
+    for shape in ((3, 7, 5, 9), (2, 16, 12, 8)):
+        x0 = (rng.randn(*shape) * 2).astype(np.float32); b0 = rng.randn(shape[1]).astype(np.float32)
+        dy0 = rng.randn(*shape).astype(np.float32); dd0 = rng.randn(*shape).astype(np.float32)
+        res = []
+        for mod, to in ((ops, lambda a: D(a, dev, True)), (orc, lambda a: torch.tensor(a, requires_grad=True))):
+            x, b, dy = to(x0), to(b0), to(dy0)
+            y = mod.bias_act(x, b, dim=1, act=act, gain=1.3, clamp=1.1)
+            dx, db = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+            dd = to(dd0).detach()
+            d_dy, d_x = torch.autograd.grad((dx * dd).sum(), [dy, x], allow_unused=True)
+            res.append([y, dx, db, d_dy, d_x])
+        for got, want, tol in zip(res[0], res[1], (4e-6, 1e-5, 2e-4, 1e-5, 2e-5)):
+            close(got, np.zeros(shape, np.float32) if want is None else want.detach().numpy(), tol)
+
+
+def _cfg(k, name):
+    return ast.literal_eval(str(k[f"up_{name}_cfg"][0]))
+
+
+@pytest.mark.parametrize("name", list("abcdeg"))
+def test_upfirdn2d_grads_golden(dev, k, name):
+    from brushstroke_engine_amd import ops
+    c = _cfg(k, name)
+    x = D(k["up_x"], dev, True)
+    y = ops.upfirdn2d(x, D(k["up_" + c["f"]], dev), up=c["up"], down=c["down"], padding=c["padding"],
+                      flip_filter=c["flip_filter"], gain=c["gain"])
+    dx, = torch.autograd.grad(y, [x], D(k[f"up_{name}_dy"], dev), create_graph=True)
+    close(y, k[f"up_{name}_y"], 4e-6)
+    close(dx, k[f"up_{name}_dx"], 4e-6)
+    # second order: upfirdn2d is linear in x, so d(dx . v)/d(dy) = upfirdn2d(v) with the forward parameters
+    v = torch.randn_like(x)
+    dy = D(k[f"up_{name}_dy"], dev, True)
+    dx2, = torch.autograd.grad(y, [x], dy, create_graph=True)
+    g, = torch.autograd.grad((dx2 * v).sum(), [dy])
+    want = ops.upfirdn2d(v, D(k["up_" + c["f"]], dev), up=c["up"], down=c["down"], padding=c["padding"],
+                         flip_filter=c["flip_filter"], gain=c["gain"])
+    close(g, want.detach().cpu().numpy(), 1e-5)
+
+
+@pytest.mark.parametrize("name,kw", [("filter2d", dict(padding=1)), ("upsample2d", dict(up=2)), ("downsample2d", dict(down=2))])
+def test_upfirdn2d_helpers_golden(dev, k, name, kw):
+    from brushstroke_engine_amd import ops
+    x = D(k["up_x"][:, :, :8, :10], dev, True)
+    y = getattr(ops, name)(x, D(k["up_f4"], dev), **kw)
+    dx, = torch.autograd.grad(y, [x], D(k[f"uph_{name}_dy"], dev))
+    close(y, k[f"uph_{name}_y"], 4e-6)
+    close(dx, k[f"uph_{name}_dx"], 4e-6)
+
+
+def test_setup_filter_separable():
+    from brushstroke_engine_amd import ops
+    f = ops.setup_filter([1, 2, 4, 7, 7, 4, 2, 1])
+    assert f.ndim == 1 and abs(float(f.sum()) - 1) < 1e-6
+    f2 = ops.setup_filter([1, 3, 3, 1])
+    assert f2.shape == (4, 4)

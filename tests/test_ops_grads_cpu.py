@@ -1,0 +1,50 @@
+"""Row f4, first slice (CPU): the oracle's bias_act / upfirdn2d - forward and, through torch.autograd, first- and
+second-order gradients - against golden vectors produced by the reference's ``_ref`` ops
+(tests/golden/make_golden_grads.py)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import neube_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ops_grads.npz")
+ACTS = ["linear", "relu", "lrelu", "tanh", "sigmoid", "elu", "selu", "softplus", "swish"]
+
+
+@pytest.fixture(scope="module")
+def k():
+    return np.load(GOLD)
+
+
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("tag,clamp", [("n", None), ("c", 0.8)])
+def test_oracle_bias_act_grads(k, act, tag, clamp):
+    x = torch.tensor(k["ba_x"], requires_grad=True); b = torch.tensor(k["ba_b"], requires_grad=True)
+    dy = torch.tensor(k["ba_dy"], requires_grad=True)
+    y = orc.bias_act(x, b, dim=1, act=act, clamp=clamp)
+    dx, db = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+    d_dy, d_x, d_b = torch.autograd.grad((dx * torch.tensor(k["ba_ddx"])).sum(), [dy, x, b], allow_unused=True)
+    p = f"ba_{act}_{tag}"
+    z = lambda t, like: np.zeros_like(like) if t is None else t.detach().numpy()
+    for got, name in ((y, "y"), (dx, "dx"), (db, "db"), (d_dy, "ddy")):
+        np.testing.assert_allclose(got.detach().numpy(), k[f"{p}_{name}"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(z(d_x, k["ba_x"]), k[f"{p}_d2x"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(z(d_b, k["ba_b"]), k[f"{p}_d2b"], rtol=0, atol=2e-5)
+
+
+def _cfg(k, name):
+    return ast.literal_eval(str(k[f"up_{name}_cfg"][0]))
+
+
+@pytest.mark.parametrize("name", list("abcdeg"))
+def test_oracle_upfirdn2d_grads(k, name):
+    c = _cfg(k, name)
+    x = torch.tensor(k["up_x"], requires_grad=True)
+    y = orc.upfirdn2d(x, torch.tensor(k["up_" + c["f"]]), up=c["up"], down=c["down"], padding=c["padding"],
+                      flip_filter=c["flip_filter"], gain=c["gain"])
+    dx, = torch.autograd.grad(y, [x], torch.tensor(k[f"up_{name}_dy"]))
+    np.testing.assert_allclose(y.detach().numpy(), k[f"up_{name}_y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(dx.numpy(), k[f"up_{name}_dx"], rtol=0, atol=2e-6)
