@@ -807,11 +807,13 @@ struct H3Up2Params {
     _Float16* yh2; const float* next_styles; int next_stride, c8_next, out_f8;      // H2 output (see H3Params)
 };
 
-template <bool F8>
+// TQH = quad rows per tile: NB_H3_TQH (12) for throughput; 5 (7 x 34 = 238 positions = 8 column blocks, one per wave)
+// when the large tiles would leave most of the chip idle - the batch-1 / interactive configuration.
+template <bool F8, int TQH>
 __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
-    constexpr int NW = 8, TQH = NB_H3_TQH, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
+    constexpr int NW = 8, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
     constexpr int NBJ = (NBLK + NW - 1) / NW;         // blocks per wave (2)
     constexpr int XR = TQH + 3, XS = TQW + 3;         // halo tile 15 x 35 input pixels
@@ -1211,6 +1213,32 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     }
 }
 
+#define NB_H3_TQH_SMALL 5
+static int g_force_tqh = -1;
+// developer / test hook: 0 = automatic tile choice, NB_H3_TQH or NB_H3_TQH_SMALL = force that tile height
+extern "C" void nb_debug_set_up2_tile(int tqh) { g_force_tqh = tqh; }
+template <int TQH>
+static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
+    p.tiles_y = (p.h + TQH - 1) / TQH;
+    p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
+    constexpr int XPL = (((TQH + 3) * 35 + 63) / 64) * 64;
+    constexpr int NBLK_ = ((TQH + 2) * 34 + 31) / 32;
+    constexpr size_t lds_stage = (size_t)NB_H3_STAGES * (4 * XPL + 36 * 32) * 16;
+    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * TQH * 32 * 16;   // FIR slots + H2 slots (hi, 2 x lo)
+    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<false, TQH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<true, TQH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
+    if (in_fmt) hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<true, TQH>), grid, dim3(512), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<false, TQH>), grid, dim3(512), lds, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("modconv3x3_up2_h3");
+    return NB_OK;
+}
+
 static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
@@ -1233,26 +1261,14 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
-    p.tiles_x = w / 32; p.tiles_y = (h + NB_H3_TQH - 1) / NB_H3_TQH; p.slices = (c_out + 31) / 32;
+    p.tiles_x = w / 32; p.slices = (c_out + 31) / 32;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.out_f8 = out_fmt;
-    p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
-    constexpr int XPL = (((NB_H3_TQH + 3) * 35 + 63) / 64) * 64;
-    constexpr int NBLK_ = ((NB_H3_TQH + 2) * 34 + 31) / 32;
-    constexpr size_t lds_stage = (size_t)NB_H3_STAGES * (4 * XPL + 36 * 32) * 16;
-    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * NB_H3_TQH * 32 * 16;   // FIR slots + H2 slots (hi, 2 x lo)
-    const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    if (in_fmt) hipLaunchKernelGGL(modconv3x3_up2_h3_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(modconv3x3_up2_h3_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, p);
-    NB_CHECK_LAUNCH("modconv3x3_up2_h3");
-    return NB_OK;
+    // tile height: the 12-row tiles unless they leave the chip mostly idle (batch-1 / interactive), then 5-row tiles
+    const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : (getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0);
+    const long wgs_big = (long)n * p.tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * p.slices;
+    const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
+    return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }
 
 extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,

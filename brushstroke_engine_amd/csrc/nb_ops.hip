@@ -228,7 +228,7 @@ extern "C" int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int ma
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void mapping_kernel(const float* __restrict__ z, const float* __restrict__ fc_w,
                                                       const float* __restrict__ fc_b, float* __restrict__ w_out,
-                                                      int z_dim, int w_dim, int num_layers, float lr_mul) {
+                                                      int z_dim, int w_dim, int num_layers, float lr_mul, int num_ws) {
     __shared__ float xa[512], xb[512], red[8];
     const int n = blockIdx.x, t = threadIdx.x;
     // normalize_2nd_moment
@@ -258,18 +258,78 @@ __global__ __launch_bounds__(512) void mapping_kernel(const float* __restrict__ 
         wl += (size_t)w_dim * in;
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    if (t < w_dim) w_out[(size_t)n * w_dim + t] = cur[t];
+    if (t < w_dim)
+        for (int k = 0; k < num_ws; ++k) w_out[((size_t)n * num_ws + k) * w_dim + t] = cur[t];
+}
+
+// The same network for the style1 shapes (z_dim = w_dim = 64, <= 8 layers), latency-oriented (it heads the batch-1
+// step): 8 lanes share one output feature (8 inputs each, two 16-byte loads of the weight row), every layer's weight
+// slice is fetched into registers before the first layer starts, and the partial sums meet through three lane shuffles.
+#define NB_MAP_MAXL 8
+__global__ __launch_bounds__(512) void mapping64_kernel(const float* __restrict__ z, const float* __restrict__ fc_w,
+                                                        const float* __restrict__ fc_b, float* __restrict__ w_out,
+                                                        int num_layers, float lr_mul, int num_ws) {
+    __shared__ float xs[2][64];
+    const int n = blockIdx.x, t = threadIdx.x, o = t >> 3, part = t & 7;
+    f32x4 wr[NB_MAP_MAXL][2];
+    float bs[NB_MAP_MAXL];
+#pragma unroll
+    for (int l = 0; l < NB_MAP_MAXL; ++l) {
+        if (l < num_layers) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(fc_w + ((size_t)l * 64 + o) * 64 + part * 8);
+            wr[l][0] = src[0]; wr[l][1] = src[1];
+            bs[l] = fc_b[l * 64 + o];
+        }
+    }
+    if (t < 64) {                                    // normalize_2nd_moment (one wave holds the whole latent)
+        const float v = z[(size_t)n * 64 + t];
+        float sq = v * v;
+        for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d);
+        xs[0][t] = v * rsqrtf(sq / 64.f + 1e-8f);
+    }
+    __syncthreads();
+    const float wg = lr_mul / 8.f;                   // lr_mul / sqrt(64)
+#pragma unroll
+    for (int l = 0; l < NB_MAP_MAXL; ++l) {
+        if (l < num_layers) {
+            const float* cur = xs[l & 1] + part * 8;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += cur[i] * (wr[l][i >> 2][i & 3] * wg);
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+            if (part == 0) {
+                acc += bs[l] * lr_mul;
+                xs[(l + 1) & 1][o] = (acc > 0.f ? acc : acc * 0.2f) * 1.41421356237309515f;
+            }
+            __syncthreads();
+        }
+    }
+    const float* fin = xs[num_layers & 1];
+    for (int e = t; e < num_ws * 64; e += 512) w_out[(size_t)n * num_ws * 64 + e] = fin[e & 63];
+}
+
+static int nb_mapping_impl(const float* z, const float* fc_w, const float* fc_b, float* w_out, int n, int z_dim, int w_dim,
+                           int num_layers, float lr_mul, int num_ws, void* stream) {
+    NB_REQUIRE(z && fc_w && fc_b && w_out, "mapping: null pointer");
+    NB_REQUIRE(n >= 1, "mapping: empty batch");
+    NB_REQUIRE(z_dim >= 1 && z_dim <= 512 && w_dim >= 1 && w_dim <= 512, "mapping: z_dim/w_dim must be in [1,512]");
+    NB_REQUIRE(num_layers >= 1 && num_ws >= 1, "mapping: need at least one layer and one ws row");
+    if (z_dim == 64 && w_dim == 64 && num_layers <= NB_MAP_MAXL && ((uintptr_t)fc_w % 16) == 0)
+        hipLaunchKernelGGL(mapping64_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, z, fc_w, fc_b, w_out, num_layers, lr_mul, num_ws);
+    else
+        hipLaunchKernelGGL(mapping_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, z, fc_w, fc_b, w_out, z_dim, w_dim, num_layers, lr_mul, num_ws);
+    NB_CHECK_LAUNCH("mapping");
+    return NB_OK;
 }
 
 extern "C" int nb_mapping_f32(const float* z, const float* fc_w, const float* fc_b, float* w_out, int n, int z_dim,
                               int w_dim, int num_layers, float lr_mul, void* stream) {
-    NB_REQUIRE(z && fc_w && fc_b && w_out, "mapping: null pointer");
-    NB_REQUIRE(n >= 1, "mapping: empty batch");
-    NB_REQUIRE(z_dim >= 1 && z_dim <= 512 && w_dim >= 1 && w_dim <= 512, "mapping: z_dim/w_dim must be in [1,512]");
-    NB_REQUIRE(num_layers >= 1, "mapping: need at least one layer");
-    hipLaunchKernelGGL(mapping_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, z, fc_w, fc_b, w_out, z_dim, w_dim, num_layers, lr_mul);
-    NB_CHECK_LAUNCH("mapping");
-    return NB_OK;
+    return nb_mapping_impl(z, fc_w, fc_b, w_out, n, z_dim, w_dim, num_layers, lr_mul, 1, stream);
+}
+
+extern "C" int nb_mapping_ws_f32(const float* z, const float* fc_w, const float* fc_b, float* ws_out, int n, int z_dim,
+                                 int w_dim, int num_layers, float lr_mul, int num_ws, void* stream) {
+    return nb_mapping_impl(z, fc_w, fc_b, ws_out, n, z_dim, w_dim, num_layers, lr_mul, num_ws, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,6 +366,77 @@ __global__ __launch_bounds__(256) void styles_kernel(const NbLayerDesc* __restri
     }
 }
 
+// Latency-oriented variant (w_dim % 16 == 0, every c_out % 4 == 0; grid = (n_layers, n, NB_STY_PARTS)): four lanes share
+// one affine output (16-byte loads of the weight row, two shuffles), and the demodulation sum of a layer is split over
+// NB_STY_PARTS workgroups (each recomputes the cheap affine and takes a slice of the c_out outputs) and, inside a
+// workgroup, over c_in slices whose partial sums meet in LDS - instead of one thread walking all c_in rows.
+#define NB_STY_PARTS 4
+__global__ __launch_bounds__(256) void styles_fast_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ ws,
+                                                          int num_ws, int w_dim) {
+    __shared__ __attribute__((aligned(16))) float wv[512];
+    __shared__ float s2[NB_MAX_AFF];
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const NbLayerDesc L = layers[blockIdx.x];
+    const int n = blockIdx.y, part = blockIdx.z, t = threadIdx.x;
+    if (!L.wsq && part > 0) return;                                 // ToRGB: no demodulation, one workgroup does the affine
+    for (int i = t; i < w_dim; i += 256) wv[i] = ws[((size_t)n * num_ws + L.w_index) * w_dim + i];
+    __syncthreads();
+    const float wg = 1.f / sqrtf((float)w_dim);
+    const int q = t & 3, per = w_dim >> 2;                          // lane q of 4 covers columns q*per .. +per
+    for (int c0 = 0; c0 < L.c_aff; c0 += 64) {
+        const int c = c0 + (t >> 2);
+        float acc = 0.f;
+        if (c < L.c_aff) {
+            const f32x4* wr = reinterpret_cast<const f32x4*>(L.affine_w + (size_t)c * w_dim + q * per);
+            const f32x4* xv = reinterpret_cast<const f32x4*>(wv + q * per);
+            for (int i = 0; i < per / 4; ++i) {
+                const f32x4 a = wr[i], b = xv[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += b[j] * (a[j] * wg);
+            }
+        }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+        if (c < L.c_aff && q == 0) {
+            acc += L.affine_b[c];
+            if (c >= L.n_plain) acc *= L.style_scale;
+            if (part == 0) L.styles[(size_t)n * L.c_aff + c] = acc;
+            s2[c] = acc * acc;
+        }
+    }
+    __syncthreads();
+    if (!L.wsq) return;
+    const int c_in = L.c_aff - L.n_plain;
+    const int slice = ((L.c_out + 4 * NB_STY_PARTS - 1) / (4 * NB_STY_PARTS)) * 4;     // outputs per workgroup (multiple of 4)
+    const int o_lo = part * slice;
+    const int ng = slice >> 2;                                      // float4 groups across the slice
+    if (ng > 64 || o_lo >= L.c_out) {
+        if (o_lo < L.c_out)                                         // very wide layer: plain loop (not a style1 shape)
+            for (int o = o_lo + t; o < min(o_lo + slice, L.c_out); o += 256) {
+                float acc = 0.f;
+                for (int i = 0; i < c_in; ++i) acc += s2[L.n_plain + i] * L.wsq[(size_t)i * L.c_out + o];
+                L.dcoefs[(size_t)n * L.c_out + o] = rsqrtf(acc + 1e-8f);
+            }
+        return;
+    }
+    const int nks = 256 / ng, g = t % ng, ks = t / ng;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int o4 = o_lo + 4 * g;
+    if (ks < nks && o4 < L.c_out) {
+#pragma unroll 4
+        for (int i = ks; i < c_in; i += nks) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(L.wsq + (size_t)i * L.c_out + o4);
+            acc += s2[L.n_plain + i] * w4;
+        }
+    }
+    if (ks < nks) *reinterpret_cast<f32x4*>(red + (ks * ng + g) * 4) = acc;
+    __syncthreads();
+    if (t < slice && o_lo + t < L.c_out) {
+        float sum = 0.f;
+        for (int k = 0; k < nks; ++k) sum += red[(k * ng + (t >> 2)) * 4 + (t & 3)];
+        L.dcoefs[(size_t)n * L.c_out + o_lo + t] = rsqrtf(sum + 1e-8f);
+    }
+}
+
 extern "C" int nb_styles_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim, int n,
                              void* stream) {
     NB_REQUIRE(layers_dev && ws, "styles: null pointer");
@@ -313,6 +444,16 @@ extern "C" int nb_styles_f32(const NbLayerDesc* layers_dev, int n_layers, const 
     NB_REQUIRE(w_dim >= 1 && w_dim <= 512, "styles: w_dim must be in [1,512]");
     hipLaunchKernelGGL(styles_kernel, dim3(n_layers, n), dim3(256), 0, (hipStream_t)stream, layers_dev, ws, num_ws, w_dim);
     NB_CHECK_LAUNCH("styles");
+    return NB_OK;
+}
+
+extern "C" int nb_styles_fast_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim, int n,
+                                  void* stream) {
+    NB_REQUIRE(layers_dev && ws, "styles: null pointer");
+    NB_REQUIRE(n_layers >= 1 && n >= 1 && n <= 65535, "styles: bad sizes");
+    NB_REQUIRE(w_dim >= 16 && w_dim <= 512 && w_dim % 16 == 0, "styles_fast: w_dim must be a multiple of 16 in [16,512]");
+    hipLaunchKernelGGL(styles_fast_kernel, dim3(n_layers, n, NB_STY_PARTS), dim3(256), 0, (hipStream_t)stream, layers_dev, ws, num_ws, w_dim);
+    NB_CHECK_LAUNCH("styles_fast");
     return NB_OK;
 }
 

@@ -80,11 +80,10 @@ class MappingNetwork(torch.nn.Module):
             raise RuntimeError(f"z is on {z.device} but the generator is on {w.device}")
         z32 = z.to(torch.float32).contiguous()                      # networks.py:261
         n = z32.shape[0]
-        x = torch.empty([n, self.w_dim], dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
-            _lib.check(_lib.lib().nb_mapping_f32(_p(z32), _p(w), _p(b), _p(x), n, self.z_dim, self.w_dim,
-                                                 self.num_layers, self.lr_multiplier, ops._stream(x)), "mapping")
-        x = x.unsqueeze(1).repeat([1, self.num_ws, 1])              # networks.py:278-280
+        x = torch.empty([n, self.num_ws, self.w_dim], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):                           # (the kernel writes the broadcast of networks.py:278-280)
+            _lib.check(_lib.lib().nb_mapping_ws_f32(_p(z32), _p(w), _p(b), _p(x), n, self.z_dim, self.w_dim, self.num_layers,
+                                                    self.lr_multiplier, self.num_ws, ops._stream(x)), "mapping")
         if truncation_psi != 1:                                     # networks.py:283-289 (not used by the engine)
             if truncation_cutoff is None:
                 x = self.w_avg.lerp(x, truncation_psi)
@@ -246,6 +245,8 @@ class SynthesisNetwork(torch.nn.Module):
         # (tools/layers_b1.py: at batch 1 the >= 128x128 layers gain 25-65 %, the <= 64x64 layers lose 40-100 %)
         self.h3_min_pixels = 128 * 128
         self.h3_min_batch = 1
+        # the latency-oriented styles / demodulation launch needs 16-byte friendly shapes (every style1 shape has them)
+        self._styles_fast = cfg.w_dim % 16 == 0 and all(l.out_channels % 4 == 0 for l in cfg.layers)
         self._h3_batch_ok = True
         self._n = 1
         self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
@@ -372,8 +373,8 @@ class SynthesisNetwork(torch.nn.Module):
         keep_alive = []
         with torch.cuda.device(device):
             stream = ops._stream(ws)
-            _lib.check(lib.nb_styles_f32(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, n, stream),
-                       "styles")
+            styles_fn = lib.nb_styles_fast_f32 if self._styles_fast else lib.nb_styles_f32
+            _lib.check(styles_fn(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, n, stream), "styles")
             noise_stride = {}
             if noise_mode == "const":
                 table = plan.table

@@ -86,6 +86,10 @@ int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int major, int in
 int nb_mapping_f32(const float* z, const float* fc_w, const float* fc_b, float* w_out, int n, int z_dim,
                    int w_dim, int num_layers, float lr_mul, void* stream);
 
+/* The same with the broadcast of networks.py:278-280 written by the kernel: ws_out [n, num_ws, w_dim]. */
+int nb_mapping_ws_f32(const float* z, const float* fc_w, const float* fc_b, float* ws_out, int n, int z_dim,
+                      int w_dim, int num_layers, float lr_mul, int num_ws, void* stream);
+
 /* One entry of the per-layer table consumed by nb_styles_f32 / nb_noise_f32 (device memory, built
  * once when weights are packed).  Pointers are device addresses. */
 typedef struct NbLayerDesc {
@@ -112,6 +116,11 @@ typedef struct NbLayerDesc {
  * (networks.py:59-62 in the algebraically equal form d = rsqrt(sum_i s_i^2 * sum_k W_oik^2 + 1e-8)). */
 int nb_styles_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim, int n,
                   void* stream);
+
+/* Same results up to fp32 summation order, latency-oriented launch shape (the batch-1 step starts with it): needs
+ * w_dim % 16 == 0, every layer's c_out % 4 == 0 and 16-byte aligned affine_w / wsq. */
+int nb_styles_fast_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim, int n,
+                       void* stream);
 
 /* Stand-alone demodulation coefficients for one layer (networks.py:59-62 in the form above):
  * dcoefs[n,o] = rsqrt(sum_i styles[n,i]^2 * wsq[i,o] + 1e-8); styles [n,c_in], wsq [c_in,c_out]. */

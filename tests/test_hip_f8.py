@@ -142,3 +142,45 @@ def test_f8_tiled_canvas_matches_reference():
     _, full, _, _ = helper.paint_image(g["geom"], opts, crop_margin=int(g["crop_margin"]), return_full=True)
     d = np.abs(full.astype(np.int32) - g["canvas_level2_clear"].astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() <= 5e-3, (d.max(), (d > 0).mean())
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 64, 32, 32), (144, 128, 24, 64)])
+def test_up2_tile_heights_agree(fmt, ci, co, h, w):
+    """The up=2 split-f16 kernel has two tile heights (12 quad rows for throughput, 5 for under-filled launches such as
+    batch 1).  Both walk the same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical; 24 rows do
+    not divide by 5 (overhanging last tile)."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(ci + h + fmt)
+    n = 2
+    x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32)).cuda()
+    wt = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    nst = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    dco = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32)).cuda()
+    noise = torch.from_numpy(rs.randn(n, 2 * h, 2 * w).astype(np.float32)).cuda()
+    xh = (ops.pack_h2f8 if fmt else ops.pack_h2)(x, st)
+    wp = (ops.pack_conv_weight_h3f8 if fmt else ops.pack_conv_weight_h3)(wt)
+    lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for tqh in (12, 5):
+            lib.nb_debug_set_up2_tile(tqh)
+            y = torch.empty([n, co, 2 * h, 2 * w], device="cuda")
+            out = torch.zeros(ops.h2_shape(n, co, 2 * h, 2 * w), dtype=torch.float16, device="cuda")
+            common = (dco.data_ptr(), noise.data_ptr(), 4 * h * w, bias.data_ptr())
+            _lib.check(lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, y.data_ptr(), None, None, 0, 0, fmt, 0,
+                                                   n, h, w, co, 0.2, 1.4142135, 256.0, S), "f32 out")
+            _lib.check(lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, None, out.data_ptr(), nst.data_ptr(), co,
+                                                   co, fmt, fmt, n, h, w, co, 0.2, 1.4142135, 256.0, S), "hand-off out")
+            torch.cuda.synchronize()
+            res[tqh] = (y, out)
+    finally:
+        lib.nb_debug_set_up2_tile(0)
+    assert torch.equal(res[12][0], res[5][0])
+    assert torch.equal(res[12][1], res[5][1])
+    # and against float64 (loose: the exact bounds live in test_f8_kernels_vs_float64)
+    ref = _conv_ref(x, wt, st, 2) * dco.double().cpu()[:, :, None, None] + noise.double().cpu()[:, None]
+    ref = torch.nn.functional.leaky_relu(ref + bias.double().cpu()[None, :, None, None], 0.2) * 1.4142135
+    assert float((res[5][0].double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
