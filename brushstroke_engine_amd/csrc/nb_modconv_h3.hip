@@ -121,12 +121,14 @@ __device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float 
     return (unsigned)w;
 }
 
-template <int MW, bool F8 = false>
+// NBW_ = 32-pixel rows per wave: 2 for throughput, 1 (half the pixels per workgroup, twice the workgroups) when the
+// launch would otherwise leave most of the chip idle - the batch-1 / interactive configuration.
+template <int MW, bool F8 = false, int NBW_ = 2>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
     NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = 8, NWN = NW / MW;          // waves along pixels
-    constexpr int MB = 2, NBW = 2;                // 32x32 MFMA tiles per wave: 64 c_out x 64 pixels
+    constexpr int MB = 2, NBW = NBW_;             // 32x32 MFMA tiles per wave: 64 c_out x 64 (32) pixels
     constexpr int CO_WG = MW * 64, TH = NWN * NBW, TWP = 34;     // tile rows (32 pixels each), halo tile width
     constexpr int SLOTS = (TH + 2) * TWP;         // 16-byte slots of one (cgroup, hi/lo) plane of the halo tile
     constexpr int PP = (SLOTS + 63) / 64;         // 1-KiB DMA pieces per plane
@@ -666,25 +668,29 @@ static int launch_h3s(H3Params p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int MW, bool F8 = false>
+template <int MW, bool F8 = false, int NBW = 2>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
-    constexpr int NWN = 8 / MW, TH = NWN * 2, CO_WG = MW * 64;
+    constexpr int NWN = 8 / MW, TH = NWN * NBW, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
     constexpr size_t lds_stage = (size_t)(2 * 4 * XPL + 4 * 12 * CO_WG) * 16, lds_h2 = (size_t)2 * TH * 32 * (CO_WG + 8) * 2;
     const size_t lds = lds_stage > lds_h2 ? lds_stage : lds_h2;
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
 }
 
 extern "C" const float* nb_zero_page_ptr(void);
+
+static int g_force_nbw = 0;
+// developer / test hook: 0 = automatic, 1 / 2 = force that many 32-pixel rows per wave in the 8-wave up=1 kernel
+extern "C" void nb_debug_set_up1_rows(int nbw) { g_force_nbw = nbw; }
 
 static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
@@ -722,9 +728,17 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     { const char* e = getenv("NB_UP1_SMALL");
       const bool small = e ? atoi(e) != 0 : (h * w <= 32 * 32);
       if (small && !f8 && (!tg || c_out <= 64)) return launch_h3s(p, n, (hipStream_t)stream); }
-    if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, (hipStream_t)stream) : launch_h3<1, true>(p, n, (hipStream_t)stream);
-    if (c_out > 64) return launch_h3<2>(p, n, (hipStream_t)stream);
-    return launch_h3<1>(p, n, (hipStream_t)stream);
+    // half-height tiles when the full ones leave the chip mostly idle (batch 1); g_force_nbw: test hook
+    const long wgs_full = (long)n * (w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64));
+    const bool half = g_force_nbw ? g_force_nbw == 1 : wgs_full < 160;
+    hipStream_t st = (hipStream_t)stream;
+    if (half) {
+        if (f8) return c_out > 64 ? launch_h3<2, true, 1>(p, n, st) : launch_h3<1, true, 1>(p, n, st);
+        return c_out > 64 ? launch_h3<2, false, 1>(p, n, st) : launch_h3<1, false, 1>(p, n, st);
+    }
+    if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
+    if (c_out > 64) return launch_h3<2>(p, n, st);
+    return launch_h3<1>(p, n, st);
 }
 
 extern "C" int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts, const float* dcoefs, const float* noise,

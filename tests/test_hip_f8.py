@@ -184,3 +184,65 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     ref = _conv_ref(x, wt, st, 2) * dco.double().cpu()[:, :, None, None] + noise.double().cpu()[:, None]
     ref = torch.nn.functional.leaky_relu(ref + bias.double().cpu()[None, :, None, None], 0.2) * 1.4142135
     assert float((res[5][0].double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 32, 64), (64, 64, 48, 32)])
+def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
+    """The 8-wave up=1 split-f16 kernel runs with 2 (throughput) or 1 (under-filled launches, batch 1) pixel rows per
+    wave; same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(ci + h + fmt)
+    n = 2
+    x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32)).cuda()
+    wt = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    nst = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    dco = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32)).cuda()
+    noise = torch.from_numpy(rs.randn(n, h, w).astype(np.float32)).cuda()
+    xh = (ops.pack_h2f8 if fmt else ops.pack_h2)(x, st)
+    wp = (ops.pack_conv_weight_h3f8 if fmt else ops.pack_conv_weight_h3)(wt)
+    lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for rows in (2, 1):
+            lib.nb_debug_set_up1_rows(rows)
+            y = torch.empty([n, co, h, w], device="cuda")
+            out = torch.zeros(ops.h2_shape(n, co, h, w), dtype=torch.float16, device="cuda")
+            common = (dco.data_ptr(), noise.data_ptr(), h * w, bias.data_ptr())
+            _lib.check(lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, y.data_ptr(), None, None, 0, 0, None, fmt, 0,
+                                                   n, h, w, co, 0.2, 1.4142135, 256.0, S), "f32 out")
+            _lib.check(lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, None, out.data_ptr(), nst.data_ptr(), co,
+                                                   co, None, fmt, fmt, n, h, w, co, 0.2, 1.4142135, 256.0, S), "hand-off out")
+            torch.cuda.synchronize()
+            res[rows] = (y, out)
+    finally:
+        lib.nb_debug_set_up1_rows(0)
+    assert torch.equal(res[2][0], res[1][0])
+    assert torch.equal(res[2][1], res[1][1])
+    ref = _conv_ref(x, wt, st, 1) * dco.double().cpu()[:, :, None, None] + noise.double().cpu()[:, None]
+    ref = torch.nn.functional.leaky_relu(ref + bias.double().cpu()[None, :, None, None], 0.2) * 1.4142135
+    assert float((res[1][0].double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_generator_batch1_tiles_equal_forced_large_tiles():
+    """Whole generator at batch 1 (small tiles chosen automatically, fused ToRGB included) == the same with the
+    throughput tiles forced: bit-identical RGBA."""
+    from brushstroke_engine_amd import _lib, config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    dev = torch.device("cuda:0")
+    cfg = cfgmod.style1_config(256)
+    G = Generator(cfg, wmod.random_state_dict(cfg, 3), conv_mode="f8").to(dev)
+    z = torch.from_numpy(synthetic.batch_z(cfg, 1, 11)).to(dev)
+    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, 1, 5)]
+    pos = torch.from_numpy(synthetic.positions(cfg, 1, 5)).to(dev)
+    lib = _lib.lib()
+    a = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
+    try:
+        lib.nb_debug_set_up1_rows(2); lib.nb_debug_set_up2_tile(12)
+        b = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.nb_debug_set_up1_rows(0); lib.nb_debug_set_up2_tile(0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2]["uvs"], b[2]["uvs"])
