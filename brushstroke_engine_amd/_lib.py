@@ -50,6 +50,7 @@ PROTOTYPES = {
     "nb_mapping_ws_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     "nb_styles_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "nb_styles_fast_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_styles_noise_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_demod_coefs_f32": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "nb_noise_f32": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_modconv3x3_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp,

@@ -371,13 +371,25 @@ __global__ __launch_bounds__(256) void styles_kernel(const NbLayerDesc* __restri
 // NB_STY_PARTS workgroups (each recomputes the cheap affine and takes a slice of the c_out outputs) and, inside a
 // workgroup, over c_in slices whose partial sums meet in LDS - instead of one thread walking all c_in rows.
 #define NB_STY_PARTS 4
+// With grid.z > NB_STY_PARTS the extra z-slices compute the layer's position-shifted noise image of sample n (the
+// noise kernel's work, independent of the styles): one launch instead of two at the head of the step.
+__device__ __forceinline__ void nb_noise_sample(const NbLayerDesc& L, const float* __restrict__ norm_pos,
+                                                const long long* __restrict__ positions, int img_res, int n, int idx0, int stride);
 __global__ __launch_bounds__(256) void styles_fast_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ ws,
-                                                          int num_ws, int w_dim) {
+                                                          int num_ws, int w_dim, const float* __restrict__ norm_pos,
+                                                          const long long* __restrict__ positions, int img_res) {
     __shared__ __attribute__((aligned(16))) float wv[512];
     __shared__ float s2[NB_MAX_AFF];
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
     const NbLayerDesc L = layers[blockIdx.x];
     const int n = blockIdx.y, part = blockIdx.z, t = threadIdx.x;
+    if (part >= NB_STY_PARTS) {
+        if (L.noise_const) {
+            const int nz = gridDim.z - NB_STY_PARTS;
+            nb_noise_sample(L, norm_pos, positions, img_res, n, (part - NB_STY_PARTS) * 256 + t, nz * 256);
+        }
+        return;
+    }
     if (!L.wsq && part > 0) return;                                 // ToRGB: no demodulation, one workgroup does the affine
     for (int i = t; i < w_dim; i += 256) wv[i] = ws[((size_t)n * num_ws + L.w_index) * w_dim + i];
     __syncthreads();
@@ -452,8 +464,22 @@ extern "C" int nb_styles_fast_f32(const NbLayerDesc* layers_dev, int n_layers, c
     NB_REQUIRE(layers_dev && ws, "styles: null pointer");
     NB_REQUIRE(n_layers >= 1 && n >= 1 && n <= 65535, "styles: bad sizes");
     NB_REQUIRE(w_dim >= 16 && w_dim <= 512 && w_dim % 16 == 0, "styles_fast: w_dim must be a multiple of 16 in [16,512]");
-    hipLaunchKernelGGL(styles_fast_kernel, dim3(n_layers, n, NB_STY_PARTS), dim3(256), 0, (hipStream_t)stream, layers_dev, ws, num_ws, w_dim);
+    hipLaunchKernelGGL(styles_fast_kernel, dim3(n_layers, n, NB_STY_PARTS), dim3(256), 0, (hipStream_t)stream, layers_dev, ws, num_ws, w_dim,
+                       (const float*)nullptr, (const long long*)nullptr, 0);
     NB_CHECK_LAUNCH("styles_fast");
+    return NB_OK;
+}
+
+extern "C" int nb_styles_noise_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim,
+                                   const float* norm_pos, const int64_t* positions, int img_resolution, int n, void* stream) {
+    NB_REQUIRE(layers_dev && ws, "styles_noise: null pointer");
+    NB_REQUIRE(n_layers >= 1 && n >= 1 && n <= 65535, "styles_noise: bad sizes");
+    NB_REQUIRE(w_dim >= 16 && w_dim <= 512 && w_dim % 16 == 0, "styles_noise: w_dim must be a multiple of 16 in [16,512]");
+    NB_REQUIRE((norm_pos != nullptr) != (positions != nullptr), "styles_noise: pass exactly one of norm_pos / positions (per-sample noise)");
+    NB_REQUIRE(!positions || img_resolution >= 2, "styles_noise: positions need img_resolution >= 2");
+    hipLaunchKernelGGL(styles_fast_kernel, dim3(n_layers, n, NB_STY_PARTS + 64), dim3(256), 0, (hipStream_t)stream, layers_dev, ws, num_ws,
+                       w_dim, norm_pos, (const long long*)positions, img_resolution);
+    NB_CHECK_LAUNCH("styles_noise");
     return NB_OK;
 }
 
@@ -482,38 +508,29 @@ extern "C" int nb_demod_coefs_f32(const float* styles, const float* wsq, float* 
 // ------------------------------------------------------------------------------------------------
 // constant noise, optionally position-shifted (networks.py:371-382, SURVEY note C), all layers at once
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ norm_pos,
-                                                    const long long* __restrict__ positions, int img_res, int n_total) {
-    const NbLayerDesc L = layers[blockIdx.y];
-    if (!L.noise_const) return;
+// one sample's noise image of one layer, pixels idx0, idx0 + stride, ... (shared by the stand-alone and the fused launch)
+__device__ __forceinline__ void nb_noise_sample(const NbLayerDesc& L, const float* __restrict__ norm_pos,
+                                                const long long* __restrict__ positions, int img_res, int n, int idx0, int stride) {
     const int r = L.res;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= r * r) return;          // (most blocks of the small layers: the grid is sized for the largest one)
     const float strength = L.noise_strength[0];
-    if (!norm_pos && !positions) {
-        if (blockIdx.z == 0) L.noise_out[idx] = L.noise_const[idx] * strength;
-        return;
+    float np0 = 0.f, np1 = 0.f;
+    if (positions) {
+        // networks_modified.py:351-353: (positions % R) / (R - 1), python-style modulo, IEEE float32 division
+        // (done here, not with a torch GPU op: torch's device division is not correctly rounded and the
+        // wrap `% 1` below is discontinuous, so a 1-ulp difference moves whole noise rows)
+        const long long R = img_res;
+        const long long p0 = ((positions[2 * n + 0] % R) + R) % R, p1 = ((positions[2 * n + 1] % R) + R) % R;
+        np0 = (float)p0 / (float)(img_res - 1);
+        np1 = (float)p1 / (float)(img_res - 1);
+    } else if (norm_pos) {
+        np0 = norm_pos[2 * n + 0];
+        np1 = norm_pos[2 * n + 1];
     }
-    const int i = idx / r, j = idx - i * r;
-    const float li = L.noise_lin[i], lj = L.noise_lin[j];
-    // a block walks the samples (grid.z is small): 4x fewer, fatter blocks than one block per (tile, layer, sample)
-    for (int n = blockIdx.z; n < n_total; n += gridDim.z) {
-        float np0, np1;
-        if (positions) {
-            // networks_modified.py:351-353: (positions % R) / (R - 1), python-style modulo, IEEE float32 division
-            // (done here, not with a torch GPU op: torch's device division is not correctly rounded and the
-            // wrap `% 1` below is discontinuous, so a 1-ulp difference moves whole noise rows)
-            const long long R = img_res;
-            const long long p0 = ((positions[2 * n + 0] % R) + R) % R, p1 = ((positions[2 * n + 1] % R) + R) % R;
-            np0 = (float)p0 / (float)(img_res - 1);
-            np1 = (float)p1 / (float)(img_res - 1);
-        } else {
-            np0 = norm_pos[2 * n + 0];
-            np1 = norm_pos[2 * n + 1];
-        }
+    for (int idx = idx0; idx < r * r; idx += stride) {
+        const int i = idx / r, j = idx - i * r;
         // grid[i,j] = (lin[i] + pos0, lin[j] + pos1); channel 0 is the COLUMN coordinate, channel 1 the ROW
-        const float g0 = fmodf(li + np0, 1.f) * 2.f - 1.f;
-        const float g1 = fmodf(lj + np1, 1.f) * 2.f - 1.f;
+        const float g0 = fmodf(L.noise_lin[i] + np0, 1.f) * 2.f - 1.f;
+        const float g1 = fmodf(L.noise_lin[j] + np1, 1.f) * 2.f - 1.f;
         const float cx = ((g0 + 1.f) / 2.f) * (float)(r - 1);
         const float cy = ((g1 + 1.f) / 2.f) * (float)(r - 1);
         const float x0 = floorf(cx), y0 = floorf(cy);
@@ -528,6 +545,21 @@ __global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restric
         v += tap(y1i, x1i) * (wx1 * wy1);
         L.noise_out[(size_t)n * r * r + idx] = v * strength;
     }
+}
+
+__global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ norm_pos,
+                                                    const long long* __restrict__ positions, int img_res, int n_total) {
+    const NbLayerDesc L = layers[blockIdx.y];
+    if (!L.noise_const) return;
+    const int r = L.res;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= r * r) return;          // (most blocks of the small layers: the grid is sized for the largest one)
+    if (!norm_pos && !positions) {
+        if (blockIdx.z == 0) L.noise_out[idx] = L.noise_const[idx] * L.noise_strength[0];
+        return;
+    }
+    // a block walks the samples (grid.z is small): 4x fewer, fatter blocks than one block per (tile, layer, sample)
+    for (int n = blockIdx.z; n < n_total; n += gridDim.z) nb_noise_sample(L, norm_pos, positions, img_res, n, idx, 1 << 30);
 }
 
 extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max_res, const float* norm_pos,

@@ -373,15 +373,12 @@ class SynthesisNetwork(torch.nn.Module):
         keep_alive = []
         with torch.cuda.device(device):
             stream = ops._stream(ws)
-            styles_fn = lib.nb_styles_fast_f32 if self._styles_fast else lib.nb_styles_f32
-            _lib.check(styles_fn(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, n, stream), "styles")
             noise_stride = {}
+            table, npos, ipos = plan.table, None, None
             if noise_mode == "const":
-                table = plan.table
                 if noise_buffers:
                     table, keep = plan.table_with_noise_overrides(self, noise_buffers)
                     keep_alive += [table] + keep
-                npos = ipos = None
                 if int_positions is not None:
                     ipos = int_positions.to(device=device, dtype=torch.int64).contiguous()
                     _assert_shape(ipos, [n, 2])
@@ -390,8 +387,18 @@ class SynthesisNetwork(torch.nn.Module):
                     npos = norm_noise_positions.to(device=device, dtype=torch.float32).contiguous()
                     _assert_shape(npos, [n, 2])
                     keep_alive.append(npos)
-                _lib.check(lib.nb_noise_f32(_p(table), plan.n_layers, plan.max_res, _p(npos), _p(ipos),
-                                            self.img_resolution, n, stream), "noise")
+            if (self._styles_fast and noise_mode == "const" and table is plan.table and n <= 8
+                    and (npos is not None or ipos is not None)):
+                # small batches: styles + per-sample noise in one launch (a launch costs more than either computes)
+                _lib.check(lib.nb_styles_noise_f32(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, _p(npos),
+                                                   _p(ipos), self.img_resolution, n, stream), "styles_noise")
+            else:
+                styles_fn = lib.nb_styles_fast_f32 if self._styles_fast else lib.nb_styles_f32
+                _lib.check(styles_fn(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, n, stream), "styles")
+                if noise_mode == "const":
+                    _lib.check(lib.nb_noise_f32(_p(table), plan.n_layers, plan.max_res, _p(npos), _p(ipos),
+                                                self.img_resolution, n, stream), "noise")
+            if noise_mode == "const":
                 shared = npos is None and ipos is None
 
             debug_data = {}

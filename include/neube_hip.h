@@ -122,6 +122,11 @@ int nb_styles_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, 
 int nb_styles_fast_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim, int n,
                        void* stream);
 
+/* nb_styles_fast_f32 and nb_noise_f32 (per-sample shifted noise: exactly one of norm_pos / positions) in ONE launch -
+ * the two are independent, and at batch 1 a launch costs more than either computes. */
+int nb_styles_noise_f32(const NbLayerDesc* layers_dev, int n_layers, const float* ws, int num_ws, int w_dim,
+                        const float* norm_pos, const int64_t* positions, int img_resolution, int n, void* stream);
+
 /* Stand-alone demodulation coefficients for one layer (networks.py:59-62 in the form above):
  * dcoefs[n,o] = rsqrt(sum_i styles[n,i]^2 * wsq[i,o] + 1e-8); styles [n,c_in], wsq [c_in,c_out]. */
 int nb_demod_coefs_f32(const float* styles, const float* wsq, float* dcoefs, int n, int c_in, int c_out,
