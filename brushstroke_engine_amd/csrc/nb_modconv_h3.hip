@@ -806,6 +806,10 @@ extern "C" int nb_modconv3x3_up1_h3_h2(const void* x_h2, int c_in, const void* w
 #ifndef NB_H3_TQH
 #define NB_H3_TQH 12
 #endif
+#define NB_H3_TQH_SMALL 5       // tile height of the under-filled (batch-1) launches ...
+#ifndef NB_H3_STAGES_SMALL
+#define NB_H3_STAGES_SMALL 2    // ... (3 stages fit its LDS and were measured at batch 1: no faster - with one position block
+#endif                           // per wave the K loop is bound by the LDS reads of the shared weight fragments, not by DMA latency)
 #ifndef NB_H3_STAGES
 #define NB_H3_STAGES 2          // LDS-DMA stages of the up=2 kernel.  3 (needs NB_H3_TQH <= 10 to fit the LDS) was measured:
 #endif                           // no faster -- the K loop is not DMA-latency bound
@@ -926,7 +930,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             for (int r = 0; r < 16; ++r) acc[j][ph][r] = 0.f;
 
     const int NC = p.nchunks;
-    constexpr int NST = NB_H3_STAGES;
+    constexpr int NST = TQH == NB_H3_TQH_SMALL ? NB_H3_STAGES_SMALL : NB_H3_STAGES;
     issue(0, ring);
     if (NST == 3) {
         issue(NC > 1 ? 1 : 0, ring + STAGE);                       // (single-chunk layers: a harmless second copy)
@@ -1227,7 +1231,6 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     }
 }
 
-#define NB_H3_TQH_SMALL 5
 static int g_force_tqh = -1;
 // developer / test hook: 0 = automatic tile choice, NB_H3_TQH or NB_H3_TQH_SMALL = force that tile height
 extern "C" void nb_debug_set_up2_tile(int tqh) { g_force_tqh = tqh; }
@@ -1237,7 +1240,7 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
     constexpr int XPL = (((TQH + 3) * 35 + 63) / 64) * 64;
     constexpr int NBLK_ = ((TQH + 2) * 34 + 31) / 32;
-    constexpr size_t lds_stage = (size_t)NB_H3_STAGES * (4 * XPL + 36 * 32) * 16;
+    constexpr size_t lds_stage = (size_t)(TQH == NB_H3_TQH_SMALL ? NB_H3_STAGES_SMALL : NB_H3_STAGES) * (4 * XPL + 36 * 32) * 16;
     constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * TQH * 32 * 16;   // FIR slots + H2 slots (hi, 2 x lo)
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static bool attr_set = false;
