@@ -21,7 +21,7 @@ class GraphedTriadRender:
     """Capture ``Generator.render_triad`` for a fixed batch size; call it like a function."""
 
     def __init__(self, G: Generator, batch: int = 1, render_mode: str = "clear", use_ws: bool = False,
-                 use_positions: bool = True, want_f32: bool = False, warmup: int = 3):
+                 use_positions: bool = True, want_f32: bool = False, warmup: int = 3, plan_slot: Optional[int] = None):
         cfg = G.cfg
         dev = G.synthesis.get_last_block().conv1.weight.device
         assert dev.type == "cuda"
@@ -34,6 +34,10 @@ class GraphedTriadRender:
         self.user_colors = torch.full([batch, 3, 3], float("nan"), dtype=torch.float32, device=dev)
         self._kw = dict(geom_feature=self.geom, positions=self.positions, render_mode=render_mode,
                         user_colors=self.user_colors, want_u8=True, want_f32=want_f32)
+        if plan_slot is not None:
+            # own workspace: graphs that replay concurrently on different streams must not share one (slot 0 is the
+            # default of eager calls; the sub-batch streams of an eager split call use 1 .. sub_streams)
+            self._kw["_plan_slot"] = plan_slot
         # warm up on a side stream (creates the plan / zero page / packed weights outside the capture)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))

@@ -1,0 +1,21 @@
+"""The bench's steady-state loop alone (batch 32, two sub-batch streams, no join), for kernel traces."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+from brushstroke_engine_amd.networks import Generator
+dev = torch.device("cuda:0")
+cfg = cfgmod.style1_config(256)
+G = Generator(cfg, wmod.random_state_dict(cfg, 0), conv_mode=os.environ.get("NB_MODE", "f8")).to(dev)
+B = 32
+z = torch.from_numpy(synthetic.batch_z(cfg, B, 0)).to(dev)
+geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, 0)]
+pos = torch.from_numpy(synthetic.positions(cfg, B, 0)).to(dev)
+for _ in range(60): G.render_triad(z=z, geom_feature=geom, positions=pos, join=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+N = int(os.environ.get("NB_STEPS", "150"))
+for _ in range(N): G.render_triad(z=z, geom_feature=geom, positions=pos, join=False)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"{B * N / dt:.0f} patches/s, {dt / N * 1e3:.3f} ms/step")
