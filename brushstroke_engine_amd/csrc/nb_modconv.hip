@@ -51,7 +51,17 @@ struct ModconvParams {
     int tw;                // up2: quad cols per tile
     int tiles_x, tiles_y, slices;
     float alpha, gain, clamp;
+    unsigned long long* tstamps;   // debug: per-workgroup phase timestamps (nb_debug_set_timestamps_f32), or null
 };
+
+static unsigned long long* g_ts32 = nullptr;
+static int g_ts32_cap = 0;
+// Debug hook (not part of the product ABI): phase timestamps [workgroup][8] of the next fp32 launches, 100 MHz ticks
+extern "C" void nb_debug_set_timestamps_f32(void* buf, int capacity_workgroups) { g_ts32 = (unsigned long long*)buf; g_ts32_cap = capacity_workgroups; }
+#define NB_TS32(k)                                                                                           \
+    do {                                                                                                     \
+        if (p.tstamps && threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 __device__ __forceinline__ float nb_epilogue(float v, float bias, float alpha, float gain, float clamp) {
     v += bias;
@@ -101,6 +111,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
     constexpr int NPW = NXPW + NWPW;                 // LDS-DMA instructions per wave per chunk (same for every wave)
     constexpr int STAGE = nb_up1_stage_floats(PIX_WG, KC, CO_WG);
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    NB_TS32(0);
     float* sty = smem;                // [sty_floats] styles of this sample (zero padded to the chunk grid)
     float* ring = smem + p.sty_floats;
 
@@ -179,6 +190,27 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
+    // split-K (the latency-bound launches): the epilogue's operands - demodulation / bias of the 4 c_out rows this wave
+    // stores, the lane's noise value - are fetched now, so that their latency hides under the K loop
+    float pre_d[MB][4], pre_b[MB][4], pre_nz[NBW];
+    if constexpr (SK) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + mb * 32 + j + 8 * wv + 4 * lh;
+                pre_d[mb][j] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
+                pre_b[mb][j] = co < p.c_out ? p.bias[co] : 0.f;
+            }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int q = nb * 32 + l31;
+            const int ty = q >> p.log2_tw, tx = q & (TW - 1);
+            const int oy = y0 + ty, ox = x0 + tx;
+            pre_nz[nb] = (ty < th && oy < H && p.noise) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * W + ox] : 0.f;
+        }
+    }
+
     const int nchunks = (p.c_in + KC - 1) / KC;
     // NST-stage ring: chunks ck+1 .. ck+NST-1 are in flight while chunk ck is multiplied.  A chunk is complete
     // for this wave when all but the (chunks still allowed in flight) x NPW youngest LDS-DMA operations have retired
@@ -195,6 +227,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    NB_TS32(1);
     int cur = 0;
     for (int ck = 0; ck < nchunks; ++ck) {
         if (ck + NST - 1 < nchunks && !(p.dbg & 2)) {
@@ -209,7 +242,10 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
         // step s has issued, so their latency rides under the remaining MB*NBW-1 MFMAs (64 cycles each).
         // The style modulates the weight fragments on their way from LDS to the MFMA (networks.py:59-60).
         constexpr int STEPS = (KC / 2) / (SK ? NW : 1) * 9;
-        float af[2][MB], bfr[2][NBW], sv[2];
+        // PF = prefetch distance in steps (2 was measured for the single-MFMA-per-step split-K variant, as were two
+        // alternating accumulators: no faster - tools/phase_times_f32.py: its K loop runs at ~55 ns per MFMA step either way)
+        constexpr int PF = 1;
+        float af[PF + 1][MB], bfr[PF + 1][NBW], sv[PF + 1];
         auto fetch = [&](int step, float (&a)[MB], float (&bb)[NBW], float& s) {
             const int kq = step / 9, tap = step - kq * 9;
             const int kk = SK ? kq * NW + wv : kq;
@@ -220,15 +256,17 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
             for (int nb = 0; nb < NBW; ++nb) bb[nb] = xb[kk * 2 * XCH + boff[nb] + ky * XS + kx];
             s = sb[kk * 2];
         };
-        fetch(0, af[0], bfr[0], sv[0]);
+#pragma unroll
+        for (int f = 0; f < PF; ++f)
+            if (f < STEPS) fetch(f, af[f], bfr[f], sv[f]);
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
-            const int cur_f = step & 1;
+            const int cur_f = step % (PF + 1), nxt_f = (step + PF) % (PF + 1);
             float a[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) a[mb] = af[cur_f][mb] * sv[cur_f];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bfr[cur_f][0], acc[0][0], 0, 0, 0);
-            if (step + 1 < STEPS) fetch(step + 1, af[cur_f ^ 1], bfr[cur_f ^ 1], sv[cur_f ^ 1]);
+            if (step + PF < STEPS) fetch(step + PF, af[nxt_f], bfr[nxt_f], sv[nxt_f]);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -236,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
                     if (mb + nb > 0)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bfr[cur_f][nb], acc[mb][nb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (step + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, MB + NBW + 1, 0);
+            if (step + PF < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, MB + NBW + 1, 0);
             if (MB * NBW > 1) __builtin_amdgcn_sched_group_barrier(0x008, MB * NBW - 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -253,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
         cur = cur == NST - 1 ? 0 : cur + 1;
     }
 
+    NB_TS32(2);
     // ---- split-K: sum the NW partial accumulators through LDS; wave w then owns registers r with (r >> 2) == w ----
     if constexpr (SK) {
         static_assert(!SK || NW == 4, "split-K register ownership assumes 4 waves");
@@ -277,6 +316,7 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
                 }
     }
 
+    NB_TS32(3);
     // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp; D[row = c_out, col = pixel] ----
     const int Wo = W, Ho = H;
     const float* dco = p.dcoefs + (size_t)n * p.c_out;
@@ -287,7 +327,8 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
         const int oy = y0 + ty, ox = x0 + tx;
         const bool ok = ty < th && oy < Ho;
         float nz = 0.f;
-        if (ok && p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox];
+        if constexpr (SK) nz = pre_nz[nb];
+        else if (ok && p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -295,13 +336,15 @@ __global__ __launch_bounds__(NW * 64) void modconv3x3_up1_kernel(const ModconvPa
                 if (SK && (r >> 2) != wv) continue;          // split-K: each wave stores a quarter of the rows
                 const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (ok && co < p.c_out && !(p.dbg & 1)) {
-                    float v = acc[mb][nb][r] * dco[co] + nz;
-                    v = nb_epilogue(v, p.bias[co], p.alpha, p.gain, p.clamp);
+                    float v = acc[mb][nb][r] * (SK ? pre_d[mb][r & 3] : dco[co]) + nz;
+                    v = nb_epilogue(v, SK ? pre_b[mb][r & 3] : p.bias[co], p.alpha, p.gain, p.clamp);
                     p.y[((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox] = v;
                 }
             }
         }
     }
+    NB_TS32(4);
+    if (p.tstamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); NB_TS32(5); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -367,6 +410,24 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
 
     // styles of this sample -> LDS (the A fragments are modulated on their way from LDS to the MFMA)
     for (int i = tid; i < NB_STY_MAX; i += 256) sty[i] = i < p.c_in ? p.styles[(size_t)n * p.c_in + i] : 0.f;
+    // small-tile variants (the latency-bound launches): the epilogue's operands - demodulation, bias, hand-off scale of
+    // the 16 channels and the tile's noise - go to LDS now instead of being fetched in each of the 4 epilogue rounds
+    constexpr bool PRE = NBP <= 3;
+    constexpr int NZ_MAX = !PRE ? 1 : NBP == 3 ? 512 : NBP == 2 ? 256 : 64;
+    __shared__ float s_pd[16], s_pb[16], s_psc[16], s_pnz[NZ_MAX];
+    if constexpr (PRE) {
+        if (tid < 16) {
+            const int co = co0 + tid;
+            const bool v = co < p.c_out;
+            s_pd[tid] = v ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
+            s_pb[tid] = v ? p.bias[co] : 0.f;
+            s_psc[tid] = v ? (p.out_scale ? p.out_scale[(size_t)n * p.c_out + co] : 1.f) : 0.f;
+        }
+        for (int e = tid; e < 4 * TQH * TQW; e += 256) {
+            const int r = e / (2 * TQW), c = e - r * (2 * TQW);
+            s_pnz[e] = p.noise ? p.noise[(size_t)n * p.noise_stride_n + (size_t)(2 * I0 + r) * (2 * W) + 2 * J0 + c] : 0.f;
+        }
+    }
 
     // ---- LDS-DMA descriptors of this wave's activation pieces (fixed for all chunks) ----
     // piece q = i*NW + wv  ->  channel k = q / PPC of the chunk, part = q % PPC; lane l copies the 16-byte group
@@ -573,9 +634,13 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const int co = cb + s4;
                         const bool v = co < p.c_out;
-                        d4[s4] = v ? dco[co] : 0.f;
-                        b4[s4] = v ? p.bias[co] : 0.f;
-                        sc4[s4] = v ? (p.out_scale ? p.out_scale[(size_t)n * p.c_out + co] : 1.f) : 0.f;
+                        if constexpr (PRE) {
+                            d4[s4] = s_pd[4 * g + s4]; b4[s4] = s_pb[4 * g + s4]; sc4[s4] = s_psc[4 * g + s4];
+                        } else {
+                            d4[s4] = v ? dco[co] : 0.f;
+                            b4[s4] = v ? p.bias[co] : 0.f;
+                            sc4[s4] = v ? (p.out_scale ? p.out_scale[(size_t)n * p.c_out + co] : 1.f) : 0.f;
+                        }
                     }
                     _Float16* ob = reinterpret_cast<_Float16*>(p.y) + (((size_t)n * c8o + (cb >> 3)) * 2) * ((size_t)Ho * Wo * 8) + (cb & 7);
 #pragma unroll
@@ -584,7 +649,8 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
                         for (int dx = 0; dx < 2; ++dx) {
                             const int oy = 2 * qi + dy, ox = 2 * qj + dx;
                             float nz = 0.f;
-                            if (p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox];
+                            if constexpr (PRE) nz = s_pnz[(2 * ti + dy) * (2 * TQW) + 2 * tj + dx];
+                            else if (p.noise) nz = p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox];
                             h4 hi, lo;
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
@@ -609,12 +675,14 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
                 fir_quad(y1s + s * Y1_SLOT + ti * PW + tj, out);
                 const int qi = I0 + ti, qj = J0 + tj;
                 if (qi < H && qj < W && co < p.c_out && !(p.dbg & 1)) {
-                    const float d = dco[co], bs = p.bias[co];
+                    const float d = PRE ? s_pd[4 * s + g] : dco[co], bs = PRE ? s_pb[4 * s + g] : p.bias[co];
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy) {
                         const int oy = 2 * qi + dy, ox = 2 * qj;
                         float n0 = 0.f, n1 = 0.f;
-                        if (p.noise) {
+                        if constexpr (PRE) {
+                            n0 = s_pnz[(2 * ti + dy) * (2 * TQW) + 2 * tj]; n1 = s_pnz[(2 * ti + dy) * (2 * TQW) + 2 * tj + 1];
+                        } else if (p.noise) {
                             const float* np_ = p.noise + (size_t)n * p.noise_stride_n + (size_t)oy * Wo + ox;
                             n0 = np_[0]; n1 = np_[1];
                         }
@@ -759,6 +827,7 @@ static int nb_modconv3x3_impl(const float* x1, int c1, const float* x2, int c2, 
     { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.sty_floats = 0; p.log2_tw = 0; p.th = 0; p.tw = 0; p.tiles_x = p.tiles_y = p.slices = 1;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.tstamps = g_ts32;
     int tq[2] = {0, 0};
     const int v = nb_select_variant(n, h, w, c_out, up, tq);
     switch (v) {
@@ -767,7 +836,7 @@ static int nb_modconv3x3_impl(const float* x1, int c1, const float* x2, int c2, 
         case 2: return launch_up1<4, 2, 2, 8, 4>(p, n, st);
         case 3: return launch_up1<4, 1, 2, 8, 4>(p, n, st);
         case 4: return launch_up1<4, 1, 1, 8, 4>(p, n, st);
-        case 10: return launch_up1<4, 1, 1, 8, 4, true>(p, n, st);    // (ring depths 6 / 8 measured at batch 1: no faster)
+        case 10: return launch_up1<4, 1, 1, 8, 4, true>(p, n, st);    // (ring depths 6 / 8 and chunks of 16 / 32 channels measured at batch 1: no faster)
         default: break;
     }
     p.th = tq[0]; p.tw = tq[1];
