@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lock = threading.Lock()
 _lib = None
@@ -46,6 +46,10 @@ PROTOTYPES = {
     "nb_bias_act_grad_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                        C.c_float, C.c_float, vp]),
     "nb_upfirdn2d_f32": (C.c_int, [vp, vp, vp] + [C.c_int] * 14 + [C.c_float, vp]),
+    "nb_modconv3x3_up1_small_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_float, C.c_float, C.c_float, vp]),
+    "nb_modconv3x3_up2_small_h3": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_float, C.c_float, C.c_float, vp]),
     "nb_mapping_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_mapping_ws_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     "nb_styles_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),

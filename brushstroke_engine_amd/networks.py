@@ -282,6 +282,8 @@ class SynthesisNetwork(torch.nn.Module):
                 self.packed[s.name]["w_h3"] = ops.pack_conv_weight_h3(layer.weight)
                 if self.conv_mode == "f8" and s.in_channels % 16 == 0:
                     self.packed[s.name]["w_f8"] = ops.pack_conv_weight_h3f8(layer.weight)
+                if s.up == 2 and s.in_res <= 32 and s.in_channels % 16 == 0:
+                    self.packed[s.name]["w_h3_up2"] = ops.pack_conv_weight_h3_up2_phases(layer.weight, layer.resample_filter)
         t = self.get_last_block().torgb
         self.packed["torgb"] = {"w": t.weight.reshape(3, -1).contiguous()}
 
@@ -295,6 +297,22 @@ class SynthesisNetwork(torch.nn.Module):
         """conv0 (up=2) layers that run on the split-f16 4-phase kernel: input rows must be multiples of 32 pixels."""
         return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 2 and s.in_res >= 32 and s.in_res % 32 == 0
                 and self._n * s.block_res ** 2 >= self.h3_min_pixels
+                and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
+
+    small_h3 = True        # <= 64x64 conv1 layers on the small-tile split-f16 kernel (csrc/nb_modconv_small.hip)
+
+    def _small_h3_eligible(self, s: LayerSpec) -> bool:
+        """conv1 layers too small for the large-tile split-f16 kernel: same hi/lo products on 32 x 32 tiles with K split
+        over the waves, fp32 in and out (needs whole 16-channel chunks and the conv_clamp bound like the other f16 paths)."""
+        return (self.small_h3 and self.conv_mode in ("h3", "f8") and s.up == 1 and s.block_res <= 64
+                and s.in_channels % 16 == 0 and s.in_channels <= 512
+                and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
+
+    def _small_h3_up2_eligible(self, s: LayerSpec) -> bool:
+        """conv0 (up = 2) layers with inputs <= 32x32 that the large-tile up=2 kernel does not take."""
+        return (self.small_h3 and self.conv_mode in ("h3", "f8") and s.up == 2 and s.in_res <= 32
+                and s.in_channels % 16 == 0 and s.in_channels <= 512 and s.name in self.packed
+                and "w_h3_up2" in self.packed[s.name]
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _operand_fmt(self, s: Optional[LayerSpec]) -> int:
@@ -503,6 +521,25 @@ class SynthesisNetwork(torch.nn.Module):
                         self.layer_kernels[name] = ("modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
                                                     if s.up == 1 else "modconv3x3_up2_h3_kernel")
                         keep_alive.append(x_h2)
+                        self._end_event(ev)
+                    elif self._small_h3_eligible(s) and c2 == 0 and x is not None:
+                        # small conv1 layer: split-f16 products on 32 x 32 tiles with K split over the waves
+                        ev = self._begin_event(name)
+                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                        _lib.check(lib.nb_modconv3x3_up1_small_h3(
+                            _p(x), c1, _p(pk["w_h3"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                            _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
+                        self.layer_kernels[name] = "modconv3x3_up1_small_h3_kernel"
+                        self._end_event(ev)
+                    elif self._small_h3_up2_eligible(s) and c1 % 16 == 0 and c2 % 16 == 0 and x is not None:
+                        # small conv0 layer: the FIR is folded into four per-phase 3x3 kernels (ops.fold_up2_fir), the
+                        # phases run through the same small-tile split-f16 kernel
+                        ev = self._begin_event(name)
+                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+                        _lib.check(lib.nb_modconv3x3_up2_small_h3(
+                            _p(x), c1, _p(x2), c2, _p(pk["w_h3_up2"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                            _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
+                        self.layer_kernels[name] = "modconv3x3_up1_small_h3_kernel"
                         self._end_event(ev)
                     else:
                         ev = self._begin_event(name)

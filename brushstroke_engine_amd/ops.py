@@ -385,6 +385,36 @@ def pack_conv_weight_h3(weight: torch.Tensor) -> torch.Tensor:
     return both.permute(1, 4, 5, 2, 0, 6, 3).contiguous()                 # [chunk, ky, kx, cg, hl, o, j]
 
 
+def fold_up2_fir(weight: torch.Tensor, resample_filter: torch.Tensor) -> torch.Tensor:
+    """Effective per-phase 3x3 kernels of `stride-2 transposed conv + 4x4 FIR (pad 1, gain 4)` (conv2d_resample.py:124-142,
+    upfirdn2d.py:168-208): out[2m+py, 2n+px] = sum_{di,dj} x[m+di, n+dj] * Keff[2 py + px][.., di+1, dj+1] with
+    Keff[py,px][a', b'] = sum_{a,b} W[a,b] * g[a - (py - 2 di) + 1, b - (px - 2 dj) + 1], g = flip(4 f), di = a' - 1.
+    Returns [4, O, I, 3, 3] (float64 accumulation, fp32 result)."""
+    o, i, kh, kw = weight.shape
+    assert kh == 3 and kw == 3 and tuple(resample_filter.shape) == (4, 4)
+    w = weight.detach().to(torch.float64)
+    g = (resample_filter.detach().to(torch.float64) * 4.0).flip([0, 1]).to(w.device)
+    out = torch.zeros([4, o, i, 3, 3], dtype=torch.float64, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for di in (-1, 0, 1):
+                for dj in (-1, 0, 1):
+                    ty, tx = py - 2 * di, px - 2 * dj
+                    for a in range(3):
+                        for b in range(3):
+                            u, v = a - ty + 1, b - tx + 1
+                            if 0 <= u < 4 and 0 <= v < 4:
+                                out[2 * py + px, :, :, di + 1, dj + 1] += w[:, :, a, b] * g[u, v]
+    return out.to(torch.float32)
+
+
+def pack_conv_weight_h3_up2_phases(weight: torch.Tensor, resample_filter: torch.Tensor) -> torch.Tensor:
+    """The four phase kernels of :func:`fold_up2_fir`, each in the pack_conv_weight_h3 format, back to back
+    (operand of nb_modconv3x3_up2_small_h3)."""
+    k = fold_up2_fir(weight, resample_filter)
+    return torch.stack([pack_conv_weight_h3(k[ph]) for ph in range(4)]).contiguous()
+
+
 def pack_conv_weight_h3f8(weight: torch.Tensor) -> torch.Tensor:
     """[O,I,3,3] fp32 -> the "f8" weight format: container of pack_conv_weight_h3 with the lo slots holding
     fp8 e4m3 (w) [cg 0] and fp8((w - f16(w)) * 2^11) [cg 1] of the chunk's 16 channels (include/neube_hip.h)."""

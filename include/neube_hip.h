@@ -266,6 +266,24 @@ int nb_modconv3x3_up2_h3_ex(const void* x, int c_in, const void* wts, const floa
                             int next_stride, int c_next, int in_fmt, int out_fmt, int n, int h, int w, int c_out,
                             float alpha, float gain, float clamp, void* stream);
 
+/* The same layer for SMALL images (csrc/nb_modconv_small.hip; the <= 64x64 conv1 layers): split-f16 products on
+ * 32 c_out x 32 position tiles with K split over the 4 waves of a workgroup, fp32 NCHW in and out, the per-sample styles
+ * applied to the activations while they are split into hi/lo f16 on their way into LDS.  Replaces nb_modconv3x3_f32
+ * (up = 1) where the fp32 matrix rate or the launch latency of few, long workgroups dominates: h, w powers of two >= 4
+ * (4x4 images are processed two samples per tile), c_in <= 512.  w_h3 = the nb_pack_conv_weight_h3 format. */
+int nb_modconv3x3_up1_small_h3(const float* x, int c_in, const void* w_h3, const float* styles, const float* dcoefs,
+                               const float* noise, int64_t noise_stride_n, const float* bias, float* y, int n, int h,
+                               int w, int c_out, float alpha, float gain, float clamp, void* stream);
+
+/* up = 2 (conv2d_resample.py:124-142: stride-2 transposed conv + 4x4 FIR, pad 1, gain 4) for small images through the same
+ * kernel: per output phase (py, px) the composite is a 3x3 correlation of the input grid with an effective kernel
+ * Keff[py,px] = W folded with the FIR (static, no styles), so w_h3_phases = the four nb_pack_conv_weight_h3(Keff[2 py + px])
+ * images back to back and the kernel runs the phases as grid.z.  (x1 ++ x2) = concatenated input, c1, c2 % 16 == 0;
+ * h, w = INPUT size; y [n, c_out, 2h, 2w]; noise [.., 2h, 2w]. */
+int nb_modconv3x3_up2_small_h3(const float* x1, int c1, const float* x2, int c2, const void* w_h3_phases, const float* styles,
+                               const float* dcoefs, const float* noise, int64_t noise_stride_n, const float* bias, float* y,
+                               int n, int h, int w, int c_out, float alpha, float gain, float clamp, void* stream);
+
 /* The two split-f16 convolutions with the output written straight into the CONSUMER's H2 input tensor
  * y_h2 = H2 [n, c_next, h_out, w_out] (channel groups 0 .. c_out/8-1; c_out % 8 == 0), already multiplied by the
  * consumer's styles next_styles[n*next_stride + c] -- the fused form of SynthesisLayer.forward followed by the next

@@ -201,3 +201,68 @@ def test_fused_torgb_equals_standalone(res):
     for a, b in zip(outs[True][1:], outs[False][1:]):
         assert torch.equal(a, b)
     assert torch.equal(outs[True][0], outs[False][0])
+
+
+# ---------------------------------------------------------------- small-image split-f16 conv1 kernel
+@pytest.mark.parametrize("shape", [(1, 128, 128, 4), (3, 128, 128, 4), (2, 128, 128, 8), (1, 128, 96, 16), (2, 64, 128, 32),
+                                   (1, 128, 128, 64), (5, 48, 40, 8)])
+def test_up1_small_h3_vs_oracle(dev, shape):
+    """nb_modconv3x3_up1_small_h3 (32 x 32 tiles, K split over the waves; 4x4 images two samples per tile, odd batch =
+    half-empty last tile) against the fp32 CPU oracle.  Tolerance 5e-5 on O(1) activations, like the large-tile kernel."""
+    from brushstroke_engine_amd import ops, _lib
+    from oracle import neube_oracle as orc
+    n, ic, oc, h = shape
+    rs = np.random.RandomState(ic + oc + h + n)
+    x = rs.randn(n, ic, h, h).astype(np.float32)
+    wt = rs.randn(oc, ic, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(n, ic)).astype(np.float32)
+    b = (0.1 * rs.randn(oc)).astype(np.float32)
+    noise = (0.1 * rs.randn(n, 1, h, h)).astype(np.float32)
+    T = torch.from_numpy
+    want = orc.modulated_conv2d(T(x), T(wt), T(s), noise=T(noise), up=1, padding=1, flip_weight=True)
+    want = orc.bias_act(want, T(b), act="lrelu", gain=np.sqrt(2), clamp=256.0)
+    wd, sd_ = D(wt, dev), D(s, dev)
+    wsq = wd.square().sum(dim=[2, 3]).t().contiguous()
+    d = (sd_.square() @ wsq + 1e-8).rsqrt()
+    w_h3 = ops.pack_conv_weight_h3(wd)
+    xd, nd, bd = D(x, dev), D(noise, dev), D(b, dev)
+    y = torch.full([n, oc, h, h], float("nan"), dtype=torch.float32, device=dev)
+    rc = _lib.lib().nb_modconv3x3_up1_small_h3(xd.data_ptr(), ic, w_h3.data_ptr(), sd_.data_ptr(), d.data_ptr(), nd.data_ptr(),
+                                               h * h, bd.data_ptr(), y.data_ptr(), n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0,
+                                               torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "small_h3")
+    assert maxerr(y, want) <= 5e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 0, 128, 4), (3, 128, 0, 128, 4), (2, 128, 0, 128, 8), (1, 128, 0, 96, 16),
+                                   (1, 128, 16, 128, 32), (2, 32, 16, 40, 8)])
+def test_up2_small_h3_vs_oracle(dev, shape):
+    """nb_modconv3x3_up2_small_h3 (FIR folded into four per-phase 3x3 kernels, phases as grid.z; optional concatenated
+    second input) against the fp32 CPU oracle's conv_transpose2d + upfirdn2d.  Tolerance 5e-5 on O(1) activations."""
+    from brushstroke_engine_amd import ops, _lib
+    from oracle import neube_oracle as orc
+    n, c1, c2, oc, h = shape
+    ic = c1 + c2
+    rs = np.random.RandomState(ic + oc + h + n)
+    x = rs.randn(n, ic, h, h).astype(np.float32)
+    wt = rs.randn(oc, ic, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(n, ic)).astype(np.float32)
+    b = (0.1 * rs.randn(oc)).astype(np.float32)
+    noise = (0.1 * rs.randn(n, 1, 2 * h, 2 * h)).astype(np.float32)
+    T = torch.from_numpy
+    f = orc.setup_filter()
+    want = orc.modulated_conv2d(T(x), T(wt), T(s), noise=T(noise), up=2, padding=1, resample_filter=f, flip_weight=False)
+    want = orc.bias_act(want, T(b), act="lrelu", gain=np.sqrt(2), clamp=256.0)
+    wd, sd_ = D(wt, dev), D(s, dev)
+    wsq = wd.square().sum(dim=[2, 3]).t().contiguous()
+    d = (sd_.square() @ wsq + 1e-8).rsqrt()
+    wph = ops.pack_conv_weight_h3_up2_phases(wd, f.to(dev))
+    x1 = D(x[:, :c1], dev)
+    x2 = D(x[:, c1:], dev) if c2 else None
+    nd, bd = D(noise, dev), D(b, dev)
+    y = torch.full([n, oc, 2 * h, 2 * h], float("nan"), dtype=torch.float32, device=dev)
+    rc = _lib.lib().nb_modconv3x3_up2_small_h3(x1.data_ptr(), c1, None if x2 is None else x2.data_ptr(), c2, wph.data_ptr(),
+                                               sd_.data_ptr(), d.data_ptr(), nd.data_ptr(), 4 * h * h, bd.data_ptr(), y.data_ptr(),
+                                               n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "small_h3_up2")
+    assert maxerr(y, want) <= 5e-5

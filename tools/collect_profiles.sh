@@ -14,6 +14,11 @@ cd $R
 python tools/pmc_mem_summary.py $O/pmc_hit $O/pmc_fetch $O/pmc_write $O/pmc_mem.json > $O/pmc_mem.txt 2>&1
 python tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma_busy.txt 2>&1
 python tools/phase_times.py > $O/phase_times.txt 2>&1
+python tools/phase_times_f32.py > $O/phase_times_f32.txt 2>&1
+python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace -d $O/b1trace -o b1 --output-format csv -- python3 $R/tools/trace_b1.py > $O/b1trace.log 2>&1)
+python tools/trace_b1_summary.py $O/b1trace > $O/b1_trace_summary.txt 2>&1; rm -rf $O/b1trace
+python tools/graph_b32.py > $O/graph_b32.txt 2>&1
 python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 --conv-mode f8 > $O/canvas_4096_r256_l2_f8.json 2>/dev/null
 python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 --breakdown > $O/canvas_4096_r256_l2.json 2>/dev/null
 python tools/bench_canvas.py --size 4096 --res 256 --level 0 --steps 3 --breakdown > $O/canvas_4096_r256_l0.json 2>/dev/null
