@@ -59,6 +59,7 @@ __device__ __forceinline__ float nb_sm_epilogue(float v, float bias, float alpha
 __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const SmallParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 2 * 4 * NB_SM_NHP * 16];     // [wave][buf][plane][slot]
     __shared__ float s_sty[2 * NB_SM_MAX_CIN];
+    __shared__ float s_epi[96];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
     const int H = p.h, W = p.w, P = H * W;
@@ -71,26 +72,18 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
     const int phase = blockIdx.z, py = phase >> 1, px = phase & 1;          // up = 2: output pixel (2 oy + py, 2 ox + px)
     const int HR = p.rows + 2, HC = p.cols + 2, RC = p.rows * p.cols, NH = p.spt * HR * HC;
 
-    for (int i = tid; i < p.spt * p.c_in; i += 256) {
-        const int s = i / p.c_in, c = i - s * p.c_in;
-        s_sty[s * NB_SM_MAX_CIN + c] = n0 + s < p.n ? p.styles[(size_t)(n0 + s) * p.c_in + c] : 0.f;
-    }
-    __syncthreads();
-
     // ---- staging tasks of this lane (chunk-invariant): task = round * 64 + lane -> (channel group, halo slot) ----
-    // xoff / xoff2 = 32-bit element offset of the slot's pixel in channel cg*8 of the sample in x / x2 (element 0 for slots
-    // outside the image, whose loaded value is multiplied by xmask = 0), tslot = LDS slot (or -1: no such task), tsty = style row
+    // xoff / xoff2 = 32-bit element offset of the slot's pixel in channel cg*8 of the sample in x / x2, tslot = LDS slot
+    // (-1: no such task - the slot lies outside the image or the tile and keeps the zero it is given once below), tsty = style row
     unsigned xoff[4], xoff2[4];
     const int c2 = p.c_in - p.c1;
     int tslot[4], tsty[4];
-    float xmask[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int task = r * 64 + lane;
         const int cg = task / NB_SM_NHP, hp = task - cg * NB_SM_NHP;
-        xoff[r] = 0; xoff2[r] = 0; tslot[r] = -1; tsty[r] = 0; xmask[r] = 0.f;
+        xoff[r] = 0; xoff2[r] = 0; tslot[r] = -1; tsty[r] = 0;
         if (cg < 2) {
-            tslot[r] = cg * 2 * NB_SM_NHP + hp;                 // plane (cg, hi); lo = + NB_SM_NHP
             if (hp < NH) {
                 const int s = hp / (HR * HC), rem = hp - s * (HR * HC);
                 const int hy = rem / HC, hx = rem - hy * HC;
@@ -99,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
                     xoff[r] = (unsigned)(((n0 + s) * p.c1 + cg * 8) * P + gy * W + gx);
                     xoff2[r] = (unsigned)(((n0 + s) * c2 + cg * 8) * P + gy * W + gx);
                     tsty[r] = s * NB_SM_MAX_CIN + cg * 8;
-                    xmask[r] = 1.f;
+                    tslot[r] = cg * 2 * NB_SM_NHP + hp;         // plane (cg, hi); lo = + NB_SM_NHP
                 }
             }
         }
@@ -111,6 +104,10 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
     const int pbase = lh * 2 * NB_SM_NHP + hb;                  // plane (cg = lh, hi); lo = + NB_SM_NHP
 
     h8* mybuf = reinterpret_cast<h8*>(smem) + wv * (2 * 4 * NB_SM_NHP);
+    {   // zero padding: slots outside the image are never staged, they keep this zero (both buffers, all planes)
+        const h8 z8 = {};
+        for (int i = lane; i < 2 * 4 * NB_SM_NHP; i += 64) mybuf[i] = z8;
+    }
     const unsigned wstep = (unsigned)(p.co_ld * 8);
     // + ((chunk*9 + tap)*4 + hl) * co_ld * 8  (halves); one weight set per output phase
     const unsigned wl = (unsigned)((lh * 2 * p.co_ld + co0 + l31) * 8) + (unsigned)phase * (unsigned)(p.nchunks * 36) * wstep;
@@ -128,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
         const unsigned cbase = (unsigned)((c * 16 - (second ? p.c1 : 0)) * P);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned o = (second ? xoff2[r] : xoff[r]) + cbase;
+            const unsigned o = (second ? xoff2[r] : xoff[r]) + cbase;       // (tasks without a slot read element 0: unused)
 #pragma unroll
             for (int j = 0; j < 8; ++j) xr[r][j] = src[o + (unsigned)(j * P)];
         }
@@ -140,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
                 h8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float v = xr[r][j] * (s_sty[tsty[r] + c * 16 + j] * xmask[r]);
+                    const float v = xr[r][j] * s_sty[tsty[r] + c * 16 + j];
                     const _Float16 hh = (_Float16)v;
                     hi[j] = hh;
                     lo[j] = (_Float16)(v - (float)hh);
@@ -175,6 +172,27 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
     const int NC = p.nchunks;
     int c = wv;
     if (c < NC) { load_w(c, wa0); load_x(c, xr0); }
+    // everything else the workgroup needs from global memory is requested now, under the first chunk's loads: the styles
+    // (to LDS) and the epilogue's operands (registers) - a launch of this kernel is a few microseconds, so every exposed
+    // round trip counts
+    const int s_ = ps, oy = y0 + pty, ox = x0 + ptx, ns = n0 + s_;
+    const bool ok = ns < p.n && l31 < p.spt * RC && oy < H && ox < W;
+    const int Wo = p.up * W, oyo = p.up * oy + py, oxo = p.up * ox + px;
+    const float nz = (ok && p.noise) ? p.noise[(size_t)ns * p.noise_stride_n + (size_t)oyo * Wo + oxo] : 0.f;
+    if (tid < 96) {                                             // [2 samples][32 c_out] demodulation, [32] bias
+        const int co = co0 + (tid & 31), sidx = tid >> 5;
+        float v = 0.f;
+        if (co < p.c_out) {
+            if (sidx < 2) { if (n0 + sidx < p.n) v = p.dcoefs[(size_t)(n0 + sidx) * p.c_out + co]; }
+            else v = p.bias[co];
+        }
+        s_epi[tid] = v;
+    }
+    for (int i = tid; i < p.spt * p.c_in; i += 256) {
+        const int s = i / p.c_in, cc = i - s * p.c_in;
+        s_sty[s * NB_SM_MAX_CIN + cc] = n0 + s < p.n ? p.styles[(size_t)(n0 + s) * p.c_in + cc] : 0.f;
+    }
+    __syncthreads();
     while (c < NC) {
         int cn = c + 4;
         stage(c, xr0, mybuf);
@@ -197,20 +215,16 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wv * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    const int s = ps, oy = y0 + pty, ox = x0 + ptx;
-    const int ns = n0 + s;
-    const bool ok = ns < p.n && l31 < p.spt * RC && oy < H && ox < W;
     if (!ok) return;
-    const int Wo = p.up * W, oyo = p.up * oy + py, oxo = p.up * ox + px;
     const size_t Po = (size_t)p.up * p.up * P;
-    const float nz = p.noise ? p.noise[(size_t)ns * p.noise_stride_n + (size_t)oyo * Wo + oxo] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = wv * 4 + j;
         const int co = co0 + j + 8 * wv + 4 * lh;
         if (co < p.c_out) {
             const float sum = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane];
-            const float v = nb_sm_epilogue(sum * p.dcoefs[(size_t)ns * p.c_out + co] + nz, p.bias[co], p.alpha, p.gain, p.clamp);
+            const int col = j + 8 * wv + 4 * lh;
+            const float v = nb_sm_epilogue(sum * s_epi[s_ * 32 + col] + nz, s_epi[64 + col], p.alpha, p.gain, p.clamp);
             p.y[((size_t)ns * p.c_out + co) * Po + (size_t)oyo * Wo + oxo] = v;
         }
     }
