@@ -57,7 +57,7 @@ __device__ __forceinline__ float nb_sm_epilogue(float v, float bias, float alpha
 }
 
 __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const SmallParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 2 * 4 * NB_SM_NHP * 16];     // [wave][buf][plane][slot]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 4 * NB_SM_NHP * 16];     // [wave][plane][slot] (26 KB: fits next to a large-tile workgroup)
     __shared__ float s_sty[2 * NB_SM_MAX_CIN];
     __shared__ float s_epi[96];
     const int tid = threadIdx.x;
@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
     const int hb = ps * (HR * HC) + pty * HC + ptx;             // + ky * HC + kx
     const int pbase = lh * 2 * NB_SM_NHP + hb;                  // plane (cg = lh, hi); lo = + NB_SM_NHP
 
-    h8* mybuf = reinterpret_cast<h8*>(smem) + wv * (2 * 4 * NB_SM_NHP);
-    {   // zero padding: slots outside the image are never staged, they keep this zero (both buffers, all planes)
+    h8* mybuf = reinterpret_cast<h8*>(smem) + wv * (4 * NB_SM_NHP);
+    {   // zero padding: slots outside the image are never staged, they keep this zero
         const h8 z8 = {};
-        for (int i = lane; i < 2 * 4 * NB_SM_NHP; i += 64) mybuf[i] = z8;
+        for (int i = lane; i < 4 * NB_SM_NHP; i += 64) mybuf[i] = z8;
     }
     const unsigned wstep = (unsigned)(p.co_ld * 8);
     // + ((chunk*9 + tap)*4 + hl) * co_ld * 8  (halves); one weight set per output phase
@@ -160,8 +160,9 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][1], bh, acc, 0, 0, 0);
         }
     };
-    // wave-private LDS hand-over: all lanes' slot writes must have landed before any lane's fragment reads, and the
-    // reads of a buffer must be done before it is written again (same wave: program order + lgkmcnt)
+    // wave-private LDS hand-over: all lanes' slot writes must have landed before any lane's fragment reads.  ONE buffer
+    // suffices: a wave's LDS instructions execute in program order, so the next chunk's slot writes (issued after this
+    // chunk's fragment reads) cannot overtake them
     auto wave_sync = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -202,10 +203,10 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const S
         c = cn;
         if (c >= NC) break;
         cn = c + 4;
-        stage(c, xr1, mybuf + 4 * NB_SM_NHP);
+        stage(c, xr1, mybuf);
         if (cn < NC) { load_w(cn, wa0); load_x(cn, xr0); }
         wave_sync();
-        mfma_chunk(wa1, mybuf + 4 * NB_SM_NHP);
+        mfma_chunk(wa1, mybuf);
         c = cn;
     }
 
