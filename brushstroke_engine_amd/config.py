@@ -9,6 +9,7 @@ geometry features are concatenated and how many ``ws`` each block consumes.
 from __future__ import annotations
 
 import dataclasses
+import functools
 import json
 import math
 from typing import List, Optional, Tuple
@@ -55,7 +56,7 @@ class GeneratorConfig:
         assert self.c_dim == 0, "conditioning labels are not part of the NeuBE path (c_dim=0)"
 
     # ---- shape rules (networks_modified.py:63-118) ----
-    @property
+    @functools.cached_property
     def block_resolutions(self) -> List[int]:
         return [2 ** i for i in range(2, int(math.log2(self.img_resolution)) + 1)]
 
@@ -68,8 +69,9 @@ class GeneratorConfig:
             return self.geom_feature_channels[self.geom_feature_resolutions.index(res)]
         return 0
 
-    @property
+    @functools.cached_property
     def layers(self) -> List[LayerSpec]:
+        """All modulated-conv layers in execution order (computed once: the forward pass consults it per layer)."""
         out: List[LayerSpec] = []
         w = 0
         for res in self.block_resolutions:
