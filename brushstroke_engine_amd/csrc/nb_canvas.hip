@@ -59,13 +59,19 @@ __global__ __launch_bounds__(256) void canvas_replay_kernel(ReplayParams p) {
     if (cx >= p.wc || cy >= p.hc) return;
     const size_t cplane = (size_t)p.hc * p.wc;
     const size_t cpix = (size_t)cy * p.wc + cx;
+    const int k0 = p.cell_off[cell], k1 = p.cell_off[cell + 1];
+    if (k0 == k1) {
+        // no tile touches this cell (an interactive stroke replays ONE tile on a large canvas): the canvas stays as it
+        // is, only the mask moves to the other buffer
+        if (blockIdx.z == 0) p.mask_out[cpix] = p.mask_in[cpix];
+        return;
+    }
     float cv[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) cv[c] = (c0 + c < p.c) ? p.canvas[(size_t)(c0 + c) * cplane + cpix] : 0.f;
     bool m = p.mask_in[cpix] != 0;
-    const int k1 = p.cell_off[cell + 1];
     const size_t tplane = (size_t)p.hw * p.hw;
-    for (int k = p.cell_off[cell]; k < k1; ++k) {
+    for (int k = k0; k < k1; ++k) {
         const int t = p.cell_tiles[k];
         const int ly = cy - p.tile_yx[2 * t], lx = cx - p.tile_yx[2 * t + 1];
         if (ly < 0 || ly >= p.hw || lx < 0 || lx >= p.hw) continue;

@@ -18,6 +18,7 @@
 //   enc_upsample2x_h2_kernel  bilinear x2, align_corners=True, fp32 NCHW -> H2 (input of the decoder conv).
 // Layer outputs go out as H2 (next layer's input) or fp32 NCHW (what the generator consumes).
 #include "nb_common.h"
+#include <cstdlib>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -359,6 +360,160 @@ static int launch_enc_conv(EncConvParams p, int n, hipStream_t st) {
     return NB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layer for launches the 128 c_out x 256 pixel tiles above cannot fill the chip with (one interactive stroke =
+// ONE tile: 4 - 32 workgroups that each walk up to 48 double-buffered steps, i.e. ~2 us of exposed DMA latency per
+// step).  Structure of modconv3x3_up1_small_h3_kernel (nb_modconv_small.hip): 4 waves = one tile of 32 c_out x 32
+// output positions, the waves SPLIT K (wave w owns the 16-channel chunks w, w+4, ...) and meet only in the final LDS
+// reduction; weight fragments go from global memory straight into registers, a whole chunk ahead; the chunk's H2
+// activations (tile + halo, reflect padding = address arithmetic) are gathered by LDS-DMA into a wave-private,
+// double-buffered region - for stride 2 simply the (2 rows + 1) x (2 cols + 1) input window, tap (ky, kx) of output
+// (ty, tx) reads slot (2 ty + ky, 2 tx + kx).
+// ------------------------------------------------------------------------------------------------
+struct EncSmallParams {
+    const _Float16* x; const _Float16* wts; const float* bias; float* y32; _Float16* yh2;
+    int c8, nchunks, c_out, co_ld, hin, win, hout, wout, rows, cols, tiles_x, slices;
+    float slope;
+};
+
+template <int STRIDE, int OUT>
+__global__ __launch_bounds__(256) void enc_conv3x3_small_h3_kernel(const EncSmallParams p) {
+    constexpr int PP = STRIDE == 2 ? 4 : 2, NHP = PP * 64;         // 64-slot DMA pieces / slots per (cg, hi/lo) plane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_es[];     // [wave 4][buf 2][plane 4][NHP] slots
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
+    int b = blockIdx.x;
+    const int slice = b % p.slices; b /= p.slices;
+    const int tile_x = b % p.tiles_x, tile_y = b / p.tiles_x;
+    const int n = blockIdx.y;
+    const int y0 = tile_y * p.rows, x0 = tile_x * p.cols, co0 = slice * 32;
+    const int HR = STRIDE * p.rows + (3 - STRIDE), HC = STRIDE * p.cols + (3 - STRIDE), NH = HR * HC;
+    const size_t HW8 = (size_t)p.hin * p.win * 8;
+    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+
+    // gather descriptors: piece q of a plane, lane -> halo slot e = q*64 + lane -> reflected input pixel
+    int xsrc[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+        int e = q * 64 + lane;
+        e = e < NH ? e : NH - 1;                                     // (tail lanes re-copy the last slot: never read)
+        const int hy = e / HC, hx = e - hy * HC;
+        const int iy = nb_reflect(STRIDE * y0 - 1 + hy, p.hin), ix = nb_reflect(STRIDE * x0 - 1 + hx, p.win);
+        xsrc[q] = (iy * p.win + ix) * 8;
+    }
+    h8* mybuf = reinterpret_cast<h8*>(smem_es) + wv * (2 * 4 * NHP);
+    auto issue_x = [&](int c, h8* buf) {
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+                const _Float16* src = xn + (size_t)(4 * c + pl) * HW8 + xsrc[q];
+                __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(buf + pl * NHP + q * 64), 16, 0, 0);
+            }
+    };
+    const unsigned wstep = (unsigned)(p.co_ld * 8);
+    const unsigned wl = (unsigned)((lh * 2 * p.co_ld + co0 + l31) * 8);
+    auto load_w = [&](int c, h8 (&wa)[9][2]) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                wa[tap][hl] = *reinterpret_cast<const h8*>(p.wts + (wl + (unsigned)((c * 9 + tap) * 4 + hl) * wstep));
+    };
+    // this lane's output position and the slot of its tap (0, 0)
+    const int pty = l31 / p.cols, ptx = l31 - pty * p.cols;
+    const int pbase = lh * 2 * NHP + (STRIDE * pty) * HC + STRIDE * ptx;     // plane (cg = lh, hi); lo = + NHP
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mfma_chunk = [&](const h8 (&wa)[9][2], const h8* buf) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int off = pbase + (tap / 3) * HC + (tap % 3);
+            const h8 bh = buf[off], bl = buf[off + NHP];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][0], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][0], bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][1], bh, acc, 0, 0, 0);
+        }
+    };
+    h8 wa0[9][2], wa1[9][2];
+    const int NC = p.nchunks;
+    int c = wv;
+    if (c < NC) { issue_x(c, mybuf); load_w(c, wa0); }
+    while (c < NC) {
+        int cn = c + 4;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // chunk c: slots in LDS, fragments in registers
+        __builtin_amdgcn_wave_barrier();
+        if (cn < NC) { issue_x(cn, mybuf + 4 * NHP); load_w(cn, wa1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(wa0, mybuf);
+        c = cn;
+        if (c >= NC) break;
+        cn = c + 4;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (cn < NC) { issue_x(cn, mybuf); load_w(cn, wa0); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(wa1, mybuf + 4 * NHP);
+        c = cn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_es);                  // [wave 4][reg 16][lane 64]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wv * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    const int oy = y0 + pty, ox = x0 + ptx;
+    if (oy >= p.hout || ox >= p.wout) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wv * 4 + j;
+        const int co = co0 + j + 8 * wv + 4 * lh;
+        const float sum = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane];
+        v[j] = co < p.c_out ? nb_lrelu(sum + p.bias[co], p.slope) : 0.f;
+    }
+    if (OUT == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + j + 8 * wv + 4 * lh;
+            if (co < p.c_out) p.y32[(((size_t)n * p.c_out + co) * p.hout + oy) * p.wout + ox] = v[j];
+        }
+    } else {
+        // H2: channel group cg = (co0 + 8 wv) / 8, this lane's 4 channels are halves 4*lh .. 4*lh+3 of the pixel's slot
+        const int c8o = (p.c_out + 7) / 8, cg = (co0 >> 3) + wv;
+        if (cg < c8o) {
+            h4 vh, vl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const _Float16 hi = (_Float16)v[j]; vh[j] = hi; vl[j] = (_Float16)(v[j] - (float)hi); }
+            const size_t OHW8 = (size_t)p.hout * p.wout * 8;
+            _Float16* dst = p.yh2 + ((size_t)n * c8o + cg) * 2 * OHW8 + ((size_t)oy * p.wout + ox) * 8 + 4 * lh;
+            *reinterpret_cast<h4*>(dst) = vh;
+            *reinterpret_cast<h4*>(dst + OHW8) = vl;
+        }
+    }
+}
+
+template <int STRIDE, int OUT>
+static int launch_enc_small(EncSmallParams p, int n, hipStream_t st) {
+    constexpr int NHP = (STRIDE == 2 ? 4 : 2) * 64;
+    constexpr size_t lds = (size_t)4 * 2 * 4 * NHP * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)enc_conv3x3_small_h3_kernel<STRIDE, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int tiles_y = p.hout / p.rows;
+    hipLaunchKernelGGL((enc_conv3x3_small_h3_kernel<STRIDE, OUT>), dim3(p.tiles_x * tiles_y * p.slices, n), dim3(256), lds, st, p);
+    NB_CHECK_LAUNCH("enc_conv3x3_small_h3");
+    return NB_OK;
+}
+
+static int g_enc_small = -1;
+// developer / test hook: -1 = automatic choice between the two tile forms of enc_conv3x3, 0 = large tiles, 1 = small tiles
+extern "C" void nb_debug_set_enc_small(int mode) { g_enc_small = mode; }
+
 extern "C" int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2,
                                  int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
     NB_REQUIRE(x_h2 && w_h3 && bias && ((y_f32 != nullptr) != (y_h2 != nullptr)), "enc_conv3x3_h3: need x, w, bias and exactly one output");
@@ -376,6 +531,23 @@ extern "C" int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, c
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 127) / 128 * 128;
     p.hin = h_in; p.win = w_in; p.hout = ho; p.wout = wo; p.slope = slope;
     hipStream_t st = (hipStream_t)stream;
+    {
+        // under-filled launch (interactive strokes, small batches): the 32 x 32 split-K tiles instead.  Needs whole
+        // 16-channel chunks and an output width that is a power of two >= 8 (32 positions = 32 / w rows).
+        const long big_wgs = (long)n * (wo / (wide ? 32 : 16)) * (ho / (wide ? 8 : 16)) * ((c_out + 127) / 128);
+        static const int env_force = getenv("NB_ENC_SMALL") ? atoi(getenv("NB_ENC_SMALL")) : -1;
+        const int force = g_enc_small >= 0 ? g_enc_small : env_force;
+        const bool pow2 = (wo & (wo - 1)) == 0 && wo >= 8;
+        const bool small = force >= 0 ? force != 0 : (big_wgs <= 48 && c_in >= 32);
+        if (small && pow2 && c_in % 16 == 0 && (wo >= 32 || ho % (32 / wo) == 0)) {
+            EncSmallParams q;
+            q.x = p.x; q.wts = p.wts; q.bias = bias; q.y32 = y_f32; q.yh2 = (_Float16*)y_h2;
+            q.c8 = p.c8; q.nchunks = p.nchunks; q.c_out = c_out; q.co_ld = p.co_ld; q.hin = h_in; q.win = w_in; q.hout = ho; q.wout = wo;
+            q.cols = wo >= 32 ? 32 : wo; q.rows = 32 / q.cols; q.tiles_x = wo / q.cols; q.slices = (c_out + 31) / 32; q.slope = slope;
+            if (stride == 2) return y_h2 ? launch_enc_small<2, 1>(q, n, st) : launch_enc_small<2, 0>(q, n, st);
+            return y_h2 ? launch_enc_small<1, 1>(q, n, st) : launch_enc_small<1, 0>(q, n, st);
+        }
+    }
     const int key = (stride == 2 ? 4 : 0) | (wide ? 2 : 0) | (y_h2 ? 1 : 0);
     switch (key) {
         case 0: return launch_enc_conv<1, 4, 0>(p, n, st);

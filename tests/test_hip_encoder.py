@@ -55,8 +55,18 @@ def test_encoder_matches_oracle(res, n, pre):
 @pytest.mark.parametrize("stride,ci,co,h,w,h2out", [(1, 16, 256, 32, 32, False), (2, 64, 128, 64, 64, True),
                                                      (2, 256, 256, 32, 32, True), (1, 32, 16, 16, 16, False),
                                                      (1, 256, 32, 16, 16, True), (2, 128, 256, 64, 128, False)])
-def test_enc_conv_layer(stride, ci, co, h, w, h2out):
-    """One layer against torch fp64 (reflect pad, cross-correlation), both output formats, both tile shapes."""
+@pytest.mark.parametrize("small", [0, 1])
+def test_enc_conv_layer(stride, ci, co, h, w, h2out, small):
+    """One layer against torch fp64 (reflect pad, cross-correlation), both output formats, both tile shapes, and both
+    kernels: the 128 c_out x 256 pixel tiles (small=0) and the 32 x 32 split-K tiles of under-filled launches (small=1)."""
+    _lib.lib().nb_debug_set_enc_small(small)
+    try:
+        _enc_conv_layer_case(stride, ci, co, h, w, h2out)
+    finally:
+        _lib.lib().nb_debug_set_enc_small(-1)
+
+
+def _enc_conv_layer_case(stride, ci, co, h, w, h2out):
     rs = np.random.RandomState(ci + co)
     n = 2
     x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32))
