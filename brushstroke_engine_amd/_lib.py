@@ -87,6 +87,8 @@ PROTOTYPES = {
     "nb_geom_tiles_f32": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
     "nb_canvas_replay_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                        vp, vp, vp]),
+    "nb_canvas_replay_box_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                       vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "nb_paste_tiles_u8": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     "nb_enc_stem7x7_f32_h2": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_enc_conv3x3_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),

@@ -48,14 +48,16 @@ struct ReplayParams {
     const int* cell_off;     // [ncells + 1]
     const int* cell_tiles;   // tile indices per cell, ascending = the reference's paint order
     int c, hw, hc, wc, crop;
+    int cell_x0, cell_y0, cells_per_row;       // launch covers cells [cell_y0 + blockIdx.y][cell_x0 + blockIdx.x]
 };
 
 template <int CG>
 __global__ __launch_bounds__(256) void canvas_replay_kernel(ReplayParams p) {
-    const int cx = blockIdx.x * NB_CELL_W + (threadIdx.x & (NB_CELL_W - 1));
-    const int cy = blockIdx.y * NB_CELL_H + (threadIdx.x / NB_CELL_W);
+    const int bx = blockIdx.x + p.cell_x0, by = blockIdx.y + p.cell_y0;
+    const int cx = bx * NB_CELL_W + (threadIdx.x & (NB_CELL_W - 1));
+    const int cy = by * NB_CELL_H + (threadIdx.x / NB_CELL_W);
     const int c0 = blockIdx.z * CG;
-    const int cell = blockIdx.y * gridDim.x + blockIdx.x;
+    const int cell = by * p.cells_per_row + bx;
     if (cx >= p.wc || cy >= p.hc) return;
     const size_t cplane = (size_t)p.hc * p.wc;
     const size_t cpix = (size_t)cy * p.wc + cx;
@@ -99,21 +101,39 @@ __global__ __launch_bounds__(256) void canvas_replay_kernel(ReplayParams p) {
     if (blockIdx.z == 0) p.mask_out[cpix] = m ? 1 : 0;
 }
 
-extern "C" int nb_canvas_replay_f32(float* tiles, int t, int c, int hw, const int32_t* tile_yx, const float* alpha0,
-                                    int crop, float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
-                                    const int32_t* cell_off,
-                                    const int32_t* cell_tiles, void* stream) {
+static int nb_canvas_replay_impl(float* tiles, int t, int c, int hw, const int32_t* tile_yx, const float* alpha0, int crop,
+                                 float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc, const int32_t* cell_off,
+                                 const int32_t* cell_tiles, int cell_x0, int cell_y0, int cells_x, int cells_y, void* stream) {
     NB_REQUIRE(tiles && tile_yx && alpha0 && canvas && mask_in && mask_out && cell_off && cell_tiles,
                "canvas_replay: null pointer");
     NB_REQUIRE(mask_in != mask_out, "canvas_replay: mask_in and mask_out must be different buffers");
     NB_REQUIRE(t >= 1 && c >= 1 && hw >= 1 && hc >= 1 && wc >= 1 && crop >= 0 && 2 * crop <= hw, "canvas_replay: bad sizes");
-    ReplayParams p{tiles, tile_yx, alpha0, canvas, mask_in, mask_out, cell_off, cell_tiles, c, hw, hc, wc, crop};
+    const int cpr = nb_cdiv(wc, NB_CELL_W), cpc = nb_cdiv(hc, NB_CELL_H);
+    NB_REQUIRE(cell_x0 >= 0 && cell_y0 >= 0 && cells_x >= 1 && cells_y >= 1 && cell_x0 + cells_x <= cpr && cell_y0 + cells_y <= cpc,
+               "canvas_replay: cell box outside the canvas");
+    ReplayParams p{tiles, tile_yx, alpha0, canvas, mask_in, mask_out, cell_off, cell_tiles, c, hw, hc, wc, crop, cell_x0, cell_y0, cpr};
     constexpr int CG = 8;
-    dim3 grid(nb_cdiv(wc, NB_CELL_W), nb_cdiv(hc, NB_CELL_H), nb_cdiv(c, CG));
+    dim3 grid(cells_x, cells_y, nb_cdiv(c, CG));
     NB_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "canvas_replay: canvas too large");
     hipLaunchKernelGGL(canvas_replay_kernel<CG>, grid, dim3(256), 0, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("canvas_replay");
     return NB_OK;
+}
+
+extern "C" int nb_canvas_replay_f32(float* tiles, int t, int c, int hw, const int32_t* tile_yx, const float* alpha0,
+                                    int crop, float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
+                                    const int32_t* cell_off,
+                                    const int32_t* cell_tiles, void* stream) {
+    return nb_canvas_replay_impl(tiles, t, c, hw, tile_yx, alpha0, crop, canvas, mask_in, mask_out, hc, wc, cell_off, cell_tiles,
+                                 0, 0, nb_cdiv(wc, NB_CELL_W), nb_cdiv(hc, NB_CELL_H), stream);
+}
+
+extern "C" int nb_canvas_replay_box_f32(float* tiles, int t, int c, int hw, const int32_t* tile_yx, const float* alpha0,
+                                        int crop, float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
+                                        const int32_t* cell_off, const int32_t* cell_tiles, int cell_x0, int cell_y0,
+                                        int cells_x, int cells_y, void* stream) {
+    return nb_canvas_replay_impl(tiles, t, c, hw, tile_yx, alpha0, crop, canvas, mask_in, mask_out, hc, wc, cell_off, cell_tiles,
+                                 cell_x0, cell_y0, cells_x, cells_y, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -313,12 +313,23 @@ class TileOps:
         return (torch.zeros([1, c, hc, wc], dtype=torch.float32, device=self.device),
                 torch.zeros([hc, wc], dtype=torch.uint8, device=self.device))
 
-    def replay(self, tiles, tile_yx, alpha0, crop, canvas, mask, cell_off, cell_tiles) -> torch.Tensor:
-        """In place on ``tiles`` and ``canvas``; returns the new mask buffer."""
+    def replay(self, tiles, tile_yx, alpha0, crop, canvas, mask, cell_off, cell_tiles, box=None) -> torch.Tensor:
+        """In place on ``tiles`` and ``canvas``; returns the new mask buffer.  ``box`` = (y0, x0, y1, x1) canvas pixels
+        that contain every tile (an interactive stroke replays one tile on a large canvas): only those cells run."""
         t, c, hw, _ = tiles.shape
         hc, wc = mask.shape
-        mask_out = torch.empty_like(mask)
         with torch.cuda.device(self.device):
+            if box is not None:
+                y0, x0 = max(0, box[0]) // CELL_H, max(0, box[1]) // CELL_W
+                y1, x1 = -(-min(hc, box[2]) // CELL_H), -(-min(wc, box[3]) // CELL_W)
+                if y1 <= y0 or x1 <= x0:
+                    return mask
+                mask_out = mask.clone()
+                _lib.check(_lib.lib().nb_canvas_replay_box_f32(_p(tiles), t, c, hw, _p(tile_yx), _p(alpha0), crop, _p(canvas),
+                                                               _p(mask), _p(mask_out), hc, wc, _p(cell_off), _p(cell_tiles),
+                                                               x0, y0, x1 - x0, y1 - y0, self._stream()), "canvas_replay")
+                return mask_out
+            mask_out = torch.empty_like(mask)
             _lib.check(_lib.lib().nb_canvas_replay_f32(_p(tiles), t, c, hw, _p(tile_yx), _p(alpha0), crop, _p(canvas),
                                                        _p(mask), _p(mask_out), hc, wc, _p(cell_off), _p(cell_tiles),
                                                        self._stream()), "canvas_replay")
@@ -505,8 +516,13 @@ class PaintingHelper:
                 self.features, self.mask = ops.new_feature_canvas(C, -(-self.rows // df), -(-self.cols // df))
             hc, wc = self.mask.shape
             off, lst = build_cells(rects, hc, wc)
+            # few tiles on a large canvas (interactive strokes): replay only the cells inside their bounding box
+            box = None
+            if len(slot) * bres * bres * 4 < hc * wc:
+                r_ = rects[slot]
+                box = (int(r_[:, 0].min()), int(r_[:, 1].min()), int(r_[:, 2].max()), int(r_[:, 3].max()))
             self.mask = ops.replay(feats_all, ops.to_device(tile_yx_sc), self._alpha0(bres, margin, crop_sc), crop_sc,
-                                   self.features, self.mask, ops.to_device(off), ops.to_device(lst))
+                                   self.features, self.mask, ops.to_device(off), ops.to_device(lst), **({"box": box} if box else {}))
             # phase 3: last block(s) + ToRGB + compositing on the blended features, own tiles
             for i, (b0, b1) in enumerate(batches()):
                 with on_stream(i):

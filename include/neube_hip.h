@@ -328,6 +328,14 @@ int nb_canvas_replay_f32(float* tiles, int t, int c, int hw, const int32_t* tile
                          float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
                          const int32_t* cell_off, const int32_t* cell_tiles, void* stream);
 
+/* The same restricted to the cells [cell_y0, cell_y0 + cells_y) x [cell_x0, cell_x0 + cells_x) (cell = NB_CELL_H x NB_CELL_W
+ * canvas pixels, the granularity of cell_off): for the interactive stroke, which replays ONE tile on a large canvas.
+ * mask_out is only written inside the box - the caller starts it as a copy of mask_in. */
+int nb_canvas_replay_box_f32(float* tiles, int t, int c, int hw, const int32_t* tile_yx, const float* alpha0,
+                             int crop, float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
+                             const int32_t* cell_off, const int32_t* cell_tiles, int cell_x0, int cell_y0,
+                             int cells_x, int cells_y, void* stream);
+
 /* Paste RGBA8 tiles [t,r,r,4] into canvas [h,w,4]: the interior [crop, r-crop)^2 of tile i lands at
  * dst_yx[i] + crop (brush.py:369-374 crop + out_meta, paint_image_main.py:173-177 paste); later tiles
  * overwrite earlier ones.  Cells are taken over the RGBA canvas from the interior rectangles. */

@@ -55,7 +55,7 @@ class OracleTileOps:
     def new_feature_canvas(self, c, hc, wc):
         return torch.zeros([1, c, hc, wc]), torch.zeros([hc, wc], dtype=torch.uint8)
 
-    def replay(self, tiles, tile_yx, alpha0, crop, canvas, mask, cell_off, cell_tiles):
+    def replay(self, tiles, tile_yx, alpha0, crop, canvas, mask, cell_off, cell_tiles, box=None):
         return sequential_replay(tiles, tile_yx, alpha0, crop, canvas, mask)
 
     def paste(self, canvas_u8, tiles_u8, dst_yx, crop, cell_off, cell_tiles):
