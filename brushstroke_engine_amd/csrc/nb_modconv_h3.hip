@@ -137,6 +137,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     constexpr int WSLOTS = 12 * CO_WG;            // slots of one (chunk, tap row) weight sub-chunk: [kx][cg][hl][c_out]
     constexpr int NWP = WSLOTS / 64, NWPW = (NWP + NW - 1) / NW;
     constexpr int WST = 4;                        // weight ring depth
+    static_assert(WST == 4, "the ring indices below are written as (t & 3)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
     h8* xbuf = reinterpret_cast<h8*>(smem_h3);                    // [2][4 planes][XPL]
     h8* wring = xbuf + 2 * 4 * XPL;                               // [WST][WSLOTS]
