@@ -228,6 +228,7 @@ class TileOps:
         self.cfg = G.cfg
         self._streams = None
         self._forked = set()
+        self._graphs, self._graph_epoch, self._capturing = {}, None, False
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -265,19 +266,74 @@ class TileOps:
     # streams (``stream``/``join_streams``), each with its own workspace, so that one batch's kernel tails and small
     # launches are covered by the other batch's work
     def head(self, ws, geom_feats, positions, stop_res: int, slot: int = 0) -> torch.Tensor:
+        if self._use_graph(ws):
+            return self._graphed(("head", stop_res), [ws, geom_feats[0], geom_feats[1], positions],
+                                 lambda w, g0, g1, ps: self.head(w, [g0, g1], ps, stop_res, slot=self._GRAPH_SLOT))
         return self.G.forward_pre_mapped(ws, geom_feats, positions=positions, noise_mode="const", _stop_after=stop_res,
                                          _plan_slot=slot)
 
     def tail(self, ws, feats, geom_feats, positions, resume_res: int, render_mode, user_colors, sfactor=None,
              slot: int = 0) -> torch.Tensor:
+        if self._use_graph(ws) and (sfactor is None or torch.is_tensor(sfactor)):
+            return self._graphed(("tail", resume_res, render_mode), [ws, feats, geom_feats[0], geom_feats[1], positions, user_colors, sfactor],
+                                 lambda w, f, g0, g1, ps, uc, sf: self.tail(w, f, [g0, g1], ps, resume_res, render_mode, uc, sf,
+                                                                           slot=self._GRAPH_SLOT + 1))
         u8, _, _ = self.G.render_triad(ws=ws, geom_feature=geom_feats, positions=positions, render_mode=render_mode,
                                        user_colors=user_colors, sfactor=sfactor, _resume=(resume_res, feats), _plan_slot=slot)
         return u8
 
     def full(self, ws, geom_feats, positions, render_mode, user_colors, sfactor=None, slot: int = 0) -> torch.Tensor:
+        if self._use_graph(ws) and (sfactor is None or torch.is_tensor(sfactor)):
+            return self._graphed(("full", render_mode), [ws, geom_feats[0], geom_feats[1], positions, user_colors, sfactor],
+                                 lambda w, g0, g1, ps, uc, sf: self.full(w, [g0, g1], ps, render_mode, uc, sf,
+                                                                         slot=self._GRAPH_SLOT + 2))
         u8, _, _ = self.G.render_triad(ws=ws, geom_feature=geom_feats, positions=positions, render_mode=render_mode,
                                        user_colors=user_colors, sfactor=sfactor, _plan_slot=slot)
         return u8
+
+    # -- hipGraph replay of the generator passes of ONE tile (interactive strokes) --
+    # An interactive stroke is bound by the ~0.2 ms of Python each eager generator pass costs, not by the device.  With
+    # ``graph_single`` set (PaintingHelper.render_stroke does), the passes of a single tile are captured once per call
+    # signature into hipGraphs that own a workspace slot; a call then copies its inputs into the graph's static
+    # tensors and replays.  The returned tensor is the graph's output buffer: valid until the next call of that pass.
+    graph_single = False
+    _GRAPH_SLOT = 16
+
+    def _use_graph(self, ws) -> bool:
+        return (self.graph_single and not self._capturing and ws.shape[0] == 1 and len(self.cfg.geom_feature_channels) == 2
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _graphed(self, key, tensors, fn):
+        packed = self.G.synthesis.packed
+        if self._graph_epoch is not packed:                   # weights were (re)loaded / moved: captured pointers are stale
+            self._graphs, self._graph_epoch = {}, packed
+        key = key + tuple(None if t is None else (tuple(t.shape), t.dtype) for t in tensors)
+        ent = self._graphs.get(key)
+        if ent is None:
+            statics = [None if t is None else t.detach().clone() for t in tensors]
+            self._capturing = True
+            try:
+                cur = torch.cuda.current_stream(self.device)
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):                # creates the slot's workspace, packs weights, warms the kernels
+                    for _ in range(2):
+                        fn(*statics)
+                cur.wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = fn(*statics)
+            finally:
+                self._capturing = False
+            ent = (graph, statics, out)
+            self._graphs[key] = ent
+        graph, statics, out = ent
+        for s_, t in zip(statics, tensors):
+            if s_ is not None:
+                s_.copy_(t, non_blocking=True)
+        graph.replay()
+        return out
 
     n_streams = 2
 
@@ -566,6 +622,8 @@ class PaintingHelper:
         ops.paste(out_canvas, rgba_all, ops.to_device(floored.astype(np.int32)), m, ops.to_device(off), ops.to_device(lst))
         return out_canvas
 
+    graph_strokes = True       # render_stroke replays hipGraph-captured generator passes (TileOps.graph_single)
+
     def render_stroke(self, stroke_patch: np.ndarray, canvas_patch, opts: GanBrushOptions, meta: Optional[dict] = None):
         """One R x R tile (reference contract, brush.py:244-398): ``stroke_patch`` [R,R,1|4] uint8 with opaque 255 =
         stroke; returns (RGBA uint8 [R-2m, R-2m, 4] numpy, None, {'x','y'}) and updates the feature canvas.
@@ -585,7 +643,14 @@ class PaintingHelper:
         fy, fx = (y // df) * df, (x // df) * df
         geom = (255 - stroke_patch[:, :, -1]).astype(np.uint8)                     # back to 255 = background
         pos = None if opts.position is None else opts.position.numpy().reshape(1, 2)
-        rgba = self._schedule(geom, np.zeros((1, 2), np.int64), np.array([[fy, fx]], np.int64), pos, opts, m)
+        prev = getattr(self.ops, "graph_single", None)
+        if prev is not None and self.graph_strokes:
+            self.ops.graph_single = True                  # one tile per call: replay captured generator passes
+        try:
+            rgba = self._schedule(geom, np.zeros((1, 2), np.int64), np.array([[fy, fx]], np.int64), pos, opts, m)
+        finally:
+            if prev is not None:
+                self.ops.graph_single = prev
         img = rgba[0, m:R - m, m:R - m].cpu().numpy()
         return np.ascontiguousarray(img), None, {"x": fx + m, "y": fy + m}
 

@@ -145,6 +145,34 @@ def test_render_stroke_interactive_sequence(eng):
     _canvas_close(result, g["canvas_level2_clear"])
 
 
+@pytest.mark.parametrize("level", [0, 2])
+def test_render_stroke_graph_replay_equals_eager(eng, level):
+    """render_stroke replays hipGraph-captured generator passes (TileOps.graph_single); the same stroke sequence with the
+    graphs switched off must give bit-identical tiles and feature canvas."""
+    g = eng["g"]
+    m = int(g["crop_margin"])
+    padded = g["geom_padded"]
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(eng["z"]), 594)
+    runs = []
+    for graphs in (True, False):
+        helper = painting.PaintingHelper(eng["ops"])
+        helper.graph_strokes = graphs
+        helper.make_new_canvas(padded.shape[0], padded.shape[1], feature_blending=level)
+        tiles = []
+        for y, x in g["crops"].tolist():
+            opts.set_position(x, y)
+            res, _, _ = helper.render_stroke((255 - padded[y:y + 128, x:x + 128])[..., None], None, opts,
+                                             meta={"x": x, "y": y, "crop_margin": m})
+            tiles.append(res)
+        runs.append((tiles, None if helper.features is None else helper.features.clone()))
+    assert eng["ops"].graph_single is False and len(eng["ops"]._graphs) >= 1
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert np.array_equal(a, b)
+    if level:
+        assert torch.equal(runs[0][1], runs[1][1])
+
+
 def test_torch_encoder_on_gpu_matches_reference(eng):
     """The PyTorch-ROCm (MIOpen) module kept for patch sizes the HIP encoder does not tile."""
     g = eng["g"]
