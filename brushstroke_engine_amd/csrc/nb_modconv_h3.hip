@@ -712,8 +712,8 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     NB_REQUIRE(p.zeros, "modconv3x3_up1_h3: could not allocate the zero page");
     p.noise_stride_n = noise_stride_n;
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
-    { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
-    { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
+    { static const int v = getenv("NB_DEBUG") ? atoi(getenv("NB_DEBUG")) : 0; p.dbg = v; }            // (read once per process)
+    { static const int v = getenv("NB_STAGGER") ? atoi(getenv("NB_STAGGER")) : 0; p.stagger_ticks = v; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.out_f8 = out_fmt;
@@ -726,8 +726,8 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     }
     // the 4-wave / 2-workgroups-per-CU form wins on small images (fewer, larger workgroups leave CUs idle there); on the
     // large layers both forms run at the same rate -- the chip is power-limited in these loops, not latency-limited
-    { const char* e = getenv("NB_UP1_SMALL");
-      const bool small = e ? atoi(e) != 0 : (h * w <= 32 * 32);
+    { static const int env_small = getenv("NB_UP1_SMALL") ? atoi(getenv("NB_UP1_SMALL")) : -1;
+      const bool small = env_small >= 0 ? env_small != 0 : (h * w <= 32 * 32);
       if (small && !f8 && (!tg || c_out <= 64)) return launch_h3s(p, n, (hipStream_t)stream); }
     // half-height tiles when the full ones leave the chip mostly idle (batch 1); g_force_nbw: test hook
     const long wgs_full = (long)n * (w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64));
@@ -1276,14 +1276,15 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     NB_REQUIRE(p.zeros, "modconv3x3_up2_h3: could not allocate the zero page");
     p.noise_stride_n = noise_stride_n;
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
-    { const char* e = getenv("NB_DEBUG"); p.dbg = e ? atoi(e) : 0; }
-    { const char* e = getenv("NB_STAGGER"); p.stagger_ticks = e ? atoi(e) : 0; }
+    { static const int v = getenv("NB_DEBUG") ? atoi(getenv("NB_DEBUG")) : 0; p.dbg = v; }            // (read once per process)
+    { static const int v = getenv("NB_STAGGER") ? atoi(getenv("NB_STAGGER")) : 0; p.stagger_ticks = v; }
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tiles_x = w / 32; p.slices = (c_out + 31) / 32;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.out_f8 = out_fmt;
     // tile height: the 12-row tiles unless they leave the chip mostly idle (batch-1 / interactive), then 5-row tiles
-    const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : (getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0);
+    static const int env_tqh = getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0;
+    const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
     const long wgs_big = (long)n * p.tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * p.slices;
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
