@@ -35,6 +35,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2/16
 PEAK_F16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA (spec, no sparsity); the split-f16 kernels
                                     # execute 3 (h3) or the time-equivalent of 2 (f8) MFMA FLOPs per algorithmic FLOP
 PEAK_FP8_MATRIX_TFLOPS = 5000.0     # dense fp8 MFMA (same guide)
+PEAK_HBM_GBPS = 8000.0              # HBM3E (same guide)
 
 
 def layer_flops(spec, batch):
@@ -381,6 +382,10 @@ def main():
                                             "2 fp8 MFMA FLOPs (both correction products in one K=64 block-scaled instruction per "
                                             "tap pair); frac = share of the matrix pipes' time (f16 peak 2500, fp8 peak 5000 TFLOP/s)"})
                                   if "_h3_" in dom_name else None),
+                "hbm": ({"what": "the same launches against the HBM roofline (MI355X_MICROARCH.md: ~8 TB/s): measured HBM bytes per "
+                                 "launch (traffic) / launch duration; the path is matrix-pipe bound, not HBM bound",
+                         "achieved": round(traffic / (dom_ms / dom_launches * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(traffic / (dom_ms / dom_launches * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)} if traffic else None),
                 "launch_ms": round(dom_ms / dom_launches, 4), "launches_per_step": dom_launches * sub,
                 "patches_per_launch": B // sub,
                 "concurrency": (f"{sub} sub-batches in flight on {sub} HIP streams: launch durations are measured while "
