@@ -1,0 +1,152 @@
+// Gradient building blocks of the modulated convolution for gfx950 (second slice): what
+// `conv2d_gradfix` (torch_utils/ops/conv2d_gradfix.py:107-168) obtains from cuDNN in the reference -
+//   * the gradient w.r.t. the input of a strided convolution = another convolution (nb_conv2d_f32: generic stride /
+//     padding / kernel size; the up = 1 layers reuse the fused forward kernel with swapped roles instead), and
+//   * the gradient w.r.t. the weights = a correlation of two feature maps over all pixels (nb_conv2d_wgrad_f32),
+// both exact fp32 on v_mfma_f32_32x32x2_f32 as implicit GEMMs whose operands are read straight from global memory
+// (L1/L2 serve the reuse).  These are FIRST, correct versions: no LDS tiling yet - the training path is not what this
+// round's performance work is about.
+#include "nb_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// y[n,co,oy,ox] = out_scale[n,co] * sum_{ci,a,b} (x[n,ci,oy*st+a-pad,ox*st+b-pad] * in_scale[n,ci]) * w[co,ci,a,b]
+// (cross-correlation, zero padding; scales optional).  Workgroup = 4 waves, wave tile = 32 c_out x 32 output pixels.
+// ------------------------------------------------------------------------------------------------
+struct ConvParams {
+    const float* x; const float* w; const float* in_scale; const float* out_scale; float* y;
+    int n, ci, h, wd, co, kh, kw, stride, pad, ho, wo;
+};
+
+__global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvParams p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, lk = lane >> 5;
+    const int n = blockIdx.z, co0 = blockIdx.y * 32;
+    const int pix = (blockIdx.x * 4 + wv) * 32 + l31;
+    const int npix = p.ho * p.wo;
+    const bool pvalid = pix < npix;
+    const int oy = pvalid ? pix / p.wo : 0, ox = pvalid ? pix - oy * p.wo : 0;
+    const int co = co0 + l31;
+    const bool cvalid = co < p.co;
+    const int ktaps = p.kh * p.kw;
+    const float* xn = p.x + (size_t)n * p.ci * p.h * p.wd;
+    const float* wr = p.w + (size_t)(cvalid ? co : 0) * p.ci * ktaps;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < p.ci; c0 += 2) {
+        const int c = c0 + lk;
+        const bool chv = c < p.ci;
+        const float sc = (chv && p.in_scale) ? p.in_scale[(size_t)n * p.ci + c] : 1.f;
+        const float* xc = xn + (size_t)(chv ? c : 0) * p.h * p.wd;
+        const float* wc = wr + (size_t)(chv ? c : 0) * ktaps;
+        for (int a = 0; a < p.kh; ++a) {
+            const int iy = oy * p.stride + a - p.pad;
+            for (int b = 0; b < p.kw; ++b) {
+                const int ix = ox * p.stride + b - p.pad;
+                float bv = 0.f, av = 0.f;
+                if (chv && pvalid && iy >= 0 && iy < p.h && ix >= 0 && ix < p.wd) bv = xc[(size_t)iy * p.wd + ix] * sc;
+                if (chv && cvalid) av = wc[a * p.kw + b];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+        }
+    }
+    if (!pvalid) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = co0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (o < p.co) {
+            const float s = p.out_scale ? p.out_scale[(size_t)n * p.co + o] : 1.f;
+            p.y[((size_t)n * p.co + o) * npix + pix] = acc[r] * s;
+        }
+    }
+}
+
+extern "C" int nb_conv2d_f32(const float* x, const float* w, const float* in_scale, const float* out_scale, float* y, int n,
+                             int c_in, int h, int wd, int c_out, int kh, int kw, int stride, int pad, void* stream) {
+    NB_REQUIRE(x && w && y, "conv2d: null pointer");
+    NB_REQUIRE(n >= 1 && n <= 65535 && c_in >= 1 && c_out >= 1 && h >= 1 && wd >= 1, "conv2d: bad sizes");
+    NB_REQUIRE(kh >= 1 && kw >= 1 && kh <= 7 && kw <= 7 && stride >= 1 && pad >= 0, "conv2d: kernel 1..7, stride >= 1, pad >= 0");
+    ConvParams p{x, w, in_scale, out_scale, y, n, c_in, h, wd, c_out, kh, kw, stride, pad, 0, 0};
+    p.ho = (h + 2 * pad - kh) / stride + 1; p.wo = (wd + 2 * pad - kw) / stride + 1;
+    NB_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d: empty output");
+    dim3 grid(nb_cdiv(p.ho * p.wo, 128), nb_cdiv(c_out, 32), n);
+    NB_REQUIRE(grid.y <= 65535, "conv2d: too many output channels");
+    hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("conv2d");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient correlation:  A[n,cu,cv,a,b] = sum_{i,j} U[n,cu, i*st+a-pad, j*st+b-pad] * V[n,cv,i,j]
+// (a, b in [0,3); zero outside U).  One wave per workgroup = one 32 (cu) x 32 (cv) tile of all 9 taps for a slice of
+// V's rows; the row slices add their partial sums atomically into A, which the caller zeroes.
+//   up = 1 layers: U = modulated input (pad 1, st 1), V = dL/d(conv output)  ->  A[n, c_in, c_out]
+//   up = 2 layers: U = FIR-adjoint of dL/dy on the (2H+1)^2 grid (pad 0, st 2), V = modulated input -> A[n, c_out, c_in]
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float* u; const float* v; float* a;
+    int n, cu, hu, wu, cv, hv, wv, stride, pad, rows_per_wg, nslices;
+};
+
+__global__ __launch_bounds__(64) void conv2d_wgrad_f32_kernel(const WgradParams p) {
+    const int lane = threadIdx.x, l31 = lane & 31, lk = lane >> 5;
+    const int cu0 = blockIdx.x * 32, cv0 = blockIdx.y * 32;
+    const int n = blockIdx.z / p.nslices, sl = blockIdx.z - n * p.nslices;
+    const int cu = cu0 + l31, cv = cv0 + l31;
+    const bool uval = cu < p.cu, vval = cv < p.cv;
+    const float* un = p.u + ((size_t)n * p.cu + (uval ? cu : 0)) * p.hu * p.wu;
+    const float* vn = p.v + ((size_t)n * p.cv + (vval ? cv : 0)) * p.hv * p.wv;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int i1 = min(p.hv, (sl + 1) * p.rows_per_wg);
+    for (int i = sl * p.rows_per_wg; i < i1; ++i) {
+        for (int j0 = 0; j0 < p.wv; j0 += 2) {
+            const int j = j0 + lk;
+            const bool jv = j < p.wv;
+            const float bv = (vval && jv) ? vn[(size_t)i * p.wv + j] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int y = i * p.stride + a - p.pad;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int x = j * p.stride + b - p.pad;
+                    float av = 0.f;
+                    if (uval && jv && y >= 0 && y < p.hu && x >= 0 && x < p.wu) av = un[(size_t)y * p.wu + x];
+                    acc[a * 3 + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a * 3 + b], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = cu0 + (r & 3) + 8 * (r >> 2) + 4 * lk;      // cu row of the D tile; this lane's column = cv
+            if (m < p.cu && vval) atomicAdd(p.a + (((size_t)n * p.cu + m) * p.cv + cv) * 9 + t, acc[t][r]);
+        }
+}
+
+extern "C" int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int n, int cu, int hu, int wu, int cv, int hv,
+                                   int wv, int stride, int pad, void* stream) {
+    NB_REQUIRE(u && v && a, "conv2d_wgrad: null pointer");
+    NB_REQUIRE(n >= 1 && cu >= 1 && cv >= 1 && hu >= 1 && wu >= 1 && hv >= 1 && wv >= 1 && stride >= 1 && pad >= 0, "conv2d_wgrad: bad sizes");
+    WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0};
+    // enough workgroups to fill the chip: slice V's rows when there are few (n, tile) combinations
+    const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 32);
+    int slices = (int)((1024 + tiles - 1) / tiles);
+    if (slices > hv) slices = hv;
+    if (slices < 1) slices = 1;
+    p.rows_per_wg = nb_cdiv(hv, slices);
+    const int nslices = nb_cdiv(hv, p.rows_per_wg);
+    p.nslices = nslices;
+    NB_REQUIRE((long)n * nslices <= 65535 && nb_cdiv(cv, 32) <= 65535, "conv2d_wgrad: grid too large");
+    (void)hipMemsetAsync(a, 0, (size_t)n * cu * cv * 9 * sizeof(float), (hipStream_t)stream);
+    dim3 grid(nb_cdiv(cu, 32), nb_cdiv(cv, 32), n * nslices);
+    hipLaunchKernelGGL(conv2d_wgrad_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("conv2d_wgrad");
+    return NB_OK;
+}

@@ -292,9 +292,140 @@ def pack_conv_weight(weight: torch.Tensor):
     return wpk, wsq
 
 
+def conv2d(x, w, in_scale=None, out_scale=None, stride=1, padding=0):
+    """Generic fp32 cross-correlation with zero padding and optional per-sample channel scales on the HIP kernel
+    (nb_conv2d_f32) - the role cuDNN plays behind ``conv2d_gradfix`` for strided gradients."""
+    _dev(x, "x"); _dev(w, "w")
+    n, ci, h, wd = x.shape
+    co, ci2, kh, kw = w.shape
+    assert ci == ci2
+    ho, wo = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
+    y = torch.empty([n, co, ho, wo], dtype=torch.float32, device=x.device)
+    isc = None if in_scale is None else in_scale.contiguous()
+    osc = None if out_scale is None else out_scale.contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nb_conv2d_f32(_p(x.contiguous()), _p(w.contiguous()), _p(isc), _p(osc), _p(y), n, ci, h, wd, co, kh, kw,
+                                            stride, padding, _stream(x)), "conv2d")
+    return y
+
+
+def conv2d_wgrad(u, v, stride=1, padding=0):
+    """a[n,cu,cv,ka,kb] = sum_{i,j} u[n,cu,i*stride+ka-pad,j*stride+kb-pad] * v[n,cv,i,j]  (3x3; nb_conv2d_wgrad_f32)."""
+    _dev(u, "u"); _dev(v, "v")
+    n, cu, hu, wu = u.shape
+    n2, cv, hv, wv = v.shape
+    assert n == n2
+    a = torch.empty([n, cu, cv, 3, 3], dtype=torch.float32, device=u.device)
+    with torch.cuda.device(u.device):
+        _lib.check(_lib.lib().nb_conv2d_wgrad_f32(_p(u.contiguous()), _p(v.contiguous()), _p(a), n, cu, hu, wu, cv, hv, wv,
+                                                  stride, padding, _stream(u)), "conv2d_wgrad")
+    return a
+
+
+class _ModulatedConv2d(torch.autograd.Function):
+    """First-order gradients of the fused modulated convolution (what autograd + ``conv2d_gradfix`` + the upfirdn2d
+    backward give the reference, networks.py:30-88).  With xs = x * s, z = conv_resample(xs, W), y = z * d + noise,
+    d = rsqrt(sum (W s)^2 + 1e-8):
+
+      dz = dy * d;  dd = sum_pix dy * z;  dq = -1/2 d^3 dd   (q = the sum under the rsqrt)
+      up = 1:  dx = s * corr(dz, W^T flipped)  - the fused forward kernel with the roles of styles and demodulation
+               swapped (x <- dy, styles <- d, weights <- W^T flipped, dcoefs <- s);
+               A[n,o,c] = sum_pix dz[n,o,p] x[n,c,p+tap]          (nb_conv2d_wgrad_f32, U = x pad 1, V = dz)
+      up = 2:  g1 = FIR-adjoint of dz on the (2H+1)^2 grid (upfirdn2d with the filter flipped the other way),
+               dx = s * conv(g1, W^T, stride 2)                    (nb_conv2d_f32);
+               A[n,o,c] = sum_{i,j} g1[n,o,2i+a,2j+b] x[n,c,i,j]   (nb_conv2d_wgrad_f32, U = g1, V = x, stride 2)
+      dW = sum_n s A + 2 W sum_n dq s^2;   ds = sum_{o,tap} W A + 2 s (dq @ Wsq);   dnoise = dy (summed over broadcast dims)
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, noise, up, resample_filter, demodulate):
+        n, o = x.shape[0], weight.shape[0]
+        wsq = weight.detach().square().sum(dim=[2, 3])                       # [O, C]
+        if demodulate:
+            d = (styles.detach().square() @ wsq.t() + 1e-8).rsqrt()          # [N, O]  (tiny GEMM: plumbing)
+        else:
+            d = torch.ones([n, o], dtype=torch.float32, device=x.device)
+        y = _modulated_conv2d_forward(x.detach(), weight.detach(), styles.detach(), None if noise is None else noise.detach(),
+                                      up=up, padding=1, resample_filter=resample_filter, demodulate=demodulate,
+                                      flip_weight=(up == 1), dcoefs=d)
+        ctx.up, ctx.demodulate = up, demodulate
+        ctx.noise_shape = None if noise is None else noise.shape
+        ctx.save_for_backward(x, weight, styles, noise, d, y, resample_filter)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, styles, noise, d, y, f = ctx.saved_tensors
+        up = ctx.up
+        dy = dy.contiguous()
+        n, c, h, w_ = x.shape
+        o = weight.shape[0]
+        need_x, need_w, need_s, need_nz = ctx.needs_input_grad[:4]
+        dx = dw = ds = dnz = None
+        if need_nz and noise is not None:
+            dnz = dy
+            for dim, (a, b) in enumerate(zip(dy.shape, ctx.noise_shape)):
+                if b == 1 and a != 1:
+                    dnz = dnz.sum(dim=dim, keepdim=True)
+        s = styles.detach()
+        wd = weight.detach()
+        if up == 1:
+            if need_x:
+                wt = wd.transpose(0, 1).flip([2, 3]).contiguous()           # [C, O, 3, 3]
+                dx = _modulated_conv2d_forward(dy, wt, d, None, up=1, padding=1, demodulate=False, flip_weight=True, dcoefs=s)
+            if need_w or need_s:
+                dz = dy * d[:, :, None, None]
+                A = conv2d_wgrad(x.detach(), dz, stride=1, padding=1).permute(0, 2, 1, 3, 4)     # [N, O, C, 3, 3]
+        else:
+            dz = dy * d[:, :, None, None]
+            fh, fw = f.shape
+            # adjoint of upfirdn2d(y1, f, padding=1, gain=4): pad fw - 1 - 1, filter flipped the other way
+            g1 = _upfirdn2d_apply(dz, f, (1, 1, 1, 1, fw - 2, fw - 2, fh - 2, fh - 2, True, 4.0))
+            if need_x:
+                dx = conv2d(g1, wd.transpose(0, 1), out_scale=s, stride=2, padding=0)
+            if need_w or need_s:
+                A = conv2d_wgrad(g1, x.detach(), stride=2, padding=0)        # [N, O, C, 3, 3]
+        if need_w or need_s:
+            dq = None
+            if ctx.demodulate:
+                z = y if noise is None else y - noise
+                dd = (dy * z).sum(dim=[2, 3]) / d                            # sum_pix dy * (z d) / d
+                dq = -0.5 * d.pow(3) * dd                                    # [N, O]
+            if need_w:
+                dw = torch.einsum("nc,nocab->ocab", s, A)
+                if dq is not None:
+                    dw = dw + 2.0 * wd * torch.einsum("no,nc->oc", dq, s.square())[:, :, None, None]
+            if need_s:
+                ds = torch.einsum("ocab,nocab->nc", wd, A)
+                if dq is not None:
+                    ds = ds + 2.0 * s * (dq @ wd.square().sum(dim=[2, 3]))
+        return dx, dw, ds, dnz, None, None, None
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                      flip_weight=True, fused_modconv=True, *, bias=None, act_gain=None, act_clamp=None,
                      fuse_bias_act=False, x2=None, wpk=None, dcoefs=None):
+    """3x3 modulated convolution, reference signature ``networks.modulated_conv2d`` (networks.py:30-88), with first-order
+    gradients w.r.t. x, weight, styles and noise when any of them requires grad (plain configuration: no fused bias /
+    second input); see :class:`_ModulatedConv2d`."""
+    wants_grad = torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad
+                                                 for t in (x, weight, styles, noise))
+    if wants_grad:
+        assert not fuse_bias_act and x2 is None and wpk is None and dcoefs is None and down == 1 and padding == 1, \
+            "gradients are implemented for the plain modulated_conv2d configuration"
+        assert (up == 1 and flip_weight) or (up == 2 and not flip_weight), "unsupported up/flip_weight combination"
+        if up == 2:
+            assert resample_filter is not None and resample_filter.ndim == 2
+        return _ModulatedConv2d.apply(x, weight, styles, noise, up, resample_filter, demodulate)
+    return _modulated_conv2d_forward(x, weight, styles, noise=noise, up=up, down=down, padding=padding,
+                                     resample_filter=resample_filter, demodulate=demodulate, flip_weight=flip_weight,
+                                     fused_modconv=fused_modconv, bias=bias, act_gain=act_gain, act_clamp=act_clamp,
+                                     fuse_bias_act=fuse_bias_act, x2=x2, wpk=wpk, dcoefs=dcoefs)
+
+
+def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                              flip_weight=True, fused_modconv=True, *, bias=None, act_gain=None, act_clamp=None,
+                              fuse_bias_act=False, x2=None, wpk=None, dcoefs=None):
     """3x3 modulated convolution, reference signature ``networks.modulated_conv2d`` (networks.py:30-88).
 
     Only the generator's two configurations exist: (up=1, padding=1, flip_weight=True) and

@@ -77,6 +77,22 @@ int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int major, int in
                      int f_h, int f_w, int upx, int upy, int downx, int downy,
                      int padx0, int padx1, int pady0, int pady1, int flip, float gain, void* stream);
 
+/* ---- gradient building blocks (row f4; csrc/nb_grad.hip) ------------------------------------------ */
+
+/* Generic fp32 convolution (cross-correlation, zero padding), what conv2d_gradfix.py:107-168 takes from cuDNN for the
+ * gradient w.r.t. the input of a strided conv:
+ *   y[n,co,oy,ox] = out_scale[n,co] * sum_{ci,a,b} (x[n,ci,oy*stride+a-pad,ox*stride+b-pad] * in_scale[n,ci]) * w[co,ci,a,b]
+ * x [n,c_in,h,wd], w [c_out,c_in,kh,kw] (kh, kw <= 7), y [n,c_out,ho,wo], ho = (h + 2 pad - kh)/stride + 1; the per-sample
+ * scales may be NULL. */
+int nb_conv2d_f32(const float* x, const float* w, const float* in_scale, const float* out_scale, float* y, int n,
+                  int c_in, int h, int wd, int c_out, int kh, int kw, int stride, int pad, void* stream);
+
+/* Weight-gradient correlation of a 3x3 conv: a[n,cu,cv,ka,kb] = sum_{i,j} u[n,cu,i*stride+ka-pad,j*stride+kb-pad] * v[n,cv,i,j]
+ * (zero outside u); a [n,cu,cv,3,3] is overwritten (partial sums are added atomically: the last bits depend on the
+ * order). */
+int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int n, int cu, int hu, int wu, int cv, int hv, int wv,
+                        int stride, int pad, void* stream);
+
 /* ---- generator path ---------------------------------------------------------------------- */
 
 /* MappingNetwork.forward (training/networks.py:255-290) for c_dim = 0, without the broadcast:

@@ -129,3 +129,61 @@ def test_setup_filter_separable():
     assert f.ndim == 1 and abs(float(f.sum()) - 1) < 1e-6
     f2 = ops.setup_filter([1, 3, 3, 1])
     assert f2.shape == (4, 4)
+
+
+MG_CASES = [f"up{up}_c{ci}_{d}" for up, ci in ((1, 12), (2, 10), (1, 40), (2, 36)) for d in ("d", "n")]
+
+
+@pytest.fixture(scope="module")
+def mg():
+    return load_golden("modconv_grads.npz")
+
+
+@pytest.mark.parametrize("tag", MG_CASES)
+def test_modulated_conv2d_grads_golden(dev, mg, tag):
+    """ops.modulated_conv2d under autograd (HIP kernels: fused forward, role-swapped forward / generic strided conv for
+    dx, pixel-contraction kernel for the weight / style gradients, upfirdn2d adjoint) against the REFERENCE's gradients."""
+    from brushstroke_engine_amd import ops
+    up = int(tag[2])
+    x, w, s, nz = (D(mg[tag + k_], dev, True) for k_ in ("_x", "_w", "_s", "_nz"))
+    y = ops.modulated_conv2d(x, w, s, noise=nz, up=up, padding=1, resample_filter=D(mg["f"], dev) if up == 2 else None,
+                             demodulate=tag.endswith("_d"), flip_weight=(up == 1))
+    g = torch.autograd.grad(y, [x, w, s, nz], D(mg[tag + "_dy"], dev))
+    for got, name in zip([y] + list(g), ("y", "dx", "dw", "ds", "dnz")):
+        want = mg[f"{tag}_{name}"]
+        close(got, want, 5e-5 * max(1.0, float(np.abs(want).max())))
+
+
+def test_modulated_conv2d_partial_grads_and_no_grad(dev, mg):
+    from brushstroke_engine_amd import ops
+    tag = "up1_c12_d"
+    x, w, s = D(mg[tag + "_x"], dev), D(mg[tag + "_w"], dev, True), D(mg[tag + "_s"], dev)
+    y = ops.modulated_conv2d(x, w, s, up=1, padding=1)                 # only the weight needs a gradient, no noise
+    dw, = torch.autograd.grad(y, [w], torch.ones_like(y))
+    assert dw.shape == w.shape and torch.isfinite(dw).all()
+    with torch.no_grad():
+        assert not ops.modulated_conv2d(x, w, s, up=1, padding=1).requires_grad
+
+
+def test_conv2d_and_wgrad_kernels_vs_torch(dev):
+    """The two gradient building blocks against torch fp64 on odd shapes (ragged channel tiles, stride 2, padding)."""
+    from brushstroke_engine_amd import ops
+    rs = np.random.RandomState(3)
+    for n, ci, co, h, w_, k, st, pad in ((2, 5, 7, 9, 11, 3, 1, 1), (1, 34, 40, 13, 9, 3, 2, 0), (2, 3, 33, 8, 8, 5, 2, 2), (1, 70, 3, 6, 7, 1, 1, 0)):
+        x = rs.randn(n, ci, h, w_).astype(np.float32); wt = rs.randn(co, ci, k, k).astype(np.float32)
+        isc = rs.rand(n, ci).astype(np.float32) + 0.5; osc = rs.rand(n, co).astype(np.float32) + 0.5
+        ref = torch.nn.functional.conv2d(torch.tensor(x).double() * torch.tensor(isc).double()[:, :, None, None], torch.tensor(wt).double(),
+                                         stride=st, padding=pad) * torch.tensor(osc).double()[:, :, None, None]
+        got = ops.conv2d(D(x, dev), D(wt, dev), D(isc, dev), D(osc, dev), stride=st, padding=pad)
+        close(got, ref.float().numpy(), 2e-5 * float(ref.abs().max()))
+    for n, cu, cv, hv, wv, st, pad in ((2, 5, 7, 6, 9, 1, 1), (1, 40, 33, 5, 4, 2, 0), (3, 33, 2, 8, 8, 1, 1)):
+        hu, wu = (hv, wv) if st == 1 else (2 * hv + 1, 2 * wv + 1)
+        u = rs.randn(n, cu, hu, wu).astype(np.float32); v = rs.randn(n, cv, hv, wv).astype(np.float32)
+        up_ = torch.nn.functional.pad(torch.tensor(u).double(), (pad, pad, pad, pad))
+        ref = torch.zeros(n, cu, cv, 3, 3, dtype=torch.float64)
+        for a in range(3):
+            for b in range(3):
+                win = up_[:, :, a:a + st * hv:st, b:b + st * wv:st]
+                ref[:, :, :, a, b] = torch.einsum("nuij,nvij->nuv", win, torch.tensor(v).double())
+        got = ops.conv2d_wgrad(D(u, dev), D(v, dev), stride=st, padding=pad)
+        close(got, ref.float().numpy(), 2e-5 * float(ref.abs().max()))

@@ -48,3 +48,23 @@ def test_oracle_upfirdn2d_grads(k, name):
     dx, = torch.autograd.grad(y, [x], torch.tensor(k[f"up_{name}_dy"]))
     np.testing.assert_allclose(y.detach().numpy(), k[f"up_{name}_y"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(dx.numpy(), k[f"up_{name}_dx"], rtol=0, atol=2e-6)
+
+
+MG = os.path.join(os.path.dirname(__file__), "golden", "modconv_grads.npz")
+MG_CASES = [f"up{up}_c{ci}_{d}" for up, ci in ((1, 12), (2, 10), (1, 40), (2, 36)) for d in ("d", "n")]
+
+
+@pytest.mark.parametrize("tag", MG_CASES)
+@pytest.mark.parametrize("fused", [True, False])
+def test_oracle_modulated_conv2d_grads(tag, fused):
+    """The oracle's modulated_conv2d under autograd (both forms) against the reference's gradients."""
+    k = np.load(MG)
+    up = int(tag[2])
+    x = torch.tensor(k[tag + "_x"], requires_grad=True); w = torch.tensor(k[tag + "_w"], requires_grad=True)
+    s = torch.tensor(k[tag + "_s"], requires_grad=True); nz = torch.tensor(k[tag + "_nz"], requires_grad=True)
+    y = orc.modulated_conv2d(x, w, s, noise=nz, up=up, padding=1, resample_filter=torch.tensor(k["f"]) if up == 2 else None,
+                             demodulate=tag.endswith("_d"), flip_weight=(up == 1), fused_modconv=fused)
+    g = torch.autograd.grad(y, [x, w, s, nz], torch.tensor(k[tag + "_dy"]))
+    for got, name in zip([y] + list(g), ("y", "dx", "dw", "ds", "dnz")):
+        want = k[f"{tag}_{name}"]
+        np.testing.assert_allclose(got.detach().numpy(), want, rtol=0, atol=3e-5 * max(1.0, float(np.abs(want).max())))
