@@ -1,0 +1,153 @@
+"""Differentiable generator: the same network as :mod:`networks`, evaluated layer by layer through the
+operator layer's autograd functions instead of the fused inference launches, so that gradients reach every parameter,
+the latents and the noise inputs - what the reference's training loop (``training_loop_modified.py:50-668``) and its
+projection script differentiate through.
+
+Where the arithmetic lives is the same as in the reference:
+  * ``modulated_conv2d`` / ``bias_act`` / ``upfirdn2d`` (the reference's native plugins + cuDNN via ``conv2d_gradfix``):
+    hand-written HIP kernels, forward and backward (:mod:`ops`, ``csrc/nb_grad.hip``);
+  * fully connected layers (``torch.addmm``, networks.py:118-120), the second-moment normalisation, ``softmax``, the triad
+    composite and the position shift of the constant noise (``grid_sample``, networks.py:373-381): torch ops, as in the
+    reference itself.
+The 1x1 modulated conv of ``ToRGBColorTriadLayer`` (networks.py:466-470) runs as the centre tap of a 3x3 one.
+
+This is the first, unfused training-mode path: correct gradients, not a tuned step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .config import GeneratorConfig
+from .weights import StateDict, validate_state_dict
+
+_TRAINABLE_SUFFIXES = (".weight", ".bias", ".noise_strength", ".const", ".color_bias")
+
+
+class TrainableGenerator(torch.nn.Module):
+    """Parameters under the reference's ``state_dict`` names (``mapping.fc0.weight``, ``synthesis.b64.conv0.weight`` ...,
+    dots replaced by ``__`` inside the module); buffers (noise_const, noise_grid, resample_filter, w_avg) likewise."""
+
+    def __init__(self, cfg: GeneratorConfig, state_dict: StateDict, device="cuda"):
+        super().__init__()
+        validate_state_dict(cfg, state_dict)
+        self.cfg = cfg
+        self.z_dim, self.c_dim, self.w_dim = cfg.z_dim, cfg.c_dim, cfg.w_dim
+        self.img_resolution, self.img_channels, self.num_ws = cfg.img_resolution, cfg.img_channels, cfg.num_ws
+        self._names: Dict[str, str] = {}
+        for k, v in state_dict.items():
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32)))
+            attr = k.replace(".", "__")
+            self._names[k] = attr
+            if k.endswith(_TRAINABLE_SUFFIXES):
+                self.register_parameter(attr, torch.nn.Parameter(t))
+            else:
+                self.register_buffer(attr, t)
+        self.to(device)
+
+    def p(self, key: str) -> torch.Tensor:
+        return getattr(self, self._names[key])
+
+    def named_reference_parameters(self):
+        """(reference key, Parameter) pairs."""
+        for k, attr in self._names.items():
+            t = getattr(self, attr)
+            if isinstance(t, torch.nn.Parameter):
+                yield k, t
+
+    # -- FullyConnectedLayer.forward, networks.py:109-122 --
+    def _fc(self, x, prefix: str, activation: str = "linear", lr_multiplier: float = 1.0):
+        w = self.p(prefix + ".weight")
+        b = self.p(prefix + ".bias")
+        w = w * (lr_multiplier / math.sqrt(w.shape[1]))
+        if lr_multiplier != 1:
+            b = b * lr_multiplier
+        if activation == "linear":
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return ops.bias_act(x.matmul(w.t()).contiguous(), b.contiguous(), act=activation)
+
+    # -- MappingNetwork.forward, networks.py:255-290 (c_dim == 0, no truncation) --
+    def mapping(self, z, c=None, truncation_psi=1, truncation_cutoff=None):
+        if truncation_psi != 1:
+            raise RuntimeError("TrainableGenerator: truncation is an inference feature (use networks.Generator)")
+        x = z.to(torch.float32)
+        x = x * (x.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+        for i in range(self.cfg.mapping_layers):
+            x = self._fc(x, f"mapping.fc{i}", "lrelu", self.cfg.mapping_lr_multiplier)
+        return x.unsqueeze(1).repeat([1, self.num_ws, 1])
+
+    # -- SynthesisLayer.forward, networks.py:362-391 --
+    def _layer(self, spec, x, w, norm_pos, noise_mode):
+        name = spec.name
+        styles = self._fc(w, name + ".affine")
+        noise = None
+        if noise_mode == "random":
+            noise = torch.randn([x.shape[0], 1, spec.block_res, spec.block_res], device=x.device) * self.p(name + ".noise_strength")
+        elif noise_mode == "const":
+            nc = self.p(name + ".noise_const")
+            if norm_pos is not None:
+                grid = (self.p(name + ".noise_grid") + norm_pos.unsqueeze(1).unsqueeze(1)) % 1 * 2 - 1
+                nc = F.grid_sample(nc[None, None].expand(x.shape[0], -1, -1, -1), grid, padding_mode="reflection", align_corners=True)
+            noise = nc * self.p(name + ".noise_strength")
+            if noise.ndim == 2:
+                noise = noise[None, None]
+        y = ops.modulated_conv2d(x.contiguous(), self.p(name + ".weight"), styles.contiguous(),
+                                 noise=None if noise is None else noise.contiguous(), up=spec.up, padding=1,
+                                 resample_filter=self.p(name + ".resample_filter"), flip_weight=(spec.up == 1))
+        return ops.bias_act(y, self.p(name + ".bias"), act="lrelu", gain=math.sqrt(2), clamp=self.cfg.conv_clamp)
+
+    # -- ToRGBColorTriadLayer.forward, networks.py:451-485 --
+    def _torgb(self, x, w):
+        t = self.cfg.torgb_name
+        c = x.shape[1]
+        scaled = self._fc(w, t + ".affine")
+        colors = ops.bias_act(scaled[:, 0:9].contiguous(), self.p(t + ".color_bias"), dim=1, act="tanh").reshape(-1, 3, 3)
+        styles = (scaled[:, 9:] * (1 / math.sqrt(c))).contiguous()
+        w3 = F.pad(self.p(t + ".weight"), (1, 1, 1, 1))                     # 1x1 kernel as the centre tap of a 3x3 one
+        y = ops.modulated_conv2d(x.contiguous(), w3, styles, up=1, padding=1, demodulate=False, flip_weight=True)
+        y = ops.bias_act(y, self.p(t + ".bias"), clamp=self.cfg.conv_clamp)
+        uvs = torch.softmax(y[:, :3], dim=1)
+        img = torch.sum(uvs.unsqueeze(1) * colors.unsqueeze(-1).unsqueeze(-1), dim=2)
+        return img, {"colors": colors, "uvs": uvs}
+
+    # -- SynthesisNetwork.forward, networks_modified.py:123-223 ('orig' architecture, triad colours) --
+    def synthesis(self, ws, geom_feature, norm_noise_positions=None, noise_mode="const", return_debug_data=False):
+        cfg = self.cfg
+        ws = ws.to(torch.float32)
+        n = ws.shape[0]
+        geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
+        layers = {l.name: l for l in cfg.layers}
+        x = img = None
+        triad = {}
+        geo_idx = 0
+        for res in cfg.block_resolutions:
+            b = f"synthesis.b{res}"
+            if res == 4:
+                x = self.p(b + ".const").unsqueeze(0).repeat([n, 1, 1, 1])
+            else:
+                sp = layers[b + ".conv0"]
+                x = self._layer(sp, x, ws[:, sp.w_index], norm_noise_positions, noise_mode)
+            sp = layers[b + ".conv1"]
+            x = self._layer(sp, x, ws[:, sp.w_index], norm_noise_positions, noise_mode)
+            if res == cfg.img_resolution:
+                img, triad = self._torgb(x, ws[:, cfg.torgb_w_index])
+            if res in cfg.geom_feature_resolutions:
+                x = torch.cat([x, geom_feature[geo_idx].to(torch.float32)], dim=1)     # networks_modified.py:218-219
+                geo_idx += 1
+        return (img, triad) if return_debug_data else img
+
+    def forward(self, z, c, geom_feature, positions=None, noise_mode="const", return_debug_data=False):
+        ws = self.mapping(z, c)
+        norm_pos = None
+        if positions is not None:                                          # networks_modified.py:351-353
+            norm_pos = (positions % self.img_resolution).to(torch.float32) / (self.img_resolution - 1)
+        res = self.synthesis(ws, geom_feature, norm_noise_positions=norm_pos, noise_mode=noise_mode,
+                             return_debug_data=return_debug_data)
+        if return_debug_data:
+            res[1]["ws"] = ws
+        return res
