@@ -292,10 +292,7 @@ def pack_conv_weight(weight: torch.Tensor):
     return wpk, wsq
 
 
-def conv2d(x, w, in_scale=None, out_scale=None, stride=1, padding=0):
-    """Generic fp32 cross-correlation with zero padding and optional per-sample channel scales on the HIP kernel
-    (nb_conv2d_f32) - the role cuDNN plays behind ``conv2d_gradfix`` for strided gradients."""
-    _dev(x, "x"); _dev(w, "w")
+def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
     n, ci, h, wd = x.shape
     co, ci2, kh, kw = w.shape
     assert ci == ci2
@@ -309,9 +306,7 @@ def conv2d(x, w, in_scale=None, out_scale=None, stride=1, padding=0):
     return y
 
 
-def conv2d_wgrad(u, v, stride=1, padding=0):
-    """a[n,cu,cv,ka,kb] = sum_{i,j} u[n,cu,i*stride+ka-pad,j*stride+kb-pad] * v[n,cv,i,j]  (3x3; nb_conv2d_wgrad_f32)."""
-    _dev(u, "u"); _dev(v, "v")
+def _wgrad_launch(u, v, stride, padding):
     n, cu, hu, wu = u.shape
     n2, cv, hv, wv = v.shape
     assert n == n2
@@ -320,6 +315,86 @@ def conv2d_wgrad(u, v, stride=1, padding=0):
         _lib.check(_lib.lib().nb_conv2d_wgrad_f32(_p(u.contiguous()), _p(v.contiguous()), _p(a), n, cu, hu, wu, cv, hv, wv,
                                                   stride, padding, _stream(u)), "conv2d_wgrad")
     return a
+
+
+def _conv2d_input_grad(dy, w, x_shape, stride, padding):
+    """Gradient of conv2d w.r.t. its input = transposed convolution, built from differentiable pieces: zero-stuffing by
+    ``stride`` (upfirdn2d with the identity filter), a stride-1 correlation with the transposed, flipped kernel, and zero
+    rows / columns where the forward window never reached."""
+    kh, kw = w.shape[2], w.shape[3]
+    h, wd = x_shape[2], x_shape[3]
+    if stride > 1:
+        dy = upfirdn2d(dy, None, up=stride, padding=[0, -(stride - 1), 0, -(stride - 1)])
+    assert kh - 1 - padding >= 0 and kw - 1 - padding >= 0, "conv2d gradient: padding larger than kernel - 1"
+    wt = w.transpose(0, 1).flip([2, 3])
+    if kh != kw:
+        raise NotImplementedError("conv2d gradient: square kernels only")
+    dx = conv2d(dy, wt, stride=1, padding=kh - 1 - padding)
+    ph, pw = h - dx.shape[2], wd - dx.shape[3]
+    if ph or pw:
+        dx = torch.nn.functional.pad(dx, (0, pw, 0, ph))
+    return dx
+
+
+class _Conv2d(torch.autograd.Function):
+    """Plain convolution with gradients of any order (``conv2d_gradfix.py:107-168``): every gradient is expressed through
+    this Function and :class:`_Conv2dWgrad` again."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        ctx.stride, ctx.padding = stride, padding
+        ctx.save_for_backward(x, w)
+        return _conv2d_launch(x, w, None, None, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv2d_input_grad(dy, w, x.shape, ctx.stride, ctx.padding)
+        if ctx.needs_input_grad[1]:
+            dw = _Conv2dWgrad.apply(x, dy, ctx.stride, ctx.padding, w.shape[2])
+        return dx, dw, None, None
+
+
+class _Conv2dWgrad(torch.autograd.Function):
+    """dw[co,ci,a,b] = sum_{n,i,j} x[n,ci,i*stride+a-pad,j*stride+b-pad] * dy[n,co,i,j] for 3x3 and 1x1 kernels (the 1x1
+    case is the centre tap of the 3x3 correlation); differentiable (R1-type double backward)."""
+
+    @staticmethod
+    def forward(ctx, x, dy, stride, padding, k):
+        assert k in (1, 3), "conv2d weight gradient: 1x1 and 3x3 kernels"
+        ctx.stride, ctx.padding, ctx.k = stride, padding, k
+        ctx.save_for_backward(x, dy)
+        a = _wgrad_launch(x, dy, stride, padding + (1 if k == 1 else 0)).sum(dim=0)          # [ci, co, 3, 3]
+        a = a.permute(1, 0, 2, 3)
+        return a[:, :, 1:2, 1:2].contiguous() if k == 1 else a.contiguous()
+
+    @staticmethod
+    def backward(ctx, ddw):
+        x, dy = ctx.saved_tensors
+        dx = ddy = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv2d_input_grad(dy, ddw, x.shape, ctx.stride, ctx.padding)
+        if ctx.needs_input_grad[1]:
+            ddy = conv2d(x, ddw, stride=ctx.stride, padding=ctx.padding)
+        return dx, ddy, None, None, None
+
+
+def conv2d(x, w, in_scale=None, out_scale=None, stride=1, padding=0):
+    """Generic fp32 cross-correlation with zero padding on the HIP kernel (nb_conv2d_f32) - the role cuDNN plays behind
+    ``conv2d_gradfix``.  Without channel scales it is differentiable to any order w.r.t. x and w (1x1 / 3x3 kernels for
+    the weight gradient); the per-sample ``in_scale`` / ``out_scale`` form is forward only."""
+    _dev(x, "x"); _dev(w, "w")
+    if in_scale is None and out_scale is None and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _Conv2d.apply(x, w, int(stride), int(padding))
+    return _conv2d_launch(x, w, in_scale, out_scale, int(stride), int(padding))
+
+
+def conv2d_wgrad(u, v, stride=1, padding=0):
+    """a[n,cu,cv,ka,kb] = sum_{i,j} u[n,cu,i*stride+ka-pad,j*stride+kb-pad] * v[n,cv,i,j]  (3x3; nb_conv2d_wgrad_f32)."""
+    _dev(u, "u"); _dev(v, "v")
+    return _wgrad_launch(u, v, stride, padding)
 
 
 class _ModulatedConv2d(torch.autograd.Function):

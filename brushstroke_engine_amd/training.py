@@ -151,3 +151,88 @@ class TrainableGenerator(torch.nn.Module):
         if return_debug_data:
             res[1]["ws"] = ws
         return res
+
+
+class TrainableDiscriminator(torch.nn.Module):
+    """``training/networks.py:788-1012`` for ``architecture='resnet'``, ``c_dim=0``, fp32: residual blocks
+    (fromrgb 1x1 at the input resolution; conv0 3x3; conv1 3x3 with FIR + stride-2 down-sampling; skip 1x1 down-sampling,
+    both halves scaled by sqrt(1/2)), minibatch-stddev feature, 3x3 conv, two fully connected layers -> one logit.
+    Every ``Conv2dLayer`` (networks.py:125-173) is ``conv2d_resample`` + ``bias_act`` on the differentiable HIP operators
+    (gradients of any order: the R1 penalty differentiates the input gradient once more); parameters carry the
+    reference's ``state_dict`` names."""
+
+    def __init__(self, state_dict: StateDict, img_resolution: int, img_channels: int, channel_base: int = 32768,
+                 channel_max: int = 512, conv_clamp: Optional[float] = None, mbstd_group_size: Optional[int] = 4,
+                 mbstd_num_channels: int = 1, resample_filter=(1, 3, 3, 1), device="cuda"):
+        super().__init__()
+        self.img_resolution, self.img_channels, self.conv_clamp = img_resolution, img_channels, conv_clamp
+        self.mbstd_group_size, self.mbstd_num_channels = mbstd_group_size, mbstd_num_channels
+        log2 = int(math.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(log2, 2, -1)]
+        self.channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        self._names: Dict[str, str] = {}
+        for k, v in state_dict.items():
+            if k.endswith("resample_filter"):
+                continue
+            attr = k.replace(".", "__")
+            self._names[k] = attr
+            self.register_parameter(attr, torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32)))))
+        self.register_buffer("fir", ops.setup_filter(resample_filter))
+        self.to(device)
+
+    def p(self, key: str):
+        return getattr(self, self._names[key]) if key in self._names else None
+
+    def named_reference_parameters(self):
+        for k, attr in self._names.items():
+            yield k, getattr(self, attr)
+
+    # -- Conv2dLayer.forward (networks.py:163-173) with conv2d_resample's down-sampling branches (conv2d_resample.py:96-113) --
+    def _conv(self, x, prefix: str, k: int, down: int = 1, activation: str = "lrelu", gain: float = 1.0, clamp=None):
+        w = self.p(prefix + ".weight")
+        w = w * (1 / math.sqrt(w.shape[1] * k * k))
+        pad = k // 2
+        if down == 1:
+            x = ops.conv2d(x, w, stride=1, padding=pad)
+        else:
+            fw = self.fir.shape[1]
+            p0, p1 = pad + (fw - down + 1) // 2, pad + (fw - down) // 2
+            if k == 1:
+                x = ops.upfirdn2d(x, self.fir, down=down, padding=[p0, p1, p0, p1])
+                x = ops.conv2d(x, w, stride=1, padding=0)
+            else:
+                x = ops.upfirdn2d(x, self.fir, padding=[p0, p1, p0, p1])
+                x = ops.conv2d(x, w, stride=down, padding=0)
+        act_gain = (math.sqrt(2) if activation == "lrelu" else 1.0) * gain
+        return ops.bias_act(x, self.p(prefix + ".bias"), act=activation, gain=act_gain, clamp=None if clamp is None else clamp * gain)
+
+    def _fc(self, x, prefix: str, activation: str = "linear"):
+        w = self.p(prefix + ".weight")
+        w = w * (1 / math.sqrt(w.shape[1]))
+        b = self.p(prefix + ".bias")
+        if activation == "linear":
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return ops.bias_act(x.matmul(w.t()).contiguous(), b, act=activation)
+
+    def forward(self, img, c=None):
+        x = None
+        img = img.to(torch.float32).contiguous()
+        for res in self.block_resolutions:
+            b = f"b{res}"
+            if x is None:
+                x = self._conv(img, b + ".fromrgb", 1, clamp=self.conv_clamp)
+            y = self._conv(x, b + ".skip", 1, down=2, activation="linear", gain=math.sqrt(0.5))
+            x = self._conv(x, b + ".conv0", 3, clamp=self.conv_clamp)
+            x = self._conv(x, b + ".conv1", 3, down=2, gain=math.sqrt(0.5), clamp=self.conv_clamp)
+            x = y + x
+        if self.mbstd_num_channels > 0:                                   # MinibatchStdLayer, networks.py:868-885
+            n, ch, h, w = x.shape
+            g = n if self.mbstd_group_size is None else min(self.mbstd_group_size, n)
+            f_, c_ = self.mbstd_num_channels, ch // self.mbstd_num_channels
+            y = x.reshape(g, -1, f_, c_, h, w)
+            y = y - y.mean(dim=0)
+            y = (y.square().mean(dim=0) + 1e-8).sqrt().mean(dim=[2, 3, 4]).reshape(-1, f_, 1, 1).repeat(g, 1, h, w)
+            x = torch.cat([x, y], dim=1)
+        x = self._conv(x.contiguous(), "b4.conv", 3, clamp=self.conv_clamp)
+        x = self._fc(x.flatten(1), "b4.fc", "lrelu")
+        return self._fc(x, "b4.out")

@@ -74,3 +74,40 @@ def test_trainable_gradients_match_oracle():
         assert err <= 2e-4 * scale + 1e-9, (name, err, scale)
         checked += 1
     assert checked >= len(train_keys) - 2
+
+
+def test_discriminator_matches_reference_golden():
+    """TrainableDiscriminator (resnet, c_dim=0) on the HIP operators against the REFERENCE discriminator's logits,
+    first-order gradients (image and every parameter) and the R1 double backward (tests/golden/discriminator_r32.npz)."""
+    import ast
+    from conftest import load_golden
+    from brushstroke_engine_amd.training import TrainableDiscriminator
+    g = load_golden("discriminator_r32.npz")
+    kw = ast.literal_eval(str(g["kw"][0]))
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    dev = torch.device("cuda:0")
+    D = TrainableDiscriminator(sd, kw["img_resolution"], kw["img_channels"], channel_base=kw["channel_base"],
+                               channel_max=kw["channel_max"], conv_clamp=kw["conv_clamp"], device=dev)
+    img = torch.tensor(g["img"], device=dev, requires_grad=True)
+    logits = D(img, None)
+    assert float((logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max()) <= 2e-5 * max(1.0, float(np.abs(g["logits"]).max()))
+    names = [k[2:] for k in g if k.startswith("g.")]
+    params = dict(D.named_reference_parameters())
+    grads = torch.autograd.grad(logits.sum(), [img] + [params[n] for n in names], create_graph=True)
+
+    def chk(got, want, what, tol=3e-4):
+        scale = max(float(np.abs(want).max()), 1e-6)
+        err = float((got.detach().cpu() - torch.from_numpy(want)).abs().max())
+        assert err <= tol * scale, (what, err, scale)
+    chk(grads[0], g["dimg"], "dimg")
+    for n, a in zip(names, grads[1:]):
+        chk(a, g["g." + n], "g." + n)
+    r1 = grads[0].square().sum()
+    assert abs(float(r1.detach()) - float(g["r1"][0])) <= 3e-4 * float(g["r1"][0])
+    g2 = torch.autograd.grad(r1, [params[n] for n in names], allow_unused=True)
+    for n, a in zip(names, g2):
+        want = g["r1." + n]
+        if a is None:
+            assert float(np.abs(want).max()) == 0.0, n
+        else:
+            chk(a, want, "r1." + n, tol=1e-3)
