@@ -236,3 +236,75 @@ class TrainableDiscriminator(torch.nn.Module):
         x = self._conv(x.contiguous(), "b4.conv", 3, clamp=self.conv_clamp)
         x = self._fc(x.flatten(1), "b4.fc", "lrelu")
         return self._fc(x, "b4.out")
+
+
+def random_discriminator_state_dict(img_resolution: int, img_channels: int, channel_base: int = 32768, channel_max: int = 512,
+                                    mbstd_num_channels: int = 1, seed: int = 0, bias_std: float = 0.0) -> Dict[str, np.ndarray]:
+    """Parameters of a freshly initialised reference discriminator (resnet, c_dim=0): N(0,1) weights, zero biases
+    (``Conv2dLayer`` networks.py:150-153, ``FullyConnectedLayer`` :104-105); ``bias_std`` > 0 randomises the biases for tests."""
+    rs = np.random.RandomState(seed)
+    log2 = int(math.log2(img_resolution))
+    ch = {res: min(channel_base // res, channel_max) for res in [2 ** i for i in range(log2, 1, -1)]}
+    sd: Dict[str, np.ndarray] = {}
+
+    def conv(name, ci, co, k, bias=True):
+        sd[name + ".weight"] = rs.randn(co, ci, k, k).astype(np.float32)
+        if bias:
+            sd[name + ".bias"] = (bias_std * rs.randn(co)).astype(np.float32)
+
+    for res in [2 ** i for i in range(log2, 2, -1)]:
+        tmp, out = ch[res], ch[res // 2]
+        if res == img_resolution:
+            conv(f"b{res}.fromrgb", img_channels, tmp, 1)
+        conv(f"b{res}.conv0", tmp, tmp, 3)
+        conv(f"b{res}.conv1", tmp, out, 3)
+        conv(f"b{res}.skip", tmp, out, 1, bias=False)
+    conv("b4.conv", ch[4] + mbstd_num_channels, ch[4], 3)
+    sd["b4.fc.weight"] = rs.randn(ch[4], ch[4] * 16).astype(np.float32)
+    sd["b4.fc.bias"] = (bias_std * rs.randn(ch[4])).astype(np.float32)
+    sd["b4.out.weight"] = rs.randn(1, ch[4]).astype(np.float32)
+    sd["b4.out.bias"] = (bias_std * rs.randn(1)).astype(np.float32)
+    return sd
+
+
+class GanLoss:
+    """The adversarial phases of ``ForgerLoss.accumulate_gradients`` (loss_modified.py:140-272): non-saturating logistic
+    losses for G and D and the R1 penalty on real images.  ``phase`` in {'Gmain', 'Dmain', 'Dreg', 'Dall'}; gradients are
+    accumulated into the parameters' ``.grad`` like the reference does.  Not ported: the path-length regulariser
+    ('Greg': needs the second-order gradient of the modulated convolution), the forger geometry / stitching losses and
+    the ADA augmentation pipeline."""
+
+    def __init__(self, G: TrainableGenerator, D: TrainableDiscriminator, r1_gamma: float = 10.0):
+        self.G, self.D, self.r1_gamma = G, D, r1_gamma
+
+    def accumulate_gradients(self, phase: str, real_img, geom_feature, gen_z, gain: float = 1.0, positions=None) -> Dict[str, float]:
+        assert phase in ("Gmain", "Dmain", "Dreg", "Dall")
+        stats: Dict[str, float] = {}
+        softplus = torch.nn.functional.softplus
+        if phase == "Gmain":                                              # maximise logits of generated images
+            gen_img = self.G(gen_z, None, geom_feature, positions=positions)
+            loss = softplus(-self.D(gen_img, None))
+            loss.mean().mul(gain).backward()
+            stats["Loss/G/loss"] = float(loss.mean().detach())
+        if phase in ("Dmain", "Dall"):                                    # minimise logits of generated images
+            with torch.no_grad():
+                gen_img = self.G(gen_z, None, geom_feature, positions=positions)
+            loss_gen = softplus(self.D(gen_img, None))
+            loss_gen.mean().mul(gain).backward()
+            stats["Loss/D/loss_gen"] = float(loss_gen.mean().detach())
+        if phase in ("Dmain", "Dreg", "Dall"):                            # maximise logits of real images (+ R1)
+            do_main, do_r1 = phase in ("Dmain", "Dall"), phase in ("Dreg", "Dall") and self.r1_gamma != 0
+            real = real_img.detach().requires_grad_(do_r1)
+            real_logits = self.D(real, None)
+            total = real_logits * 0
+            if do_main:
+                loss_real = softplus(-real_logits)
+                total = total + loss_real
+                stats["Loss/D/loss_real"] = float(loss_real.mean().detach())
+            if do_r1:
+                r1_grads, = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real], create_graph=True, only_inputs=True)
+                r1_penalty = r1_grads.square().sum([1, 2, 3])
+                total = total + (r1_penalty * (self.r1_gamma / 2))[:, None]
+                stats["Loss/r1_penalty"] = float(r1_penalty.mean().detach())
+            total.mean().mul(gain).backward()
+        return stats

@@ -111,3 +111,31 @@ def test_discriminator_matches_reference_golden():
             assert float(np.abs(want).max()) == 0.0, n
         else:
             chk(a, want, "r1." + n, tol=1e-3)
+
+
+def test_gan_loss_phases():
+    """GanLoss phases accumulate the gradients the formulas of loss_modified.py:140-272 prescribe: Gmain reaches only G,
+    the D phases only D; the R1 statistic equals the penalty computed by hand from D's input gradient."""
+    from brushstroke_engine_amd.training import (TrainableGenerator, TrainableDiscriminator, GanLoss,
+                                                 random_discriminator_state_dict)
+    cfg, sd, z, geom, pos = _setup(n=4)
+    dev = torch.device("cuda:0")
+    G = TrainableGenerator(cfg, sd, dev)
+    D = TrainableDiscriminator(random_discriminator_state_dict(32, 3, channel_base=512, channel_max=24, seed=3, bias_std=0.1),
+                               32, 3, channel_base=512, channel_max=24, conv_clamp=256, device=dev)
+    loss = GanLoss(G, D, r1_gamma=10.0)
+    zt = torch.from_numpy(z).to(dev); gt = [torch.from_numpy(g).to(dev) for g in geom]
+    real = torch.tanh(torch.randn(4, 3, 32, 32, device=dev))
+    st = loss.accumulate_gradients("Gmain", real, gt, zt)
+    assert np.isfinite(st["Loss/G/loss"])
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in G.parameters() if p.requires_grad and p.numel() > 1)
+    g_d = [p.grad.clone() for p in D.parameters()]          # Gmain back-propagates THROUGH D; the optimiser of D is not stepped
+    for p in list(G.parameters()) + list(D.parameters()):
+        p.grad = None
+    st = loss.accumulate_gradients("Dall", real, gt, zt)
+    assert all(p.grad is None for p in G.parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in D.parameters())
+    r = real.clone().requires_grad_(True)
+    gr, = torch.autograd.grad(D(r, None).sum(), [r])
+    assert abs(st["Loss/r1_penalty"] - float(gr.square().sum([1, 2, 3]).mean())) <= 1e-4 * st["Loss/r1_penalty"]
+    assert len(g_d) == len(list(D.parameters()))
