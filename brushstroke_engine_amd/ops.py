@@ -432,6 +432,18 @@ class _ModulatedConv2d(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, styles, noise, d, y, f = ctx.saved_tensors
         up = ctx.up
+        if torch.is_grad_enabled():
+            # create_graph=True (path-length regulariser, loss_modified.py:205-221): the gradients themselves must be
+            # differentiable.  Re-evaluate the layer through the generic differentiable operators and let autograd
+            # produce (and later differentiate) them - slower kernels, used only in this mode.
+            inputs = [t for t, need in zip((x, weight, styles, noise), ctx.needs_input_grad[:4]) if need and t is not None]
+            with torch.enable_grad():
+                y2 = _modulated_conv2d_generic(x, weight, styles, noise, up, f, ctx.demodulate)
+                grads = list(torch.autograd.grad(y2, inputs, dy, create_graph=True, allow_unused=True))
+            out = []
+            for t, need in zip((x, weight, styles, noise), ctx.needs_input_grad[:4]):
+                out.append(grads.pop(0) if (need and t is not None) else None)
+            return out[0], out[1], out[2], out[3], None, None, None
         dy = dy.contiguous()
         n, c, h, w_ = x.shape
         o = weight.shape[0]
@@ -477,12 +489,29 @@ class _ModulatedConv2d(torch.autograd.Function):
         return dx, dw, ds, dnz, None, None, None
 
 
+def _modulated_conv2d_generic(x, weight, styles, noise, up, f, demodulate):
+    """The layer in its non-fused form (networks.py:67-76) on the generic differentiable operators: x*s -> shared conv
+    (up = 2: zero-stuffing + correlation with the flipped kernel = the stride-2 transposed conv, then the FIR) -> *d + noise."""
+    n = x.shape[0]
+    xs = x * styles.reshape(n, -1, 1, 1)
+    if up == 1:
+        z = conv2d(xs, weight, stride=1, padding=1)
+    else:
+        stuffed = upfirdn2d(xs, None, up=2, padding=[0, -1, 0, -1])
+        y1 = conv2d(stuffed, weight.flip([2, 3]), stride=1, padding=2)
+        z = upfirdn2d(y1, f, padding=1, gain=4)
+    if demodulate:
+        d = ((styles.square() @ weight.square().sum(dim=[2, 3]).t()) + 1e-8).rsqrt()
+        z = z * d.reshape(n, -1, 1, 1)
+    return z if noise is None else z + noise
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                      flip_weight=True, fused_modconv=True, *, bias=None, act_gain=None, act_clamp=None,
                      fuse_bias_act=False, x2=None, wpk=None, dcoefs=None):
     """3x3 modulated convolution, reference signature ``networks.modulated_conv2d`` (networks.py:30-88), with first-order
     gradients w.r.t. x, weight, styles and noise when any of them requires grad (plain configuration: no fused bias /
-    second input); see :class:`_ModulatedConv2d`."""
+    second input) and, under ``create_graph=True``, gradients of those gradients; see :class:`_ModulatedConv2d`."""
     wants_grad = torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad
                                                  for t in (x, weight, styles, noise))
     if wants_grad:

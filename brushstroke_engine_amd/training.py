@@ -269,18 +269,35 @@ def random_discriminator_state_dict(img_resolution: int, img_channels: int, chan
 
 class GanLoss:
     """The adversarial phases of ``ForgerLoss.accumulate_gradients`` (loss_modified.py:140-272): non-saturating logistic
-    losses for G and D and the R1 penalty on real images.  ``phase`` in {'Gmain', 'Dmain', 'Dreg', 'Dall'}; gradients are
-    accumulated into the parameters' ``.grad`` like the reference does.  Not ported: the path-length regulariser
-    ('Greg': needs the second-order gradient of the modulated convolution), the forger geometry / stitching losses and
-    the ADA augmentation pipeline."""
+    losses for G and D, the R1 penalty on real images and the path-length regulariser of G (second-order gradient of
+    the modulated convolution).  ``phase`` in {'Gmain', 'Greg', 'Dmain', 'Dreg', 'Dall'}; gradients are accumulated into
+    the parameters' ``.grad`` like the reference does.  Not ported: the forger geometry / stitching losses and the ADA
+    augmentation pipeline."""
 
-    def __init__(self, G: TrainableGenerator, D: TrainableDiscriminator, r1_gamma: float = 10.0):
+    def __init__(self, G: TrainableGenerator, D: TrainableDiscriminator, r1_gamma: float = 10.0, pl_batch_shrink: int = 2,
+                 pl_decay: float = 0.01, pl_weight: float = 2.0):
         self.G, self.D, self.r1_gamma = G, D, r1_gamma
+        self.pl_batch_shrink, self.pl_decay, self.pl_weight = pl_batch_shrink, pl_decay, pl_weight
+        self.pl_mean = torch.zeros([], device=next(G.parameters()).device)
 
-    def accumulate_gradients(self, phase: str, real_img, geom_feature, gen_z, gain: float = 1.0, positions=None) -> Dict[str, float]:
-        assert phase in ("Gmain", "Dmain", "Dreg", "Dall")
+    def accumulate_gradients(self, phase: str, real_img, geom_feature, gen_z, gain: float = 1.0, positions=None,
+                             pl_noise=None) -> Dict[str, float]:
+        assert phase in ("Gmain", "Greg", "Dmain", "Dreg", "Dall")
         stats: Dict[str, float] = {}
         softplus = torch.nn.functional.softplus
+        if phase == "Greg" and self.pl_weight != 0:                       # path-length regularisation, loss_modified.py:205-221
+            b = max(1, gen_z.shape[0] // self.pl_batch_shrink)
+            gen_img, data = self.G(gen_z[:b], None, [g[:b] for g in geom_feature],
+                                   positions=None if positions is None else positions[:b], return_debug_data=True)
+            if pl_noise is None:
+                pl_noise = torch.randn_like(gen_img) / math.sqrt(gen_img.shape[2] * gen_img.shape[3])
+            pl_grads, = torch.autograd.grad(outputs=[(gen_img * pl_noise).sum()], inputs=[data["ws"]], create_graph=True, only_inputs=True)
+            pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
+            pl_mean = self.pl_mean.lerp(pl_lengths.mean(), self.pl_decay)
+            self.pl_mean.copy_(pl_mean.detach())
+            pl_penalty = (pl_lengths - pl_mean).square()
+            (gen_img[:, 0, 0, 0] * 0 + pl_penalty * self.pl_weight).mean().mul(gain).backward()
+            stats["Loss/pl_penalty"] = float(pl_penalty.mean().detach())
         if phase == "Gmain":                                              # maximise logits of generated images
             gen_img = self.G(gen_z, None, geom_feature, positions=positions)
             loss = softplus(-self.D(gen_img, None))

@@ -51,6 +51,18 @@ def main():
             out.update({tag + "_x": x0, tag + "_w": w0, tag + "_s": s0, tag + "_nz": nz0, tag + "_dy": dy0})
             for name, v in zip(("y", "dx", "dw", "ds", "dnz"), res[True]):
                 out[f"{tag}_{name}"] = v
+            # path-length style double backward (loss_modified.py:205-221): gradient of |d(y . r)/d styles|^2
+            x = torch.tensor(x0, requires_grad=True); w = torch.tensor(w0, requires_grad=True)
+            s = torch.tensor(s0, requires_grad=True)
+            y = ref_networks.modulated_conv2d(x=x, weight=w, styles=s, noise=torch.tensor(nz0), up=up, padding=1,
+                                              resample_filter=f if up == 2 else None, demodulate=demod,
+                                              flip_weight=(up == 1), fused_modconv=False)
+            gs, = torch.autograd.grad((y * torch.tensor(dy0)).sum(), [s], create_graph=True)
+            pl = gs.square().sum()
+            g2 = torch.autograd.grad(pl, [x, w, s], allow_unused=True)       # (without demodulation pl does not depend on s)
+            out[f"{tag}_pl"] = np.array([float(pl)])
+            for name, v, like in zip(("pl_dx", "pl_dw", "pl_ds"), g2, (x0, w0, s0)):
+                out[f"{tag}_{name}"] = np.zeros_like(like) if v is None else v.numpy()
     np.savez_compressed(os.path.join(HERE, "modconv_grads.npz"), **out)
     print("modconv_grads.npz:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "modconv_grads.npz")) // 1024, "KiB")
 

@@ -187,3 +187,21 @@ def test_conv2d_and_wgrad_kernels_vs_torch(dev):
                 ref[:, :, :, a, b] = torch.einsum("nuij,nvij->nuv", win, torch.tensor(v).double())
         got = ops.conv2d_wgrad(D(u, dev), D(v, dev), stride=st, padding=pad)
         close(got, ref.float().numpy(), 2e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("tag", MG_CASES)
+def test_modulated_conv2d_double_backward_golden(dev, mg, tag):
+    """Path-length style second order (loss_modified.py:205-221): gradient of |d(y . r)/d styles|^2 w.r.t. x, weight and
+    styles - the create_graph=True mode of ops.modulated_conv2d - against the REFERENCE's autograd."""
+    from brushstroke_engine_amd import ops
+    up = int(tag[2])
+    x, w, s = (D(mg[tag + k_], dev, True) for k_ in ("_x", "_w", "_s"))
+    y = ops.modulated_conv2d(x, w, s, noise=D(mg[tag + "_nz"], dev), up=up, padding=1,
+                             resample_filter=D(mg["f"], dev) if up == 2 else None, demodulate=tag.endswith("_d"), flip_weight=(up == 1))
+    gs, = torch.autograd.grad((y * D(mg[tag + "_dy"], dev)).sum(), [s], create_graph=True)
+    pl = gs.square().sum()
+    assert abs(float(pl.detach()) - float(mg[tag + "_pl"][0])) <= 2e-4 * float(mg[tag + "_pl"][0])
+    g2 = torch.autograd.grad(pl, [x, w, s], allow_unused=True)
+    for got, name in zip(g2, ("pl_dx", "pl_dw", "pl_ds")):
+        want = mg[f"{tag}_{name}"]
+        close(got, want, 5e-4 * max(1e-6, float(np.abs(want).max())))

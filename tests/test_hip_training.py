@@ -139,3 +139,49 @@ def test_gan_loss_phases():
     gr, = torch.autograd.grad(D(r, None).sum(), [r])
     assert abs(st["Loss/r1_penalty"] - float(gr.square().sum([1, 2, 3]).mean())) <= 1e-4 * st["Loss/r1_penalty"]
     assert len(g_d) == len(list(D.parameters()))
+
+
+def test_path_length_regulariser_matches_oracle():
+    """'Greg' phase: gradients of the path-length penalty (a second-order quantity: it differentiates d(img . noise)/d ws)
+    w.r.t. the generator parameters, HIP autograd path vs the oracle under torch.autograd on CPU, same pl noise."""
+    from brushstroke_engine_amd.training import (TrainableGenerator, TrainableDiscriminator, GanLoss,
+                                                 random_discriminator_state_dict)
+    from oracle import neube_oracle as orc
+    cfg, sd, z, geom, pos = _setup(n=4)
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(2)
+    b = 2                                                                  # pl_batch_shrink = 2
+    noise = (rs.randn(b, 3, cfg.img_resolution, cfg.img_resolution) / cfg.img_resolution).astype(np.float32)
+    # oracle in float64 (a second-order quantity through 8 layers: fp32 evaluations of it differ at the 1e-2 level)
+    O = orc.OracleGenerator(cfg, sd, dtype=torch.float64)
+    keys = [k for k in O.sd if k.endswith((".weight", ".bias", ".noise_strength", ".const", ".color_bias"))]
+    for k in keys:
+        O.sd[k].requires_grad_(True)
+    ws = O.mapping(torch.tensor(z[:b], dtype=torch.float64))
+    img, _ = O.synthesis(ws, [torch.tensor(g[:b], dtype=torch.float64) for g in geom], return_debug_data=True)
+    plg, = torch.autograd.grad((img * torch.tensor(noise, dtype=torch.float64)).sum(), [ws], create_graph=True)
+    pl_len = plg.square().sum(2).mean(1).sqrt()
+    pl_mean = torch.zeros([], dtype=torch.float64).lerp(pl_len.mean(), 0.01).detach()
+    loss_o = ((pl_len - pl_mean).square() * 2.0).mean()
+    grads_o = torch.autograd.grad(loss_o, [O.sd[k] for k in keys], allow_unused=True)
+    # HIP
+    G = TrainableGenerator(cfg, sd, dev)
+    D = TrainableDiscriminator(random_discriminator_state_dict(32, 3, channel_base=512, channel_max=24), 32, 3, channel_base=512,
+                               channel_max=24, device=dev)
+    loss = GanLoss(G, D)
+    st = loss.accumulate_gradients("Greg", None, [torch.from_numpy(g).to(dev) for g in geom], torch.from_numpy(z).to(dev),
+                                   pl_noise=torch.from_numpy(noise).to(dev))
+    want_pen = float((pl_len - pl_mean).square().mean().detach())
+    assert abs(st["Loss/pl_penalty"] - want_pen) <= 1e-3 * want_pen
+    params = dict(G.named_reference_parameters())
+    checked = 0
+    for k, go in zip(keys, grads_o):
+        gt = params[k].grad
+        if go is None or float(go.abs().max()) == 0.0:
+            assert gt is None or float(gt.abs().max()) <= 1e-7
+            continue
+        scale = float(go.abs().max())
+        err = float((gt.cpu().double() - go).abs().max())
+        assert err <= 2e-2 * scale + 1e-9, (k, err, scale)
+        checked += 1
+    assert checked >= 20
