@@ -292,10 +292,20 @@ def pack_conv_weight(weight: torch.Tensor):
     return wpk, wsq
 
 
+def _pow2(v: int) -> bool:
+    return v >= 4 and (v & (v - 1)) == 0
+
+
 def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
     n, ci, h, wd = x.shape
     co, ci2, kh, kw = w.shape
     assert ci == ci2
+    if kh == 3 and kw == 3 and stride == 1 and padding == 1 and _pow2(h) and _pow2(wd):
+        # the tiled fp32-MFMA kernel of the generator (LDS-staged, 5-20x the generic kernel's rate): its styles / demodulation
+        # slots carry the optional channel scales (ones otherwise), identity epilogue
+        ones = lambda c: torch.ones([n, c], dtype=torch.float32, device=x.device)
+        return _modulated_conv2d_forward(x, w, ones(ci) if in_scale is None else in_scale, None, up=1, padding=1, demodulate=False,
+                                         flip_weight=True, dcoefs=ones(co) if out_scale is None else out_scale)
     ho, wo = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
     y = torch.empty([n, co, ho, wo], dtype=torch.float32, device=x.device)
     isc = None if in_scale is None else in_scale.contiguous()
