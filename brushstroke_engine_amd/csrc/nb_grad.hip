@@ -79,8 +79,7 @@ extern "C" int nb_conv2d_f32(const float* x, const float* w, const float* in_sca
 
 // ------------------------------------------------------------------------------------------------
 // Weight-gradient correlation:  A[n,cu,cv,a,b] = sum_{i,j} U[n,cu, i*st+a-pad, j*st+b-pad] * V[n,cv,i,j]
-// (a, b in [0,3); zero outside U).  One wave per workgroup = one 32 (cu) x 32 (cv) tile of all 9 taps for a slice of
-// V's rows; the row slices add their partial sums atomically into A, which the caller zeroes.
+// (a, b in [0,3); zero outside U); the row slices of a launch add their partial sums atomically into A (zeroed first).
 //   up = 1 layers: U = modulated input (pad 1, st 1), V = dL/d(conv output)  ->  A[n, c_in, c_out]
 //   up = 2 layers: U = FIR-adjoint of dL/dy on the (2H+1)^2 grid (pad 0, st 2), V = modulated input -> A[n, c_out, c_in]
 // ------------------------------------------------------------------------------------------------
@@ -89,64 +88,100 @@ struct WgradParams {
     int n, cu, hu, wu, cv, hv, wv, stride, pad, rows_per_wg, nslices;
 };
 
-__global__ __launch_bounds__(64) void conv2d_wgrad_f32_kernel(const WgradParams p) {
-    const int lane = threadIdx.x, l31 = lane & 31, lk = lane >> 5;
-    const int cu0 = blockIdx.x * 32, cv0 = blockIdx.y * 32;
+// Workgroup = 4 waves = 32 (cu) x 128 (cv) of all 9 taps (wave w owns cv columns 32w .. 32w+31, so no cross-wave
+// reduction), for one sample and a slice of V's rows.  Per V row and 64-pixel column chunk the operands are staged in
+// LDS with coalesced loads (lanes along pixels): V[128 cv][64] and the three U rows the taps need, U[3][32 cu][64 st + 2]
+// (zeros outside the image), odd row pitches so that the channel-on-the-lane fragment reads are conflict free; then per
+// pixel pair 1 + 9 single-dword LDS reads feed 9 v_mfma_f32_32x32x2_f32.  Row slices add their partial sums atomically.
+#define NB_WG_CW 64
+__global__ __launch_bounds__(256) void conv2d_wgrad_f32_kernel(const WgradParams p) {
+    extern __shared__ float smem_wg[];
+    const int st = p.stride;
+    const int UW = NB_WG_CW * st + 3;                       // staged U columns per row (odd pitch)
+    constexpr int VP = NB_WG_CW + 1;                        // V row pitch (odd)
+    float* sv = smem_wg;                                    // [128][VP]
+    float* su = smem_wg + 128 * VP;                         // [3][32][UW]
+    const int tid = threadIdx.x, lane = tid & 63, wvid = tid >> 6, l31 = lane & 31, lk = lane >> 5;
+    const int cu0 = blockIdx.x * 32, cv0 = blockIdx.y * 128;
     const int n = blockIdx.z / p.nslices, sl = blockIdx.z - n * p.nslices;
-    const int cu = cu0 + l31, cv = cv0 + l31;
-    const bool uval = cu < p.cu, vval = cv < p.cv;
-    const float* un = p.u + ((size_t)n * p.cu + (uval ? cu : 0)) * p.hu * p.wu;
-    const float* vn = p.v + ((size_t)n * p.cv + (vval ? cv : 0)) * p.hv * p.wv;
+    const float* un = p.u + (size_t)n * p.cu * p.hu * p.wu;
+    const float* vn = p.v + (size_t)n * p.cv * p.hv * p.wv;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool wave_active = cv0 + wvid * 32 < p.cv;
     const int i1 = min(p.hv, (sl + 1) * p.rows_per_wg);
     for (int i = sl * p.rows_per_wg; i < i1; ++i) {
-        for (int j0 = 0; j0 < p.wv; j0 += 2) {
-            const int j = j0 + lk;
-            const bool jv = j < p.wv;
-            const float bv = (vval && jv) ? vn[(size_t)i * p.wv + j] : 0.f;
+        for (int jc = 0; jc < p.wv; jc += NB_WG_CW) {
+            __syncthreads();                                 // previous chunk's fragment reads are done
+            for (int idx = tid; idx < 128 * NB_WG_CW; idx += 256) {
+                const int c = idx / NB_WG_CW, j = idx - c * NB_WG_CW;
+                float val = 0.f;
+                if (cv0 + c < p.cv && jc + j < p.wv) val = vn[((size_t)(cv0 + c) * p.hv + i) * p.wv + jc + j];
+                sv[c * VP + j] = val;
+            }
+            const int ucols = NB_WG_CW * st + 2;
+            for (int idx = tid; idx < 3 * 32 * ucols; idx += 256) {
+                const int a = idx / (32 * ucols), rem = idx - a * (32 * ucols);
+                const int c = rem / ucols, t = rem - c * ucols;
+                const int y = i * st + a - p.pad, x = jc * st - p.pad + t;
+                float val = 0.f;
+                if (cu0 + c < p.cu && y >= 0 && y < p.hu && x >= 0 && x < p.wu) val = un[((size_t)(cu0 + c) * p.hu + y) * p.wu + x];
+                su[(a * 32 + c) * UW + t] = val;
+            }
+            __syncthreads();
+            if (wave_active) {
+                const float* svw = sv + (wvid * 32 + l31) * VP + lk;
+                const float* suw = su + l31 * UW + lk * st;
+#pragma unroll 4
+                for (int j0 = 0; j0 < NB_WG_CW; j0 += 2) {
+                    const float bv = svw[j0];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int y = i * p.stride + a - p.pad;
+                    for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const int x = j * p.stride + b - p.pad;
-                    float av = 0.f;
-                    if (uval && jv && y >= 0 && y < p.hu && x >= 0 && x < p.wu) av = un[(size_t)y * p.wu + x];
-                    acc[a * 3 + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a * 3 + b], 0, 0, 0);
+                        for (int b = 0; b < 3; ++b)
+                            acc[a * 3 + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(suw[a * 32 * UW + j0 * st + b], bv, acc[a * 3 + b], 0, 0, 0);
                 }
             }
         }
     }
+    if (!wave_active) return;
+    const int cvl = cv0 + wvid * 32 + l31;
+    if (cvl >= p.cv) return;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = cu0 + (r & 3) + 8 * (r >> 2) + 4 * lk;      // cu row of the D tile; this lane's column = cv
-            if (m < p.cu && vval) atomicAdd(p.a + (((size_t)n * p.cu + m) * p.cv + cv) * 9 + t, acc[t][r]);
+            if (m < p.cu) atomicAdd(p.a + (((size_t)n * p.cu + m) * p.cv + cvl) * 9 + t, acc[t][r]);
         }
 }
 
 extern "C" int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int n, int cu, int hu, int wu, int cv, int hv,
                                    int wv, int stride, int pad, void* stream) {
     NB_REQUIRE(u && v && a, "conv2d_wgrad: null pointer");
-    NB_REQUIRE(n >= 1 && cu >= 1 && cv >= 1 && hu >= 1 && wu >= 1 && hv >= 1 && wv >= 1 && stride >= 1 && pad >= 0, "conv2d_wgrad: bad sizes");
+    NB_REQUIRE(n >= 1 && cu >= 1 && cv >= 1 && hu >= 1 && wu >= 1 && hv >= 1 && wv >= 1 && (stride == 1 || stride == 2) && pad >= 0,
+               "conv2d_wgrad: bad sizes (stride 1 or 2)");
     WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0};
     // enough workgroups to fill the chip: slice V's rows when there are few (n, tile) combinations
-    const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 32);
-    int slices = (int)((1024 + tiles - 1) / tiles);
+    const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
+    int slices = (int)((512 + tiles - 1) / tiles);
     if (slices > hv) slices = hv;
     if (slices < 1) slices = 1;
     p.rows_per_wg = nb_cdiv(hv, slices);
-    const int nslices = nb_cdiv(hv, p.rows_per_wg);
-    p.nslices = nslices;
-    NB_REQUIRE((long)n * nslices <= 65535 && nb_cdiv(cv, 32) <= 65535, "conv2d_wgrad: grid too large");
+    p.nslices = nb_cdiv(hv, p.rows_per_wg);
+    NB_REQUIRE((long)n * p.nslices <= 65535 && nb_cdiv(cv, 128) <= 65535, "conv2d_wgrad: grid too large");
+    const size_t lds = (size_t)(128 * (NB_WG_CW + 1) + 3 * 32 * (NB_WG_CW * stride + 3)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv2d_wgrad_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
     (void)hipMemsetAsync(a, 0, (size_t)n * cu * cv * 9 * sizeof(float), (hipStream_t)stream);
-    dim3 grid(nb_cdiv(cu, 32), nb_cdiv(cv, 32), n * nslices);
-    hipLaunchKernelGGL(conv2d_wgrad_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, p);
+    dim3 grid(nb_cdiv(cu, 32), nb_cdiv(cv, 128), n * p.nslices);
+    hipLaunchKernelGGL(conv2d_wgrad_f32_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("conv2d_wgrad");
     return NB_OK;
 }
