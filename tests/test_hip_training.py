@@ -185,3 +185,31 @@ def test_path_length_regulariser_matches_oracle():
         assert err <= 2e-2 * scale + 1e-9, (k, err, scale)
         checked += 1
     assert checked >= 20
+
+
+def test_ddp_gradients_equal_full_batch(tmp_path):
+    """Data parallelism of the training path: two ranks (both on cuda:0, gloo backend) wrap the differentiable generator in
+    DistributedDataParallel and each back-propagates its half of the batch; the all-reduced (averaged) gradients must
+    equal the single-process gradients of the mean loss over the whole batch."""
+    import os, socket, subprocess, sys
+    from brushstroke_engine_amd.training import TrainableGenerator
+    cfg, sd, z, geom, pos = _setup(n=4)
+    dev = torch.device("cuda:0")
+    G = TrainableGenerator(cfg, sd, dev)
+    target = np.random.RandomState(1).randn(4, 3, 32, 32).astype(np.float32)
+    img = G(torch.from_numpy(z).to(dev), None, [torch.from_numpy(g).to(dev) for g in geom])
+    (img - torch.from_numpy(target).to(dev)).square().mean().backward()
+    want = {k: p.grad.cpu().numpy() for k, p in G.named_reference_parameters() if p.grad is not None}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = str(tmp_path / "ddp_grads.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ddp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", out], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    assert set(got.files) == set(want)
+    for k in want:
+        scale = max(float(np.abs(want[k]).max()), 1e-8)
+        assert float(np.abs(got[k] - want[k]).max()) <= 1e-4 * scale + 1e-9, k
