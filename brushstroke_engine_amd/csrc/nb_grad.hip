@@ -19,6 +19,9 @@ struct ConvParams {
     int n, ci, h, wd, co, kh, kw, stride, pad, ho, wo;
 };
 
+// KS = compile-time kernel size (1 or 3: fully unrolled taps, so a channel pair's 2 x KS^2 operand loads are all in flight
+// before its MFMAs), 0 = run-time kh x kw.
+template <int KS>
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvParams p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, lk = lane >> 5;
     const int n = blockIdx.z, co0 = blockIdx.y * 32;
@@ -28,7 +31,8 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvParams p) {
     const int oy = pvalid ? pix / p.wo : 0, ox = pvalid ? pix - oy * p.wo : 0;
     const int co = co0 + l31;
     const bool cvalid = co < p.co;
-    const int ktaps = p.kh * p.kw;
+    const int kh = KS ? KS : p.kh, kw = KS ? KS : p.kw;
+    const int ktaps = kh * kw;
     const float* xn = p.x + (size_t)n * p.ci * p.h * p.wd;
     const float* wr = p.w + (size_t)(cvalid ? co : 0) * p.ci * ktaps;
     f32x16 acc;
@@ -40,14 +44,29 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvParams p) {
         const float sc = (chv && p.in_scale) ? p.in_scale[(size_t)n * p.ci + c] : 1.f;
         const float* xc = xn + (size_t)(chv ? c : 0) * p.h * p.wd;
         const float* wc = wr + (size_t)(chv ? c : 0) * ktaps;
-        for (int a = 0; a < p.kh; ++a) {
-            const int iy = oy * p.stride + a - p.pad;
-            for (int b = 0; b < p.kw; ++b) {
-                const int ix = ox * p.stride + b - p.pad;
-                float bv = 0.f, av = 0.f;
-                if (chv && pvalid && iy >= 0 && iy < p.h && ix >= 0 && ix < p.wd) bv = xc[(size_t)iy * p.wd + ix] * sc;
-                if (chv && cvalid) av = wc[a * p.kw + b];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        if constexpr (KS != 0) {
+            float av[KS * KS], bv[KS * KS];
+#pragma unroll
+            for (int a = 0; a < KS; ++a)
+#pragma unroll
+                for (int b = 0; b < KS; ++b) {
+                    const int iy = oy * p.stride + a - p.pad, ix = ox * p.stride + b - p.pad;
+                    const bool ok = chv && pvalid && iy >= 0 && iy < p.h && ix >= 0 && ix < p.wd;
+                    bv[a * KS + b] = ok ? xc[(size_t)iy * p.wd + ix] : 0.f;
+                    av[a * KS + b] = (chv && cvalid) ? wc[a * KS + b] : 0.f;
+                }
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t] * sc, acc, 0, 0, 0);
+        } else {
+            for (int a = 0; a < kh; ++a) {
+                const int iy = oy * p.stride + a - p.pad;
+                for (int b = 0; b < kw; ++b) {
+                    const int ix = ox * p.stride + b - p.pad;
+                    float bv = 0.f, av = 0.f;
+                    if (chv && pvalid && iy >= 0 && iy < p.h && ix >= 0 && ix < p.wd) bv = xc[(size_t)iy * p.wd + ix] * sc;
+                    if (chv && cvalid) av = wc[a * kw + b];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                }
             }
         }
     }
@@ -72,7 +91,9 @@ extern "C" int nb_conv2d_f32(const float* x, const float* w, const float* in_sca
     NB_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv2d: empty output");
     dim3 grid(nb_cdiv(p.ho * p.wo, 128), nb_cdiv(c_out, 32), n);
     NB_REQUIRE(grid.y <= 65535, "conv2d: too many output channels");
-    hipLaunchKernelGGL(conv2d_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (kh == 3 && kw == 3) hipLaunchKernelGGL(conv2d_f32_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (kh == 1 && kw == 1) hipLaunchKernelGGL(conv2d_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv2d_f32_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("conv2d");
     return NB_OK;
 }
