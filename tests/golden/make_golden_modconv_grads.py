@@ -29,7 +29,7 @@ def main():
     rng = np.random.RandomState(4321)
     f = rup.setup_filter([1, 3, 3, 1])
     out["f"] = f.numpy()
-    for up, n, ci, co, h in ((1, 2, 12, 10, 8), (2, 2, 10, 12, 4), (1, 3, 40, 36, 16), (2, 1, 36, 40, 8)):
+    for up, n, ci, co, h in ((1, 2, 12, 10, 8), (2, 2, 10, 12, 4), (1, 2, 40, 36, 8), (2, 1, 36, 40, 4)):
         for demod in (True, False):
             tag = f"up{up}_c{ci}_{'d' if demod else 'n'}"
             x0 = rng.randn(n, ci, h, h).astype(np.float32)
