@@ -275,10 +275,28 @@ class GanLoss:
     augmentation pipeline."""
 
     def __init__(self, G: TrainableGenerator, D: TrainableDiscriminator, r1_gamma: float = 10.0, pl_batch_shrink: int = 2,
-                 pl_decay: float = 0.01, pl_weight: float = 2.0):
-        self.G, self.D, self.r1_gamma = G, D, r1_gamma
+                 pl_decay: float = 0.01, pl_weight: float = 2.0, augment_pipe=None):
+        self.G, self.r1_gamma = G, r1_gamma
+        self._D, self.augment_pipe = D, augment_pipe
+        self.real_sign_sum, self.real_sign_count = 0.0, 0          # 'Loss/signs/real': what ADA adapts p on
         self.pl_batch_shrink, self.pl_decay, self.pl_weight = pl_batch_shrink, pl_decay, pl_weight
         self.pl_mean = torch.zeros([], device=next(G.parameters()).device)
+
+    def D(self, img, c=None):
+        """``ForgerLoss.run_D`` (loss_modified.py:102-107): the discriminator sees augmented images."""
+        if self.augment_pipe is not None:
+            img = self.augment_pipe(img)
+        return self._D(img, c)
+
+    def ada_update(self, ada_target: float, batch_size: int, ada_interval: int, ada_kimg: float) -> float:
+        """The training loop's ADA heuristic (training_loop_modified.py: adjust p by the sign of E[sign(D(real))] - target)."""
+        if self.augment_pipe is None or self.real_sign_count == 0:
+            return 0.0
+        sign = self.real_sign_sum / self.real_sign_count
+        adjust = float(np.sign(sign - ada_target)) * (batch_size * ada_interval) / (ada_kimg * 1000)
+        self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp(min=0))
+        self.real_sign_sum, self.real_sign_count = 0.0, 0
+        return float(self.augment_pipe.p)
 
     def accumulate_gradients(self, phase: str, real_img, geom_feature, gen_z, gain: float = 1.0, positions=None,
                              pl_noise=None) -> Dict[str, float]:
@@ -313,6 +331,8 @@ class GanLoss:
             do_main, do_r1 = phase in ("Dmain", "Dall"), phase in ("Dreg", "Dall") and self.r1_gamma != 0
             real = real_img.detach().requires_grad_(do_r1)
             real_logits = self.D(real, None)
+            self.real_sign_sum += float(real_logits.detach().sign().sum())
+            self.real_sign_count += real_logits.numel()
             total = real_logits * 0
             if do_main:
                 loss_real = softplus(-real_logits)
