@@ -1,0 +1,87 @@
+"""BASELINE config 5 (training step, synthetic / random init): G + D forward / backward with the StyleGAN2-ADA phase
+schedule (Gmain every iteration, Greg = path length every 4th, Dmain every iteration, Dreg = R1 every 16th; ADA 'bgc'
+pipe in front of D), on the differentiable HIP operators.  One process per GPU; with WORLD_SIZE > 1 both networks are
+wrapped in DistributedDataParallel over RCCL (gradient all-reduce ~8 MB per network per step).  Prints one JSON line.
+
+    python tools/bench_train.py [--res 256] [--batch 8] [--iters 16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_train.py
+"""
+import argparse, json, os, sys, time
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+from brushstroke_engine_amd.augment import AugmentPipe
+from brushstroke_engine_amd.training import TrainableGenerator, TrainableDiscriminator, GanLoss, random_discriminator_state_dict
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--res", type=int, default=256); ap.add_argument("--batch", type=int, default=8, help="per GPU")
+    ap.add_argument("--iters", type=int, default=16); ap.add_argument("--warmup", type=int, default=4)
+    a = ap.parse_args()
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    cfg = cfgmod.style1_config(a.res)
+    G = TrainableGenerator(cfg, wmod.random_state_dict(cfg, 0), dev)
+    D = TrainableDiscriminator(random_discriminator_state_dict(a.res, 3, channel_base=16384, channel_max=128), a.res, 3,
+                               channel_base=16384, channel_max=128, conv_clamp=256, device=dev)
+    Gm, Dm = G, D
+    if world > 1:
+        ddp = lambda m: torch.nn.parallel.DistributedDataParallel(m, device_ids=[local], broadcast_buffers=False, find_unused_parameters=True)
+        Gm, Dm = ddp(G), ddp(D)
+    pipe = AugmentPipe(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1,
+                       saturation=1).to(dev)
+    pipe.p.fill_(0.3)
+    loss = GanLoss(G, D, augment_pipe=pipe)
+    if world > 1:                       # route the forward calls through the DDP wrappers (gradient all-reduce hooks)
+        loss.G, loss._D = (lambda *x, **k: Gm(*x, **k)), (lambda *x, **k: Dm(*x, **k))
+        loss.pl_mean = torch.zeros([], device=dev)
+    optG = torch.optim.Adam(G.parameters(), lr=2e-3, betas=(0.0, 0.99)); optD = torch.optim.Adam(D.parameters(), lr=2e-3, betas=(0.0, 0.99))
+    n = a.batch
+    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, n, rank)]
+    real = torch.tanh(torch.nn.functional.interpolate(torch.randn(n, 3, 8, 8, device=dev), size=a.res, mode="bilinear"))
+
+    def iteration(it):
+        z = torch.randn(n, cfg.z_dim, device=dev)
+        optG.zero_grad(set_to_none=True)
+        loss.accumulate_gradients("Gmain", real, geom, z)
+        if it % 4 == 0:
+            loss.accumulate_gradients("Greg", real, geom, z, gain=4)
+        optG.step()
+        optD.zero_grad(set_to_none=True)
+        loss.accumulate_gradients("Dmain", real, geom, z)
+        if it % 16 == 0:
+            loss.accumulate_gradients("Dreg", real, geom, z, gain=16)
+        optD.step()
+
+    for it in range(a.warmup):
+        iteration(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for it in range(a.iters):
+        iteration(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
+    if rank == 0:
+        print(json.dumps({"metric": "training throughput, images/s (G+D fwd/bwd, lazy path-length and R1 regularisation, ADA bgc)",
+                          "value": round(world * n * a.iters / dt, 2), "unit": "img/s", "n_gpus": world, "ms_per_iteration": round(dt / a.iters * 1e3, 2),
+                          "config": {"resolution": a.res, "batch_per_gpu": n, "schedule": "Gmain 1/1, Greg 1/4, Dmain 1/1, Dreg 1/16",
+                                     "parallelism": f"data-parallel x{world}" + (" (DistributedDataParallel over RCCL)" if world > 1 else "")},
+                          "dtype": "f32", "data": "synthetic"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
