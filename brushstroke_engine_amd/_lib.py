@@ -52,6 +52,7 @@ PROTOTYPES = {
                                              C.c_int, C.c_float, C.c_float, C.c_float, vp]),
     "nb_conv2d_f32": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
     "nb_conv2d_wgrad_f32": (C.c_int, [vp, vp, vp] + [C.c_int] * 9 + [vp]),
+    "nb_conv2d_wgrad_h3": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
     "nb_mapping_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_mapping_ws_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     "nb_styles_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),

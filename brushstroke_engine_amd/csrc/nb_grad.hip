@@ -206,3 +206,131 @@ extern "C" int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int
     NB_CHECK_LAUNCH("conv2d_wgrad");
     return NB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same correlation on the f16 matrix cores with the split products of the inference kernels (hi/lo f16 halves of both
+// operands, x y ~= xh yh + xh yl + xl yh, fp32 accumulate: ~2^-22 relative) - 27 v_mfma_f32_32x32x16_f16 per 16 pixels
+// instead of 72 fp32 MFMAs.  Gradients can be far below the f16 range, so both operands are multiplied by a power of two
+// (scales[0] for U, scales[1] for V, computed by the caller from the tensors' max-abs so that the largest value sits
+// near 2^10) while they are split on their way into LDS, and the result is divided by the product.
+// LDS: V hi/lo [128][72] f16 and, per tap (a, b), U hi/lo [32][72] f16 holding U[row a][(j)*stride + b - pad] - one
+// pre-shifted (and, for stride 2, decimated) copy per tap, so that every MFMA fragment is one aligned ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8g __attribute__((ext_vector_type(8)));
+typedef _Float16 h2g __attribute__((ext_vector_type(2)));
+#define NB_WH_P 72             // row pitch in halves (144 B: 16-byte aligned rows, conflict-free b128 reads over 8 rows)
+
+__global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams p, const float* __restrict__ scales) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wh[];
+    _Float16* svh = reinterpret_cast<_Float16*>(smem_wh);                 // [128][P]
+    _Float16* svl = svh + 128 * NB_WH_P;
+    _Float16* suh = svl + 128 * NB_WH_P;                                  // [9][32][P]
+    _Float16* sul = suh + 9 * 32 * NB_WH_P;
+    const int st = p.stride;
+    const int tid = threadIdx.x, lane = tid & 63, wvid = tid >> 6, l31 = lane & 31, lk = lane >> 5;
+    const int cu0 = blockIdx.x * 32, cv0 = blockIdx.y * 128;
+    const int n = blockIdx.z / p.nslices, sl = blockIdx.z - n * p.nslices;
+    const float* un = p.u + (size_t)n * p.cu * p.hu * p.wu;
+    const float* vn = p.v + (size_t)n * p.cv * p.hv * p.wv;
+    const float scu = scales[0], scv = scales[1];
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool wave_active = cv0 + wvid * 32 < p.cv;
+    auto split2 = [](float a, float b, h2g& hi, h2g& lo) {
+        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+        hi[0] = ah; hi[1] = bh;
+        lo[0] = (_Float16)(a - (float)ah); lo[1] = (_Float16)(b - (float)bh);
+    };
+    const int i1 = min(p.hv, (sl + 1) * p.rows_per_wg);
+    for (int i = sl * p.rows_per_wg; i < i1; ++i) {
+        for (int jc = 0; jc < p.wv; jc += NB_WG_CW) {
+            __syncthreads();
+            for (int idx = tid; idx < 128 * (NB_WG_CW / 2); idx += 256) {                     // V: pixel pairs
+                const int c = idx / (NB_WG_CW / 2), j = 2 * (idx - c * (NB_WG_CW / 2));
+                float v0 = 0.f, v1 = 0.f;
+                if (cv0 + c < p.cv) {
+                    const float* row = vn + ((size_t)(cv0 + c) * p.hv + i) * p.wv;
+                    if (jc + j < p.wv) v0 = row[jc + j] * scv;
+                    if (jc + j + 1 < p.wv) v1 = row[jc + j + 1] * scv;
+                }
+                h2g hi, lo;
+                split2(v0, v1, hi, lo);
+                *reinterpret_cast<h2g*>(svh + c * NB_WH_P + j) = hi;
+                *reinterpret_cast<h2g*>(svl + c * NB_WH_P + j) = lo;
+            }
+            for (int idx = tid; idx < 9 * 32 * (NB_WG_CW / 2); idx += 256) {                  // U: one shifted copy per tap
+                const int ab = idx / (32 * (NB_WG_CW / 2)), rem = idx - ab * (32 * (NB_WG_CW / 2));
+                const int c = rem / (NB_WG_CW / 2), j = 2 * (rem - c * (NB_WG_CW / 2));
+                const int a = ab / 3, b = ab - 3 * a;
+                const int y = i * st + a - p.pad, x0 = (jc + j) * st + b - p.pad, x1 = x0 + st;
+                float u0 = 0.f, u1 = 0.f;
+                if (cu0 + c < p.cu && y >= 0 && y < p.hu) {
+                    const float* row = un + ((size_t)(cu0 + c) * p.hu + y) * p.wu;
+                    if (x0 >= 0 && x0 < p.wu && jc + j < p.wv) u0 = row[x0] * scu;
+                    if (x1 >= 0 && x1 < p.wu && jc + j + 1 < p.wv) u1 = row[x1] * scu;
+                }
+                h2g hi, lo;
+                split2(u0, u1, hi, lo);
+                *reinterpret_cast<h2g*>(suh + (ab * 32 + c) * NB_WH_P + j) = hi;
+                *reinterpret_cast<h2g*>(sul + (ab * 32 + c) * NB_WH_P + j) = lo;
+            }
+            __syncthreads();
+            if (wave_active) {
+                const int vo = (wvid * 32 + l31) * NB_WH_P + 8 * lk, uo = l31 * NB_WH_P + 8 * lk;
+#pragma unroll
+                for (int ks = 0; ks < NB_WG_CW / 16; ++ks) {
+                    const h8g bh = *reinterpret_cast<const h8g*>(svh + vo + ks * 16);
+                    const h8g bl = *reinterpret_cast<const h8g*>(svl + vo + ks * 16);
+#pragma unroll
+                    for (int ab = 0; ab < 9; ++ab) {
+                        const h8g ah = *reinterpret_cast<const h8g*>(suh + ab * 32 * NB_WH_P + uo + ks * 16);
+                        const h8g al = *reinterpret_cast<const h8g*>(sul + ab * 32 * NB_WH_P + uo + ks * 16);
+                        acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ab], 0, 0, 0);
+                        acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ab], 0, 0, 0);
+                        acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ab], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+    const int cvl = cv0 + wvid * 32 + l31;
+    if (cvl >= p.cv) return;
+    const float inv = 1.f / (scu * scv);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = cu0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < p.cu) atomicAdd(p.a + (((size_t)n * p.cu + m) * p.cv + cvl) * 9 + t, acc[t][r] * inv);
+        }
+}
+
+extern "C" int nb_conv2d_wgrad_h3(const float* u, const float* v, const float* scales, float* a, int n, int cu, int hu, int wu,
+                                  int cv, int hv, int wv, int stride, int pad, void* stream) {
+    NB_REQUIRE(u && v && a && scales, "conv2d_wgrad_h3: null pointer");
+    NB_REQUIRE(n >= 1 && cu >= 1 && cv >= 1 && hu >= 1 && wu >= 1 && hv >= 1 && wv >= 1 && (stride == 1 || stride == 2) && pad >= 0,
+               "conv2d_wgrad_h3: bad sizes (stride 1 or 2)");
+    WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0};
+    const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
+    int slices = (int)((512 + tiles - 1) / tiles);
+    if (slices > hv) slices = hv;
+    if (slices < 1) slices = 1;
+    p.rows_per_wg = nb_cdiv(hv, slices);
+    p.nslices = nb_cdiv(hv, p.rows_per_wg);
+    NB_REQUIRE((long)n * p.nslices <= 65535 && nb_cdiv(cv, 128) <= 65535, "conv2d_wgrad_h3: grid too large");
+    const size_t lds = (size_t)(2 * 128 + 2 * 9 * 32) * NB_WH_P * sizeof(_Float16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv2d_wgrad_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    (void)hipMemsetAsync(a, 0, (size_t)n * cu * cv * 9 * sizeof(float), (hipStream_t)stream);
+    dim3 grid(nb_cdiv(cu, 32), nb_cdiv(cv, 128), n * p.nslices);
+    hipLaunchKernelGGL(conv2d_wgrad_h3_kernel, grid, dim3(256), lds, (hipStream_t)stream, p, scales);
+    NB_CHECK_LAUNCH("conv2d_wgrad_h3");
+    return NB_OK;
+}

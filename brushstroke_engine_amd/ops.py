@@ -316,11 +316,26 @@ def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
     return y
 
 
+# Weight-gradient correlations on the f16 matrix cores (split operands, nb_conv2d_wgrad_h3) instead of the exact-fp32 MFMA
+# kernel.  Off by default: measured only 11 % faster (589 vs 662 us per launch in tools/bench_train.py) - with one 4-wave
+# workgroup per CU the operand staging (global -> split -> LDS, nine pre-shifted copies of every U row) is latency bound,
+# not the matrix pipe; it needs a rolling window of U rows and register prefetch under the MFMAs first.
+WGRAD_SPLIT_F16 = False
+
+
 def _wgrad_launch(u, v, stride, padding):
     n, cu, hu, wu = u.shape
     n2, cv, hv, wv = v.shape
     assert n == n2
     a = torch.empty([n, cu, cv, 3, 3], dtype=torch.float32, device=u.device)
+    if WGRAD_SPLIT_F16:
+        # power-of-two scales that bring each operand's largest magnitude near 2^10 (computed on the device: no sync)
+        mx = torch.stack([u.detach().abs().amax(), v.detach().abs().amax()]).clamp_min(1e-30)
+        scales = torch.exp2(torch.floor(torch.log2(1024.0 / mx))).to(torch.float32).contiguous()
+        with torch.cuda.device(u.device):
+            _lib.check(_lib.lib().nb_conv2d_wgrad_h3(_p(u.contiguous()), _p(v.contiguous()), _p(scales), _p(a), n, cu, hu, wu, cv, hv, wv,
+                                                     stride, padding, _stream(u)), "conv2d_wgrad_h3")
+        return a
     with torch.cuda.device(u.device):
         _lib.check(_lib.lib().nb_conv2d_wgrad_f32(_p(u.contiguous()), _p(v.contiguous()), _p(a), n, cu, hu, wu, cv, hv, wv,
                                                   stride, padding, _stream(u)), "conv2d_wgrad")

@@ -93,6 +93,11 @@ int nb_conv2d_f32(const float* x, const float* w, const float* in_scale, const f
 int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int n, int cu, int hu, int wu, int cv, int hv, int wv,
                         int stride, int pad, void* stream);
 
+/* The same on the f16 matrix cores with split (hi/lo) operands: scales = 2 floats in device memory, powers of two that bring
+ * max|u| and max|v| near 2^10 (gradients may sit far below the f16 range); the result is divided by their product. */
+int nb_conv2d_wgrad_h3(const float* u, const float* v, const float* scales, float* a, int n, int cu, int hu, int wu, int cv,
+                       int hv, int wv, int stride, int pad, void* stream);
+
 /* ---- generator path ---------------------------------------------------------------------- */
 
 /* MappingNetwork.forward (training/networks.py:255-290) for c_dim = 0, without the broadcast:

@@ -165,9 +165,20 @@ def test_modulated_conv2d_partial_grads_and_no_grad(dev, mg):
         assert not ops.modulated_conv2d(x, w, s, up=1, padding=1).requires_grad
 
 
-def test_conv2d_and_wgrad_kernels_vs_torch(dev):
-    """The two gradient building blocks against torch fp64 on odd shapes (ragged channel tiles, stride 2, padding)."""
+@pytest.mark.parametrize("split_f16", [False, True])
+def test_conv2d_and_wgrad_kernels_vs_torch(dev, split_f16):
+    """The two gradient building blocks against torch fp64 on odd shapes (ragged channel tiles, stride 2, padding); the
+    weight-gradient correlation in its exact-fp32 and its split-f16 form."""
     from brushstroke_engine_amd import ops
+    prev = ops.WGRAD_SPLIT_F16
+    ops.WGRAD_SPLIT_F16 = split_f16
+    try:
+        _conv2d_and_wgrad_case(dev, ops)
+    finally:
+        ops.WGRAD_SPLIT_F16 = prev
+
+
+def _conv2d_and_wgrad_case(dev, ops):
     rs = np.random.RandomState(3)
     for n, ci, co, h, w_, k, st, pad in ((2, 5, 7, 9, 11, 3, 1, 1), (1, 34, 40, 13, 9, 3, 2, 0), (2, 3, 33, 8, 8, 5, 2, 2), (1, 70, 3, 6, 7, 1, 1, 0)):
         x = rs.randn(n, ci, h, w_).astype(np.float32); wt = rs.randn(co, ci, k, k).astype(np.float32)
