@@ -7,6 +7,7 @@
 // (L1/L2 serve the reuse).  These are FIRST, correct versions: no LDS tiling yet - the training path is not what this
 // round's performance work is about.
 #include "nb_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -188,7 +189,8 @@ extern "C" int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int
     WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0};
     // enough workgroups to fill the chip: slice V's rows when there are few (n, tile) combinations
     const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
-    int slices = (int)((512 + tiles - 1) / tiles);
+    static const int wg_target = getenv("NB_WGRAD_WGS") ? atoi(getenv("NB_WGRAD_WGS")) : 256;     // one workgroup per CU: more row slices only add atomic traffic (tools/bench_wgrad.py)
+    int slices = (int)((wg_target + tiles - 1) / tiles);
     if (slices > hv) slices = hv;
     if (slices < 1) slices = 1;
     p.rows_per_wg = nb_cdiv(hv, slices);
@@ -316,7 +318,8 @@ extern "C" int nb_conv2d_wgrad_h3(const float* u, const float* v, const float* s
                "conv2d_wgrad_h3: bad sizes (stride 1 or 2)");
     WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0};
     const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
-    int slices = (int)((512 + tiles - 1) / tiles);
+    static const int wg_target = getenv("NB_WGRAD_WGS") ? atoi(getenv("NB_WGRAD_WGS")) : 256;     // one workgroup per CU: more row slices only add atomic traffic (tools/bench_wgrad.py)
+    int slices = (int)((wg_target + tiles - 1) / tiles);
     if (slices > hv) slices = hv;
     if (slices < 1) slices = 1;
     p.rows_per_wg = nb_cdiv(hv, slices);
