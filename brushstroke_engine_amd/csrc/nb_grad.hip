@@ -222,12 +222,20 @@ typedef _Float16 h8g __attribute__((ext_vector_type(8)));
 typedef _Float16 h2g __attribute__((ext_vector_type(2)));
 #define NB_WH_P 72             // row pitch in halves (144 B: 16-byte aligned rows, conflict-free b128 reads over 8 rows)
 
+#ifndef NB_WHC
+#define NB_WHC 32             // V pixels per column chunk of the split-f16 kernel
+#endif
+#define NB_WHP (NB_WHC + 8)    // LDS row pitch in halves: 16-byte aligned rows, conflict-free b128 reads over 8 rows
+// Pipeline: column chunks of NB_WHC V-pixels outermost, V rows inside.  Moving one V row down needs only `stride` new U rows, so
+// U lives in a 4-slot ring of rows (slot = row & 3), each with its three pre-shifted copies; while the MFMAs of row i run,
+// the fp32 values of row i+1 (V row + the new U rows) are already on their way into registers, and are split / written to
+// LDS after the MFMAs - global latency hides under the matrix work even with one workgroup per CU.
 __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams p, const float* __restrict__ scales) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wh[];
     _Float16* svh = reinterpret_cast<_Float16*>(smem_wh);                 // [128][P]
-    _Float16* svl = svh + 128 * NB_WH_P;
-    _Float16* suh = svl + 128 * NB_WH_P;                                  // [9][32][P]
-    _Float16* sul = suh + 9 * 32 * NB_WH_P;
+    _Float16* svl = svh + 128 * NB_WHP;
+    _Float16* suh = svl + 128 * NB_WHP;                                  // [4 ring rows][3 shifts][32][P]
+    _Float16* sul = suh + 12 * 32 * NB_WHP;
     const int st = p.stride;
     const int tid = threadIdx.x, lane = tid & 63, wvid = tid >> 6, l31 = lane & 31, lk = lane >> 5;
     const int cu0 = blockIdx.x * 32, cv0 = blockIdx.y * 128;
@@ -241,60 +249,105 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const bool wave_active = cv0 + wvid * 32 < p.cv;
+    constexpr int HP = NB_WHC / 2;                                      // pixel pairs per row chunk
+    constexpr int VPT = 128 * HP / 256, UPT = 3 * 32 * HP / 256;          // pairs per thread: V row chunk (16), one U row x 3 shifts (12)
     auto split2 = [](float a, float b, h2g& hi, h2g& lo) {
         const _Float16 ah = (_Float16)a, bh = (_Float16)b;
         hi[0] = ah; hi[1] = bh;
         lo[0] = (_Float16)(a - (float)ah); lo[1] = (_Float16)(b - (float)bh);
     };
-    const int i1 = min(p.hv, (sl + 1) * p.rows_per_wg);
-    for (int i = sl * p.rows_per_wg; i < i1; ++i) {
-        for (int jc = 0; jc < p.wv; jc += NB_WG_CW) {
-            __syncthreads();
-            for (int idx = tid; idx < 128 * (NB_WG_CW / 2); idx += 256) {                     // V: pixel pairs
-                const int c = idx / (NB_WG_CW / 2), j = 2 * (idx - c * (NB_WG_CW / 2));
-                float v0 = 0.f, v1 = 0.f;
-                if (cv0 + c < p.cv) {
-                    const float* row = vn + ((size_t)(cv0 + c) * p.hv + i) * p.wv;
-                    if (jc + j < p.wv) v0 = row[jc + j] * scv;
-                    if (jc + j + 1 < p.wv) v1 = row[jc + j + 1] * scv;
-                }
-                h2g hi, lo;
-                split2(v0, v1, hi, lo);
-                *reinterpret_cast<h2g*>(svh + c * NB_WH_P + j) = hi;
-                *reinterpret_cast<h2g*>(svl + c * NB_WH_P + j) = lo;
-            }
-            for (int idx = tid; idx < 9 * 32 * (NB_WG_CW / 2); idx += 256) {                  // U: one shifted copy per tap
-                const int ab = idx / (32 * (NB_WG_CW / 2)), rem = idx - ab * (32 * (NB_WG_CW / 2));
-                const int c = rem / (NB_WG_CW / 2), j = 2 * (rem - c * (NB_WG_CW / 2));
-                const int a = ab / 3, b = ab - 3 * a;
-                const int y = i * st + a - p.pad, x0 = (jc + j) * st + b - p.pad, x1 = x0 + st;
-                float u0 = 0.f, u1 = 0.f;
-                if (cu0 + c < p.cu && y >= 0 && y < p.hu) {
-                    const float* row = un + ((size_t)(cu0 + c) * p.hu + y) * p.wu;
-                    if (x0 >= 0 && x0 < p.wu && jc + j < p.wv) u0 = row[x0] * scu;
-                    if (x1 >= 0 && x1 < p.wu && jc + j + 1 < p.wv) u1 = row[x1] * scu;
-                }
-                h2g hi, lo;
-                split2(u0, u1, hi, lo);
-                *reinterpret_cast<h2g*>(suh + (ab * 32 + c) * NB_WH_P + j) = hi;
-                *reinterpret_cast<h2g*>(sul + (ab * 32 + c) * NB_WH_P + j) = lo;
-            }
-            __syncthreads();
-            if (wave_active) {
-                const int vo = (wvid * 32 + l31) * NB_WH_P + 8 * lk, uo = l31 * NB_WH_P + 8 * lk;
+    auto load_v = [&](int i, int jc, float (&r)[VPT][2]) {
 #pragma unroll
-                for (int ks = 0; ks < NB_WG_CW / 16; ++ks) {
+        for (int k = 0; k < VPT; ++k) {
+            const int idx = k * 256 + tid, c = idx / HP, j = 2 * (idx - c * HP);
+            r[k][0] = r[k][1] = 0.f;
+            if (cv0 + c < p.cv && i < p.hv) {
+                const float* row = vn + ((size_t)(cv0 + c) * p.hv + i) * p.wv;
+                if (jc + j < p.wv) r[k][0] = row[jc + j];
+                if (jc + j + 1 < p.wv) r[k][1] = row[jc + j + 1];
+            }
+        }
+    };
+    auto store_v = [&](const float (&r)[VPT][2]) {
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+            const int idx = k * 256 + tid, c = idx / HP, j = 2 * (idx - c * HP);
+            h2g hi, lo;
+            split2(r[k][0] * scv, r[k][1] * scv, hi, lo);
+            *reinterpret_cast<h2g*>(svh + c * NB_WHP + j) = hi;
+            *reinterpret_cast<h2g*>(svl + c * NB_WHP + j) = lo;
+        }
+    };
+    auto load_u = [&](int y, int jc, float (&r)[UPT][2]) {               // U row y, its three shifted / decimated copies
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            const int idx = k * 256 + tid, b = idx / (32 * HP), rem = idx - b * (32 * HP);
+            const int c = rem / HP, j = 2 * (rem - c * HP);
+            const int x0 = (jc + j) * st + b - p.pad, x1 = x0 + st;
+            r[k][0] = r[k][1] = 0.f;
+            if (cu0 + c < p.cu && y >= 0 && y < p.hu) {
+                const float* row = un + ((size_t)(cu0 + c) * p.hu + y) * p.wu;
+                if (x0 >= 0 && x0 < p.wu && jc + j < p.wv) r[k][0] = row[x0];
+                if (x1 >= 0 && x1 < p.wu && jc + j + 1 < p.wv) r[k][1] = row[x1];
+            }
+        }
+    };
+    auto store_u = [&](int y, const float (&r)[UPT][2]) {
+        const int slot = y & 3;
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            const int idx = k * 256 + tid, b = idx / (32 * HP), rem = idx - b * (32 * HP);
+            const int c = rem / HP, j = 2 * (rem - c * HP);
+            h2g hi, lo;
+            split2(r[k][0] * scu, r[k][1] * scu, hi, lo);
+            *reinterpret_cast<h2g*>(suh + ((slot * 3 + b) * 32 + c) * NB_WHP + j) = hi;
+            *reinterpret_cast<h2g*>(sul + ((slot * 3 + b) * 32 + c) * NB_WHP + j) = lo;
+        }
+    };
+    const int i0 = sl * p.rows_per_wg, i1 = min(p.hv, (sl + 1) * p.rows_per_wg);
+    float rv[VPT][2], ru0[UPT][2], ru1[UPT][2];
+    for (int jc = 0; jc < p.wv; jc += NB_WHC) {
+        if (i0 >= i1) break;
+        __syncthreads();                                                  // previous column chunk's last MFMAs are done
+        // prologue of the chunk: V row i0 and the three U rows it needs
+        load_v(i0, jc, rv); store_v(rv);
+        for (int a = 0; a < 3; ++a) { load_u(i0 * st + a - p.pad, jc, ru0); store_u(i0 * st + a - p.pad, ru0); }
+        __syncthreads();
+        for (int i = i0; i < i1; ++i) {
+            const bool more = i + 1 < i1;
+            if (more) {                                                   // next row's operands -> registers (in flight under the MFMAs)
+                load_v(i + 1, jc, rv);
+                if (st == 1) load_u((i + 1) + 2 - p.pad, jc, ru0);
+                else { load_u((i + 1) * 2 + 1 - p.pad, jc, ru0); load_u((i + 1) * 2 + 2 - p.pad, jc, ru1); }
+            }
+            if (wave_active) {
+                const int vo = (wvid * 32 + l31) * NB_WHP + 8 * lk, uo = l31 * NB_WHP + 8 * lk;
+#pragma unroll
+                for (int ks = 0; ks < NB_WHC / 16; ++ks) {
                     const h8g bh = *reinterpret_cast<const h8g*>(svh + vo + ks * 16);
                     const h8g bl = *reinterpret_cast<const h8g*>(svl + vo + ks * 16);
 #pragma unroll
-                    for (int ab = 0; ab < 9; ++ab) {
-                        const h8g ah = *reinterpret_cast<const h8g*>(suh + ab * 32 * NB_WH_P + uo + ks * 16);
-                        const h8g al = *reinterpret_cast<const h8g*>(sul + ab * 32 * NB_WH_P + uo + ks * 16);
-                        acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ab], 0, 0, 0);
-                        acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ab], 0, 0, 0);
-                        acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ab], 0, 0, 0);
+                    for (int a = 0; a < 3; ++a) {
+                        const int slot = (i * st + a - p.pad) & 3;
+#pragma unroll
+                        for (int b_ = 0; b_ < 3; ++b_) {
+                            const int ro = (slot * 3 + b_) * 32 * NB_WHP + uo + ks * 16;
+                            const h8g ah = *reinterpret_cast<const h8g*>(suh + ro);
+                            const h8g al = *reinterpret_cast<const h8g*>(sul + ro);
+                            f32x16& c_ = acc[a * 3 + b_];
+                            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c_, 0, 0, 0);
+                            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c_, 0, 0, 0);
+                            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c_, 0, 0, 0);
+                        }
                     }
                 }
+            }
+            if (more) {
+                __syncthreads();                                          // every wave has read row i's fragments
+                store_v(rv);
+                if (st == 1) store_u((i + 1) + 2 - p.pad, ru0);
+                else { store_u((i + 1) * 2 + 1 - p.pad, ru0); store_u((i + 1) * 2 + 2 - p.pad, ru1); }
+                __syncthreads();
             }
         }
     }
@@ -325,7 +378,7 @@ extern "C" int nb_conv2d_wgrad_h3(const float* u, const float* v, const float* s
     p.rows_per_wg = nb_cdiv(hv, slices);
     p.nslices = nb_cdiv(hv, p.rows_per_wg);
     NB_REQUIRE((long)n * p.nslices <= 65535 && nb_cdiv(cv, 128) <= 65535, "conv2d_wgrad_h3: grid too large");
-    const size_t lds = (size_t)(2 * 128 + 2 * 9 * 32) * NB_WH_P * sizeof(_Float16);
+    const size_t lds = (size_t)(2 * 128 + 2 * 12 * 32) * NB_WHP * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv2d_wgrad_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -316,11 +316,9 @@ def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
     return y
 
 
-# Weight-gradient correlations on the f16 matrix cores (split operands, nb_conv2d_wgrad_h3) instead of the exact-fp32 MFMA
-# kernel.  Off by default: measured only 11 % faster (589 vs 662 us per launch in tools/bench_train.py) - with one 4-wave
-# workgroup per CU the operand staging (global -> split -> LDS, nine pre-shifted copies of every U row) is latency bound,
-# not the matrix pipe; it needs a rolling window of U rows and register prefetch under the MFMAs first.
-WGRAD_SPLIT_F16 = False
+# Weight-gradient correlations on the f16 matrix cores (split operands with power-of-two range scaling, pipelined staging:
+# nb_conv2d_wgrad_h3, 1.8x the exact-fp32 MFMA kernel on the 128-channel 128x128 layers); False: the exact-fp32 kernel.
+WGRAD_SPLIT_F16 = True
 
 
 def _wgrad_launch(u, v, stride, padding):
