@@ -219,3 +219,32 @@ def test_odd_channel_counts_vs_oracle(res, cmax, cbase, geom):
                    return_debug_data=True, return_features=[res // 2], noise_mode="const")
         assert float((got["uvs"].cpu() - want["uvs"]).abs().max()) <= tol, mode
         assert float((got[f"features{res // 2}"].cpu() - want[f"features{res // 2}"]).abs().max()) <= 5 * tol, mode
+
+
+def test_baseline_size_properties(dev):
+    """BASELINE.json configs[1] at its full size (batch 32, R=256, style1 shapes), through size-independent properties:
+    the three arithmetic modes agree within their documented bounds, a run is reproducible bit for bit, and a patch does
+    not depend on what else is in the batch (batch-1 and batch-32 launches take different kernel variants / tile shapes)."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    cfg = cfgmod.style1_config(256)
+    sd = wmod.random_state_dict(cfg, 2)
+    n = 32
+    z = torch.from_numpy(synthetic.batch_z(cfg, n, 40)).to(dev)
+    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, n, 4)]
+    pos = torch.from_numpy(synthetic.positions(cfg, n, 4)).to(dev)
+    out = {}
+    for mode in ("f32", "h3", "f8"):
+        G = Generator(cfg, sd, conv_mode=mode).to(dev)
+        u8, rgba, dbg = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
+        out[mode] = (u8.clone(), rgba.clone())
+        if mode == "f8":
+            u8b, rgbab, _ = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
+            assert torch.equal(u8, u8b) and torch.equal(rgba, rgbab)                       # reproducible
+            for k in (0, 13, 31):                                                          # batch independence
+                _, r1, _ = G.render_triad(z=z[k:k + 1], geom_feature=[g[k:k + 1] for g in geom], positions=pos[k:k + 1], want_f32=True)
+                assert float((r1[0] - rgba[k]).abs().max()) <= 3e-4
+    assert float((out["h3"][1] - out["f32"][1]).abs().max()) <= 5e-5
+    assert float((out["f8"][1] - out["f32"][1]).abs().max()) <= 3e-4                       # north_star budget: 1e-3
+    assert int((out["f8"][0].int() - out["f32"][0].int()).abs().max()) <= 1
+    assert float(out["f32"][1].std()) > 0.05                                               # (not a degenerate image)
