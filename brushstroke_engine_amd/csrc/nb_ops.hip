@@ -183,17 +183,19 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirdnParams p) {
         const int ux0 = ox * p.downx - p.padx0, uy0 = oy * p.downy - p.pady0;
         const float* xm = p.x + (size_t)m * p.in_h * p.in_w;
         float v = 0.f;
-        for (int fy = 0; fy < p.f_h; ++fy) {
-            const int uy = uy0 + fy;
-            if (uy < 0 || uy % p.upy != 0) continue;
-            const int iy = uy / p.upy;
-            if (iy >= p.in_h) continue;
-            for (int fx = 0; fx < p.f_w; ++fx) {
-                const int ux = ux0 + fx;
-                if (ux < 0 || ux % p.upx != 0) continue;
-                const int ix = ux / p.upx;
-                if (ix >= p.in_w) continue;
-                v += xm[iy * p.in_w + ix] * sf[fy * p.f_w + fx];
+        // only every upy-th (upx-th) tap meets a sample of the zero-stuffed image: start at the first one, step by the
+        // up-sampling factor (no modulo per tap), and clip the tap range to the image once
+        const int fy0 = uy0 >= 0 ? (p.upy - uy0 % p.upy) % p.upy : -uy0;      // first tap with uy >= 0 and uy % upy == 0 (uy = 0 when uy0 < 0)
+        const int fx0 = ux0 >= 0 ? (p.upx - ux0 % p.upx) % p.upx : -ux0;
+        for (int fy = fy0; fy < p.f_h; fy += p.upy) {
+            const int iy = (uy0 + fy) / p.upy;
+            if (iy >= p.in_h) break;
+            const float* xr = xm + iy * p.in_w;
+            const float* fr = sf + fy * p.f_w;
+            for (int fx = fx0; fx < p.f_w; fx += p.upx) {
+                const int ix = (ux0 + fx) / p.upx;
+                if (ix >= p.in_w) break;
+                v += xr[ix] * fr[fx];
             }
         }
         p.y[idx] = v;
