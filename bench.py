@@ -3,6 +3,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--res 256] [--batch 32] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a torchrun environment and --gpus N > 1, it launches the N ranks itself (one process per GPU through
+``python -m torch.distributed.run`` as a CHILD process, before anything in this process touches the GPU -- the
+reference's counterpart is ``torch.multiprocessing.spawn`` per GPU + ``init_process_group('nccl')`` in
+thirdparty/stylegan2_ada_pytorch/train.py:811-816, 523-530) and exits with the child's exit code.
+
 A step = one pass of the hot path (mapping -> styles/noise -> 15 fused modulated-conv launches ->
 fused ToRGB/softmax/triad + paint-engine compositing to uint8 RGBA) over one batch of 32 synthetic
 patches per GPU (BASELINE.json configs[1]: random z, random stroke-geometry features, random patch
@@ -149,19 +154,32 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # self-launch: N ranks as a child torchrun.  Nothing in this process has touched the GPU (importing torch does
+        # not), and it only waits for the child -- no exec of a GPU-initialised process.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
     # test hooks for a 1-GPU box: NB_BENCH_SHARE_GPU=1 puts every rank on device 0, NB_BENCH_BACKEND=gloo swaps RCCL out
     # (exercises the N>1 control flow; numbers from such a run mean nothing)
     if os.environ.get("NB_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
+    if os.environ.get("NB_BENCH_FAIL_RANK") == str(rank) and world > 1:        # test hook: a rank that dies at start-up
+        raise SystemExit(7)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -190,9 +208,9 @@ def main():
     # gathered from the part's own stream, so steps keep overlapping across the streams at any N
     sub = G.sub_streams if B >= G.sub_stream_min_batch else 1
     gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if (world > 1 and not args.no_gather) else None
-    gather_note = ""
     if gatherer is not None:
-        # pre-flight: one small RCCL gather; if the fabric refuses it the bench still measures the sharded compute
+        # pre-flight: one small RCCL gather, checked on rank 0.  The gather IS part of the measured job (north_star: "RCCL
+        # gather over xGMI to assemble the stylized canvas"): if the fabric refuses it the run fails, non-zero.
         try:
             probe = TileGatherer([4, 8, 8, 4], torch.uint8, dev)
             probe.start(torch.full([4, 8, 8, 4], rank, dtype=torch.uint8, device=dev))
@@ -204,7 +222,11 @@ def main():
             ok = torch.tensor([0.0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() < 1:
-            gatherer, gather_note = None, " (RCCL gather of RGBA tiles disabled: pre-flight failed)"
+            if rank == 0:
+                print("[bench] FAILED: the RCCL gather of RGBA tiles did not pass its pre-flight; no number is reported "
+                      "(--no-gather measures the sharded compute alone, and says so in config.parallelism)", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            raise SystemExit(3)
     part_gatherers = []
     if gatherer is not None and sub > 1:
         bounds = [(i * B // sub, (i + 1) * B // sub) for i in range(sub)]
@@ -428,7 +450,9 @@ def main():
                                    f"style1 checkpoint shapes (BASELINE.json configs[1]); generator + triad compositing "
                                    f"to uint8 RGBA; geometry features precomputed",
                        "batch_per_gpu": B, "resolution": args.res, "gflop_per_patch": round(2 * cfg.macs_per_patch() / 1e9, 3),
-                       "parallelism": f"patch-parallel x{world}" + (" + RCCL gather of RGBA tiles to rank 0" if gatherer else "") + gather_note},
+                       "parallelism": f"patch-parallel x{world}" + ("" if world == 1 else
+                                                                   f" + {'RCCL' if backend == 'nccl' else backend} gather of RGBA tiles to rank 0 "
+                                                                   f"inside every step" if gatherer else " (NO gather: --no-gather)")},
             "roofline": roofline,
             "rehearsal_ms_per_step": round(rehearsal_ms, 4),
             "burn_in_ms_per_step": [round(b, 3) for b in burn_in[:6]] + (["..."] if len(burn_in) > 7 else []) + [round(b, 3) for b in burn_in[6:][-1:]],

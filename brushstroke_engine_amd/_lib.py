@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lock = threading.Lock()
 _lib = None
@@ -92,12 +92,20 @@ PROTOTYPES = {
                                        vp, vp, vp]),
     "nb_canvas_replay_box_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int,
                                        vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_canvas_replay_pieces_f32": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "nb_paste_tiles_u8": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     "nb_enc_stem7x7_f32_h2": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_enc_conv3x3_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_enc_upsample2x_h2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "nb_pack_conv_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
 }
+
+
+class NbTilePiece(C.Structure):
+    """``struct NbTilePiece`` of include/neube_hip.h."""
+    _fields_ = [("data", C.c_uint64), ("cstride", C.c_int32), ("rstride", C.c_int32), ("cy", C.c_int32), ("cx", C.c_int32),
+                ("h", C.c_int32), ("w", C.c_int32), ("ly0", C.c_int32), ("lx0", C.c_int32)]
 
 
 class NbTorgbArgs(C.Structure):

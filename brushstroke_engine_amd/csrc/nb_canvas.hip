@@ -137,6 +137,90 @@ extern "C" int nb_canvas_replay_box_f32(float* tiles, int t, int c, int hw, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// feature-canvas replay over tile PIECES (multi-GPU halo exchange): a rank replays its own tiles (full
+// pieces) together with the strips of earlier foreign tiles that overlap them (received from the neighbouring
+// ranks, compact buffers).  A piece is a rectangle of ONE tile; pieces of the same tile are disjoint, so a canvas
+// pixel meets every tile at most once, and ascending piece order = paint order.  Same arithmetic per (pixel, tile)
+// as canvas_replay_kernel above.
+// ------------------------------------------------------------------------------------------------
+struct ReplayPiecesParams {
+    const NbTilePiece* pieces;
+    const float* alpha0;     // [hw, hw]
+    float* canvas;
+    const uint8_t* mask_in;
+    uint8_t* mask_out;
+    const int* cell_off;
+    const int* cell_pieces;
+    int c, hw, hc, wc, crop;
+    int cell_x0, cell_y0, cells_per_row;
+};
+
+template <int CG>
+__global__ __launch_bounds__(256) void canvas_replay_pieces_kernel(ReplayPiecesParams p) {
+    const int bx = blockIdx.x + p.cell_x0, by = blockIdx.y + p.cell_y0;
+    const int cx = bx * NB_CELL_W + (threadIdx.x & (NB_CELL_W - 1));
+    const int cy = by * NB_CELL_H + (threadIdx.x / NB_CELL_W);
+    const int c0 = blockIdx.z * CG;
+    const int cell = by * p.cells_per_row + bx;
+    if (cx >= p.wc || cy >= p.hc) return;
+    const size_t cplane = (size_t)p.hc * p.wc;
+    const size_t cpix = (size_t)cy * p.wc + cx;
+    const int k0 = p.cell_off[cell], k1 = p.cell_off[cell + 1];
+    if (k0 == k1) {
+        if (blockIdx.z == 0) p.mask_out[cpix] = p.mask_in[cpix];
+        return;
+    }
+    float cv[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) cv[c] = (c0 + c < p.c) ? p.canvas[(size_t)(c0 + c) * cplane + cpix] : 0.f;
+    bool m = p.mask_in[cpix] != 0;
+    for (int k = k0; k < k1; ++k) {
+        const NbTilePiece pc = p.pieces[p.cell_pieces[k]];
+        const int py = cy - pc.cy, px = cx - pc.cx;
+        if (py < 0 || py >= pc.h || px < 0 || px >= pc.w) continue;
+        const int ly = py + pc.ly0, lx = px + pc.lx0;                  // position inside the piece's tile
+        const float a0 = p.alpha0[ly * p.hw + lx];
+        bool upd = (a0 > 0.99f) || (m && a0 > 0.f);
+        if (ly < p.crop || ly >= p.hw - p.crop || lx < p.crop || lx >= p.hw - p.crop) upd = false;
+        const float a = 1.f - (m ? a0 : 1.f);
+        const float na = 1.f - a;
+        float* tp = (float*)pc.data + (size_t)c0 * pc.cstride + (size_t)py * pc.rstride + px;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            if (c0 + c < p.c) {
+                const float f = a * cv[c] + na * tp[(size_t)c * pc.cstride];
+                tp[(size_t)c * pc.cstride] = f;
+                if (upd) cv[c] = f;
+            }
+        }
+        m = m || upd;
+    }
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+        if (c0 + c < p.c) p.canvas[(size_t)(c0 + c) * cplane + cpix] = cv[c];
+    if (blockIdx.z == 0) p.mask_out[cpix] = m ? 1 : 0;
+}
+
+extern "C" int nb_canvas_replay_pieces_f32(const NbTilePiece* pieces, int n, int c, int hw, const float* alpha0, int crop,
+                                           float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
+                                           const int32_t* cell_off, const int32_t* cell_pieces, int cell_x0, int cell_y0,
+                                           int cells_x, int cells_y, void* stream) {
+    NB_REQUIRE(pieces && alpha0 && canvas && mask_in && mask_out && cell_off && cell_pieces, "canvas_replay_pieces: null pointer");
+    NB_REQUIRE(mask_in != mask_out, "canvas_replay_pieces: mask_in and mask_out must be different buffers");
+    NB_REQUIRE(n >= 1 && c >= 1 && hw >= 1 && hc >= 1 && wc >= 1 && crop >= 0 && 2 * crop <= hw, "canvas_replay_pieces: bad sizes");
+    const int cpr = nb_cdiv(wc, NB_CELL_W), cpc = nb_cdiv(hc, NB_CELL_H);
+    NB_REQUIRE(cell_x0 >= 0 && cell_y0 >= 0 && cells_x >= 1 && cells_y >= 1 && cell_x0 + cells_x <= cpr && cell_y0 + cells_y <= cpc,
+               "canvas_replay_pieces: cell box outside the canvas");
+    ReplayPiecesParams p{pieces, alpha0, canvas, mask_in, mask_out, cell_off, cell_pieces, c, hw, hc, wc, crop, cell_x0, cell_y0, cpr};
+    constexpr int CG = 8;
+    dim3 grid(cells_x, cells_y, nb_cdiv(c, CG));
+    NB_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "canvas_replay_pieces: canvas too large");
+    hipLaunchKernelGGL(canvas_replay_pieces_kernel<CG>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("canvas_replay_pieces");
+    return NB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RGBA tile paste (paint_image_main.py:173-177 with the server-side crop of brush.py:369-374): the interior
 // [crop, r-crop)^2 of tile t lands at dst_yx[t] + crop; where interiors overlap the LAST tile wins.
 // ------------------------------------------------------------------------------------------------

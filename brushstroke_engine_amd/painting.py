@@ -12,16 +12,20 @@ three-phase schedule with identical results (verified against the ref
   phase 2  one launch replays the canvas blend tile after tile (``nb_canvas_replay_f32``)
   phase 3  last block + triad ToRGB + compositing, batched     (``_resume``), then one paste launch
 
-Multi-GPU: the tile list is cut into contiguous per-rank ranges (``sharding.shard_bounds``); phase 1 and 3 run on the
-rank's own tiles, the phase-1 features are exchanged with ONE ``all_gather`` (the only data-path collective the
-schedule needs: 8.4 MB per 256-tile over RCCL/xGMI), every rank replays the (cheap, pointwise) blend for the whole
-canvas and keeps its own tiles, and the RGBA tiles are gathered on rank 0 for the paste.
+Multi-GPU: the tile list is cut into contiguous per-rank ranges (``sharding.shard_bounds``); all three phases run on
+the rank's own tiles only.  The blend of a tile reads what EARLIER tiles left under it, so a rank needs from the ranks
+before it just the strips of their tiles that overlap its own (``sharding.halo_plan``: 20 px wide at R/2 for crop
+margin 10, ~0.65 MB per neighbour pair at R=256) -- ONE ``all_to_all_single`` of those strips over RCCL/xGMI, started
+as soon as the rank's boundary tiles are through phase 1 (they are scheduled first) and overlapped with the rest of
+phase 1.  Each rank then replays its own tiles plus the received strips (``nb_canvas_replay_pieces_f32``) on the cells
+its tiles cover, and the RGBA tiles are gathered on rank 0 for the paste.
 
 Device work goes through ``TileOps`` (HIP kernels + the PyTorch-ROCm encoder).  There is no CPU fallback here: the
 tests inject an oracle-backed ``TileOps`` stand-in to check the host logic and the sharded schedule on CPU.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -29,7 +33,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .sharding import shard_bounds
+from .sharding import halo_plan, shard_bounds
 
 CELL_H, CELL_W = 4, 64          # NB_CELL_H / NB_CELL_W of include/neube_hip.h
 
@@ -359,6 +363,24 @@ class TileOps:
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(main)
 
+    def comm_stream(self):
+        """Context manager for the halo exchange: a side stream that first waits for everything enqueued so far on the
+        batch streams (the boundary tiles' phase 1), so that packing + the collective overlap the remaining batches."""
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=self.device)
+        self._comm.wait_stream(torch.cuda.current_stream(self.device))
+        for st in (self._streams or []):
+            self._comm.wait_stream(st)
+        return torch.cuda.stream(self._comm)
+
+    def join_comm(self, tensors=()):
+        if getattr(self, "_comm", None) is not None:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self._comm)
+            for t in tensors:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
+
     def background_weight(self, ws, geom_feats) -> torch.Tensor:
         """S = uvs[:, 2:3] of an un-positioned render (what StyleUVSMapper calibrates on, mapper.py:74-87)."""
         _, dbg = self.G.forward_pre_mapped(ws, geom_feats, return_debug_data=True, noise_mode="const")
@@ -389,6 +411,29 @@ class TileOps:
             _lib.check(_lib.lib().nb_canvas_replay_f32(_p(tiles), t, c, hw, _p(tile_yx), _p(alpha0), crop, _p(canvas),
                                                        _p(mask), _p(mask_out), hc, wc, _p(cell_off), _p(cell_tiles),
                                                        self._stream()), "canvas_replay")
+        return mask_out
+
+    def replay_pieces(self, pieces, hw, alpha0, crop, canvas, mask, cell_off, cell_pieces, box) -> torch.Tensor:
+        """The replay over tile pieces (multi-GPU halo exchange).  ``pieces`` = [(view [C,h,w] with unit column stride,
+        cy, cx, ly0, lx0), ...] in paint order; in place on the views and ``canvas``; returns the new mask buffer.
+        ``box`` = (y0, x0, y1, x1) canvas pixels containing every piece."""
+        import ctypes as C
+        hc, wc = mask.shape
+        c = pieces[0][0].shape[0]
+        arr = (_lib.NbTilePiece * len(pieces))()
+        for i, (v, cy, cx, ly0, lx0) in enumerate(pieces):
+            assert v.dtype == torch.float32 and v.stride(2) == 1 and v.shape[0] == c
+            arr[i] = _lib.NbTilePiece(v.data_ptr(), v.stride(0), v.stride(1), cy, cx, v.shape[1], v.shape[2], ly0, lx0)
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device, non_blocking=True)
+        y0, x0 = max(0, box[0]) // CELL_H, max(0, box[1]) // CELL_W
+        y1, x1 = -(-min(hc, box[2]) // CELL_H), -(-min(wc, box[3]) // CELL_W)
+        if y1 <= y0 or x1 <= x0:
+            return mask
+        mask_out = mask.clone()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().nb_canvas_replay_pieces_f32(_p(table), len(pieces), c, hw, _p(alpha0), crop, _p(canvas),
+                                                              _p(mask), _p(mask_out), hc, wc, _p(cell_off), _p(cell_pieces),
+                                                              x0, y0, x1 - x0, y1 - y0, self._stream()), "canvas_replay_pieces")
         return mask_out
 
     def paste(self, canvas_u8, tiles_u8, dst_yx, crop, cell_off, cell_tiles) -> None:
@@ -458,6 +503,8 @@ class PaintingHelper:
         self.feature_blending_level = 0
         self.rows = self.cols = None
         self.features = self.mask = None
+        self._canvas_rank_local = False
+        self.halo_bytes = None
         self.down_factor = None
         self._alpha_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
 
@@ -469,6 +516,7 @@ class PaintingHelper:
     def set_feature_blending(self, feature_blending_level: int = 0):
         self.feature_blending_level = int(feature_blending_level)
         self.features = self.mask = None
+        self._canvas_rank_local = False
         self.down_factor = 2 ** (self.feature_blending_level - 1) if self.feature_blending_level > 0 else None
 
     def set_render_mode(self, mode: str):
@@ -499,6 +547,9 @@ class PaintingHelper:
         rank, world = self._world()
         T = areas_yx.shape[0]
         level, df = self.feature_blending_level, self.down_factor
+        if world > 1 and level > 0 and self._canvas_rank_local:
+            raise RuntimeError("the feature canvas is rank-local after a sharded render_tiles: call make_new_canvas "
+                               "before painting on it again with world size > 1")
         t0, t1 = shard_bounds(T, rank, world)
         n_own = t1 - t0
         n_pad = -(-T // world)                                                 # equal per-rank count for collectives
@@ -525,7 +576,6 @@ class PaintingHelper:
         def pos(b0, b1):
             return None if own_pos is None else own_pos[b0:b1]
 
-        import contextlib
         on_stream = getattr(ops, "stream", lambda k: contextlib.nullcontext())      # (CPU stand-ins have no streams)
         join = getattr(ops, "join_streams", lambda tensors=(): None)
         plan_slot = lambda k: 1 + k % getattr(ops, "n_streams", 1)
@@ -545,42 +595,85 @@ class PaintingHelper:
             bres = R // df
             C = ops.cfg.channels(bres)
             margin, crop_sc = self.feature_blending_margin // df, crop_margin // df
-            # phase 1: everything up to the blending resolution, own tiles; features land in the exchange buffer
-            feats_all = torch.empty([world * n_pad, C, bres, bres], dtype=torch.float32, device=ops.device)
-            mine = feats_all[rank * n_pad: rank * n_pad + n_own]
-            geom_feats_own = []
-            for k, (b0, b1) in enumerate(batches()):
-                with on_stream(k):
-                    gf = ops.encode(ops.geom_tiles(geom_dev, own_yx[b0:b1]))
-                    geom_feats_own.append(gf)
-                    mine[b0:b1] = ops.head(style(b1 - b0), gf, pos(b0, b1), bres, slot=plan_slot(k))
-            join()
-            if world > 1:
-                if n_own < n_pad:
-                    feats_all[rank * n_pad + n_own: (rank + 1) * n_pad].zero_()
-                dist.all_gather_into_tensor(feats_all, feats_all[rank * n_pad:(rank + 1) * n_pad].clone(),
-                                            group=self.group)
-            # phase 2: the sequential canvas blend, replayed for all tiles in one launch (every rank, redundantly).
-            # Rows of feats_all: rank r holds tiles [t0_r, t1_r) at rows r*n_pad...; ranks own ascending contiguous
-            # ranges, so ascending row order == paint order, which the CSR lists must follow.
-            slot = np.concatenate([r * n_pad + np.arange(counts[r]) for r in range(world)])
-            tile_yx_sc = np.full((world * n_pad, 2), -(1 << 20), np.int32)     # padding rows: far off-canvas
-            tile_yx_sc[slot] = (areas_yx // df).astype(np.int32)
-            rects = np.zeros((world * n_pad, 4), np.int64)
-            rects[slot] = np.concatenate([areas_yx // df, areas_yx // df + bres], axis=1)
+            rects = np.concatenate([areas_yx // df, areas_yx // df + bres], axis=1).astype(np.int64)
             if self.features is None:
                 self.features, self.mask = ops.new_feature_canvas(C, -(-self.rows // df), -(-self.cols // df))
             hc, wc = self.mask.shape
-            off, lst = build_cells(rects, hc, wc)
-            # few tiles on a large canvas (interactive strokes): replay only the cells inside their bounding box
-            box = None
-            if len(slot) * bres * bres * 4 < hc * wc:
-                r_ = rects[slot]
-                box = (int(r_[:, 0].min()), int(r_[:, 1].min()), int(r_[:, 2].max()), int(r_[:, 3].max()))
-            self.mask = ops.replay(feats_all, ops.to_device(tile_yx_sc), self._alpha0(bres, margin, crop_sc), crop_sc,
-                                   self.features, self.mask, ops.to_device(off), ops.to_device(lst), **({"box": box} if box else {}))
+            alpha0 = self._alpha0(bres, margin, crop_sc)
+            # halo plan: the strips of earlier foreign tiles under my tiles (recv) and of my tiles under later ranks' (send)
+            bounds = [shard_bounds(T, r, world) for r in range(world)]
+            plan = halo_plan(rects, bounds) if world > 1 else {}
+            send = {d: plan[(rank, d)] for d in range(world) if (rank, d) in plan}
+            recv = {s_: plan[(s_, rank)] for s_ in range(world) if (s_, rank) in plan}
+            first_send = min((f for lst in send.values() for f, _ in lst), default=t1) - t0
+            # phase 1: everything up to the blending resolution, own tiles.  The batches run last-to-first: the tiles the
+            # later ranks need (the end of my range) finish first, and their strips travel under the rest of phase 1.
+            mine = torch.empty([n_own, C, bres, bres], dtype=torch.float32, device=ops.device)
+            geom_feats_own = {}
+            work = recv_buf = send_buf = None
+            nfl = lambda lst: sum(C * (q[2] - q[0]) * (q[3] - q[1]) for _, q in lst)
+            in_split = [nfl(send.get(d, [])) for d in range(world)]
+            out_split = [nfl(recv.get(s_, [])) for s_ in range(world)]
+            comm = getattr(ops, "comm_stream", lambda: contextlib.nullcontext())
+
+            def exchange():
+                nonlocal work, recv_buf, send_buf
+                recv_buf = torch.empty([sum(out_split)], dtype=torch.float32, device=ops.device)
+                with comm():
+                    parts = [mine[f - t0, :, q[0] - rects[f, 0]:q[2] - rects[f, 0], q[1] - rects[f, 1]:q[3] - rects[f, 1]].reshape(-1)
+                             for d in range(world) for f, q in send.get(d, [])]
+                    send_buf = torch.cat(parts) if parts else torch.empty([0], dtype=torch.float32, device=ops.device)
+                    work = dist.all_to_all_single(recv_buf, send_buf, out_split, in_split, group=self.group, async_op=True)
+                self.halo_bytes = {"sent": 4 * sum(in_split), "received": 4 * sum(out_split)}
+
+            blist = list(enumerate(batches()))
+            for k, (b0, b1) in reversed(blist):
+                with on_stream(k):
+                    gf = ops.encode(ops.geom_tiles(geom_dev, own_yx[b0:b1]))
+                    geom_feats_own[k] = gf
+                    mine[b0:b1] = ops.head(style(b1 - b0), gf, pos(b0, b1), bres, slot=plan_slot(k))
+                if world > 1 and work is None and b0 <= first_send:
+                    exchange()
+            if world > 1 and work is None:
+                exchange()                                                        # (a rank without tiles still takes part)
+            join()
+            if work is not None:
+                work.wait()
+                getattr(ops, "join_comm", lambda tensors=(): None)([recv_buf])
+            # phase 2: the sequential canvas blend of my tiles, replayed in one launch
+            if world == 1:
+                off, lst = build_cells(rects, hc, wc)
+                # few tiles on a large canvas (interactive strokes): replay only the cells inside their bounding box
+                box = None
+                if T * bres * bres * 4 < hc * wc:
+                    box = (int(rects[:, 0].min()), int(rects[:, 1].min()), int(rects[:, 2].max()), int(rects[:, 3].max()))
+                self.mask = ops.replay(mine, ops.to_device((areas_yx // df).astype(np.int32)), alpha0, crop_sc,
+                                       self.features, self.mask, ops.to_device(off), ops.to_device(lst), **({"box": box} if box else {}))
+            elif n_own:
+                # pieces in paint order: received strips of earlier foreign tiles (compact [C,h,w] blocks of recv_buf), then
+                # my own full tiles (every foreign tile a rank needs precedes its range)
+                pieces, prect, o = [], [], 0
+                for s_ in range(world):
+                    for f, q in recv.get(s_, []):
+                        h_, w_ = q[2] - q[0], q[3] - q[1]
+                        pieces.append((f, recv_buf[o:o + C * h_ * w_].view(C, h_, w_), q[0], q[1], q[0] - rects[f, 0], q[1] - rects[f, 1]))
+                        prect.append(q)
+                        o += C * h_ * w_
+                order = sorted(range(len(pieces)), key=lambda i: pieces[i][0])
+                pieces = [pieces[i][1:] for i in order]
+                prect = [prect[i] for i in order]
+                for i in range(n_own):
+                    pieces.append((mine[i], int(rects[t0 + i, 0]), int(rects[t0 + i, 1]), 0, 0))
+                    prect.append(tuple(int(v) for v in rects[t0 + i]))
+                off, lst = build_cells(np.asarray(prect, np.int64), hc, wc)
+                own_r = rects[t0:t1]
+                box = (int(own_r[:, 0].min()), int(own_r[:, 1].min()), int(own_r[:, 2].max()), int(own_r[:, 3].max()))
+                self.mask = ops.replay_pieces(pieces, bres, alpha0, crop_sc, self.features, self.mask,
+                                              ops.to_device(off), ops.to_device(lst), box)
+            if world > 1:
+                self._canvas_rank_local = True       # my canvas now holds the paint sequence under MY tiles only
             # phase 3: last block(s) + ToRGB + compositing on the blended features, own tiles
-            for i, (b0, b1) in enumerate(batches()):
+            for i, (b0, b1) in blist:
                 with on_stream(i):
                     outs.append(ops.tail(style(b1 - b0), mine[b0:b1], geom_feats_own[i], pos(b0, b1), bres,
                                          self.render_mode, colors(b1 - b0), sfac, slot=plan_slot(i)))

@@ -12,8 +12,9 @@ CPU tests.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -28,6 +29,61 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def shard_sizes(n_items: int, world: int) -> List[int]:
     return [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
+
+
+# ------------------------------------------------------------------------------------------------
+# halo plan of the feature-blended canvas
+# ------------------------------------------------------------------------------------------------
+Rect = Tuple[int, int, int, int]            # (y0, x0, y1, x1), end-exclusive
+
+
+def rect_subtract(a: Rect, b: Rect) -> List[Rect]:
+    """a minus b as up to four disjoint rectangles (top band, bottom band, left and right of the cut)."""
+    y0, x0, y1, x1 = max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
+    if y0 >= y1 or x0 >= x1:
+        return [a]
+    out = []
+    if a[0] < y0:
+        out.append((a[0], a[1], y0, a[3]))
+    if y1 < a[2]:
+        out.append((y1, a[1], a[2], a[3]))
+    if a[1] < x0:
+        out.append((y0, a[1], y1, x0))
+    if x1 < a[3]:
+        out.append((y0, x1, y1, a[3]))
+    return out
+
+
+def halo_plan(rects: np.ndarray, bounds: Sequence[Tuple[int, int]]) -> Dict[Tuple[int, int], List[Tuple[int, Rect]]]:
+    """Which strips of which tiles every rank needs from the others to replay the feature-canvas blend of its OWN tiles.
+
+    ``rects`` [T,4] are the tiles' rectangles on the feature canvas in paint order, ``bounds[r] = (t0, t1)`` the
+    contiguous ascending tile range rank r owns.  The blended value of tile t at a pixel depends on every EARLIER
+    tile covering that pixel (forger/ui/brush.py:190-227 reads what they left on the FeatureCanvas), so rank d needs,
+    of every earlier foreign tile f, exactly the pixels f shares with d's tiles.  Returns
+    ``{(src, dst): [(f, (y0, x0, y1, x1)), ...]}`` in canvas coordinates, ascending in f; the rectangles of one f
+    towards one dst are disjoint (a pixel must meet a tile once in the replay)."""
+    r = np.asarray(rects, np.int64).reshape(-1, 4)
+    owner = np.empty(r.shape[0], np.int64)
+    for k, (a, b) in enumerate(bounds):
+        owner[a:b] = k
+    plan: Dict[Tuple[int, int], List[Tuple[int, Rect]]] = {}
+    for dst, (t0, t1) in enumerate(bounds):
+        if t1 <= t0 or t0 == 0:
+            continue
+        own, ear = r[t0:t1], r[:t0]
+        iy0 = np.maximum(ear[:, None, 0], own[None, :, 0]); ix0 = np.maximum(ear[:, None, 1], own[None, :, 1])
+        iy1 = np.minimum(ear[:, None, 2], own[None, :, 2]); ix1 = np.minimum(ear[:, None, 3], own[None, :, 3])
+        hit = (iy1 > iy0) & (ix1 > ix0)
+        for f in np.nonzero(hit.any(axis=1))[0].tolist():
+            pieces: List[Rect] = []
+            for j in np.nonzero(hit[f])[0].tolist():
+                new = [(int(iy0[f, j]), int(ix0[f, j]), int(iy1[f, j]), int(ix1[f, j]))]
+                for q in pieces:                                   # keep only what no earlier piece of f covers
+                    new = [x for n_ in new for x in rect_subtract(n_, q)]
+                pieces.extend(new)
+            plan.setdefault((int(owner[f]), dst), []).extend((f, q) for q in pieces)
+    return plan
 
 
 class TileGatherer:

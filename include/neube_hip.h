@@ -357,6 +357,24 @@ int nb_canvas_replay_box_f32(float* tiles, int t, int c, int hw, const int32_t* 
                              const int32_t* cell_off, const int32_t* cell_tiles, int cell_x0, int cell_y0,
                              int cells_x, int cells_y, void* stream);
 
+/* The replay over tile PIECES, for the multi-GPU halo exchange ("P2P halo send/recv of only the overlapped
+ * strips"): a rank replays its own tiles together with the strips of earlier foreign tiles that overlap them.  A piece is
+ * a rectangle [ly0, ly0+h) x [lx0, lx0+w) of one tile, sitting at (cy, cx) on the feature canvas, with its values at
+ * data[ch * cstride + row * rstride + col] (a full own tile: h = w = hw, rstride = hw, cstride = hw*hw; a received strip:
+ * a compact buffer).  Pieces of one tile must be disjoint; ascending piece index = paint order (cell_pieces lists piece
+ * indices).  Same per-pixel arithmetic as nb_canvas_replay_f32; only the cells of the given box run and mask_out is only
+ * written there (start it as a copy of mask_in). */
+typedef struct NbTilePiece {
+    uint64_t data;               /* device pointer (float*) */
+    int32_t cstride, rstride;    /* in floats */
+    int32_t cy, cx, h, w;        /* piece rectangle on the feature canvas */
+    int32_t ly0, lx0;            /* its origin inside the tile (alpha template / crop border lookup) */
+} NbTilePiece;
+int nb_canvas_replay_pieces_f32(const NbTilePiece* pieces, int n, int c, int hw, const float* alpha0, int crop,
+                                float* canvas, const uint8_t* mask_in, uint8_t* mask_out, int hc, int wc,
+                                const int32_t* cell_off, const int32_t* cell_pieces, int cell_x0, int cell_y0,
+                                int cells_x, int cells_y, void* stream);
+
 /* Paste RGBA8 tiles [t,r,r,4] into canvas [h,w,4]: the interior [crop, r-crop)^2 of tile i lands at
  * dst_yx[i] + crop (brush.py:369-374 crop + out_meta, paint_image_main.py:173-177 paste); later tiles
  * overwrite earlier ones.  Cells are taken over the RGBA canvas from the interior rectangles. */

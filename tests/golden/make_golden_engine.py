@@ -42,9 +42,10 @@ from brushstroke_engine_amd import config as cfgmod, weights as wmod  # noqa: E4
 from brushstroke_engine_amd import encoder as encmod  # noqa: E402
 
 
-def main():
+def build_engine(R):
+    """The reference paint engine (PaintEngineFactory.create on a pickled synthetic snapshot) carrying
+    this repo's seeded generator / encoder weights."""
     torch.manual_seed(0)
-    R = 128
     cfg = cfgmod.style1_config(R)
     sd = wmod.random_state_dict(cfg, seed=0)
     ap = argparse.ArgumentParser()
@@ -76,7 +77,65 @@ def main():
     path = "/tmp/neube_snap.pkl"
     with open(path, "wb") as f:
         pickle.dump(snap, f)
-    eng = brush.PaintEngineFactory.create(gan_checkpoint=path, device=torch.device("cpu"))
+    return brush.PaintEngineFactory.create(gan_checkpoint=path, device=torch.device("cpu"))
+
+
+def paint_like_paint_image_main(eng, geom, R, crop_margin, level, style_seed=594):
+    """forger/viz/paint_image_main.py:145-177 on a thresholded geometry image [H,W,1] uint8 (255 = background)."""
+    gp = np.ones((geom.shape[0] + crop_margin, geom.shape[1] + crop_margin, 1), np.uint8) * 255
+    gp[crop_margin:, crop_margin:] = geom
+    crops, gpad = style_transfer.generate_stitching_crops(gp, R, mode="all", overlap_margin=crop_margin * 2)
+    helper = brush.PaintingHelper(eng, style_seed=0)
+    helper.make_new_canvas(gpad.shape[0], gpad.shape[1], feature_blending=level)
+    helper.set_render_mode("clear")
+    opts = brush.GanBrushOptions()
+    opts.set_style(eng.random_style(style_seed), style_seed)
+    result = np.zeros((gpad.shape[0], gpad.shape[1], 4), np.uint8)
+    with torch.no_grad():
+        for (y, x, _, _) in crops:
+            opts.set_position(x, y)
+            res, _, meta = helper.render_stroke(255 - gpad[y:y + R, x:x + R, :], None, opts,
+                                                meta={"x": x, "y": y, "crop_margin": crop_margin})
+            result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+    return result, crops, gpad, helper
+
+
+def main_lamali():
+    """BASELINE config 3 on its named input: neube_stylize.sh:79-85 -> paint_image_main on
+    forger/images/large_guidance/lamali_sm.png (514 x 800), P = 256, crop margin 10, feature blending level 2:
+    12 tiles.  The geometry is thresholded with this repo's Otsu restatement (scikit-image is absent here) and stored
+    bit-packed, so the fixture pins everything AFTER `_read_any_geo`; the uint8 canvas is what the reference engine
+    painted tile by tile."""
+    from PIL import Image
+    from brushstroke_engine_amd import painting
+    R, crop_margin = 256, 10
+    eng = build_engine(R)
+    img = np.array(Image.open("/root/reference/forger/images/large_guidance/lamali_sm.png"))
+    geom = painting.prepare_geometry_image(img)                                   # [H,W,1] uint8, 255 = background
+    assert set(np.unique(geom)) <= {0, 255}
+    out = {"geom_shape": np.array(geom.shape[:2], np.int64), "geom_bits": np.packbits(geom[..., 0] > 0),
+           "crop_margin": np.int64(crop_margin), "style_seed": np.int64(594), "weights_seed": np.int64(0),
+           "encoder_seed": np.int64(5), "resolution": np.int64(R)}
+    for level in (2, 0):
+        result, crops, gpad, helper = paint_like_paint_image_main(eng, geom, R, crop_margin, level)
+        if level == 2:
+            out["canvas_level2_clear"] = result
+            fc = helper.feature_canvas
+            out["feature_canvas_stats"] = np.array([float(fc.features.double().sum()), float(fc.features.double().square().sum()),
+                                                    float(fc.mask.sum())])
+            out["feature_canvas_sub"] = fc.features[0, ::16, ::8, ::8].numpy()
+        else:                                       # without blending: interior checksum rows only (the tiles are independent)
+            out["canvas_level0_rows"] = result[::37].copy()
+    out["crops"] = np.array([c[:2] for c in crops], np.int64)
+    assert len(crops) == 12, len(crops)
+    np.savez_compressed(os.path.join(HERE, "engine_lamali_r256.npz"), **out)
+    print("engine_lamali_r256.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def main():
+    R = 128
+    cfg = cfgmod.style1_config(R)
+    eng = build_engine(R)
 
     # synthetic line drawing: 255 = background, 0 = stroke (what _read_any_geo hands out, paint_image_main.py:28-55)
     rs = np.random.RandomState(42)
@@ -165,4 +224,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--lamali" in sys.argv:
+        main_lamali()
+    else:
+        main()

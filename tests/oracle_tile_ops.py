@@ -58,6 +58,9 @@ class OracleTileOps:
     def replay(self, tiles, tile_yx, alpha0, crop, canvas, mask, cell_off, cell_tiles, box=None):
         return sequential_replay(tiles, tile_yx, alpha0, crop, canvas, mask)
 
+    def replay_pieces(self, pieces, hw, alpha0, crop, canvas, mask, cell_off, cell_pieces, box):
+        return sequential_replay_pieces(pieces, hw, alpha0, crop, canvas, mask)
+
     def paste(self, canvas_u8, tiles_u8, dst_yx, crop, cell_off, cell_tiles):
         r = tiles_u8.shape[1]
         for t, (y, x) in enumerate(dst_yx.tolist()):
@@ -86,5 +89,27 @@ def sequential_replay(tiles, tile_yx, alpha0, crop, canvas, mask):
         tiles[t] = a * f + (1 - a) * tiles[t]
         u = upd[None].expand(tiles.shape[1], -1, -1)
         f[u] = tiles[t][u]
+        m[upd] = True
+    return mask.to(torch.uint8)
+
+
+def sequential_replay_pieces(pieces, hw, alpha0, crop, canvas, mask):
+    """The same loop over rectangular PIECES of tiles (view [C,h,w], cy, cx, ly0, lx0) in paint order -- what a rank
+    of the halo-exchange schedule replays: received strips of earlier foreign tiles, then its own full tiles."""
+    mask = mask.clone().bool()
+    inner = torch.zeros([hw, hw], dtype=torch.bool)
+    inner[crop:hw - crop, crop:hw - crop] = True
+    for v, cy, cx, ly0, lx0 in pieces:
+        h, w = v.shape[1:]
+        a0 = alpha0[ly0:ly0 + h, lx0:lx0 + w]
+        m = mask[cy:cy + h, cx:cx + w]
+        upd = ((a0 > 0.99) | (m & (a0 > 0))) & inner[ly0:ly0 + h, lx0:lx0 + w]
+        a = a0.clone()
+        a[~m] = 1
+        a = 1 - a
+        f = canvas[0, :, cy:cy + h, cx:cx + w]
+        v.copy_(a * f + (1 - a) * v)
+        u = upd[None].expand(v.shape[0], -1, -1)
+        f[u] = v[u]
         m[upd] = True
     return mask.to(torch.uint8)

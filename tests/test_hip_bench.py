@@ -1,0 +1,40 @@
+"""bench.py's N>1 control flow on a one-GPU box: `python bench.py --gpus 2` must launch its two ranks itself (child
+torchrun, one process per rank), gather the RGBA tiles inside the step and print ONE JSON line with n_gpus = 2.
+Both ranks share device 0 and the collective backend is gloo (RCCL refuses two ranks on one device); the numbers of
+such a run mean nothing -- the test is about the launch path the driver's `--gpus N` run takes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, cwd=REPO, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_self_spawns_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--res", "128", "--batch", "16", "--no-cpu", "--no-latency"],
+             {"NB_BENCH_SHARE_GPU": "1", "NB_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert "gather of RGBA tiles to rank 0" in out["config"]["parallelism"]
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_bench_fails_nonzero_when_a_rank_dies():
+    """A failing child must surface as a non-zero exit code of `python bench.py --gpus N`, with no JSON line."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--res", "128", "--batch", "16", "--no-cpu", "--no-latency"],
+             {"NB_BENCH_SHARE_GPU": "1", "NB_BENCH_BACKEND": "gloo", "NB_BENCH_FAIL_RANK": "1"}, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -72,6 +72,66 @@ def test_canvas_replay_bitwise(eng, c, hw, crop, margin):
     assert 0 < int(mask_ref.sum()) < hc * wc
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 5])
+def test_canvas_replay_pieces_halo_bitwise(eng, world):
+    """What the ranks of the halo-exchange schedule compute, emulated on one GPU: every virtual rank replays its own
+    tiles plus the strips `sharding.halo_plan` says it receives (copied out of the other ranks' tiles) with
+    nb_canvas_replay_pieces_f32 -- blended own tiles, and the canvas / mask under them, equal the one-launch replay
+    of the whole sequence bit for bit.  world = 1: full-tile pieces only == nb_canvas_replay_f32."""
+    from brushstroke_engine_amd.sharding import halo_plan, shard_bounds
+    ops = eng["ops"]
+    c, hw, crop, margin = 24, 32, 3, 4
+    rs = np.random.RandomState(world)
+    stride = hw - 4 * crop
+    ys, xs = np.meshgrid(np.arange(4) * stride, np.arange(3) * stride, indexing="ij")
+    yx = np.stack([ys.ravel(), xs.ravel()], 1).astype(np.int32)
+    T = yx.shape[0]
+    hc, wc = int(yx[:, 0].max()) + hw + 2, int(yx[:, 1].max()) + hw + 5
+    alpha0 = ops.to_device(painting.dirty_area_alpha(hw, margin, crop))
+    rects = np.concatenate([yx, yx + hw], 1).astype(np.int64)
+    pre = rs.randn(T, c, hw, hw).astype(np.float32)
+    # the whole sequence in one launch (world size 1 path)
+    canvas_all, mask_all = ops.new_feature_canvas(c, hc, wc)
+    t_all = ops.to_device(pre.copy())
+    off, lst = painting.build_cells(rects, hc, wc)
+    mask_all = ops.replay(t_all, ops.to_device(yx), alpha0, crop, canvas_all, mask_all, ops.to_device(off), ops.to_device(lst))
+    bounds = [shard_bounds(T, r, world) for r in range(world)]
+    plan = halo_plan(rects, bounds)
+    sent = 0
+    for rank, (t0, t1) in enumerate(bounds):
+        mine = ops.to_device(pre[t0:t1].copy())
+        pieces, prect = [], []
+        for src in range(world):
+            for f, q in plan.get((src, rank), []):
+                strip = ops.to_device(pre[f][:, q[0] - rects[f, 0]:q[2] - rects[f, 0], q[1] - rects[f, 1]:q[3] - rects[f, 1]].copy())
+                sent += strip.numel() * 4
+                pieces.append((f, strip, q[0], q[1], int(q[0] - rects[f, 0]), int(q[1] - rects[f, 1])))
+                prect.append(q)
+        order = sorted(range(len(pieces)), key=lambda i: pieces[i][0])
+        pieces = [pieces[i][1:] for i in order]
+        prect = [prect[i] for i in order]
+        for i in range(t1 - t0):
+            pieces.append((mine[i], int(rects[t0 + i, 0]), int(rects[t0 + i, 1]), 0, 0))
+            prect.append(tuple(int(v) for v in rects[t0 + i]))
+        off, lst = painting.build_cells(np.asarray(prect, np.int64), hc, wc)
+        own = rects[t0:t1]
+        box = (int(own[:, 0].min()), int(own[:, 1].min()), int(own[:, 2].max()), int(own[:, 3].max()))
+        canvas, mask = ops.new_feature_canvas(c, hc, wc)
+        mask = ops.replay_pieces(pieces, hw, alpha0, crop, canvas, mask, ops.to_device(off), ops.to_device(lst), box)
+        assert torch.equal(mine, t_all[t0:t1]), f"rank {rank}: blended tiles differ"
+        # under the LAST own tile nothing later was painted by anyone but later ranks' tiles; compare the canvas where
+        # only tiles <= t1-1 ever wrote: the footprint of own tiles minus the footprint of later tiles
+        foot = np.zeros((hc, wc), bool)
+        for y0, x0, y1, x1 in own:
+            foot[y0:y1, x0:x1] = True
+        for y0, x0, y1, x1 in rects[t1:]:
+            foot[y0:y1, x0:x1] = False
+        f_ = torch.from_numpy(foot).cuda()
+        assert torch.equal(canvas[0][:, f_], canvas_all[0][:, f_]) and torch.equal(mask[f_], mask_all[f_])
+    if world > 1:
+        assert 0 < sent < (world - 1) * 3 * c * hw * hw * 4      # strips, not whole tiles
+
+
 def test_paste_tiles_bitwise(eng):
     ops = eng["ops"]
     rs = np.random.RandomState(3)
@@ -125,6 +185,38 @@ def test_tiled_canvas_matches_reference(eng, level, mode):
         assert white.shape == g["geom"].shape + (3,)
     finally:
         eng["G"].set_conv_mode("h3")
+
+
+@pytest.mark.parametrize("mode", ["h3", "f8", "f32"])
+def test_lamali_canvas_matches_reference(mode):
+    """BASELINE config 3 on its named input (neube_stylize.sh:79-85): lamali_sm.png, P = 256, crop margin 10, feature
+    blending level 2 = 12 tiles; the HIP three-phase schedule (HIP encoder + generator + canvas kernels) against the
+    canvas the REFERENCE engine painted tile by tile (tests/golden/make_golden_engine.py --lamali)."""
+    from test_painting_cpu import lamali_setup
+    from brushstroke_engine_amd.networks import Generator
+    e = lamali_setup()
+    g = e["g"]
+    G = Generator(e["cfg"], e["sd"], conv_mode=mode).to("cuda")
+    ops = painting.TileOps(G, encmod.HipGeometryEncoder(e["esd"]))
+    for batch in (32, 5):                                   # one batch; three ragged batches alternating between streams
+        helper = painting.PaintingHelper(ops, batch=batch)
+        helper.set_feature_blending(2)
+        opts = painting.GanBrushOptions()
+        opts.set_style(torch.from_numpy(e["z"]), 594)
+        out, full, crops, padded = helper.paint_image(e["geom"], opts, crop_margin=int(g["crop_margin"]), return_full=True)
+        assert len(crops) == 12 and np.array_equal(np.array([c[:2] for c in crops]), g["crops"])
+        d = np.abs(full.astype(np.int32) - g["canvas_level2_clear"].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 5e-3, (mode, d.max(), (d > 0).mean())
+        assert float(helper.mask.sum()) == g["feature_canvas_stats"][2]
+        np.testing.assert_allclose(helper.features[0, ::16, ::8, ::8].cpu().numpy(), g["feature_canvas_sub"],
+                                   atol={"f32": 5e-5, "h3": 2e-4, "f8": 2e-3}[mode])
+        assert out.shape == (800, 514, 4)
+    helper = painting.PaintingHelper(ops, batch=32)          # level 0: independent tiles
+    opts = painting.GanBrushOptions()
+    opts.set_style(torch.from_numpy(e["z"]), 594)
+    _, full0, _, _ = helper.paint_image(e["geom"], opts, crop_margin=int(g["crop_margin"]), return_full=True)
+    d = np.abs(full0[::37].astype(np.int32) - g["canvas_level0_rows"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3
 
 
 def test_render_stroke_interactive_sequence(eng):

@@ -27,6 +27,24 @@ def eng():
     return dict(g=g, cfg=cfg, sd=sd, esd=esd, z=z)
 
 
+@pytest.fixture(scope="module")
+def lam():
+    """BASELINE config 3 on its named input: lamali_sm.png (514 x 800) painted by the REFERENCE engine at P = 256, crop
+    margin 10, blending level 2 -- 12 tiles (tests/golden/make_golden_engine.py --lamali)."""
+    return lamali_setup()
+
+
+def lamali_setup():
+    g = load_golden("engine_lamali_r256.npz")
+    h, w = g["geom_shape"].tolist()
+    geom = (np.unpackbits(g["geom_bits"])[:h * w].reshape(h, w) * 255).astype(np.uint8)
+    cfg = cfgmod.style1_config(int(g["resolution"]))
+    sd = wmod.random_state_dict(cfg, seed=int(g["weights_seed"]))
+    esd = encmod.random_encoder_state_dict(int(g["encoder_seed"]))
+    z = np.random.RandomState(int(g["style_seed"])).randn(1, cfg.z_dim)
+    return dict(g=g, geom=geom, cfg=cfg, sd=sd, esd=esd, z=z)
+
+
 def _canvas_close(a, b, max_frac=2e-4):
     d = np.abs(a.astype(np.int32) - b.astype(np.int32))
     assert d.max() <= 1, d.max()                    # fp32 reassociation can flip a uint8 truncation
@@ -56,6 +74,21 @@ def test_oracle_painter_matches_reference_canvas(eng, level):
         assert float(P.mask.sum()) == st[2]
         np.testing.assert_allclose(float(P.features.double().sum()), st[0], rtol=1e-6)
         np.testing.assert_allclose(P.features[0, ::16, ::4, ::4].numpy(), g["feature_canvas_sub"], atol=2e-5)
+
+
+def test_oracle_painter_matches_reference_lamali(lam):
+    """Config 3's named workload through the oracle's sequential tile loop."""
+    g = lam["g"]
+    P = po.OraclePainter(no.OracleGenerator(lam["cfg"], lam["sd"]), lam["esd"])
+    out, full, crops, padded = P.paint_image(lam["geom"][..., None], z=lam["z"], crop_margin=int(g["crop_margin"]),
+                                             feature_blending=2)
+    assert len(crops) == 12 and np.array_equal(np.array([c[:2] for c in crops]), g["crops"])
+    _canvas_close(full, g["canvas_level2_clear"])
+    st = g["feature_canvas_stats"]
+    assert float(P.mask.sum()) == st[2]
+    np.testing.assert_allclose(float(P.features.double().sum()), st[0], rtol=1e-5)
+    np.testing.assert_allclose(P.features[0, ::16, ::8, ::8].numpy(), g["feature_canvas_sub"], atol=5e-5)
+    assert out.shape == (800, 514, 4)
 
 
 # ---------------------------------------------------------------- host logic
@@ -227,13 +260,55 @@ def _worker(rank, world, port, tmp):
             helper, res = _paint(e, level, batch=2)
             if rank == 0:
                 np.save(os.path.join(tmp, f"full{level}.npy"), res[1])
-                if level == 2:
-                    np.save(os.path.join(tmp, "mask.npy"), helper.mask.numpy())
             else:
                 assert res is None
+            if level == 2:
+                # the feature canvas is rank-local after the halo schedule: a rank's mask covers what was painted
+                # under ITS tiles; their union is the reference's mask
+                m = helper.mask.clone()
+                dist.all_reduce(m, op=dist.ReduceOp.MAX)
+                hb = torch.tensor([helper.halo_bytes["sent"], helper.halo_bytes["received"]], dtype=torch.int64)
+                allhb = [torch.zeros_like(hb) for _ in range(world)]
+                dist.all_gather(allhb, hb)
+                if rank == 0:
+                    np.save(os.path.join(tmp, "mask.npy"), m.numpy())
+                    np.save(os.path.join(tmp, "halo_bytes.npy"), torch.stack(allhb).numpy())
+                with pytest.raises(RuntimeError, match="rank-local"):
+                    helper.render_tiles(g["geom_padded"], g["crops"], painting.GanBrushOptions(), crop_margin=10)
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_lamali(rank, world, port, tmp):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    torch.set_num_threads(max(1, 8 // world))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        e = lamali_setup()
+        ops = OracleTileOps(e["cfg"], e["sd"], e["esd"])
+        helper = painting.PaintingHelper(ops, batch=2)
+        helper.set_feature_blending(2)
+        opts = painting.GanBrushOptions()
+        opts.set_style(torch.from_numpy(e["z"]), 594)
+        res = helper.paint_image(e["geom"], opts, crop_margin=int(e["g"]["crop_margin"]), return_full=True)
+        if rank == 0:
+            np.save(os.path.join(tmp, "lamali_full.npy"), res[1])
+        else:
+            assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lamali_sharded_world3_gloo(lam, tmp_path):
+    """Config 3: lamali_sm.png, 12 tiles (4 rows x 3) over 3 ranks (4 + 4 + 4: every range ends mid-row), halo
+    exchange + RGBA gather, against the canvas the reference engine painted."""
+    mp.spawn(_worker_lamali, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    _canvas_close(np.load(tmp_path / "lamali_full.npy"), lam["g"]["canvas_level2_clear"])
 
 
 def _worker_one_tile(rank, world, port, tmp):
@@ -273,12 +348,19 @@ def test_fewer_tiles_than_ranks_gloo(eng, tmp_path):
     assert np.array_equal(np.load(tmp_path / "one.npy"), ref)
 
 
-def test_sharded_schedule_world2_gloo(eng, tmp_path):
-    """9 tiles over 2 ranks (5 + 4, padded all_gather of phase-1 features, padded RGBA gather)."""
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_schedule_gloo(eng, tmp_path, world):
+    """9 tiles (3 x 3) over 2 ranks (5 + 4) and over 4 ranks (3 + 2 + 2 + 2: the ranges end mid-row, so right, down and
+    both diagonal neighbours cross ranks): halo exchange of the overlapped strips only, padded RGBA gather."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for level in (0, 2):
         _canvas_close(np.load(tmp_path / f"full{level}.npy"), eng["g"][f"canvas_level{level}_clear"])
     assert float(np.load(tmp_path / "mask.npy").sum()) == eng["g"]["feature_canvas_stats"][2]
+    # exchanged volume: strips only -- far below one whole phase-1 tile (128 ch x 64 x 64 fp32 = 2 MB) per boundary tile
+    hb = np.load(tmp_path / "halo_bytes.npy")
+    assert hb[:, 0].sum() == hb[:, 1].sum() > 0
+    tile_bytes = 128 * 64 * 64 * 4
+    assert hb.max() < 2 * tile_bytes, hb                      # (the old schedule moved 9 whole tiles to every rank)
 
 
 # ---------------------------------------------------------------- clear-background (UVS) mapping

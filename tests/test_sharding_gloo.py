@@ -81,3 +81,63 @@ def test_two_rank_gather_assembles_canvas(tmp_path):
     for i in range(n_tiles):
         y, x = (i // cols) * size, (i % cols) * size
         np.testing.assert_array_equal(canvas[y:y + size, x:x + size], want[i])
+
+
+# ---------------------------------------------------------------- halo plan (host logic)
+def _coverage(plan, rects, bounds, dst):
+    """pixel -> set of foreign earlier tiles delivered there, and a flag for duplicate deliveries."""
+    got, dup = {}, False
+    for (src, d), lst in plan.items():
+        if d != dst:
+            continue
+        for f, (y0, x0, y1, x1) in lst:
+            assert bounds[src][0] <= f < bounds[src][1] and src < dst
+            ry0, rx0, ry1, rx1 = rects[f]
+            assert ry0 <= y0 < y1 <= ry1 and rx0 <= x0 < x1 <= rx1
+            for y in range(y0, y1):
+                for x in range(x0, x1):
+                    s_ = got.setdefault((y, x), set())
+                    dup |= f in s_
+                    s_.add(f)
+    return got, dup
+
+
+@pytest.mark.parametrize("world,cols,n", [(2, 3, 9), (4, 3, 9), (3, 4, 10), (8, 5, 23), (4, 1, 5)])
+def test_halo_plan_delivers_exactly_the_earlier_tiles_under_own_tiles(world, cols, n):
+    from brushstroke_engine_amd.sharding import halo_plan, shard_bounds
+    hw, stride = 12, 8                                       # overlap 4, as (R/2 - 2*crop) strides do
+    rects = np.array([[(i // cols) * stride, (i % cols) * stride, (i // cols) * stride + hw, (i % cols) * stride + hw]
+                      for i in range(n)])
+    bounds = [shard_bounds(n, r, world) for r in range(world)]
+    plan = halo_plan(rects, bounds)
+    for dst, (t0, t1) in enumerate(bounds):
+        got, dup = _coverage(plan, rects, bounds, dst)
+        assert not dup
+        want = {}
+        for t in range(t0, t1):
+            for f in range(t0):
+                y0, x0 = max(rects[t][0], rects[f][0]), max(rects[t][1], rects[f][1])
+                y1, x1 = min(rects[t][2], rects[f][2]), min(rects[t][3], rects[f][3])
+                for y in range(y0, y1):
+                    for x in range(x0, x1):
+                        want.setdefault((y, x), set()).add(f)
+        assert got == want
+
+
+def test_halo_plan_irregular_tiles():
+    """Arbitrary (non-grid) tile positions: strokes painted anywhere on the canvas."""
+    from brushstroke_engine_amd.sharding import halo_plan, shard_bounds, rect_subtract
+    rs = np.random.RandomState(3)
+    yx = rs.randint(0, 40, size=(14, 2))
+    rects = np.concatenate([yx, yx + 16], axis=1)
+    bounds = [shard_bounds(14, r, 3) for r in range(3)]
+    plan = halo_plan(rects, bounds)
+    for dst, (t0, t1) in enumerate(bounds):
+        got, dup = _coverage(plan, rects, bounds, dst)
+        assert not dup
+        for (y, x), fs in got.items():
+            for f in fs:
+                assert any(rects[t][0] <= y < rects[t][2] and rects[t][1] <= x < rects[t][3] for t in range(t0, t1))
+    assert rect_subtract((0, 0, 4, 4), (1, 1, 3, 3)) == [(0, 0, 1, 4), (3, 0, 4, 4), (1, 0, 3, 1), (1, 3, 3, 4)]
+    assert rect_subtract((0, 0, 4, 4), (5, 5, 6, 6)) == [(0, 0, 4, 4)]
+    assert rect_subtract((0, 0, 4, 4), (0, 0, 4, 4)) == []
