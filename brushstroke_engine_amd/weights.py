@@ -93,6 +93,23 @@ def random_state_dict(cfg: GeneratorConfig, seed: int = 0) -> StateDict:
     return sd
 
 
+def hdr_state_dict(cfg: GeneratorConfig, seed: int = 0, act_scale: float = 60.0, logit_scale: float = 0.25) -> StateDict:
+    """High-dynamic-range variant of :func:`random_state_dict` for precision tests: the learned constant, the biases and
+    the noise strengths are scaled so that activations run at an rms of ~50 and several layers reach ``conv_clamp`` = 256
+    (trained StyleGAN2 generators do -- that is why the reference clamps, networks.py:389), and the ToRGB weights so that
+    the triad logits span about +-20 (saturated and steep softmax regions both present).  The split-f16 / fp8 conv
+    modes have RELATIVE error bounds, so this is where their absolute pixel error is largest."""
+    sd = random_state_dict(cfg, seed)
+    a = np.float32(act_scale)
+    sd["synthesis.b4.const"] = sd["synthesis.b4.const"] * a
+    for l in cfg.layers:
+        sd[f"{l.name}.bias"] = (sd[f"{l.name}.bias"] * (a * 3)).astype(np.float32)
+        sd[f"{l.name}.noise_strength"] = (sd[f"{l.name}.noise_strength"] * (a * 3)).astype(np.float32)
+    t = cfg.torgb_name
+    sd[f"{t}.weight"] = (sd[f"{t}.weight"] * np.float32(logit_scale / 3.0 / act_scale * 20)).astype(np.float32)
+    return sd
+
+
 def expected_shapes(cfg: GeneratorConfig) -> Dict[str, tuple]:
     return {k: tuple(v.shape) for k, v in random_state_dict(cfg, 0).items()}
 

@@ -282,9 +282,75 @@ def make_full(res, step):
     print(f"gen_r{res}.npz:", len(out), "arrays")
 
 
+def make_hdr():
+    """High-dynamic-range fixture (R=128, N=2): weights.hdr_state_dict drives several layers into conv_clamp = 256 and
+    the triad logits over +-20; full uvs / img of the reference's fp32 evaluation + per-layer range statistics."""
+    res = 128
+    cfg = cfgmod.style1_config(res)
+    sd = wmod.hdr_state_dict(cfg, seed=0)
+    G = build_reference(cfg, sd)
+    n = 2
+    z = synthetic.batch_z(cfg, n, first_seed=594)
+    geom = synthetic.geom_features(cfg, n, seed=0)
+    pos = np.array([[0, 0], [37, 211]], np.int64)
+    out = {"z": z, "positions": pos, "weights_seed": np.int64(0), "geom_seed": np.int64(0)}
+    with Capture(G, cfg) as cap:
+        (img, dbg), taps = run_case(G, cfg, cap, z=z, geom=geom, positions=pos, return_debug_data=True,
+                                    return_features=[res // 2])
+    out["uvs"], out["img"], out["colors"] = np32(dbg["uvs"]), np32(img), np32(dbg["colors"])
+    out["logits.sub"] = sub(np32(taps["torgb.logits"]), 4)
+    out[f"features{res // 2}.sub"] = sub(np32(dbg[f"features{res // 2}"])[:, ::8], 4)
+    names, rng = [], []
+    for l in cfg.layers:
+        v = np32(taps[f"{l.name}.out"])
+        names.append(l.name)
+        rng.append([np.sqrt((v.astype(np.float64) ** 2).mean()), np.abs(v).max(), (np.abs(v) >= 255.99).mean()])
+    out["layer_range"] = np.array(rng, np.float64)               # rms, max-abs, fraction at the clamp, per layer
+    lg = np32(taps["torgb.logits"])
+    out["logits.range"] = np.array([lg.min(), lg.max()], np.float64)
+    assert (out["layer_range"][:, 1] >= 255.99).sum() >= 5 and lg.min() < -15 and lg.max() > 20
+    np.savez_compressed(os.path.join(HERE, "gen_hdr_r128.npz"), **out)
+    print("gen_hdr_r128.npz: layers at the clamp:", [n_ for n_, r in zip(names, rng) if r[1] >= 255.99], "logits", out["logits.range"])
+
+
+def make_b32():
+    """The BASELINE workload itself (batch 32, R=256, the inputs bench.py's rank 0 uses) through the reference on CPU:
+    per-sample checksums of uvs / img and one full pixel row per sample."""
+    res, n = 256, 32
+    cfg = cfgmod.style1_config(res)
+    sd = wmod.random_state_dict(cfg, seed=0)
+    G = build_reference(cfg, sd)
+    z = synthetic.batch_z(cfg, n, first_seed=0)
+    geom = synthetic.geom_features(cfg, n, seed=0)
+    pos = synthetic.positions(cfg, n, seed=0)
+    uvs, img, colors = [], [], []
+    with torch.no_grad():
+        for i in range(0, n, 8):
+            im, dbg = G(z=torch.from_numpy(z[i:i + 8]), c=None, geom_feature=[torch.from_numpy(g[i:i + 8]) for g in geom],
+                        positions=torch.from_numpy(pos[i:i + 8]), noise_mode="const", force_fp32=True, return_debug_data=True)
+            uvs.append(np32(dbg["uvs"])); img.append(np32(im)); colors.append(np32(dbg["colors"]))
+    uvs, img, colors = np.concatenate(uvs), np.concatenate(img), np.concatenate(colors)
+    u64, i64 = uvs.astype(np.float64), img.astype(np.float64)
+    out = {"weights_seed": np.int64(0), "first_seed": np.int64(0), "geom_seed": np.int64(0), "pos_seed": np.int64(0),
+           "colors": colors,
+           "uvs.sum": u64.sum(axis=(2, 3)), "uvs.sumsq": (u64 * u64).sum(axis=(2, 3)),          # [32, 3]
+           "img.sum": i64.sum(axis=(2, 3)), "img.sumsq": (i64 * i64).sum(axis=(2, 3)),
+           "uvs.row": uvs[:, :, 85, :], "img.row": img[:, :, 170, :], "uvs.sub": uvs[:, :, ::32, ::32]}
+    np.savez_compressed(os.path.join(HERE, "gen_b32_r256.npz"), **out)
+    print("gen_b32_r256.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--hdr" in sys.argv or "--b32" in sys.argv:
+        if "--hdr" in sys.argv:
+            make_hdr()
+        if "--b32" in sys.argv:
+            make_b32()
+        sys.exit(0)
     make_ops()
     make_tiny()
     make_full(128, 4)
     make_full(256, 8)
+    make_hdr()
+    make_b32()

@@ -12,6 +12,10 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 PIX_TOL = 1e-4
 ACT_TOL = 5e-4
+# per arithmetic mode (Generator(conv_mode=...)): pixels / uvs, activations and logits.  north_star budget: 1e-3 on pixels.
+MODES = ("h3", "f8")
+PIX = {"f32": 1e-4, "h3": 1e-4, "f8": 3e-4}
+ACT = {"f32": 5e-4, "h3": 5e-4, "f8": 4e-3}
 
 
 @pytest.fixture(scope="module")
@@ -31,11 +35,11 @@ def err(got, want):
     return float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
 
 
-def build(cfg, seed, dev):
+def build(cfg, seed, dev, mode=None):
     from brushstroke_engine_amd import weights as wmod
     from brushstroke_engine_amd.networks import Generator
     sd = wmod.random_state_dict(cfg, seed=seed)
-    return Generator(cfg, sd).to(dev), sd
+    return (Generator(cfg, sd) if mode is None else Generator(cfg, sd, conv_mode=mode)).to(dev), sd
 
 
 def test_api_surface(dev):
@@ -49,12 +53,14 @@ def test_api_surface(dev):
         G.synthesis(torch.zeros(1, 3, 32, device=dev), [])             # misc.assert_shape on ws (NM:145)
 
 
-def test_tiny_golden_all_cases(dev):
+@pytest.mark.parametrize("mode", MODES)
+def test_tiny_golden_all_cases(dev, mode):
     from brushstroke_engine_amd import config as cfgmod, synthetic
     from brushstroke_engine_amd.stitching import BlendedFeatures
     g = load_golden("gen_tiny.npz")
     cfg = cfgmod.tiny_config(32)
-    G, _ = build(cfg, int(g["weights_seed"]), dev)
+    G, _ = build(cfg, int(g["weights_seed"]), dev, mode)
+    PIX_TOL, ACT_TOL = PIX[mode], ACT[mode]
     geom = [D(x, dev) for x in synthetic.geom_features(cfg, 3, seed=int(g["geom_seed"]))]
     z, pos = D(g["z"], dev), D(g["positions"], dev)
     # A: stylize path
@@ -93,13 +99,15 @@ def test_tiny_golden_all_cases(dev):
     assert err(dbg["features32"], g["E_features32"]) <= ACT_TOL
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("res", [128, 256])
-def test_style1_shapes_golden(dev, res):
+def test_style1_shapes_golden(dev, res, mode):
     """style1 checkpoint shapes at 128 (as shipped) and 256 (BASELINE metric) against reference outputs."""
     from brushstroke_engine_amd import config as cfgmod, synthetic
     g = load_golden(f"gen_r{res}.npz")
     cfg = cfgmod.style1_config(res)
-    G, _ = build(cfg, int(g["weights_seed"]), dev)
+    G, _ = build(cfg, int(g["weights_seed"]), dev, mode)
+    PIX_TOL, ACT_TOL = PIX[mode], ACT[mode]
     geom = [D(x, dev) for x in synthetic.geom_features(cfg, 2, seed=int(g["geom_seed"]))]
     half = res // 2
     extra = {"logits": True}
@@ -120,19 +128,21 @@ def test_style1_shapes_golden(dev, res):
     assert err(dbg["ws"], g["ws"]) <= 1e-5
     assert err(dbg["colors"], g["colors"]) <= 1e-5
     chk(f"features{half}", dbg[f"features{half}"], ACT_TOL)
-    chk("logits", extra["out"]["logits"], 1e-3)
+    chk("logits", extra["out"]["logits"], max(1e-3, ACT_TOL))
     chk("uvs", dbg["uvs"], PIX_TOL)
     chk("img", img, PIX_TOL)
     assert err(dbg["uvs"][:, :, res // 3, :], g["uvs.row"]) <= PIX_TOL
 
 
-def test_batch_vs_oracle_and_engine_composite(dev):
+@pytest.mark.parametrize("mode", MODES)
+def test_batch_vs_oracle_and_engine_composite(dev, mode):
     """Random batch (n=5, odd) at R=64 style1 channel widths against the CPU oracle, including the fused
     paint-engine compositing (RGBA float + uint8, both render modes, user color override)."""
     from brushstroke_engine_amd import config as cfgmod, synthetic
     from oracle import neube_oracle as orc
     cfg = cfgmod.style1_config(64)
-    G, sd = build(cfg, 3, dev)
+    G, sd = build(cfg, 3, dev, mode)
+    PIX_TOL = PIX[mode]
     O = orc.OracleGenerator(cfg, sd)
     n = 5
     z = synthetic.batch_z(cfg, n, 100)
@@ -142,17 +152,17 @@ def test_batch_vs_oracle_and_engine_composite(dev):
     user = np.full((n, 3, 3), np.nan, np.float32)
     user[1, :, 0] = [0.9, 0.1, 0.2]
     user[3, :, 1] = [0.0, 1.0, 0.5]
-    for mode in ("clear", "full"):
+    for rmode in ("clear", "full"):
         u8, f32, dbg = G.render_triad(z=D(z, dev), geom_feature=[D(x, dev) for x in geom], positions=D(pos, dev),
-                                      render_mode=mode, user_colors=D(user, dev), want_f32=True)
+                                      render_mode=rmode, user_colors=D(user, dev), want_f32=True)
         assert err(dbg["uvs"], want["uvs"]) <= PIX_TOL
-        rgba = orc.triad_composite(want["uvs"], want["colors"], mode, user_colors=user)
+        rgba = orc.triad_composite(want["uvs"], want["colors"], rmode, user_colors=user)
         assert err(f32, rgba) <= PIX_TOL
         want8 = orc.rgba_to_uint8(rgba).permute(0, 2, 3, 1).numpy().astype(np.int32)
         got8 = u8.cpu().numpy().astype(np.int32)
         assert got8.shape == want8.shape
         assert np.abs(got8 - want8).max() <= 1                  # truncation of values within 1e-4 of an integer
-        assert (got8 != want8).mean() < 2e-3
+        assert (got8 != want8).mean() < (2e-3 if mode == "h3" else 2e-2)
     with pytest.raises(RuntimeError, match="Unknown render mode"):
         G.render_triad(z=D(z, dev), geom_feature=[D(x, dev) for x in geom], render_mode="bogus")
 
@@ -180,13 +190,14 @@ def test_linearity_and_determinism_full_size(dev):
     assert err(c, a[idx]) <= 2e-5
 
 
-def test_graphed_batch1_matches_eager(dev):
+@pytest.mark.parametrize("mode,res", [("h3", 64), ("f8", 64), ("f8", 256), ("h3", 256)])
+def test_graphed_batch1_matches_eager(dev, mode, res):
     """Config 4: the hipGraph-captured batch-1 step reproduces the eager result bit for bit, also after
-    its inputs have been overwritten in place."""
+    its inputs have been overwritten in place -- at R=64 and at the size bench.py times (R=256)."""
     from brushstroke_engine_amd import config as cfgmod, synthetic
     from brushstroke_engine_amd.graphed import GraphedTriadRender
-    cfg = cfgmod.style1_config(64)
-    G, _ = build(cfg, 5, dev)
+    cfg = cfgmod.style1_config(res)
+    G, _ = build(cfg, 5, dev, mode)
     gr = GraphedTriadRender(G, batch=1, want_f32=True)
     for seed in (1, 2):
         z = D(synthetic.batch_z(cfg, 1, seed), dev).to(torch.float32)
@@ -248,3 +259,57 @@ def test_baseline_size_properties(dev):
     assert float((out["f8"][1] - out["f32"][1]).abs().max()) <= 3e-4                       # north_star budget: 1e-3
     assert int((out["f8"][0].int() - out["f32"][0].int()).abs().max()) <= 1
     assert float(out["f32"][1].std()) > 0.05                                               # (not a degenerate image)
+
+
+@pytest.mark.parametrize("mode", ["f32", "h3", "f8"])
+def test_high_dynamic_range_fixture(dev, mode):
+    """Activations at rms ~50 with ten layers reaching conv_clamp = 256 and triad logits over -21..+42 (weights.hdr_state_dict),
+    against the REFERENCE's fp32 evaluation (tests/golden/make_golden.py --hdr).  The split-f16 / fp8 modes have relative
+    error bounds, so this is where their absolute pixel error is largest: all three modes must stay inside the
+    north_star budget of 1e-3 on pixels."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    g = load_golden("gen_hdr_r128.npz")
+    assert (g["layer_range"][:, 1] >= 255.99).sum() >= 5 and g["logits.range"][0] < -15 and g["logits.range"][1] > 20
+    cfg = cfgmod.style1_config(128)
+    G = Generator(cfg, wmod.hdr_state_dict(cfg, seed=int(g["weights_seed"])), conv_mode=mode).to(dev)
+    geom = [D(x, dev) for x in synthetic.geom_features(cfg, 2, seed=int(g["geom_seed"]))]
+    extra = {"logits": True}
+    img, dbg = G(D(g["z"], dev), None, geom, positions=D(g["positions"], dev), return_debug_data=True, return_features=[64],
+                 noise_mode="const", _extra_outputs=extra)
+    e_uvs, e_img = err(dbg["uvs"], g["uvs"]), err(img, g["img"])
+    e_lg = err(extra["out"]["logits"][..., ::4, ::4], g["logits.sub"])
+    e_ft = err(dbg["features64"][:, ::8, ::4, ::4], g["features64.sub"])
+    print(f"[hdr {mode}] uvs {e_uvs:.2e} img {e_img:.2e} logits {e_lg:.2e} features64 {e_ft:.2e}")
+    assert err(dbg["colors"], g["colors"]) <= 1e-5
+    assert e_uvs <= 1e-3 and e_img <= 1e-3, (mode, e_uvs, e_img)
+    assert e_ft <= {"f32": 2e-3, "h3": 2e-3, "f8": 0.25}[mode] and e_lg <= {"f32": 1e-3, "h3": 1e-3, "f8": 4e-3 * 10}[mode]
+
+
+@pytest.mark.parametrize("mode", ["h3", "f8"])
+def test_baseline_batch32_r256_golden(dev, mode):
+    """BASELINE.json configs[1] at FULL size -- batch 32, R=256, the very inputs bench.py's rank 0 renders -- against values the
+    reference produced on CPU (tests/golden/make_golden.py --b32): per-sample checksums of uvs / img, a pixel row per sample.
+    This runs the batch-32 kernel mix (two sub-batches of 16 on two streams, large-tile kernels for b32 / b64)."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic
+    g = load_golden("gen_b32_r256.npz")
+    cfg = cfgmod.style1_config(256)
+    G, _ = build(cfg, int(g["weights_seed"]), dev, mode)
+    n = 32
+    z = D(synthetic.batch_z(cfg, n, int(g["first_seed"])), dev)
+    geom = [D(x, dev) for x in synthetic.geom_features(cfg, n, seed=int(g["geom_seed"]))]
+    pos = D(synthetic.positions(cfg, n, seed=int(g["pos_seed"])), dev)
+    img, dbg = G(z, None, geom, positions=pos, return_debug_data=True, noise_mode="const")
+    tol = PIX[mode]
+    assert err(dbg["colors"], g["colors"]) <= 1e-5
+    assert err(dbg["uvs"][:, :, 85, :], g["uvs.row"]) <= tol and err(img[:, :, 170, :], g["img.row"]) <= tol
+    assert err(dbg["uvs"][:, :, ::32, ::32], g["uvs.sub"]) <= tol
+    for name, t in (("uvs", dbg["uvs"]), ("img", img)):
+        t64 = t.double()
+        s1, s2 = t64.sum(dim=(2, 3)).cpu().numpy(), (t64 * t64).sum(dim=(2, 3)).cpu().numpy()
+        # a checksum over 65 536 pixels: errors of +-tol add up at worst linearly; observed: random-walk level
+        assert np.abs(s1 - g[f"{name}.sum"]).max() <= 65536 * tol * 0.02, name
+        assert np.abs(s2 - g[f"{name}.sumsq"]).max() <= 65536 * tol * 0.04, name
+    # the same batch through the fused compositing entry the benchmark times
+    u8, rgba, dbg2 = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
+    assert torch.equal(dbg2["uvs"], dbg["uvs"])

@@ -163,7 +163,7 @@ def test_split_generator_equals_whole(eng):
 
 
 @pytest.mark.parametrize("level", [0, 2])
-@pytest.mark.parametrize("mode", ["h3", "f32"])
+@pytest.mark.parametrize("mode", ["h3", "f32", "f8"])
 def test_tiled_canvas_matches_reference(eng, level, mode):
     """BASELINE config 3 at test size: the HIP tiled schedule reproduces the canvas the reference engine painted
     tile by tile (9 tiles, R=128, crop margin 10)."""
@@ -175,12 +175,12 @@ def test_tiled_canvas_matches_reference(eng, level, mode):
         opts = painting.GanBrushOptions()
         opts.set_style(torch.from_numpy(eng["z"]), 594)
         out, full, crops, padded = helper.paint_image(g["geom"], opts, crop_margin=int(g["crop_margin"]), return_full=True)
-        _canvas_close(full, g[f"canvas_level{level}_clear"])
+        _canvas_close(full, g[f"canvas_level{level}_clear"], max_frac=5e-3 if mode == "f8" else 1e-3)
         assert out.shape == g["geom"].shape + (4,)
         if level == 2:
             assert float(helper.mask.sum()) == g["feature_canvas_stats"][2]
             np.testing.assert_allclose(helper.features[0, ::16, ::4, ::4].cpu().numpy(), g["feature_canvas_sub"],
-                                       atol=1e-4 if mode == "h3" else 2e-5)
+                                       atol={"h3": 1e-4, "f32": 2e-5, "f8": 2e-3}[mode])
         white = helper.paint_image(g["geom"], opts, crop_margin=int(g["crop_margin"]), on_white=True)
         assert white.shape == g["geom"].shape + (3,)
     finally:

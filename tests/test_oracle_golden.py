@@ -188,6 +188,37 @@ def test_generator_full_shapes_256_slow():
     _check_full(256)
 
 
+def test_oracle_high_dynamic_range_fixture():
+    """The oracle against the reference on the clamp-reaching weights (ten layers at conv_clamp, logits -21..+42)."""
+    g = load_golden("gen_hdr_r128.npz")
+    cfg = cfgmod.style1_config(128)
+    sd = wmod.hdr_state_dict(cfg, seed=int(g["weights_seed"]))
+    geom = synthetic.geom_features(cfg, 2, seed=int(g["geom_seed"]))
+    taps = {}
+    img, dbg = orc.OracleGenerator(cfg, sd)(g["z"], None, geom, positions=g["positions"], return_debug_data=True,
+                                            return_features=[64], taps=taps)
+    close(dbg["uvs"], g["uvs"], 2e-4)
+    close(img, g["img"], 2e-4)
+    close(taps["torgb.logits"].numpy()[..., ::4, ::4], g["logits.sub"], 2e-3)
+    rng = np.array([[float(taps[f"{l.name}.out"].abs().max())] for l in cfg.layers])
+    assert np.array_equal(rng[:, 0] >= 255.99, g["layer_range"][:, 1] >= 255.99)
+
+
+def test_oracle_baseline_batch_rows():
+    """First 4 samples of the BASELINE batch (R=256, bench.py's rank-0 inputs) against the reference's rows / checksums."""
+    g = load_golden("gen_b32_r256.npz")
+    cfg = cfgmod.style1_config(256)
+    sd = wmod.random_state_dict(cfg, seed=int(g["weights_seed"]))
+    n = 4
+    z = synthetic.batch_z(cfg, 32, int(g["first_seed"]))[:n]
+    geom = [x[:n] for x in synthetic.geom_features(cfg, 32, seed=int(g["geom_seed"]))]
+    pos = synthetic.positions(cfg, 32, seed=int(g["pos_seed"]))[:n]
+    img, dbg = orc.OracleGenerator(cfg, sd)(z, None, geom, positions=pos, return_debug_data=True)
+    close(dbg["uvs"].numpy()[:, :, 85, :], g["uvs.row"][:n], 5e-5)
+    close(img.numpy()[:, :, 170, :], g["img.row"][:n], 5e-5)
+    np.testing.assert_allclose(dbg["uvs"].double().sum(dim=(2, 3)).numpy(), g["uvs.sum"][:n], atol=0.05)
+
+
 def test_triad_composite_semantics():
     rs = np.random.RandomState(3)
     uvs = torch.softmax(T(rs.randn(2, 3, 5, 5).astype(np.float32)), dim=1)
