@@ -148,8 +148,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 hipGraph latency leg")
-    ap.add_argument("--conv-mode", default="f8", choices=["h3", "f8", "f32"],
-                    help="f8 (default): split-f16 MFMA with the two correction products on block-scaled fp8 MFMAs (pixels within "
+    ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f32"],
+                    help="default: the library default (networks.DEFAULT_CONV_MODE = f8); f8: split-f16 MFMA with the two correction products on block-scaled fp8 MFMAs (pixels within "
                          "1e-4 of fp32; budget 1e-3); h3: all three products in f16 (5e-6); f32: all layers on the fp32 MFMA kernels")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
     args = ap.parse_args()
@@ -193,8 +193,10 @@ def main():
             dist.init_process_group(backend, timeout=tmo)
 
     from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
-    from brushstroke_engine_amd.networks import Generator
+    from brushstroke_engine_amd.networks import Generator, DEFAULT_CONV_MODE
     from brushstroke_engine_amd.sharding import TileGatherer
+    if args.conv_mode is None:
+        args.conv_mode = DEFAULT_CONV_MODE
 
     cfg = cfgmod.style1_config(args.res)
     sd = wmod.random_state_dict(cfg, seed=0)

@@ -127,10 +127,19 @@ def lib() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            raise NeubeHipError(
-                f"HIP kernel library not found at {LIB_PATH}. Build it with "
-                f"`python -m brushstroke_engine_amd.build` (needs hipcc, gfx950). There is no CPU fallback.")
+        from . import build as _build
+        if _build.is_stale():
+            # missing, or built from other sources than the tree holds now (kernel edits without an ABI bump would
+            # otherwise run the old code silently): rebuild if a compiler is here, else fail loudly
+            if os.path.exists(_build.HIPCC) and os.environ.get("NEUBE_NO_AUTOBUILD") != "1":
+                try:
+                    _build.build(verbose=False)
+                except Exception as e:                                   # noqa: BLE001
+                    raise NeubeHipError(f"rebuilding the stale HIP kernel library failed: {e}") from e
+            else:
+                raise NeubeHipError(
+                    f"HIP kernel library at {LIB_PATH} is missing or was built from different sources. Build it with "
+                    f"`python -m brushstroke_engine_amd.build` (needs hipcc, gfx950). There is no CPU fallback.")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             try:

@@ -24,22 +24,81 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fn
          "-Wno-unused-function", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
 
+STAMP = LIB + ".stamp"
+
+
+def source_digest() -> str:
+    """sha256 over the kernel sources, headers and compiler flags: what the library was (or would be) built from.
+    Content, not mtimes -- a source snapshot copied to another machine keeps its digest."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    """True if there is no library or it was not built from the sources that are in the tree now."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_digest()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Build if stale.  Safe under concurrent callers (torchrun ranks): an exclusive lock serialises them and the library
+    is written to a per-process temporary before an atomic rename."""
+    import fcntl
     if not force and not is_stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():                 # another process built it while this one waited
+            return LIB
+        digest = source_digest()
+        tmp = f"{LIB}.{os.getpid()}.tmp"
+        # one object per source file, compiled in parallel and cached by content (sources + headers + flags): editing one
+        # kernel file recompiles that file only
+        import hashlib
+        from concurrent.futures import ThreadPoolExecutor
+        objdir = os.path.join(CSRC, "build")
+        os.makedirs(objdir, exist_ok=True)
+        hdr = hashlib.sha256(" ".join(FLAGS).encode())
+        for name in HEADERS:
+            with open(os.path.join(CSRC, name), "rb") as f:
+                hdr.update(f.read())
+        cflags = [f for f in FLAGS if f != "-shared"]
+
+        def compile_one(src):
+            with open(os.path.join(CSRC, src), "rb") as f:
+                key = hashlib.sha256(hdr.digest() + f.read()).hexdigest()[:16]
+            obj = os.path.join(objdir, f"{src}.{key}.o")
+            if not os.path.exists(obj) or force:
+                cmd = [HIPCC] + cflags + ["-c", os.path.join(CSRC, src), "-o", f"{obj}.{os.getpid()}.tmp"]
+                if verbose:
+                    print("[build]", " ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                os.replace(f"{obj}.{os.getpid()}.tmp", obj)
+                for old in os.listdir(objdir):                     # drop older objects of this source
+                    if old.startswith(src + ".") and old.endswith(".o") and os.path.join(objdir, old) != obj:
+                        os.remove(os.path.join(objdir, old))
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+            objs = list(ex.map(compile_one, SOURCES))
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"] + objs + ["-o", tmp]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        with open(f"{STAMP}.{os.getpid()}.tmp", "w") as f:
+            f.write(digest + "\n")
+        os.replace(f"{STAMP}.{os.getpid()}.tmp", STAMP)
     return LIB
 
 

@@ -41,6 +41,9 @@ def _assert_shape(t: torch.Tensor, ref_shape) -> None:
             raise AssertionError(f"Wrong size for dimension {idx}: got {size}, expected {ref}")
 
 
+# the arithmetic mode of the conv layers unless a caller asks otherwise (Generator(conv_mode=...)); bench.py times this one
+DEFAULT_CONV_MODE = "f8"
+
 class FullyConnectedLayer(torch.nn.Module):
     """Parameter holder for ``networks.py:92-122``; evaluated inside nb_mapping_f32 / nb_styles_f32."""
 
@@ -237,9 +240,10 @@ class SynthesisNetwork(torch.nn.Module):
             setattr(self, f"b{res}", SynthesisBlock(cfg, res, layers))
         self.packed: Dict[str, Dict[str, torch.Tensor]] = {}
         self._plans: Dict[int, _Plan] = {}      # per-batch workspaces, one per concurrent sub-batch (slot)
-        # "h3": large conv1 layers on the f16 matrix cores as hi/lo split products (fp32-grade, ~5x the fp32 MFMA
-        # rate); "f32": every layer on the exact-fp32 MFMA kernels.
-        self.conv_mode = "h3"
+        # "f8" (default): split-f16 products with both correction terms on block-scaled fp8 MFMAs (pixels within 1e-4 of
+        # fp32 on O(1) activations, 1.4e-4 with ten layers at the conv_clamp: tests/golden/gen_hdr_r128.npz; budget 1e-3);
+        # "h3": all three hi/lo products on the f16 matrix cores (5e-6); "f32": every layer on the exact-fp32 MFMA kernels.
+        self.conv_mode = DEFAULT_CONV_MODE
         # a layer takes the split-f16 kernels when it has enough output pixels to fill the chip with their (large)
         # workgroups: below ~64 workgroups the fp32 kernels (smaller tiles, split-K) have the lower latency
         # (tools/layers_b1.py: at batch 1 the >= 128x128 layers gain 25-65 %, the <= 64x64 layers lose 40-100 %)
@@ -329,6 +333,10 @@ class SynthesisNetwork(torch.nn.Module):
         self._ensure_packed()
         plan = self._plans.get(slot)
         if plan is None or plan.n_max < n or plan.device != device:
+            if plan is not None and plan.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                # the old workspace may still be read by kernels on ANOTHER stream than the one it returns to when freed
+                # (a slot is used from side streams): let them finish before it goes back to the allocator (rare: growth)
+                torch.cuda.synchronize(plan.device)
             plan = _Plan(self, max(n, 1 if plan is None else plan.n_max), device)
             self._plans[slot] = plan
         return plan
@@ -690,8 +698,8 @@ class _SplitForward:
 class Generator(torch.nn.Module):
     """``networks_modified.py:227-400``."""
 
-    def __init__(self, cfg: GeneratorConfig = None, state_dict: Optional[StateDict] = None, conv_mode: str = "h3",
-                 **kwargs):
+    def __init__(self, cfg: GeneratorConfig = None, state_dict: Optional[StateDict] = None,
+                 conv_mode: str = DEFAULT_CONV_MODE, **kwargs):
         super().__init__()
         if conv_mode not in ("h3", "f8", "f32"):
             raise RuntimeError(f"unknown conv_mode {conv_mode!r}")

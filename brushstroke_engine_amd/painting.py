@@ -36,6 +36,7 @@ from . import _lib
 from .sharding import halo_plan, shard_bounds
 
 CELL_H, CELL_W = 4, 64          # NB_CELL_H / NB_CELL_W of include/neube_hip.h
+PAINT_SLOT0 = 8                 # first generator workspace slot of the tiled schedule (TileOps._GRAPH_SLOT = 16 onwards: graphs)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -578,7 +579,9 @@ class PaintingHelper:
 
         on_stream = getattr(ops, "stream", lambda k: contextlib.nullcontext())      # (CPU stand-ins have no streams)
         join = getattr(ops, "join_streams", lambda tensors=(): None)
-        plan_slot = lambda k: 1 + k % getattr(ops, "n_streams", 1)
+        # workspace slots of the painting schedule: disjoint from the generator's own sub-batch slots (1..sub_streams), whose
+        # side-stream kernels of an un-joined throughput call may still be reading theirs
+        plan_slot = lambda k: PAINT_SLOT0 + k % getattr(ops, "n_streams", 1)
         if n_own <= self.batch:                      # a single batch (interactive strokes): nothing to overlap with
             on_stream, join, plan_slot = (lambda k: contextlib.nullcontext()), (lambda tensors=(): None), (lambda k: 0)
         user_dev = None if user is None else user.to(ops.device)

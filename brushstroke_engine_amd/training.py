@@ -72,14 +72,25 @@ class TrainableGenerator(torch.nn.Module):
         return ops.bias_act(x.matmul(w.t()).contiguous(), b.contiguous(), act=activation)
 
     # -- MappingNetwork.forward, networks.py:255-290 (c_dim == 0, no truncation) --
-    def mapping(self, z, c=None, truncation_psi=1, truncation_cutoff=None):
-        if truncation_psi != 1:
-            raise RuntimeError("TrainableGenerator: truncation is an inference feature (use networks.Generator)")
+    w_avg_beta = 0.995                                  # MappingNetwork default, networks.py:227
+
+    def mapping(self, z, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
         x = z.to(torch.float32)
         x = x * (x.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
         for i in range(self.cfg.mapping_layers):
             x = self._fc(x, f"mapping.fc{i}", "lrelu", self.cfg.mapping_lr_multiplier)
-        return x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:      # networks.py:274-276
+            with torch.no_grad():
+                w_avg = self.p("mapping.w_avg")
+                w_avg.copy_(x.detach().mean(dim=0).lerp(w_avg, self.w_avg_beta))
+        x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:                                                          # networks.py:283-289
+            w_avg = self.p("mapping.w_avg")
+            if truncation_cutoff is None:
+                x = w_avg.lerp(x, truncation_psi)
+            else:
+                x = torch.cat([w_avg.lerp(x[:, :truncation_cutoff], truncation_psi), x[:, truncation_cutoff:]], dim=1)
+        return x
 
     # -- SynthesisLayer.forward, networks.py:362-391 --
     def _layer(self, spec, x, w, norm_pos, noise_mode):
@@ -116,7 +127,9 @@ class TrainableGenerator(torch.nn.Module):
         return img, {"colors": colors, "uvs": uvs}
 
     # -- SynthesisNetwork.forward, networks_modified.py:123-223 ('orig' architecture, triad colours) --
-    def synthesis(self, ws, geom_feature, norm_noise_positions=None, noise_mode="const", return_debug_data=False):
+    def synthesis(self, ws, geom_feature, norm_noise_positions=None, noise_mode="random", return_debug_data=False):
+        """``noise_mode`` defaults to 'random' like ``SynthesisLayer.forward`` (networks.py:362): training draws fresh
+        per-layer noise every step; 'const' is what inference (and the golden-vector tests) pass explicitly."""
         cfg = self.cfg
         ws = ws.to(torch.float32)
         n = ws.shape[0]
@@ -141,8 +154,16 @@ class TrainableGenerator(torch.nn.Module):
                 geo_idx += 1
         return (img, triad) if return_debug_data else img
 
-    def forward(self, z, c, geom_feature, positions=None, noise_mode="const", return_debug_data=False):
-        ws = self.mapping(z, c)
+    def forward(self, z, c, geom_feature, positions=None, noise_mode="random", return_debug_data=False,
+                truncation_psi=1, truncation_cutoff=None, style_mixing_prob=0):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        if style_mixing_prob > 0:                                          # networks_modified.py:385-394
+            cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
+            cutoff = torch.where(torch.rand([], device=ws.device) < style_mixing_prob, cutoff, torch.full_like(cutoff, ws.shape[1]))
+            ws2 = self.mapping(torch.randn_like(z), c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff,
+                               skip_w_avg_update=True)
+            sel = (torch.arange(ws.shape[1], device=ws.device) >= cutoff)[None, :, None]
+            ws = torch.where(sel, ws2, ws)
         norm_pos = None
         if positions is not None:                                          # networks_modified.py:351-353
             norm_pos = (positions % self.img_resolution).to(torch.float32) / (self.img_resolution - 1)
@@ -271,16 +292,30 @@ class GanLoss:
     """The adversarial phases of ``ForgerLoss.accumulate_gradients`` (loss_modified.py:140-272): non-saturating logistic
     losses for G and D, the R1 penalty on real images and the path-length regulariser of G (second-order gradient of
     the modulated convolution).  ``phase`` in {'Gmain', 'Greg', 'Dmain', 'Dreg', 'Dall'}; gradients are accumulated into
-    the parameters' ``.grad`` like the reference does.  Not ported: the forger geometry / stitching losses and the ADA
-    augmentation pipeline."""
+    the parameters' ``.grad`` like the reference does.  The generator runs with fresh random per-layer noise and
+    ``style_mixing_prob`` like ``ForgerLoss.run_G`` (loss_modified.py:72-100); ``noise_mode='const'`` is for tests that
+    need a deterministic forward.  Each phase switches ``requires_grad`` off on the network it does not optimise, the
+    way the reference loop brackets a phase (training_loop_modified.py: ``phase.module.requires_grad_(True)`` ...
+    ``requires_grad_(False)``), so a G phase runs none of D's weight-gradient kernels (and DDP reduces none).
+    ``augment_pipe`` = the ADA pipeline (:mod:`augment`).  Not ported: the forger geometry / stitching loss items."""
 
     def __init__(self, G: TrainableGenerator, D: TrainableDiscriminator, r1_gamma: float = 10.0, pl_batch_shrink: int = 2,
-                 pl_decay: float = 0.01, pl_weight: float = 2.0, augment_pipe=None):
-        self.G, self.r1_gamma = G, r1_gamma
+                 pl_decay: float = 0.01, pl_weight: float = 2.0, augment_pipe=None, style_mixing_prob: float = 0.9,
+                 noise_mode: str = "random"):
+        self._G, self.r1_gamma = G, r1_gamma
         self._D, self.augment_pipe = D, augment_pipe
+        self.style_mixing_prob, self.noise_mode = style_mixing_prob, noise_mode
         self.real_sign_sum, self.real_sign_count = 0.0, 0          # 'Loss/signs/real': what ADA adapts p on
         self.pl_batch_shrink, self.pl_decay, self.pl_weight = pl_batch_shrink, pl_decay, pl_weight
         self.pl_mean = torch.zeros([], device=next(G.parameters()).device)
+
+    def G(self, z, c, geom_feature, **kw):
+        """``ForgerLoss.run_G``: random noise (the layers' default) + style mixing."""
+        return self._G(z, c, geom_feature, noise_mode=self.noise_mode, style_mixing_prob=self.style_mixing_prob, **kw)
+
+    @staticmethod
+    def _unwrap(m):
+        return getattr(m, "module", m)                                     # DistributedDataParallel wraps the network
 
     def D(self, img, c=None):
         """``ForgerLoss.run_D`` (loss_modified.py:102-107): the discriminator sees augmented images."""
@@ -301,6 +336,16 @@ class GanLoss:
     def accumulate_gradients(self, phase: str, real_img, geom_feature, gen_z, gain: float = 1.0, positions=None,
                              pl_noise=None) -> Dict[str, float]:
         assert phase in ("Gmain", "Greg", "Dmain", "Dreg", "Dall")
+        g_phase = phase in ("Gmain", "Greg")
+        self._unwrap(self._G).requires_grad_(g_phase)
+        self._unwrap(self._D).requires_grad_(not g_phase)
+        try:
+            return self._accumulate(phase, real_img, geom_feature, gen_z, gain, positions, pl_noise)
+        finally:
+            self._unwrap(self._G).requires_grad_(True)
+            self._unwrap(self._D).requires_grad_(True)
+
+    def _accumulate(self, phase, real_img, geom_feature, gen_z, gain, positions, pl_noise) -> Dict[str, float]:
         stats: Dict[str, float] = {}
         softplus = torch.nn.functional.softplus
         if phase == "Greg" and self.pl_weight != 0:                       # path-length regularisation, loss_modified.py:205-221

@@ -25,7 +25,7 @@ def main():
     geom = [g.astype(np.float32) for g in synthetic.geom_features(cfg, n, 7)]
     target = np.random.RandomState(1).randn(n, 3, 32, 32).astype(np.float32)
     a, b = rank * n // world, (rank + 1) * n // world          # this rank's shard of the batch
-    img = ddp(torch.from_numpy(z[a:b]).to(dev), None, [torch.from_numpy(g[a:b]).to(dev) for g in geom])
+    img = ddp(torch.from_numpy(z[a:b]).to(dev), None, [torch.from_numpy(g[a:b]).to(dev) for g in geom], noise_mode="const")
     loss = (img - torch.from_numpy(target[a:b]).to(dev)).square().mean()
     loss.backward()
     if rank == 0:

@@ -301,6 +301,7 @@ def test_baseline_batch32_r256_golden(dev, mode):
     pos = D(synthetic.positions(cfg, n, seed=int(g["pos_seed"])), dev)
     img, dbg = G(z, None, geom, positions=pos, return_debug_data=True, noise_mode="const")
     tol = PIX[mode]
+    assert G.synthesis.conv_mode == mode
     assert err(dbg["colors"], g["colors"]) <= 1e-5
     assert err(dbg["uvs"][:, :, 85, :], g["uvs.row"]) <= tol and err(img[:, :, 170, :], g["img.row"]) <= tol
     assert err(dbg["uvs"][:, :, ::32, ::32], g["uvs.sub"]) <= tol
@@ -308,8 +309,8 @@ def test_baseline_batch32_r256_golden(dev, mode):
         t64 = t.double()
         s1, s2 = t64.sum(dim=(2, 3)).cpu().numpy(), (t64 * t64).sum(dim=(2, 3)).cpu().numpy()
         # a checksum over 65 536 pixels: errors of +-tol add up at worst linearly; observed: random-walk level
-        assert np.abs(s1 - g[f"{name}.sum"]).max() <= 65536 * tol * 0.02, name
-        assert np.abs(s2 - g[f"{name}.sumsq"]).max() <= 65536 * tol * 0.04, name
+        assert np.abs(s1 - g[f"{name}.sum"]).max() <= 65536 * tol * 0.05, name      # i.e. a mean pixel error <= 5 % of the tolerance
+        assert np.abs(s2 - g[f"{name}.sumsq"]).max() <= 65536 * tol * 0.1, name
     # the same batch through the fused compositing entry the benchmark times
     u8, rgba, dbg2 = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
     assert torch.equal(dbg2["uvs"], dbg["uvs"])

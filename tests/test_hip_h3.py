@@ -161,7 +161,7 @@ def test_generator_h2_handoff_equals_pack_path():
     from brushstroke_engine_amd import config as cfgmod, weights as wmod
     from brushstroke_engine_amd.networks import Generator
     cfg = cfgmod.style1_config(256)
-    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0)).to("cuda")
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode="h3").to("cuda")
     from brushstroke_engine_amd import synthetic
     n = 4
     z = torch.from_numpy(synthetic.batch_z(cfg, n)).cuda()
@@ -185,7 +185,7 @@ def test_fused_torgb_equals_standalone(res):
     from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
     from brushstroke_engine_amd.networks import Generator
     cfg = cfgmod.style1_config(res)
-    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0)).to("cuda")
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode="h3").to("cuda")
     n = 5
     z = torch.from_numpy(synthetic.batch_z(cfg, n)).cuda()
     gf = [torch.from_numpy(a).cuda() for a in synthetic.geom_features(cfg, n, seed=1)]

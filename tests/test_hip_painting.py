@@ -19,7 +19,7 @@ def eng():
     esd = encmod.random_encoder_state_dict(5)
     z = np.random.RandomState(594).randn(1, cfg.z_dim)
     from brushstroke_engine_amd.networks import Generator
-    G = Generator(cfg, sd).to("cuda")
+    G = Generator(cfg, sd, conv_mode="h3").to("cuda")
     enc = encmod.HipGeometryEncoder(esd)
     return dict(g=g, cfg=cfg, sd=sd, esd=esd, z=z, ops=painting.TileOps(G, enc), G=G)
 
