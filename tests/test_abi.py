@@ -60,7 +60,27 @@ def test_pack_conv_weight_host_helper(library):
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No library and no compiler: every product-path op raises (there is no CPU fallback)."""
+    from brushstroke_engine_amd import build
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(build, "LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(build, "STAMP", str(tmp_path / "nope.so.stamp"))
+    monkeypatch.setattr(build, "HIPCC", str(tmp_path / "no-hipcc"))
     with pytest.raises(_lib.NeubeHipError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_stale_library_is_detected(monkeypatch, tmp_path):
+    """A library built from other sources than the tree holds (a kernel edit without a rebuild) is not loaded silently:
+    the content digest in the stamp file no longer matches."""
+    from brushstroke_engine_amd import build
+    assert not build.is_stale()                                   # conftest / build() left a current library
+    stamp = tmp_path / "stamp"
+    stamp.write_text("0" * 64 + "\n")
+    monkeypatch.setattr(build, "STAMP", str(stamp))
+    assert build.is_stale()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("NEUBE_NO_AUTOBUILD", "1")
+    with pytest.raises(_lib.NeubeHipError, match="built from different sources"):
         _lib.lib()

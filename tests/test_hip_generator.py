@@ -167,12 +167,13 @@ def test_batch_vs_oracle_and_engine_composite(dev, mode):
         G.render_triad(z=D(z, dev), geom_feature=[D(x, dev) for x in geom], render_mode="bogus")
 
 
-def test_linearity_and_determinism_full_size(dev):
+@pytest.mark.parametrize("mode", MODES)
+def test_linearity_and_determinism_full_size(dev, mode):
     """Size-independent properties at the BASELINE size (R=256, batch 32): bitwise run-to-run
     determinism, batch-composition independence (sample i does not depend on its batch mates)."""
     from brushstroke_engine_amd import config as cfgmod, synthetic
     cfg = cfgmod.style1_config(256)
-    G, _ = build(cfg, 0, dev)
+    G, _ = build(cfg, 0, dev, mode)
     n = 32
     z = D(synthetic.batch_z(cfg, n, 0), dev)
     geom = [D(x, dev) for x in synthetic.geom_features(cfg, n, seed=1)]
@@ -185,9 +186,10 @@ def test_linearity_and_determinism_full_size(dev):
     assert float((s - 1).abs().max()) <= 1e-5                     # softmax over u,v,s
     idx = [5, 17, 31]
     # a sub-batch may run other kernel variants (tile shapes / split-K are chosen by problem size), i.e. another
-    # summation order: equal to fp32 rounding, not bitwise
+    # summation order (and, below the large-tile kernels' batch threshold, fp32 kernels for some layers): equal within the
+    # mode's distance from fp32, not bitwise
     c = G(z[idx], None, [x[idx] for x in geom], positions=pos[idx], noise_mode="const")
-    assert err(c, a[idx]) <= 2e-5
+    assert err(c, a[idx]) <= {"h3": 2e-5, "f8": 3e-4}[mode]
 
 
 @pytest.mark.parametrize("mode,res", [("h3", 64), ("f8", 64), ("f8", 256), ("h3", 256)])
