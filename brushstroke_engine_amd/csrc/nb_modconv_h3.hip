@@ -828,11 +828,15 @@ struct H3Up2Params {
 
 // TQH = quad rows per tile: NB_H3_TQH (12) for throughput; 5 (7 x 34 = 238 positions = 8 column blocks, one per wave)
 // when the large tiles would leave most of the chip idle - the batch-1 / interactive configuration.
-template <bool F8, int TQH>
-__global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
+// NW_ = waves per workgroup: 8 (two per SIMD, <= 256 registers each) or 4 (one per SIMD with the whole 512-entry register
+// file: 4 position blocks x 4 phases = 256 accumulators per wave, the shared weight fragments are read once per 4 blocks
+// instead of once per 2, and a wave has room to keep the next tap group's fragments in flight under the current MFMAs)
+// OUTM = output mode: 0 = fp32 NCHW, 1 = the consumer's H2 tensor, 2 = the consumer's tensor in the "f8" operand format
+template <bool F8, int TQH, int NW_ = 8, int OUTM = 0>
+__global__ __launch_bounds__(NW_ * 64) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
-    constexpr int NW = 8, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
+    constexpr int NW = NW_, NT = NW_ * 64, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
     constexpr int NBJ = (NBLK + NW - 1) / NW;         // blocks per wave (2)
     constexpr int XR = TQH + 3, XS = TQW + 3;         // halo tile 15 x 35 input pixels
@@ -870,7 +874,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
         s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
-    for (int e = tid; e < 2 * TQH * 2 * TQW; e += 512) {
+    for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
         const int r = e / (2 * TQW), c = e - r * (2 * TQW);
         const int oy = 2 * I0 + r, ox = 2 * J0 + c;
         s_noise[e] = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
@@ -951,6 +955,123 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int kPha[9] = {3, 2, 1, 0, 2, 0, 1, 0, 0};                 // kTapPhase[kOrd[i]]
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
+    if constexpr (F8 && NW == 4) {
+        // ---- one wave per SIMD: software-pipelined K loop -------------------------------------------------------
+        // A wave carries 4 position blocks x 4 phases (256 accumulators) and owns its SIMD's matrix pipe, so the LDS
+        // and DMA-issue latencies have to be covered inside the wave.  The matrix instructions are volatile asm
+        // statements with a memory clobber, i.e. the program order below IS the issue order: fragment reads for a
+        // later stage and the next chunk's LDS-DMA issues sit in the shadows of the 64-cycle fp8 instructions.
+        // Same products in the same order per accumulator as the 8-wave form (bit-identical results):
+        //   P0a: ph0 += A8 B0 + A6 B1 + f8(A8,A6 | B0,B1)     P2: ph2 += A5 B0 + A3 B1 + f8(..)     P3: ph3 += A4 B0 + f8(A4,0 | B0,.)
+        //   P1:  ph1 += A7 B0 + A1 BX + f8(A7,A1 | B0,BX)     P0b: ph0 += A2 BX + A0 BY + f8(A2,A0 | BX,BY)    (BX = offset XS, BY = XS+1)
+        // fp8 operand tuples are 8 consecutive registers: the low halves are kept as [B0 B1] and [B0' BX BY] (B0 is read
+        // twice) so that every pair is adjacent without register moves and no stage reloads a register another stage reads.
+        typedef int i32x12 __attribute__((ext_vector_type(12)));
+        const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
+        h8 bh0[NBJ], bh1[NBJ], bhx[NBJ];      // bh1: offset 1, from stage 2 on offset XS + 1
+        i32x8 bl01[NBJ];
+        i32x12 blx[NBJ];                              // [B0' | BX | BY]
+        h8 a8h, a6h, a5h, a3h, a4h, a7h, a1h, a2h, a0h;
+        i32x8 a86l, a53l, a4l, a71l, a20l;
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 12; ++r) blx[j][r] = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a4l[r] = 0;
+        // builtins + a scheduling fence after every statement group: the compiler keeps this order and counts the LDS reads
+#define NB_SB __builtin_amdgcn_sched_barrier(0)
+#define NB_M16(c_, a_, b_) { c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0); NB_SB; }
+#define NB_MF8(c_, a_, b_) { c_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c_, 0, 0, 0, sa, 0, sb); NB_SB; }
+#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
+#define NB_LDA2(st_, tA, tB, hA, hB, l2) { hA = st_[aoff + (tA) * 128]; hB = st_[aoff + (tB) * 128]; NB_Q(l2, 0, st_[aoff + (tA) * 128 + 32]); NB_Q(l2, 1, st_[aoff + (tB) * 128 + 32]); NB_SB; }
+        auto issue_x1 = [&](int c, h8* st_, int i) {
+            // (branch-free source select: the loop body must stay one basic block)
+            const int cg = 2 * c + (xpl[i] >> 1);
+            const unsigned long long a_ = (unsigned long long)(xn + (size_t)(4 * c + xpl[i]) * HW8 + xsp[i]);
+            const unsigned long long z_ = (unsigned long long)p.zeros;
+            const unsigned long long m_ = 0ull - (unsigned long long)(xsp[i] >= 0 && cg < p.c8);
+            const _Float16* src = reinterpret_cast<const _Float16*>((a_ & m_) | (z_ & ~m_));
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st_ + xdst[i]), 16, 0, 0);
+            NB_SB;
+        };
+        auto issue_w1 = [&](int c, h8* st_, int i) {
+            int q = i * NW + wv;
+            q = q < NWP ? q : NWP - 1;
+            const int e = q * 64 + lane;
+            const int row = e >> 5, j = e & 31;
+            const _Float16* src = p.wts + (((size_t)c * 36 + row) * p.co_ld + co0 + j) * 8;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st_ + 4 * XPL + q * 64), 16, 0, 0);
+            NB_SB;
+        };
+        static_assert(NXPW == 9 && NWPW == 5 && NBJ == 4, "the interleaving below is written for 9 + 5 DMA pieces and 4 blocks per wave");
+        auto rd_b01 = [&](const h8* st_, int j) {
+            bh0[j] = st_[boff[j]]; bh1[j] = st_[boff[j] + 1];
+            NB_Q(bl01[j], 0, st_[boff[j] + XPL]); NB_Q(bl01[j], 1, st_[boff[j] + XPL + 1]);
+            NB_SB;
+        };
+        NB_LDA2(ring, 8, 6, a8h, a6h, a86l);
+        rd_b01(ring, 0);
+        rd_b01(ring, 1);
+        for (int c = 0; c < NC; ++c) {
+            const h8* st = ring + (c & 1) * STAGE;
+            h8* nst = ring + ((c + 1) & 1) * STAGE;
+            const int cn = c + 1 < NC ? c + 1 : NC - 1;       // (last chunk: a harmless re-copy keeps the loop body branch-free)
+            // ---- stage 0: P0a; reads of blocks 1..3 for this stage, then A5 A3 A4 and BX for the later ones; x pieces 0..4
+            NB_M16(acc[0][0], a8h, bh0[0]); rd_b01(st, 2); NB_M16(acc[0][0], a6h, bh1[0]); NB_MF8(acc[0][0], a86l, bl01[0]);
+            issue_x1(cn, nst, 0);
+            NB_M16(acc[1][0], a8h, bh0[1]); rd_b01(st, 3); NB_M16(acc[1][0], a6h, bh1[1]); NB_MF8(acc[1][0], a86l, bl01[1]);
+            issue_x1(cn, nst, 1);
+            NB_M16(acc[2][0], a8h, bh0[2]); NB_M16(acc[2][0], a6h, bh1[2]); NB_MF8(acc[2][0], a86l, bl01[2]);
+            NB_LDA2(st, 5, 3, a5h, a3h, a53l); issue_x1(cn, nst, 2);
+            NB_M16(acc[3][0], a8h, bh0[3]); NB_M16(acc[3][0], a6h, bh1[3]); NB_MF8(acc[3][0], a86l, bl01[3]);
+            a4h = st[aoff + 4 * 128]; NB_Q(a4l, 0, st[aoff + 4 * 128 + 32]); issue_x1(cn, nst, 3);
+            // ---- stage 1: P2, P3; reads B0' BX (then BY) and A7 A1; x pieces 4..8
+            NB_M16(acc[0][2], a5h, bh0[0]); NB_M16(acc[0][2], a3h, bh1[0]); NB_MF8(acc[0][2], a53l, bl01[0]);
+            NB_Q(blx[0], 0, st[boff[0] + XPL]); bhx[0] = st[boff[0] + XS]; NB_Q(blx[0], 1, st[boff[0] + XPL + XS]); issue_x1(cn, nst, 4);
+            NB_M16(acc[1][2], a5h, bh0[1]); NB_M16(acc[1][2], a3h, bh1[1]); NB_MF8(acc[1][2], a53l, bl01[1]);
+            NB_Q(blx[1], 0, st[boff[1] + XPL]); bhx[1] = st[boff[1] + XS]; NB_Q(blx[1], 1, st[boff[1] + XPL + XS]); issue_x1(cn, nst, 5);
+            NB_M16(acc[2][2], a5h, bh0[2]); NB_M16(acc[2][2], a3h, bh1[2]); NB_MF8(acc[2][2], a53l, bl01[2]);
+            NB_Q(blx[2], 0, st[boff[2] + XPL]); bhx[2] = st[boff[2] + XS]; NB_Q(blx[2], 1, st[boff[2] + XPL + XS]); issue_x1(cn, nst, 6);
+            NB_M16(acc[3][2], a5h, bh0[3]); NB_M16(acc[3][2], a3h, bh1[3]); NB_MF8(acc[3][2], a53l, bl01[3]);
+            NB_Q(blx[3], 0, st[boff[3] + XPL]); bhx[3] = st[boff[3] + XS]; NB_Q(blx[3], 1, st[boff[3] + XPL + XS]); issue_x1(cn, nst, 7);
+            NB_M16(acc[0][3], a4h, bh0[0]); NB_MF8(acc[0][3], a4l, bl01[0]);
+            NB_LDA2(st, 7, 1, a7h, a1h, a71l); issue_x1(cn, nst, 8);
+            NB_M16(acc[1][3], a4h, bh0[1]); NB_MF8(acc[1][3], a4l, bl01[1]);
+            bh1[0] = st[boff[0] + XS + 1]; NB_Q(blx[0], 2, st[boff[0] + XPL + XS + 1]); issue_w1(cn, nst, 0);
+            NB_M16(acc[2][3], a4h, bh0[2]); NB_MF8(acc[2][3], a4l, bl01[2]);
+            bh1[1] = st[boff[1] + XS + 1]; NB_Q(blx[1], 2, st[boff[1] + XPL + XS + 1]); issue_w1(cn, nst, 1);
+            NB_M16(acc[3][3], a4h, bh0[3]); NB_MF8(acc[3][3], a4l, bl01[3]);
+            bh1[2] = st[boff[2] + XS + 1]; NB_Q(blx[2], 2, st[boff[2] + XPL + XS + 1]); issue_w1(cn, nst, 2);
+            // ---- stage 2: P1; reads A2 A0; w pieces 3, 4
+            NB_M16(acc[0][1], a7h, bh0[0]); NB_M16(acc[0][1], a1h, bhx[0]);
+            NB_MF8(acc[0][1], a71l, __builtin_shufflevector(blx[0], blx[0], 0, 1, 2, 3, 4, 5, 6, 7));
+            bh1[3] = st[boff[3] + XS + 1]; NB_Q(blx[3], 2, st[boff[3] + XPL + XS + 1]); issue_w1(cn, nst, 3);
+            NB_M16(acc[1][1], a7h, bh0[1]); NB_M16(acc[1][1], a1h, bhx[1]);
+            NB_MF8(acc[1][1], a71l, __builtin_shufflevector(blx[1], blx[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            NB_LDA2(st, 2, 0, a2h, a0h, a20l); issue_w1(cn, nst, 4);
+            NB_M16(acc[2][1], a7h, bh0[2]); NB_M16(acc[2][1], a1h, bhx[2]);
+            NB_MF8(acc[2][1], a71l, __builtin_shufflevector(blx[2], blx[2], 0, 1, 2, 3, 4, 5, 6, 7));
+            NB_M16(acc[3][1], a7h, bh0[3]); NB_M16(acc[3][1], a1h, bhx[3]);
+            NB_MF8(acc[3][1], a71l, __builtin_shufflevector(blx[3], blx[3], 0, 1, 2, 3, 4, 5, 6, 7));
+            // ---- stage 3: P0b, then the chunk hand-over (chunk c+1 has landed everywhere; its first fragments)
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) {
+                NB_M16(acc[j][0], a2h, bhx[j]); NB_M16(acc[j][0], a0h, bh1[j]);
+                NB_MF8(acc[j][0], a20l, __builtin_shufflevector(blx[j], blx[j], 4, 5, 6, 7, 8, 9, 10, 11));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            NB_LDA2(nst, 8, 6, a8h, a6h, a86l);
+            rd_b01(nst, 0);
+            rd_b01(nst, 1);
+        }
+#undef NB_Q
+#undef NB_LDA2
+#undef NB_M16
+#undef NB_MF8
+#undef NB_SB
+    } else
     for (int c = 0; c < NC; ++c) {
         h8* st = ring + (c % NST) * STAGE;
         if (NST == 3) {
@@ -1080,18 +1201,20 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_w += t_ - te0; te0 = t_; }
         // FIR + activation: one item = one channel x one row of quads x 2 adjacent quads (2 x 4 output pixels).
         // Column pairs are evaluated with packed fp32 math; the expressions keep the operand order of the reference
-        // polyphase form  0.25 a + 0.75 b + 0.75 c + 0.25 d  (left to right).
-        for (int it = tid; it < RPR * 2 * TQH * (TQW / 2); it += 512) {
+        // polyphase form  0.25 a + 0.75 b + 0.75 c + 0.25 d  (left to right) and the operation order of nb_h3_epilogue.
+        // The output mode is a template parameter (no uniform branches in the item) and a thread's items of a round are
+        // unrolled, so that one item's LDS reads are in flight under another's arithmetic.
+        auto fir_item = [&](const int it) {
             // lanes walk the quad pairs of one channel (conflict-free phase reads); the H2 / f8 results are staged
             // channel-planar so that the lane's 4 consecutive pixels go out as one 8- / 4-byte LDS write
             const int p2 = it % (TQW / 2);
             const int rr_ = it / (TQW / 2);
-            const int ti = rr_ % TQH, s = rr_ / TQH;
+            const int ti = rr_ % TQH, s_ = rr_ / TQH;
             const int tj = 2 * p2;
-            const int rho = round * RPR + (s >> 1);
-            const int col = (rho & 3) + 8 * (rho >> 2) + 4 * (s & 1);
+            const int rho = round * RPR + (s_ >> 1);
+            const int col = (rho & 3) + 8 * (rho >> 2) + 4 * (s_ & 1);
             const int co = co0 + col;
-            const float* ee = y1s + s * Y1_SLOT + ti * PW + tj;
+            const float* ee = y1s + s_ * Y1_SLOT + ti * PW + tj;
             const float* eo = ee + 1 * Y1_PHASE;
             const float* oe = ee + 2 * Y1_PHASE;
             const float* oo = ee + 3 * Y1_PHASE;
@@ -1104,30 +1227,40 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 q75 = 0.75f; q25 = 0.25f;
                 return __builtin_elementwise_fma(q25, d, __builtin_elementwise_fma(q75, c, __builtin_elementwise_fma(q75, b, 0.25f * a)));
             };
-            auto fv0 = [&](auto o0, auto e0, auto o1, auto e1) { return fir4(o0, e0, o1, e1); };
-            auto fv1 = [&](auto e0, auto o1, auto e1, auto o2) { return fir4(e0, o1, e1, o2); };
             // even output columns come from (ee, oe) at quad columns tj..tj+2, odd ones from (eo, oo) at tj..tj+3
             const f32x2 eeA0 = ld2(ee), eeA1 = ld2(ee + PW), oeA0 = ld2(oe), oeA1 = ld2(oe + PW), oeA2 = ld2(oe + 2 * PW);
             const float eeB0 = ee[2], eeB1 = ee[PW + 2], oeB0 = oe[2], oeB1 = oe[PW + 2], oeB2 = oe[2 * PW + 2];
             const f32x2 eoA0 = ld2(eo), eoA1 = ld2(eo + PW), ooA0 = ld2(oo), ooA1 = ld2(oo + PW), ooA2 = ld2(oo + 2 * PW);
             const f32x2 eoC0 = ld2(eo + 2), eoC1 = ld2(eo + PW + 2), ooC0 = ld2(oo + 2), ooC1 = ld2(oo + PW + 2), ooC2 = ld2(oo + 2 * PW + 2);
-            const f32x2 ve0A = fv0(oeA0, eeA0, oeA1, eeA1), ve1A = fv1(eeA0, oeA1, eeA1, oeA2);
-            const float ve0B = fv0(oeB0, eeB0, oeB1, eeB1), ve1B = fv1(eeB0, oeB1, eeB1, oeB2);
-            const f32x2 vo0A = fv0(ooA0, eoA0, ooA1, eoA1), vo1A = fv1(eoA0, ooA1, eoA1, ooA2);
-            const f32x2 vo0C = fv0(ooC0, eoC0, ooC1, eoC1), vo1C = fv1(eoC0, ooC1, eoC1, ooC2);
-            const float ve[2][3] = {{ve0A[0], ve0A[1], ve0B}, {ve1A[0], ve1A[1], ve1B}};
-            const float vo[2][4] = {{vo0A[0], vo0A[1], vo0C[0], vo0C[1]}, {vo1A[0], vo1A[1], vo1C[0], vo1C[1]}};
-            float out[2][4];
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    out[dy][2 * q] = fir4(vo[dy][q], ve[dy][q], vo[dy][q + 1], ve[dy][q + 1]);
-                    out[dy][2 * q + 1] = fir4(ve[dy][q], vo[dy][q + 1], ve[dy][q + 1], vo[dy][q + 2]);
-                }
+            const f32x2 ve0A = fir4(oeA0, eeA0, oeA1, eeA1), ve1A = fir4(eeA0, oeA1, eeA1, oeA2);
+            const float ve0B = fir4(oeB0, eeB0, oeB1, eeB1), ve1B = fir4(eeB0, oeB1, eeB1, oeB2);
+            const f32x2 vo0A = fir4(ooA0, eoA0, ooA1, eoA1), vo1A = fir4(eoA0, ooA1, eoA1, ooA2);
+            const f32x2 vo0C = fir4(ooC0, eoC0, ooC1, eoC1), vo1C = fir4(eoC0, ooC1, eoC1, ooC2);
+            // horizontal pass, packed over the two quads (q = 0, 1):  even pixel = fir4(vo[q], ve[q], vo[q+1], ve[q+1]),
+            //                                                          odd pixel  = fir4(ve[q], vo[q+1], ve[q+1], vo[q+2])
+            const f32x2 veS0 = {ve0A[1], ve0B}, veS1 = {ve1A[1], ve1B};                 // ve[q+1]
+            const f32x2 voS0 = {vo0A[1], vo0C[0]}, voS1 = {vo1A[1], vo1C[0]};           // vo[q+1]
+            const f32x2 ev0 = fir4(vo0A, ve0A, voS0, veS0), od0 = fir4(ve0A, voS0, veS0, vo0C);   // row dy = 0: {q0, q1}
+            const f32x2 ev1 = fir4(vo1A, ve1A, voS1, veS1), od1 = fir4(ve1A, voS1, veS1, vo1C);   // row dy = 1
+            // pixel order within the row: (q0 even, q0 odd, q1 even, q1 odd)
+            const f32x2 oa[2] = {f32x2{ev0[0], od0[0]}, f32x2{ev1[0], od1[0]}};
+            const f32x2 ob2[2] = {f32x2{ev0[1], od0[1]}, f32x2{ev1[1], od1[1]}};
             const int qi = I0 + ti, qj = J0 + tj;
             const float d = s_dco[col], bs = s_bias[col];
-            if (p.yh2) {
+            // *d, +noise, +bias, lrelu, *gain, clamp -- the operation order of nb_h3_epilogue, two pixels per instruction
+            auto act2 = [&](f32x2 o, f32x2 nz) {
+                f32x2 t = o * d;
+                t = t + nz;
+                t = t + bs;
+                const f32x2 ta = t * p.alpha;
+                // lrelu = max(t, alpha t) for 0 <= alpha <= 1 (the launcher checks); med3 with +inf is a max without the NaN
+                // canonicalisation instructions fmaxf() costs
+                t[0] = __builtin_amdgcn_fmed3f(t[0], ta[0], __builtin_inff()); t[1] = __builtin_amdgcn_fmed3f(t[1], ta[1], __builtin_inff());
+                t = t * p.gain;
+                if (p.clamp >= 0.f) { t[0] = __builtin_amdgcn_fmed3f(t[0], -p.clamp, p.clamp); t[1] = __builtin_amdgcn_fmed3f(t[1], -p.clamp, p.clamp); }
+                return t;
+            };
+            if constexpr (OUTM != 0) {
                 // the round's 8 channels are exactly channel group co0/8 + round.  Staging (after the phase slots):
                 //   hi plane [ch 8][OPIX] f16 | H2: lo plane [ch 8][OPIX] f16 | f8: [16][OPIX] fp8(xl 2^9), [16][OPIX] fp8(v/4)
                 const float ns = s_nst[col];
@@ -1136,21 +1269,20 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 for (int dy = 0; dy < 2; ++dy) {
                     const int opix0 = (2 * ti + dy) * (2 * TQW) + 2 * tj;
                     const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + opix0);
-                    float vv[4], xl[4];
-                    h4 vh, vl;
-#pragma unroll
-                    for (int dx = 0; dx < 4; ++dx) {
-                        const float v = nb_h3_epilogue(out[dy][dx] * d + nz[dx], bs, p.alpha, p.gain, p.clamp) * ns;
-                        const _Float16 hi = (_Float16)v;
-                        vh[dx] = hi; vv[dx] = v; xl[dx] = v - (float)hi; vl[dx] = (_Float16)xl[dx];
-                    }
+                    const f32x2 v01 = act2(oa[dy], f32x2{nz[0], nz[1]}) * ns, v23 = act2(ob2[dy], f32x2{nz[2], nz[3]}) * ns;
+                    h4 vh;
+                    vh[0] = (_Float16)v01[0]; vh[1] = (_Float16)v01[1]; vh[2] = (_Float16)v23[0]; vh[3] = (_Float16)v23[1];
+                    const f32x2 xl01 = v01 - f32x2{(float)vh[0], (float)vh[1]}, xl23 = v23 - f32x2{(float)vh[2], (float)vh[3]};
                     *reinterpret_cast<h4*>(obuf + (size_t)ch * OPIX + opix0) = vh;
-                    if (!p.out_f8) {
+                    if constexpr (OUTM == 1) {
+                        h4 vl;
+                        vl[0] = (_Float16)xl01[0]; vl[1] = (_Float16)xl01[1]; vl[2] = (_Float16)xl23[0]; vl[3] = (_Float16)xl23[1];
                         *reinterpret_cast<h4*>(obuf + (size_t)(8 + ch) * OPIX + opix0) = vl;
                     } else if (!(p.dbg & 32)) {
                         unsigned char* ob = reinterpret_cast<unsigned char*>(obuf + (size_t)8 * OPIX) + (size_t)((round & 1) * 8 + ch) * OPIX + opix0;
-                        *reinterpret_cast<unsigned*>(ob) = nb_pk2_fp8<true>(xl[0] * 512.f, xl[1] * 512.f) | (nb_pk2_fp8<true>(xl[2] * 512.f, xl[3] * 512.f) << 16);
-                        *reinterpret_cast<unsigned*>(ob + (size_t)16 * OPIX) = nb_pk2_fp8<true>(vv[0] * 0.25f, vv[1] * 0.25f) | (nb_pk2_fp8<true>(vv[2] * 0.25f, vv[3] * 0.25f) << 16);
+                        const f32x2 s01 = xl01 * 512.f, s23 = xl23 * 512.f, q01 = v01 * 0.25f, q23 = v23 * 0.25f;
+                        *reinterpret_cast<unsigned*>(ob) = nb_pk2_fp8<true>(s01[0], s01[1]) | (nb_pk2_fp8<true>(s23[0], s23[1]) << 16);
+                        *reinterpret_cast<unsigned*>(ob + (size_t)16 * OPIX) = nb_pk2_fp8<true>(q01[0], q01[1]) | (nb_pk2_fp8<true>(q23[0], q23[1]) << 16);
                     }
                 }
             } else if (co < p.c_out && qi < H && !(p.dbg & 1)) {
@@ -1158,24 +1290,29 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 for (int dy = 0; dy < 2; ++dy) {
                     const int oy = 2 * qi + dy, ox = 2 * qj;
                     const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + (2 * ti + dy) * (2 * TQW) + 2 * tj);
-                    f32x4 o;
-#pragma unroll
-                    for (int dx = 0; dx < 4; ++dx) o[dx] = nb_h3_epilogue(out[dy][dx] * d + nz[dx], bs, p.alpha, p.gain, p.clamp);
-                    *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = o;
+                    const f32x2 v01 = act2(oa[dy], f32x2{nz[0], nz[1]}), v23 = act2(ob2[dy], f32x2{nz[2], nz[3]});
+                    *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = f32x4{v01[0], v01[1], v23[0], v23[1]};
                 }
             }
+        };
+        constexpr int NIT = RPR * 2 * TQH * (TQW / 2);
+        if constexpr (NIT % NT == 0) {
+#pragma unroll
+            for (int k = 0; k < NIT / NT; ++k) fir_item(tid + k * NT);
+        } else {
+            for (int it = tid; it < NIT; it += NT) fir_item(it);
         }
         __syncthreads();
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_f += t_ - te0; te0 = t_; }
-        if (p.yh2) {
+        if constexpr (OUTM != 0) {
             const int cg = co0 / 8 + round;
             if (cg * 8 < p.c_out && !(p.dbg & 1)) {
                 const size_t OHW8 = (size_t)Ho * Wo * 8;
                 _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
                 // planar staging -> 16-byte slots: a task transposes 4 consecutive pixels x 8 channels (f16) resp. x 16
                 // channels (fp8) in registers and stores the 4 slots (64 contiguous bytes per lane)
-                const int nf16 = p.out_f8 ? 1 : 2;                                  // f16 planes sets: hi (+ lo for H2)
-                for (int e = tid; e < nf16 * (OPIX / 4); e += 512) {
+                constexpr int nf16 = OUTM == 2 ? 1 : 2;                                  // f16 planes sets: hi (+ lo for H2)
+                for (int e = tid; e < nf16 * (OPIX / 4); e += NT) {
                     const int k = e / (OPIX / 4), t4 = e - k * (OPIX / 4);
                     const int opix = 4 * t4;
                     const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
@@ -1193,9 +1330,9 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                         }
                     }
                 }
-                if (p.out_f8 && (round & 1)) {
+                if (OUTM == 2 && (round & 1)) {
                     // the chunk's two lo slots: (cg-1, lo) = fp8(xl 2^9) of its 16 channels, (cg, lo) = fp8(v/4)
-                    for (int e = tid; e < 2 * (OPIX / 4); e += 512) {
+                    for (int e = tid; e < 2 * (OPIX / 4); e += NT) {
                         const int k = e / (OPIX / 4), t4 = e - k * (OPIX / 4);
                         const int opix = 4 * t4;
                         const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
@@ -1235,7 +1372,20 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
 static int g_force_tqh = -1;
 // developer / test hook: 0 = automatic tile choice, NB_H3_TQH or NB_H3_TQH_SMALL = force that tile height
 extern "C" void nb_debug_set_up2_tile(int tqh) { g_force_tqh = tqh; }
-template <int TQH>
+template <int TQH, int NW, bool F8, int OUTM>
+static int nb_up2_h3_launch1(const H3Up2Params& p, int n, size_t lds, void* stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<F8, TQH, NW, OUTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
+    hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<F8, TQH, NW, OUTM>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("modconv3x3_up2_h3");
+    return NB_OK;
+}
+
+template <int TQH, int NW = 8>
 static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
     p.tiles_y = (p.h + TQH - 1) / TQH;
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
@@ -1244,17 +1394,17 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
     constexpr size_t lds_stage = (size_t)(TQH == NB_H3_TQH_SMALL ? NB_H3_STAGES_SMALL : NB_H3_STAGES) * (4 * XPL + 36 * 32) * 16;
     constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * TQH * 32 * 16;   // FIR slots + H2 slots (hi, 2 x lo)
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<false, TQH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<true, TQH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
+    if constexpr (NW == 4) {          // the one-wave-per-SIMD form exists for the f8 operand format only
+        return outm == 2 ? nb_up2_h3_launch1<TQH, 4, true, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, 4, true, 1>(p, n, lds, stream)
+                                                                                            : nb_up2_h3_launch1<TQH, 4, true, 0>(p, n, lds, stream);
+    } else {
+        if (in_fmt)
+            return outm == 2 ? nb_up2_h3_launch1<TQH, 8, true, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, 8, true, 1>(p, n, lds, stream)
+                                                                                                : nb_up2_h3_launch1<TQH, 8, true, 0>(p, n, lds, stream);
+        return outm == 2 ? nb_up2_h3_launch1<TQH, 8, false, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, 8, false, 1>(p, n, lds, stream)
+                                                                                             : nb_up2_h3_launch1<TQH, 8, false, 0>(p, n, lds, stream);
     }
-    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    if (in_fmt) hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<true, TQH>), grid, dim3(512), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<false, TQH>), grid, dim3(512), lds, (hipStream_t)stream, p);
-    NB_CHECK_LAUNCH("modconv3x3_up2_h3");
-    return NB_OK;
 }
 
 static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
@@ -1269,6 +1419,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
                "modconv3x3_up2_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up2_h3: bad sizes");
     NB_REQUIRE(w % 32 == 0 && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0 (got %dx%d)", h, w);
+    NB_REQUIRE(alpha >= 0.f && alpha <= 1.f, "modconv3x3_up2_h3: leaky-ReLU slope must lie in [0, 1] (got %g)", alpha);
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up2_h3: pointers must be 16-byte aligned");
     H3Up2Params p;
     p.x = (const _Float16*)x_h2; p.wts = (const _Float16*)w_h3; p.dcoefs = dcoefs; p.noise = noise; p.bias = bias; p.y = y;
@@ -1287,6 +1438,8 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
     const long wgs_big = (long)n * p.tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * p.slices;
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
+    static const int env_nw = getenv("NB_UP2_NW") ? atoi(getenv("NB_UP2_NW")) : 8;
+    if (!small_tiles && env_nw == 4 && in_fmt == 1) return nb_up2_h3_launch<NB_H3_TQH, 4>(p, n, in_fmt, stream);
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }
 

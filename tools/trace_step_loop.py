@@ -7,7 +7,9 @@ from brushstroke_engine_amd.networks import Generator
 dev = torch.device("cuda:0")
 cfg = cfgmod.style1_config(256)
 G = Generator(cfg, wmod.random_state_dict(cfg, 0), conv_mode=os.environ.get("NB_MODE", "f8")).to(dev)
-B = 32
+B = int(os.environ.get("NB_B", "32"))
+if os.environ.get("NB_SUB"):
+    G.sub_streams = int(os.environ["NB_SUB"])
 if os.environ.get("NB_H3_MIN_PIX"):
     G.synthesis.h3_min_pixels = int(os.environ["NB_H3_MIN_PIX"])
 z = torch.from_numpy(synthetic.batch_z(cfg, B, 0)).to(dev)
