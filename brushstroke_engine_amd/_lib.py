@@ -128,7 +128,10 @@ def lib() -> C.CDLL:
         if _lib is not None:
             return _lib
         from . import build as _build
-        if _build.is_stale():
+        override = os.environ.get("NEUBE_LIB_PATH")          # developer A/B switch: load this prebuilt library instead
+        if override:
+            globals()["LIB_PATH"] = override
+        if not override and _build.is_stale():
             # missing, or built from other sources than the tree holds now (kernel edits without an ABI bump would
             # otherwise run the old code silently): rebuild if a compiler is here, else fail loudly
             if os.path.exists(_build.HIPCC) and os.environ.get("NEUBE_NO_AUTOBUILD") != "1":
@@ -140,7 +143,7 @@ def lib() -> C.CDLL:
                 raise NeubeHipError(
                     f"HIP kernel library at {LIB_PATH} is missing or was built from different sources. Build it with "
                     f"`python -m brushstroke_engine_amd.build` (needs hipcc, gfx950). There is no CPU fallback.")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(globals()["LIB_PATH"])
         for name, (res, args) in PROTOTYPES.items():
             try:
                 fn = getattr(l, name)

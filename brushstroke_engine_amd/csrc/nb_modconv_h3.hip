@@ -235,6 +235,99 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
+    if constexpr (F8) {
+        // ---- f8 operands: explicitly ordered, software-pipelined step -------------------------------------------
+        // The compiler, left alone, sinks every fragment read to just before its first use and waits with lgkmcnt(0)
+        // right after issuing it (five exposed LDS latencies per step with both waves of a SIMD in lockstep).  Here
+        // every statement group is followed by a scheduling fence, so the program order below is the issue order:
+        //     after barrier(t-1):  reads tap 0, tap 1 of step t | corrections of tap 2 of step t-1 (4 x 64 cycles of cover)
+        //     tap 0 main | reads tap 2 | tap 1 main | corrections taps 0+1 | tap 2 main | DMA issues | wait | barrier(t)
+        // i.e. a fragment is read at least one matrix group (128-256 cycles) before the group that consumes it.
+        // Per accumulator: step t contributes  f8(A2,0|B2,.)[t-1], A0 B0, A1 B1, f8(A0,A1|B0,B1), A2 B2.
+#define NB_SB __builtin_amdgcn_sched_barrier(0)
+#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
+        const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
+        h8 ah0[MB], ah1[MB], ah2[MB], bh0[NBW], bh1[NBW], bh2[NBW];
+        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];          // fp8 operand tuples: (tap 0 | tap 1), (tap 2 | zero)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) al2[mb][r] = 0;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bl2[nb][r] = 0;
+        auto rd_tap01 = [&](const h8* wb, const h8* xb, int ky, int kx) {       // kx = 0 or 1: hi fragments + quad kx of the lo tuples
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                (kx ? ah1 : ah0)[mb] = wb[a_base + kx * 4 * CO_WG + mb * 32];
+                if (kx) { NB_Q(al01[mb], 1, wb[a_base + kx * 4 * CO_WG + CO_WG + mb * 32]); } else { NB_Q(al01[mb], 0, wb[a_base + CO_WG + mb * 32]); }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                (kx ? bh1 : bh0)[nb] = xb[b_base + (nb + ky) * TWP + kx];
+                if (kx) { NB_Q(bl01[nb], 1, xb[b_base + XPL + (nb + ky) * TWP + kx]); } else { NB_Q(bl01[nb], 0, xb[b_base + XPL + (nb + ky) * TWP]); }
+            }
+            NB_SB;
+        };
+        auto rd_tap2 = [&](const h8* wb, const h8* xb, int ky) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                ah2[mb] = wb[a_base + 2 * 4 * CO_WG + mb * 32];
+                NB_Q(al2[mb], 0, wb[a_base + 2 * 4 * CO_WG + CO_WG + mb * 32]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                bh2[nb] = xb[b_base + (nb + ky) * TWP + 2];
+                NB_Q(bl2[nb], 0, xb[b_base + XPL + (nb + ky) * TWP + 2]);
+            }
+            NB_SB;
+        };
+        auto main4 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) { acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0); NB_SB; }
+        };
+        auto corr4 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 0, 0, 0, sa, 0, sb);
+                    NB_SB;
+                }
+        };
+        for (int c = 0; c < NC; ++c) {
+            const h8* xb = xbuf + (c & 1) * 4 * XPL;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int t = c * 3 + ky;
+                const h8* wb = wring + (t & 3) * WSLOTS;
+                NB_SB;
+                rd_tap01(wb, xb, ky, 0);
+                rd_tap01(wb, xb, ky, 1);
+                corr4(al2, bl2);                       // tap 2 of the previous step (zeros before the first one)
+                main4(ah0, bh0);
+                rd_tap2(wb, xb, ky);
+                main4(ah1, bh1);
+                corr4(al01, bl01);
+                // keep the LDS-DMA stream 3 sub-chunks ahead (past the end: harmless re-copies keep the counts uniform)
+                issue_w(clampt(t + 3), wring + ((t + 3) & 3) * WSLOTS);
+                if (ky == 0) issue_x(c + 1 < NC ? c + 1 : NC - 1, xbuf + ((c + 1) & 1) * 4 * XPL);
+                NB_SB;
+                main4(ah2, bh2);
+                // everything issued before sub-chunk t-1 must have landed (it is what sub-chunk t+1 reads)
+                if (ky == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW + NXPW) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        NB_SB;
+        corr4(al2, bl2);                               // the last step's tap 2
+#undef NB_Q
+#undef NB_SB
+    } else
     for (int c = 0; c < NC; ++c) {
         const h8* xb = xbuf + (c & 1) * 4 * XPL;
 #pragma unroll
@@ -336,7 +429,10 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
         ts[6] = t_dma; ts[7] = t_bar | ((__builtin_amdgcn_s_memtime() - t_loop0) << 32);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail re-copies before the LDS is released
+    // drain the tail re-copies before the staging LDS is reused: every wave waits for ITS pieces, and the barrier makes
+    // sure no other wave's late piece lands on top of epilogue data (without it the outcome depended on DMA timing)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
 
@@ -832,8 +928,9 @@ struct H3Up2Params {
 // file: 4 position blocks x 4 phases = 256 accumulators per wave, the shared weight fragments are read once per 4 blocks
 // instead of once per 2, and a wave has room to keep the next tap group's fragments in flight under the current MFMAs)
 // OUTM = output mode: 0 = fp32 NCHW, 1 = the consumer's H2 tensor, 2 = the consumer's tensor in the "f8" operand format
+// (TQH = 5 with NW_ = 4: two 4-wave workgroups share a CU, so one's VALU epilogue runs beside the other's K loop)
 template <bool F8, int TQH, int NW_ = 8, int OUTM = 0>
-__global__ __launch_bounds__(NW_ * 64) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
+__global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && TQH == NB_H3_TQH_SMALL) ? 2 : 1) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = NW_, NT = NW_ * 64, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
@@ -955,7 +1052,7 @@ __global__ __launch_bounds__(NW_ * 64) void modconv3x3_up2_h3_kernel(const H3Up2
     constexpr int kPha[9] = {3, 2, 1, 0, 2, 0, 1, 0, 0};                 // kTapPhase[kOrd[i]]
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
-    if constexpr (F8 && NW == 4) {
+    if constexpr (F8 && NW == 4 && TQH == NB_H3_TQH) {
         // ---- one wave per SIMD: software-pipelined K loop -------------------------------------------------------
         // A wave carries 4 position blocks x 4 phases (256 accumulators) and owns its SIMD's matrix pipe, so the LDS
         // and DMA-issue latencies have to be covered inside the wave.  The matrix instructions are volatile asm
@@ -1440,6 +1537,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
     static const int env_nw = getenv("NB_UP2_NW") ? atoi(getenv("NB_UP2_NW")) : 8;
     if (!small_tiles && env_nw == 4 && in_fmt == 1) return nb_up2_h3_launch<NB_H3_TQH, 4>(p, n, in_fmt, stream);
+    if (!small_tiles && env_nw == 45 && in_fmt == 1) return nb_up2_h3_launch<NB_H3_TQH_SMALL, 4>(p, n, in_fmt, stream);
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }
 
