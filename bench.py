@@ -387,15 +387,23 @@ def main():
     rows.sort(reverse=True)
     conv_ms = sum(r[0] for r in rows)
     conv_fl = sum(r[2] for r in rows)
-    traffic = None
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read inside this process, so the figure comes from
+    # profiles/hbm_traffic.json (tools/collect_profiles.sh: separate rocprofv3 --pmc passes of this very command), and only
+    # if that file was measured on the kernel sources that are running now (content digest) -- otherwise null
+    traffic, traffic_note = None, "profiles/hbm_traffic.json missing"
     tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom_name)
-        except Exception:
-            traffic = None
+            from brushstroke_engine_amd import build as _b
+            tj = json.load(open(tpath))
+            if tj.get("_stamp", {}).get("source_digest") == _b.source_digest():
+                traffic, traffic_note = tj.get(dom_name), f"rocprofv3 PMC passes at {tj['_stamp'].get('git_head')}, same kernel sources"
+            else:
+                traffic_note = "profiles/hbm_traffic.json was measured on other kernel sources (stale): not used"
+        except Exception as e:                                  # noqa: BLE001
+            traffic_note = f"profiles/hbm_traffic.json unreadable: {e}"
     roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": dom_peak,
-                "unit": "TFLOP/s", "frac": round(achieved / dom_peak, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(achieved / dom_peak, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "executed_mfma": (({"tflops": round(3 * achieved, 1), "frac": round(3 * achieved / dom_peak, 4),
                                     "what": "f16 MFMA FLOPs actually executed for the algorithmic ones (3 products per fp32 "
                                             "product; halo / block-rounding overhead of the up=2 kernel not included)"}
@@ -456,6 +464,17 @@ def main():
                                                                    f" + {'RCCL' if backend == 'nccl' else backend} gather of RGBA tiles to rank 0 "
                                                                    f"inside every step" if gatherer else " (NO gather: --no-gather)")},
             "roofline": roofline,
+            "roofline_whole_step": {
+                "what": "the whole step (all launches of one GPU) against the ceilings of SURVEY 8d: algorithmic FLOPs of the batch / ms_per_step",
+                "achieved": round(B * 2 * cfg.macs_per_patch() / (ms_per_step * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                "fp32_matrix_peak": PEAK_F32_MATRIX_TFLOPS,
+                "scheme_ceiling": {"f32": PEAK_F32_MATRIX_TFLOPS, "h3": round(PEAK_F16_MATRIX_TFLOPS / 3, 1),
+                                   "f8": round(1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS), 1)}[args.conv_mode],
+                "frac_of_scheme_ceiling": round(B * 2 * cfg.macs_per_patch() / (ms_per_step * 1e-3) / 1e12 /
+                                                {"f32": PEAK_F32_MATRIX_TFLOPS, "h3": PEAK_F16_MATRIX_TFLOPS / 3,
+                                                 "f8": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS)}[args.conv_mode], 4),
+                "note": "scheme ceiling = the matrix work the arithmetic mode executes per algorithmic FLOP at nominal dense peaks (f8: one f16 "
+                        "+ two fp8 MFMA FLOPs; h3: three f16); the K loops run at ~1.6-1.8 GHz under load (in-kernel s_memtime clock), not 2.4"},
             "rehearsal_ms_per_step": round(rehearsal_ms, 4),
             "burn_in_ms_per_step": [round(b, 3) for b in burn_in[:6]] + (["..."] if len(burn_in) > 7 else []) + [round(b, 3) for b in burn_in[6:][-1:]],
         }

@@ -1,0 +1,37 @@
+/*
+ * neube_hip_debug.h -- developer / test hooks of libneube_hip.so.  NOT part of the drop-in boundary
+ * (include/neube_hip.h): nothing in the product path calls these.  They are process-global switches that the
+ * parity tests and the profiling tools use to force a kernel variant or to collect in-kernel timestamps; a
+ * caller sets one, runs, and restores the default (0 / -1 / NULL) afterwards.  Thread-compatible only in the
+ * sense that no product call changes them.
+ */
+#ifndef NEUBE_HIP_DEBUG_H
+#define NEUBE_HIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tile form of the 8-wave split-f16 up=1 kernel: 0 = automatic (by workgroup count), 1 / 2 = that many 32-pixel rows per
+ * wave.  tests/test_hip_f8.py asserts both forms bit-identical. */
+void nb_debug_set_up1_rows(int nbw);
+
+/* Tile height of the split-f16 up=2 kernel: 0 = automatic, 12 = throughput tiles, 5 = the under-filled (batch-1) tiles. */
+void nb_debug_set_up2_tile(int tqh);
+
+/* Tile form of nb_enc_conv3x3_h3: -1 = automatic, 0 = large tiles, 1 = small split-K tiles. */
+void nb_debug_set_enc_small(int mode);
+
+/* Per-workgroup phase timestamps of the next split-f16 (resp. fp32 split-K) conv launches: buf = device pointer to
+ * capacity_workgroups x 8 uint64 (s_memrealtime ticks; layout: tools/phase_times.py), NULL = off. */
+void nb_debug_set_timestamps(void* buf, int capacity_workgroups);
+void nb_debug_set_timestamps_f32(void* buf, int capacity_workgroups);
+
+/* The library's 64 KiB device page of zeros (source of out-of-image halo slots for the LDS-DMA staging); lazily
+ * allocated, one per process. */
+const float* nb_zero_page_ptr(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -18,8 +18,8 @@ def library():
     return _lib.lib()
 
 
-def declared_symbols():
-    text = open(os.path.join(REPO, "include", "neube_hip.h")).read()
+def declared_symbols(header="neube_hip.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", text)))
 
@@ -30,6 +30,24 @@ def test_header_and_binding_agree(library):
     assert sorted(_lib.PROTOTYPES) == names
     for n in names:
         assert hasattr(library, n), n
+
+
+def test_debug_hooks_are_declared_apart(library):
+    """Everything the library exports is declared: the product ABI in neube_hip.h, the process-global developer / test
+    switches in neube_hip_debug.h (none of which the product path calls)."""
+    import subprocess
+    dbg = declared_symbols("neube_hip_debug.h")
+    assert dbg and not set(dbg) & set(declared_symbols())
+    for n in dbg:
+        assert hasattr(library, n), n
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r"\bT (nb_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == sorted(set(dbg) | set(declared_symbols())), sorted(set(exported) ^ (set(dbg) | set(declared_symbols())))
+    pkg = os.path.join(REPO, "brushstroke_engine_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                assert "nb_debug_" not in open(os.path.join(root, f)).read(), f
 
 
 def test_abi_version_and_error_string(library):

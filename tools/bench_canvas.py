@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--conv-mode", default="h3")
+    ap.add_argument("--conv-mode", default="f8")
     ap.add_argument("--breakdown", action="store_true")
     ap.add_argument("--encoder", default="hip", choices=["hip", "torch"])
     a = ap.parse_args()
