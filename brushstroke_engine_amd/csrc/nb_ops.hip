@@ -549,19 +549,85 @@ __device__ __forceinline__ void nb_noise_sample(const NbLayerDesc& L, const floa
     }
 }
 
+// The sampling grid is separable and TRANSPOSING -- the source column depends on the output row i, the source row on the
+// output column j (SURVEY note C) -- so a straight gather has either its loads or its stores strided by a whole image row.
+// A block takes a 32 x 32 output tile of one (layer, sample): the bilinear parameters of its 32 rows and 32 columns are
+// computed once, the 32 x 2 x 32 x 2 source taps are fetched with lanes along the source COLUMN (coalesced) into LDS, and
+// the outputs are formed with lanes along the output column (coalesced stores, conflict-free 8-byte LDS reads).  Same
+// expressions in the same order per pixel as nb_noise_sample (bit-identical).
+#define NB_NOISE_T 32
 __global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restrict__ layers, const float* __restrict__ norm_pos,
                                                     const long long* __restrict__ positions, int img_res, int n_total) {
     const NbLayerDesc L = layers[blockIdx.y];
     if (!L.noise_const) return;
     const int r = L.res;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= r * r) return;          // (most blocks of the small layers: the grid is sized for the largest one)
+    const int tiles = (r + NB_NOISE_T - 1) / NB_NOISE_T;
+    const int t = threadIdx.x;
+    // a block walks tiles blockIdx.x, + gridDim.x, ... (few blocks per (layer, sample): most layers have 1-4 tiles, and
+    // tens of thousands of empty blocks cost more than the work)
+    for (int tile = blockIdx.x; tile < tiles * tiles; tile += gridDim.x) {
+    const int i0 = (tile / tiles) * NB_NOISE_T, j0 = (tile % tiles) * NB_NOISE_T;
+    __syncthreads();                                         // (the previous tile's LDS tables are done with)
     if (!norm_pos && !positions) {
-        if (blockIdx.z == 0) L.noise_out[idx] = L.noise_const[idx] * L.noise_strength[0];
-        return;
+        if (blockIdx.z == 0)
+            for (int e = t; e < NB_NOISE_T * NB_NOISE_T; e += 256) {
+                const int i = i0 + e / NB_NOISE_T, j = j0 + e % NB_NOISE_T;
+                if (i < r && j < r) L.noise_out[i * r + j] = L.noise_const[i * r + j] * L.noise_strength[0];
+            }
+        continue;
     }
-    // a block walks the samples (grid.z is small): 4x fewer, fatter blocks than one block per (tile, layer, sample)
-    for (int n = blockIdx.z; n < n_total; n += gridDim.z) nb_noise_sample(L, norm_pos, positions, img_res, n, idx, 1 << 30);
+    const int n = blockIdx.z;
+    const float strength = L.noise_strength[0];
+    float np0 = 0.f, np1 = 0.f;
+    if (positions) {
+        // networks_modified.py:351-353: (positions % R) / (R - 1), python-style modulo, IEEE float32 division
+        const long long R = img_res;
+        const long long p0 = ((positions[2 * n + 0] % R) + R) % R, p1 = ((positions[2 * n + 1] % R) + R) % R;
+        np0 = (float)p0 / (float)(img_res - 1);
+        np1 = (float)p1 / (float)(img_res - 1);
+    } else {
+        np0 = norm_pos[2 * n + 0];
+        np1 = norm_pos[2 * n + 1];
+    }
+    constexpr int PITCH = 2 * NB_NOISE_T * 2 + 2;            // floats per output column jj: [dy 2][ii 32][dx 2] (+2: bank spread)
+    __shared__ int s_x0[NB_NOISE_T], s_y0[NB_NOISE_T];
+    __shared__ float s_wx0[NB_NOISE_T], s_wx1[NB_NOISE_T], s_wy0[NB_NOISE_T], s_wy1[NB_NOISE_T];
+    __shared__ __attribute__((aligned(8))) float s_tap[NB_NOISE_T * PITCH];
+    if (t < 2 * NB_NOISE_T) {
+        // grid[i,j] = (lin[i] + pos0, lin[j] + pos1); channel 0 is the COLUMN coordinate, channel 1 the ROW
+        const int k = t & (NB_NOISE_T - 1), idx = (t < NB_NOISE_T ? i0 : j0) + k;
+        if (idx < r) {
+            const float g = fmodf(L.noise_lin[idx] + (t < NB_NOISE_T ? np0 : np1), 1.f) * 2.f - 1.f;
+            const float cc = ((g + 1.f) / 2.f) * (float)(r - 1);
+            const float c0 = floorf(cc);
+            if (t < NB_NOISE_T) { s_x0[k] = (int)c0; s_wx1[k] = cc - c0; s_wx0[k] = (c0 + 1.f) - cc; }
+            else { s_y0[k] = (int)c0; s_wy1[k] = cc - c0; s_wy0[k] = (c0 + 1.f) - cc; }
+        } else if (t < NB_NOISE_T) { s_x0[k] = -2; s_wx0[k] = s_wx1[k] = 0.f; }
+        else { s_y0[k] = -2; s_wy0[k] = s_wy1[k] = 0.f; }
+    }
+    __syncthreads();
+    // taps: lanes along the source column (output row ii); all 16 loads of a thread in flight together
+#pragma unroll
+    for (int e = t; e < NB_NOISE_T * 2 * NB_NOISE_T * 2; e += 256) {
+        const int dx = e & 1, ii = (e >> 1) & (NB_NOISE_T - 1), dy = (e >> 6) & 1, jj = e >> 7;
+        const int xi = s_x0[ii] + dx, yi = s_y0[jj] + dy;
+        s_tap[jj * PITCH + (dy * NB_NOISE_T + ii) * 2 + dx] = (yi >= 0 && yi < r && xi >= 0 && xi < r) ? L.noise_const[yi * r + xi] : 0.f;
+    }
+    __syncthreads();
+    const int jj = t & (NB_NOISE_T - 1);
+    if (j0 + jj >= r) continue;
+    const float wy0 = s_wy0[jj], wy1 = s_wy1[jj];
+    for (int ii = t >> 5; ii < NB_NOISE_T && i0 + ii < r; ii += 8) {
+        const float wx0 = s_wx0[ii], wx1 = s_wx1[ii];
+        const float2 r0 = *reinterpret_cast<const float2*>(s_tap + jj * PITCH + ii * 2);
+        const float2 r1 = *reinterpret_cast<const float2*>(s_tap + jj * PITCH + (NB_NOISE_T + ii) * 2);
+        float v = r0.x * (wx0 * wy0);
+        v += r0.y * (wx1 * wy0);
+        v += r1.x * (wx0 * wy1);
+        v += r1.y * (wx1 * wy1);
+        L.noise_out[(size_t)n * r * r + (size_t)(i0 + ii) * r + j0 + jj] = v * strength;
+    }
+    }
 }
 
 extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max_res, const float* norm_pos,
@@ -570,7 +636,8 @@ extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max
     NB_REQUIRE(n_layers >= 1 && n_layers <= 65535 && max_res >= 1 && n >= 1 && n <= 65535, "noise: bad sizes");
     NB_REQUIRE(!(norm_pos && positions), "noise: pass either norm_pos or positions, not both");
     NB_REQUIRE(!positions || img_resolution >= 2, "noise: positions need img_resolution >= 2");
-    dim3 grid(nb_cdiv(max_res * max_res, 256), n_layers, (norm_pos || positions) ? (n < 4 ? n : 4) : 1);
+    const int tiles = nb_cdiv(max_res, NB_NOISE_T);
+    dim3 grid(tiles * tiles, n_layers, (norm_pos || positions) ? n : 1);
     hipLaunchKernelGGL(noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, layers_dev, norm_pos,
                        (const long long*)positions, img_resolution, n);
     NB_CHECK_LAUNCH("noise");
