@@ -192,6 +192,7 @@ class _Plan:
         d.c_aff, d.n_plain, d.c_out, d.w_index, d.res = c_aff[-1], 9, 3, cfg.torgb_w_index, 0
         d.style_scale = float(t.weight_gain)
         self.host_descs = descs
+        self.pack_stream, self.pack_events = None, {}      # side stream for the early geometry packing of this slot
         self.n_layers = len(specs) + 1
         self.table = self._upload(descs)
 
@@ -254,6 +255,7 @@ class SynthesisNetwork(torch.nn.Module):
         self._h3_batch_ok = True
         self._n = 1
         self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
+        self.early_geom_pack = True       # geometry channels of such inputs are packed at the start, on a side stream
         self.fuse_torgb = True            # last conv1 + ToRGB + compositing in one launch (split-f16 path)
         self.layer_kernels: Dict[str, str] = {}
 
@@ -427,6 +429,48 @@ class SynthesisNetwork(torch.nn.Module):
             if noise_mode == "const":
                 shared = npos is None and ipos is None
 
+            # Geometry channels of the layers that receive their input in H2 / f8 operand format: packed NOW on a side
+            # stream (they only need the consumer's styles), under the small first layers, instead of between the
+            # producer and the consumer.  pre_h2[res] = (consumer input tensor, event).
+            pre_h2 = {}
+            if self.early_geom_pack and self.h2_handoff:
+                specs_ = {s_.name: (i_, s_) for i_, s_ in enumerate(cfg.layers)}
+                gi = 0
+                for gres in self.geom_feature_resolutions:
+                    g_idx, gi = gi, gi + 1
+                    if (resume is not None and gres <= resume[0]) or gres >= cfg.img_resolution:
+                        continue
+                    if gres in return_features or gres in blended_features or stop_after == gres or g_idx >= len(geom_feature):
+                        continue
+                    ip, sp_ = specs_[f"synthesis.b{gres}.conv1"]
+                    ic, sc_ = specs_[f"synthesis.b{2 * gres}.conv0"]
+                    gch = self.geom_feature_channels[g_idx]
+                    ofmt = self._operand_fmt(sc_)
+                    if not (self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 8 == 0
+                            and (ofmt == 0 or (sp_.out_channels % 16 == 0 and gch % 16 == 0))):
+                        continue
+                    g = geom_feature[g_idx]
+                    if g.device != device or g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != (n, gch, gres, gres):
+                        continue                                           # (the in-line path validates and converts)
+                    cur = torch.cuda.current_stream(device)
+                    if plan.pack_stream is None:
+                        plan.pack_stream = torch.cuda.Stream(device=device)
+                        plan.pack_events = {}
+                    dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
+                    if not pre_h2:
+                        plan.pack_stream.wait_stream(cur)                   # the styles are computed
+                    part = lib.nb_pack_h2f8_part_f32 if ofmt else lib.nb_pack_h2_part_f32
+                    c_prod = sc_.in_channels - gch
+                    _lib.check(part(_p(g), gch, plan.styles[ic].data_ptr() + 4 * c_prod, sc_.in_channels, _p(dst),
+                                    (sc_.in_channels + 7) // 8, c_prod // 8, n, gres * gres, plan.pack_stream.cuda_stream), "pack_h2_part")
+                    ev_ = plan.pack_events.get(gres)
+                    if ev_ is None:
+                        ev_ = plan.pack_events[gres] = torch.cuda.Event()
+                    ev_.record(plan.pack_stream)
+                    g.record_stream(plan.pack_stream)
+                    dst.record_stream(plan.pack_stream)
+                    pre_h2[gres] = (dst, ev_)
+
             debug_data = {}
             x = img = None
             x2 = None
@@ -507,8 +551,11 @@ class SynthesisNetwork(torch.nn.Module):
                             if res in return_features or stop_after == res:
                                 y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
                         elif fuse_out:
-                            next_h2 = torch.empty(ops.h2_shape(n, nxt.in_channels, s.block_res, s.block_res),
-                                                  dtype=torch.float16, device=device)
+                            if at_block_end and res in pre_h2:
+                                next_h2 = pre_h2[res][0]                    # geometry channels are (being) packed into it
+                            else:
+                                next_h2 = torch.empty(ops.h2_shape(n, nxt.in_channels, s.block_res, s.block_res),
+                                                      dtype=torch.float16, device=device)
                         else:
                             y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
                         nst = _p(plan.styles[i + 1]) if next_h2 is not None else None
@@ -586,7 +633,11 @@ class SynthesisNetwork(torch.nn.Module):
                         raise RuntimeError(f"geom_feature is on {g.device} but the generator is on {device}")
                     x2 = g.to(torch.float32).contiguous()
                     _assert_shape(x2, [n, self.geom_feature_channels[self.geom_feature_resolutions.index(res)], res, res])
-                    if x_h2 is not None:
+                    if x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
+                        torch.cuda.current_stream(device).wait_event(pre_h2[res][1])     # packed early on the side stream
+                        keep_alive.append(x2)
+                        x2 = None
+                    elif x_h2 is not None:
                         # the block's last layer already wrote its channels into the consumer's H2 input: add the
                         # geometry channels (x the consumer's styles) behind them
                         inext, snext = specs[f"synthesis.b{2 * res}.conv0"]
