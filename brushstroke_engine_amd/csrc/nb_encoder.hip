@@ -136,6 +136,15 @@ extern "C" int nb_enc_stem7x7_f32_h2(const float* x, const float* w50, const flo
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv, stride 1 or 2, reflect padding 1, split-f16
 // ------------------------------------------------------------------------------------------------
+// four values -> four e4m3 bytes, saturated to the format's range (the same conversion as nb_pk4_fp8 of nb_modconv_h3.hip)
+__device__ __forceinline__ unsigned nb_enc_pk4_fp8(float a, float b, float c, float d) {
+    auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+    return (unsigned)w;
+}
+
 struct EncConvParams {
     const _Float16* x;      // H2 [n][c8][2][hin][win][8]
     const _Float16* wts;    // [nchunks][3][3][2][2][co_ld][8], co_ld % 128 == 0
@@ -145,6 +154,10 @@ struct EncConvParams {
     const float* zeros;
     int c8, nchunks, c_out, co_ld, hin, win, hout, wout, tiles_x, tiles_y, slices;
     float slope;
+    // hand-off into a CONSUMER's operand tensor (OUT == 1): the result times oscale[n][co] goes into channel groups
+    // cg0 .. of a tensor with c8_total groups, in H2 (hi/lo f16) or "f8" (hi f16 + fp8 correction operands) format
+    const float* oscale;
+    int oscale_stride, c8_total, cg0, out_f8;
 };
 
 template <int STRIDE, int LW, int OUT>
@@ -314,22 +327,34 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 for (int g = 0; g < 4; ++g) {
                     const int col = wm * 64 + mb * 32 + 8 * g + 4 * lh;
                     h4 vh, vl;
+                    float vv[4], xl[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int co = co0 + col + j;
                         float v = 0.f;
-                        if (co < p.c_out) v = nb_lrelu(acc[mb][nb][4 * g + j] + p.bias[co], p.slope);
+                        if (co < p.c_out) {
+                            v = nb_lrelu(acc[mb][nb][4 * g + j] + p.bias[co], p.slope);
+                            if (p.oscale) v *= p.oscale[(size_t)n * p.oscale_stride + co];
+                        }
                         const _Float16 hi = (_Float16)v;
-                        vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                        vv[j] = v; xl[j] = v - (float)hi;
+                        vh[j] = hi; vl[j] = (_Float16)xl[j];
                     }
                     *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
-                    *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                    if (p.out_f8) {
+                        // lo image as bytes: per 16-channel chunk 16 x fp8(xl 2^9) then 16 x fp8(v/4) (see nb_modconv_h3.hip)
+                        unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)pix * (CP * 2) + (col >> 4) * 32 + (col & 15);
+                        *reinterpret_cast<unsigned*>(sb) = nb_enc_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
+                        *reinterpret_cast<unsigned*>(sb + 16) = nb_enc_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
+                    } else {
+                        *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
+                    }
                 }
         }
         __syncthreads();
         const int c8o = (p.c_out + 7) / 8;
         const size_t OHW8 = (size_t)p.hout * p.wout * 8;
-        _Float16* yn = p.yh2 + (size_t)n * c8o * 2 * OHW8;
+        _Float16* yn = p.yh2 + ((size_t)n * p.c8_total + p.cg0) * 2 * OHW8;
         for (int e = tid; e < (CO_WG / 8) * 2 * 256; e += 512) {  // [cg 16][hl 2][pixel 256]
             const int pix = e & 255, hl = (e >> 8) & 1, cgl = e >> 9;
             const int cg = co0 / 8 + cgl;
@@ -514,8 +539,9 @@ static int g_enc_small = -1;
 // developer / test hook: -1 = automatic choice between the two tile forms of enc_conv3x3, 0 = large tiles, 1 = small tiles
 extern "C" void nb_debug_set_enc_small(int mode) { g_enc_small = mode; }
 
-extern "C" int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2,
-                                 int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
+static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2,
+                               const float* oscale, int oscale_stride, int c8_total, int cg0, int out_fmt,
+                               int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
     NB_REQUIRE(x_h2 && w_h3 && bias && ((y_f32 != nullptr) != (y_h2 != nullptr)), "enc_conv3x3_h3: need x, w, bias and exactly one output");
     NB_REQUIRE(n >= 1 && n <= 65535 && c_in >= 1 && c_out >= 1 && (stride == 1 || stride == 2), "enc_conv3x3_h3: bad sizes");
     NB_REQUIRE(h_in % stride == 0 && w_in % stride == 0 && h_in >= 2 && w_in >= 2, "enc_conv3x3_h3: bad input size %dx%d", h_in, w_in);
@@ -530,8 +556,14 @@ extern "C" int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, c
     NB_REQUIRE(p.zeros, "enc_conv3x3_h3: could not allocate the zero page");
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 127) / 128 * 128;
     p.hin = h_in; p.win = w_in; p.hout = ho; p.wout = wo; p.slope = slope;
+    const bool handoff = oscale != nullptr || c8_total > 0 || out_fmt != 0;
+    NB_REQUIRE(!handoff || (y_h2 && c8_total >= cg0 + (c_out + 7) / 8 && cg0 >= 0 && (out_fmt == 0 || (out_fmt == 1 && c_out % 16 == 0 && cg0 % 2 == 0))
+                            && (!oscale || oscale_stride >= c_out)),
+               "enc_conv3x3_h3: bad hand-off arguments (needs an H2 destination with room for the channel groups; f8: whole 16-channel chunks)");
+    p.oscale = oscale; p.oscale_stride = oscale_stride; p.c8_total = handoff ? c8_total : (c_out + 7) / 8; p.cg0 = handoff ? cg0 : 0;
+    p.out_f8 = out_fmt;
     hipStream_t st = (hipStream_t)stream;
-    {
+    if (!handoff) {
         // under-filled launch (interactive strokes, small batches): the 32 x 32 split-K tiles instead.  Needs whole
         // 16-channel chunks and an output width that is a power of two >= 8 (32 positions = 32 / w rows).
         const long big_wgs = (long)n * (wo / (wide ? 32 : 16)) * (ho / (wide ? 8 : 16)) * ((c_out + 127) / 128);
@@ -559,6 +591,19 @@ extern "C" int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, c
         case 6: return launch_enc_conv<2, 5, 0>(p, n, st);
         default: return launch_enc_conv<2, 5, 1>(p, n, st);
     }
+}
+
+extern "C" int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2,
+                                 int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
+    return nb_enc_conv3x3_impl(x_h2, c_in, w_h3, bias, y_f32, y_h2, nullptr, 0, 0, 0, 0, n, h_in, w_in, c_out, stride, slope, stream);
+}
+
+extern "C" int nb_enc_conv3x3_h3_handoff(const void* x_h2, int c_in, const void* w_h3, const float* bias, void* y_h2,
+                                         const float* oscale, int oscale_stride, int c8_total, int cg0, int out_fmt,
+                                         int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
+    NB_REQUIRE(y_h2 && c8_total > 0, "enc_conv3x3_h3_handoff: needs the consumer's tensor and its channel-group count");
+    return nb_enc_conv3x3_impl(x_h2, c_in, w_h3, bias, nullptr, y_h2, oscale, oscale_stride, c8_total, cg0, out_fmt, n, h_in, w_in,
+                               c_out, stride, slope, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

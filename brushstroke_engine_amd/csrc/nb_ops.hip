@@ -606,8 +606,7 @@ __global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restric
         else { s_y0[k] = -2; s_wy0[k] = s_wy1[k] = 0.f; }
     }
     __syncthreads();
-    // taps: lanes along the source column (output row ii); all 16 loads of a thread in flight together
-#pragma unroll
+    // taps: lanes along the source column (output row ii)
     for (int e = t; e < NB_NOISE_T * 2 * NB_NOISE_T * 2; e += 256) {
         const int dx = e & 1, ii = (e >> 1) & (NB_NOISE_T - 1), dy = (e >> 6) & 1, jj = e >> 7;
         const int xi = s_x0[ii] + dx, yi = s_y0[jj] + dy;

@@ -12,7 +12,7 @@ headline.  State-dict keys equal the reference's (``encoder.model.{i}.conv.{0,1}
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -202,8 +202,16 @@ class HipGeometryEncoder:
     def supports(resolution: int) -> bool:
         return resolution >= 128 and resolution % 128 == 0
 
+    def lazy(self, geom: torch.Tensor) -> "LazyGeometry":
+        """The geometry features of ``geom`` as a provider the HIP generator evaluates itself, right after it has computed
+        its styles: the 256-channel decoder feature then goes straight into the consuming layer's operand tensor
+        (``nb_enc_conv3x3_h3_handoff``) instead of fp32 NCHW + a packing pass."""
+        return LazyGeometry(self, geom)
+
     @torch.no_grad()
-    def encode(self, geom: torch.Tensor, res=None) -> List[torch.Tensor]:
+    def encode(self, geom: torch.Tensor, res=None, targets=None) -> List[torch.Tensor]:
+        """``targets`` (optional, from the generator): ``{1: dict(dst, scale_ptr, scale_stride, c8_total, cg0, fmt)}`` --
+        feature 1 is then written into ``dst`` (the consumer's H2 / f8 input tensor) and returned as None."""
         if res is not None and list(res) != [0, 1]:
             raise RuntimeError("HipGeometryEncoder evaluates the shipped configuration: res=[0, 1]")
         lib, check = self._lib.lib(), self._lib.check
@@ -232,6 +240,50 @@ class HipGeometryEncoder:
             up = f16(co, 2 * r)
             check(lib.nb_enc_upsample2x_h2(P(enc), P(up), n, co, r, r, st), "enc_upsample")
             wt, b, ci, co, stride = self.convs[5]            # first decoder stage, 16 -> 256
-            dec = f32(co, 2 * r)
-            check(lib.nb_enc_conv3x3_h3(P(up), ci, P(wt), P(b), P(dec), None, n, 2 * r, 2 * r, co, 1, 0.01, st), "enc_conv")
+            tg = None if not targets else targets.get(1)
+            if tg is not None:
+                dec = None
+                check(lib.nb_enc_conv3x3_h3_handoff(P(up), ci, P(wt), P(b), P(tg["dst"]), tg["scale_ptr"], tg["scale_stride"],
+                                                    tg["c8_total"], tg["cg0"], tg["fmt"], n, 2 * r, 2 * r, co, 1, 0.01, st), "enc_conv")
+            else:
+                dec = f32(co, 2 * r)
+                check(lib.nb_enc_conv3x3_h3(P(up), ci, P(wt), P(b), P(dec), None, n, 2 * r, 2 * r, co, 1, 0.01, st), "enc_conv")
         return [enc, dec]
+
+
+class LazyGeometry:
+    """Geometry features that have not been computed yet (``HipGeometryEncoder.lazy``).  ``networks.SynthesisNetwork``
+    calls :meth:`encode_for` once its styles are on the device; everything else that indexes it like the list of feature
+    tensors the reference passes (``geom_feature[i]``, ``len``) gets the plain fp32 features, computed on first use."""
+
+    def __init__(self, encoder: "HipGeometryEncoder", geom: torch.Tensor):
+        self.encoder, self.geom = encoder, geom
+        self._plain = None
+
+    def plain(self) -> List[torch.Tensor]:
+        if self._plain is None:
+            self._plain = self.encoder.encode(self.geom)
+        return self._plain
+
+    def encode_for(self, targets) -> List[Optional[torch.Tensor]]:
+        if self._plain is not None or not targets:
+            return self.plain()
+        return self.encoder.encode(self.geom, targets=targets)
+
+    def sliced(self, a: int, b: int) -> "LazyGeometry":
+        """The provider of samples a..b-1 (the generator runs a large batch as sub-batches on separate streams)."""
+        return LazyGeometry(self.encoder, self.geom[a:b])
+
+    def feature_shape(self, i: int):
+        n, _, h, _ = self.geom.shape
+        r = self.encoder.featuremap_resolution(h, i)
+        return (n, self.encoder.feature_channels(i), r, r)
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        return self.plain()[i]
+
+    def __iter__(self):
+        return iter(self.plain())

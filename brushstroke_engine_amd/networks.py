@@ -397,7 +397,9 @@ class SynthesisNetwork(torch.nn.Module):
         self._n = n
         plan = self._get_plan(n, device, plan_slot)
         lib = _lib.lib()
-        geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
+        lazy_geom = geom_feature if hasattr(geom_feature, "encode_for") else None      # encoder.LazyGeometry
+        if lazy_geom is None:
+            geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
         keep_alive = []
         with torch.cuda.device(device):
             stream = ops._stream(ws)
@@ -433,6 +435,35 @@ class SynthesisNetwork(torch.nn.Module):
             # stream (they only need the consumer's styles), under the small first layers, instead of between the
             # producer and the consumer.  pre_h2[res] = (consumer input tensor, event).
             pre_h2 = {}
+            if lazy_geom is not None:
+                # geometry not encoded yet: let the encoder write the features that feed an H2 / f8 layer input straight into
+                # that layer's operand tensor (x the consumer's styles, which exist now); the rest comes back as fp32
+                targets = {}
+                if self.h2_handoff:
+                    specs_ = {s_.name: (i_, s_) for i_, s_ in enumerate(cfg.layers)}
+                    for g_idx, gres in enumerate(self.geom_feature_resolutions):
+                        if g_idx != 1 or (resume is not None and gres <= resume[0]) or gres >= cfg.img_resolution:
+                            continue                        # (feature 0 also feeds the encoder's own decoder: it stays fp32)
+                        if gres in return_features or gres in blended_features or stop_after == gres:
+                            continue
+                        ip, sp_ = specs_[f"synthesis.b{gres}.conv1"]
+                        ic, sc_ = specs_[f"synthesis.b{2 * gres}.conv0"]
+                        gch = self.geom_feature_channels[g_idx]
+                        ofmt = self._operand_fmt(sc_)
+                        if (self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 16 == 0 and gch % 16 == 0
+                                and tuple(lazy_geom.feature_shape(g_idx)) == (n, gch, gres, gres)):
+                            dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
+                            c_prod = sc_.in_channels - gch
+                            targets[g_idx] = dict(dst=dst, scale_ptr=plan.styles[ic].data_ptr() + 4 * c_prod, scale_stride=sc_.in_channels,
+                                                  c8_total=sc_.in_channels // 8, cg0=c_prod // 8, fmt=ofmt)
+                            pre_h2[gres] = (dst, None)
+                needed = [gres for gres in self.geom_feature_resolutions if resume is None or gres >= resume[0]]
+                if not needed:
+                    geom_feature = [None] * len(self.geom_feature_resolutions)      # a resumed pass past the last injection
+                else:
+                    geom_feature = list(lazy_geom.encode_for(targets))
+                    if any(geom_feature[k] is None and k not in targets for k in range(len(geom_feature))):
+                        raise RuntimeError("geometry provider returned no tensor for a feature the generator needs in fp32")
             if self.early_geom_pack and self.h2_handoff:
                 specs_ = {s_.name: (i_, s_) for i_, s_ in enumerate(cfg.layers)}
                 gi = 0
@@ -441,6 +472,8 @@ class SynthesisNetwork(torch.nn.Module):
                     if (resume is not None and gres <= resume[0]) or gres >= cfg.img_resolution:
                         continue
                     if gres in return_features or gres in blended_features or stop_after == gres or g_idx >= len(geom_feature):
+                        continue
+                    if gres in pre_h2 or geom_feature[g_idx] is None:
                         continue
                     ip, sp_ = specs_[f"synthesis.b{gres}.conv1"]
                     ic, sc_ = specs_[f"synthesis.b{2 * gres}.conv0"]
@@ -628,13 +661,19 @@ class SynthesisNetwork(torch.nn.Module):
                     debug_data["features%d" % res] = x
                 if res in self.geom_feature_resolutions:
                     g = geom_feature[geo_idx]
+                    if g is None and x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
+                        geo_idx += 1                                    # the encoder wrote these channels into x_h2 itself
+                        continue
+                    if g is None:                                       # (the producer did not take the hand-off after all)
+                        g = lazy_geom.plain()[geo_idx]
                     geo_idx += 1
                     if g.device != device:
                         raise RuntimeError(f"geom_feature is on {g.device} but the generator is on {device}")
                     x2 = g.to(torch.float32).contiguous()
                     _assert_shape(x2, [n, self.geom_feature_channels[self.geom_feature_resolutions.index(res)], res, res])
                     if x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
-                        torch.cuda.current_stream(device).wait_event(pre_h2[res][1])     # packed early on the side stream
+                        if pre_h2[res][1] is not None:
+                            torch.cuda.current_stream(device).wait_event(pre_h2[res][1])     # packed early on the side stream
                         keep_alive.append(x2)
                         x2 = None
                     elif x_h2 is not None:
@@ -826,7 +865,11 @@ class Generator(torch.nn.Module):
     def _forward_split(self, ws, geom_feature, positions, return_debug_data, return_features, kw):
         n = ws.shape[0]
         dev = ws.device
-        geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
+        lazy_geom = geom_feature if hasattr(geom_feature, "encode_for") else None      # encoder.LazyGeometry: split per sub-batch
+        if lazy_geom is not None:
+            geom_feature = []
+        else:
+            geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
         kw = dict(kw)
         extra = kw.pop("_extra_outputs", None)
         resume = kw.pop("_resume", None)
@@ -848,8 +891,11 @@ class Generator(torch.nn.Module):
             for t in [ws, positions, npos, None if resume is None else resume[1]] + geom_feature:
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(st)               # allocated on the caller's stream, read on this one
+            if lazy_geom is not None and torch.is_tensor(lazy_geom.geom) and lazy_geom.geom.is_cuda:
+                lazy_geom.geom.record_stream(st)
             with torch.cuda.stream(st):
-                res = self.synthesis(ws[a:b], [g[a:b] for g in geom_feature], pos_encoding=None,
+                res = self.synthesis(ws[a:b], lazy_geom.sliced(a, b) if lazy_geom is not None else [g[a:b] for g in geom_feature],
+                                     pos_encoding=None,
                                      return_debug_data=return_debug_data, return_features=return_features, **kw,
                                      _positions=sl(positions, a, b), norm_noise_positions=sl(npos, a, b),
                                      _resume=None if resume is None else (resume[0], resume[1][a:b]),

@@ -258,7 +258,11 @@ class TileOps:
                        "geom_tiles")
         return out
 
-    def encode(self, geom: torch.Tensor) -> List[torch.Tensor]:
+    lazy_geometry = True       # hand the generator a geometry provider (encoder output straight into the layer operands)
+
+    def encode(self, geom: torch.Tensor):
+        if self.lazy_geometry and hasattr(self.encoder, "lazy"):
+            return self.encoder.lazy(geom)
         return self.encoder.encode(geom)
 
     def map_style(self, z=None, ws=None) -> torch.Tensor:

@@ -398,6 +398,15 @@ int nb_enc_stem7x7_f32_h2(const float* x, const float* w50, const float* bias, v
 int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2, int n,
                       int h_in, int w_in, int c_out, int stride, float slope, void* stream);
 
+/* The same convolution writing straight into a CONSUMER's split-f16 operand tensor (the generator layer that takes these
+ * geometry features as extra input channels, networks_modified.py:218-219 `torch.cat`): the result times
+ * oscale[n * oscale_stride + co] (the consumer's styles of those channels; NULL = 1) goes into channel groups
+ * cg0 .. cg0 + c_out/8 - 1 of y_h2 [n][c8_total][2][h][w][8]; out_fmt 0 = H2 (hi/lo f16), 1 = "f8" (hi f16 + fp8
+ * correction operands: c_out % 16 == 0, cg0 even).  Removes the fp32 round trip + nb_pack_h2*_part_f32 pass. */
+int nb_enc_conv3x3_h3_handoff(const void* x_h2, int c_in, const void* w_h3, const float* bias, void* y_h2,
+                              const float* oscale, int oscale_stride, int c8_total, int cg0, int out_fmt,
+                              int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream);
+
 /* Bilinear x2, align_corners=True (nn.Upsample in ScaleUp, simple_autoencoder.py:106-121): fp32 NCHW [n,c,h,w]
  * (c % 8 == 0) -> H2 [n, c, 2h, 2w]. */
 int nb_enc_upsample2x_h2(const float* x, void* y_h2, int n, int c, int h, int w, void* stream);

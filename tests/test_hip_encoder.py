@@ -123,3 +123,33 @@ def test_encoder_rejects_unsupported():
     with pytest.raises(RuntimeError):
         encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(1), preproc_type="bogus")
     assert _lib.lib().nb_enc_conv3x3_h3(None, 16, None, None, None, None, 1, 16, 16, 16, 1, 0.01, None) < 0
+
+
+@pytest.mark.parametrize("mode", ["f8", "h3"])
+def test_lazy_geometry_handoff_equals_fp32_path(mode):
+    """HipGeometryEncoder.lazy: the generator asks the encoder to write the 256-channel decoder feature straight into the
+    consuming layer's operand tensor (nb_enc_conv3x3_h3_handoff, x the consumer's styles) -- the same pixels as the fp32
+    features + packing pass, up to the one rounding the fused scaling saves (compared at the output: uvs)."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    cfg = cfgmod.style1_config(256)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode=mode).to("cuda")
+    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5))
+    n = 6
+    rs = np.random.RandomState(3)
+    geom = torch.from_numpy((rs.rand(n, 1, 256, 256) > 0.1).astype(np.float32)).cuda()
+    ws = G.mapping(torch.from_numpy(synthetic.batch_z(cfg, n, 7)).cuda(), None)
+    pos = torch.from_numpy(synthetic.positions(cfg, n, seed=1)).cuda()
+    _, want = G.forward_pre_mapped(ws, enc.encode(geom), positions=pos, return_debug_data=True, noise_mode="const")
+    lazy = enc.lazy(geom)
+    _, got = G.forward_pre_mapped(ws, lazy, positions=pos, return_debug_data=True, noise_mode="const")
+    assert lazy._plain is None                                    # the fp32 feature tensors were never materialised
+    assert float((got["uvs"] - want["uvs"]).abs().max()) <= 2e-5
+    # a tapped geometry resolution (features returned at 64) keeps the fp32 route
+    _, a = G.forward_pre_mapped(ws, enc.lazy(geom), positions=pos, return_debug_data=True, return_features=[64], noise_mode="const")
+    _, b = G.forward_pre_mapped(ws, enc.encode(geom), positions=pos, return_debug_data=True, return_features=[64], noise_mode="const")
+    assert torch.equal(a["uvs"], b["uvs"]) and torch.equal(a["features64"], b["features64"])
+    # batch 1: no layer takes the hand-off (the producer runs on the small-image kernel): identical to the plain path
+    _, c1 = G.forward_pre_mapped(ws[:1], enc.lazy(geom[:1]), positions=pos[:1], return_debug_data=True, noise_mode="const")
+    _, c2 = G.forward_pre_mapped(ws[:1], enc.encode(geom[:1]), positions=pos[:1], return_debug_data=True, noise_mode="const")
+    assert torch.equal(c1["uvs"], c2["uvs"])

@@ -65,6 +65,9 @@ def run(kind, n, ci, co, res):
         # counts instead): epilogue = stamp 2 -> stamp 4
         us = us[:, [0, 1, 2, 4, 5]]
         names = ["prologue", "k-loop", "epilogue (4 rounds)", "store drain"]
+    elif H2OUT:
+        us = us[:, :5]                                       # (the H2-output epilogue returns after stamp 4)
+        names = ["prologue", "k-loop", "epilogue(LDS)", "slot stores"]
     else:
         us = us[:, :6]
         names = ["prologue", "k-loop", "epilogue(LDS)", "store issue", "store drain"]
