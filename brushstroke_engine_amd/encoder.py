@@ -5,10 +5,9 @@ The reference's ``sauto`` autoencoder (``forger/experimental/autoenc/simple_auto
 feature maps the generator consumes: the 16-channel bottleneck at R/8 and the first decoder stage (bilinear x2 +
 conv, 256 channels) at R/4.  It is a plain conv / eval-mode BatchNorm / LeakyReLU(0.01) stack with reflect padding.
 
-Round-1 status: evaluated with PyTorch-ROCm ops (MIOpen convolutions) -- plumbing, as SURVEY 8f prescribes until
-the hand-written kernels exist; end-to-end numbers that include it are reported separately from the generator-only
-headline.  State-dict keys equal the reference's (``encoder.model.{i}.conv.{0,1}.*``, ``decoder.model.{i}...``) so
-``strong.pt``-style checkpoints load unchanged.
+Evaluated by hand-written gfx950 kernels only (``HipGeometryEncoder`` on ``csrc/nb_encoder.hip``): there is no
+PyTorch / MIOpen module of it in this package (patch sizes the kernels do not tile raise).  State-dict keys equal the
+reference's (``encoder.model.{i}.conv.{0,1}.*``, ``decoder.model.{i}...``) so ``strong.pt``-style checkpoints load unchanged.
 """
 from __future__ import annotations
 
@@ -16,111 +15,29 @@ from typing import Dict, List, Optional
 
 import numpy as np
 import torch
-import torch.nn as nn
 
 
-class _SingleConvolution(nn.Module):
-    """conv (reflect padding) -> BatchNorm -> LeakyReLU(0.01)   (simple_autoencoder.py:88-103, neg_slope=None)."""
-
-    def __init__(self, in_ch, out_ch, kernel_size=3, padding=1, stride=1):
-        super().__init__()
-        self.conv = nn.Sequential(nn.Conv2d(in_ch, out_ch, kernel_size, padding=padding, stride=stride, padding_mode="reflect"),
-                                  nn.BatchNorm2d(out_ch), nn.LeakyReLU(inplace=True))
-
-    def forward(self, x):
-        return self.conv(x)
+# state_dict keys and shapes of the reference's ``sauto`` autoencoder (simple_autoencoder.py:155-199, defaults of
+# add_model_flags: pre 64 @7x7, down 128,256,256, post 32,16, up 256,128,64, 1 channel in / out); every _SingleConvolution is
+# `conv.0` (Conv2d) + `conv.1` (BatchNorm2d), decoder stages are ScaleUp(`conv` = _SingleConvolution), `decoder.model.3` is the
+# final 1x1 conv.  Checked against the instantiated reference in tests/golden/make_golden_engine.py (strict load).
+def _conv_bn(prefix, o, i, k):
+    return [(f"{prefix}.0.weight", (o, i, k, k)), (f"{prefix}.0.bias", (o,)), (f"{prefix}.1.weight", (o,)), (f"{prefix}.1.bias", (o,)),
+            (f"{prefix}.1.running_mean", (o,)), (f"{prefix}.1.running_var", (o,)), (f"{prefix}.1.num_batches_tracked", ())]
 
 
-class _ScaleUp(nn.Module):
-    """bilinear x2 (align_corners=True) -> _SingleConvolution   (simple_autoencoder.py:106-121)."""
-
-    def __init__(self, in_ch, out_ch):
-        super().__init__()
-        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
-        self.conv = _SingleConvolution(in_ch, out_ch)
-
-    def forward(self, x):
-        return self.conv(self.up(x))
-
-
-class _Encoder(nn.Module):
-    def __init__(self, in_channels=1, pre=64, down=(128, 256, 256), post=(32, 16)):
-        super().__init__()
-        layers = [_SingleConvolution(in_channels, pre, kernel_size=7, stride=1, padding=3)]
-        f = [pre] + list(down)
-        for i in range(1, len(f)):
-            layers.append(_SingleConvolution(f[i - 1], f[i], kernel_size=3, stride=2, padding=1))
-        f = [f[-1]] + list(post)
-        for i in range(1, len(f)):
-            layers.append(_SingleConvolution(f[i - 1], f[i], kernel_size=3, stride=1, padding=1))
-        self.model = nn.Sequential(*layers)
-        self.emb_channels = post[-1]
-        self.num_down_layers = len(down)
-
-    def forward(self, x):
-        return self.model(x)
-
-
-class _Decoder(nn.Module):
-    def __init__(self, in_channels=16, out_channels=1, up=(256, 128, 64)):
-        super().__init__()
-        f = [in_channels] + list(up)
-        layers = [_ScaleUp(f[i - 1], f[i]) for i in range(1, len(f))]
-        if out_channels != f[-1]:
-            layers.append(nn.Conv2d(f[-1], out_channels, 1))
-        self.model = nn.Sequential(*layers)
-        self.up_layer_filters = list(up)
-        self.n_up = len(up)
-
-
-class GeometryEncoder(nn.Module):
-    """``AutoEncoder.encode`` of the reference for the default ``sauto`` flags."""
-
-    def __init__(self, preproc_type=None, encode_resolutions=(0, 1)):
-        super().__init__()
-        self.encoder = _Encoder()
-        self.decoder = _Decoder()
-        self.preproc_type = preproc_type
-        self.res = list(encode_resolutions)
-        self.eval().requires_grad_(False)
-
-    def feature_channels(self, res=0):
-        return ([self.encoder.emb_channels] + self.decoder.up_layer_filters)[res]
-
-    def featuremap_resolution(self, input_res, res=0):
-        return (input_res // (2 ** self.encoder.num_down_layers)) * (2 ** res)      # base.py:101-109
-
-    def preprocess(self, x):                                                          # base.py:30-52
-        if self.preproc_type in (None, "none"):
-            return x
-        if self.preproc_type == "-11inverse":
-            return (1 - x) * 2 - 1
-        if self.preproc_type == "inverse":
-            return 1 - x
-        raise RuntimeError(f'Unknown preprocessing type "{self.preproc_type}"')
-
-    @torch.no_grad()
-    def encode(self, geom, res=None) -> List[torch.Tensor]:
-        res = self.res if res is None else res
-        single = not isinstance(res, (list, tuple))
-        res_l = [res] if single else list(res)
-        enc = self.encoder(self.preprocess(geom))
-        results = [enc]
-        x = enc
-        for i in range(max(res_l)):                                                  # decode_partial, :251-261
-            assert i < self.decoder.n_up
-            x = self.decoder.model[i](x)
-            results.append(x)
-        return [results[r] for r in res_l]
+ENCODER_STATE_SHAPES = (
+    _conv_bn("encoder.model.0.conv", 64, 1, 7) + _conv_bn("encoder.model.1.conv", 128, 64, 3) + _conv_bn("encoder.model.2.conv", 256, 128, 3)
+    + _conv_bn("encoder.model.3.conv", 256, 256, 3) + _conv_bn("encoder.model.4.conv", 32, 256, 3) + _conv_bn("encoder.model.5.conv", 16, 32, 3)
+    + _conv_bn("decoder.model.0.conv.conv", 256, 16, 3) + _conv_bn("decoder.model.1.conv.conv", 128, 256, 3)
+    + _conv_bn("decoder.model.2.conv.conv", 64, 128, 3) + [("decoder.model.3.weight", (1, 64, 1, 1)), ("decoder.model.3.bias", (1,))])
 
 
 def random_encoder_state_dict(seed: int = 5) -> Dict[str, np.ndarray]:
     """Seeded synthetic encoder weights with the reference's key names (no encoder checkpoint ships with it)."""
-    m = GeometryEncoder()
     rs = np.random.RandomState(seed)
     sd = {}
-    for k, v in m.state_dict().items():
-        shp = tuple(v.shape)
+    for k, shp in ENCODER_STATE_SHAPES:
         if k.endswith("num_batches_tracked"):
             sd[k] = np.zeros(shp, np.int64)
         elif k.endswith("running_var"):
@@ -133,12 +50,6 @@ def random_encoder_state_dict(seed: int = 5) -> Dict[str, np.ndarray]:
         else:                                     # BatchNorm weight
             sd[k] = rs.uniform(0.8, 1.2, shp).astype(np.float32)
     return sd
-
-
-def build_encoder(state_dict: Dict[str, np.ndarray], preproc_type=None, device="cuda") -> GeometryEncoder:
-    m = GeometryEncoder(preproc_type=preproc_type)
-    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_dict.items()}, strict=True)
-    return m.to(device).eval()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -168,7 +79,8 @@ def pack_enc_weight_h3(w: np.ndarray) -> np.ndarray:
 class HipGeometryEncoder:
     """``AutoEncoder.encode(geom, res=[0, 1])`` on the hand-written gfx950 kernels: 8 launches per batch
     (stem, 3 stride-2 convs, 2 bottleneck convs, bilinear x2, decoder conv), BatchNorm folded on the host.
-    Same interface as ``GeometryEncoder``.  Patch sizes the kernels do not tile (R % 128 != 0) raise."""
+    Interface of the reference's ``AutoEncoder`` as the engine uses it (``encode``, ``feature_channels``,
+    ``featuremap_resolution``).  Patch sizes the kernels do not tile (R % 128 != 0) raise."""
 
     _PRE = {None: 0, "none": 0, "-11inverse": 1, "inverse": 2}
 

@@ -68,10 +68,9 @@ def main(argv=None) -> str:
         dist.init_process_group("nccl", device_id=device)
     cfg, gen_sd, enc_sd, preproc, _ = formats.load_engine_snapshot(args.gan_checkpoint)
     G = Generator(cfg, gen_sd).to(device)
-    if encoder.HipGeometryEncoder.supports(cfg.img_resolution):
-        enc = encoder.HipGeometryEncoder(enc_sd, preproc_type=preproc, device=device)
-    else:
-        enc = encoder.build_encoder(enc_sd, preproc_type=preproc, device=device)
+    if not encoder.HipGeometryEncoder.supports(cfg.img_resolution):
+        raise RuntimeError(f"the geometry-encoder kernels tile patches of 128 k pixels; this checkpoint paints {cfg.img_resolution}")
+    enc = encoder.HipGeometryEncoder(enc_sd, preproc_type=preproc, device=device)
     ops = painting.TileOps(G, enc)
     mapper = None
     if not args.no_uvs_mapping and args.uvs_calibration:

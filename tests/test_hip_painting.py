@@ -265,14 +265,6 @@ def test_render_stroke_graph_replay_equals_eager(eng, level):
         assert torch.equal(runs[0][1], runs[1][1])
 
 
-def test_torch_encoder_on_gpu_matches_reference(eng):
-    """The PyTorch-ROCm (MIOpen) module kept for patch sizes the HIP encoder does not tile."""
-    g = eng["g"]
-    f = encmod.build_encoder(eng["esd"], device="cuda").encode(torch.from_numpy(g["enc_in"]).cuda())
-    np.testing.assert_allclose(f[0].cpu().numpy(), g["enc_f0"], atol=1e-4)
-    np.testing.assert_allclose(f[1].cpu().numpy()[:, ::8], g["enc_f1"], atol=1e-4)
-
-
 def test_uvs_mapping_on_gpu(eng):
     """enable_uvs_mapping: sfactor calibration + the remap fused into the ToRGB launch, against the reference."""
     g = eng["g"]

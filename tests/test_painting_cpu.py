@@ -149,16 +149,18 @@ def test_otsu_and_geometry_preparation():
     assert (painting.prepare_geometry_image(255 - rgba[..., 3]) == g).all()      # gray input, same drawing
 
 
-def test_encoder_module_matches_reference(eng):
-    g = eng["g"]
-    m = encmod.build_encoder(eng["esd"], device="cpu")
-    f = m.encode(torch.from_numpy(g["enc_in"]))
-    np.testing.assert_allclose(f[0].numpy(), g["enc_f0"], atol=1e-6)
-    np.testing.assert_allclose(f[1].numpy()[:, ::8], g["enc_f1"], atol=1e-6)
-    assert m.feature_channels(0) == 16 and m.feature_channels(1) == 256
-    assert m.featuremap_resolution(128, 0) == 16 and m.featuremap_resolution(128, 1) == 32
+def test_encoder_state_table_and_errors(eng):
+    """The encoder's key / shape table (what random_encoder_state_dict fills and strong.pt-style checkpoints carry) and the
+    loud failures: no GPU -> no encoder (there is no torch / CPU module of it in the package)."""
+    sd = encmod.random_encoder_state_dict(5)
+    assert [k for k, _ in encmod.ENCODER_STATE_SHAPES] == list(sd.keys()) and len(sd) == 65
+    assert sd["decoder.model.0.conv.conv.0.weight"].shape == (256, 16, 3, 3) and sd["encoder.model.0.conv.0.weight"].shape == (64, 1, 7, 7)
+    assert not hasattr(encmod, "GeometryEncoder") and not hasattr(encmod, "build_encoder")
     with pytest.raises(RuntimeError):
-        encmod.GeometryEncoder(preproc_type="bogus").encode(torch.zeros(1, 1, 32, 32))
+        encmod.HipGeometryEncoder(sd, device="cpu")
+    with pytest.raises(RuntimeError):
+        encmod.HipGeometryEncoder(sd, preproc_type="bogus", device="cpu")
+    assert encmod.HipGeometryEncoder.supports(256) and encmod.HipGeometryEncoder.supports(128) and not encmod.HipGeometryEncoder.supports(96)
 
 
 def test_tile_ops_needs_gpu(eng):

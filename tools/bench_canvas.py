@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--conv-mode", default="f8")
     ap.add_argument("--breakdown", action="store_true")
-    ap.add_argument("--encoder", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--encoder", default="hip", choices=["hip"])
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -56,10 +56,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     cfg = cfgmod.style1_config(a.res)
     G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode=a.conv_mode).to("cuda")
-    if a.encoder == "hip":
-        enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5))
-    else:
-        enc = encmod.build_encoder(encmod.random_encoder_state_dict(5), device="cuda")
+    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5))
     ops = painting.TileOps(G, enc)
     helper = painting.PaintingHelper(ops, batch=a.batch)
     helper.set_feature_blending(a.level)
