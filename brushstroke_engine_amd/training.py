@@ -297,14 +297,29 @@ class GanLoss:
     need a deterministic forward.  Each phase switches ``requires_grad`` off on the network it does not optimise, the
     way the reference loop brackets a phase (training_loop_modified.py: ``phase.module.requires_grad_(True)`` ...
     ``requires_grad_(False)``), so a G phase runs none of D's weight-gradient kernels (and DDP reduces none).
-    ``augment_pipe`` = the ADA pipeline (:mod:`augment`).  Not ported: the forger geometry / stitching loss items."""
+    ``augment_pipe`` = the ADA pipeline (:mod:`augment`).  The forger phases: ``Ggeom`` / ``Ggeom-warm`` evaluate
+    ``geom_phase_losses`` / ``geom_warmstart_losses`` (strings of :mod:`forger_losses`, e.g. the shipped
+    ``'1.0*iou_inv(uvs)'``) on the generator's debug dict against the stroke geometry (loss_modified.py:181-203),
+    ``Gmain`` adds ``main_phase_losses``, and :meth:`accumulate_gradients_stitch` is the ``Gstitch`` phase
+    (loss_modified.py:108-138: two overlapping crops, composites judged by D, ``stitch_phase_losses``)."""
 
     def __init__(self, G: TrainableGenerator, D: TrainableDiscriminator, r1_gamma: float = 10.0, pl_batch_shrink: int = 2,
                  pl_decay: float = 0.01, pl_weight: float = 2.0, augment_pipe=None, style_mixing_prob: float = 0.9,
-                 noise_mode: str = "random"):
+                 noise_mode: str = "random", geom_phase_losses: str = "", main_phase_losses: str = "",
+                 geom_warmstart_losses: Optional[str] = None, stitch_phase_losses: str = "", stitcher=None,
+                 partial_loss_with_triband_input: bool = False):
+        from .forger_losses import ForgerLosses, RandomStitcher
         self._G, self.r1_gamma = G, r1_gamma
         self._D, self.augment_pipe = D, augment_pipe
         self.style_mixing_prob, self.noise_mode = style_mixing_prob, noise_mode
+        self.geom_phase_losses = ForgerLosses.create_from_string(geom_phase_losses)
+        self.main_phase_losses = ForgerLosses.create_from_string(main_phase_losses)
+        self.stitch_phase_losses = ForgerLosses.create_from_string(stitch_phase_losses)
+        self.geom_warmstart_losses = (ForgerLosses.create_from_string(geom_warmstart_losses) if geom_warmstart_losses is not None
+                                      else self.geom_phase_losses)
+        self.geom_phase_losses.set_partial_loss_with_triband_input(partial_loss_with_triband_input)
+        self.main_phase_losses.set_partial_loss_with_triband_input(partial_loss_with_triband_input)
+        self.stitcher = stitcher if stitcher is not None else RandomStitcher()
         self.real_sign_sum, self.real_sign_count = 0.0, 0          # 'Loss/signs/real': what ADA adapts p on
         self.pl_batch_shrink, self.pl_decay, self.pl_weight = pl_batch_shrink, pl_decay, pl_weight
         self.pl_mean = torch.zeros([], device=next(G.parameters()).device)
@@ -333,21 +348,89 @@ class GanLoss:
         self.real_sign_sum, self.real_sign_count = 0.0, 0
         return float(self.augment_pipe.p)
 
+    @staticmethod
+    def all_reduce_gradients(module, group=None) -> int:
+        """Data parallelism of the training step (BASELINE config 5): average the accumulated gradients of ``module`` over the
+        ranks with ONE all-reduce of the flattened gradients (RCCL on GPUs; ~8 MB per network), before the optimiser step.
+        The reference gets the same average from DistributedDataParallel around each network
+        (training_loop_modified.py:243-252, ``misc.ddp_sync``); the explicit form does not depend on which parameters a phase
+        touches (the path-length phase differentiates w.r.t. an intermediate tensor, frozen networks take no gradient).
+        Returns the number of gradient elements reduced."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return 0
+        params = [p for p in module.parameters() if p.requires_grad]
+        for p in params:                                  # every rank must contribute the same tensors
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        flat = torch.cat([p.grad.flatten() for p in params])
+        dist.all_reduce(flat, group=group)
+        flat /= dist.get_world_size(group)
+        torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)      # as the reference loop does before a step
+        off = 0
+        for p in params:
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return off
+
+    def requires_frozen_generator(self) -> bool:
+        return self.geom_phase_losses.require_original_fake_image() or self.geom_warmstart_losses.require_original_fake_image()
+
     def accumulate_gradients(self, phase: str, real_img, geom_feature, gen_z, gain: float = 1.0, positions=None,
-                             pl_noise=None) -> Dict[str, float]:
-        assert phase in ("Gmain", "Greg", "Dmain", "Dreg", "Dall")
-        g_phase = phase in ("Gmain", "Greg")
+                             pl_noise=None, real_geom=None, G_orig=None) -> Dict[str, float]:
+        assert phase in ("Gmain", "Greg", "Ggeom", "Ggeom-warm", "Dmain", "Dreg", "Dall")
+        g_phase = phase in ("Gmain", "Greg", "Ggeom", "Ggeom-warm")
         self._unwrap(self._G).requires_grad_(g_phase)
         self._unwrap(self._D).requires_grad_(not g_phase)
         try:
-            return self._accumulate(phase, real_img, geom_feature, gen_z, gain, positions, pl_noise)
+            return self._accumulate(phase, real_img, geom_feature, gen_z, gain, positions, pl_noise, real_geom, G_orig)
         finally:
             self._unwrap(self._G).requires_grad_(True)
             self._unwrap(self._D).requires_grad_(True)
 
-    def _accumulate(self, phase, real_img, geom_feature, gen_z, gain, positions, pl_noise) -> Dict[str, float]:
+    def accumulate_gradients_stitch(self, geom_feature1, geom_feature2, crop1, crop2, gen_z, gain: float = 1.0,
+                                    positions1=None) -> Dict[str, float]:
+        """``Gstitch`` (loss_modified.py:108-138; the loop runs it every ``stitch_interval`` iterations,
+        training_loop_modified.py:264-301): the generator paints two overlapping crops of one drawing, each result is
+        composited into the other where they overlap, D judges plain and composite images, and ``stitch_phase_losses``
+        (e.g. ``gan(fake_composite)+l1(patch)``) is back-propagated into G."""
+        assert not self.stitch_phase_losses.is_empty()
+        self._unwrap(self._G).requires_grad_(True)
+        self._unwrap(self._D).requires_grad_(False)
+        try:
+            res = self.stitcher.generate_with_stitching(self._G, gen_z, None, geom_feature1, geom_feature2, crop1, crop2,
+                                                        positions1=positions1, noise_mode=self.noise_mode)
+            fake = torch.cat([res["fake1"], res["fake2"]], dim=0)
+            composite = torch.cat([res["fake1_composite"], res["fake2_composite"]], dim=0)
+            fake_logits, composite_logits = self.D(fake, None), self.D(composite, None)
+            data = {"fake": fake, "fake_logits": fake_logits, "fake_composite": composite, "fake_composite_logits": composite_logits,
+                    "patch1": res["patch1"], "patch2": res["patch2"]}
+            loss, vals = self.stitch_phase_losses.compute(data, None)
+            loss.mul(gain).backward()
+            stats = {f"Loss/forger/Gstitch/{k}": float(v.detach()) for k, v in vals.items()}
+            stats["Loss/forger/Gstitch/total"] = float(loss.detach())
+            return stats
+        finally:
+            self._unwrap(self._D).requires_grad_(True)
+
+    def _accumulate(self, phase, real_img, geom_feature, gen_z, gain, positions, pl_noise, real_geom=None, G_orig=None) -> Dict[str, float]:
         stats: Dict[str, float] = {}
         softplus = torch.nn.functional.softplus
+        if phase in ("Ggeom", "Ggeom-warm"):                              # loss_modified.py:181-203
+            losses = self.geom_warmstart_losses if phase == "Ggeom-warm" else self.geom_phase_losses
+            if not losses.is_empty():
+                frozen = losses.require_original_fake_image()
+                kw = dict(positions=positions, return_debug_data=True, noise_mode=self.noise_mode)
+                gen_img, data = self._G(gen_z, None, geom_feature, style_mixing_prob=0 if frozen else self.style_mixing_prob, **kw)
+                data = dict(data)
+                data["fake_img"] = gen_img
+                if frozen:
+                    with torch.no_grad():
+                        data["fake_orig"] = G_orig(gen_z, None, geom_feature, positions=positions, style_mixing_prob=0,
+                                                   noise_mode=self.noise_mode)
+                loss, vals = losses.compute(data, real_geom)
+                loss.mean().backward()                                    # (no gain: loss_modified.py:203)
+                stats.update({f"Loss/forger/{phase}/{k}": float(v.detach()) for k, v in vals.items()})
         if phase == "Greg" and self.pl_weight != 0:                       # path-length regularisation, loss_modified.py:205-221
             b = max(1, gen_z.shape[0] // self.pl_batch_shrink)
             gen_img, data = self.G(gen_z[:b], None, [g[:b] for g in geom_feature],
@@ -362,10 +445,14 @@ class GanLoss:
             (gen_img[:, 0, 0, 0] * 0 + pl_penalty * self.pl_weight).mean().mul(gain).backward()
             stats["Loss/pl_penalty"] = float(pl_penalty.mean().detach())
         if phase == "Gmain":                                              # maximise logits of generated images
-            gen_img = self.G(gen_z, None, geom_feature, positions=positions)
+            gen_img, gen_data = self.G(gen_z, None, geom_feature, positions=positions, return_debug_data=True)
             loss = softplus(-self.D(gen_img, None))
-            loss.mean().mul(gain).backward()
             stats["Loss/G/loss"] = float(loss.mean().detach())
+            if not self.main_phase_losses.is_empty():                     # loss_modified.py:170-175
+                extra, vals = self.main_phase_losses.compute(gen_data, real_geom)
+                loss = loss + extra
+                stats.update({f"Loss/forger/Gmain/{k}": float(v.detach()) for k, v in vals.items()})
+            loss.mean().mul(gain).backward()
         if phase in ("Dmain", "Dall"):                                    # minimise logits of generated images
             with torch.no_grad():
                 gen_img = self.G(gen_z, None, geom_feature, positions=positions)

@@ -38,3 +38,18 @@ def test_bench_fails_nonzero_when_a_rank_dies():
              {"NB_BENCH_SHARE_GPU": "1", "NB_BENCH_BACKEND": "gloo", "NB_BENCH_FAIL_RANK": "1"}, timeout=600)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_train_bench_two_ranks_gradient_all_reduce():
+    """BASELINE config 5's data-parallel step with its N>1 launch path on a one-GPU box: `tools/bench_train.py --gpus 2`
+    launches two ranks itself; every optimiser step is preceded by the all-reduce of the flattened gradients (gloo here,
+    RCCL on a multi-GPU node), incl. the path-length, R1 and forger geometry phases."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"NB_BENCH_SHARE_GPU": "1", "NB_BENCH_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_train.py"), "--gpus", "2", "--res", "128", "--batch", "2",
+                        "--iters", "4", "--warmup", "1", "--geom-interval", "2"], env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "all-reduce" in out["config"]["parallelism"]

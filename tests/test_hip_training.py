@@ -215,3 +215,64 @@ def test_ddp_gradients_equal_full_batch(tmp_path):
     for k in want:
         scale = max(float(np.abs(want[k]).max()), 1e-8)
         assert float(np.abs(got[k] - want[k]).max()) <= 1e-4 * scale + 1e-9, k
+
+
+def test_forger_geometry_and_stitch_phases():
+    """Ggeom / Ggeom-warm / Gstitch of ForgerLoss (loss_modified.py:108-138, 181-203) on the differentiable HIP generator
+    and discriminator: the geometry phase's loss equals the loss items evaluated on the CPU oracle's uvs, its gradients
+    equal oracle autograd, only G receives gradients; the stitch phase composites two overlapping crops and trains G
+    through a frozen D."""
+    from brushstroke_engine_amd.training import (TrainableGenerator, TrainableDiscriminator, GanLoss, random_discriminator_state_dict)
+    from brushstroke_engine_amd import forger_losses as fl
+    from oracle import neube_oracle as orc
+    cfg, sd, z, geom, pos = _setup(n=2)
+    dev = torch.device("cuda:0")
+    G = TrainableGenerator(cfg, sd, dev)
+    D = TrainableDiscriminator(random_discriminator_state_dict(32, 3, channel_base=512, channel_max=24, seed=3, bias_std=0.1),
+                               32, 3, channel_base=512, channel_max=24, conv_clamp=256, device=dev)
+    loss = GanLoss(G, D, geom_phase_losses="1.0*iou_inv(uvs)", geom_warmstart_losses="1.0*iou_inv(uvs)+1.0*iou(u)",
+                   stitch_phase_losses="gan(fake_composite)+0.5*l1(patch)", main_phase_losses="0.1*iou(u)",
+                   style_mixing_prob=0, noise_mode="const", stitcher=fl.RandomStitcher(crop_margin=2, min_overlap=8))
+    zt = torch.from_numpy(z).to(dev); gt = [torch.from_numpy(g).to(dev) for g in geom]
+    pt = torch.from_numpy(pos).to(dev)
+    truth = (torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(1)) > 0.3).float()
+    # oracle under autograd: the same phase on CPU
+    O = orc.OracleGenerator(cfg, sd)
+    keys = [k for k in O.sd if k.endswith((".weight", ".bias", ".const", ".noise_strength", ".color_bias"))]
+    for k in keys:
+        O.sd[k].requires_grad_(True)
+    npos = ((pos % cfg.img_resolution) / (cfg.img_resolution - 1)).astype(np.float32)
+    _, dbg = O.synthesis(O.mapping(torch.tensor(z)), [torch.tensor(g_) for g_ in geom], return_debug_data=True, norm_noise_positions=npos)
+    want, _ = fl.ForgerLosses.create_from_string("1.0*iou_inv(uvs)+1.0*iou(u)").compute({"uvs": dbg["uvs"]}, truth)
+    grads_o = torch.autograd.grad(want, [O.sd[k] for k in keys], allow_unused=True)
+    st = loss.accumulate_gradients("Ggeom-warm", None, gt, zt, positions=pt, real_geom=truth.to(dev))
+    got = st["Loss/forger/Ggeom-warm/iou_inv_uvs"] + st["Loss/forger/Ggeom-warm/iou_u"]
+    assert abs(got - float(want.detach())) <= 1e-4 * abs(float(want.detach()))
+    params = dict(G.named_reference_parameters())
+    checked, worst = 0, {}
+    for k, go in zip(keys, grads_o):
+        gp = params[k].grad
+        if go is None or float(go.abs().max()) < 1e-12:
+            continue
+        assert gp is not None, k
+        worst[k] = float((gp.cpu() - go).abs().max()) / float(go.abs().max())
+        checked += 1
+    bad = {k: round(v, 5) for k, v in worst.items() if v > 1e-3}
+    assert not bad, bad
+    assert checked >= 20 and all(p.grad is None for p in D.parameters())
+    for p in G.parameters():
+        p.grad = None
+    st = loss.accumulate_gradients("Ggeom", None, gt, zt, positions=pt, real_geom=truth.to(dev))
+    assert set(st) == {"Loss/forger/Ggeom/iou_inv_uvs"} and np.isfinite(list(st.values())[0])
+    st = loss.accumulate_gradients("Gmain", None, gt, zt, positions=pt, real_geom=truth.to(dev))
+    assert "Loss/forger/Gmain/iou_u" in st and np.isfinite(st["Loss/G/loss"])
+    for p in G.parameters():
+        p.grad = None
+    # stitch phase: two overlapping crops (their geometry features stand for the two crops of one drawing)
+    g2 = [torch.from_numpy(a).to(dev) for a in synthetic.geom_features(cfg, 2, 8)]
+    st = loss.accumulate_gradients_stitch(gt, g2, (40, 44, 32, 32), (48, 38, 32, 32), zt, gain=1.0, positions1=pt)
+    assert np.isfinite(st["Loss/forger/Gstitch/total"]) and {"Loss/forger/Gstitch/gan_fake_composite", "Loss/forger/Gstitch/l1_patch"} <= set(st)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in G.parameters() if p.requires_grad and p.numel() > 1)
+    assert all(p.grad is None for p in D.parameters()) and all(p.requires_grad for p in D.parameters())
+    with pytest.raises(RuntimeError, match="LPIPS"):
+        GanLoss(G, D, stitch_phase_losses="lpips(patch)")

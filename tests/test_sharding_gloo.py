@@ -141,3 +141,48 @@ def test_halo_plan_irregular_tiles():
     assert rect_subtract((0, 0, 4, 4), (1, 1, 3, 3)) == [(0, 0, 1, 4), (3, 0, 4, 4), (1, 0, 3, 1), (1, 3, 3, 4)]
     assert rect_subtract((0, 0, 4, 4), (5, 5, 6, 6)) == [(0, 0, 4, 4)]
     assert rect_subtract((0, 0, 4, 4), (0, 0, 4, 4)) == []
+
+
+# ---------------------------------------------------------------- training: gradient all-reduce (BASELINE config 5)
+def _grad_worker(rank, world, port, tmp):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from brushstroke_engine_amd.training import GanLoss
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        m[2].bias.requires_grad_(False)                                  # a frozen parameter takes no part
+        x = torch.arange(24, dtype=torch.float32).reshape(4, 6) / 10
+        shard = x[rank * 2:(rank + 1) * 2]
+        (m(shard) ** 2).mean().backward()
+        m[0].bias.grad = None if rank == 1 else m[0].bias.grad          # a rank without a gradient contributes zeros
+        n = GanLoss.all_reduce_gradients(m)
+        assert n == sum(p.numel() for p in m.parameters() if p.requires_grad)
+        if rank == 0:
+            torch.save({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, os.path.join(tmp, "g.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_gradient_all_reduce_gloo(tmp_path):
+    """GanLoss.all_reduce_gradients: the ranks' gradients are averaged with one all-reduce of the flattened gradients --
+    equal to the gradient of the mean loss over the whole batch."""
+    mp.spawn(_grad_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "g.pt")
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    x = torch.arange(24, dtype=torch.float32).reshape(4, 6) / 10
+    (0.5 * (m(x[:2]) ** 2).mean() + 0.5 * (m(x[2:]) ** 2).mean()).backward()
+    for k, p in m.named_parameters():
+        if k == "2.bias":
+            assert k not in got
+        elif k == "0.bias":                                              # rank 1 contributed zeros for this one
+            m2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+            m2.load_state_dict(m.state_dict())
+            (m2(x[:2]) ** 2).mean().backward()
+            assert torch.allclose(got[k], 0.5 * m2[0].bias.grad, atol=1e-6)
+        else:
+            assert torch.allclose(got[k], p.grad, atol=1e-6), k
