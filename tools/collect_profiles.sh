@@ -29,6 +29,7 @@ python tools/trace_b1_summary.py $O/b1trace > $O/b1_trace_summary.txt 2>&1; rm -
 python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 --breakdown > $O/canvas_4096_r256_l2.json 2>/dev/null
 python tools/bench_canvas.py --size 4096 --res 256 --level 0 --steps 3 --breakdown > $O/canvas_4096_r256_l0.json 2>/dev/null
 python tools/bench_canvas.py --size 1024 --res 128 --level 2 --steps 3 --breakdown > $O/canvas_1024_r128_l2.json 2>/dev/null
+python tools/bench_lamali.py > $O/lamali.json 2> $O/lamali.err
 python tools/bench_train.py > $O/train_bench.json 2> $O/train_bench.err
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 rm -rf $O/stats $O/pmc_hit $O/pmc_fetch $O/pmc_write $O/pmc_mfma
