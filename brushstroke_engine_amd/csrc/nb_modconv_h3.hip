@@ -924,16 +924,16 @@ struct H3Up2Params {
 
 // TQH = quad rows per tile: NB_H3_TQH (12) for throughput; 5 (7 x 34 = 238 positions = 8 column blocks, one per wave)
 // when the large tiles would leave most of the chip idle - the batch-1 / interactive configuration.
-// NW_ = waves per workgroup: 8 (two per SIMD, <= 256 registers each) or 4 (one per SIMD with the whole 512-entry register
-// file: 4 position blocks x 4 phases = 256 accumulators per wave, the shared weight fragments are read once per 4 blocks
-// instead of once per 2, and a wave has room to keep the next tap group's fragments in flight under the current MFMAs)
-// OUTM = output mode: 0 = fp32 NCHW, 1 = the consumer's H2 tensor, 2 = the consumer's tensor in the "f8" operand format
-// (TQH = 5 with NW_ = 4: two 4-wave workgroups share a CU, so one's VALU epilogue runs beside the other's K loop)
-template <bool F8, int TQH, int NW_ = 8, int OUTM = 0>
-__global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && TQH == NB_H3_TQH_SMALL) ? 2 : 1) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
+// OUTM = output mode: 0 = fp32 NCHW, 1 = the consumer's H2 tensor, 2 = the consumer's tensor in the "f8" operand format.
+// TQW_ = quad columns per tile: 32, or 16 for 16-wide inputs (b32.conv0 at large batch: 8 x 16 tiles = 10 x 18 = 180
+// positions = 6 blocks, one per wave).
+// (Tried and dropped, DESIGN.md 6: a one-wave-per-SIMD form with 256 accumulators per wave and a hand-ordered K loop, and two
+//  4-wave workgroups per CU on 5-row tiles -- neither was faster.)
+template <bool F8, int TQH, int OUTM = 0, int TQW_ = 32>
+__global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
     nb_stagger(p.stagger_ticks, 256);
-    constexpr int NW = NW_, NT = NW_ * 64, TQW = 32, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
+    constexpr int NW = 8, NT = 512, TQW = TQW_, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
     constexpr int NBJ = (NBLK + NW - 1) / NW;         // blocks per wave (2)
     constexpr int XR = TQH + 3, XS = TQW + 3;         // halo tile 15 x 35 input pixels
@@ -1052,123 +1052,6 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && TQH == NB_H3_TQH_SMALL) ? 2 
     constexpr int kPha[9] = {3, 2, 1, 0, 2, 0, 1, 0, 0};                 // kTapPhase[kOrd[i]]
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
-    if constexpr (F8 && NW == 4 && TQH == NB_H3_TQH) {
-        // ---- one wave per SIMD: software-pipelined K loop -------------------------------------------------------
-        // A wave carries 4 position blocks x 4 phases (256 accumulators) and owns its SIMD's matrix pipe, so the LDS
-        // and DMA-issue latencies have to be covered inside the wave.  The matrix instructions are volatile asm
-        // statements with a memory clobber, i.e. the program order below IS the issue order: fragment reads for a
-        // later stage and the next chunk's LDS-DMA issues sit in the shadows of the 64-cycle fp8 instructions.
-        // Same products in the same order per accumulator as the 8-wave form (bit-identical results):
-        //   P0a: ph0 += A8 B0 + A6 B1 + f8(A8,A6 | B0,B1)     P2: ph2 += A5 B0 + A3 B1 + f8(..)     P3: ph3 += A4 B0 + f8(A4,0 | B0,.)
-        //   P1:  ph1 += A7 B0 + A1 BX + f8(A7,A1 | B0,BX)     P0b: ph0 += A2 BX + A0 BY + f8(A2,A0 | BX,BY)    (BX = offset XS, BY = XS+1)
-        // fp8 operand tuples are 8 consecutive registers: the low halves are kept as [B0 B1] and [B0' BX BY] (B0 is read
-        // twice) so that every pair is adjacent without register moves and no stage reloads a register another stage reads.
-        typedef int i32x12 __attribute__((ext_vector_type(12)));
-        const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
-        h8 bh0[NBJ], bh1[NBJ], bhx[NBJ];      // bh1: offset 1, from stage 2 on offset XS + 1
-        i32x8 bl01[NBJ];
-        i32x12 blx[NBJ];                              // [B0' | BX | BY]
-        h8 a8h, a6h, a5h, a3h, a4h, a7h, a1h, a2h, a0h;
-        i32x8 a86l, a53l, a4l, a71l, a20l;
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 12; ++r) blx[j][r] = 0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) a4l[r] = 0;
-        // builtins + a scheduling fence after every statement group: the compiler keeps this order and counts the LDS reads
-#define NB_SB __builtin_amdgcn_sched_barrier(0)
-#define NB_M16(c_, a_, b_) { c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0); NB_SB; }
-#define NB_MF8(c_, a_, b_) { c_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c_, 0, 0, 0, sa, 0, sb); NB_SB; }
-#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
-#define NB_LDA2(st_, tA, tB, hA, hB, l2) { hA = st_[aoff + (tA) * 128]; hB = st_[aoff + (tB) * 128]; NB_Q(l2, 0, st_[aoff + (tA) * 128 + 32]); NB_Q(l2, 1, st_[aoff + (tB) * 128 + 32]); NB_SB; }
-        auto issue_x1 = [&](int c, h8* st_, int i) {
-            // (branch-free source select: the loop body must stay one basic block)
-            const int cg = 2 * c + (xpl[i] >> 1);
-            const unsigned long long a_ = (unsigned long long)(xn + (size_t)(4 * c + xpl[i]) * HW8 + xsp[i]);
-            const unsigned long long z_ = (unsigned long long)p.zeros;
-            const unsigned long long m_ = 0ull - (unsigned long long)(xsp[i] >= 0 && cg < p.c8);
-            const _Float16* src = reinterpret_cast<const _Float16*>((a_ & m_) | (z_ & ~m_));
-            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st_ + xdst[i]), 16, 0, 0);
-            NB_SB;
-        };
-        auto issue_w1 = [&](int c, h8* st_, int i) {
-            int q = i * NW + wv;
-            q = q < NWP ? q : NWP - 1;
-            const int e = q * 64 + lane;
-            const int row = e >> 5, j = e & 31;
-            const _Float16* src = p.wts + (((size_t)c * 36 + row) * p.co_ld + co0 + j) * 8;
-            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st_ + 4 * XPL + q * 64), 16, 0, 0);
-            NB_SB;
-        };
-        static_assert(NXPW == 9 && NWPW == 5 && NBJ == 4, "the interleaving below is written for 9 + 5 DMA pieces and 4 blocks per wave");
-        auto rd_b01 = [&](const h8* st_, int j) {
-            bh0[j] = st_[boff[j]]; bh1[j] = st_[boff[j] + 1];
-            NB_Q(bl01[j], 0, st_[boff[j] + XPL]); NB_Q(bl01[j], 1, st_[boff[j] + XPL + 1]);
-            NB_SB;
-        };
-        NB_LDA2(ring, 8, 6, a8h, a6h, a86l);
-        rd_b01(ring, 0);
-        rd_b01(ring, 1);
-        for (int c = 0; c < NC; ++c) {
-            const h8* st = ring + (c & 1) * STAGE;
-            h8* nst = ring + ((c + 1) & 1) * STAGE;
-            const int cn = c + 1 < NC ? c + 1 : NC - 1;       // (last chunk: a harmless re-copy keeps the loop body branch-free)
-            // ---- stage 0: P0a; reads of blocks 1..3 for this stage, then A5 A3 A4 and BX for the later ones; x pieces 0..4
-            NB_M16(acc[0][0], a8h, bh0[0]); rd_b01(st, 2); NB_M16(acc[0][0], a6h, bh1[0]); NB_MF8(acc[0][0], a86l, bl01[0]);
-            issue_x1(cn, nst, 0);
-            NB_M16(acc[1][0], a8h, bh0[1]); rd_b01(st, 3); NB_M16(acc[1][0], a6h, bh1[1]); NB_MF8(acc[1][0], a86l, bl01[1]);
-            issue_x1(cn, nst, 1);
-            NB_M16(acc[2][0], a8h, bh0[2]); NB_M16(acc[2][0], a6h, bh1[2]); NB_MF8(acc[2][0], a86l, bl01[2]);
-            NB_LDA2(st, 5, 3, a5h, a3h, a53l); issue_x1(cn, nst, 2);
-            NB_M16(acc[3][0], a8h, bh0[3]); NB_M16(acc[3][0], a6h, bh1[3]); NB_MF8(acc[3][0], a86l, bl01[3]);
-            a4h = st[aoff + 4 * 128]; NB_Q(a4l, 0, st[aoff + 4 * 128 + 32]); issue_x1(cn, nst, 3);
-            // ---- stage 1: P2, P3; reads B0' BX (then BY) and A7 A1; x pieces 4..8
-            NB_M16(acc[0][2], a5h, bh0[0]); NB_M16(acc[0][2], a3h, bh1[0]); NB_MF8(acc[0][2], a53l, bl01[0]);
-            NB_Q(blx[0], 0, st[boff[0] + XPL]); bhx[0] = st[boff[0] + XS]; NB_Q(blx[0], 1, st[boff[0] + XPL + XS]); issue_x1(cn, nst, 4);
-            NB_M16(acc[1][2], a5h, bh0[1]); NB_M16(acc[1][2], a3h, bh1[1]); NB_MF8(acc[1][2], a53l, bl01[1]);
-            NB_Q(blx[1], 0, st[boff[1] + XPL]); bhx[1] = st[boff[1] + XS]; NB_Q(blx[1], 1, st[boff[1] + XPL + XS]); issue_x1(cn, nst, 5);
-            NB_M16(acc[2][2], a5h, bh0[2]); NB_M16(acc[2][2], a3h, bh1[2]); NB_MF8(acc[2][2], a53l, bl01[2]);
-            NB_Q(blx[2], 0, st[boff[2] + XPL]); bhx[2] = st[boff[2] + XS]; NB_Q(blx[2], 1, st[boff[2] + XPL + XS]); issue_x1(cn, nst, 6);
-            NB_M16(acc[3][2], a5h, bh0[3]); NB_M16(acc[3][2], a3h, bh1[3]); NB_MF8(acc[3][2], a53l, bl01[3]);
-            NB_Q(blx[3], 0, st[boff[3] + XPL]); bhx[3] = st[boff[3] + XS]; NB_Q(blx[3], 1, st[boff[3] + XPL + XS]); issue_x1(cn, nst, 7);
-            NB_M16(acc[0][3], a4h, bh0[0]); NB_MF8(acc[0][3], a4l, bl01[0]);
-            NB_LDA2(st, 7, 1, a7h, a1h, a71l); issue_x1(cn, nst, 8);
-            NB_M16(acc[1][3], a4h, bh0[1]); NB_MF8(acc[1][3], a4l, bl01[1]);
-            bh1[0] = st[boff[0] + XS + 1]; NB_Q(blx[0], 2, st[boff[0] + XPL + XS + 1]); issue_w1(cn, nst, 0);
-            NB_M16(acc[2][3], a4h, bh0[2]); NB_MF8(acc[2][3], a4l, bl01[2]);
-            bh1[1] = st[boff[1] + XS + 1]; NB_Q(blx[1], 2, st[boff[1] + XPL + XS + 1]); issue_w1(cn, nst, 1);
-            NB_M16(acc[3][3], a4h, bh0[3]); NB_MF8(acc[3][3], a4l, bl01[3]);
-            bh1[2] = st[boff[2] + XS + 1]; NB_Q(blx[2], 2, st[boff[2] + XPL + XS + 1]); issue_w1(cn, nst, 2);
-            // ---- stage 2: P1; reads A2 A0; w pieces 3, 4
-            NB_M16(acc[0][1], a7h, bh0[0]); NB_M16(acc[0][1], a1h, bhx[0]);
-            NB_MF8(acc[0][1], a71l, __builtin_shufflevector(blx[0], blx[0], 0, 1, 2, 3, 4, 5, 6, 7));
-            bh1[3] = st[boff[3] + XS + 1]; NB_Q(blx[3], 2, st[boff[3] + XPL + XS + 1]); issue_w1(cn, nst, 3);
-            NB_M16(acc[1][1], a7h, bh0[1]); NB_M16(acc[1][1], a1h, bhx[1]);
-            NB_MF8(acc[1][1], a71l, __builtin_shufflevector(blx[1], blx[1], 0, 1, 2, 3, 4, 5, 6, 7));
-            NB_LDA2(st, 2, 0, a2h, a0h, a20l); issue_w1(cn, nst, 4);
-            NB_M16(acc[2][1], a7h, bh0[2]); NB_M16(acc[2][1], a1h, bhx[2]);
-            NB_MF8(acc[2][1], a71l, __builtin_shufflevector(blx[2], blx[2], 0, 1, 2, 3, 4, 5, 6, 7));
-            NB_M16(acc[3][1], a7h, bh0[3]); NB_M16(acc[3][1], a1h, bhx[3]);
-            NB_MF8(acc[3][1], a71l, __builtin_shufflevector(blx[3], blx[3], 0, 1, 2, 3, 4, 5, 6, 7));
-            // ---- stage 3: P0b, then the chunk hand-over (chunk c+1 has landed everywhere; its first fragments)
-#pragma unroll
-            for (int j = 0; j < NBJ; ++j) {
-                NB_M16(acc[j][0], a2h, bhx[j]); NB_M16(acc[j][0], a0h, bh1[j]);
-                NB_MF8(acc[j][0], a20l, __builtin_shufflevector(blx[j], blx[j], 4, 5, 6, 7, 8, 9, 10, 11));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            NB_LDA2(nst, 8, 6, a8h, a6h, a86l);
-            rd_b01(nst, 0);
-            rd_b01(nst, 1);
-        }
-#undef NB_Q
-#undef NB_LDA2
-#undef NB_M16
-#undef NB_MF8
-#undef NB_SB
-    } else
     for (int c = 0; c < NC; ++c) {
         h8* st = ring + (c % NST) * STAGE;
         if (NST == 3) {
@@ -1469,39 +1352,35 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ == 4 && TQH == NB_H3_TQH_SMALL) ? 2 
 static int g_force_tqh = -1;
 // developer / test hook: 0 = automatic tile choice, NB_H3_TQH or NB_H3_TQH_SMALL = force that tile height
 extern "C" void nb_debug_set_up2_tile(int tqh) { g_force_tqh = tqh; }
-template <int TQH, int NW, bool F8, int OUTM>
+template <int TQH, int TQW, bool F8, int OUTM>
 static int nb_up2_h3_launch1(const H3Up2Params& p, int n, size_t lds, void* stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<F8, TQH, NW, OUTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<F8, TQH, OUTM, TQW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<F8, TQH, NW, OUTM>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<F8, TQH, OUTM, TQW>), grid, dim3(512), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2_h3");
     return NB_OK;
 }
 
-template <int TQH, int NW = 8>
+template <int TQH, int TQW = 32>
 static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
+    p.tiles_x = p.w / TQW;
     p.tiles_y = (p.h + TQH - 1) / TQH;
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
-    constexpr int XPL = (((TQH + 3) * 35 + 63) / 64) * 64;
-    constexpr int NBLK_ = ((TQH + 2) * 34 + 31) / 32;
+    constexpr int XPL = (((TQH + 3) * (TQW + 3) + 63) / 64) * 64;
+    constexpr int NBLK_ = ((TQH + 2) * (TQW + 2) + 31) / 32;
     constexpr size_t lds_stage = (size_t)(TQH == NB_H3_TQH_SMALL ? NB_H3_STAGES_SMALL : NB_H3_STAGES) * (4 * XPL + 36 * 32) * 16;
-    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * TQH * 32 * 16;   // FIR slots + H2 slots (hi, 2 x lo)
+    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * TQH * TQW * 16;   // FIR slots + H2 slots (hi, 2 x lo)
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
-    if constexpr (NW == 4) {          // the one-wave-per-SIMD form exists for the f8 operand format only
-        return outm == 2 ? nb_up2_h3_launch1<TQH, 4, true, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, 4, true, 1>(p, n, lds, stream)
-                                                                                            : nb_up2_h3_launch1<TQH, 4, true, 0>(p, n, lds, stream);
-    } else {
-        if (in_fmt)
-            return outm == 2 ? nb_up2_h3_launch1<TQH, 8, true, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, 8, true, 1>(p, n, lds, stream)
-                                                                                                : nb_up2_h3_launch1<TQH, 8, true, 0>(p, n, lds, stream);
-        return outm == 2 ? nb_up2_h3_launch1<TQH, 8, false, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, 8, false, 1>(p, n, lds, stream)
-                                                                                             : nb_up2_h3_launch1<TQH, 8, false, 0>(p, n, lds, stream);
-    }
+    if (in_fmt)
+        return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, true, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, true, 1>(p, n, lds, stream)
+                                                                                              : nb_up2_h3_launch1<TQH, TQW, true, 0>(p, n, lds, stream);
+    return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, false, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, false, 1>(p, n, lds, stream)
+                                                                                           : nb_up2_h3_launch1<TQH, TQW, false, 0>(p, n, lds, stream);
 }
 
 static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
@@ -1515,7 +1394,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
                "modconv3x3_up2_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up2_h3: bad sizes");
-    NB_REQUIRE(w % 32 == 0 && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0 (got %dx%d)", h, w);
+    NB_REQUIRE((w % 32 == 0 || w == 16) && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0 or w == 16 (got %dx%d)", h, w);
     NB_REQUIRE(alpha >= 0.f && alpha <= 1.f, "modconv3x3_up2_h3: leaky-ReLU slope must lie in [0, 1] (got %g)", alpha);
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up2_h3: pointers must be 16-byte aligned");
     H3Up2Params p;
@@ -1530,14 +1409,12 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     p.tiles_x = w / 32; p.slices = (c_out + 31) / 32;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.out_f8 = out_fmt;
+    if (w == 16) return nb_up2_h3_launch<8, 16>(p, n, in_fmt, stream);      // 16-wide inputs: 8 x 16 quad tiles
     // tile height: the 12-row tiles unless they leave the chip mostly idle (batch-1 / interactive), then 5-row tiles
     static const int env_tqh = getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0;
     const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
     const long wgs_big = (long)n * p.tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * p.slices;
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
-    static const int env_nw = getenv("NB_UP2_NW") ? atoi(getenv("NB_UP2_NW")) : 8;
-    if (!small_tiles && env_nw == 4 && in_fmt == 1) return nb_up2_h3_launch<NB_H3_TQH, 4>(p, n, in_fmt, stream);
-    if (!small_tiles && env_nw == 45 && in_fmt == 1) return nb_up2_h3_launch<NB_H3_TQH_SMALL, 4>(p, n, in_fmt, stream);
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }
 

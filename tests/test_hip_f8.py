@@ -21,7 +21,7 @@ def _conv_ref(x, w, st, up):
 
 
 @pytest.mark.parametrize("up,ci,co,res", [(1, 64, 64, 64), (1, 128, 128, 32), (1, 144, 96, 64), (2, 128, 64, 64),
-                                           (2, 384, 128, 64), (2, 144, 128, 64)])
+                                           (2, 384, 128, 64), (2, 144, 128, 64), (2, 128, 128, 32)])
 def test_f8_kernels_vs_float64(up, ci, co, res):
     """One layer, f8 operands, fp32 output: error against float64 at the level of the fp8 correction terms
     (2^-11 * 2^-4 relative per product), ~20x the h3 error and ~30x below a plain f16 evaluation."""
@@ -51,7 +51,8 @@ def test_f8_kernels_vs_float64(up, ci, co, res):
     assert errs[0] <= 2e-6 * scale and errs[1] <= 4e-5 * scale, (errs, scale)
 
 
-@pytest.mark.parametrize("up,ci,co,res,c_next", [(1, 64, 64, 64, 64), (1, 128, 128, 32, 384), (2, 128, 64, 64, 64), (2, 144, 128, 64, 128)])
+@pytest.mark.parametrize("up,ci,co,res,c_next", [(1, 64, 64, 64, 64), (1, 128, 128, 32, 384), (2, 128, 64, 64, 64), (2, 144, 128, 64, 128),
+                                                  (2, 128, 128, 32, 128)])
 def test_f8_handoff_equals_pack(up, ci, co, res, c_next):
     """f8-format output of a producer == fp32 output followed by nb_pack_h2f8_f32 with the consumer's styles
     (same value; the fp8 bytes may differ where the product is an exact tie, so the decoded planes are compared)."""

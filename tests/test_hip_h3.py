@@ -91,7 +91,8 @@ def test_up2_h2_output_vs_oracle(dev, shape):
     assert maxerr(got, want) <= 5e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 144, 128, 32, 32), (1, 384, 128, 64, 64), (1, 128, 64, 128, 128), (2, 40, 48, 16, 32)])
+@pytest.mark.parametrize("shape", [(2, 144, 128, 32, 32), (1, 384, 128, 64, 64), (1, 128, 64, 128, 128), (2, 40, 48, 16, 32),
+                                   (3, 128, 128, 16, 16), (2, 48, 40, 24, 16)])
 def test_up2_h3_vs_oracle(dev, shape):
     from brushstroke_engine_amd import ops
     from oracle import neube_oracle as orc
@@ -117,7 +118,7 @@ def test_up2_h3_vs_oracle(dev, shape):
 
 # ---------------------------------------------------------------- fused H2 hand-off between split-f16 layers
 @pytest.mark.parametrize("up,ci,co,res,c_next", [(1, 64, 64, 64, 64), (1, 128, 128, 32, 384), (2, 128, 64, 64, 64),
-                                                  (2, 144, 128, 64, 128)])
+                                                  (2, 144, 128, 64, 128), (2, 128, 128, 32, 128)])
 def test_h2_handoff_kernels(up, ci, co, res, c_next):
     """nb_modconv3x3_up{1,2}_h3_h2 == the fp32-output kernel followed by nb_pack_h2_f32 with the consumer's styles."""
     from brushstroke_engine_amd import _lib, ops
