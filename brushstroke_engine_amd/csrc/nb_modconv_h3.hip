@@ -113,6 +113,27 @@ __device__ __forceinline__ unsigned nb_pk2_fp8(float a, float b) {
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
 }
 
+// four values -> four fp8 bytes in a wave whose MODE.FP16_OVFL is set (nb_set_fp16_ovfl): the conversion itself saturates
+// to +-448 (and f32 -> f16 to +-65504), no clamp instructions
+__device__ __forceinline__ unsigned nb_pk4_fp8_sat(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ void nb_set_fp16_ovfl() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// v - (float)h[hi ? 1 : 0] in one instruction
+__device__ __forceinline__ float nb_sub_f16(float v, h2 h, bool hi) {
+    float r;
+    if (hi) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float d) {
     auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
     int w = 0;
@@ -932,6 +953,7 @@ struct H3Up2Params {
 template <bool F8, int TQH, int OUTM = 0, int TQW_ = 32>
 __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
+    if constexpr (OUTM == 2) nb_set_fp16_ovfl();
     nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = 8, NT = 512, TQW = TQW_, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
@@ -941,10 +963,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;                     // 36 -> 5 per wave
     constexpr int WSLOTS = 36 * 32, NWP = WSLOTS / 64, NWPW = (NWP + NW - 1) / NW;   // 18 -> 3 per wave
     constexpr int STAGE = 4 * XPL + WSLOTS;           // 16-byte slots per stage
-    constexpr int Y1_PHASE = NBLK * 32, Y1_SLOT = 4 * Y1_PHASE + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
     h8* ring = reinterpret_cast<h8*>(smem_h3);        // [2][ x: 4 planes x XPL | w: 36 rows x 32 ]
-    float* y1s = reinterpret_cast<float*>(smem_h3);   // epilogue reuse: [2 slots][4 phases][640]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
@@ -963,18 +983,19 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     const int nblk = wv < NBLK - (NBJ - 1) * NW ? NBJ : NBJ - 1;      // blocks wv, wv+8 (< 15)
 
     // epilogue operands fetched under the prologue DMA: demodulation / bias per channel and the tile's noise
-    __shared__ float s_dco[32], s_bias[32], s_nst[32];
+    __shared__ __attribute__((aligned(16))) float s_dco[32], s_bias[32], s_nst[32];
     __shared__ __attribute__((aligned(16))) float s_noise[2 * TQH * 2 * TQW];
     if (tid < 32) {
         const int co = co0 + tid;
-        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
-        s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
+        // the activation gain is folded into the three addends: lrelu(g t) = g lrelu(t) for g > 0 (the launcher checks)
+        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] * p.gain : 0.f;
+        s_bias[tid] = co < p.c_out ? p.bias[co] * p.gain : 0.f;
         s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
     for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
         const int r = e / (2 * TQW), c = e - r * (2 * TQW);
         const int oy = 2 * I0 + r, ox = 2 * J0 + c;
-        s_noise[e] = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
+        s_noise[e] = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] * p.gain : 0.f;
     }
 
     int xsp[NXPW], xpl[NXPW], xdst[NXPW];
@@ -1154,193 +1175,174 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
 
     NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
-    // ---- epilogue: 4 rounds of 4 accumulator registers = 8 c_out each (register rho <-> c_out rows
-    //      (rho&3) + 8(rho>>2) + 4*lh): phases -> LDS, polyphase FIR, demodulate, noise, bias, lrelu, store ----
+    // ---- epilogue: 2 rounds of 16 c_out.  Accumulator register rho <-> c_out row (rho&3) + 8(rho>>2) + 4*lh, so the four
+    //      registers rho = 4g..4g+3 of a lane are four CONSECUTIVE channels: they go to LDS as one 16-byte slot
+    //      y4[g&1][lh][phase][position].  Then one item = one quad (2 x 2 output pixels) x those 4 channels: 25 slot reads,
+    //      the separable polyphase FIR with every instruction packed over channel pairs (no lane-half shuffles), activation,
+    //      hi/lo split and fp8 conversion in registers.  Lanes l and l+32 hold the two channel halves of the same quad and
+    //      trade rows with v_permlane32_swap, after which a lane owns 8 channels of one output row of the quad = whole
+    //      16-byte H2 slots (8-byte halves of the f8 slots) that go straight to global memory: no staging buffer, no
+    //      transposition stage, 4 barriers instead of 12. ----
     const int Wo = 2 * W, Ho = 2 * H;
     constexpr int nquads = TQH * TQW;
-    constexpr int RPR = 4;                            // accumulator registers per round
-    constexpr int OPIX = 4 * nquads;                  // output pixels of the tile
-    _Float16* obuf = reinterpret_cast<_Float16*>(y1s + RPR * 2 * Y1_SLOT);      // H2 output: [hi/lo][OPIX][8]
-    unsigned long long te_w = 0, te_f = 0, te_s = 0, te0 = 0;     // debug: cycles in (phase write + sync), (FIR stage + sync), (store stage)
+    constexpr int Y1P = NBLK * 32;                    // slots per (g, lh, phase) plane
+    f32x4* y4 = reinterpret_cast<f32x4*>(smem_h3);
+    const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();     // (no clamp: med3 against +-inf)
+    unsigned long long te_w = 0, te_f = 0, te0 = 0;   // debug: cycles in (phase write + sync), (items)
 #pragma unroll
-    for (int round = 0; round < 16 / RPR; ++round) {
+    for (int R = 0; R < 2; ++R) {
         if (p.tstamps) te0 = __builtin_amdgcn_s_memtime();
+        if (R) __syncthreads();                       // the previous round's reads are done
 #pragma unroll
-        for (int rr = 0; rr < RPR; ++rr) {
-            const int rho = round * RPR + rr;
+        for (int gs = 0; gs < 2; ++gs) {
+            const int r0 = (2 * R + gs) * 4;
 #pragma unroll
             for (int j = 0; j < NBJ; ++j) {
                 if (j < nblk) {
                     const int pidx = (wv + NW * j) * 32 + l31;
 #pragma unroll
-                    for (int ph = 0; ph < 4; ++ph) y1s[(rr * 2 + lh) * Y1_SLOT + ph * Y1_PHASE + pidx] = acc[j][ph][rho];
+                    for (int ph = 0; ph < 4; ++ph)
+                        y4[((gs * 2 + lh) * 4 + ph) * Y1P + pidx] = f32x4{acc[j][ph][r0], acc[j][ph][r0 + 1], acc[j][ph][r0 + 2], acc[j][ph][r0 + 3]};
                 }
             }
         }
         __syncthreads();
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_w += t_ - te0; te0 = t_; }
-        // FIR + activation: one item = one channel x one row of quads x 2 adjacent quads (2 x 4 output pixels).
-        // Column pairs are evaluated with packed fp32 math; the expressions keep the operand order of the reference
-        // polyphase form  0.25 a + 0.75 b + 0.75 c + 0.25 d  (left to right) and the operation order of nb_h3_epilogue.
-        // The output mode is a template parameter (no uniform branches in the item) and a thread's items of a round are
-        // unrolled, so that one item's LDS reads are in flight under another's arithmetic.
-        auto fir_item = [&](const int it) {
-            // lanes walk the quad pairs of one channel (conflict-free phase reads); the H2 / f8 results are staged
-            // channel-planar so that the lane's 4 consecutive pixels go out as one 8- / 4-byte LDS write
-            const int p2 = it % (TQW / 2);
-            const int rr_ = it / (TQW / 2);
-            const int ti = rr_ % TQH, s_ = rr_ / TQH;
-            const int tj = 2 * p2;
-            const int rho = round * RPR + (s_ >> 1);
-            const int col = (rho & 3) + 8 * (rho >> 2) + 4 * (s_ & 1);
-            const int co = co0 + col;
-            const float* ee = y1s + s_ * Y1_SLOT + ti * PW + tj;
-            const float* eo = ee + 1 * Y1_PHASE;
-            const float* oe = ee + 2 * Y1_PHASE;
-            const float* oo = ee + 3 * Y1_PHASE;
-            auto ld2 = [](const float* q) { return *reinterpret_cast<const f32x2*>(q); };
+        auto quad_item = [&](const int wi) {
+            const int hq = wi * 32 + l31;             // (g, quad); lane half = channel half
+            const int gs = hq / nquads, qd = hq - gs * nquads;
+            const int ti = qd / TQW, tj = qd - ti * TQW;
+            const int c4 = 8 * (2 * R + gs) + 4 * lh; // the lane's four channels within the slice
+            const f32x4* ee = y4 + ((gs * 2 + lh) * 4) * Y1P + ti * PW + tj;
+            const f32x4* eo = ee + 1 * Y1P;
+            const f32x4* oe = ee + 2 * Y1P;
+            const f32x4* oo = ee + 3 * Y1P;
             // 4-tap polyphase FIR 0.25 a + 0.75 b + 0.75 c + 0.25 d as one multiply + three fused multiply-adds (the
-            // reference's upfirdn2d is a convolution whose summation order and fusing are the backend's; the epilogue is
-            // VALU-bound, so the 4-instead-of-7 instructions per tap row matter)
-            auto fir4 = [](auto a, auto b, auto c, auto d) {
-                decltype(a) q75 = a, q25 = a;
+            // reference's upfirdn2d is a convolution whose summation order and fusing are the backend's)
+            auto fir4 = [](f32x4 a, f32x4 b, f32x4 c, f32x4 d) {
+                f32x4 q75, q25;
                 q75 = 0.75f; q25 = 0.25f;
                 return __builtin_elementwise_fma(q25, d, __builtin_elementwise_fma(q75, c, __builtin_elementwise_fma(q75, b, 0.25f * a)));
             };
-            // even output columns come from (ee, oe) at quad columns tj..tj+2, odd ones from (eo, oo) at tj..tj+3
-            const f32x2 eeA0 = ld2(ee), eeA1 = ld2(ee + PW), oeA0 = ld2(oe), oeA1 = ld2(oe + PW), oeA2 = ld2(oe + 2 * PW);
-            const float eeB0 = ee[2], eeB1 = ee[PW + 2], oeB0 = oe[2], oeB1 = oe[PW + 2], oeB2 = oe[2 * PW + 2];
-            const f32x2 eoA0 = ld2(eo), eoA1 = ld2(eo + PW), ooA0 = ld2(oo), ooA1 = ld2(oo + PW), ooA2 = ld2(oo + 2 * PW);
-            const f32x2 eoC0 = ld2(eo + 2), eoC1 = ld2(eo + PW + 2), ooC0 = ld2(oo + 2), ooC1 = ld2(oo + PW + 2), ooC2 = ld2(oo + 2 * PW + 2);
-            const f32x2 ve0A = fir4(oeA0, eeA0, oeA1, eeA1), ve1A = fir4(eeA0, oeA1, eeA1, oeA2);
-            const float ve0B = fir4(oeB0, eeB0, oeB1, eeB1), ve1B = fir4(eeB0, oeB1, eeB1, oeB2);
-            const f32x2 vo0A = fir4(ooA0, eoA0, ooA1, eoA1), vo1A = fir4(eoA0, ooA1, eoA1, ooA2);
-            const f32x2 vo0C = fir4(ooC0, eoC0, ooC1, eoC1), vo1C = fir4(eoC0, ooC1, eoC1, ooC2);
-            // horizontal pass, packed over the two quads (q = 0, 1):  even pixel = fir4(vo[q], ve[q], vo[q+1], ve[q+1]),
-            //                                                          odd pixel  = fir4(ve[q], vo[q+1], ve[q+1], vo[q+2])
-            const f32x2 veS0 = {ve0A[1], ve0B}, veS1 = {ve1A[1], ve1B};                 // ve[q+1]
-            const f32x2 voS0 = {vo0A[1], vo0C[0]}, voS1 = {vo1A[1], vo1C[0]};           // vo[q+1]
-            const f32x2 ev0 = fir4(vo0A, ve0A, voS0, veS0), od0 = fir4(ve0A, voS0, veS0, vo0C);   // row dy = 0: {q0, q1}
-            const f32x2 ev1 = fir4(vo1A, ve1A, voS1, veS1), od1 = fir4(ve1A, voS1, veS1, vo1C);   // row dy = 1
-            // pixel order within the row: (q0 even, q0 odd, q1 even, q1 odd)
-            const f32x2 oa[2] = {f32x2{ev0[0], od0[0]}, f32x2{ev1[0], od1[0]}};
-            const f32x2 ob2[2] = {f32x2{ev0[1], od0[1]}, f32x2{ev1[1], od1[1]}};
+            // vertical pass at the quad's 5 intermediate columns: even ones (ve) from (ee, oe) at quad columns tj, tj+1,
+            // odd ones (vo) from (eo, oo) at tj .. tj+2; [dy] = output row of the quad
+            f32x4 ve[2][2], vo[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < 2) {
+                    const f32x4 e0 = ee[c], e1 = ee[PW + c], o0 = oe[c], o1 = oe[PW + c], o2 = oe[2 * PW + c];
+                    ve[c][0] = fir4(o0, e0, o1, e1); ve[c][1] = fir4(e0, o1, e1, o2);
+                }
+                const f32x4 e0 = eo[c], e1 = eo[PW + c], o0 = oo[c], o1 = oo[PW + c], o2 = oo[2 * PW + c];
+                vo[c][0] = fir4(o0, e0, o1, e1); vo[c][1] = fir4(e0, o1, e1, o2);
+            }
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dco + c4), b4 = *reinterpret_cast<const f32x4*>(s_bias + c4);
             const int qi = I0 + ti, qj = J0 + tj;
-            const float d = s_dco[col], bs = s_bias[col];
-            // *d, +noise, +bias, lrelu, *gain, clamp -- the operation order of nb_h3_epilogue, two pixels per instruction
-            auto act2 = [&](f32x2 o, f32x2 nz) {
-                f32x2 t = o * d;
-                t = t + nz;
-                t = t + bs;
-                const f32x2 ta = t * p.alpha;
+            // g (o d + noise + bias), lrelu, clamp with g folded into d, noise and bias (s_dco, s_noise, s_bias hold g d,
+            // g noise, g bias)
+            auto act4 = [&](f32x4 o, float nz) {
+                f32x4 t = __builtin_elementwise_fma(o, d4, b4 + nz);
+                const f32x4 ta = t * p.alpha;
                 // lrelu = max(t, alpha t) for 0 <= alpha <= 1 (the launcher checks); med3 with +inf is a max without the NaN
                 // canonicalisation instructions fmaxf() costs
-                t[0] = __builtin_amdgcn_fmed3f(t[0], ta[0], __builtin_inff()); t[1] = __builtin_amdgcn_fmed3f(t[1], ta[1], __builtin_inff());
-                t = t * p.gain;
-                if (p.clamp >= 0.f) { t[0] = __builtin_amdgcn_fmed3f(t[0], -p.clamp, p.clamp); t[1] = __builtin_amdgcn_fmed3f(t[1], -p.clamp, p.clamp); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t[i], ta[i], __builtin_inff()), -clampv, clampv);
                 return t;
             };
-            if constexpr (OUTM != 0) {
-                // the round's 8 channels are exactly channel group co0/8 + round.  Staging (after the phase slots):
-                //   hi plane [ch 8][OPIX] f16 | H2: lo plane [ch 8][OPIX] f16 | f8: [16][OPIX] fp8(xl 2^9), [16][OPIX] fp8(v/4)
-                const float ns = s_nst[col];
-                const int ch = col & 7;
+            f32x4 v[2][2];                            // [dy][px]
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int opix0 = (2 * ti + dy) * (2 * TQW) + 2 * tj;
-                    const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + opix0);
-                    const f32x2 v01 = act2(oa[dy], f32x2{nz[0], nz[1]}) * ns, v23 = act2(ob2[dy], f32x2{nz[2], nz[3]}) * ns;
-                    h4 vh;
-                    vh[0] = (_Float16)v01[0]; vh[1] = (_Float16)v01[1]; vh[2] = (_Float16)v23[0]; vh[3] = (_Float16)v23[1];
-                    const f32x2 xl01 = v01 - f32x2{(float)vh[0], (float)vh[1]}, xl23 = v23 - f32x2{(float)vh[2], (float)vh[3]};
-                    *reinterpret_cast<h4*>(obuf + (size_t)ch * OPIX + opix0) = vh;
-                    if constexpr (OUTM == 1) {
-                        h4 vl;
-                        vl[0] = (_Float16)xl01[0]; vl[1] = (_Float16)xl01[1]; vl[2] = (_Float16)xl23[0]; vl[3] = (_Float16)xl23[1];
-                        *reinterpret_cast<h4*>(obuf + (size_t)(8 + ch) * OPIX + opix0) = vl;
-                    } else if (!(p.dbg & 32)) {
-                        unsigned char* ob = reinterpret_cast<unsigned char*>(obuf + (size_t)8 * OPIX) + (size_t)((round & 1) * 8 + ch) * OPIX + opix0;
-                        const f32x2 s01 = xl01 * 512.f, s23 = xl23 * 512.f, q01 = v01 * 0.25f, q23 = v23 * 0.25f;
-                        *reinterpret_cast<unsigned*>(ob) = nb_pk2_fp8<true>(s01[0], s01[1]) | (nb_pk2_fp8<true>(s23[0], s23[1]) << 16);
-                        *reinterpret_cast<unsigned*>(ob + (size_t)16 * OPIX) = nb_pk2_fp8<true>(q01[0], q01[1]) | (nb_pk2_fp8<true>(q23[0], q23[1]) << 16);
+            for (int dy = 0; dy < 2; ++dy) {
+                const f32x2 nz = *reinterpret_cast<const f32x2*>(s_noise + (2 * ti + dy) * (2 * TQW) + 2 * tj);
+                // horizontal pass: even pixel = fir4(vo[0], ve[0], vo[1], ve[1]), odd pixel = fir4(ve[0], vo[1], ve[1], vo[2])
+                // The two noise values get registers of their own.  Left in the loaded pair, the compiler adds the second one
+                // as `v_pk_add_f32 d, bias, v[pair] op_sel:[0,1]` (low result reads the pair's HIGH dword), and that
+                // instruction returned, for 8-16 lanes of the upper half-wave and run-to-run differently, the sum with the
+                // pair's LOW dword in its low result (measured: tools/determinism_up2.py; waits forced to zero and s_nops
+                // did not change it, this did).
+                float nz0 = nz[0], nz1 = nz[1];
+                asm volatile("v_mov_b32 %0, %0" : "+v"(nz0));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(nz1));
+                v[dy][0] = act4(fir4(vo[0][dy], ve[0][dy], vo[1][dy], ve[1][dy]), nz0);
+                v[dy][1] = act4(fir4(ve[0][dy], vo[1][dy], ve[1][dy], vo[2][dy]), nz1);
+            }
+            if constexpr (OUTM == 0) {
+                if (qi < H && !(p.dbg & 1)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co0 + c4 + i;
+                        if (co < p.c_out) {
+                            float* dst = p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)(2 * qi) * Wo + 2 * qj;
+                            *reinterpret_cast<f32x2*>(dst) = f32x2{v[0][0][i], v[0][1][i]};
+                            *reinterpret_cast<f32x2*>(dst + Wo) = f32x2{v[1][0][i], v[1][1][i]};
+                        }
                     }
                 }
-            } else if (co < p.c_out && qi < H && !(p.dbg & 1)) {
+            } else {
+                const f32x4 ns4 = *reinterpret_cast<const f32x4*>(s_nst + c4);
+                unsigned hi[2][2][2], lo[2][2][2];    // [dy][px][dword]: hi = 4 x f16; lo = H2: 4 x f16 residual, f8: {fp8(xl 2^9) x 4, fp8(v/4) x 4}
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int oy = 2 * qi + dy, ox = 2 * qj;
-                    const f32x4 nz = *reinterpret_cast<const f32x4*>(s_noise + (2 * ti + dy) * (2 * TQW) + 2 * tj);
-                    const f32x2 v01 = act2(oa[dy], f32x2{nz[0], nz[1]}), v23 = act2(ob2[dy], f32x2{nz[2], nz[3]});
-                    *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)oy * Wo + ox) = f32x4{v01[0], v01[1], v23[0], v23[1]};
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        f32x4 w = v[dy][px] * ns4;
+                        const h2 h01 = __builtin_convertvector(f32x2{w[0], w[1]}, h2), h23 = __builtin_convertvector(f32x2{w[2], w[3]}, h2);
+                        // residual w - f16(w) as a mixed-precision fma (reads the f16 half directly)
+                        const f32x4 xl = {nb_sub_f16(w[0], h01, false), nb_sub_f16(w[1], h01, true), nb_sub_f16(w[2], h23, false), nb_sub_f16(w[3], h23, true)};
+                        hi[dy][px][0] = __builtin_bit_cast(unsigned, h01); hi[dy][px][1] = __builtin_bit_cast(unsigned, h23);
+                        if constexpr (OUTM == 1) {
+                            const h2 l01 = __builtin_convertvector(f32x2{xl[0], xl[1]}, h2), l23 = __builtin_convertvector(f32x2{xl[2], xl[3]}, h2);
+                            lo[dy][px][0] = __builtin_bit_cast(unsigned, l01); lo[dy][px][1] = __builtin_bit_cast(unsigned, l23);
+                        } else {
+                            // (conversions saturate: FP16_OVFL is set for this kernel)
+                            const f32x4 s = xl * 512.f, q = w * 0.25f;
+                            lo[dy][px][0] = nb_pk4_fp8_sat(s[0], s[1], s[2], s[3]);
+                            lo[dy][px][1] = nb_pk4_fp8_sat(q[0], q[1], q[2], q[3]);
+                        }
+                    }
+                // lanes l (channels 0-3 of the group) and l+32 (channels 4-7) trade rows: afterwards a lane holds output row
+                // dy = lh of the quad with all 8 channels -- a = channels 0-3, b = channels 4-7
+                unsigned ha[2][2], hb[2][2], la[2][2], lb[2][2];     // [px][dword]
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const u32x2 rh = __builtin_amdgcn_permlane32_swap(hi[0][px][k], hi[1][px][k], false, false);
+                        const u32x2 rl = __builtin_amdgcn_permlane32_swap(lo[0][px][k], lo[1][px][k], false, false);
+                        ha[px][k] = rh[0]; hb[px][k] = rh[1]; la[px][k] = rl[0]; lb[px][k] = rl[1];
+                    }
+                const int cg = co0 / 8 + 2 * R + gs;
+                const int oy = 2 * qi + lh, ox = 2 * qj;
+                if (qi < H && cg * 8 < p.c_out && !(p.dbg & 1)) {
+                    const size_t OHW8 = (size_t)Ho * Wo * 8;
+                    _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
+                    const size_t opix8 = ((size_t)oy * Wo + ox) * 8;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        *reinterpret_cast<u32x4*>(yn + opix8 + px * 8) = u32x4{ha[px][0], ha[px][1], hb[px][0], hb[px][1]};
+                        if constexpr (OUTM == 1) {
+                            *reinterpret_cast<u32x4*>(yn + OHW8 + opix8 + px * 8) = u32x4{la[px][0], la[px][1], lb[px][0], lb[px][1]};
+                        } else {
+                            // the 16-channel chunk's two lo slots: (even group, lo) = fp8(xl 2^9) of its 16 channels, (odd group,
+                            // lo) = fp8(v/4); this group's 8 channels are bytes 8 (cg & 1) .. + 7 of both
+                            _Float16* lo_xl = p.yh2 + ((size_t)n * p.c8_next + (cg & ~1)) * 2 * OHW8 + OHW8 + opix8 + px * 8 + (cg & 1) * 4;
+                            *reinterpret_cast<u32x2*>(lo_xl) = u32x2{la[px][0], lb[px][0]};
+                            *reinterpret_cast<u32x2*>(lo_xl + 2 * OHW8) = u32x2{la[px][1], lb[px][1]};
+                        }
+                    }
                 }
             }
         };
-        constexpr int NIT = RPR * 2 * TQH * (TQW / 2);
-        if constexpr (NIT % NT == 0) {
+        constexpr int NWI = nquads * 2 / 32;          // wave-iterations of 32 quads x both channel halves per round
+        static_assert(nquads * 2 % 32 == 0, "tile quads must fill whole waves");
+        if constexpr (NWI % NW == 0) {
 #pragma unroll
-            for (int k = 0; k < NIT / NT; ++k) fir_item(tid + k * NT);
+            for (int k = 0; k < NWI / NW; ++k) quad_item(wv + k * NW);
         } else {
-            for (int it = tid; it < NIT; it += NT) fir_item(it);
+            for (int wi = wv; wi < NWI; wi += NW) quad_item(wi);
         }
-        __syncthreads();
-        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_f += t_ - te0; te0 = t_; }
-        if constexpr (OUTM != 0) {
-            const int cg = co0 / 8 + round;
-            if (cg * 8 < p.c_out && !(p.dbg & 1)) {
-                const size_t OHW8 = (size_t)Ho * Wo * 8;
-                _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
-                // planar staging -> 16-byte slots: a task transposes 4 consecutive pixels x 8 channels (f16) resp. x 16
-                // channels (fp8) in registers and stores the 4 slots (64 contiguous bytes per lane)
-                constexpr int nf16 = OUTM == 2 ? 1 : 2;                                  // f16 planes sets: hi (+ lo for H2)
-                for (int e = tid; e < nf16 * (OPIX / 4); e += NT) {
-                    const int k = e / (OPIX / 4), t4 = e - k * (OPIX / 4);
-                    const int opix = 4 * t4;
-                    const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
-                    if (oy < Ho) {
-                        h4 pl[8];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) pl[c] = *reinterpret_cast<const h4*>(obuf + (size_t)(k * 8 + c) * OPIX + opix);
-                        _Float16* dst = yn + (size_t)k * OHW8 + ((size_t)oy * Wo + ox) * 8;
-#pragma unroll
-                        for (int px = 0; px < 4; ++px) {
-                            h8 sl8;
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) sl8[c] = pl[c][px];
-                            *reinterpret_cast<h8*>(dst + px * 8) = sl8;
-                        }
-                    }
-                }
-                if (OUTM == 2 && (round & 1)) {
-                    // the chunk's two lo slots: (cg-1, lo) = fp8(xl 2^9) of its 16 channels, (cg, lo) = fp8(v/4)
-                    for (int e = tid; e < 2 * (OPIX / 4); e += NT) {
-                        const int k = e / (OPIX / 4), t4 = e - k * (OPIX / 4);
-                        const int opix = 4 * t4;
-                        const int oy = 2 * I0 + opix / (2 * TQW), ox = 2 * J0 + (opix & (2 * TQW - 1));
-                        if (oy < Ho) {
-                            const unsigned char* src = reinterpret_cast<const unsigned char*>(obuf + (size_t)8 * OPIX) + (size_t)k * 16 * OPIX + opix;
-                            unsigned r[16];
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const unsigned*>(src + (size_t)c * OPIX);
-                            _Float16* dst = (k == 0 ? yn - OHW8 : yn + OHW8) + ((size_t)oy * Wo + ox) * 8;
-#pragma unroll
-                            for (int px = 0; px < 4; ++px) {
-                                i32x4 sl4;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    // bytes px of r[4q .. 4q+3] -> one dword (v_perm_b32: selector bytes 0-3 pick from the 2nd operand, 4-7 from the 1st)
-                                    const unsigned lo2 = __builtin_amdgcn_perm(r[4 * q + 1], r[4 * q], 0x0c0c0400u + px * 0x0101u);
-                                    const unsigned hi2 = __builtin_amdgcn_perm(r[4 * q + 3], r[4 * q + 2], 0x0c0c0400u + px * 0x0101u);
-                                    sl4[q] = (int)((lo2 & 0xffffu) | (hi2 << 16));
-                                }
-                                *reinterpret_cast<i32x4*>(dst + px * 8) = sl4;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_s += t_ - te0; }
+        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_f += t_ - te0; }
     }
+    const unsigned long long te_s = 0;
     NB_TSTAMP(4);
     if (p.tstamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1373,7 +1375,7 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
     constexpr int XPL = (((TQH + 3) * (TQW + 3) + 63) / 64) * 64;
     constexpr int NBLK_ = ((TQH + 2) * (TQW + 2) + 31) / 32;
     constexpr size_t lds_stage = (size_t)(TQH == NB_H3_TQH_SMALL ? NB_H3_STAGES_SMALL : NB_H3_STAGES) * (4 * XPL + 36 * 32) * 16;
-    constexpr size_t lds_epi = (size_t)8 * (4 * NBLK_ * 32 + 16) * 4 + (size_t)3 * 4 * TQH * TQW * 16;   // FIR slots + H2 slots (hi, 2 x lo)
+    constexpr size_t lds_epi = (size_t)16 * NBLK_ * 32 * 16;       // epilogue: [2 groups][2 halves][4 phases][positions] x 4 channels fp32
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
     if (in_fmt)
@@ -1395,7 +1397,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
                "modconv3x3_up2_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up2_h3: bad sizes");
     NB_REQUIRE((w % 32 == 0 || w == 16) && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0 or w == 16 (got %dx%d)", h, w);
-    NB_REQUIRE(alpha >= 0.f && alpha <= 1.f, "modconv3x3_up2_h3: leaky-ReLU slope must lie in [0, 1] (got %g)", alpha);
+    NB_REQUIRE(alpha >= 0.f && alpha <= 1.f && gain > 0.f, "modconv3x3_up2_h3: leaky-ReLU slope must lie in [0, 1] and the gain be positive (got %g, %g)", alpha, gain);
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up2_h3: pointers must be 16-byte aligned");
     H3Up2Params p;
     p.x = (const _Float16*)x_h2; p.wts = (const _Float16*)w_h3; p.dcoefs = dcoefs; p.noise = noise; p.bias = bias; p.y = y;
