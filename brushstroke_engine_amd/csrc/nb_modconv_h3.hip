@@ -68,12 +68,13 @@ extern "C" void nb_debug_set_timestamps(void* buf, int capacity_workgroups) { g_
         if (p.tstamps && threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-__device__ __forceinline__ float nb_h3_epilogue(float v, float bias, float alpha, float gain, float clamp) {
-    v += bias;
-    v = v < 0.f ? v * alpha : v;
-    v *= gain;
-    if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
-    return v;
+// Activation of the split-f16 kernels: lrelu(g (a d + noise + bias)) clamped, with the gain g > 0 folded into the three
+// addends (lrelu(g t) = g lrelu(t)).  Every output path of a kernel -- fp32, H2, f8 -- evaluates exactly this expression
+// (dg = d g, nbg = bias g + noise g), so that a fused hand-off equals the fp32 output packed afterwards bit for bit.
+__device__ __forceinline__ float nb_h3_act(float a, float dg, float nbg, float alpha, float clampv) {
+    const float t = __builtin_fmaf(a, dg, nbg);
+    // lrelu = max(t, alpha t) for 0 <= alpha <= 1 (the launchers check); clampv = +inf for "no clamp"
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t, t * alpha, __builtin_inff()), -clampv, clampv);
 }
 
 // De-synchronise the chip: without this every CU runs the same tile schedule in lockstep, so all epilogue store
@@ -142,11 +143,92 @@ __device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float 
     return (unsigned)w;
 }
 
+// Hand-off epilogue of the up=1 kernels (H2 or "f8" output into the consumer's operand tensor), straight from the
+// accumulators: no LDS image, no barrier.  D[row = c_out, col = pixel]: a lane holds, for ITS pixel, four consecutive
+// channels (4 lh .. 4 lh + 3) of each 8-channel group g; activation / consumer style / hi-lo split run packed over those
+// four; then lanes l and l+32 (same pixel, the two halves of every group) trade groups with v_permlane32_swap -- the lower
+// lane ends up with all 8 channels of the even groups, the upper lane with the odd ones -- and every lane stores whole
+// 16-byte slots (8-byte halves of the f8 lo slots) at consecutive pixels: 512 contiguous bytes per half-wave.
+// s_dco / s_bias / s_nst: the workgroup's per-channel tables (16-byte aligned); colbase = first channel of the wave's
+// 64-row band within them; trow0 = the wave's first tile row.
+template <int MB, int NBW>
+__device__ __forceinline__ void nb_up1_handoff_epilogue(const H3Params& p, const f32x16 (&acc)[MB][NBW], const float (&nzr)[NBW], const float* s_dco,
+                                                        const float* s_bias, const float* s_nst, int colbase, int trow0, int co0, int n, int y0, int x0,
+                                                        int lh, int l31) {
+    const int W = p.w;
+    const size_t HW8 = (size_t)p.h * W * 8;
+    const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+    _Float16* yn = p.yh2 + (size_t)n * p.c8_next * 2 * HW8;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            // g (acc d + noise + bias), lrelu, clamp with the gain g folded into d, noise and bias (lrelu(g t) = g lrelu(t))
+            f32x4 d4[2], b4[2], ns4[2];
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int col = colbase + mb * 32 + 8 * (2 * gp + gi) + 4 * lh;
+                d4[gi] = *reinterpret_cast<const f32x4*>(s_dco + col) * p.gain;
+                b4[gi] = *reinterpret_cast<const f32x4*>(s_bias + col) * p.gain;
+                ns4[gi] = *reinterpret_cast<const f32x4*>(s_nst + col);
+            }
+            const int cg = (co0 + colbase + mb * 32) / 8 + 2 * gp + lh;     // the group this lane owns after the trade
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const float nzg = nzr[nb] * p.gain;
+                unsigned hi[2][2], lo[2][2];              // [group of the pair][dword]
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int r0 = 4 * (2 * gp + gi);
+                    const f32x4 a4 = {acc[mb][nb][r0], acc[mb][nb][r0 + 1], acc[mb][nb][r0 + 2], acc[mb][nb][r0 + 3]};
+                    f32x4 t = __builtin_elementwise_fma(a4, d4[gi], b4[gi] + nzg);
+                    const f32x4 ta = t * p.alpha;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t[i], ta[i], __builtin_inff()), -clampv, clampv);
+                    const f32x4 w = t * ns4[gi];
+                    const h2 h01 = __builtin_convertvector(f32x2{w[0], w[1]}, h2), h23 = __builtin_convertvector(f32x2{w[2], w[3]}, h2);
+                    const f32x4 xl = {nb_sub_f16(w[0], h01, false), nb_sub_f16(w[1], h01, true), nb_sub_f16(w[2], h23, false), nb_sub_f16(w[3], h23, true)};
+                    hi[gi][0] = __builtin_bit_cast(unsigned, h01); hi[gi][1] = __builtin_bit_cast(unsigned, h23);
+                    if (p.out_f8) {
+                        // (conversions saturate: FP16_OVFL is set when out_f8)
+                        const f32x4 s = xl * 512.f, q = w * 0.25f;
+                        lo[gi][0] = nb_pk4_fp8_sat(s[0], s[1], s[2], s[3]);
+                        lo[gi][1] = nb_pk4_fp8_sat(q[0], q[1], q[2], q[3]);
+                    } else {
+                        const h2 l01 = __builtin_convertvector(f32x2{xl[0], xl[1]}, h2), l23 = __builtin_convertvector(f32x2{xl[2], xl[3]}, h2);
+                        lo[gi][0] = __builtin_bit_cast(unsigned, l01); lo[gi][1] = __builtin_bit_cast(unsigned, l23);
+                    }
+                }
+                unsigned ha[2], hb[2], la[2], lb[2];      // a = channels 0-3, b = channels 4-7 of the owned group
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32x2 rh = __builtin_amdgcn_permlane32_swap(hi[0][k], hi[1][k], false, false);
+                    const u32x2 rl = __builtin_amdgcn_permlane32_swap(lo[0][k], lo[1][k], false, false);
+                    ha[k] = rh[0]; hb[k] = rh[1]; la[k] = rl[0]; lb[k] = rl[1];
+                }
+                if (cg * 8 < p.c_out && !(p.dbg & 1)) {
+                    const size_t pix8 = ((size_t)(y0 + trow0 + nb) * W + x0 + l31) * 8;
+                    *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2) * HW8 + pix8) = u32x4{ha[0], ha[1], hb[0], hb[1]};
+                    if (p.out_f8) {
+                        // the 16-channel chunk's two lo slots: (even group, lo) = fp8(xl 2^9), (odd group, lo) = fp8(v/4); this
+                        // group's 8 channels are bytes 8 (cg & 1) .. + 7 of both
+                        _Float16* lo_xl = yn + (size_t)((cg & ~1) * 2 + 1) * HW8 + pix8 + (cg & 1) * 4;
+                        *reinterpret_cast<u32x2*>(lo_xl) = u32x2{la[0], lb[0]};
+                        *reinterpret_cast<u32x2*>(lo_xl + 2 * HW8) = u32x2{la[1], lb[1]};
+                    } else {
+                        *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2 + 1) * HW8 + pix8) = u32x4{la[0], la[1], lb[0], lb[1]};
+                    }
+                }
+            }
+        }
+}
+
 // NBW_ = 32-pixel rows per wave: 2 for throughput, 1 (half the pixels per workgroup, twice the workgroups) when the
 // launch would otherwise leave most of the chip idle - the batch-1 / interactive configuration.
 template <int MW, bool F8 = false, int NBW_ = 2>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
     NB_TSTAMP(0);
+    if (p.out_f8) nb_set_fp16_ovfl();             // f8 hand-off: the fp8 (and f16) conversions saturate
     nb_stagger(p.stagger_ticks, 256);
     constexpr int NW = 8, NWN = NW / MW;          // waves along pixels
     constexpr int MB = 2, NBW = NBW_;             // 32x32 MFMA tiles per wave: 64 c_out x 64 (32) pixels
@@ -178,7 +260,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 
     // epilogue operands are fetched now, under the prologue DMA: per-channel demodulation / bias into LDS, the
     // lane's noise values into registers (fetching them in the epilogue costs ~10 us of exposed latency per tile)
-    __shared__ float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
+    __shared__ __attribute__((aligned(16))) float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
     if (tid < CO_WG) {
         const int co = co0 + tid;
         s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
@@ -463,52 +545,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     // the accumulator registers directly, and whole 512-byte row segments per wave-instruction.
     constexpr int PIX_WG = TH * 32;
     if (p.yh2) {
-        // H2 epilogue: [pixel][channel] hi and lo images in LDS (pitch +8 halves), then 16-byte slot stores
-        constexpr int CP = CO_WG + 8;
-        _Float16* sh = reinterpret_cast<_Float16*>(smem_h3);
-        _Float16* sl = sh + PIX_WG * CP;
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const int pix = (wn * NBW + nb) * 32 + l31;
-            const float nz = nzr[nb];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = wm * 64 + mb * 32 + 8 * g + 4 * lh;
-                    h4 vh, vl;
-                    float vv[4], xl[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = nb_h3_epilogue(acc[mb][nb][4 * g + j] * s_dco[col + j] + nz, s_bias[col + j], p.alpha, p.gain, p.clamp) * s_nst[col + j];
-                        const _Float16 hi = (_Float16)v;
-                        vv[j] = v; xl[j] = v - (float)hi;
-                        vh[j] = hi; vl[j] = (_Float16)xl[j];
-                    }
-                    *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
-                    if (p.out_f8) {
-                        // lo image as bytes: per 16-channel chunk 16 x fp8(xl 2^9) then 16 x fp8(v/4) (= the chunk's two lo slots)
-                        unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)pix * (CP * 2) + (col >> 4) * 32 + (col & 15);
-                        *reinterpret_cast<unsigned*>(sb) = nb_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
-                        *reinterpret_cast<unsigned*>(sb + 16) = nb_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
-                    } else {
-                        *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
-                    }
-                }
-        }
-        __syncthreads();
+        nb_up1_handoff_epilogue<MB, NBW>(p, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
         NB_TSTAMP(3);
-        _Float16* yn = p.yh2 + (size_t)n * p.c8_next * 2 * HW8;
-        if (!(p.dbg & 1)) {
-            for (int e = tid; e < (CO_WG / 8) * 2 * PIX_WG; e += 512) {
-                const int pix = e % PIX_WG, hl = (e / PIX_WG) & 1, cgl = e / (2 * PIX_WG);
-                const int cg = co0 / 8 + cgl;
-                if (cg * 8 < p.c_out) {
-                    const h8 v = *reinterpret_cast<const h8*>((hl ? sl : sh) + pix * CP + cgl * 8);
-                    *reinterpret_cast<h8*>(yn + (size_t)(cg * 2 + hl) * HW8 + ((size_t)(y0 + (pix >> 5)) * W + x0 + (pix & 31)) * 8) = v;
-                }
-            }
-        }
         NB_TSTAMP(4);
         return;
     }
@@ -516,14 +554,14 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int trow = wn * NBW + nb;
-        const float nz = nzr[nb];
+        const float nzg = nzr[nb] * p.gain, clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // c_out within the workgroup
                 // (channels past c_out carry dco = bias = 0 and are never stored)
-                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_epilogue(acc[mb][nb][r] * s_dco[col] + nz, s_bias[col], p.alpha, p.gain, p.clamp);
+                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_act(acc[mb][nb][r], s_dco[col] * p.gain, s_bias[col] * p.gain + nzg, p.alpha, clampv);
             }
         }
     }
@@ -568,6 +606,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 // image), the next step's DMA is in flight under the current step's MFMAs (the scheme of nb_encoder.hip).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Params p) {
+    if (p.out_f8) nb_set_fp16_ovfl();             // f8 hand-off: the fp8 (and f16) conversions saturate
     constexpr int NW = 4, MB = 2, NBW = 2, CO_WG = 64, TH = NW * NBW, PW = 34, PIX_WG = TH * 32;
     constexpr int SLOTS = TH * PW, PP = (SLOTS + 63) / 64, XPL = PP * 64, NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;
     constexpr int WSLOTS = 12 * CO_WG, NWP = WSLOTS / 64, NWPW = NWP / NW;
@@ -586,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
     const size_t HW8 = (size_t)H * W * 8;
     const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
 
-    __shared__ float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
+    __shared__ __attribute__((aligned(16))) float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
     __shared__ float s_tw[3 * 128], s_tcol[9], s_tcol01[9];
     if (tid < CO_WG) {
         const int co = co0 + tid;
@@ -691,60 +730,20 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
 
     if (p.yh2) {
-        constexpr int CP = CO_WG + 8;
-        _Float16* sh = reinterpret_cast<_Float16*>(smem_h3);
-        _Float16* sl = sh + PIX_WG * CP;
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const int pix = (wn * NBW + nb) * 32 + l31;
-            const float nz = nzr[nb];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = mb * 32 + 8 * g + 4 * lh;
-                    h4 vh, vl;
-                    float vv[4], xl[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = nb_h3_epilogue(acc[mb][nb][4 * g + j] * s_dco[col + j] + nz, s_bias[col + j], p.alpha, p.gain, p.clamp) * s_nst[col + j];
-                        const _Float16 hi = (_Float16)v;
-                        vv[j] = v; xl[j] = v - (float)hi;
-                        vh[j] = hi; vl[j] = (_Float16)xl[j];
-                    }
-                    *reinterpret_cast<h4*>(sh + pix * CP + col) = vh;
-                    if (p.out_f8) {
-                        unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)pix * (CP * 2) + (col >> 4) * 32 + (col & 15);
-                        *reinterpret_cast<unsigned*>(sb) = nb_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
-                        *reinterpret_cast<unsigned*>(sb + 16) = nb_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
-                    } else {
-                        *reinterpret_cast<h4*>(sl + pix * CP + col) = vl;
-                    }
-                }
-        }
-        __syncthreads();
-        _Float16* yn = p.yh2 + (size_t)n * p.c8_next * 2 * HW8;
-        for (int e = tid; e < (CO_WG / 8) * 2 * PIX_WG; e += 256) {
-            const int pix = e % PIX_WG, hl = (e / PIX_WG) & 1, cgl = e / (2 * PIX_WG);
-            const int cg = co0 / 8 + cgl;
-            if (cg * 8 < p.c_out) {
-                const h8 v = *reinterpret_cast<const h8*>((hl ? sl : sh) + pix * CP + cgl * 8);
-                *reinterpret_cast<h8*>(yn + (size_t)(cg * 2 + hl) * HW8 + ((size_t)(y0 + (pix >> 5)) * W + x0 + (pix & 31)) * 8) = v;
-            }
-        }
+        nb_up1_handoff_epilogue<MB, NBW>(p, acc, nzr, s_dco, s_bias, s_nst, 0, wn * NBW, co0, n, y0, x0, lh, l31);
         return;
     }
     float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG]
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int trow = wn * NBW + nb;
-        const float nz = nzr[nb];
+        const float nzg = nzr[nb] * p.gain, clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_epilogue(acc[mb][nb][r] * s_dco[col] + nz, s_bias[col], p.alpha, p.gain, p.clamp);
+                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_act(acc[mb][nb][r], s_dco[col] * p.gain, s_bias[col] * p.gain + nzg, p.alpha, clampv);
             }
     }
     __syncthreads();
@@ -821,6 +820,7 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
                "modconv3x3_up1_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up1_h3: bad sizes");
+    NB_REQUIRE(alpha >= 0.f && alpha <= 1.f && gain > 0.f, "modconv3x3_up1_h3: leaky-ReLU slope must lie in [0, 1] and the gain be positive (got %g, %g)", alpha, gain);
     NB_REQUIRE(w % 32 == 0 && h % 16 == 0, "modconv3x3_up1_h3: needs w %% 32 == 0 and h %% 16 == 0 (got %dx%d)", h, w);
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up1_h3: pointers must be 16-byte aligned");
     H3Params p;
