@@ -267,7 +267,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
         s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
-    __shared__ float s_tw[3 * CO_WG], s_tcol[9], s_tcol01[9];
+    __shared__ __attribute__((aligned(16))) float s_tw[3 * CO_WG];
+    __shared__ float s_tcol[9], s_tcol01[9];
     if (p.tg.c) nb_torgb_setup(p.tg, n, s_tw, s_tcol, s_tcol01, tid, 512, blockIdx.x == 0);
     float nzr[NBW];
 #pragma unroll
@@ -550,6 +551,51 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         NB_TSTAMP(4);
         return;
     }
+    if constexpr (MW == 1) {
+        if (p.tg.c && !p.y && p.c_out % 8 == 0) {
+            // ToRGB straight from the accumulators (nobody taps the fp32 activations): the lane holds 32 of its pixel's 64
+            // channels (4 lh .. + 3 of every group), lane l + 32 the other 32; partial sums in the order of nb_torgb_dot
+            // (j = the four registers of a group, summed over (mb, g)), then the two lane halves meet through one
+            // v_permlane32_swap per output.  No LDS image, no barrier.
+            const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const float nzg = nzr[nb] * p.gain;
+                f32x4 s0, s1, s2;
+                s0 = 0.f; s1 = 0.f; s2 = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = mb * 32 + 8 * g + 4 * lh;
+                        if (col < p.c_out) {
+                            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dco + col) * p.gain;
+                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + col) * p.gain + nzg;
+                            const f32x4 a4 = {acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]};
+                            f32x4 t = __builtin_elementwise_fma(a4, d4, b4);
+                            const f32x4 ta = t * p.alpha;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t[i], ta[i], __builtin_inff()), -clampv, clampv);
+                            s0 = __builtin_elementwise_fma(t, *reinterpret_cast<const f32x4*>(s_tw + col), s0);
+                            s1 = __builtin_elementwise_fma(t, *reinterpret_cast<const f32x4*>(s_tw + p.c_out + col), s1);
+                            s2 = __builtin_elementwise_fma(t, *reinterpret_cast<const f32x4*>(s_tw + 2 * p.c_out + col), s2);
+                        }
+                    }
+                float pk[3] = {(s0[0] + s0[1]) + (s0[2] + s0[3]), (s1[0] + s1[1]) + (s1[2] + s1[3]), (s2[0] + s2[1]) + (s2[2] + s2[3])};
+                float a[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned u = __builtin_bit_cast(unsigned, pk[k]);
+                    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = lower half's, r[1] = upper half's
+                    a[k] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+                }
+                if (lh == 0) nb_torgb_pixel(p.tg, n, (y0 + wn * NBW + nb) * W + x0 + l31, a[0], a[1], a[2], s_tcol, s_tcol01);
+            }
+            NB_TSTAMP(3);
+            NB_TSTAMP(4);
+            return;
+        }
+    }
     float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG] floats (<= 128 KiB)
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -570,12 +616,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     if (p.tg.c) {
         // ToRGB on the tile while it sits in LDS: 3 dot products over the channels per pixel, then the triad tail
         for (int pix = tid; pix < PIX_WG; pix += 512) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-            for (int ch = 0; ch < p.c_out; ++ch) {
-                const float xv = ot[ch * PIX_WG + pix];
-                a0 += xv * s_tw[ch]; a1 += xv * s_tw[p.c_out + ch]; a2 += xv * s_tw[2 * p.c_out + ch];
-            }
+            float a0, a1, a2;
+            nb_torgb_dot(p.c_out, s_tw, [&](int ch) { return ot[ch * PIX_WG + pix]; }, a0, a1, a2);
             nb_torgb_pixel(p.tg, n, (y0 + (pix >> 5)) * W + x0 + (pix & 31), a0, a1, a2, s_tcol, s_tcol01);
         }
         if (!p.y) return;
@@ -749,12 +791,8 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
     __syncthreads();
     if (p.tg.c) {
         for (int pix = tid; pix < PIX_WG; pix += 256) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-            for (int ch = 0; ch < p.c_out; ++ch) {
-                const float xv = ot[ch * PIX_WG + pix];
-                a0 += xv * s_tw[ch]; a1 += xv * s_tw[p.c_out + ch]; a2 += xv * s_tw[2 * p.c_out + ch];
-            }
+            float a0, a1, a2;
+            nb_torgb_dot(p.c_out, s_tw, [&](int ch) { return ot[ch * PIX_WG + pix]; }, a0, a1, a2);
             nb_torgb_pixel(p.tg, n, (y0 + (pix >> 5)) * W + x0 + (pix & 31), a0, a1, a2, s_tcol, s_tcol01);
         }
         if (!p.y) return;

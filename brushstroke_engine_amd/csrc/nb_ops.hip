@@ -672,22 +672,50 @@ __global__ __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
     __syncthreads();
     const int pix = (blockIdx.x * 256 + t) * V;
     if (pix >= p.hw) return;
+    // the summation order of nb_torgb_dot (nb_torgb.h), V pixels at a time
     float a0[V], a1[V], a2[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) a0[j] = a1[j] = a2[j] = 0.f;
     const float* xp = p.x + (size_t)n * p.c * p.hw + pix;
-#pragma unroll 8
-    for (int ch = 0; ch < p.c; ++ch) {
-        float xv[V];
-        if constexpr (V == 4) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(xp + (size_t)ch * p.hw);
-            xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2]; xv[3] = q[3];
-        } else {
-            xv[0] = xp[(size_t)ch * p.hw];
-        }
-        const float w0 = sw[ch], w1 = sw[p.c + ch], w2 = sw[2 * p.c + ch];
+    {
+        float s[3][2][4][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) { a0[j] += xv[j] * w0; a1[j] += xv[j] * w1; a2[j] += xv[j] * w2; }
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) s[k][h][j][v] = 0.f;
+        for (int mg = 0; mg * 8 < p.c; ++mg) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = mg * 8 + 4 * h + j;
+                    if (ch < p.c) {
+                        float xv[V];
+                        if constexpr (V == 4) {
+                            const f32x4 q = *reinterpret_cast<const f32x4*>(xp + (size_t)ch * p.hw);
+                            xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2]; xv[3] = q[3];
+                        } else {
+                            xv[0] = xp[(size_t)ch * p.hw];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float wk = sw[k * p.c + ch];
+#pragma unroll
+                            for (int v = 0; v < V; ++v) s[k][h][j][v] = __builtin_fmaf(xv[v], wk, s[k][h][j][v]);
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float a[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                a[k] = ((s[k][0][0][v] + s[k][0][1][v]) + (s[k][0][2][v] + s[k][0][3][v])) + ((s[k][1][0][v] + s[k][1][1][v]) + (s[k][1][2][v] + s[k][1][3][v]));
+            a0[v] = a[0]; a1[v] = a[1]; a2[v] = a[2];
+        }
     }
     const float b0 = p.bias[0], b1 = p.bias[1], b2 = p.bias[2];
     const float sf = p.sfactor ? p.sfactor[n] : 0.f;

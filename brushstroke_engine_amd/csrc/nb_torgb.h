@@ -35,6 +35,41 @@ __device__ __forceinline__ void nb_torgb_setup(const TorgbParams& p, int n, floa
     }
 }
 
+// The 3 x c dot products of the 1x1 conv in ONE summation order, shared by every implementation (standalone kernel, LDS
+// image of the fused kernel, accumulator registers of the fused kernel) so that they agree bit for bit.  The order follows
+// the MFMA accumulator layout: channel ch = 32 m + 8 g + 4 h + j (h = lane half, j = register within a group of 4); the
+// partial sums s[h][j] run over (m, g) ascending with fused multiply-adds, and
+//   total = ((s[0][0] + s[0][1]) + (s[0][2] + s[0][3])) + ((s[1][0] + s[1][1]) + (s[1][2] + s[1][3])).
+// x(ch) returns channel ch of the pixel; sw = [3][c] modulated weights.
+template <typename GetX>
+__device__ __forceinline__ void nb_torgb_dot(int c, const float* sw, GetX x, float& a0, float& a1, float& a2) {
+    float s[3][2][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[k][h][j] = 0.f;
+    for (int mg = 0; mg * 8 < c; ++mg) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = mg * 8 + 4 * h + j;
+                if (ch < c) {
+                    const float xv = x(ch);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s[k][h][j] = __builtin_fmaf(xv, sw[k * c + ch], s[k][h][j]);
+                }
+            }
+    }
+    float a[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        a[k] = ((s[k][0][0] + s[k][0][1]) + (s[k][0][2] + s[k][0][3])) + ((s[k][1][0] + s[k][1][1]) + (s[k][1][2] + s[k][1][3]));
+    a0 = a[0]; a1 = a[1]; a2 = a[2];
+}
+
 // One pixel: (a0, a1, a2) = the 1x1 modulated conv before the bias -> every requested output.
 __device__ __forceinline__ void nb_torgb_pixel(const TorgbParams& p, int n, int pix, float a0, float a1, float a2,
                                                const float* scol, const float* scol01) {
