@@ -102,5 +102,35 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def kernel_resources(lib: str = LIB) -> dict:
+    """Per-kernel register / scratch figures from the code-object metadata of the built library:
+    {kernel name: dict(vgpr, sgpr_spill, vgpr_spill, scratch_bytes, lds_bytes)}.  The split-f16 kernels count their
+    outstanding LDS-DMA operations (``s_waitcnt vmcnt(N)``), so compiler-made scratch traffic inside them is a
+    defect to be caught at build time (tests/test_abi.py), not a performance footnote."""
+    import re
+    import shutil
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin")
+    tmp = tempfile.mkdtemp(prefix="nbres")
+    try:
+        work = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, work)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", work], cwd=tmp, check=True, capture_output=True)
+        out = {}
+        for f in sorted(os.listdir(tmp)):
+            if ARCH not in f:
+                continue
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            for block in notes.split("- .agpr_count:")[1:]:
+                def field(name):
+                    m = re.search(r"\." + name + r":\s+(\S+)", block)
+                    return m.group(1) if m else None
+                out[field("name")] = dict(vgpr=int(field("vgpr_count")), sgpr_spill=int(field("sgpr_spill_count")), vgpr_spill=int(field("vgpr_spill_count")),
+                                          scratch_bytes=int(field("private_segment_fixed_size")), lds_bytes=int(field("group_segment_fixed_size")))
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

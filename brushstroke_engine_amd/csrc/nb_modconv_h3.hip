@@ -124,6 +124,16 @@ __device__ __forceinline__ unsigned nb_pk4_fp8_sat(float a, float b, float c, fl
 }
 __device__ __forceinline__ void nb_set_fp16_ovfl() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
+// v_permlane32_swap: exchanges a[lanes 32..63] with b[lanes 0..31] in place.  Afterwards lanes 0..31 hold (a, b) = (their
+// own a, the upper lanes' a) and lanes 32..63 hold (the lower lanes' b, their own b).  Written as inline assembly with both
+// registers read-write: the compiler's builtin (__builtin_amdgcn_permlane32_swap, ROCm 7.2) returned the FIRST result for
+// both elements whenever its two results met again in one expression or one of the operands was a constant
+// (tools/microbench/permlane_swap_const.hip).  The two wait states cover a VALU write of an operand right before it
+// (the hazard the compiler pads with s_nop when it emits the instruction itself).  Needs every lane active.
+__device__ __forceinline__ void nb_swap32(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -151,8 +161,19 @@ __device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float 
 // 16-byte slots (8-byte halves of the f8 lo slots) at consecutive pixels: 512 contiguous bytes per half-wave.
 // s_dco / s_bias / s_nst: the workgroup's per-channel tables (16-byte aligned); colbase = first channel of the wave's
 // 64-row band within them; trow0 = the wave's first tile row.
+// (The kernel parameters it needs come by value: handing the __global__ function's parameter struct on by reference makes
+//  the compiler keep a copy of it in scratch memory.)
+struct H3HandoffArgs {
+    _Float16* yh2;
+    int c8_next, c_out, h, w, out_f8, dbg;
+    float alpha, gain, clamp;
+};
+__device__ __forceinline__ H3HandoffArgs nb_handoff_args(_Float16* yh2, int c8_next, int c_out, int h, int w, int out_f8, int dbg, float alpha, float gain,
+                                                         float clamp) {
+    return H3HandoffArgs{yh2, c8_next, c_out, h, w, out_f8, dbg, alpha, gain, clamp};
+}
 template <int MB, int NBW>
-__device__ __forceinline__ void nb_up1_handoff_epilogue(const H3Params& p, const f32x16 (&acc)[MB][NBW], const float (&nzr)[NBW], const float* s_dco,
+__device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, const f32x16 (&acc)[MB][NBW], const float (&nzr)[NBW], const float* s_dco,
                                                         const float* s_bias, const float* s_nst, int colbase, int trow0, int co0, int n, int y0, int x0,
                                                         int lh, int l31) {
     const int W = p.w;
@@ -202,9 +223,9 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3Params& p, const
                 unsigned ha[2], hb[2], la[2], lb[2];      // a = channels 0-3, b = channels 4-7 of the owned group
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const u32x2 rh = __builtin_amdgcn_permlane32_swap(hi[0][k], hi[1][k], false, false);
-                    const u32x2 rl = __builtin_amdgcn_permlane32_swap(lo[0][k], lo[1][k], false, false);
-                    ha[k] = rh[0]; hb[k] = rh[1]; la[k] = rl[0]; lb[k] = rl[1];
+                    ha[k] = hi[0][k]; hb[k] = hi[1][k]; la[k] = lo[0][k]; lb[k] = lo[1][k];
+                    nb_swap32(ha[k], hb[k]);
+                    nb_swap32(la[k], lb[k]);
                 }
                 if (cg * 8 < p.c_out && !(p.dbg & 1)) {
                     const size_t pix8 = ((size_t)(y0 + trow0 + nb) * W + x0 + l31) * 8;
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     // the accumulator registers directly, and whole 512-byte row segments per wave-instruction.
     constexpr int PIX_WG = TH * 32;
     if (p.yh2) {
-        nb_up1_handoff_epilogue<MB, NBW>(p, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
+        nb_up1_handoff_epilogue<MB, NBW>(nb_handoff_args(p.yh2, p.c8_next, p.c_out, p.h, p.w, p.out_f8, p.dbg, p.alpha, p.gain, p.clamp), acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
         NB_TSTAMP(3);
         NB_TSTAMP(4);
         return;
@@ -585,9 +606,10 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 float a[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const unsigned u = __builtin_bit_cast(unsigned, pk[k]);
-                    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = lower half's, r[1] = upper half's
-                    a[k] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+                    // swap(x, 0): the lower lanes get (their own, the upper lanes') partial sums
+                    unsigned u0 = __builtin_bit_cast(unsigned, pk[k]), u1 = 0;
+                    nb_swap32(u0, u1);
+                    a[k] = __builtin_bit_cast(float, u0) + __builtin_bit_cast(float, u1);
                 }
                 if (lh == 0) nb_torgb_pixel(p.tg, n, (y0 + wn * NBW + nb) * W + x0 + l31, a[0], a[1], a[2], s_tcol, s_tcol01);
             }
@@ -772,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
 
     if (p.yh2) {
-        nb_up1_handoff_epilogue<MB, NBW>(p, acc, nzr, s_dco, s_bias, s_nst, 0, wn * NBW, co0, n, y0, x0, lh, l31);
+        nb_up1_handoff_epilogue<MB, NBW>(nb_handoff_args(p.yh2, p.c8_next, p.c_out, p.h, p.w, p.out_f8, p.dbg, p.alpha, p.gain, p.clamp), acc, nzr, s_dco, s_bias, s_nst, 0, wn * NBW, co0, n, y0, x0, lh, l31);
         return;
     }
     float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG]
@@ -1344,9 +1366,9 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 for (int px = 0; px < 2; ++px)
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const u32x2 rh = __builtin_amdgcn_permlane32_swap(hi[0][px][k], hi[1][px][k], false, false);
-                        const u32x2 rl = __builtin_amdgcn_permlane32_swap(lo[0][px][k], lo[1][px][k], false, false);
-                        ha[px][k] = rh[0]; hb[px][k] = rh[1]; la[px][k] = rl[0]; lb[px][k] = rl[1];
+                        ha[px][k] = hi[0][px][k]; hb[px][k] = hi[1][px][k]; la[px][k] = lo[0][px][k]; lb[px][k] = lo[1][px][k];
+                        nb_swap32(ha[px][k], hb[px][k]);
+                        nb_swap32(la[px][k], lb[px][k]);
                     }
                 const int cg = co0 / 8 + 2 * R + gs;
                 const int oy = 2 * qi + lh, ox = 2 * qj;
