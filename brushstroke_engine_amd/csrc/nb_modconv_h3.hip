@@ -365,15 +365,18 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         // The compiler, left alone, sinks every fragment read to just before its first use and waits with lgkmcnt(0)
         // right after issuing it (five exposed LDS latencies per step with both waves of a SIMD in lockstep).  Here
         // every statement group is followed by a scheduling fence, so the program order below is the issue order:
-        //     after barrier(t-1):  reads tap 0, tap 1 of step t | corrections of tap 2 of step t-1 (4 x 64 cycles of cover)
-        //     tap 0 main | reads tap 2 | tap 1 main | corrections taps 0+1 | tap 2 main | DMA issues | wait | barrier(t)
+        //     after barrier(t-1):  reads tap 0, tap 1 of step t | tap 2 main of step t-1 (4 x 32 cycles of cover) |
+        //                          on even t: tap-2 corrections of steps t-2 and t-1 together (4 x 64 cycles)
+        //     tap 0 main | reads tap 2 | tap 1 main | corrections taps 0+1 | DMA issues | wait | barrier(t)
         // i.e. a fragment is read at least one matrix group (128-256 cycles) before the group that consumes it.
-        // Per accumulator: step t contributes  f8(A2,0|B2,.)[t-1], A0 B0, A1 B1, f8(A0,A1|B0,B1), A2 B2.
+        // The third tap of a row has no partner within its step, so its corrections ride with the third tap of the NEXT step
+        // in one K = 64 fp8 instruction (quad 0 = even step, quad 1 = odd step): 7 fp8 instructions per two steps instead of
+        // 8, 768 instead of 896 matrix cycles per step and tile row.
 #define NB_SB __builtin_amdgcn_sched_barrier(0)
 #define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
         const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
         h8 ah0[MB], ah1[MB], ah2[MB], bh0[NBW], bh1[NBW], bh2[NBW];
-        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];          // fp8 operand tuples: (tap 0 | tap 1), (tap 2 | zero)
+        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];          // fp8 operand tuples: (tap 0 | tap 1), (tap 2 of an even step | of the odd step after it)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -395,16 +398,16 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             }
             NB_SB;
         };
-        auto rd_tap2 = [&](const h8* wb, const h8* xb, int ky) {
+        auto rd_tap2 = [&](const h8* wb, const h8* xb, int ky, int odd) {       // odd = quad of the tap-2 tuples
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 ah2[mb] = wb[a_base + 2 * 4 * CO_WG + mb * 32];
-                NB_Q(al2[mb], 0, wb[a_base + 2 * 4 * CO_WG + CO_WG + mb * 32]);
+                if (odd) { NB_Q(al2[mb], 1, wb[a_base + 2 * 4 * CO_WG + CO_WG + mb * 32]); } else { NB_Q(al2[mb], 0, wb[a_base + 2 * 4 * CO_WG + CO_WG + mb * 32]); }
             }
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 bh2[nb] = xb[b_base + (nb + ky) * TWP + 2];
-                NB_Q(bl2[nb], 0, xb[b_base + XPL + (nb + ky) * TWP + 2]);
+                if (odd) { NB_Q(bl2[nb], 1, xb[b_base + XPL + (nb + ky) * TWP + 2]); } else { NB_Q(bl2[nb], 0, xb[b_base + XPL + (nb + ky) * TWP + 2]); }
             }
             NB_SB;
         };
@@ -423,33 +426,46 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                     NB_SB;
                 }
         };
-        for (int c = 0; c < NC; ++c) {
+        // the loop runs over PAIRS of steps (t = 2 tp, 2 tp + 1) so that the tuple quad is a compile-time constant
+        auto step = [&](int t, int odd, bool first) {
+            const int c = t / 3, ky = t - 3 * c;
             const h8* xb = xbuf + (c & 1) * 4 * XPL;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int t = c * 3 + ky;
-                const h8* wb = wring + (t & 3) * WSLOTS;
-                NB_SB;
-                rd_tap01(wb, xb, ky, 0);
-                rd_tap01(wb, xb, ky, 1);
-                corr4(al2, bl2);                       // tap 2 of the previous step (zeros before the first one)
-                main4(ah0, bh0);
-                rd_tap2(wb, xb, ky);
-                main4(ah1, bh1);
-                corr4(al01, bl01);
-                // keep the LDS-DMA stream 3 sub-chunks ahead (past the end: harmless re-copies keep the counts uniform)
-                issue_w(clampt(t + 3), wring + ((t + 3) & 3) * WSLOTS);
-                if (ky == 0) issue_x(c + 1 < NC ? c + 1 : NC - 1, xbuf + ((c + 1) & 1) * 4 * XPL);
-                NB_SB;
-                main4(ah2, bh2);
-                // everything issued before sub-chunk t-1 must have landed (it is what sub-chunk t+1 reads)
-                if (ky == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW + NXPW) : "memory");
-                __builtin_amdgcn_s_barrier();
-            }
+            const h8* wb = wring + (t & 3) * WSLOTS;
+            NB_SB;
+            rd_tap01(wb, xb, ky, 0);
+            rd_tap01(wb, xb, ky, 1);
+            if (!first) main4(ah2, bh2);               // tap 2 of the previous step
+            if (!odd && !first) corr4(al2, bl2);       // tap-2 corrections of the two previous steps
+            main4(ah0, bh0);
+            rd_tap2(wb, xb, ky, odd);
+            main4(ah1, bh1);
+            corr4(al01, bl01);
+            // keep the LDS-DMA stream 3 sub-chunks ahead (past the end: harmless re-copies keep the counts uniform)
+            issue_w(clampt(t + 3), wring + ((t + 3) & 3) * WSLOTS);
+            if (ky == 0) issue_x(c + 1 < NC ? c + 1 : NC - 1, xbuf + ((c + 1) & 1) * 4 * XPL);
+            NB_SB;
+            // everything issued before sub-chunk t-1 must have landed (it is what sub-chunk t+1 reads)
+            if (ky == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW + NXPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        for (int t = 0; t < T; t += 2) {
+            step(t, 0, t == 0);
+            if (t + 1 < T) step(t + 1, 1, false);
         }
         NB_SB;
-        corr4(al2, bl2);                               // the last step's tap 2
+        main4(ah2, bh2);                               // the last step's tap 2
+        if (T & 1) {                                   // odd number of steps: the last tuple holds one tap only
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) al2[mb][r] = 0;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
+        }
+        corr4(al2, bl2);
 #undef NB_Q
 #undef NB_SB
     } else
