@@ -1268,7 +1268,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
 #pragma unroll
     for (int R = 0; R < 2; ++R) {
         if (p.tstamps) te0 = __builtin_amdgcn_s_memtime();
-        if (R) __syncthreads();                       // the previous round's reads are done
+        // LDS-only barriers: __syncthreads() would also wait (vmcnt(0)) for the previous round's global stores to retire
+        if (R) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the previous round's reads are done
 #pragma unroll
         for (int gs = 0; gs < 2; ++gs) {
             const int r0 = (2 * R + gs) * 4;
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 }
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_w += t_ - te0; te0 = t_; }
         auto quad_item = [&](const int wi) {
             const int hq = wi * 32 + l31;             // (g, quad); lane half = channel half
