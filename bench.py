@@ -342,7 +342,7 @@ def main():
     # after the timed region: the dominant kernel once more with the whole batch on ONE stream (3 steps), so that its
     # launch duration is also known without another stream's kernels sharing the chip
     iso = {}
-    if G.sub_streams > 1:
+    if sub > 1:
         keep = G.sub_streams
         G.sub_streams = 1
         for _ in range(2):                           # (first single-stream steps build that workspace: not measured)

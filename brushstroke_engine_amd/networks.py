@@ -861,9 +861,12 @@ class Generator(torch.nn.Module):
 
     # Two sub-batches in flight on two HIP streams: every launch of a layer ends with a partially filled last round
     # of workgroups and the next layer cannot start before it drains; with a second, independent chain of launches
-    # the CUs that fall idle at one chain's kernel boundary pick up the other chain's workgroups (+7.6 % at batch 32).
+    # the CUs that fall idle at one chain's kernel boundary pick up the other chain's workgroups.  Worth +5 % at batch 64;
+    # at batch 32 it was +7.6 % in round 1 and is +0.5 % since the small-image layers moved to the large kernels and the
+    # epilogues were rewritten (tools/sub_stream_sweep.py), so a batch of 32 runs as ONE chain: every launch then has the
+    # chip to itself and its HIP-event duration is the kernel's own time.
     sub_streams = 2
-    sub_stream_min_batch = 16
+    sub_stream_min_batch = 64
 
     def _forward_split(self, ws, geom_feature, positions, return_debug_data, return_features, kw):
         n = ws.shape[0]
