@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lock = threading.Lock()
 _lib = None
@@ -100,6 +100,10 @@ PROTOTYPES = {
     "nb_enc_conv3x3_h3_handoff": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_float, vp]),
     "nb_enc_upsample2x_h2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_enc_stem7x7_f32_h2_ex": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "nb_enc_conv3x3_ex": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "nb_enc_upsample2x_h2_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "nb_pack_conv_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
 }
 

@@ -36,10 +36,20 @@ __device__ __forceinline__ float nb_lrelu(float v, float slope) { return v < 0.f
 // ------------------------------------------------------------------------------------------------
 // stem: 1 -> 64 channels, 7x7, reflect padding 3; fp32 [n,1,h,w] -> H2 [n,8,2,h,w,8]
 // ------------------------------------------------------------------------------------------------
+// four values -> four e4m3 bytes, saturated to the format's range (the same conversion as nb_pk4_fp8 of nb_modconv_h3.hip)
+__device__ __forceinline__ unsigned nb_enc_pk4_fp8(float a, float b, float c, float d) {
+    auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+    return (unsigned)w;
+}
+
 struct StemParams {
     const float* x; const float* w50; const float* bias; _Float16* y;
     int h, w, tiles_x, preproc;
     float slope;
+    int out_f8;             // lo planes in the "f8" operand format (fp8 correction operands) instead of f16 residuals
 };
 
 __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
@@ -98,14 +108,23 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
             for (int g = 0; g < 4; ++g) {
                 const int co = mb * 32 + 8 * g + 4 * lh;
                 h4 vh, vl;
+                float vv[4], xl[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = nb_lrelu(acc[mb][nb][4 * g + j] + p.bias[co + j], p.slope);
                     const _Float16 hi = (_Float16)v;
-                    vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+                    vv[j] = v; xl[j] = v - (float)hi;
+                    vh[j] = hi; vl[j] = (_Float16)xl[j];
                 }
                 *reinterpret_cast<h4*>(sh + l31 * CP + co) = vh;
-                *reinterpret_cast<h4*>(sl + l31 * CP + co) = vl;
+                if (p.out_f8) {
+                    // lo image as bytes: per 16-channel chunk 16 x fp8(xl 2^9) then 16 x fp8(v/4) (= the chunk's two lo slots)
+                    unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)l31 * (CP * 2) + (co >> 4) * 32 + (co & 15);
+                    *reinterpret_cast<unsigned*>(sb) = nb_enc_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
+                    *reinterpret_cast<unsigned*>(sb + 16) = nb_enc_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
+                } else {
+                    *reinterpret_cast<h4*>(sl + l31 * CP + co) = vl;
+                }
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes are done (wave-private stage)
         const int oy = y0 + wv * NBW + nb;
@@ -120,14 +139,21 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
     }
 }
 
+extern "C" int nb_enc_stem7x7_f32_h2_ex(const float* x, const float* w50, const float* bias, void* y_h2, int out_fmt, int n, int h, int w,
+                                        int preproc, float slope, void* stream);
 extern "C" int nb_enc_stem7x7_f32_h2(const float* x, const float* w50, const float* bias, void* y_h2, int n, int h, int w,
                                      int preproc, float slope, void* stream) {
+    return nb_enc_stem7x7_f32_h2_ex(x, w50, bias, y_h2, 0, n, h, w, preproc, slope, stream);
+}
+extern "C" int nb_enc_stem7x7_f32_h2_ex(const float* x, const float* w50, const float* bias, void* y_h2, int out_fmt, int n, int h, int w,
+                                        int preproc, float slope, void* stream) {
+    NB_REQUIRE(out_fmt == 0 || out_fmt == 1, "enc_stem7x7: output format must be 0 (H2) or 1 (f8)");
     NB_REQUIRE(x && w50 && bias && y_h2, "enc_stem7x7: null pointer");
     NB_REQUIRE(n >= 1 && n <= 65535 && h % 16 == 0 && w % 32 == 0 && h >= 16 && w >= 32,
                "enc_stem7x7: needs h %% 16 == 0 and w %% 32 == 0 (got %dx%d)", h, w);
     NB_REQUIRE(preproc >= 0 && preproc <= 2, "Unknown preprocessing type %d", preproc);
     NB_REQUIRE((uintptr_t)y_h2 % 16 == 0, "enc_stem7x7: output must be 16-byte aligned");
-    StemParams p{x, w50, bias, (_Float16*)y_h2, h, w, w / 32, preproc, slope};
+    StemParams p{x, w50, bias, (_Float16*)y_h2, h, w, w / 32, preproc, slope, out_fmt};
     hipLaunchKernelGGL(enc_stem7x7_kernel, dim3((w / 32) * (h / 16), n), dim3(256), 0, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("enc_stem7x7");
     return NB_OK;
@@ -136,15 +162,6 @@ extern "C" int nb_enc_stem7x7_f32_h2(const float* x, const float* w50, const flo
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv, stride 1 or 2, reflect padding 1, split-f16
 // ------------------------------------------------------------------------------------------------
-// four values -> four e4m3 bytes, saturated to the format's range (the same conversion as nb_pk4_fp8 of nb_modconv_h3.hip)
-__device__ __forceinline__ unsigned nb_enc_pk4_fp8(float a, float b, float c, float d) {
-    auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
-    return (unsigned)w;
-}
-
 struct EncConvParams {
     const _Float16* x;      // H2 [n][c8][2][hin][win][8]
     const _Float16* wts;    // [nchunks][3][3][2][2][co_ld][8], co_ld % 128 == 0
@@ -160,7 +177,15 @@ struct EncConvParams {
     int oscale_stride, c8_total, cg0, out_f8;
 };
 
-template <int STRIDE, int LW, int OUT>
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// F8: the input activations and the weights carry their corrections as fp8 (the "f8" operand format of nb_modconv_h3.hip:
+// lo slot of an even channel group = fp8(xl 2^9) of the 16-channel chunk, of the odd group = fp8(x/4); weights fp8(w) /
+// fp8(wl 2^11)); per tap one f16 MFMA for the main product and, per PAIR of taps, one block-scaled K=64 fp8 MFMA for both
+// correction products (the third tap of a step pairs with the third tap of the next step): 768 instead of 1152 matrix
+// cycles per step and tile row.
+template <int STRIDE, int LW, int OUT, bool F8 = false>
 __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams p) {
     constexpr int NW = 8, NWN = 4, MB = 2, NBW = 2, CO_WG = 128;
     constexpr int WT = 1 << LW, RPB = 32 / WT, TH = NWN * NBW * RPB, PW = WT + 2;      // output tile TH x WT = 256 pixels
@@ -243,6 +268,94 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     const int a_base = lh * 2 * CO_WG + wm * 64 + l31;
     const int b_base = lh * 2 * XPL + ((wn * NBW) * RPB + (l31 >> LW)) * PW + (l31 & (WT - 1));
     issue(0, 0);
+    if constexpr (F8) {
+#define NB_SB __builtin_amdgcn_sched_barrier(0)
+#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
+        const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;        // E8M0 block scales: fp8(w) fp8(xl 2^9) 2^-9 | fp8(wl 2^11) 2^-11 fp8(x/4) 2^2
+        h8 ah0[MB], ah1[MB], ah2[MB], bh0[NBW], bh1[NBW], bh2[NBW];
+        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];          // fp8 tuples: (tap 0 | tap 1), (tap 2 of an even step | of the odd step after it)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) al2[mb][r] = 0;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bl2[nb][r] = 0;
+        auto main4 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) { acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0); NB_SB; }
+        };
+        auto corr4 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 0, 0, 0, sa, 0, sb);
+                    NB_SB;
+                }
+        };
+        auto step = [&](int t, int odd, bool first) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of step t has landed
+            __builtin_amdgcn_s_barrier();                         // ... everybody's has, and step t-1 is fully consumed
+            issue(t + 1 < T ? t + 1 : T - 1, (t + 1) & 1);        // past the end: a harmless re-copy keeps the flow uniform
+            NB_SB;
+            const h8* xb = xbuf + (t & 1) * 4 * XPL;
+            const h8* wb = wbuf + (t & 1) * WSLOTS;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                ah0[mb] = wb[a_base + mb * 32];
+                NB_Q(al01[mb], 0, wb[a_base + CO_WG + mb * 32]);
+                ah1[mb] = wb[a_base + 4 * CO_WG + mb * 32];
+                NB_Q(al01[mb], 1, wb[a_base + 4 * CO_WG + CO_WG + mb * 32]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                bh0[nb] = xb[b_base + nb * RPB * PW + KX0];
+                NB_Q(bl01[nb], 0, xb[b_base + XPL + nb * RPB * PW + KX0]);
+                bh1[nb] = xb[b_base + nb * RPB * PW + KX1];
+                NB_Q(bl01[nb], 1, xb[b_base + XPL + nb * RPB * PW + KX1]);
+            }
+            NB_SB;
+            if (!first) main4(ah2, bh2);                           // tap 2 of the previous step
+            if (!odd && !first) corr4(al2, bl2);                   // tap-2 corrections of the two previous steps
+            main4(ah0, bh0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                ah2[mb] = wb[a_base + 2 * 4 * CO_WG + mb * 32];
+                if (odd) { NB_Q(al2[mb], 1, wb[a_base + 2 * 4 * CO_WG + CO_WG + mb * 32]); } else { NB_Q(al2[mb], 0, wb[a_base + 2 * 4 * CO_WG + CO_WG + mb * 32]); }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                bh2[nb] = xb[b_base + nb * RPB * PW + KX2];
+                if (odd) { NB_Q(bl2[nb], 1, xb[b_base + XPL + nb * RPB * PW + KX2]); } else { NB_Q(bl2[nb], 0, xb[b_base + XPL + nb * RPB * PW + KX2]); }
+            }
+            NB_SB;
+            main4(ah1, bh1);
+            corr4(al01, bl01);
+        };
+        for (int t = 0; t < T; t += 2) {
+            step(t, 0, t == 0);
+            if (t + 1 < T) step(t + 1, 1, false);
+        }
+        NB_SB;
+        main4(ah2, bh2);                                           // the last step's tap 2
+        if (T & 1) {                                               // odd number of steps: the last tuple holds one tap only
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) al2[mb][r] = 0;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
+        }
+        corr4(al2, bl2);
+#undef NB_Q
+#undef NB_SB
+    } else
     for (int t = 0; t < T; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my share of step t has landed
         __builtin_amdgcn_s_barrier();                             // ... everybody's has, and step t-1 is fully consumed
@@ -367,7 +480,7 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     }
 }
 
-template <int STRIDE, int LW, int OUT>
+template <int STRIDE, int LW, int OUT, bool F8 = false>
 static int launch_enc_conv(EncConvParams p, int n, hipStream_t st) {
     constexpr int WT = 1 << LW, TH = 8 * (32 / WT), PW = WT + 2, SLOTS = STRIDE * TH * PW, XPL = ((SLOTS + 63) / 64) * 64;
     constexpr size_t staging = (size_t)(2 * 4 * XPL + 2 * 12 * 128) * 16;
@@ -377,10 +490,10 @@ static int launch_enc_conv(EncConvParams p, int n, hipStream_t st) {
     p.tiles_x = p.wout / WT; p.tiles_y = p.hout / TH; p.slices = (p.c_out + 127) / 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)enc_conv3x3_h3_kernel<STRIDE, LW, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((enc_conv3x3_h3_kernel<STRIDE, LW, OUT>), dim3(p.tiles_x * p.tiles_y * p.slices, n), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8>), dim3(p.tiles_x * p.tiles_y * p.slices, n), dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("enc_conv3x3_h3");
     return NB_OK;
 }
@@ -541,7 +654,8 @@ extern "C" void nb_debug_set_enc_small(int mode) { g_enc_small = mode; }
 
 static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2,
                                const float* oscale, int oscale_stride, int c8_total, int cg0, int out_fmt,
-                               int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
+                               int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream, int in_fmt = 0) {
+    NB_REQUIRE(in_fmt == 0 || (in_fmt == 1 && c_in % 16 == 0), "enc_conv3x3_h3: operand format must be 0 (H2) or 1 (f8, c_in %% 16 == 0)");
     NB_REQUIRE(x_h2 && w_h3 && bias && ((y_f32 != nullptr) != (y_h2 != nullptr)), "enc_conv3x3_h3: need x, w, bias and exactly one output");
     NB_REQUIRE(n >= 1 && n <= 65535 && c_in >= 1 && c_out >= 1 && (stride == 1 || stride == 2), "enc_conv3x3_h3: bad sizes");
     NB_REQUIRE(h_in % stride == 0 && w_in % stride == 0 && h_in >= 2 && w_in >= 2, "enc_conv3x3_h3: bad input size %dx%d", h_in, w_in);
@@ -563,7 +677,7 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
     p.oscale = oscale; p.oscale_stride = oscale_stride; p.c8_total = handoff ? c8_total : (c_out + 7) / 8; p.cg0 = handoff ? cg0 : 0;
     p.out_f8 = out_fmt;
     hipStream_t st = (hipStream_t)stream;
-    if (!handoff) {
+    if (!handoff && in_fmt == 0) {
         // under-filled launch (interactive strokes, small batches): the 32 x 32 split-K tiles instead.  Needs whole
         // 16-channel chunks and an output width that is a power of two >= 8 (32 positions = 32 / w rows).
         const long big_wgs = (long)n * (wo / (wide ? 32 : 16)) * (ho / (wide ? 8 : 16)) * ((c_out + 127) / 128);
@@ -581,6 +695,18 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
         }
     }
     const int key = (stride == 2 ? 4 : 0) | (wide ? 2 : 0) | (y_h2 ? 1 : 0);
+    if (in_fmt == 1) {
+        switch (key) {
+            case 0: return launch_enc_conv<1, 4, 0, true>(p, n, st);
+            case 1: return launch_enc_conv<1, 4, 1, true>(p, n, st);
+            case 2: return launch_enc_conv<1, 5, 0, true>(p, n, st);
+            case 3: return launch_enc_conv<1, 5, 1, true>(p, n, st);
+            case 4: return launch_enc_conv<2, 4, 0, true>(p, n, st);
+            case 5: return launch_enc_conv<2, 4, 1, true>(p, n, st);
+            case 6: return launch_enc_conv<2, 5, 0, true>(p, n, st);
+            default: return launch_enc_conv<2, 5, 1, true>(p, n, st);
+        }
+    }
     switch (key) {
         case 0: return launch_enc_conv<1, 4, 0>(p, n, st);
         case 1: return launch_enc_conv<1, 4, 1>(p, n, st);
@@ -606,12 +732,19 @@ extern "C" int nb_enc_conv3x3_h3_handoff(const void* x_h2, int c_in, const void*
                                c_out, stride, slope, stream);
 }
 
+extern "C" int nb_enc_conv3x3_ex(const void* x, int c_in, const void* wts, const float* bias, float* y_f32, void* y_h2,
+                                 const float* oscale, int oscale_stride, int c8_total, int cg0, int in_fmt, int out_fmt,
+                                 int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
+    return nb_enc_conv3x3_impl(x, c_in, wts, bias, y_f32, y_h2, oscale, oscale_stride, c8_total, cg0, out_fmt, n, h_in, w_in, c_out,
+                               stride, slope, stream, in_fmt);
+}
+
 // ------------------------------------------------------------------------------------------------
 // bilinear x2 upsampling, align_corners=True (nn.Upsample in ScaleUp, simple_autoencoder.py:106-121):
 // fp32 NCHW [n,c,h,w] -> H2 [n,c/8,2,2h,2w,8]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void enc_upsample2x_h2_kernel(const float* __restrict__ x, _Float16* __restrict__ y,
-                                                                int c, int h, int w, long long total) {
+                                                                int c, int h, int w, long long total, int out_f8) {
     const int oh = 2 * h, ow = 2 * w, c8 = c / 8;
     const float sy = (float)(h - 1) / (float)(oh - 1), sx = (float)(w - 1) / (float)(ow - 1);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -625,27 +758,46 @@ __global__ __launch_bounds__(256) void enc_upsample2x_h2_kernel(const float* __r
         const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
         const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
         h8 vh, vl;
+        float vv[8], xl[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float* xp = x + ((size_t)n * c + cg * 8 + j) * ((size_t)h * w);
             const float v = hy * (hx * xp[y0 * w + x0] + lx * xp[y0 * w + x1]) + ly * (hx * xp[y1 * w + x0] + lx * xp[y1 * w + x1]);
             const _Float16 hi = (_Float16)v;
-            vh[j] = hi; vl[j] = (_Float16)(v - (float)hi);
+            vv[j] = v; xl[j] = v - (float)hi;
+            vh[j] = hi; vl[j] = (_Float16)xl[j];
         }
-        _Float16* yp = y + ((size_t)(n * c8 + cg) * 2) * ((size_t)oh * ow * 8) + ((size_t)oy * ow + ox) * 8;
+        const size_t OHW8 = (size_t)oh * ow * 8;
+        _Float16* yp = y + ((size_t)(n * c8 + cg) * 2) * OHW8 + ((size_t)oy * ow + ox) * 8;
         *reinterpret_cast<h8*>(yp) = vh;
-        *reinterpret_cast<h8*>(yp + (size_t)oh * ow * 8) = vl;
+        if (out_f8) {
+            // the 16-channel chunk's two lo slots: (even group, lo) = fp8(xl 2^9), (odd group, lo) = fp8(v/4); this group's 8
+            // channels are bytes 8 (cg & 1) .. + 7 of both
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            _Float16* lo_xl = y + ((size_t)(n * c8 + (cg & ~1)) * 2 + 1) * OHW8 + ((size_t)oy * ow + ox) * 8 + (cg & 1) * 4;
+            *reinterpret_cast<u32x2*>(lo_xl) = u32x2{nb_enc_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f),
+                                                     nb_enc_pk4_fp8(xl[4] * 512.f, xl[5] * 512.f, xl[6] * 512.f, xl[7] * 512.f)};
+            *reinterpret_cast<u32x2*>(lo_xl + 2 * OHW8) = u32x2{nb_enc_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f),
+                                                                nb_enc_pk4_fp8(vv[4] * 0.25f, vv[5] * 0.25f, vv[6] * 0.25f, vv[7] * 0.25f)};
+        } else {
+            *reinterpret_cast<h8*>(yp + OHW8) = vl;
+        }
     }
 }
 
+extern "C" int nb_enc_upsample2x_h2_ex(const float* x, void* y_h2, int out_fmt, int n, int c, int h, int w, void* stream);
 extern "C" int nb_enc_upsample2x_h2(const float* x, void* y_h2, int n, int c, int h, int w, void* stream) {
+    return nb_enc_upsample2x_h2_ex(x, y_h2, 0, n, c, h, w, stream);
+}
+extern "C" int nb_enc_upsample2x_h2_ex(const float* x, void* y_h2, int out_fmt, int n, int c, int h, int w, void* stream) {
     NB_REQUIRE(x && y_h2, "enc_upsample2x: null pointer");
+    NB_REQUIRE(out_fmt == 0 || (out_fmt == 1 && c % 16 == 0), "enc_upsample2x: output format must be 0 (H2) or 1 (f8, c %% 16 == 0)");
     NB_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && h >= 2 && w >= 2, "enc_upsample2x: bad sizes (c must be a multiple of 8)");
     NB_REQUIRE((uintptr_t)y_h2 % 16 == 0, "enc_upsample2x: output must be 16-byte aligned");
     const long long total = (long long)n * (c / 8) * 4 * h * w;
     int grid = (int)((total + 255) / 256);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(enc_upsample2x_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y_h2, c, h, w, total);
+    hipLaunchKernelGGL(enc_upsample2x_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y_h2, c, h, w, total, out_fmt);
     NB_CHECK_LAUNCH("enc_upsample2x");
     return NB_OK;
 }

@@ -76,6 +76,29 @@ def pack_enc_weight_h3(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(a.transpose(1, 4, 5, 2, 0, 6, 3))           # [chunk][ky][kx][cg][hl][co][8]
 
 
+def pack_enc_weight_f8(w: np.ndarray) -> np.ndarray:
+    """[O,I,3,3] fp32 (I % 16 == 0) -> the "f8" weight operands in the same containers as :func:`pack_enc_weight_h3`: hi slots
+    = f16(w) of 8 channels; lo slot of chunk group 0 = fp8 e4m3(w), of group 1 = fp8((w - f16(w)) * 2^11), each over the 16
+    channels of the chunk (the weight side of nb_modconv_h3.hip's f8 arithmetic)."""
+    o, i = w.shape[:2]
+    assert i % 16 == 0
+    nch, co_ld = i // 16, -(-o // 128) * 128
+    wp = np.zeros([i, 3, 3, co_ld], np.float32)
+    wp[:, :, :, :o] = w.transpose(1, 2, 3, 0)
+    hi = wp.astype(np.float16)
+    wl = (wp - hi.astype(np.float32)) * 2048.0
+    f8 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    # [chunk][16 ch][ky][kx][co] -> per (chunk, ky, kx, co): 16 bytes
+    b_w = f8(wp).reshape(nch, 16, 3, 3, co_ld).transpose(0, 2, 3, 4, 1)           # [chunk][ky][kx][co][16]
+    b_wl = f8(wl).reshape(nch, 16, 3, 3, co_ld).transpose(0, 2, 3, 4, 1)
+    out = np.zeros([nch, 3, 3, 2, 2, co_ld, 8], np.float16)
+    out[:, :, :, :, 0] = hi.reshape(nch, 2, 8, 3, 3, co_ld).transpose(0, 3, 4, 1, 5, 2)   # [chunk][ky][kx][cg][co][8]
+    ob = out.view(np.uint8).reshape(nch, 3, 3, 2, 2, co_ld, 16)
+    ob[:, :, :, 0, 1] = b_w
+    ob[:, :, :, 1, 1] = b_wl
+    return out
+
+
 class HipGeometryEncoder:
     """``AutoEncoder.encode(geom, res=[0, 1])`` on the hand-written gfx950 kernels: 8 launches per batch
     (stem, 3 stride-2 convs, 2 bottleneck convs, bilinear x2, decoder conv), BatchNorm folded on the host.
@@ -83,6 +106,8 @@ class HipGeometryEncoder:
     ``featuremap_resolution``).  Patch sizes the kernels do not tile (R % 128 != 0) raise."""
 
     _PRE = {None: 0, "none": 0, "-11inverse": 1, "inverse": 2}
+    arith = "f8"           # operand format between the layers for large batches ("h3": hi/lo f16 everywhere)
+    f8_min_batch = 8       # below this the launches are under-filled and the H2-reading small-tile kernel takes over
 
     def __init__(self, state_dict: Dict[str, np.ndarray], preproc_type=None, device="cuda"):
         from . import _lib
@@ -102,7 +127,8 @@ class HipGeometryEncoder:
         for prefix, stride in (("encoder.model.1", 2), ("encoder.model.2", 2), ("encoder.model.3", 2),
                                ("encoder.model.4", 1), ("encoder.model.5", 1), ("decoder.model.0.conv", 1)):
             w, b = _fold_bn(state_dict, prefix)
-            self.convs.append((dev(pack_enc_weight_h3(w)).view(torch.float16), dev(b), w.shape[1], w.shape[0], stride))
+            self.convs.append((dev(pack_enc_weight_h3(w)).view(torch.float16), dev(b), w.shape[1], w.shape[0], stride,
+                               dev(pack_enc_weight_f8(w)).view(torch.float16)))
 
     def feature_channels(self, res=0):
         return [16, 256, 128, 64][res]
@@ -136,30 +162,38 @@ class HipGeometryEncoder:
         P = lambda t: t.data_ptr()
         with torch.cuda.device(self.device):
             st = torch.cuda.current_stream().cuda_stream
+            # operand format between the layers: "f8" (fp8 correction operands, 2/3 of the matrix cycles) for batches that
+            # fill the chip with the large-tile kernel; H2 (hi/lo f16) otherwise -- the small-tile kernel of interactive
+            # strokes reads H2
+            fmt = 1 if (self.arith == "f8" and n >= self.f8_min_batch) else 0
+            W = lambda cv: P(cv[5] if fmt else cv[0])
             a = f16(64, h)
-            check(lib.nb_enc_stem7x7_f32_h2(P(x), P(self.stem[0]), P(self.stem[1]), P(a), n, h, w,
-                                            self._PRE[self.preproc_type], 0.01, st), "enc_stem")
+            check(lib.nb_enc_stem7x7_f32_h2_ex(P(x), P(self.stem[0]), P(self.stem[1]), P(a), fmt, n, h, w,
+                                               self._PRE[self.preproc_type], 0.01, st), "enc_stem")
             r = h
             for i in range(4):                               # three stride-2 stages + 256 -> 32
-                wt, b, ci, co, stride = self.convs[i]
+                _, b, ci, co, stride, _ = self.convs[i]
                 r_out = r // stride
                 y = f16(co, r_out)
-                check(lib.nb_enc_conv3x3_h3(P(a), ci, P(wt), P(b), None, P(y), n, r, r, co, stride, 0.01, st), "enc_conv")
+                check(lib.nb_enc_conv3x3_ex(P(a), ci, W(self.convs[i]), P(b), None, P(y), None, 0, co // 8 if fmt else 0, 0, fmt, fmt,
+                                            n, r, r, co, stride, 0.01, st), "enc_conv")
                 a, r = y, r_out
-            wt, b, ci, co, stride = self.convs[4]            # 32 -> 16: the bottleneck the generator consumes
+            _, b, ci, co, stride, _ = self.convs[4]          # 32 -> 16: the bottleneck the generator consumes
             enc = f32(co, r)
-            check(lib.nb_enc_conv3x3_h3(P(a), ci, P(wt), P(b), P(enc), None, n, r, r, co, 1, 0.01, st), "enc_conv")
+            check(lib.nb_enc_conv3x3_ex(P(a), ci, W(self.convs[4]), P(b), P(enc), None, None, 0, 0, 0, fmt, 0, n, r, r, co, 1, 0.01, st),
+                  "enc_conv")
             up = f16(co, 2 * r)
-            check(lib.nb_enc_upsample2x_h2(P(enc), P(up), n, co, r, r, st), "enc_upsample")
-            wt, b, ci, co, stride = self.convs[5]            # first decoder stage, 16 -> 256
+            check(lib.nb_enc_upsample2x_h2_ex(P(enc), P(up), fmt, n, co, r, r, st), "enc_upsample")
+            _, b, ci, co, stride, _ = self.convs[5]          # first decoder stage, 16 -> 256
             tg = None if not targets else targets.get(1)
             if tg is not None:
                 dec = None
-                check(lib.nb_enc_conv3x3_h3_handoff(P(up), ci, P(wt), P(b), P(tg["dst"]), tg["scale_ptr"], tg["scale_stride"],
-                                                    tg["c8_total"], tg["cg0"], tg["fmt"], n, 2 * r, 2 * r, co, 1, 0.01, st), "enc_conv")
+                check(lib.nb_enc_conv3x3_ex(P(up), ci, W(self.convs[5]), P(b), None, P(tg["dst"]), tg["scale_ptr"], tg["scale_stride"],
+                                            tg["c8_total"], tg["cg0"], fmt, tg["fmt"], n, 2 * r, 2 * r, co, 1, 0.01, st), "enc_conv")
             else:
                 dec = f32(co, 2 * r)
-                check(lib.nb_enc_conv3x3_h3(P(up), ci, P(wt), P(b), P(dec), None, n, 2 * r, 2 * r, co, 1, 0.01, st), "enc_conv")
+                check(lib.nb_enc_conv3x3_ex(P(up), ci, W(self.convs[5]), P(b), P(dec), None, None, 0, 0, 0, fmt, 0, n, 2 * r, 2 * r, co, 1,
+                                            0.01, st), "enc_conv")
         return [enc, dec]
 
 

@@ -231,6 +231,10 @@ class TileOps:
             raise _lib.NeubeHipError("the painting engine needs the generator on a GPU (no CPU path in this build)")
         self.patch_width = G.img_resolution
         self.cfg = G.cfg
+        # the encoder computes in the generator's arithmetic: fp8 correction operands between its layers only when the generator
+        # itself runs "f8" (its features then carry ~3e-4 instead of ~2e-5 absolute error on O(5) values)
+        if hasattr(encoder, "arith"):
+            encoder.arith = "f8" if getattr(G.synthesis, "conv_mode", None) == "f8" else "h3"
         self._streams = None
         self._forked = set()
         self._graphs, self._graph_epoch, self._capturing = {}, None, False

@@ -411,6 +411,19 @@ int nb_enc_conv3x3_h3_handoff(const void* x_h2, int c_in, const void* w_h3, cons
  * (c % 8 == 0) -> H2 [n, c, 2h, 2w]. */
 int nb_enc_upsample2x_h2(const float* x, void* y_h2, int n, int c, int h, int w, void* stream);
 
+/* The encoder layers with the "f8" operand format BETWEEN them (the format of the generator's f8 arithmetic mode: hi f16
+ * + fp8 correction operands per 16-channel chunk; one f16 + half an fp8 MFMA per tap instead of three f16 MFMAs).
+ * in_fmt / out_fmt: 0 = H2, 1 = f8 (c % 16 == 0).  For in_fmt 1 the weights are packed like the generator's f8 weights:
+ * lo slot of chunk group 0 = fp8(w), of group 1 = fp8((w - f16(w)) 2^11), over the 16 channels of the chunk
+ * ([ceil(c_in/16)][3][3][2][2][ceil128(c_out)][8] containers as for H2).  nb_enc_conv3x3_ex is the general form of the
+ * two entry points above (oscale / c8_total / cg0 as in the hand-off; c8_total 0 = a plain tensor of c_out channels). */
+int nb_enc_stem7x7_f32_h2_ex(const float* x, const float* w50, const float* bias, void* y_h2, int out_fmt, int n, int h, int w,
+                             int preproc, float slope, void* stream);
+int nb_enc_conv3x3_ex(const void* x, int c_in, const void* wts, const float* bias, float* y_f32, void* y_h2,
+                      const float* oscale, int oscale_stride, int c8_total, int cg0, int in_fmt, int out_fmt,
+                      int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream);
+int nb_enc_upsample2x_h2_ex(const float* x, void* y_h2, int out_fmt, int n, int c, int h, int w, void* stream);
+
 /* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into the zero-padded
  * wpk[ceil8(c_in)][9][ceil32(c_out)] and wsq[c_in][c_out] = sum_k W^2.  Either output may be NULL. */
 int nb_pack_conv_weight(const float* w, int c_out, int c_in, float* wpk, float* wsq);

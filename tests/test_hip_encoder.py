@@ -153,3 +153,68 @@ def test_lazy_geometry_handoff_equals_fp32_path(mode):
     _, c1 = G.forward_pre_mapped(ws[:1], enc.lazy(geom[:1]), positions=pos[:1], return_debug_data=True, noise_mode="const")
     _, c2 = G.forward_pre_mapped(ws[:1], enc.encode(geom[:1]), positions=pos[:1], return_debug_data=True, noise_mode="const")
     assert torch.equal(c1["uvs"], c2["uvs"])
+
+
+def _f8_decode(t, c):
+    """f8-format tensor [n, c/8, 2, h, w, 8] -> (hi + xl) as fp32 NCHW, i.e. the activation to ~15 bits"""
+    n, c8, _, h, w, _ = t.shape
+    hi = t[:, :, 0].float().permute(0, 1, 4, 2, 3).reshape(n, c8 * 8, h, w)
+    lo = t[:, :, 1].contiguous().view(torch.uint8).view(torch.float8_e4m3fn).float()      # [n, c8, h, w, 16]
+    xl = lo[:, 0::2].permute(0, 1, 4, 2, 3).reshape(n, c8 * 8, h, w)
+    return (hi + xl / 512)[:, :c]
+
+
+@pytest.mark.parametrize("stride,ci,co,h,w,h2out", [(1, 16, 256, 32, 32, False), (2, 64, 128, 64, 64, True),
+                                                     (2, 256, 256, 32, 32, True), (1, 256, 32, 16, 16, True),
+                                                     (2, 128, 256, 64, 128, False), (1, 48, 16, 16, 32, False)])
+def test_enc_conv_layer_f8(stride, ci, co, h, w, h2out):
+    """The same layer with "f8" operands (one f16 + half an fp8 MFMA per tap; the third tap's corrections paired across
+    K steps -- odd and even step counts are both here) against torch fp64: the fp8 correction terms leave
+    2^-11 * 2^-4 relative per product, i.e. ~20x the hi/lo-f16 error."""
+    from brushstroke_engine_amd import ops
+    rs = np.random.RandomState(ci + co)
+    n = 2
+    x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32))
+    wt = (rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rs.randn(co).astype(np.float32)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(
+        torch.nn.functional.pad(x.double(), (1, 1, 1, 1), mode="reflect"), torch.from_numpy(wt).double(),
+        torch.from_numpy(b).double(), stride=stride), 0.01)
+    ho, wo = h // stride, w // stride
+    xd = ops.pack_h2f8(x.cuda(), torch.ones(n, ci, device="cuda"))
+    wd = torch.from_numpy(encmod.pack_enc_weight_f8(wt)).cuda()
+    bd = torch.from_numpy(b).cuda()
+    S = torch.cuda.current_stream().cuda_stream
+    if h2out:
+        y = torch.zeros([n, co // 8, 2, ho, wo, 8], dtype=torch.float16, device="cuda")
+        _lib.check(_lib.lib().nb_enc_conv3x3_ex(_p(xd), ci, _p(wd), _p(bd), None, _p(y), None, 0, co // 8, 0, 1, 1, n, h, w, co, stride,
+                                                0.01, S), "enc_conv")
+        out = _f8_decode(y, co).cpu()
+        tol = 4e-5 + 2e-5 * float(ref.abs().max())            # (+ the 15-bit read-back of the f8 container itself)
+    else:
+        y = torch.empty([n, co, ho, wo], dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib().nb_enc_conv3x3_ex(_p(xd), ci, _p(wd), _p(bd), _p(y), None, None, 0, 0, 0, 1, 0, n, h, w, co, stride, 0.01, S),
+                   "enc_conv")
+        out = y.cpu()
+        tol = 4e-5 * float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) <= tol, (float((out.double() - ref).abs().max()), tol)
+
+
+@pytest.mark.parametrize("res,n,pre", [(128, 9, None), (256, 8, "-11inverse")])
+def test_encoder_f8_matches_oracle(res, n, pre):
+    """Batches >= f8_min_batch run the encoder with f8 operands between its layers: features within 5e-4 of the fp32 oracle
+    (O(1) values; 2e-4 for the hi/lo-f16 path), and the two formats agree to the same level."""
+    rs = np.random.RandomState(res + n)
+    esd = encmod.random_encoder_state_dict(11)
+    geom = (rs.rand(n, 1, res, res) > 0.1).astype(np.float32)
+    geom[:, :, ::7, :] = rs.rand(n, 1, len(range(0, res, 7)), res).astype(np.float32)
+    enc = encmod.HipGeometryEncoder(esd, preproc_type=pre)
+    assert enc.arith == "f8" and n >= enc.f8_min_batch
+    f = enc.encode(torch.from_numpy(geom).cuda())
+    ref = po.encoder_encode(esd, torch.from_numpy(geom), pre)
+    enc.arith = "h3"
+    g = enc.encode(torch.from_numpy(geom).cuda())
+    for a, b, c in zip(f, ref, g):
+        assert float((a.cpu() - b).abs().max()) <= 5e-4, float((a.cpu() - b).abs().max())
+        assert float((c.cpu() - b).abs().max()) <= TOL
+        assert not torch.equal(a, c)                              # (the f8 path really ran)
