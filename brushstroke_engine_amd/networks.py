@@ -429,8 +429,14 @@ class SynthesisNetwork(torch.nn.Module):
                 styles_fn = lib.nb_styles_fast_f32 if self._styles_fast else lib.nb_styles_f32
                 _lib.check(styles_fn(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, n, stream), "styles")
                 if noise_mode == "const":
-                    _lib.check(lib.nb_noise_f32(_p(table), plan.n_layers, plan.max_res, _p(npos), _p(ipos),
-                                                self.img_resolution, n, stream), "noise")
+                    # only the layers this pass runs (the tiled-canvas schedule splits the generator at R/2: the head pass
+                    # needs no 256x256 noise images, the tail pass nothing but those); layers are ordered by resolution
+                    lo_ = 0 if resume is None else sum(1 for sp in cfg.layers if sp.block_res <= resume[0])
+                    hi_ = plan.n_layers if stop_after is None else sum(1 for sp in cfg.layers if sp.block_res <= stop_after)
+                    if hi_ > lo_:
+                        _lib.check(lib.nb_noise_f32(table.data_ptr() + lo_ * ctypes.sizeof(_lib.NbLayerDesc), hi_ - lo_,
+                                                    max(sp.block_res for sp in cfg.layers[lo_:hi_]), _p(npos), _p(ipos),
+                                                    self.img_resolution, n, stream), "noise")
             if noise_mode == "const":
                 shared = npos is None and ipos is None
 
