@@ -871,8 +871,20 @@ class Generator(torch.nn.Module):
     # at batch 32 it was +7.6 % in round 1 and is +0.5 % since the small-image layers moved to the large kernels and the
     # epilogues were rewritten (tools/sub_stream_sweep.py), so a batch of 32 runs as ONE chain: every launch then has the
     # chip to itself and its HIP-event duration is the kernel's own time.
+    # (Below 256x256 the launches are a quarter of the size and the second chain still pays: R=128, batch 32: 34 900 vs
+    # 31 400 patches/s.)
     sub_streams = 2
-    sub_stream_min_batch = 64
+    _sub_stream_min_batch = None             # set to override the rule below
+
+    @property
+    def sub_stream_min_batch(self) -> int:
+        if self._sub_stream_min_batch is not None:
+            return self._sub_stream_min_batch
+        return 64 if self.img_resolution >= 256 else 16
+
+    @sub_stream_min_batch.setter
+    def sub_stream_min_batch(self, v: int):
+        self._sub_stream_min_batch = v
 
     def _forward_split(self, ws, geom_feature, positions, return_debug_data, return_features, kw):
         n = ws.shape[0]
