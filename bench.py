@@ -396,7 +396,9 @@ def main():
         try:
             from brushstroke_engine_amd import build as _b
             tj = json.load(open(tpath))
-            if tj.get("_stamp", {}).get("source_digest") == _b.source_digest():
+            if not (args.res == 256 and B == 32 and args.conv_mode == "f8"):
+                traffic_note = "profiles/hbm_traffic.json holds the default workload (R=256, batch 32, f8): not used for this one"
+            elif tj.get("_stamp", {}).get("source_digest") == _b.source_digest():
                 traffic, traffic_note = tj.get(dom_name), f"rocprofv3 PMC passes at {tj['_stamp'].get('git_head')}, same kernel sources"
             else:
                 traffic_note = "profiles/hbm_traffic.json was measured on other kernel sources (stale): not used"
