@@ -132,5 +132,25 @@ def kernel_resources(lib: str = LIB) -> dict:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def disassembly(lib: str = LIB) -> str:
+    """gfx950 disassembly of every code object in the built library (llvm-objdump; < 1 s)."""
+    import shutil
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin")
+    tmp = tempfile.mkdtemp(prefix="nbdis")
+    try:
+        work = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, work)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", work], cwd=tmp, check=True, capture_output=True)
+        out = []
+        for f in sorted(os.listdir(tmp)):
+            if ARCH in f:
+                out.append(subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", f"--mcpu={ARCH}", os.path.join(tmp, f)], check=True,
+                                          capture_output=True, text=True).stdout)
+        return "\n".join(out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
