@@ -119,8 +119,8 @@ def test_no_scratch_in_counted_wait_kernels(library):
 
 def test_no_packed_f32_high_dword_broadcast(library):
     """`v_pk_{add,mul,fma}_f32 ... op_sel:[0,1]` with the default op_sel_hi (both results read the HIGH dword of a register
-    pair) gave run-to-run different low results on MI355X when the pair came straight from an LDS load (found in
-    the up=2 epilogue's noise add and removed there).  No kernel of the library may contain that operand form."""
+    pair) was the one instruction whose removal ended run-to-run differences of the up=2 epilogue on MI355X (its noise
+    add; a stand-alone loop of the instruction does not reproduce it, so this is a tripwire, not a diagnosis).  No kernel of the library may contain that operand form."""
     dis = build.disassembly()
     assert dis.count("v_mfma_") > 100                             # (it is the real disassembly)
     bad = [ln.strip() for ln in dis.splitlines() if re.search(r"v_pk_(add|mul|fma)_f32 .*op_sel:\[0,1\](?! op_sel_hi)", ln)]
