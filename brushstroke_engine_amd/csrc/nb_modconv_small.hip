@@ -56,7 +56,11 @@ __device__ __forceinline__ float nb_sm_epilogue(float v, float bias, float alpha
     return v;
 }
 
-__global__ __launch_bounds__(256, 2) void modconv3x3_up1_small_h3_kernel(const SmallParams p) {
+// OCC = workgroups per CU the register budget is sized for: 2 (256 VGPRs: 20 of them spill, but two workgroups share a CU
+// when a launch has more than one round of them) or 1 (no spills: 1-2 us less per launch when every CU gets at most one
+// workgroup anyway -- batch 1 and the <= 8x8 layers of a batch)
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void modconv3x3_up1_small_h3_kernel(const SmallParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 4 * NB_SM_NHP * 16];     // [wave][plane][slot] (26 KB: fits next to a large-tile workgroup)
     __shared__ float s_sty[2 * NB_SM_MAX_CIN];
     __shared__ float s_epi[96];
@@ -257,7 +261,8 @@ static int nb_small_h3_impl(const float* x, int c1, const float* x2, int c2, con
     p.slices = (c_out + 31) / 32;
     NB_REQUIRE(p.spt <= 2 && p.spt * (p.rows + 2) * (p.cols + 2) <= NB_SM_NHP, "modconv3x3_small_h3: unsupported image size %dx%d", h, w);
     dim3 grid(p.tiles_x * tiles_y * p.slices, (n + p.spt - 1) / p.spt, up * up);
-    hipLaunchKernelGGL(modconv3x3_up1_small_h3_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if ((long)grid.x * grid.y * grid.z <= 256) hipLaunchKernelGGL(modconv3x3_up1_small_h3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(modconv3x3_up1_small_h3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_small_h3");
     return NB_OK;
 }
