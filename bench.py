@@ -152,6 +152,9 @@ def main():
                     help="default: the library default (networks.DEFAULT_CONV_MODE = f8); f8: split-f16 MFMA with the two correction products on block-scaled fp8 MFMAs (pixels within "
                          "1e-4 of fp32; budget 1e-3); h3: all three products in f16 (5e-6); f32: all layers on the fp32 MFMA kernels")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket the dominant kernel's launches with HIP events in every K-th timed step (an event pair costs ~10 us "
+                         "of stream time, which a single chain of launches cannot hide)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -311,9 +314,11 @@ def main():
         torch.cuda.synchronize()
         return pool
     G.synthesis.event_pool = make_pool()
-    G.synthesis.layer_events, G.synthesis.event_filter = [], dom_layers
+    G.synthesis.layer_events = []
+    none_ = frozenset()
     t_reh = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
+        G.synthesis.event_filter = dom_layers if i_ % args.event_every == 0 else none_
         step()
     finish_gathers()
     torch.cuda.synchronize()
@@ -322,9 +327,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    G.synthesis.layer_events, G.synthesis.event_filter = [], dom_layers
+    G.synthesis.layer_events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
+        G.synthesis.event_filter = dom_layers if i_ % args.event_every == 0 else none_
         step()
     finish_gathers()
     torch.cuda.synchronize()
@@ -366,7 +372,8 @@ def main():
         timed.setdefault(name, []).append(e0.elapsed_time(e1))
     # a layer is launched once per sub-batch (the generator runs the batch as `sub` sub-batches on separate streams):
     # every launch is bracketed on its own stream and carries batch/sub patches
-    sub = max(1, round(len(next(iter(timed.values()))) / args.steps))
+    sampled_steps = len(range(0, args.steps, args.event_every))
+    sub = max(1, round(len(next(iter(timed.values()))) / sampled_steps))
     dom_ms = sum(float(np.mean(ts)) for ts in timed.values())            # mean launch duration, summed over the kernel's layers
     dom_fl = sum(layer_flops(specs[name], B / sub) for name in timed)
     dom_launches = len(timed)
@@ -421,6 +428,8 @@ def main():
                          "achieved": round(traffic / (dom_ms / dom_launches * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(traffic / (dom_ms / dom_launches * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)} if traffic else None),
                 "launch_ms": round(dom_ms / dom_launches, 4), "launches_per_step": dom_launches * sub,
+                "sampling": f"HIP events around the kernel's launches in every {args.event_every}-th of the {args.steps} timed steps "
+                            f"({sampled_steps} steps sampled)",
                 "patches_per_launch": B // sub,
                 "concurrency": (f"{sub} sub-batches in flight on {sub} HIP streams: launch durations are measured while "
                                 f"the other stream's kernels share the chip") if sub > 1 else "single stream",
