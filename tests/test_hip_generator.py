@@ -316,3 +316,28 @@ def test_baseline_batch32_r256_golden(dev, mode):
     # the same batch through the fused compositing entry the benchmark times
     u8, rgba, dbg2 = G.render_triad(z=z, geom_feature=geom, positions=pos, want_f32=True)
     assert torch.equal(dbg2["uvs"], dbg["uvs"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_two_sub_batch_chains_equal_one_chain(dev, mode):
+    """Batches >= sub_stream_min_batch (64 at R=256) run as two sub-batches on two HIP streams (Generator._forward_split).
+    Forced here at batch 32: run-to-run identical, and equal to the single chain within the mode's distance from fp32 (a
+    sub-batch of 16 may pick other tile shapes than the batch of 32)."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic
+    cfg = cfgmod.style1_config(256)
+    G, _ = build(cfg, 0, dev, mode)
+    n = 32
+    z = D(synthetic.batch_z(cfg, n, 3), dev)
+    geom = [D(x, dev) for x in synthetic.geom_features(cfg, n, seed=2)]
+    pos = D(synthetic.positions(cfg, n, seed=2), dev)
+    assert G.sub_stream_min_batch == 64
+    one = G(z, None, geom, positions=pos, noise_mode="const")
+    G.sub_stream_min_batch = 16
+    try:
+        two_a = G(z, None, geom, positions=pos, noise_mode="const")
+        two_b = G(z, None, geom, positions=pos, noise_mode="const")
+    finally:
+        G.sub_stream_min_batch = None
+    assert G.sub_stream_min_batch == 64
+    assert torch.equal(two_a, two_b)
+    assert err(two_a, one) <= {"h3": 2e-5, "f8": 3e-4}[mode]

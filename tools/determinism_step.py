@@ -8,6 +8,7 @@ dev = torch.device("cuda:0")
 cfg = cfgmod.style1_config(256)
 for mode in os.environ.get("NB_MODES", "f8 h3").split():
     G = Generator(cfg, wmod.random_state_dict(cfg, 2), conv_mode=mode).to(dev)
+    G.sub_stream_min_batch = 16                     # two sub-batch chains also at batch 32 (the default starts them at 64)
     if os.environ.get("NB_SUB"):
         G.sub_streams = int(os.environ["NB_SUB"])
     B = 32
