@@ -1234,13 +1234,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         }
         __builtin_amdgcn_sched_barrier(0);
         // chunk c+1 must have landed; with 3 stages the DMA of chunk c+2 may stay in flight
-        unsigned long long tw0 = 0;
-        if (p.tstamps) tw0 = __builtin_amdgcn_s_memtime();
+        // (no timestamp reads in here: the branches around them split the loop body into several basic blocks, and the
+        //  compiler then sinks 8 of a chunk's 10 fp8 instructions past the wait and the barrier below)
         if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXPW + NWPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.tstamps) { const unsigned long long tw1 = __builtin_amdgcn_s_memtime(); t_dma += tw1 - tw0; tw0 = tw1; }
         __builtin_amdgcn_s_barrier();
-        if (p.tstamps) t_bar += __builtin_amdgcn_s_memtime() - tw0;
     }
     if (p.tstamps && tid == 0) {
         unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;

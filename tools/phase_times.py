@@ -87,7 +87,11 @@ def run(kind, n, ci, co, res):
     if True:
         raw = ts.cpu().numpy()[: t.shape[0]]
         dma, bar, loop = raw[:, 6].astype(np.float64), (raw[:, 7] & 0xffffffff).astype(np.float64), (raw[:, 7] >> 32).astype(np.float64)
-        print(f"    wave 0 inside the k-loop (shader cycles): total {loop.mean():.0f}, parked on vmcnt {dma.mean():.0f} "
+        if dma.mean() == 0 and bar.mean() == 0:
+            # (the up=2 kernel carries no in-loop stamps: their branches made the compiler sink matrix instructions past the barrier)
+            print(f"    wave 0 inside the k-loop (shader cycles): total {loop.mean():.0f}; s_memtime ticks per us {loop.mean() / d[:, 1].mean():.0f}")
+        else:
+          print(f"    wave 0 inside the k-loop (shader cycles): total {loop.mean():.0f}, parked on vmcnt {dma.mean():.0f} "
               f"({dma.mean() / loop.mean() * 100:.1f}%), parked on the barrier {bar.mean():.0f} ({bar.mean() / loop.mean() * 100:.1f}%); "
               f"s_memtime ticks per us {loop.mean() / d[:, 1].mean():.0f}")
     if kind == "up2":
