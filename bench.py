@@ -15,10 +15,14 @@ positions, style1 checkpoint shapes at R=256, fp32).  Inputs are resident in HBM
 region.  With N > 1 every rank renders its own batch (weak scaling, replicated weights) and the
 uint8 RGBA tiles are gathered to rank 0 over RCCL inside the step, overlapped with the next batch.
 
-Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel,
-algorithmic FLOPs / HIP-event time on the launch stream, against the fp32 matrix peak of
-MI355X_MICROARCH.md) and `cpu_baseline` (the CPU oracle = port of the reference path, timed on this
-box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task brief).  Top level = the PRIMARY arithmetic mode (the library
+default, `f8`): `value`, `ms_per_step`, `roofline` (dominant kernel: algorithmic FLOPs / HIP-event time on the launch
+stream, against the dense MFMA peak of the type that kernel MULTIPLIES in -- MI355X_MICROARCH.md), `dtype` (what
+multiplies; never "f32" for a split mode).  At N=1 the same process then measures the other two modes the same way
+(own Generator, same W warm-up + K timed steps) and reports all three under `modes` = {"f8": .., "h3": .., "f32": ..},
+each with value / ms_per_step / roofline / live parity against the fp32 CPU oracle; `value_fp32_parity` = the `h3`
+number (SURVEY 8d's "fp32 parity mode": products to ~2^-22).  `cpu_baseline` = the CPU oracle (port of the reference
+path) timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
 
@@ -57,7 +61,7 @@ def kernel_label(spec):
     return f"modconv3x3_up{spec.up}[{spec.in_channels}->{spec.out_channels}@{spec.block_res}]"
 
 
-def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16, G=None, dev=None):
+def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16, gens=None, dev=None):
     """The CPU oracle (oracle/neube_oracle.py, a port of the reference path onto plain torch CPU ops, fused
     modulated conv = the reference's eval-mode fp32 default) timed on this box's host cores.  Bounded
     sample: `n_sample` patches per pass, repeated until ~seconds_budget of CPU time is spent.  16 threads:
@@ -96,18 +100,20 @@ def cpu_baseline(cfg, sd, seconds_budget=12.0, n_sample=8, threads=16, G=None, d
            "sample": f"{reps} passes of batch {n_sample} at {cfg.img_resolution}x{cfg.img_resolution} "
                      f"(oracle = torch-CPU port of the reference generator + compositing, fp32, {el:.1f} s, "
                      f"{torch.get_num_threads()} of {avail} host CPUs)"}
-    if G is not None:
-        # the oracle as the checker: the same sample through the benchmarked HIP generator (same conv mode), compared
-        # with the oracle's fp32 result at the full 256x256 size
+    # the oracle as the checker: the same sample through every benchmarked HIP generator (one per arithmetic mode), compared
+    # with the oracle's fp32 result at the full 256x256 size
+    to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    out["parity_by_mode"] = {}
+    for mode, G in (gens or {}).items():
         u8, rgba, dbg = G.render_triad(z=torch.from_numpy(z).to(dev), geom_feature=[torch.from_numpy(g).to(dev) for g in geom],
                                        positions=torch.from_numpy(pos).to(dev), render_mode="clear", want_f32=True)
         torch.cuda.synchronize()
-        to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
-        out["parity"] = {"max_abs_rgba_vs_oracle": float(np.abs(to_np(rgba) - to_np(last["rgba"])).max()),
-                         "max_abs_uvs_vs_oracle": float(np.abs(to_np(dbg["uvs"]) - to_np(last["uvs"])).max()),
-                         "max_u8_diff": int(np.abs(to_np(u8).astype(np.int32) - to_np(u8_ref).transpose(0, 2, 3, 1).astype(np.int32)).max()),
-                         "tolerance": 1e-3, "patches": n_sample,
-                         "what": "HIP generator (the benchmarked conv mode) vs the fp32 CPU oracle on the cpu_baseline sample"}
+        out["parity_by_mode"][mode] = {
+            "max_abs_rgba_vs_oracle": float(np.abs(to_np(rgba) - to_np(last["rgba"])).max()),
+            "max_abs_uvs_vs_oracle": float(np.abs(to_np(dbg["uvs"]) - to_np(last["uvs"])).max()),
+            "max_u8_diff": int(np.abs(to_np(u8).astype(np.int32) - to_np(u8_ref).transpose(0, 2, 3, 1).astype(np.int32)).max()),
+            "tolerance": 1e-3, "patches": n_sample,
+            "what": f"HIP generator in mode {mode} vs the fp32 CPU oracle on the cpu_baseline sample"}
     return out
 
 
@@ -139,99 +145,69 @@ def latency_batch1(G, cfg, dev, geom, pos, iters=300):
             "what": "batch=1 256x256 patch, hipGraph replay of the whole generator step (mapping ... fused ToRGB) + stream sync"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--res", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 hipGraph latency leg")
-    ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f32"],
-                    help="default: the library default (networks.DEFAULT_CONV_MODE = f8); f8: split-f16 MFMA with the two correction products on block-scaled fp8 MFMAs (pixels within "
-                         "1e-4 of fp32; budget 1e-3); h3: all three products in f16 (5e-6); f32: all layers on the fp32 MFMA kernels")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
-    ap.add_argument("--event-every", type=int, default=4,
-                    help="bracket the dominant kernel's launches with HIP events in every K-th timed step (an event pair costs ~10 us "
-                         "of stream time, which a single chain of launches cannot hide)")
-    args = ap.parse_args()
+MODE_DTYPE = {
+    # what MULTIPLIES in the conv layers of each arithmetic mode (accumulation is fp32 in all three); never a precision claim
+    "f32": "f32 x f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), fp32 accumulate: exact fp32 products",
+    "h3": "f16 x f16 MFMA, three per fp32 product on hi/lo-split operands (xh*wh + xl*wh + xh*wl), fp32 accumulate: ~2^-22 "
+          "relative per product, ~5e-6 from an all-fp32 evaluation on pixels",
+    "f8": "f16 hi x f16 hi MFMA + 2 block-scaled fp8 (e4m3) correction products per fp32 product, fp32 accumulate: ~2^-15 relative "
+          "per product, ~1e-4 from an all-fp32 evaluation on pixels (north_star budget 1e-3)",
+}
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # self-launch: N ranks as a child torchrun.  Nothing in this process has touched the GPU (importing torch does
-        # not), and it only waits for the child -- no exec of a GPU-initialised process.
-        import socket
-        import subprocess
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", "8")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd, env=env))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
-    # test hooks for a 1-GPU box: NB_BENCH_SHARE_GPU=1 puts every rank on device 0, NB_BENCH_BACKEND=gloo swaps RCCL out
-    # (exercises the N>1 control flow; numbers from such a run mean nothing)
-    if os.environ.get("NB_BENCH_SHARE_GPU") == "1":
-        local_rank = 0
-    backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
-    if os.environ.get("NB_BENCH_FAIL_RANK") == str(rank) and world > 1:        # test hook: a rank that dies at start-up
-        raise SystemExit(7)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import datetime
-        tmo = datetime.timedelta(seconds=300)            # a wedged collective should fail the run, not hang it
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
-        else:
-            dist.init_process_group(backend, timeout=tmo)
 
-    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
-    from brushstroke_engine_amd.networks import Generator, DEFAULT_CONV_MODE
+def scheme_ceiling(mode):
+    """Matrix work a mode executes per algorithmic FLOP, at the nominal dense peaks."""
+    return {"f32": PEAK_F32_MATRIX_TFLOPS, "h3": PEAK_F16_MATRIX_TFLOPS / 3,
+            "f8": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS)}[mode]
+
+
+def load_traffic(mode, res, batch):
+    """HBM bytes per launch by kernel: PMC counters cannot be read inside this process, so the figures come from
+    profiles/hbm_traffic.json (tools/collect_profiles.sh: separate rocprofv3 --pmc passes of this very command per mode), and
+    only if that file was measured on the kernel sources that are running now (content digest) -- otherwise null."""
+    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tpath):
+        return {}, "profiles/hbm_traffic.json missing"
+    try:
+        from brushstroke_engine_amd import build as _b
+        tj = json.load(open(tpath))
+        stamp = tj.get("_stamp", {})
+        if not (res == 256 and batch == 32):
+            return {}, "profiles/hbm_traffic.json holds the default workload (R=256, batch 32): not used for this one"
+        if stamp.get("source_digest") != _b.source_digest():
+            return {}, "profiles/hbm_traffic.json was measured on other kernel sources (stale): not used"
+        table = tj.get("modes", {}).get(mode)
+        if table is None and mode == "f8" and "modes" not in tj:
+            table = {k: v for k, v in tj.items() if not k.startswith("_")}
+        if table is None:
+            return {}, f"profiles/hbm_traffic.json has no PMC pass for mode {mode}"
+        return table, f"rocprofv3 PMC passes at commit {stamp.get('git_head') or '(unrecorded)'}, same kernel sources"
+    except Exception as e:                                  # noqa: BLE001
+        return {}, f"profiles/hbm_traffic.json unreadable: {e}"
+
+
+def traffic_lookup(table, kname):
+    """Bytes per launch of kernel `kname`; the fp32 kernels are named by their leading template parameters only
+    (nb_modconv3x3_variant), the profiler prints all of them."""
+    if kname in table:
+        return table[kname]
+    if kname.endswith(">"):
+        hits = [v for k, v in table.items() if k.startswith(kname[:-1] + ",") or k.startswith(kname[:-1] + ">")]
+        if len(hits) == 1:
+            return hits[0]
+    return None
+
+
+def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
+    """W warm-up steps, then exactly K timed steps of the hot path in one arithmetic mode, bracketed by barrier +
+    synchronize; returns this mode's figures (value, ms_per_step, roofline of its dominant kernel)."""
     from brushstroke_engine_amd.sharding import TileGatherer
-    if args.conv_mode is None:
-        args.conv_mode = DEFAULT_CONV_MODE
-
-    cfg = cfgmod.style1_config(args.res)
-    sd = wmod.random_state_dict(cfg, seed=0)
-    G = Generator(cfg, sd, conv_mode=args.conv_mode).to(dev)
+    z, geom, pos = inputs
     B = args.batch
-    # synthetic inputs, resident in HBM before anything is timed (different per rank)
-    z = torch.from_numpy(synthetic.batch_z(cfg, B, first_seed=rank * B)).to(dev)
-    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, seed=rank)]
-    pos = torch.from_numpy(synthetic.positions(cfg, B, seed=rank)).to(dev)
     # the generator runs a batch as `sub` sub-batches on separate HIP streams; with N>1 each part's RGBA tiles are
     # gathered from the part's own stream, so steps keep overlapping across the streams at any N
     sub = G.sub_streams if B >= G.sub_stream_min_batch else 1
-    gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if (world > 1 and not args.no_gather) else None
-    if gatherer is not None:
-        # pre-flight: one small RCCL gather, checked on rank 0.  The gather IS part of the measured job (north_star: "RCCL
-        # gather over xGMI to assemble the stylized canvas"): if the fabric refuses it the run fails, non-zero.
-        try:
-            probe = TileGatherer([4, 8, 8, 4], torch.uint8, dev)
-            probe.start(torch.full([4, 8, 8, 4], rank, dtype=torch.uint8, device=dev))
-            got = probe.finish()
-            torch.cuda.synchronize()
-            ok = torch.tensor([1.0 if (rank != 0 or all(int(g.flatten()[0]) == r for r, g in enumerate(got))) else 0.0], device=dev)
-        except Exception as e:                                     # noqa: BLE001
-            print(f"[bench] rank {rank}: RCCL gather pre-flight failed: {e}", file=sys.stderr, flush=True)
-            ok = torch.tensor([0.0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() < 1:
-            if rank == 0:
-                print("[bench] FAILED: the RCCL gather of RGBA tiles did not pass its pre-flight; no number is reported "
-                      "(--no-gather measures the sharded compute alone, and says so in config.parallelism)", file=sys.stderr, flush=True)
-            dist.destroy_process_group()
-            raise SystemExit(3)
+    gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if gather else None
     part_gatherers = []
     if gatherer is not None and sub > 1:
         bounds = [(i * B // sub, (i + 1) * B // sub) for i in range(sub)]
@@ -244,7 +220,7 @@ def main():
                 g_.finish()
 
     def step():
-        # without a gather the step is enqueued without joining the generator's two sub-batch streams, so consecutive
+        # without a gather the step is enqueued without joining the generator's sub-batch streams, so consecutive
         # steps overlap across them (the timed region ends with a device-wide synchronize)
         res = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False)
         if gatherer is not None:
@@ -259,7 +235,7 @@ def main():
 
     # Burn-in (untimed, before the W warmup steps): a fresh process on a fresh box runs its first steps well below
     # steady state (host-side first-touch costs: lazily loaded code objects, allocator growth, cold Python paths, clock
-    # ramp), and one step is only ~4 ms.  Run chunks of 5 steps until two consecutive chunks agree within 3 %
+    # ramp), and one step is only ~2 ms.  Run chunks of 5 steps until two consecutive chunks agree within 3 %
     # (at least 0.5 s, at most 8 s); the chunk times are reported as "burn_in_ms_per_step".
     burn_in = []
     t_burn = time.perf_counter()
@@ -377,7 +353,8 @@ def main():
     dom_ms = sum(float(np.mean(ts)) for ts in timed.values())            # mean launch duration, summed over the kernel's layers
     dom_fl = sum(layer_flops(specs[name], B / sub) for name in timed)
     dom_launches = len(timed)
-    dom_peak = PEAK_F16_MATRIX_TFLOPS if "_h3_" in dom_name else PEAK_F32_MATRIX_TFLOPS
+    peak_of = lambda kname: PEAK_F16_MATRIX_TFLOPS if "_h3_" in kname else PEAK_F32_MATRIX_TFLOPS
+    dom_peak = peak_of(dom_name)
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12
     # calibration table (all launches bracketed, untimed pass)
     rows, kernels = [], {}
@@ -388,41 +365,28 @@ def main():
         fl = layer_flops(specs[name], B / max(1, round(len(ts) / 3)))
         kname = layer_kernels[name]
         rows.append((ms, kernel_label(specs[name]), fl, kname))
-        k = kernels.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0,
-                                       "peak": PEAK_F16_MATRIX_TFLOPS if "_h3_" in kname else PEAK_F32_MATRIX_TFLOPS})
+        k = kernels.setdefault(kname, {"ms": 0.0, "flops": 0.0, "launches": 0, "peak": peak_of(kname)})
         k["ms"] += ms; k["flops"] += fl; k["launches"] += 1
     rows.sort(reverse=True)
     conv_ms = sum(r[0] for r in rows)
     conv_fl = sum(r[2] for r in rows)
-    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read inside this process, so the figure comes from
-    # profiles/hbm_traffic.json (tools/collect_profiles.sh: separate rocprofv3 --pmc passes of this very command), and only
-    # if that file was measured on the kernel sources that are running now (content digest) -- otherwise null
-    traffic, traffic_note = None, "profiles/hbm_traffic.json missing"
-    tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            from brushstroke_engine_amd import build as _b
-            tj = json.load(open(tpath))
-            if not (args.res == 256 and B == 32 and args.conv_mode == "f8"):
-                traffic_note = "profiles/hbm_traffic.json holds the default workload (R=256, batch 32, f8): not used for this one"
-            elif tj.get("_stamp", {}).get("source_digest") == _b.source_digest():
-                traffic, traffic_note = tj.get(dom_name), f"rocprofv3 PMC passes at {tj['_stamp'].get('git_head')}, same kernel sources"
-            else:
-                traffic_note = "profiles/hbm_traffic.json was measured on other kernel sources (stale): not used"
-        except Exception as e:                                  # noqa: BLE001
-            traffic_note = f"profiles/hbm_traffic.json unreadable: {e}"
+    ttable, traffic_note = load_traffic(mode, args.res, B)
+    traffic = traffic_lookup(ttable, dom_name)
+    split = "_h3_" in dom_name
     roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": dom_peak,
                 "unit": "TFLOP/s", "frac": round(achieved / dom_peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+                "peak_what": ("dense f16 MFMA (MI355X_MICROARCH.md ~2.5 PFLOP/s): the type this kernel multiplies in" if split else
+                              "fp32 MFMA (MI355X_MICROARCH.md 157.3 TFLOP/s): the type this kernel multiplies in"),
                 "executed_mfma": (({"tflops": round(3 * achieved, 1), "frac": round(3 * achieved / dom_peak, 4),
                                     "what": "f16 MFMA FLOPs actually executed for the algorithmic ones (3 products per fp32 "
                                             "product; halo / block-rounding overhead of the up=2 kernel not included)"}
-                                   if args.conv_mode == "h3" else
+                                   if mode == "h3" else
                                    {"f16_tflops": round(achieved, 1), "fp8_tflops": round(2 * achieved, 1),
                                     "frac": round(achieved / PEAK_F16_MATRIX_TFLOPS + 2 * achieved / PEAK_FP8_MATRIX_TFLOPS, 4),
                                     "what": "matrix work actually executed per algorithmic FLOP: 1 f16 MFMA FLOP (main product) + "
                                             "2 fp8 MFMA FLOPs (both correction products in one K=64 block-scaled instruction per "
                                             "tap pair); frac = share of the matrix pipes' time (f16 peak 2500, fp8 peak 5000 TFLOP/s)"})
-                                  if "_h3_" in dom_name else None),
+                                  if split else None),
                 "hbm": ({"what": "the same launches against the HBM roofline (MI355X_MICROARCH.md: ~8 TB/s): measured HBM bytes per "
                                  "launch (traffic) / launch duration; the path is matrix-pipe bound, not HBM bound",
                          "achieved": round(traffic / (dom_ms / dom_launches * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -441,58 +405,191 @@ def main():
                                             / (sum(float(np.mean(t)) for t in iso.values()) * 1e-3) / 1e12 / dom_peak, 4)}
                              if iso else None),
                 "flops_per_launch": dom_fl / dom_launches,
-                "note": ("fp32 MFMA" if "_h3_" not in dom_name else
+                "note": ("fp32 MFMA" if not split else
                          "split-f16 kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
-                         if args.conv_mode == "h3" else
+                         if mode == "h3" else
                          "split-f16 + fp8-correction kernels spend 2 f16-MFMA-equivalents of matrix time per algorithmic fp32 FLOP: "
                          "frac (against the f16 peak) <= 1/2 by construction"),
                 "calibration": {"what": "untimed pass with every launch bracketed by HIP events",
                                 "all_conv_launches": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4)},
                                 "kernels": {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
-                                                "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "peak": v["peak"]}
+                                                "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "peak": v["peak"],
+                                                "traffic": traffic_lookup(ttable, k)}
                                             for k, v in kernels.items()},
                                 "layers_ms": {r[1]: round(r[0], 4) for r in rows},
                                 "other_ms": {k: round(float(np.sum(v)) / 3, 4) for k, v in cal.items() if k not in specs}}}
+    ms_per_step = elapsed / args.steps * 1e3
+    whole = B * 2 * cfg.macs_per_patch() / (ms_per_step * 1e-3) / 1e12
+    return {
+        "value": round(world * B * args.steps / elapsed, 2), "unit": "patches/s", "ms_per_step": round(ms_per_step, 4),
+        "steps": args.steps, "warmup": args.warmup, "dtype": MODE_DTYPE[mode],
+        "roofline": roofline,
+        "roofline_whole_step": {
+            "what": "the whole step (all launches of one GPU) against the ceilings of SURVEY 8d: algorithmic FLOPs of the batch / ms_per_step",
+            "achieved": round(whole, 1), "unit": "TFLOP/s", "fp32_matrix_peak": PEAK_F32_MATRIX_TFLOPS,
+            "scheme_ceiling": round(scheme_ceiling(mode), 1), "frac_of_scheme_ceiling": round(whole / scheme_ceiling(mode), 4),
+            "note": "scheme ceiling = the matrix work the arithmetic mode executes per algorithmic FLOP at nominal dense peaks (f8: one f16 "
+                    "+ two fp8 MFMA FLOPs; h3: three f16); the K loops run at ~1.6-1.8 GHz under load (in-kernel s_memtime clock), not 2.4"},
+        "rehearsal_ms_per_step": round(rehearsal_ms, 4),
+        "burn_in_ms_per_step": [round(b, 3) for b in burn_in[:6]] + (["..."] if len(burn_in) > 7 else []) + [round(b, 3) for b in burn_in[6:][-1:]],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and with it the live parity of every mode)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 hipGraph latency leg")
+    ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f32"],
+                    help="the PRIMARY arithmetic mode = top-level value; default: the library default (networks.DEFAULT_CONV_MODE = f8). "
+                         "f8: f16 main product + two block-scaled fp8 correction products (pixels within 1e-4 of fp32; budget 1e-3); "
+                         "h3: three f16 products on hi/lo-split operands (5e-6); f32: all layers on the fp32 MFMA kernels")
+    ap.add_argument("--modes", default=None,
+                    help="comma list of arithmetic modes measured one after the other in this process (each its own Generator, W warm-up + K "
+                         "timed steps) and reported under `modes`; default: all three at N=1, the primary one only at N>1; 'primary' = only it")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline leg")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket the dominant kernel's launches with HIP events in every K-th timed step (an event pair costs ~10 us "
+                         "of stream time, which a single chain of launches cannot hide)")
+    args = ap.parse_args()
+    if args.event_every < 1:
+        ap.error("--event-every must be >= 1")
+    if args.steps < 1 or args.warmup < 0:
+        ap.error("--steps must be >= 1 and --warmup >= 0")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # self-launch: N ranks as a child torchrun.  Nothing in this process has touched the GPU (importing torch does
+        # not), and it only waits for the child -- no exec of a GPU-initialised process.  The kernel library is built
+        # here, once, so that no rank compiles while the others wait in a collective.  --standalone lets torchrun's own
+        # rendezvous pick the port (no bind-and-close race with other jobs on the node).
+        import subprocess
+        from brushstroke_engine_amd import build as _build
+        _build.build(verbose=False)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+    # test hooks for a 1-GPU box: NB_BENCH_SHARE_GPU=1 puts every rank on device 0, NB_BENCH_BACKEND=gloo swaps RCCL out
+    # (exercises the N>1 control flow; numbers from such a run mean nothing)
+    if os.environ.get("NB_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
+    if os.environ.get("NB_BENCH_FAIL_RANK") == str(rank) and world > 1:        # test hook: a rank that dies at start-up
+        raise SystemExit(7)
+    # the kernel library exists (and is current) BEFORE the process group does: a rank that compiles for minutes while
+    # the others sit in init / a collective would run into their timeouts (build() is a no-op when up to date and
+    # serialises concurrent callers on a file lock)
+    from brushstroke_engine_amd import build as _build, _lib as _nblib
+    _build.build(verbose=False)
+    _nblib.lib()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)            # a wedged collective should fail the run, not hang it
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+        else:
+            dist.init_process_group(backend, timeout=tmo)
+
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator, DEFAULT_CONV_MODE
+    from brushstroke_engine_amd.sharding import TileGatherer
+    if args.conv_mode is None:
+        args.conv_mode = DEFAULT_CONV_MODE
+    if args.modes in (None, "all"):
+        modes = ["f8", "h3", "f32"] if (world == 1 or args.modes == "all") else [args.conv_mode]
+    elif args.modes == "primary":
+        modes = [args.conv_mode]
+    else:
+        modes = [m.strip() for m in args.modes.split(",") if m.strip()]
+        if any(m not in MODE_DTYPE for m in modes):
+            raise SystemExit(f"--modes: unknown mode in {modes}")
+    modes = [args.conv_mode] + [m for m in modes if m != args.conv_mode]        # the primary mode is measured first
+
+    cfg = cfgmod.style1_config(args.res)
+    sd = wmod.random_state_dict(cfg, seed=0)
+    B = args.batch
+    # synthetic inputs, resident in HBM before anything is timed (different per rank)
+    z = torch.from_numpy(synthetic.batch_z(cfg, B, first_seed=rank * B)).to(dev)
+    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, seed=rank)]
+    pos = torch.from_numpy(synthetic.positions(cfg, B, seed=rank)).to(dev)
+    gather = world > 1 and not args.no_gather
+    if gather:
+        # pre-flight: one small RCCL gather, checked on rank 0.  The gather IS part of the measured job (north_star: "RCCL
+        # gather over xGMI to assemble the stylized canvas"): if the fabric refuses it the run fails, non-zero.
+        try:
+            probe = TileGatherer([4, 8, 8, 4], torch.uint8, dev)
+            probe.start(torch.full([4, 8, 8, 4], rank, dtype=torch.uint8, device=dev))
+            got = probe.finish()
+            torch.cuda.synchronize()
+            ok = torch.tensor([1.0 if (rank != 0 or all(int(g.flatten()[0]) == r for r, g in enumerate(got))) else 0.0], device=dev)
+        except Exception as e:                                     # noqa: BLE001
+            print(f"[bench] rank {rank}: RCCL gather pre-flight failed: {e}", file=sys.stderr, flush=True)
+            ok = torch.tensor([0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1:
+            if rank == 0:
+                print("[bench] FAILED: the RCCL gather of RGBA tiles did not pass its pre-flight; no number is reported "
+                      "(--no-gather measures the sharded compute alone, and says so in config.parallelism)", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            raise SystemExit(3)
+
+    gens, results = {}, {}
+    for m in modes:
+        gens[m] = Generator(cfg, sd, conv_mode=m).to(dev)
+        results[m] = measure_mode(gens[m], m, args, cfg, (z, geom, pos), world, rank, dev, backend, gather)
+    G = gens[args.conv_mode]
+    prim = results[args.conv_mode]
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
         out = {
             "metric": "stylized 256x256 stroke patches/sec at batch=32" if args.res == 256 and B == 32
                       else f"stylized {args.res}x{args.res} stroke patches/sec at batch={B}",
-            "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32",
-                      "h3": "f32 (layers >= 32x32: 3-pass split-f16 MFMA, within 5e-6 of fp32 on pixels)",
-                      "f8": "f32 (layers >= 32x32: split-f16 MFMA, correction products on block-scaled fp8 MFMA; within 1e-4 of "
-                            "fp32 on pixels, north_star budget 1e-3)"}[args.conv_mode],
+            "value": prim["value"], "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": MODE_DTYPE[args.conv_mode],
+            "conv_mode": args.conv_mode,
             "data": "synthetic",
             "config": {"workload": f"batch={B} random-z {args.res}x{args.res} patches through the HIP SynthesisNetwork, "
                                    f"style1 checkpoint shapes (BASELINE.json configs[1]); generator + triad compositing "
                                    f"to uint8 RGBA; geometry features precomputed",
                        "batch_per_gpu": B, "resolution": args.res, "gflop_per_patch": round(2 * cfg.macs_per_patch() / 1e9, 3),
                        "parallelism": f"patch-parallel x{world}" + ("" if world == 1 else
-                                                                   f" + {'RCCL' if backend == 'nccl' else backend} gather of RGBA tiles to rank 0 "
-                                                                   f"inside every step" if gatherer else " (NO gather: --no-gather)")},
-            "roofline": roofline,
-            "roofline_whole_step": {
-                "what": "the whole step (all launches of one GPU) against the ceilings of SURVEY 8d: algorithmic FLOPs of the batch / ms_per_step",
-                "achieved": round(B * 2 * cfg.macs_per_patch() / (ms_per_step * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
-                "fp32_matrix_peak": PEAK_F32_MATRIX_TFLOPS,
-                "scheme_ceiling": {"f32": PEAK_F32_MATRIX_TFLOPS, "h3": round(PEAK_F16_MATRIX_TFLOPS / 3, 1),
-                                   "f8": round(1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS), 1)}[args.conv_mode],
-                "frac_of_scheme_ceiling": round(B * 2 * cfg.macs_per_patch() / (ms_per_step * 1e-3) / 1e12 /
-                                                {"f32": PEAK_F32_MATRIX_TFLOPS, "h3": PEAK_F16_MATRIX_TFLOPS / 3,
-                                                 "f8": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS)}[args.conv_mode], 4),
-                "note": "scheme ceiling = the matrix work the arithmetic mode executes per algorithmic FLOP at nominal dense peaks (f8: one f16 "
-                        "+ two fp8 MFMA FLOPs; h3: three f16); the K loops run at ~1.6-1.8 GHz under load (in-kernel s_memtime clock), not 2.4"},
-            "rehearsal_ms_per_step": round(rehearsal_ms, 4),
-            "burn_in_ms_per_step": [round(b, 3) for b in burn_in[:6]] + (["..."] if len(burn_in) > 7 else []) + [round(b, 3) for b in burn_in[6:][-1:]],
+                                                                   (f" + {'RCCL' if backend == 'nccl' else backend} gather of RGBA tiles to rank 0 "
+                                                                    f"inside every step (rank 0 receives {world - 1} x {B * args.res * args.res * 4 / 1e6:.1f} MB "
+                                                                    f"per step; no overlap evidence for N > 1 exists yet)") if gather else " (NO gather: --no-gather)")},
+            "roofline": prim["roofline"],
+            "roofline_whole_step": prim["roofline_whole_step"],
+            "rehearsal_ms_per_step": prim["rehearsal_ms_per_step"],
+            "burn_in_ms_per_step": prim["burn_in_ms_per_step"],
         }
+        if "h3" in results:
+            # SURVEY 8(d)'s "fp32 parity mode": every fp32 product to ~2^-22 (5e-6 on pixels), the same grade as an fp32 evaluation
+            out["value_fp32_parity"] = results["h3"]["value"]
+            out["value_fp32_parity_what"] = "patches/s of mode h3 (fp32-grade products: 5e-6 from an all-fp32 evaluation); f32 = exact fp32 MFMA"
+        out["modes"] = {m: {k: v for k, v in r.items()} for m, r in results.items()}
         if world == 1 and not args.no_latency:
             out["latency_batch1"] = latency_batch1(G, cfg, dev, geom, pos)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, G=G, dev=dev)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, seconds_budget=args.cpu_seconds, gens=gens, dev=dev)
+            for m, pr in out["cpu_baseline"].pop("parity_by_mode", {}).items():
+                out["modes"][m]["parity"] = pr
+            out["cpu_baseline"]["parity"] = out["modes"][args.conv_mode].get("parity")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

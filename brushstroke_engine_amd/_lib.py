@@ -137,9 +137,18 @@ def lib() -> C.CDLL:
         override = os.environ.get("NEUBE_LIB_PATH")          # developer A/B switch: load this prebuilt library instead
         if override:
             globals()["LIB_PATH"] = override
-        if not override and _build.is_stale():
+        if not override and os.path.exists(LIB_PATH) and not os.path.exists(_build.STAMP):
+            # a prebuilt library without a build stamp (packaged deployment, older checkout, built by hand with other
+            # flags): its sources cannot be compared, so it is loaded as it is -- the export and ABI-version checks below
+            # still apply -- and says so
+            import warnings
+            warnings.warn(f"{LIB_PATH} has no build stamp ({os.path.basename(_build.STAMP)}): loading it without checking that "
+                          f"it was built from the kernel sources in this tree (python -m brushstroke_engine_amd.build rebuilds)")
+        elif not override and _build.is_stale():
             # missing, or built from other sources than the tree holds now (kernel edits without an ABI bump would
-            # otherwise run the old code silently): rebuild if a compiler is here, else fail loudly
+            # otherwise run the old code silently): rebuild if a compiler is here, else fail loudly.  Multi-process
+            # callers build BEFORE init_process_group (bench.py, paint_image_main, tools/bench_*.py call build.build()
+            # first), so that no rank sits in a collective timeout while another compiles.
             if os.path.exists(_build.HIPCC) and os.environ.get("NEUBE_NO_AUTOBUILD") != "1":
                 try:
                     _build.build(verbose=False)

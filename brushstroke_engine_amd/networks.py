@@ -444,6 +444,7 @@ class SynthesisNetwork(torch.nn.Module):
             # stream (they only need the consumer's styles), under the small first layers, instead of between the
             # producer and the consumer.  pre_h2[res] = (consumer input tensor, event).
             pre_h2 = {}
+            pack_waited = False           # has plan.pack_stream been ordered behind this call's styles launch yet?
             if lazy_geom is not None:
                 # geometry not encoded yet: let the encoder write the features that feed an H2 / f8 layer input straight into
                 # that layer's operand tensor (x the consumer's styles, which exist now); the rest comes back as fp32
@@ -499,8 +500,11 @@ class SynthesisNetwork(torch.nn.Module):
                         plan.pack_stream = torch.cuda.Stream(device=device)
                         plan.pack_events = {}
                     dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
-                    if not pre_h2:
-                        plan.pack_stream.wait_stream(cur)                   # the styles are computed
+                    if not pack_waited:
+                        # the styles (and, on the lazy path, the encoder's fp32 features) are enqueued on `cur`; tracked apart
+                        # from pre_h2, which the lazy path may already have filled for another feature
+                        plan.pack_stream.wait_stream(cur)
+                        pack_waited = True
                     part = lib.nb_pack_h2f8_part_f32 if ofmt else lib.nb_pack_h2_part_f32
                     c_prod = sc_.in_channels - gch
                     _lib.check(part(_p(g), gch, plan.styles[ic].data_ptr() + 4 * c_prod, sc_.in_channels, _p(dst),

@@ -104,6 +104,19 @@ def test_stale_library_is_detected(monkeypatch, tmp_path):
         _lib.lib()
 
 
+def test_stampless_prebuilt_library_loads_with_warning(monkeypatch, tmp_path):
+    """A prebuilt library WITHOUT a build stamp (packaged deployment, hand build) is loaded -- with a warning, and still
+    subject to the export / ABI-version checks -- instead of failing on machines without hipcc or rebuilding silently."""
+    from brushstroke_engine_amd import build
+    assert os.path.exists(build.LIB)
+    monkeypatch.setattr(build, "STAMP", str(tmp_path / "absent.stamp"))
+    monkeypatch.setattr(build, "HIPCC", str(tmp_path / "no-hipcc"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.warns(UserWarning, match="no build stamp"):
+        l = _lib.lib()
+    assert l.nb_abi_version() == _lib.ABI_VERSION
+
+
 def test_no_scratch_in_counted_wait_kernels(library):
     """The split-f16 and fp32-MFMA conv kernels keep several LDS-DMA operations in flight and wait on COUNTS
     (``s_waitcnt vmcnt(N)``); register spills or other compiler-made scratch accesses inside them would sit in the same

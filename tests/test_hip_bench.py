@@ -32,6 +32,26 @@ def test_bench_self_spawns_two_ranks():
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
+def test_bench_line_carries_every_arithmetic_mode():
+    """The driver's command (N=1) reports all three arithmetic modes in ONE line: each with its own value, dominant-kernel
+    roofline against the peak of the type it multiplies in, and a live parity figure against the fp32 CPU oracle; the label of
+    a split mode never claims "f32"."""
+    r = _run(["--steps", "2", "--warmup", "1", "--res", "128", "--batch", "8", "--no-latency", "--cpu-seconds", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert set(out["modes"]) == {"f8", "h3", "f32"} and out["conv_mode"] == "f8"
+    assert out["value"] == out["modes"]["f8"]["value"] and out["value_fp32_parity"] == out["modes"]["h3"]["value"]
+    assert not out["dtype"].startswith("f32") and not out["modes"]["h3"]["dtype"].startswith("f32")
+    tol = {"f8": 3e-4, "h3": 2e-5, "f32": 2e-5}
+    for m, rec in out["modes"].items():
+        assert rec["value"] > 0 and rec["roofline"]["frac"] > 0
+        assert rec["roofline"]["peak"] == (157.3 if m == "f32" else 2500.0)
+        assert rec["parity"]["max_abs_rgba_vs_oracle"] <= tol[m], (m, rec["parity"])
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+
+
 def test_bench_fails_nonzero_when_a_rank_dies():
     """A failing child must surface as a non-zero exit code of `python bench.py --gpus N`, with no JSON line."""
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--res", "128", "--batch", "16", "--no-cpu", "--no-latency"],

@@ -155,6 +155,33 @@ def test_lazy_geometry_handoff_equals_fp32_path(mode):
     assert torch.equal(c1["uvs"], c2["uvs"])
 
 
+@pytest.mark.parametrize("mode", ["f8", "h3"])
+def test_lazy_geometry_batch16_side_stream_ordering(mode):
+    """Batch 16 at R=256: b32.conv1 takes the large split-f16 kernel, so BOTH geometry features are handed over in operand
+    format -- feature 1 by the encoder (lazy hand-off) and feature 0 by the early pack on the plan's side stream.  That
+    pack reads the styles and the encoder's fp32 feature, both just enqueued on the caller's stream: the side stream must
+    wait for them although `pre_h2` is already non-empty (a data race of round 2).  A different geometry batch and other
+    latents run first, so stale styles / recycled allocator blocks would show up in the result."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    cfg = cfgmod.style1_config(256)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode=mode).to("cuda")
+    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5))
+    n = 16
+    rs = np.random.RandomState(4)
+    geoms = [torch.from_numpy((rs.rand(n, 1, 256, 256) > thr).astype(np.float32)).cuda() for thr in (0.5, 0.1)]
+    wss = [G.mapping(torch.from_numpy(synthetic.batch_z(cfg, n, sd)).cuda(), None) for sd in (100, 7)]
+    pos = torch.from_numpy(synthetic.positions(cfg, n, seed=1)).cuda()
+    _, want = G.forward_pre_mapped(wss[1], enc.encode(geoms[1]), positions=pos, return_debug_data=True, noise_mode="const")
+    want_uvs = want["uvs"].clone()
+    for _ in range(3):
+        # the other batch first (fills the workspaces with ITS styles, leaves its buffers in the allocator's free lists)
+        G.forward_pre_mapped(wss[0], enc.lazy(geoms[0]), positions=pos, return_debug_data=True, noise_mode="const")
+        lazy = enc.lazy(geoms[1])
+        _, got = G.forward_pre_mapped(wss[1], lazy, positions=pos, return_debug_data=True, noise_mode="const")
+        assert float((got["uvs"] - want_uvs).abs().max()) <= 2e-5
+
+
 def _f8_decode(t, c):
     """f8-format tensor [n, c/8, 2, h, w, 8] -> (hi + xl) as fp32 NCHW, i.e. the activation to ~15 bits"""
     n, c8, _, h, w, _ = t.shape

@@ -1,25 +1,32 @@
 #!/bin/bash
 # Collect the round's judged artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 1800 -- "bash tools/collect_profiles.sh r03 $(git rev-parse --short HEAD)"   (no git on the GPU box)
 # Writes gpurun_out/<tag>/...; copy what is to be judged into profiles/ (tools/copy_profiles.sh <tag>).
-TAG=${1:-r02}
+TAG=${1:-r03}; GIT_HEAD=${2:-unknown}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench_f8.json 2> $O/bench_f8.err
-python3 $R/bench.py --conv-mode h3 --no-cpu > $O/bench_h3.json 2> $O/bench_h3.err
-python3 $R/bench.py --conv-mode f32 --no-cpu --no-latency > $O/bench_f32.json 2> $O/bench_f32.err
-python3 $R/bench.py --res 128 --no-cpu > $O/bench_r128_f8.json 2> $O/bench_r128.err
-# per-kernel averages of the same command (timing pass: kernel trace + stats only)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-latency > $O/stats.log 2>&1
-# counters: each group in its own pass, with the kernel trace only
-for c in "hit:TCC_HIT_sum TCC_MISS_sum" "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
-  n=${c%%:*}
-  rocprofv3 --kernel-trace --pmc ${c#*:} --output-format csv -d $O/pmc_$n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency > $O/pmc_$n.log 2>&1
+# the driver's command: one line carrying all three arithmetic modes
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+python3 $R/bench.py --res 128 --no-cpu --modes primary > $O/bench_r128_f8.json 2> $O/bench_r128.err
+# per-kernel averages of the same command (timing pass: kernel trace + stats only), per mode
+for m in f8 h3 f32; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode $m > $O/stats_$m.log 2>&1
+  cp $(ls $O/stats_$m/*/*kernel_stats.csv | head -1) $O/kernel_stats_$m.csv 2>/dev/null
+done
+# counters: each group in its own pass, with the kernel trace only; memory counters per mode, MFMA-busy for the split modes
+for m in f8 h3 f32; do
+  for c in "hit:TCC_HIT_sum TCC_MISS_sum" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+    n=${c%%:*}
+    rocprofv3 --kernel-trace --pmc ${c#*:} --output-format csv -d $O/pmc_${n}_$m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode $m > $O/pmc_${n}_$m.log 2>&1
+  done
+  (cd $R && python tools/pmc_mem_summary.py $O/pmc_hit_$m $O/pmc_fetch_$m $O/pmc_write_$m $O/pmc_mem_$m.json > $O/pmc_mem_$m.txt 2>&1)
+done
+for m in f8 h3; do
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode $m > $O/pmc_mfma_$m.log 2>&1
+  (cd $R && python tools/pmc_summary.py $O/pmc_mfma_$m > $O/pmc_mfma_busy_$m.txt 2>&1)
 done
 cd $R
-python tools/pmc_mem_summary.py $O/pmc_hit $O/pmc_fetch $O/pmc_write $O/pmc_mem.json > $O/pmc_mem.txt 2>&1
-python tools/make_hbm_traffic.py $O/pmc_mem.json $O/hbm_traffic.json > $O/hbm_traffic.log 2>&1
-python tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma_busy.txt 2>&1
+python tools/make_hbm_traffic.py $O/hbm_traffic.json "${GIT_HEAD:-unknown}" f8=$O/pmc_mem_f8.json h3=$O/pmc_mem_h3.json f32=$O/pmc_mem_f32.json > $O/hbm_traffic.log 2>&1
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv 2>/dev/null
 NB_PHASE_F8=1 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times.txt 2>&1
 python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
@@ -32,5 +39,5 @@ python tools/bench_canvas.py --size 1024 --res 128 --level 2 --steps 3 --breakdo
 python tools/bench_lamali.py > $O/lamali.json 2> $O/lamali.err
 python tools/bench_train.py > $O/train_bench.json 2> $O/train_bench.err
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
-rm -rf $O/stats $O/pmc_hit $O/pmc_fetch $O/pmc_write $O/pmc_mfma
-ls $O; tail -c 400 $O/bench_f8.json; tail -2 $O/smoke.txt
+rm -rf $O/stats_* $O/pmc_hit_* $O/pmc_fetch_* $O/pmc_write_* $O/pmc_mfma_f8 $O/pmc_mfma_h3
+ls $O; tail -c 400 $O/bench.json; tail -2 $O/smoke.txt

@@ -32,7 +32,7 @@ for (k, g), v in sorted(rows.items(), key=lambda t: -sum(dur[t[0]])):
     fetch = m.get("FETCH_SIZE")
     write = m.get("WRITE_SIZE")
     line = f"{k[:60]:60s} grid {g:>9s} {sum(dur[(k, g)]) / len(dur[(k, g)]) / 1e3:8.1f}us"
-    rec = {"grid": g}
+    rec = {"grid": g, "launches": len(dur[(k, g)])}
     if hit is not None and miss is not None and hit + miss > 0:
         line += f"  L2 hit {hit / (hit + miss) * 100:5.1f}%"
         rec["l2_hit"] = hit / (hit + miss)
