@@ -1,0 +1,106 @@
+"""One process per GPU: start-up shared by the multi-GPU entry points (``paint_image_main``, ``tools/bench_canvas.py``,
+``tools/bench_lamali.py``; ``bench.py`` carries its own copy so that the driver's file stands alone).
+
+The reference's counterpart is ``torch.multiprocessing.spawn`` per GPU + ``init_process_group('nccl')`` in
+``thirdparty/stylegan2_ada_pytorch/train.py:811-816, 523-530``; its painting job itself is single-device
+(``forger/viz/paint_image_main.py:126``, ``neube_stylize.sh:79-85``).
+
+``self_launch`` re-runs the calling script under ``python -m torch.distributed.run`` as a CHILD process -- before
+anything in the parent has touched the GPU, and the parent only waits (no exec of a GPU-initialised process) -- and
+returns the child's exit code: a rank that dies or a failed collective pre-flight surfaces as a non-zero exit.
+``init`` is what every rank calls first: the kernel library is built / loaded BEFORE the process group exists (a rank that
+compiles for minutes while the others wait in a collective would run into their timeouts), then the device is chosen
+and the group created.
+
+Test hooks for a one-GPU box (numbers from such a run mean nothing): ``NB_BENCH_SHARE_GPU=1`` puts every rank on
+device 0, ``NB_BENCH_BACKEND=gloo`` swaps RCCL out (RCCL refuses two ranks on one device).
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import subprocess
+import sys
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def under_torchrun() -> bool:
+    return "WORLD_SIZE" in os.environ
+
+
+def self_launch(script: str, argv: List[str], gpus: int) -> int:
+    """Run ``script argv`` as ``gpus`` ranks of a child torchrun; returns its exit code."""
+    from . import build as _build
+    _build.build(verbose=False)                     # once, here: no rank compiles while the others wait
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={gpus}", os.path.abspath(script)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def init(timeout_s: int = 300) -> Tuple[int, int, torch.device, str]:
+    """(rank, world, device, backend) of this process; creates the process group when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NB_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
+    if os.environ.get("NB_BENCH_FAIL_RANK") == str(rank) and world > 1:        # test hook: a rank that dies at start-up
+        raise SystemExit(7)
+    from . import build as _build, _lib
+    _build.build(verbose=False)
+    _lib.lib()
+    if not torch.cuda.is_available():
+        raise _lib.NeubeHipError("no GPU: the painting / generator path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tmo = datetime.timedelta(seconds=timeout_s)            # a wedged collective should fail the run, not hang it
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+        else:
+            dist.init_process_group(backend, timeout=tmo)
+    return rank, world, dev, backend
+
+
+def preflight(dev: torch.device, rank: int, world: int) -> None:
+    """One small all-to-all + gather through the fabric, checked; raises SystemExit(3) on every rank if it fails (a job
+    whose exchange does not work must not print a number)."""
+    if world == 1:
+        return
+    try:
+        send = torch.full([world * 4], float(rank), device=dev)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)
+        t = torch.full([8], rank, dtype=torch.uint8, device=dev)
+        got = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, got, dst=0)
+        torch.cuda.synchronize()
+        good = bool((recv.view(world, 4)[:, 0].cpu() == torch.arange(world, dtype=torch.float32)).all())
+        if rank == 0:
+            good = good and all(int(g[0]) == r for r, g in enumerate(got))
+        ok = torch.tensor([1.0 if good else 0.0], device=dev)
+    except Exception as e:                                     # noqa: BLE001
+        print(f"[launch] rank {rank}: collective pre-flight failed: {e}", file=sys.stderr, flush=True)
+        ok = torch.tensor([0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1:
+        if rank == 0:
+            print("[launch] FAILED: the halo exchange / tile gather did not pass its pre-flight; no number is reported",
+                  file=sys.stderr, flush=True)
+        dist.destroy_process_group()
+        raise SystemExit(3)
+
+
+def finish(world: int) -> None:
+    if world > 1 and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

@@ -512,7 +512,7 @@ class PaintingHelper:
         self.feature_blending_level = 0
         self.rows = self.cols = None
         self.features = self.mask = None
-        self._canvas_rank_local = False
+        self._canvas_rank_local, self._sync_layout = False, None
         self.halo_bytes = None
         self.down_factor = None
         self._alpha_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
@@ -525,8 +525,49 @@ class PaintingHelper:
     def set_feature_blending(self, feature_blending_level: int = 0):
         self.feature_blending_level = int(feature_blending_level)
         self.features = self.mask = None
-        self._canvas_rank_local = False
+        self._canvas_rank_local, self._sync_layout = False, None
         self.down_factor = 2 ** (self.feature_blending_level - 1) if self.feature_blending_level > 0 else None
+
+    def sync_canvas(self):
+        """Make the feature canvas whole on every rank after a sharded ``render_tiles`` (collective: all ranks call it).
+
+        A sharded call replays, on each rank, the paint sequence under that rank's own tiles only (plus the strips of
+        earlier foreign tiles under them), so a rank's canvas is final exactly where the LAST tile covering a pixel is one
+        of its own.  Every pixel under this call's tiles therefore has one owning rank; the owners' values are summed with
+        zeros from everybody else (one all-reduce over the tiles' bounding box: exact, x + 0 + ... + 0) and every rank ends
+        up with the canvas the reference's single persistent ``FeatureCanvas`` (brush.py:33-92) would hold.  Runs lazily --
+        ``_schedule`` calls it when a second sharded call paints on the same canvas; a canvas that is painted once (the
+        ``paint_image`` job) never pays for it."""
+        if not self._canvas_rank_local:
+            return
+        rank, world = self._world()
+        rects, bounds = self._sync_layout
+        self._canvas_rank_local, self._sync_layout = False, None
+        if world == 1 or self.features is None:
+            return
+        hc, wc = self.mask.shape
+        y0, x0 = max(0, int(rects[:, 0].min())), max(0, int(rects[:, 1].min()))
+        y1, x1 = min(hc, int(rects[:, 2].max())), min(wc, int(rects[:, 3].max()))
+        if y1 <= y0 or x1 <= x0:
+            return
+        last = np.full((hc, wc), -1, np.int64)                       # paint order: the last tile over a pixel wins
+        owner_of = np.empty(rects.shape[0] + 1, np.int64)
+        owner_of[-1] = -1
+        for r_, (a, b) in enumerate(bounds):
+            owner_of[a:b] = r_
+        for t, (a0, b0, a1, b1) in enumerate(rects.tolist()):
+            last[max(0, a0):a1, max(0, b0):b1] = t
+        owner = owner_of[last[y0:y1, x0:x1]]
+        ops = self.ops
+        mine = ops.to_device((owner == rank))
+        touched = ops.to_device((owner >= 0))
+        f = self.features[0, :, y0:y1, x0:x1]
+        m = self.mask[y0:y1, x0:x1]
+        buf = torch.cat([(f * mine).reshape(-1), (m * mine).to(torch.float32).reshape(-1)])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        nf = f.numel()
+        self.features[0, :, y0:y1, x0:x1] = torch.where(touched, buf[:nf].view(f.shape), f)
+        self.mask[y0:y1, x0:x1] = torch.where(touched, buf[nf:].view(m.shape).to(torch.uint8), m)
 
     def set_render_mode(self, mode: str):
         if mode not in ("clear", "full"):
@@ -557,8 +598,7 @@ class PaintingHelper:
         T = areas_yx.shape[0]
         level, df = self.feature_blending_level, self.down_factor
         if world > 1 and level > 0 and self._canvas_rank_local:
-            raise RuntimeError("the feature canvas is rank-local after a sharded render_tiles: call make_new_canvas "
-                               "before painting on it again with world size > 1")
+            self.sync_canvas()                   # the previous sharded call left every rank with ITS tiles' paint sequence only
         t0, t1 = shard_bounds(T, rank, world)
         n_own = t1 - t0
         n_pad = -(-T // world)                                                 # equal per-rank count for collectives
@@ -682,7 +722,10 @@ class PaintingHelper:
                 self.mask = ops.replay_pieces(pieces, bres, alpha0, crop_sc, self.features, self.mask,
                                               ops.to_device(off), ops.to_device(lst), box)
             if world > 1:
-                self._canvas_rank_local = True       # my canvas now holds the paint sequence under MY tiles only
+                # my canvas now holds the paint sequence under MY tiles only; what it takes to make it whole again
+                # (sync_canvas, run lazily by the next sharded call on this canvas) is the tile layout of this call
+                self._canvas_rank_local = True
+                self._sync_layout = (rects.copy(), bounds)
             # phase 3: last block(s) + ToRGB + compositing on the blended features, own tiles
             for i, (b0, b1) in blist:
                 with on_stream(i):

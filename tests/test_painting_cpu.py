@@ -257,7 +257,7 @@ def _worker(rank, world, port, tmp):
         g = load_golden("engine_r128.npz")
         cfg = cfgmod.style1_config(128)
         e = dict(g=g, cfg=cfg, sd=wmod.random_state_dict(cfg, seed=0), esd=encmod.random_encoder_state_dict(5),
-                 z=np.random.RandomState(594).randn(1, cfg.z_dim))
+                 z=np.random.RandomState(594).randn(1, cfg.z_dim), pad2=g["geom_padded"])
         for level in (0, 2):
             helper, res = _paint(e, level, batch=2)
             if rank == 0:
@@ -275,8 +275,17 @@ def _worker(rank, world, port, tmp):
                 if rank == 0:
                     np.save(os.path.join(tmp, "mask.npy"), m.numpy())
                     np.save(os.path.join(tmp, "halo_bytes.npy"), torch.stack(allhb).numpy())
-                with pytest.raises(RuntimeError, match="rank-local"):
-                    helper.render_tiles(g["geom_padded"], g["crops"], painting.GanBrushOptions(), crop_margin=10)
+                # painting on the SAME canvas again across ranks (the reference keeps one persistent FeatureCanvas over
+                # strokes, brush.py:33-92): the second sharded call first makes the canvas whole on every rank
+                # (sync_canvas: one all-reduce in which every pixel has exactly one owner), then blends against it
+                opts2 = painting.GanBrushOptions()
+                opts2.set_style(torch.from_numpy(np.random.RandomState(7).randn(1, cfg.z_dim)), 7)
+                second = helper.render_tiles(e["pad2"], g["crops"][2:7], opts2, crop_margin=10)
+                helper.sync_canvas()
+                if rank == 0:
+                    np.save(os.path.join(tmp, "second.npy"), second.numpy())
+                np.save(os.path.join(tmp, f"features_after_second_{rank}.npy"), helper.features.numpy())
+                np.save(os.path.join(tmp, f"mask_after_second_{rank}.npy"), helper.mask.numpy())
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -363,6 +372,15 @@ def test_sharded_schedule_gloo(eng, tmp_path, world):
     assert hb[:, 0].sum() == hb[:, 1].sum() > 0
     tile_bytes = 128 * 64 * 64 * 4
     assert hb.max() < 2 * tile_bytes, hb                      # (the old schedule moved 9 whole tiles to every rank)
+    # a second sharded call on the same canvas == the same two calls in one process (one persistent feature canvas)
+    helper, res = _paint(eng, 2, batch=2)
+    opts2 = painting.GanBrushOptions()
+    opts2.set_style(torch.from_numpy(np.random.RandomState(7).randn(1, eng["cfg"].z_dim)), 7)
+    ref2 = helper.render_tiles(eng["g"]["geom_padded"], eng["g"]["crops"][2:7], opts2, crop_margin=10).numpy()
+    _canvas_close(np.load(tmp_path / "second.npy"), ref2)
+    for r in range(world):                                    # ... and every rank holds the whole canvas afterwards
+        np.testing.assert_allclose(np.load(tmp_path / f"features_after_second_{r}.npy"), helper.features.numpy(), atol=2e-5)
+        assert np.array_equal(np.load(tmp_path / f"mask_after_second_{r}.npy"), helper.mask.numpy())
 
 
 # ---------------------------------------------------------------- clear-background (UVS) mapping

@@ -1,7 +1,15 @@
-"""BASELINE config 3 (tiled canvas stylization) on the HIP path: synthetic line drawing -> tiles -> 3-phase schedule
--> RGBA canvas.  One process per GPU (launch with torch.distributed.run for N>1); prints one JSON line on rank 0.
+"""BASELINE config 3 (tiled canvas stylization) on the HIP path: synthetic line drawing (or, with --lamali, the job's
+named input lamali_sm.png from its fixture) -> tiles -> 3-phase schedule -> RGBA canvas on rank 0's host.
+One process per GPU; prints one JSON line on rank 0.
 
-    python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3
+    python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 [--gpus N] [--breakdown] [--lamali]
+
+``--gpus N`` (N > 1) without a torchrun environment launches the N ranks itself (child torchrun before anything here
+touches the GPU, brushstroke_engine_amd/launch.py) and exits with the child's code: a rank that dies or a failed
+collective pre-flight is a non-zero exit without a JSON line.  With N > 1 the tiles are cut into contiguous per-rank
+ranges; the line reports tiles/s (max-over-ranks wall clock between barriers), the halo bytes every rank sent / received
+and, with --breakdown, each rank's per-phase device times.  Reference job: neube_stylize.sh:79-85 +
+forger/viz/paint_image_main.py:145-192 (single device there).
 """
 import argparse
 import json
@@ -14,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from brushstroke_engine_amd import config as cfgmod, weights as wmod, encoder as encmod, painting  # noqa: E402
+from brushstroke_engine_amd import config as cfgmod, weights as wmod, encoder as encmod, painting, launch  # noqa: E402
 from brushstroke_engine_amd.networks import Generator  # noqa: E402
 
 
@@ -35,8 +43,15 @@ def synthetic_drawing(h, w, seed=0, n_lines=None):
     return g[..., None]
 
 
-def main():
+def lamali_geometry():
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "engine_lamali_r256.npz")))
+    h, w = g["geom_shape"].tolist()
+    return (np.unpackbits(g["geom_bits"])[:h * w].reshape(h, w) * 255).astype(np.uint8)[..., None], g
+
+
+def parser():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--level", type=int, default=2)
@@ -46,63 +61,102 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--conv-mode", default="f8")
     ap.add_argument("--breakdown", action="store_true")
+    ap.add_argument("--lamali", action="store_true", help="paint lamali_sm.png (tests/golden/engine_lamali_r256.npz, R=256) instead of the "
+                                                            "synthetic drawing and report the distance to the reference-painted canvas")
     ap.add_argument("--encoder", default="hip", choices=["hip"])
-    a = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return ap
+
+
+def main():
+    a = parser().parse_args()
+    if not launch.under_torchrun() and a.gpus > 1:
+        raise SystemExit(launch.self_launch(__file__, sys.argv[1:], a.gpus))
+    rank, world, dev, backend = launch.init()
+    launch.preflight(dev, rank, world)
+    line = run(a, rank, world, dev, backend)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    launch.finish(world)
+
+
+def run(a, rank, world, dev, backend):
+    """One configuration on an initialised process (group); returns the JSON-able result on rank 0, None elsewhere."""
+    _TIMES.clear()
+    gold = None
+    if a.lamali:
+        a.res = 256
+        geom, gold = lamali_geometry()
+    else:
+        geom = synthetic_drawing(a.size, a.size)
     cfg = cfgmod.style1_config(a.res)
-    G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode=a.conv_mode).to("cuda")
-    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5))
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=int(gold["weights_seed"]) if gold else 0), conv_mode=a.conv_mode).to(dev)
+    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(int(gold["encoder_seed"]) if gold else 5), device=dev)
     ops = painting.TileOps(G, enc)
     helper = painting.PaintingHelper(ops, batch=a.batch)
     helper.set_feature_blending(a.level)
     opts = painting.GanBrushOptions()
-    opts.set_style(torch.from_numpy(np.random.RandomState(594).randn(1, cfg.z_dim)), 594)
-    geom = synthetic_drawing(a.size, a.size)
+    opts.set_style(torch.from_numpy(np.random.RandomState(int(gold["style_seed"]) if gold else 594).randn(1, cfg.z_dim)), 594)
     times = []
-    if a.breakdown and world == 1:
+    if a.breakdown:
         _wrap_timers(ops)
+    full = line = None
     for i in range(a.warmup + a.steps):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = helper.paint_image(geom, opts, crop_margin=a.crop_margin)
+        if gold is not None and i == a.warmup + a.steps - 1:
+            res = helper.paint_image(geom, opts, crop_margin=a.crop_margin, return_full=True)
+            full = None if res is None else res[1]
+        else:
+            helper.paint_image(geom, opts, crop_margin=a.crop_margin)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        dt = torch.tensor([time.perf_counter() - t0], device="cuda")
+        dt = torch.tensor([time.perf_counter() - t0], device=dev)
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         if i >= a.warmup:
             times.append(float(dt))
-        elif a.breakdown and world == 1:
+        elif a.breakdown:
             _TIMES.clear()
+    # per-rank figures: halo bytes of the exchange, per-phase device time
+    torch.cuda.synchronize()
+    mine = {"rank": rank, "halo_bytes": helper.halo_bytes,
+            "breakdown_ms": {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / a.steps, 3) for k, v in _TIMES.items()} if _TIMES else None}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         n_tiles = len(painting.generate_stitching_crops(painting.pad_geo(geom, a.crop_margin), a.res, 'all', 2 * a.crop_margin)[0])
         t = float(np.mean(times))
         line = {"metric": "tiled canvas stylization, tiles/s (end to end: host tiling + H2D + encoder + generator + "
                           "paste + D2H)", "value": n_tiles / t, "unit": "tiles/s", "n_gpus": world, "seconds": t,
-                "tiles": n_tiles, "canvas": [a.size, a.size], "res": a.res, "feature_blending_level": a.level,
+                "tiles": n_tiles, "canvas": list(geom.shape[:2]), "input": "lamali_sm.png (fixture)" if gold else "synthetic line drawing",
+                "res": a.res, "feature_blending_level": a.level,
                 "crop_margin": a.crop_margin, "batch": a.batch, "conv_mode": a.conv_mode, "encoder": a.encoder, "steps": a.steps,
-                "stroke_fraction": float((geom == 0).mean())}
-        if _TIMES:
-            torch.cuda.synchronize()
-            line["breakdown_ms"] = {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / a.steps, 3) for k, v in _TIMES.items()}
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+                "stroke_fraction": float((geom == 0).mean()),
+                "parallelism": "single GPU" if world == 1 else
+                               f"tiles in {world} contiguous ranges; halo strips by one all_to_all_single ({'RCCL' if backend == 'nccl' else backend}) "
+                               f"under phase 1, RGBA tiles gathered on rank 0",
+                "timing": "max over ranks of the wall clock between barriers, mean over steps"}
+        if world > 1:
+            line["halo_bytes_per_rank"] = [p["halo_bytes"] for p in per_rank]
+        if a.breakdown:
+            line["breakdown_ms" if world == 1 else "breakdown_ms_per_rank"] = per_rank[0]["breakdown_ms"] if world == 1 else [p["breakdown_ms"] for p in per_rank]
+        if gold is not None and a.level in (0, 2) and f"canvas_level{a.level}_clear" in gold and full is not None:
+            d = np.abs(full.astype(np.int32) - gold[f"canvas_level{a.level}_clear"].astype(np.int32))
+            line["vs_reference_canvas"] = {"max_lsb": int(d.max()), "bytes_differing": float((d > 0).mean())}
+        return line
+    return None
 
 
 _TIMES = {}
 
 
 def _wrap_timers(ops):
-    for name in ("geom_tiles", "encode", "head", "tail", "full", "replay", "paste", "map_style"):
+    for name in ("geom_tiles", "encode", "head", "tail", "full", "replay", "replay_pieces", "paste", "map_style"):
         fn = getattr(ops, name)
 
         def wrapped(*args, _fn=fn, _name=name, **kw):
