@@ -5,7 +5,9 @@
     python -m brushstroke_engine_amd.paint_image_main --gan_checkpoint engine.npz --geom_image drawing.png \\
         --output_file_prefix out/drawing --style_id 594 --feature_blending_level 2 [--on_white]
 
-Under ``torch.distributed.run`` (one process per GPU) the tiles are sharded over the ranks and rank 0 writes the file.
+``--gpus N`` (or running it under ``torch.distributed.run``, one process per GPU) shards the tiles over the ranks;
+rank 0 writes the file.  ``--conv_mode`` chooses the arithmetic of the conv layers explicitly (default: the library
+default, ``f8``; ``h3`` = fp32-grade products, ``f32`` = exact fp32 MFMA).
 """
 from __future__ import annotations
 
@@ -18,7 +20,8 @@ import torch
 import torch.distributed as dist
 
 from . import encoder, formats, painting
-from .networks import Generator
+from . import launch
+from .networks import DEFAULT_CONV_MODE, Generator
 
 logger = logging.getLogger(__name__)
 
@@ -54,20 +57,21 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--color_mode", default=None)
     ap.add_argument("--on_white", action="store_true")
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--conv_mode", default=None, choices=["f8", "h3", "f32"],
+                    help="arithmetic of the conv layers (default: networks.DEFAULT_CONV_MODE = f8: f16 main product + fp8 corrections, "
+                         "~1e-4 from fp32 on pixels; h3: three f16 products, 5e-6; f32: exact fp32 MFMA)")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: launch N ranks (one per GPU) and shard the tiles over them")
     return ap
 
 
 def main(argv=None) -> str:
     args = build_parser().parse_args(argv)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+    if args.gpus > 1 and not launch.under_torchrun():
+        import sys
+        raise SystemExit(launch.self_launch(__file__, sys.argv[1:] if argv is None else list(argv), args.gpus))
+    rank, world, device, _ = launch.init()          # kernel library first, then the device and (world > 1) the process group
     cfg, gen_sd, enc_sd, preproc, _ = formats.load_engine_snapshot(args.gan_checkpoint)
-    G = Generator(cfg, gen_sd).to(device)
+    G = Generator(cfg, gen_sd, conv_mode=args.conv_mode or DEFAULT_CONV_MODE).to(device)
     if not encoder.HipGeometryEncoder.supports(cfg.img_resolution):
         raise RuntimeError(f"the geometry-encoder kernels tile patches of 128 k pixels; this checkpoint paints {cfg.img_resolution}")
     enc = encoder.HipGeometryEncoder(enc_sd, preproc_type=preproc, device=device)
