@@ -24,6 +24,7 @@
 #include "nb_common.h"
 #include "nb_torgb.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -92,6 +93,15 @@ __device__ __forceinline__ void nb_stagger(int stagger_ticks, int first_round) {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, K0>{}) ... f(std::integral_constant<int, K1 - 1>{})
+template <int K0, int K1, class F>
+__device__ __forceinline__ void nb_static_for(F&& f) {
+    if constexpr (K0 < K1) {
+        f(std::integral_constant<int, K0>{});
+        nb_static_for<K0 + 1, K1>(f);
+    }
+}
 
 // "f8" operand format (F8 = true): the two correction products run on ONE block-scaled fp8 MFMA per tap pair.
 //   activations: the (cg, lo) slots of a 16-channel chunk hold, instead of the f16 low halves,
@@ -1000,13 +1010,8 @@ extern "C" int nb_modconv3x3_up1_h3_h2(const void* x_h2, int c_in, const void* w
 #ifndef NB_H3_TQH
 #define NB_H3_TQH 12
 #endif
-#define NB_H3_TQH_SMALL 5       // tile height of the under-filled (batch-1) launches ...
-#ifndef NB_H3_STAGES_SMALL
-#define NB_H3_STAGES_SMALL 2    // ... (3 stages fit its LDS and were measured at batch 1: no faster - with one position block
-#endif                           // per wave the K loop is bound by the LDS reads of the shared weight fragments, not by DMA latency)
-#ifndef NB_H3_STAGES
-#define NB_H3_STAGES 2          // LDS-DMA stages of the up=2 kernel.  3 (needs NB_H3_TQH <= 10 to fit the LDS) was measured:
-#endif                           // no faster -- the K loop is not DMA-latency bound
+#define NB_H3_TQH_SMALL 5       // tile height of the under-filled (batch-1) launches
+#define NB_H3_STAGES 3          // LDS-DMA stages of the up=2 kernel (planes at their exact size: 3 x 52 032 B for the 12-row tile)
 struct H3Up2Params {
     const _Float16* x;      // H2 [n][c8][2][H][W][8]
     const _Float16* wts;    // [nchunks][9][2][2][co_ld][8]
@@ -1035,12 +1040,16 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
     constexpr int NBJ = (NBLK + NW - 1) / NW;         // blocks per wave (2)
     constexpr int XR = TQH + 3, XS = TQW + 3;         // halo tile 15 x 35 input pixels
-    constexpr int SLOTS = XR * XS, PP = (SLOTS + 63) / 64, XPL = PP * 64;       // 525 -> 9 pieces
+    // planes are packed at their exact size (the last 1-KiB DMA piece of a plane is partial: lanes past the plane do not
+    // copy), which is what lets THREE stages of the 12-row tile fit the 160 KiB of LDS
+    constexpr int SLOTS = XR * XS, PP = (SLOTS + 63) / 64, XPL = SLOTS;         // 525 slots -> 9 pieces
     constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;                     // 36 -> 5 per wave
     constexpr int WSLOTS = 36 * 32, NWP = WSLOTS / 64, NWPW = (NWP + NW - 1) / NW;   // 18 -> 3 per wave
+    constexpr int NPC = NXPW + NWPW;                  // LDS-DMA pieces a wave issues per chunk (8)
     constexpr int STAGE = 4 * XPL + WSLOTS;           // 16-byte slots per stage
+    constexpr int NST = NB_H3_STAGES;                 // 3
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
-    h8* ring = reinterpret_cast<h8*>(smem_h3);        // [2][ x: 4 planes x XPL | w: 36 rows x 32 ]
+    h8* ring = reinterpret_cast<h8*>(smem_h3);        // [NST][ x: 4 planes x XPL | w: 36 rows x 32 ]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
@@ -1074,7 +1083,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         s_noise[e] = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] * p.gain : 0.f;
     }
 
+    // LDS-DMA descriptors of this wave's pieces.  Activation piece i: plane xpl (= cg_local*2 + hi/lo), 64 slots from
+    // `part`; xsp = element offset of the lane's source slot inside a plane (-1: outside the image -> zero page),
+    // xok = the lane's slot belongs to the plane (the last piece of a plane is partial)
     int xsp[NXPW], xpl[NXPW], xdst[NXPW];
+    bool xok[NXPW];
 #pragma unroll
     for (int i = 0; i < NXPW; ++i) {
         int q = i * NW + wv;
@@ -1084,29 +1097,35 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         xpl[i] = pl;
         xdst[i] = pl * XPL + part * 64;
         xsp[i] = -1;
+        xok[i] = e < SLOTS;
         if (e < SLOTS) {
             const int r = e / XS, c = e - r * XS;
             const int gy = I0 - 1 + r, gx = J0 - 1 + c;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) xsp[i] = (gy * W + gx) * 8;
         }
     }
-    auto issue = [&](int c, h8* st) {
-#pragma unroll
-        for (int i = 0; i < NXPW; ++i) {
-            const int cg = 2 * c + (xpl[i] >> 1);
+    // piece k of chunk c into stage st: k < NXPW activations, else weights
+    auto issue_piece = [&](auto kk, int c, h8* st) {
+        constexpr int k = decltype(kk)::value;
+        if constexpr (k < NXPW) {
+            const int cg = 2 * c + (xpl[k] >> 1);
             const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
-            if (xsp[i] >= 0 && cg < p.c8) src = xn + (size_t)(4 * c + xpl[i]) * HW8 + xsp[i];
-            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + xdst[i]), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NWPW; ++i) {
-            int q = i * NW + wv;
+            if (xsp[k] >= 0 && cg < p.c8) src = xn + (size_t)(4 * c + xpl[k]) * HW8 + xsp[k];
+            if (xok[k]) __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + xdst[k]), 16, 0, 0);
+        } else {
+            int q = (k - NXPW) * NW + wv;
             q = q < NWP ? q : NWP - 1;
             const int e = q * 64 + lane;
             const int row = e >> 5, j = e & 31;           // row = tap*4 + cg*2 + hl
             const _Float16* src = p.wts + (((size_t)c * 36 + row) * p.co_ld + co0 + j) * 8;
             __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + 4 * XPL + q * 64), 16, 0, 0);
         }
+    };
+    auto issue = [&](int c, h8* st) { nb_static_for<0, NPC>([&](auto k) { issue_piece(k, c, st); }); };
+    // the pieces of one chunk spread over S points of the MFMA stream: point s issues pieces [s NPC / S, (s+1) NPC / S)
+    auto issue_at = [&](auto ss, auto SS, int c, h8* st) {
+        constexpr int s_ = decltype(ss)::value, S_ = decltype(SS)::value;
+        nb_static_for<s_ * NPC / S_, (s_ + 1) * NPC / S_>([&](auto k) { issue_piece(k, c, st); });
     };
 
     // B-fragment base slots: position (r, c) of block (wv + 8j); X(r, c) = slot r*XS + c of plane (lh*2 + hl)
@@ -1128,12 +1147,19 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][ph][r] = 0.f;
 
+    // ---- K loop: 16-channel chunks through a THREE-stage LDS ring.  Chunk c is read from stage c % 3 while the LDS-DMA
+    //      pieces of chunk c+2 are issued one or two at a time BETWEEN the chunk's MFMA groups (a piece costs the issuing
+    //      wave ~60 cycles among MFMAs, 100-185 in a burst next to the fragment reads -- and after a barrier both waves of a
+    //      SIMD would burst at the same moment, with nobody feeding the matrix pipe: that burst was a third of the K loop
+    //      of the 2-stage form).  One wait + barrier per chunk: vmcnt(NPC) = everything but the pieces just issued, i.e.
+    //      chunk c+1 (issued a whole chunk ago) has landed; the barrier also frees stage (c-1) % 3 = (c+2) % 3 for the
+    //      next chunk's pieces.  The last two chunks issue nothing (own copies of the body: no branch inside it). ----
     const int NC = p.nchunks;
-    constexpr int NST = TQH == NB_H3_TQH_SMALL ? NB_H3_STAGES_SMALL : NB_H3_STAGES;
+    static_assert(NST == 3, "ring indices below are written for three stages");
     issue(0, ring);
-    if (NST == 3) {
-        issue(NC > 1 ? 1 : 0, ring + STAGE);                       // (single-chunk layers: a harmless second copy)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXPW + NWPW) : "memory");
+    if (NC > 1) {
+        issue(1, ring + STAGE);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1149,17 +1175,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int kPha[9] = {3, 2, 1, 0, 2, 0, 1, 0, 0};                 // kTapPhase[kOrd[i]]
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
-    for (int c = 0; c < NC; ++c) {
-        h8* st = ring + (c % NST) * STAGE;
-        if (NST == 3) {
-            // two chunks of LDS-DMA in flight: chunk c+2 goes into the stage chunk c-1 just left (past the end: a
-            // harmless re-copy of the last chunk keeps the vmcnt bookkeeping uniform)
-            issue(c + 2 < NC ? c + 2 : NC - 1, ring + ((c + 2) % NST) * STAGE);
-        } else if (c + 1 < NC && !(p.dbg & 2)) {
-            issue(c + 1, ring + ((c + 1) & 1) * STAGE);
-        }
+    // one chunk: reads from `st`; DMA = issue the pieces of chunk cn into `sn` between the MFMA groups
+    auto chunk = [&](auto dma_, const h8* st, int cn, h8* sn) {
+        constexpr bool DMA = decltype(dma_)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if (F8) {
+        if constexpr (F8) {
             // "f8" operands (see modconv3x3_up1_h3_kernel): one f16 MFMA per tap for the main product, and the two
             // correction products of a PAIR of taps that feed the same output phase on one block-scaled fp8 MFMA:
             //   phase 0 (ee): taps (8,6) and (2,0)   phase 1 (eo): (7,1)   phase 2 (oe): (5,3)   phase 3 (oo): 4 alone
@@ -1168,6 +1188,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             const h8 z8 = {};
             h8 b0h[NBJ], b0l[NBJ], b1h[NBJ], b1l[NBJ], b2h[NBJ], b2l[NBJ];
             h8 a1h, a1l, a2h, a2l, n1h, n1l, n2h, n2l;
+            using S4 = std::integral_constant<int, 4>;
 #define NB_LDA(tap, hi, lo) { hi = st[aoff + (tap) * 128]; lo = st[aoff + (tap) * 128 + 32]; }
 #define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) { hi[j] = st[boff[j] + (del)]; lo[j] = st[boff[j] + XPL + (del)]; } }
 #define NB_PAIR(ph, ah_a, al_a, bha, bla, ah_b, al_b, bhb, blb)                                                                   \
@@ -1176,11 +1197,14 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_a, bha[j], a_, 0, 0, 0);                                            \
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_b, bhb[j], a_, 0, 0, 0);                                            \
                 a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(al_a, al_b), nb_cat8(bla[j], blb[j]), a_, 0, 0, 0, sa, 0, sb); } }
+#define NB_DMA(slot) { if constexpr (DMA) { __builtin_amdgcn_sched_barrier(0); issue_at(std::integral_constant<int, slot>{}, S4{}, cn, sn); __builtin_amdgcn_sched_barrier(0); } }
             NB_LDB(0, b0h, b0l); NB_LDB(1, b1h, b1l); NB_LDA(8, a1h, a1l); NB_LDA(6, a2h, a2l);
             NB_LDA(5, n1h, n1l); NB_LDA(3, n2h, n2l);
             NB_PAIR(0, a1h, a1l, b0h, b0l, a2h, a2l, b1h, b1l);                   // taps 8, 6
+            NB_DMA(0);
             NB_LDA(4, a1h, a1l);
             NB_PAIR(2, n1h, n1l, b0h, b0l, n2h, n2l, b1h, b1l);                   // taps 5, 3
+            NB_DMA(1);
             NB_LDB(XS, b1h, b1l); NB_LDA(7, n1h, n1l); NB_LDA(1, n2h, n2l);
 #pragma unroll
             for (int j = 0; j < NBJ; ++j) {                                       // tap 4 alone
@@ -1188,57 +1212,75 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h[j], a_, 0, 0, 0);
                 a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(a1l, z8), nb_cat8(b0l[j], z8), a_, 0, 0, 0, sa, 0, sb);
             }
+            NB_DMA(2);
             NB_LDB(XS + 1, b2h, b2l); NB_LDA(2, a1h, a1l); NB_LDA(0, a2h, a2l);
             NB_PAIR(1, n1h, n1l, b0h, b0l, n2h, n2l, b1h, b1l);                   // taps 7, 1
+            NB_DMA(3);
             NB_PAIR(0, a1h, a1l, b1h, b1l, a2h, a2l, b2h, b2l);                   // taps 2, 0
 #undef NB_LDA
 #undef NB_LDB
 #undef NB_PAIR
+#undef NB_DMA
         } else {
-        h8 ah[2], al[2], bh[2][NBJ], bl[2][NBJ];
-        ah[0] = st[aoff + kOrd[0] * 128]; al[0] = st[aoff + kOrd[0] * 128 + 32];
+            h8 ah[2], al[2], bh[2][NBJ], bl[2][NBJ];
+            ah[0] = st[aoff + kOrd[0] * 128]; al[0] = st[aoff + kOrd[0] * 128 + 32];
 #pragma unroll
-        for (int j = 0; j < NBJ; ++j) { bh[0][j] = st[boff[j] + kDel[0]]; bl[0][j] = st[boff[j] + XPL + kDel[0]]; }
+            for (int j = 0; j < NBJ; ++j) { bh[0][j] = st[boff[j] + kDel[0]]; bl[0][j] = st[boff[j] + XPL + kDel[0]]; }
+            nb_static_for<0, 9>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                constexpr int ca = i & 1, cb = kGrp[i] & 1;
+                f32x16& a0 = acc[0][kPha[i]];
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][0], a0, 0, 0, 0);
+                constexpr int nfetch = i + 1 < 9 ? (kGrp[i + 1 < 9 ? i + 1 : i] != kGrp[i] ? 2 + 2 * NBJ : 2) : 0;
+                if constexpr (i + 1 < 9) {
+                    ah[ca ^ 1] = st[aoff + kOrd[i + 1] * 128]; al[ca ^ 1] = st[aoff + kOrd[i + 1] * 128 + 32];
+                    if constexpr (kGrp[i + 1] != kGrp[i]) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int ca = i & 1, cb = kGrp[i] & 1;
-            f32x16& a0 = acc[0][kPha[i]];
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][0], a0, 0, 0, 0);
-            int nfetch = 0;
-            if (i + 1 < 9) {
-                ah[ca ^ 1] = st[aoff + kOrd[i + 1] * 128]; al[ca ^ 1] = st[aoff + kOrd[i + 1] * 128 + 32];
-                nfetch = 2;
-                if (kGrp[i + 1] != kGrp[i]) {
-#pragma unroll
-                    for (int j = 0; j < NBJ; ++j) {
-                        bh[cb ^ 1][j] = st[boff[j] + kDel[i + 1]]; bl[cb ^ 1][j] = st[boff[j] + XPL + kDel[i + 1]];
+                        for (int j = 0; j < NBJ; ++j) {
+                            bh[cb ^ 1][j] = st[boff[j] + kDel[i + 1]]; bl[cb ^ 1][j] = st[boff[j] + XPL + kDel[i + 1]];
+                        }
                     }
-                    nfetch += 2 * NBJ;
                 }
-            }
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][0], a0, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][0], a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][0], a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][0], a0, 0, 0, 0);
 #pragma unroll
-            for (int j = 1; j < NBJ; ++j) {
-                f32x16& aj = acc[j][kPha[i]];
-                aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][j], aj, 0, 0, 0);
-                aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][j], aj, 0, 0, 0);
-                aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][j], aj, 0, 0, 0);
-            }
-            // next tap's fragment reads go out BEFORE this tap's six MFMAs (their registers are free: the previous tap
-            // has issued), which gives the LDS the whole tap to answer
-            if (nfetch == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            else if (nfetch) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NBJ, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ, 0);
-        }
+                for (int j = 1; j < NBJ; ++j) {
+                    f32x16& aj = acc[j][kPha[i]];
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][j], aj, 0, 0, 0);
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][j], aj, 0, 0, 0);
+                    aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][j], aj, 0, 0, 0);
+                }
+                // next tap's fragment reads go out BEFORE this tap's six MFMAs (their registers are free: the previous tap
+                // has issued), which gives the LDS the whole tap to answer
+                if constexpr (nfetch > 0) __builtin_amdgcn_sched_group_barrier(0x100, nfetch, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ, 0);
+                // this chunk's share of the next-but-one chunk's LDS-DMA pieces, behind the tap's MFMAs (taps 0..7)
+                if constexpr (DMA && i < 8) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_at(ii, std::integral_constant<int, 8>{}, cn, sn);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
         }
         __builtin_amdgcn_sched_barrier(0);
-        // chunk c+1 must have landed; with 3 stages the DMA of chunk c+2 may stay in flight
+    };
+    int c = 0;
+    int s_cur = 0;                                    // stage of chunk c
+    for (; c + 2 < NC; ++c) {
+        const int s_nn = s_cur == 0 ? 2 : s_cur - 1;  // (c + 2) % 3
+        chunk(std::true_type{}, ring + s_cur * STAGE, c + 2, ring + s_nn * STAGE);
+        // chunk c+1 has landed (the pieces of c+2 may stay in flight); everybody is done reading chunk c
         // (no timestamp reads in here: the branches around them split the loop body into several basic blocks, and the
-        //  compiler then sinks 8 of a chunk's 10 fp8 instructions past the wait and the barrier below)
-        if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXPW + NWPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        //  compiler then sinks MFMAs past the wait and the barrier)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
         __builtin_amdgcn_s_barrier();
+        s_cur = s_cur == 2 ? 0 : s_cur + 1;
+    }
+    for (; c < NC; ++c) {
+        chunk(std::false_type{}, ring + s_cur * STAGE, 0, nullptr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        s_cur = s_cur == 2 ? 0 : s_cur + 1;
     }
     if (p.tstamps && tid == 0) {
         unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
@@ -1447,9 +1489,9 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
     p.tiles_x = p.w / TQW;
     p.tiles_y = (p.h + TQH - 1) / TQH;
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
-    constexpr int XPL = (((TQH + 3) * (TQW + 3) + 63) / 64) * 64;
+    constexpr int XPL = (TQH + 3) * (TQW + 3);
     constexpr int NBLK_ = ((TQH + 2) * (TQW + 2) + 31) / 32;
-    constexpr size_t lds_stage = (size_t)(TQH == NB_H3_TQH_SMALL ? NB_H3_STAGES_SMALL : NB_H3_STAGES) * (4 * XPL + 36 * 32) * 16;
+    constexpr size_t lds_stage = (size_t)NB_H3_STAGES * (4 * XPL + 36 * 32) * 16;
     constexpr size_t lds_epi = (size_t)16 * NBLK_ * 32 * 16;       // epilogue: [2 groups][2 halves][4 phases][positions] x 4 channels fp32
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
