@@ -536,7 +536,10 @@ __global__ __launch_bounds__(256) void enc_conv3x3_small_h3_kernel(const EncSmal
         int e = q * 64 + lane;
         e = e < NH ? e : NH - 1;                                     // (tail lanes re-copy the last slot: never read)
         const int hy = e / HC, hx = e - hy * HC;
-        const int iy = nb_reflect(STRIDE * y0 - 1 + hy, p.hin), ix = nb_reflect(STRIDE * x0 - 1 + hx, p.win);
+        // (positions of a ragged tile past the image reach further than the one reflected pixel: clamped, never stored)
+        int iy = nb_reflect(STRIDE * y0 - 1 + hy, p.hin), ix = nb_reflect(STRIDE * x0 - 1 + hx, p.win);
+        iy = iy < 0 ? 0 : (iy >= p.hin ? p.hin - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= p.win ? p.win - 1 : ix);
         xsrc[q] = (iy * p.win + ix) * 8;
     }
     h8* mybuf = reinterpret_cast<h8*>(smem_es) + wv * (2 * 4 * NHP);
@@ -642,7 +645,7 @@ static int launch_enc_small(EncSmallParams p, int n, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)enc_conv3x3_small_h3_kernel<STRIDE, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int tiles_y = p.hout / p.rows;
+    const int tiles_y = (p.hout + p.rows - 1) / p.rows;          // (ragged last tile row: masked at the store)
     hipLaunchKernelGGL((enc_conv3x3_small_h3_kernel<STRIDE, OUT>), dim3(p.tiles_x * tiles_y * p.slices, n), dim3(256), lds, st, p);
     NB_CHECK_LAUNCH("enc_conv3x3_small_h3");
     return NB_OK;
@@ -661,7 +664,12 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
     NB_REQUIRE(h_in % stride == 0 && w_in % stride == 0 && h_in >= 2 && w_in >= 2, "enc_conv3x3_h3: bad input size %dx%d", h_in, w_in);
     const int ho = h_in / stride, wo = w_in / stride;
     const bool wide = wo % 32 == 0 && ho % 8 == 0, narrow = wo == 16 && ho % 16 == 0;
-    NB_REQUIRE(wide || narrow, "enc_conv3x3_h3: output must be 16 wide (rows %% 16 == 0) or a multiple of 32 wide (rows %% 8 == 0), got %dx%d", ho, wo);
+    // the 32-position split-K tiles take any output whose width is a power of two >= 4 (4- and 8-wide images: the encoder's
+    // inner layers at patch sizes 32 and 64; rows that do not fill the last tile are masked)
+    const bool pow2 = (wo & (wo - 1)) == 0 && wo >= 4;
+    const bool small_ok = pow2 && c_in % 16 == 0 && in_fmt == 0;
+    NB_REQUIRE(wide || narrow || small_ok, "enc_conv3x3_h3: output must be a multiple of 32 wide (rows %% 8 == 0), 16 wide (rows %% 16 == 0), or -- H2 "
+               "operands, c_in %% 16 == 0 -- a power of two >= 4 wide; got %dx%d", ho, wo);
     NB_REQUIRE(y_f32 || c_out % 8 == 0, "enc_conv3x3_h3: H2 output needs c_out %% 8 == 0");
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y_f32 | (uintptr_t)y_h2) % 16 == 0, "enc_conv3x3_h3: pointers must be 16-byte aligned");
     EncConvParams p;
@@ -671,6 +679,7 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 127) / 128 * 128;
     p.hin = h_in; p.win = w_in; p.hout = ho; p.wout = wo; p.slope = slope;
     const bool handoff = oscale != nullptr || c8_total > 0 || out_fmt != 0;
+    NB_REQUIRE(!handoff || wide || narrow, "enc_conv3x3_h3: the hand-off into a consumer's operand tensor needs the large tiles (output %dx%d)", ho, wo);
     NB_REQUIRE(!handoff || (y_h2 && c8_total >= cg0 + (c_out + 7) / 8 && cg0 >= 0 && (out_fmt == 0 || (out_fmt == 1 && c_out % 16 == 0 && cg0 % 2 == 0))
                             && (!oscale || oscale_stride >= c_out)),
                "enc_conv3x3_h3: bad hand-off arguments (needs an H2 destination with room for the channel groups; f8: whole 16-channel chunks)");
@@ -683,9 +692,8 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
         const long big_wgs = (long)n * (wo / (wide ? 32 : 16)) * (ho / (wide ? 8 : 16)) * ((c_out + 127) / 128);
         static const int env_force = getenv("NB_ENC_SMALL") ? atoi(getenv("NB_ENC_SMALL")) : -1;
         const int force = g_enc_small >= 0 ? g_enc_small : env_force;
-        const bool pow2 = (wo & (wo - 1)) == 0 && wo >= 8;
-        const bool small = force >= 0 ? force != 0 : (big_wgs <= 48 && c_in >= 32);
-        if (small && pow2 && c_in % 16 == 0 && (wo >= 32 || ho % (32 / wo) == 0)) {
+        const bool small = !(wide || narrow) || (force >= 0 ? force != 0 : (big_wgs <= 48 && c_in >= 32));
+        if (small && small_ok) {
             EncSmallParams q;
             q.x = p.x; q.wts = p.wts; q.bias = bias; q.y32 = y_f32; q.yh2 = (_Float16*)y_h2;
             q.c8 = p.c8; q.nchunks = p.nchunks; q.c_out = c_out; q.co_ld = p.co_ld; q.hin = h_in; q.win = w_in; q.hout = ho; q.wout = wo;

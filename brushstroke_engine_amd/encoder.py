@@ -103,7 +103,7 @@ class HipGeometryEncoder:
     """``AutoEncoder.encode(geom, res=[0, 1])`` on the hand-written gfx950 kernels: 8 launches per batch
     (stem, 3 stride-2 convs, 2 bottleneck convs, bilinear x2, decoder conv), BatchNorm folded on the host.
     Interface of the reference's ``AutoEncoder`` as the engine uses it (``encode``, ``feature_channels``,
-    ``featuremap_resolution``).  Patch sizes the kernels do not tile (R % 128 != 0) raise."""
+    ``featuremap_resolution``).  Patch sizes: 32, 64 and multiples of 128 (``supports``)."""
 
     _PRE = {None: 0, "none": 0, "-11inverse": 1, "inverse": 2}
     arith = "f8"           # operand format between the layers for large batches ("h3": hi/lo f16 everywhere)
@@ -138,7 +138,19 @@ class HipGeometryEncoder:
 
     @staticmethod
     def supports(resolution: int) -> bool:
+        """Patch sizes the kernels tile: multiples of 128 (every layer on the large tiles) and the powers of two below -- 32
+        and 64, the remaining sizes a StyleGAN2 generator can have -- whose inner layers (outputs 4 or 8 pixels wide) take the
+        32-position split-K tiles (``enc_conv3x3_small_h3_kernel``), which read hi/lo-f16 operands."""
+        return resolution in (32, 64) or (resolution >= 128 and resolution % 128 == 0)
+
+    @staticmethod
+    def large_tiles_only(resolution: int) -> bool:
         return resolution >= 128 and resolution % 128 == 0
+
+    def can_handoff(self, resolution: int, i: int) -> bool:
+        """Can feature i of a patch of this size be written straight into a generator layer's operand tensor (large tiles)?"""
+        r = self.featuremap_resolution(resolution, i)
+        return i == 1 and (r % 32 == 0 or r == 16)
 
     def lazy(self, geom: torch.Tensor) -> "LazyGeometry":
         """The geometry features of ``geom`` as a provider the HIP generator evaluates itself, right after it has computed
@@ -155,7 +167,7 @@ class HipGeometryEncoder:
         lib, check = self._lib.lib(), self._lib.check
         n, c, h, w = geom.shape
         if c != 1 or not self.supports(h) or h != w:
-            raise RuntimeError(f"HipGeometryEncoder: unsupported geometry shape {tuple(geom.shape)} (square, R % 128 == 0)")
+            raise RuntimeError(f"HipGeometryEncoder: unsupported geometry shape {tuple(geom.shape)} (square; R = 32, 64 or a multiple of 128)")
         x = geom.to(self.device, torch.float32).contiguous()
         f16 = lambda ch, r: torch.empty([n, ch // 8, 2, r, r, 8], dtype=torch.float16, device=self.device)
         f32 = lambda ch, r: torch.empty([n, ch, r, r], dtype=torch.float32, device=self.device)
@@ -165,7 +177,7 @@ class HipGeometryEncoder:
             # operand format between the layers: "f8" (fp8 correction operands, 2/3 of the matrix cycles) for batches that
             # fill the chip with the large-tile kernel; H2 (hi/lo f16) otherwise -- the small-tile kernel of interactive
             # strokes reads H2
-            fmt = 1 if (self.arith == "f8" and n >= self.f8_min_batch) else 0
+            fmt = 1 if (self.arith == "f8" and n >= self.f8_min_batch and self.large_tiles_only(h)) else 0
             W = lambda cv: P(cv[5] if fmt else cv[0])
             a = f16(64, h)
             check(lib.nb_enc_stem7x7_f32_h2_ex(P(x), P(self.stem[0]), P(self.stem[1]), P(a), fmt, n, h, w,
@@ -186,6 +198,8 @@ class HipGeometryEncoder:
             check(lib.nb_enc_upsample2x_h2_ex(P(enc), P(up), fmt, n, co, r, r, st), "enc_upsample")
             _, b, ci, co, stride, _ = self.convs[5]          # first decoder stage, 16 -> 256
             tg = None if not targets else targets.get(1)
+            if tg is not None and not self.can_handoff(h, 1):
+                raise RuntimeError(f"HipGeometryEncoder: no hand-off into operand tensors at patch size {h} (LazyGeometry.can_handoff)")
             if tg is not None:
                 dec = None
                 check(lib.nb_enc_conv3x3_ex(P(up), ci, W(self.convs[5]), P(b), None, P(tg["dst"]), tg["scale_ptr"], tg["scale_stride"],
@@ -219,6 +233,9 @@ class LazyGeometry:
     def sliced(self, a: int, b: int) -> "LazyGeometry":
         """The provider of samples a..b-1 (the generator runs a large batch as sub-batches on separate streams)."""
         return LazyGeometry(self.encoder, self.geom[a:b])
+
+    def can_handoff(self, i: int) -> bool:
+        return self.encoder.can_handoff(self.geom.shape[2], i)
 
     def feature_shape(self, i: int):
         n, _, h, _ = self.geom.shape

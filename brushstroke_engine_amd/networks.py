@@ -461,7 +461,8 @@ class SynthesisNetwork(torch.nn.Module):
                         gch = self.geom_feature_channels[g_idx]
                         ofmt = self._operand_fmt(sc_)
                         if (self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 16 == 0 and gch % 16 == 0
-                                and tuple(lazy_geom.feature_shape(g_idx)) == (n, gch, gres, gres)):
+                                and tuple(lazy_geom.feature_shape(g_idx)) == (n, gch, gres, gres)
+                                and getattr(lazy_geom, "can_handoff", lambda i_: True)(g_idx)):
                             dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
                             c_prod = sc_.in_channels - gch
                             targets[g_idx] = dict(dst=dst, scale_ptr=plan.styles[ic].data_ptr() + 4 * c_prod, scale_stride=sc_.in_channels,

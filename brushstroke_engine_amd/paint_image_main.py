@@ -73,7 +73,7 @@ def main(argv=None) -> str:
     cfg, gen_sd, enc_sd, preproc, _ = formats.load_engine_snapshot(args.gan_checkpoint)
     G = Generator(cfg, gen_sd, conv_mode=args.conv_mode or DEFAULT_CONV_MODE).to(device)
     if not encoder.HipGeometryEncoder.supports(cfg.img_resolution):
-        raise RuntimeError(f"the geometry-encoder kernels tile patches of 128 k pixels; this checkpoint paints {cfg.img_resolution}")
+        raise RuntimeError(f"the geometry-encoder kernels tile patches of 32, 64 or 128 k pixels; this checkpoint paints {cfg.img_resolution}")
     enc = encoder.HipGeometryEncoder(enc_sd, preproc_type=preproc, device=device)
     ops = painting.TileOps(G, enc)
     mapper = None

@@ -110,6 +110,29 @@ def hdr_state_dict(cfg: GeneratorConfig, seed: int = 0, act_scale: float = 60.0,
     return sd
 
 
+def trained_like_state_dict(cfg: GeneratorConfig, seed: int = 0) -> StateDict:
+    """Variant of :func:`random_state_dict` with the STATISTICS of a trained StyleGAN2 generator instead of i.i.d. Gaussian
+    weights (there is no checkpoint in the reference tree): every conv weight gets log-normal per-input-channel and
+    per-output-channel scales (sigma = 1: a few channels carry most of the energy, heavy tails), two input channels per
+    layer are DOMINANT styles (affine bias x8, so the demodulated contraction is dominated by a handful of terms and the
+    errors of the split products do not average out over 128+ channels), the affine weights are 3x larger (styles vary
+    strongly with w) and the noise strengths 5x.  Used by the f8 margin fixtures (tests/golden/gen_trained_r128.npz)."""
+    sd = random_state_dict(cfg, seed)
+    rs = np.random.RandomState(seed + 7919)
+    for l in cfg.layers:
+        w = sd[f"{l.name}.weight"]
+        ci = np.exp(rs.randn(l.in_channels)).astype(np.float32)
+        co = np.exp(rs.randn(l.out_channels)).astype(np.float32)
+        sd[f"{l.name}.weight"] = (w * co[:, None, None, None] * ci[None, :, None, None]).astype(np.float32)
+        ab = sd[f"{l.name}.affine.bias"].copy()
+        dom = rs.choice(l.in_channels, size=min(2, l.in_channels), replace=False)
+        ab[dom] *= np.float32(8.0)
+        sd[f"{l.name}.affine.bias"] = ab
+        sd[f"{l.name}.affine.weight"] = (sd[f"{l.name}.affine.weight"] * np.float32(3.0)).astype(np.float32)
+        sd[f"{l.name}.noise_strength"] = (sd[f"{l.name}.noise_strength"] * np.float32(5.0)).astype(np.float32)
+    return sd
+
+
 def expected_shapes(cfg: GeneratorConfig) -> Dict[str, tuple]:
     return {k: tuple(v.shape) for k, v in random_state_dict(cfg, 0).items()}
 

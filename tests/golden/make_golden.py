@@ -102,6 +102,7 @@ def stats(a):
 # ----------------------------------------------------------------------------------------------
 
 def make_ops():
+    torch.manual_seed(0)                  # (the FC known-answer tests draw their weights from torch's generator)
     rs = np.random.RandomState(1234)
     out = {}
     # bias_act KATs (bias_act.py:93-123): lrelu / linear / tanh x clamp on/off
@@ -313,6 +314,39 @@ def make_hdr():
     print("gen_hdr_r128.npz: layers at the clamp:", [n_ for n_, r in zip(names, rng) if r[1] >= 255.99], "logits", out["logits.range"])
 
 
+def make_trained():
+    """Trained-like statistics (weights.trained_like_state_dict: log-normal channel scales, dominant styles, strong noise),
+    R=128, N=3 with three different latents and positions: the reference's fp32 evaluation -- full uvs / img, the features at
+    R/2 (what the FeatureCanvas carries from stroke to stroke) on every 4th channel, logits subsampled, per-layer ranges."""
+    res = 128
+    cfg = cfgmod.style1_config(res)
+    sd = wmod.trained_like_state_dict(cfg, seed=0)
+    G = build_reference(cfg, sd)
+    n = 3
+    z = synthetic.batch_z(cfg, n, first_seed=1234)
+    geom = synthetic.geom_features(cfg, n, seed=3)
+    pos = np.array([[0, 0], [37, 211], [4095, 17]], np.int64)
+    out = {"z": z, "positions": pos, "weights_seed": np.int64(0), "geom_seed": np.int64(3)}
+    half = res // 2
+    with Capture(G, cfg) as cap:
+        (img, dbg), taps = run_case(G, cfg, cap, z=z, geom=geom, positions=pos, return_debug_data=True, return_features=[half])
+    out["uvs"], out["img"], out["colors"] = np32(dbg["uvs"]), np32(img), np32(dbg["colors"])
+    out["logits.sub"] = sub(np32(taps["torgb.logits"]), 2)
+    f = np32(dbg[f"features{half}"])
+    out[f"features{half}.c4"] = f[:, ::4]
+    out[f"features{half}.maxabs"] = np.float64(np.abs(f).max())
+    rng = []
+    for l in cfg.layers:
+        v = np32(taps[f"{l.name}.out"])
+        rng.append([np.sqrt((v.astype(np.float64) ** 2).mean()), np.abs(v).max(), (np.abs(v) >= 255.99).mean()])
+    out["layer_range"] = np.array(rng, np.float64)
+    lg = np32(taps["torgb.logits"])
+    out["logits.range"] = np.array([lg.min(), lg.max()], np.float64)
+    np.savez_compressed(os.path.join(HERE, "gen_trained_r128.npz"), **out)
+    print("gen_trained_r128.npz: layer rms/max/clamped", np.round(out["layer_range"], 3).tolist(), "logits", out["logits.range"],
+          "features max", out[f"features{half}.maxabs"])
+
+
 def make_b32():
     """The BASELINE workload itself (batch 32, R=256, the inputs bench.py's rank 0 uses) through the reference on CPU:
     per-sample checksums of uvs / img and one full pixel row per sample."""
@@ -342,7 +376,9 @@ def make_b32():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    if "--hdr" in sys.argv or "--b32" in sys.argv:
+    if "--hdr" in sys.argv or "--b32" in sys.argv or "--trained" in sys.argv:
+        if "--trained" in sys.argv:
+            make_trained()
         if "--hdr" in sys.argv:
             make_hdr()
         if "--b32" in sys.argv:
@@ -353,4 +389,5 @@ if __name__ == "__main__":
     make_full(128, 4)
     make_full(256, 8)
     make_hdr()
+    make_trained()
     make_b32()

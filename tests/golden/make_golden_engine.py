@@ -132,6 +132,92 @@ def main_lamali():
     print("engine_lamali_r256.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def stroke_sequence(R, n_strokes=20, seed=11, size=400):
+    """The inputs of the multi-stroke fixture: n strokes on a size x size canvas -- (x, y) of the tile, the stroke patch
+    [R,R,1] uint8 with 255 = stroke (what the UI sends: forger/ui/brush.py:244-262) and the style seed of each stroke.  The
+    tiles overlap heavily, so most pixels are blended against features that several earlier strokes left on the canvas."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n_strokes):
+        x, y = int(rs.randint(0, size - R)), int(rs.randint(0, size - R))
+        patch = np.zeros((R, R, 1), np.uint8)
+        py, px = rs.randint(20, R - 20), rs.randint(20, R - 20)
+        ang = rs.rand() * 2 * np.pi
+        half = int(rs.randint(1, 4))
+        for _ in range(rs.randint(60, 160)):
+            ang += rs.randn() * 0.2
+            py, px = py + np.sin(ang) * 1.5, px + np.cos(ang) * 1.5
+            yi, xi = int(py), int(px)
+            if half <= yi < R - half and half <= xi < R - half:
+                patch[yi - half:yi + half + 1, xi - half:xi + half + 1] = 255
+        out.append((x, y, patch, int([594, 12, 77][i % 3])))
+    return out
+
+
+def main_strokes():
+    """An interactive session: 20 overlapping strokes in three alternating styles on ONE canvas with feature blending
+    level 2, each through the reference's PaintingHelper.render_stroke (brush.py:244-398) with the FeatureCanvas carried
+    from stroke to stroke -- the state an arithmetic error would accumulate in.  Stored: the final RGBA canvas, every
+    stroke's returned tile checksum, the feature canvas (subsampled) after strokes 5, 10 and 20."""
+    R, crop_margin, size = 128, 10, 400
+    eng = build_engine(R)
+    seq = stroke_sequence(R, size=size)
+    helper = brush.PaintingHelper(eng, style_seed=0)
+    helper.make_new_canvas(size, size, feature_blending=2)
+    helper.set_render_mode("clear")
+    result = np.zeros((size, size, 4), np.uint8)
+    out = {"resolution": np.int64(R), "crop_margin": np.int64(crop_margin), "size": np.int64(size), "weights_seed": np.int64(0),
+           "encoder_seed": np.int64(5), "xy": np.array([(x, y) for x, y, _, _ in seq], np.int64),
+           "styles": np.array([s_ for _, _, _, s_ in seq], np.int64), "patches": np.packbits(np.stack([p_[..., 0] for _, _, p_, _ in seq]) > 0)}
+    sums, placed = [], []
+    with torch.no_grad():
+        for i, (x, y, patch, style) in enumerate(seq):
+            opts = brush.GanBrushOptions()
+            opts.set_style(eng.random_style(style), style)
+            opts.set_position(x, y)
+            res, _, meta = helper.render_stroke(patch, None, opts, meta={"x": x, "y": y, "crop_margin": crop_margin})
+            result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+            sums.append(res.astype(np.int64).sum(axis=(0, 1)))
+            placed.append((meta["x"], meta["y"]))
+            if i + 1 in (5, 10, 20):
+                out[f"feature_canvas_sub_{i + 1}"] = helper.feature_canvas.features[0, ::8, ::4, ::4].numpy().copy()
+                out[f"feature_canvas_mask_sum_{i + 1}"] = np.float64(helper.feature_canvas.mask.sum())
+            if i == 19:
+                out["last_tile"] = res
+    out["canvas"] = result
+    out["tile_sums"] = np.array(sums, np.int64)
+    out["placed_xy"] = np.array(placed, np.int64)
+    out["feature_canvas_maxabs"] = np.float64(helper.feature_canvas.features.abs().max())
+    np.savez_compressed(os.path.join(HERE, "engine_strokes_r128.npz"), **out)
+    print("engine_strokes_r128.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def main_encoder_small():
+    """The reference geometry encoder (forger/experimental/autoenc/simple_autoencoder.py:155-199, 251-261; preprocessing
+    base.py:30-52) at the patch sizes below 128 -- 64 and 32 -- on seeded stroke patches: inputs after prepare_geom_input and
+    both features the generator consumes (res 0 = the 16-channel bottleneck, res 1 = the 256-channel decoder stage)."""
+    out = {"encoder_seed": np.int64(5)}
+    for R in (64, 32):
+        eng = build_engine(R)
+        rs = np.random.RandomState(R)
+        patches = np.zeros((3, R, R, 1), np.uint8)
+        for i in range(3):
+            for _ in range(4):
+                y, x = rs.randint(2, R - 2), rs.randint(2, R - 2)
+                dy, dx = rs.randint(-R // 2, R // 2), rs.randint(-R // 2, R // 2)
+                for t in np.linspace(0, 1, 4 * R):
+                    yy, xx = int(y + t * dy), int(x + t * dx)
+                    if 1 <= yy < R - 1 and 1 <= xx < R - 1:
+                        patches[i, yy - 1:yy + 2, xx - 1:xx + 2] = rs.randint(128, 256)      # (gray levels too)
+        g = torch.cat([eng.prepare_geom_input(p_) for p_ in patches])
+        with torch.no_grad():
+            f = eng.encoder.encode(g)
+        out[f"enc_in_r{R}"] = g.numpy()
+        out[f"enc_f0_r{R}"], out[f"enc_f1_r{R}"] = f[0].numpy(), f[1].numpy()
+    np.savez_compressed(os.path.join(HERE, "encoder_small.npz"), **out)
+    print("encoder_small.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
 def main():
     R = 128
     cfg = cfgmod.style1_config(R)
@@ -224,7 +310,11 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--lamali" in sys.argv:
+    if "--encoder-small" in sys.argv:
+        main_encoder_small()
+    elif "--strokes" in sys.argv:
+        main_strokes()
+    elif "--lamali" in sys.argv:
         main_lamali()
     else:
         main()

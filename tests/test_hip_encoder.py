@@ -116,10 +116,64 @@ def test_enc_stem_and_upsample():
     assert float((_h2_to_nchw(up).cpu() - ref).abs().max()) <= 2e-6
 
 
+@pytest.mark.parametrize("res", [64, 32])
+@pytest.mark.parametrize("n_rep", [1, 4])
+def test_encoder_small_patch_sizes_match_reference(res, n_rep):
+    """Patch sizes below 128 (a resolution-generic build): the inner layers' outputs are 8 or 4 pixels wide and
+    run on the 32-position split-K tiles (ragged last tile rows masked).  Against the REFERENCE encoder's outputs
+    (tests/golden/make_golden_engine.py --encoder-small; simple_autoencoder.py:155-199, 251-261), also at a batch that
+    would take the f8 inter-layer format at the large sizes (12 samples: stays on hi/lo f16 here)."""
+    g = load_golden("encoder_small.npz")
+    enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(int(g["encoder_seed"])))
+    assert enc.supports(res) and not enc.large_tiles_only(res)
+    x = torch.from_numpy(np.concatenate([g[f"enc_in_r{res}"]] * n_rep)).cuda()
+    f = enc.encode(x)
+    for k in range(n_rep):
+        np.testing.assert_allclose(f[0][3 * k:3 * k + 3].cpu().numpy(), g[f"enc_f0_r{res}"], atol=TOL)
+        np.testing.assert_allclose(f[1][3 * k:3 * k + 3].cpu().numpy(), g[f"enc_f1_r{res}"], atol=TOL)
+    lazy = enc.lazy(x)
+    assert lazy.feature_shape(1) == (3 * n_rep, 256, res // 4, res // 4)
+    assert lazy.can_handoff(1) == (res == 64) and not lazy.can_handoff(0)
+
+
+@pytest.mark.parametrize("res", [64, 32])
+def test_painting_at_small_patch_sizes(res):
+    """The engine end to end at patch sizes 64 and 32 (HIP encoder + generator + canvas kernels, feature blending 2, lazy
+    geometry provider) against the oracle painter's sequential tile loop."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, painting
+    from brushstroke_engine_amd.networks import Generator
+    from oracle import neube_oracle as no
+    cfg = cfgmod.style1_config(res)
+    sd, esd = wmod.random_state_dict(cfg, seed=2), encmod.random_encoder_state_dict(5)
+    rs = np.random.RandomState(res)
+    geom = np.full((3 * res - 11, 2 * res + 7, 1), 255, np.uint8)
+    for _ in range(12):
+        y, x = rs.randint(2, geom.shape[0] - 2), rs.randint(2, geom.shape[1] - 2)
+        geom[max(y - 9, 0):y + 9, x - 1:x + 2] = 0
+        geom[y - 1:y + 2, max(x - 9, 0):x + 9] = 0
+    z = np.random.RandomState(594).randn(1, cfg.z_dim)
+    m = 4 if res == 32 else 6
+    P = po.OraclePainter(no.OracleGenerator(cfg, sd), esd)
+    P.feature_blending_margin = 8 if res == 32 else 16          # (16 leaves no interior on the 16 x 16 blending grid of R = 32)
+    ref = P.paint_image(geom, z=z, crop_margin=m, feature_blending=2)[0]
+    for mode in ("h3", "f8"):
+        G = Generator(cfg, sd, conv_mode=mode).to("cuda")
+        helper = painting.PaintingHelper(painting.TileOps(G, encmod.HipGeometryEncoder(esd)), batch=5)
+        helper.feature_blending_margin = 8 if res == 32 else 16
+        helper.set_feature_blending(2)
+        opts = painting.GanBrushOptions()
+        opts.set_style(torch.from_numpy(z), 594)
+        out = helper.paint_image(geom, opts, crop_margin=m)
+        d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() <= 5e-3, (res, mode, d.max(), (d > 0).mean())
+
+
 def test_encoder_rejects_unsupported():
     enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(1))
     with pytest.raises(RuntimeError):
-        enc.encode(torch.zeros(1, 1, 64, 64).cuda())
+        enc.encode(torch.zeros(1, 1, 48, 48).cuda())
+    with pytest.raises(RuntimeError):
+        enc.encode(torch.zeros(1, 1, 64, 32).cuda())
     with pytest.raises(RuntimeError):
         encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(1), preproc_type="bogus")
     assert _lib.lib().nb_enc_conv3x3_h3(None, 16, None, None, None, None, 1, 16, 16, 16, 1, 0.01, None) < 0

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 PIX_TOL = 1e-4
 ACT_TOL = 5e-4
 # per arithmetic mode (Generator(conv_mode=...)): pixels / uvs, activations and logits.  north_star budget: 1e-3 on pixels.
-MODES = ("h3", "f8")
+MODES = ("h3", "f8", "f32")
 PIX = {"f32": 1e-4, "h3": 1e-4, "f8": 3e-4}
 ACT = {"f32": 5e-4, "h3": 5e-4, "f8": 4e-3}
 
@@ -189,7 +189,7 @@ def test_linearity_and_determinism_full_size(dev, mode):
     # summation order (and, below the large-tile kernels' batch threshold, fp32 kernels for some layers): equal within the
     # mode's distance from fp32, not bitwise
     c = G(z[idx], None, [x[idx] for x in geom], positions=pos[idx], noise_mode="const")
-    assert err(c, a[idx]) <= {"h3": 2e-5, "f8": 3e-4}[mode]
+    assert err(c, a[idx]) <= {"f32": 2e-5, "h3": 2e-5, "f8": 3e-4}[mode]
 
 
 @pytest.mark.parametrize("mode,res", [("h3", 64), ("f8", 64), ("f8", 256), ("h3", 256)])
@@ -288,6 +288,32 @@ def test_high_dynamic_range_fixture(dev, mode):
     assert e_ft <= {"f32": 2e-3, "h3": 2e-3, "f8": 0.25}[mode] and e_lg <= {"f32": 1e-3, "h3": 1e-3, "f8": 4e-3 * 10}[mode]
 
 
+@pytest.mark.parametrize("mode", ["f32", "h3", "f8"])
+def test_trained_like_fixture(dev, mode):
+    """Trained-like weight statistics (weights.trained_like_state_dict: log-normal per-channel scales, two dominant styles per
+    layer, strong noise; max activation >= 8x rms, logits -30..+59) against the REFERENCE's fp32 evaluation
+    (tests/golden/make_golden.py --trained).  With a few channels carrying the contraction, the split products' errors do
+    not average out over 128+ terms: this is where the f8 mode's margin is measured -- pixels <= 3e-4 (budget 1e-3), and the
+    features at R/2, which the FeatureCanvas carries from stroke to stroke, <= 1e-3 of their range."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator
+    g = load_golden("gen_trained_r128.npz")
+    cfg = cfgmod.style1_config(128)
+    G = Generator(cfg, wmod.trained_like_state_dict(cfg, seed=int(g["weights_seed"])), conv_mode=mode).to(dev)
+    geom = [D(x, dev) for x in synthetic.geom_features(cfg, 3, seed=int(g["geom_seed"]))]
+    extra = {"logits": True}
+    img, dbg = G(D(g["z"], dev), None, geom, positions=D(g["positions"], dev), return_debug_data=True, return_features=[64],
+                 noise_mode="const", _extra_outputs=extra)
+    e_uvs, e_img = err(dbg["uvs"], g["uvs"]), err(img, g["img"])
+    e_lg = err(extra["out"]["logits"][..., ::2, ::2], g["logits.sub"])
+    e_ft = err(dbg["features64"][:, ::4], g["features64.c4"]) / float(g["features64.maxabs"])
+    print(f"[trained {mode}] uvs {e_uvs:.2e} img {e_img:.2e} logits {e_lg:.2e} features64 (relative to max {float(g['features64.maxabs']):.1f}) {e_ft:.2e}")
+    assert err(dbg["colors"], g["colors"]) <= 1e-5
+    assert e_uvs <= PIX[mode] and e_img <= PIX[mode], (mode, e_uvs, e_img)
+    assert e_ft <= {"f32": 2e-5, "h3": 2e-5, "f8": 1e-3}[mode], (mode, e_ft)
+    assert e_lg <= {"f32": 5e-4, "h3": 5e-4, "f8": 2e-2}[mode], (mode, e_lg)
+
+
 @pytest.mark.parametrize("mode", ["h3", "f8"])
 def test_baseline_batch32_r256_golden(dev, mode):
     """BASELINE.json configs[1] at FULL size -- batch 32, R=256, the very inputs bench.py's rank 0 renders -- against values the
@@ -340,4 +366,4 @@ def test_two_sub_batch_chains_equal_one_chain(dev, mode):
         G.sub_stream_min_batch = None
     assert G.sub_stream_min_batch == 64
     assert torch.equal(two_a, two_b)
-    assert err(two_a, one) <= {"h3": 2e-5, "f8": 3e-4}[mode]
+    assert err(two_a, one) <= {"f32": 2e-5, "h3": 2e-5, "f8": 3e-4}[mode]

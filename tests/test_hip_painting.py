@@ -237,6 +237,53 @@ def test_render_stroke_interactive_sequence(eng):
     _canvas_close(result, g["canvas_level2_clear"])
 
 
+def _stroke_session(g):
+    R = int(g["resolution"])
+    patches = np.unpackbits(g["patches"])[:20 * R * R].reshape(20, R, R, 1) * 255
+    return R, patches.astype(np.uint8)
+
+
+@pytest.mark.parametrize("mode", ["f8", "h3", "f32"])
+def test_twenty_stroke_session_drift(eng, mode):
+    """An interactive session painted by the REFERENCE engine (tests/golden/make_golden_engine.py --strokes): 20 heavily
+    overlapping strokes in three alternating styles on one canvas, feature blending level 2, the FeatureCanvas carried
+    from stroke to stroke.  An arithmetic error in the features at R/2 feeds back through the canvas into every later
+    stroke, so this bounds the ACCUMULATED error of each conv mode (f8 in particular: it is the library default):
+    final canvas <= 1 LSB on few bytes, feature canvas after 5 / 10 / 20 strokes within the mode's per-stroke tolerance --
+    no growth with the number of strokes."""
+    g = load_golden("engine_strokes_r128.npz")
+    R, patches = _stroke_session(g)
+    m, size = int(g["crop_margin"]), int(g["size"])
+    eng["G"].set_conv_mode(mode)
+    try:
+        helper = painting.PaintingHelper(eng["ops"])
+        helper.make_new_canvas(size, size, feature_blending=2)
+        result = np.zeros((size, size, 4), np.uint8)
+        errs = {}
+        for i in range(20):
+            x, y = g["xy"][i].tolist()
+            style = int(g["styles"][i])
+            opts = painting.GanBrushOptions()
+            opts.set_style(torch.from_numpy(np.random.RandomState(style).randn(1, eng["cfg"].z_dim)), style)
+            opts.set_position(x, y)
+            res, _, meta = helper.render_stroke(patches[i], None, opts, meta={"x": x, "y": y, "crop_margin": m})
+            assert (meta["x"], meta["y"]) == tuple(g["placed_xy"][i].tolist())
+            result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+            assert np.abs(res.astype(np.int64).sum(axis=(0, 1)) - g["tile_sums"][i]).max() <= res.shape[0] * res.shape[1] * 0.02, i
+            if i + 1 in (5, 10, 20):
+                errs[i + 1] = float(np.abs(helper.features[0, ::8, ::4, ::4].cpu().numpy() - g[f"feature_canvas_sub_{i + 1}"]).max())
+                assert float(helper.mask.sum()) == float(g[f"feature_canvas_mask_sum_{i + 1}"])
+        d = np.abs(result.astype(np.int32) - g["canvas"].astype(np.int32))
+        print(f"[strokes {mode}] feature-canvas error after 5/10/20 strokes {errs}, canvas bytes differing {(d > 0).mean():.2e} (max {d.max()})")
+        tol = {"f32": 2e-5, "h3": 1e-4, "f8": 2e-3}[mode] * max(1.0, float(g["feature_canvas_maxabs"]) / 4)
+        assert max(errs.values()) <= tol, (mode, errs)
+        assert errs[20] <= 2 * max(errs[5], tol / 4), (mode, errs)          # no drift with the number of strokes
+        assert d.max() <= 1 and (d > 0).mean() <= (5e-3 if mode == "f8" else 1e-3), (mode, d.max(), (d > 0).mean())
+        assert np.abs(res.astype(np.int32) - g["last_tile"].astype(np.int32)).max() <= 1
+    finally:
+        eng["G"].set_conv_mode("h3")
+
+
 @pytest.mark.parametrize("level", [0, 2])
 def test_render_stroke_graph_replay_equals_eager(eng, level):
     """render_stroke replays hipGraph-captured generator passes (TileOps.graph_single); the same stroke sequence with the

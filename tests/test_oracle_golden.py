@@ -204,6 +204,24 @@ def test_oracle_high_dynamic_range_fixture():
     assert np.array_equal(rng[:, 0] >= 255.99, g["layer_range"][:, 1] >= 255.99)
 
 
+def test_oracle_trained_like_fixture():
+    """The oracle against the reference on trained-like weight statistics (log-normal channel scales, dominant styles, strong
+    noise: weights.trained_like_state_dict) -- the fixture the f8 margin is measured on."""
+    g = load_golden("gen_trained_r128.npz")
+    cfg = cfgmod.style1_config(128)
+    sd = wmod.trained_like_state_dict(cfg, seed=int(g["weights_seed"]))
+    geom = synthetic.geom_features(cfg, 3, seed=int(g["geom_seed"]))
+    taps = {}
+    img, dbg = orc.OracleGenerator(cfg, sd)(g["z"], None, geom, positions=g["positions"], return_debug_data=True,
+                                            return_features=[64], taps=taps)
+    close(dbg["uvs"], g["uvs"], 5e-5)
+    close(img, g["img"], 5e-5)
+    close(dbg["features64"].numpy()[:, ::4], g["features64.c4"], 2e-4)
+    close(taps["torgb.logits"].numpy()[..., ::2, ::2], g["logits.sub"], 1e-3)
+    # heavy-tailed: the largest activation is >= 8x a layer's rms, and the logits leave the softmax's linear range
+    assert (g["layer_range"][:, 1] / g["layer_range"][:, 0]).max() >= 8 and g["logits.range"][1] > 20
+
+
 def test_oracle_baseline_batch_rows():
     """First 4 samples of the BASELINE batch (R=256, bench.py's rank-0 inputs) against the reference's rows / checksums."""
     g = load_golden("gen_b32_r256.npz")

@@ -160,7 +160,7 @@ def test_encoder_state_table_and_errors(eng):
         encmod.HipGeometryEncoder(sd, device="cpu")
     with pytest.raises(RuntimeError):
         encmod.HipGeometryEncoder(sd, preproc_type="bogus", device="cpu")
-    assert encmod.HipGeometryEncoder.supports(256) and encmod.HipGeometryEncoder.supports(128) and not encmod.HipGeometryEncoder.supports(96)
+    assert all(encmod.HipGeometryEncoder.supports(r) for r in (32, 64, 128, 256, 512)) and not any(encmod.HipGeometryEncoder.supports(r) for r in (16, 48, 96, 192))
 
 
 def test_tile_ops_needs_gpu(eng):
@@ -237,6 +237,37 @@ def test_user_colors_and_full_mode(eng):
     ref, _ = P.render_stroke((255 - padded[y:y + 128, x:x + 128])[..., None], z=eng["z"], x=x, y=y, position=(y, x),
                              user_colors=opts.user_colors())
     _canvas_close(out[y:y + 128, x:x + 128], ref)
+
+
+@pytest.mark.parametrize("res", [64, 32])
+def test_oracle_encoder_small_patch_sizes(res):
+    """The encoder restatement against the REFERENCE encoder at patch sizes 64 and 32 (tests/golden/encoder_small.npz)."""
+    g = load_golden("encoder_small.npz")
+    f = po.encoder_encode(encmod.random_encoder_state_dict(int(g["encoder_seed"])), torch.from_numpy(g[f"enc_in_r{res}"]))
+    np.testing.assert_allclose(f[0].numpy(), g[f"enc_f0_r{res}"], atol=2e-6)
+    np.testing.assert_allclose(f[1].numpy(), g[f"enc_f1_r{res}"], atol=2e-6)
+
+
+def test_oracle_twenty_stroke_session(eng):
+    """The painting oracle against the REFERENCE's 20-stroke interactive session (three alternating styles, one canvas,
+    feature blending 2; tests/golden/make_golden_engine.py --strokes): final canvas and the feature canvas after 5 / 10 / 20
+    strokes.  Pins the oracle for state carried across strokes with changing styles."""
+    g = load_golden("engine_strokes_r128.npz")
+    R = int(g["resolution"])
+    patches = (np.unpackbits(g["patches"])[:20 * R * R].reshape(20, R, R, 1) * 255).astype(np.uint8)
+    m, size = int(g["crop_margin"]), int(g["size"])
+    P = po.OraclePainter(no.OracleGenerator(eng["cfg"], eng["sd"]), eng["esd"])
+    P.make_new_canvas(size, size, feature_blending=2)
+    result = np.zeros((size, size, 4), np.uint8)
+    for i in range(20):
+        x, y = g["xy"][i].tolist()
+        z = np.random.RandomState(int(g["styles"][i])).randn(1, eng["cfg"].z_dim)
+        res, meta = P.render_stroke(patches[i], z=z, x=x, y=y, crop_margin=m, position=(y, x))
+        result[meta["y"]:meta["y"] + res.shape[0], meta["x"]:meta["x"] + res.shape[1]] = res
+        if i + 1 in (5, 10, 20):
+            np.testing.assert_allclose(P.features[0, ::8, ::4, ::4].numpy(), g[f"feature_canvas_sub_{i + 1}"], atol=2e-5)
+            assert float(P.mask.sum()) == float(g[f"feature_canvas_mask_sum_{i + 1}"])
+    _canvas_close(result, g["canvas"], max_frac=5e-4)
 
 
 # ---------------------------------------------------------------- world size 2 (gloo)
