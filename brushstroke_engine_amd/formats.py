@@ -66,20 +66,18 @@ def decode_render_request_metadata(bytes_msg: bytes, offset: int = 0):
 # brush libraries (forger/ui/library.py)
 # ------------------------------------------------------------------------------------------------
 def read_zs(saved_file: str) -> Tuple[List[int], int]:
-    """Seed file: one style per line, first token the integer seed (lines starting with '#' are comments)."""
-    zs, zdim = [], 0
+    """Seed-library file (``forger/ui/library.py`` format): one style per line, the first whitespace-separated token is the
+    integer seed, any further tokens are the stored latent; ``#`` starts a comment line.  Returns (seeds in file order,
+    number of latent values on the last parsed line).  A missing file is an empty library; a line whose first token is not
+    an integer is skipped (the reference logs it and goes on)."""
     if not os.path.isfile(saved_file):
-        return zs, zdim
+        return [], 0
+    records = []
     with open(saved_file) as f:
-        for line in f:
-            line = line.strip()
-            if line and line[0] != "#":
-                try:
-                    zs.append(int(line.split()[0]))
-                    zdim = len(line.split()) - 1
-                except ValueError:
-                    pass                                        # the reference logs and skips unparsable lines
-    return zs, zdim
+        for tokens in (ln.split() for ln in f if ln.strip() and not ln.lstrip().startswith("#")):
+            if re.fullmatch(r"[+-]?\d+", tokens[0]):
+                records.append((int(tokens[0]), len(tokens) - 1))
+    return [seed for seed, _ in records], (records[-1][1] if records else 0)
 
 
 def _interp_style_id(style_id1, style_id2, alpha) -> str:
