@@ -217,6 +217,85 @@ def test_ddp_gradients_equal_full_batch(tmp_path):
         assert float(np.abs(got[k] - want[k]).max()) <= 1e-4 * scale + 1e-9, k
 
 
+def test_config5_full_size_iteration():
+    """BASELINE config 5 AT ITS SIZE: one full iteration of the StyleGAN2-ADA schedule at R=256, style1 channel widths, batch 8
+    -- Gmain + Greg (path length), Dmain + Dreg (R1), Ggeom, ADA 'bgc' pipe in front of D, random noise and style mixing,
+    Adam steps -- is finite everywhere, moves every trained parameter, and a second iteration still is."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.augment import AugmentPipe
+    from brushstroke_engine_amd.training import TrainableGenerator, TrainableDiscriminator, GanLoss, random_discriminator_state_dict
+    dev, res, n = torch.device("cuda:0"), 256, 8
+    torch.manual_seed(0)
+    cfg = cfgmod.style1_config(res)
+    G = TrainableGenerator(cfg, wmod.random_state_dict(cfg, 0), dev)
+    D = TrainableDiscriminator(random_discriminator_state_dict(res, 3, channel_base=16384, channel_max=128), res, 3,
+                               channel_base=16384, channel_max=128, conv_clamp=256, device=dev)
+    pipe = AugmentPipe(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1,
+                       saturation=1).to(dev)
+    pipe.p.fill_(0.3)
+    loss = GanLoss(G, D, augment_pipe=pipe, geom_phase_losses="1.0*iou_inv(uvs)", geom_warmstart_losses="1.0*iou_inv(uvs)+1.0*iou(u)")
+    optG = torch.optim.Adam(G.parameters(), lr=2e-3, betas=(0.0, 0.99))
+    optD = torch.optim.Adam(D.parameters(), lr=2e-3, betas=(0.0, 0.99))
+    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, n, 0)]
+    real = torch.tanh(torch.nn.functional.interpolate(torch.randn(n, 3, 8, 8, device=dev), size=res, mode="bilinear"))
+    real_geom = (torch.rand(n, 1, res, res, device=dev) > 0.08).float()
+    before = {k: p.detach().clone() for k, p in list(G.named_parameters()) + list(D.named_parameters())}
+    finite = lambda m: all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    for it in range(2):
+        z = torch.randn(n, cfg.z_dim, device=dev)
+        stats = {}
+        optG.zero_grad(set_to_none=True)
+        stats.update(loss.accumulate_gradients("Gmain", real, geom, z))
+        if it == 0:
+            stats.update(loss.accumulate_gradients("Greg", real, geom, z, gain=4))
+        assert finite(G)
+        optG.step()
+        optD.zero_grad(set_to_none=True)
+        stats.update(loss.accumulate_gradients("Dmain", real, geom, z))
+        if it == 0:
+            stats.update(loss.accumulate_gradients("Dreg", real, geom, z, gain=16))
+        assert finite(D)
+        optD.step()
+        if it == 0:
+            optG.zero_grad(set_to_none=True)
+            stats.update(loss.accumulate_gradients("Ggeom", real, geom, z, real_geom=real_geom))
+            assert finite(G)
+            optG.step()
+        assert stats and all(np.isfinite(v) for v in stats.values()), stats
+        if it == 0:
+            assert {"Loss/G/loss", "Loss/pl_penalty", "Loss/r1_penalty"} <= set(stats), sorted(stats)
+    moved = [k for k, p in list(G.named_parameters()) + list(D.named_parameters()) if p.requires_grad and not torch.equal(p, before[k])]
+    assert len(moved) >= 0.9 * sum(1 for _, p in list(G.named_parameters()) + list(D.named_parameters()) if p.requires_grad)
+    assert all(bool(torch.isfinite(p).all()) for p in list(G.parameters()) + list(D.parameters()))
+
+
+def test_config5_full_size_two_ranks_equal_full_batch(tmp_path):
+    """Config 5's data parallelism at its size: two ranks (4 + 4 samples at R=256, both on cuda:0, gloo) run Gmain and Dmain and
+    all-reduce the flattened gradients (GanLoss.all_reduce_gradients); the result equals the single-process gradients of
+    the whole batch of 8."""
+    import os, socket, subprocess, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _train_worker as tw
+    dev = torch.device("cuda:0")
+    G, D, loss, z, geom, real = tw.setup(dev)
+    wantG, wantD = tw.grads(loss, G, D, z, geom, real, dev, 0, z.shape[0])
+    assert np.isfinite(wantG).all() and np.isfinite(wantD).all() and np.abs(wantG).max() > 0 and np.abs(wantD).max() > 0
+    del G, D, loss
+    torch.cuda.empty_cache()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = str(tmp_path / "grads.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_train_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", out], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    for name, want in (("G", wantG), ("D", wantD)):
+        assert got[name].shape == want.shape
+        assert float(np.abs(got[name] - want).max()) <= 2e-3 * float(np.abs(want).max()), name
+
+
 def test_forger_geometry_and_stitch_phases():
     """Ggeom / Ggeom-warm / Gstitch of ForgerLoss (loss_modified.py:108-138, 181-203) on the differentiable HIP generator
     and discriminator: the geometry phase's loss equals the loss items evaluated on the CPU oracle's uvs, its gradients
