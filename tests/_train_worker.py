@@ -1,4 +1,4 @@
-"""Rank program of tests/test_hip_training.py::test_config5_full_size_two_ranks_equal_full_batch (one process per rank, both on
+"""Rank program of tests/test_hip_training.py::test_config5_full_size_two_ranks_equal_accumulated_shards (one process per rank, both on
 cuda:0, gloo): BASELINE config 5's shapes -- R=256, style1 channel widths, batch 8 over two ranks of 4 -- Gmain and Dmain
 gradients through GanLoss with the flattened-gradient all-reduce; rank 0 writes the reduced gradients."""
 import os

@@ -316,24 +316,25 @@ def make_hdr():
 
 def make_trained():
     """Trained-like statistics (weights.trained_like_state_dict: log-normal channel scales, dominant styles, strong noise),
-    R=128, N=3 with three different latents and positions: the reference's fp32 evaluation -- full uvs / img, the features at
-    R/2 (what the FeatureCanvas carries from stroke to stroke) on every 4th channel, logits subsampled, per-layer ranges."""
+    R=128, N=6 (the batch from which the 64 x 64 layers take the large-tile kernels, i.e. run in the mode's own arithmetic)
+    with different latents and positions: the reference's fp32 evaluation -- full uvs / img, the features at R/2 (what the
+    FeatureCanvas carries from stroke to stroke) on every 8th channel, logits subsampled, per-layer ranges."""
     res = 128
     cfg = cfgmod.style1_config(res)
     sd = wmod.trained_like_state_dict(cfg, seed=0)
     G = build_reference(cfg, sd)
-    n = 3
+    n = 6
     z = synthetic.batch_z(cfg, n, first_seed=1234)
     geom = synthetic.geom_features(cfg, n, seed=3)
-    pos = np.array([[0, 0], [37, 211], [4095, 17]], np.int64)
+    pos = np.array([[0, 0], [37, 211], [4095, 17], [5, 5], [100, 3], [77, 900]], np.int64)
     out = {"z": z, "positions": pos, "weights_seed": np.int64(0), "geom_seed": np.int64(3)}
     half = res // 2
     with Capture(G, cfg) as cap:
         (img, dbg), taps = run_case(G, cfg, cap, z=z, geom=geom, positions=pos, return_debug_data=True, return_features=[half])
-    out["uvs"], out["img"], out["colors"] = np32(dbg["uvs"]), np32(img), np32(dbg["colors"])
+    out["uvs"], out["img.sub"], out["colors"] = np32(dbg["uvs"]), sub(np32(img), 2), np32(dbg["colors"])
     out["logits.sub"] = sub(np32(taps["torgb.logits"]), 2)
     f = np32(dbg[f"features{half}"])
-    out[f"features{half}.c4"] = f[:, ::4]
+    out[f"features{half}.c16"] = f[:, ::16]
     out[f"features{half}.maxabs"] = np.float64(np.abs(f).max())
     rng = []
     for l in cfg.layers:

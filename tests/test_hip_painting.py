@@ -243,18 +243,25 @@ def _stroke_session(g):
     return R, patches.astype(np.uint8)
 
 
-@pytest.mark.parametrize("mode", ["f8", "h3", "f32"])
+@pytest.mark.parametrize("mode", ["f8-forced", "f8", "h3", "f32"])
 def test_twenty_stroke_session_drift(eng, mode):
     """An interactive session painted by the REFERENCE engine (tests/golden/make_golden_engine.py --strokes): 20 heavily
     overlapping strokes in three alternating styles on one canvas, feature blending level 2, the FeatureCanvas carried
     from stroke to stroke.  An arithmetic error in the features at R/2 feeds back through the canvas into every later
     stroke, so this bounds the ACCUMULATED error of each conv mode (f8 in particular: it is the library default):
     final canvas <= 1 LSB on few bytes, feature canvas after 5 / 10 / 20 strokes within the mode's per-stroke tolerance --
-    no growth with the number of strokes."""
+    no growth with the number of strokes.  A single tile runs its <= 64 x 64 layers on the small-tile kernel, whose products
+    are hi/lo f16 in every mode; "f8-forced" lowers the generator's pixel threshold so that every layer from 32 x 32 up runs
+    the large-tile kernels with fp8 correction operands, as the tiles of a batched canvas do -- the features written to the
+    canvas then really carry the f8 arithmetic."""
     g = load_golden("engine_strokes_r128.npz")
     R, patches = _stroke_session(g)
     m, size = int(g["crop_margin"]), int(g["size"])
+    forced, mode = mode == "f8-forced", mode.split("-")[0]
     eng["G"].set_conv_mode(mode)
+    keep_px = eng["G"].synthesis.h3_min_pixels
+    if forced:
+        eng["G"].synthesis.h3_min_pixels = 1
     try:
         helper = painting.PaintingHelper(eng["ops"])
         helper.make_new_canvas(size, size, feature_blending=2)
@@ -275,12 +282,16 @@ def test_twenty_stroke_session_drift(eng, mode):
                 assert float(helper.mask.sum()) == float(g[f"feature_canvas_mask_sum_{i + 1}"])
         d = np.abs(result.astype(np.int32) - g["canvas"].astype(np.int32))
         print(f"[strokes {mode}] feature-canvas error after 5/10/20 strokes {errs}, canvas bytes differing {(d > 0).mean():.2e} (max {d.max()})")
+        if forced:
+            assert "modconv3x3_up1_h3_kernel<2>" in set(eng["G"].synthesis.layer_kernels.values())
+            assert errs[20] > 5e-5                      # (the fp8 corrections are in the features: not the h3-grade 2e-5)
         tol = {"f32": 2e-5, "h3": 1e-4, "f8": 2e-3}[mode] * max(1.0, float(g["feature_canvas_maxabs"]) / 4)
         assert max(errs.values()) <= tol, (mode, errs)
         assert errs[20] <= 2 * max(errs[5], tol / 4), (mode, errs)          # no drift with the number of strokes
         assert d.max() <= 1 and (d > 0).mean() <= (5e-3 if mode == "f8" else 1e-3), (mode, d.max(), (d > 0).mean())
         assert np.abs(res.astype(np.int32) - g["last_tile"].astype(np.int32)).max() <= 1
     finally:
+        eng["G"].synthesis.h3_min_pixels = keep_px
         eng["G"].set_conv_mode("h3")
 
 

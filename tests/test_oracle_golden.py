@@ -210,13 +210,13 @@ def test_oracle_trained_like_fixture():
     g = load_golden("gen_trained_r128.npz")
     cfg = cfgmod.style1_config(128)
     sd = wmod.trained_like_state_dict(cfg, seed=int(g["weights_seed"]))
-    geom = synthetic.geom_features(cfg, 3, seed=int(g["geom_seed"]))
+    geom = synthetic.geom_features(cfg, 6, seed=int(g["geom_seed"]))
     taps = {}
     img, dbg = orc.OracleGenerator(cfg, sd)(g["z"], None, geom, positions=g["positions"], return_debug_data=True,
                                             return_features=[64], taps=taps)
     close(dbg["uvs"], g["uvs"], 5e-5)
-    close(img, g["img"], 5e-5)
-    close(dbg["features64"].numpy()[:, ::4], g["features64.c4"], 2e-4)
+    close(img.numpy()[..., ::2, ::2], g["img.sub"], 5e-5)
+    close(dbg["features64"].numpy()[:, ::16], g["features64.c16"], 2e-4)
     close(taps["torgb.logits"].numpy()[..., ::2, ::2], g["logits.sub"], 1e-3)
     # heavy-tailed: the largest activation is >= 8x a layer's rms, and the logits leave the softmax's linear range
     assert (g["layer_range"][:, 1] / g["layer_range"][:, 0]).max() >= 8 and g["logits.range"][1] > 20
