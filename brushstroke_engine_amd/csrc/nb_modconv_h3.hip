@@ -1176,6 +1176,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
     // one chunk: reads from `st`; DMA = issue the pieces of chunk cn into `sn` between the MFMA groups
+    // (Measured, round 3 -- an ablation build without the in-loop pieces, and one that also drops the barrier: the pieces cost
+    //  ~480 of a chunk's ~3 550 cycles wherever they sit in the chunk, also with the two waves of a SIMD issuing theirs at
+    //  different points; the barrier costs nothing; the loop without DMA still needs ~3 050 cycles for 2 432 cycles of MFMA.
+    //  A variant with masked out-of-image lanes and pre-zeroed halo slots saved registers but is WRONG: a piece whose lanes
+    //  are all masked is skipped, and the counted vmcnt waits below rely on every wave issuing exactly NPC pieces per chunk.)
     auto chunk = [&](auto dma_, const h8* st, int cn, h8* sn) {
         constexpr bool DMA = decltype(dma_)::value;
         __builtin_amdgcn_sched_barrier(0);

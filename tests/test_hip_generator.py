@@ -15,7 +15,8 @@ ACT_TOL = 5e-4
 # per arithmetic mode (Generator(conv_mode=...)): pixels / uvs, activations and logits.  north_star budget: 1e-3 on pixels.
 MODES = ("h3", "f8", "f32")
 PIX = {"f32": 1e-4, "h3": 1e-4, "f8": 3e-4}
-ACT = {"f32": 5e-4, "h3": 5e-4, "f8": 4e-3}
+# (observed on MI355X, round 3: features 4.5e-5 / logits 1.6e-4 in f8, 6e-6 / 1.8e-5 in h3 and f32: asserted at ~3x)
+ACT = {"f32": 5e-5, "h3": 5e-5, "f8": 5e-4}
 
 
 @pytest.fixture(scope="module")
@@ -68,6 +69,8 @@ def test_tiny_golden_all_cases(dev, mode):
     img, dbg = G(z, None, geom, positions=pos, return_debug_data=True, return_features=[16], noise_mode="const",
                  force_fp32=True, _extra_outputs=extra)
     assert err(dbg["ws"], g["A_ws"]) <= 1e-5
+    print(f"[tiny {mode}] features16 {err(dbg['features16'], g['A_features16']):.2e} logits {err(extra['out']['logits'], g['A_torgb.logits']):.2e} "
+          f"uvs {err(dbg['uvs'], g['A_uvs']):.2e}")
     assert err(dbg["features16_preblend"], g["A_features16_preblend"]) <= ACT_TOL
     assert err(dbg["features16"], g["A_features16"]) <= ACT_TOL
     assert err(extra["out"]["logits"], g["A_torgb.logits"]) <= ACT_TOL
@@ -119,7 +122,9 @@ def test_style1_shapes_golden(dev, res, mode):
         full = full.detach().cpu().numpy()
         s = 1 if full.shape[-1] <= 16 else step
         got = full[..., ::s, ::s] if full.shape[1] <= 4 else full[:, ::8, ::s, ::s]
-        assert err(got, g[f"{name}.sub"]) <= tol, name
+        e_ = err(got, g[f"{name}.sub"])
+        print(f"[style1 R={res} {mode}] {name}: {e_:.2e} (tolerance {tol:.1e})")
+        assert e_ <= tol, name
         st = g[f"{name}.stats"]
         f64 = full.astype(np.float64)
         assert abs(f64.sum() - st[0]) <= 1e-4 * max(1.0, np.sqrt(st[1] * f64.size)), name
@@ -128,7 +133,7 @@ def test_style1_shapes_golden(dev, res, mode):
     assert err(dbg["ws"], g["ws"]) <= 1e-5
     assert err(dbg["colors"], g["colors"]) <= 1e-5
     chk(f"features{half}", dbg[f"features{half}"], ACT_TOL)
-    chk("logits", extra["out"]["logits"], max(1e-3, ACT_TOL))
+    chk("logits", extra["out"]["logits"], 2 * ACT_TOL)
     chk("uvs", dbg["uvs"], PIX_TOL)
     chk("img", img, PIX_TOL)
     assert err(dbg["uvs"][:, :, res // 3, :], g["uvs.row"]) <= PIX_TOL
