@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lock = threading.Lock()
 _lib = None
@@ -112,6 +112,15 @@ class NbTilePiece(C.Structure):
     """``struct NbTilePiece`` of include/neube_hip.h."""
     _fields_ = [("data", C.c_uint64), ("cstride", C.c_int32), ("rstride", C.c_int32), ("cy", C.c_int32), ("cx", C.c_int32),
                 ("h", C.c_int32), ("w", C.c_int32), ("ly0", C.c_int32), ("lx0", C.c_int32)]
+
+
+class NbNoiseSrc(C.Structure):
+    """``struct NbNoiseSrc`` of include/neube_hip.h (noise computed inside the split-f16 convolutions)."""
+    _fields_ = [("noise_const_t", vp), ("noise_lin", vp), ("noise_strength", vp), ("norm_pos", vp), ("positions", vp),
+                ("res", C.c_int), ("img_resolution", C.c_int)]
+
+
+NB_NOISE_IN_KERNEL = -1
 
 
 class NbTorgbArgs(C.Structure):

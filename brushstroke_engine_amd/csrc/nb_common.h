@@ -5,7 +5,7 @@
 #include <cstdarg>
 #include "../../include/neube_hip.h"
 
-#define NB_ABI_VERSION 8
+#define NB_ABI_VERSION 9
 
 void nb_set_error(const char* fmt, ...);
 
@@ -27,3 +27,42 @@ void nb_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int nb_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- position-shifted constant noise (networks.py:371-382), the per-pixel arithmetic shared by nb_noise_f32's kernels
+//      (nb_ops.hip) and the convolutions that compute their noise themselves (NbNoiseSrc) ----
+#ifdef __HIPCC__
+struct NbNoiseSrcDev {
+    const float* const_t; const float* lin; const float* strength; const float* norm_pos; const long long* positions;
+    int res, img_res;
+};
+// normalised position of sample n: (positions % R) / (R - 1), python-style modulo, IEEE float32 division
+__device__ __forceinline__ void nb_noise_np(const NbNoiseSrcDev& s, int n, float& np0, float& np1) {
+    if (s.positions) {
+        const long long R = s.img_res;
+        const long long p0 = ((s.positions[2 * n + 0] % R) + R) % R, p1 = ((s.positions[2 * n + 1] % R) + R) % R;
+        np0 = (float)p0 / (float)(s.img_res - 1);
+        np1 = (float)p1 / (float)(s.img_res - 1);
+    } else {
+        np0 = s.norm_pos[2 * n + 0];
+        np1 = s.norm_pos[2 * n + 1];
+    }
+}
+// bilinear parameters of one axis: output index idx -> first source index c0 and the two weights
+__device__ __forceinline__ void nb_noise_axis(const NbNoiseSrcDev& s, int idx, float np, int& c0, float& w0, float& w1) {
+    const float g = fmodf(s.lin[idx] + np, 1.f) * 2.f - 1.f;
+    const float cc = ((g + 1.f) / 2.f) * (float)(s.res - 1);
+    const float f0 = floorf(cc);
+    c0 = (int)f0; w1 = cc - f0; w0 = (f0 + 1.f) - cc;
+}
+// noise of output pixel (row i, column j): the SOURCE COLUMN parameters (x0, wx0, wx1) come from row i, the source row
+// parameters (y0, wy0, wy1) from column j (the reference's grid transposes); const_t[x * res + y] = noise_const[y, x]
+__device__ __forceinline__ float nb_noise_value(const NbNoiseSrcDev& s, float strength, int x0, float wx0, float wx1, int y0, float wy0, float wy1) {
+    const int r = s.res;
+    auto tap = [&](int yi, int xi) -> float { return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? s.const_t[xi * r + yi] : 0.f; };
+    float v = tap(y0, x0) * (wx0 * wy0);
+    v += tap(y0, x0 + 1) * (wx1 * wy0);
+    v += tap(y0 + 1, x0) * (wx0 * wy1);
+    v += tap(y0 + 1, x0 + 1) * (wx1 * wy1);
+    return v * strength;
+}
+#endif

@@ -35,11 +35,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define NB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define NB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// `noise` / `noise_stride_n` of the entry points -> kernel fields: a [n or 1][H][W] tensor, or (NB_NOISE_IN_KERNEL) a host
+// NbNoiseSrc describing how the kernel computes the noise itself
+static int nb_noise_src_setup(const float* noise, int64_t stride_n, int ho, int wo, const float** k_noise, long long* k_stride, NbNoiseSrcDev* k_src) {
+    *k_src = NbNoiseSrcDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (stride_n != NB_NOISE_IN_KERNEL) { *k_noise = noise; *k_stride = stride_n; return NB_OK; }
+    const NbNoiseSrc* s = reinterpret_cast<const NbNoiseSrc*>(noise);
+    if (!s || !s->noise_const_t || !s->noise_lin || !s->noise_strength || ((s->norm_pos != nullptr) == (s->positions != nullptr))) return NB_EINVAL;
+    if (s->res != ho || s->res != wo || (s->positions && s->img_resolution < 2)) return NB_EINVAL;
+    *k_src = NbNoiseSrcDev{s->noise_const_t, s->noise_lin, s->noise_strength, s->norm_pos, (const long long*)s->positions, s->res, s->img_resolution};
+    *k_noise = nullptr; *k_stride = 0;
+    return NB_OK;
+}
+
 struct H3Params {
     const _Float16* x;      // H2 [n][c8][2][H][W][8], already multiplied by this layer's styles
     const _Float16* wts;    // [nchunks][3][3][2][2][co_ld][8]
     const float* dcoefs;    // [n][c_out]
     const float* noise;     // [n or 1][H][W] or null
+    NbNoiseSrcDev nsrc;     // nsrc.const_t != null: the noise is computed here (NbNoiseSrc), `noise` is null
     const float* bias;      // [c_out]
     float* y;               // fp32 NCHW [n][c_out][H][W] or null
     const float* zeros;
@@ -305,6 +319,21 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
         nzr[nb] = p.noise ? p.noise[(size_t)n * p.noise_stride_n + (size_t)(y0 + wn * NBW + nb) * W + x0 + l31] : 0.f;
+    if (p.nsrc.const_t) {
+        // the lane's pixels (row y0 + wn NBW + nb, column x0 + l31): column parameters once, row parameters per row
+        float np0, np1, wy0, wy1;
+        int sy0;
+        nb_noise_np(p.nsrc, n, np0, np1);
+        nb_noise_axis(p.nsrc, x0 + l31, np1, sy0, wy0, wy1);
+        const float strength = p.nsrc.strength[0];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            float wx0, wx1;
+            int sx0;
+            nb_noise_axis(p.nsrc, y0 + wn * NBW + nb, np0, sx0, wx0, wx1);
+            nzr[nb] = nb_noise_value(p.nsrc, strength, sx0, wx0, wx1, sy0, wy0, wy1);
+        }
+    }
 
     // ---- DMA descriptors of this wave's activation pieces ----
     int xsp[NXPW], xpl[NXPW], xdst[NXPW];
@@ -728,6 +757,21 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
         nzr[nb] = p.noise ? p.noise[(size_t)n * p.noise_stride_n + (size_t)(y0 + wn * NBW + nb) * W + x0 + l31] : 0.f;
+    if (p.nsrc.const_t) {
+        // the lane's pixels (row y0 + wn NBW + nb, column x0 + l31): column parameters once, row parameters per row
+        float np0, np1, wy0, wy1;
+        int sy0;
+        nb_noise_np(p.nsrc, n, np0, np1);
+        nb_noise_axis(p.nsrc, x0 + l31, np1, sy0, wy0, wy1);
+        const float strength = p.nsrc.strength[0];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            float wx0, wx1;
+            int sx0;
+            nb_noise_axis(p.nsrc, y0 + wn * NBW + nb, np0, sx0, wx0, wx1);
+            nzr[nb] = nb_noise_value(p.nsrc, strength, sx0, wx0, wx1, sy0, wy0, wy1);
+        }
+    }
 
     int xcol[NXPW], xrow[NXPW], xpl[NXPW], xdst[NXPW];
 #pragma unroll
@@ -914,6 +958,8 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     p.zeros = nb_zero_page_ptr();
     NB_REQUIRE(p.zeros, "modconv3x3_up1_h3: could not allocate the zero page");
     p.noise_stride_n = noise_stride_n;
+    NB_REQUIRE(nb_noise_src_setup(noise, noise_stride_n, h, w, &p.noise, &p.noise_stride_n, &p.nsrc) == NB_OK, "modconv3x3_up1_h3: bad NbNoiseSrc (needs the "
+               "transposed constant, the grid row, the strength, exactly one of norm_pos / positions, and res = the %dx%d output)", h, w);
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
     { static const int v = getenv("NB_DEBUG") ? atoi(getenv("NB_DEBUG")) : 0; p.dbg = v; }            // (read once per process)
     { static const int v = getenv("NB_STAGGER") ? atoi(getenv("NB_STAGGER")) : 0; p.stagger_ticks = v; }
@@ -1016,6 +1062,7 @@ struct H3Up2Params {
     const _Float16* x;      // H2 [n][c8][2][H][W][8]
     const _Float16* wts;    // [nchunks][9][2][2][co_ld][8]
     const float* dcoefs; const float* noise; const float* bias; float* y; const float* zeros;
+    NbNoiseSrcDev nsrc;     // see H3Params
     long long noise_stride_n;
     int c8, nchunks, c_out, co_ld, h, w;
     int tiles_x, tiles_y, slices, dbg, stagger_ticks;
@@ -1080,7 +1127,16 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
         const int r = e / (2 * TQW), c = e - r * (2 * TQW);
         const int oy = 2 * I0 + r, ox = 2 * J0 + c;
-        s_noise[e] = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] * p.gain : 0.f;
+        float v = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
+        if (p.nsrc.const_t && oy < 2 * H) {
+            float np0, np1, wx0, wx1, wy0, wy1;
+            int sx0, sy0;
+            nb_noise_np(p.nsrc, n, np0, np1);
+            nb_noise_axis(p.nsrc, oy, np0, sx0, wx0, wx1);
+            nb_noise_axis(p.nsrc, ox, np1, sy0, wy0, wy1);
+            v = nb_noise_value(p.nsrc, p.nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
+        }
+        s_noise[e] = v * p.gain;
     }
 
     // LDS-DMA descriptors of this wave's pieces.  Activation piece i: plane xpl (= cg_local*2 + hi/lo), 64 slots from
@@ -1526,6 +1582,8 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     p.zeros = nb_zero_page_ptr();
     NB_REQUIRE(p.zeros, "modconv3x3_up2_h3: could not allocate the zero page");
     p.noise_stride_n = noise_stride_n;
+    NB_REQUIRE(nb_noise_src_setup(noise, noise_stride_n, 2 * h, 2 * w, &p.noise, &p.noise_stride_n, &p.nsrc) == NB_OK, "modconv3x3_up2_h3: bad NbNoiseSrc (needs the "
+               "transposed constant, the grid row, the strength, exactly one of norm_pos / positions, and res = the %dx%d output)", 2 * h, 2 * w);
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
     { static const int v = getenv("NB_DEBUG") ? atoi(getenv("NB_DEBUG")) : 0; p.dbg = v; }            // (read once per process)
     { static const int v = getenv("NB_STAGGER") ? atoi(getenv("NB_STAGGER")) : 0; p.stagger_ticks = v; }

@@ -194,11 +194,24 @@ class _Plan:
         self.host_descs = descs
         self.pack_stream, self.pack_events = None, {}      # side stream for the early geometry packing of this slot
         self.n_layers = len(specs) + 1
+        self._noise_cut = {}
         self.table = self._upload(descs)
 
     def _upload(self, descs) -> torch.Tensor:
         raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
         return torch.from_numpy(raw).to(self.device)
+
+    def table_without_noise_from(self, first: int) -> torch.Tensor:
+        """The layer table with ``noise_const`` cleared for layers >= ``first`` (they compute their noise inside the
+        convolution, NbNoiseSrc): the fused styles + noise launch of small batches then skips their noise images."""
+        t = self._noise_cut.get(first)
+        if t is None:
+            descs = (_lib.NbLayerDesc * self.n_layers)()
+            ctypes.memmove(descs, self.host_descs, ctypes.sizeof(descs))
+            for i in range(first, self.n_layers - 1):
+                descs[i].noise_const = 0
+            t = self._noise_cut[first] = self._upload(descs)
+        return t
 
     def table_with_noise_overrides(self, syn, noise_buffers) -> torch.Tensor:
         """Reference noise_buffers (networks_modified.py:163-165): per-call replacement of noise_const."""
@@ -258,6 +271,7 @@ class SynthesisNetwork(torch.nn.Module):
         self.h2_handoff = True            # split-f16 layers write the next layer's H2 input directly (no pack pass)
         self.early_geom_pack = True       # geometry channels of such inputs are packed at the start, on a side stream
         self.fuse_torgb = True            # last conv1 + ToRGB + compositing in one launch (split-f16 path)
+        self.noise_in_kernel = True       # large split-f16 layers compute their (position-shifted) noise themselves
         self.layer_kernels: Dict[str, str] = {}
 
     # -- helpers --
@@ -284,7 +298,9 @@ class SynthesisNetwork(torch.nn.Module):
             layer = self.layer_module(s)
             wpk, wsq = ops.pack_conv_weight(layer.weight)
             self.packed[s.name] = {"wpk": wpk, "wsq": wsq,
-                                   "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous()}
+                                   "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous(),
+                                   # transposed copy for the convolutions that compute their noise themselves (NbNoiseSrc)
+                                   "noise_const_t": layer.noise_const.t().contiguous()}
             if self.conv_mode in ("h3", "f8") and self.cfg.conv_clamp is not None:
                 self.packed[s.name]["w_h3"] = ops.pack_conv_weight_h3(layer.weight)
                 if self.conv_mode == "f8" and s.in_channels % 16 == 0:
@@ -420,10 +436,20 @@ class SynthesisNetwork(torch.nn.Module):
                     npos = norm_noise_positions.to(device=device, dtype=torch.float32).contiguous()
                     _assert_shape(npos, [n, 2])
                     keep_alive.append(npos)
+            # first layer (in resolution order) from which every layer runs on the large split-f16 kernels: those compute their
+            # position-shifted noise in their own prologue.  Not with per-call noise buffers (their transposes do not exist).
+            inkernel_from = None
+            if (self.noise_in_kernel and noise_mode == "const" and table is plan.table and (npos is not None or ipos is not None)):
+                elig = [(self._h3_up2_eligible(sp) if sp.up == 2 else self._h3_eligible(sp)) for sp in cfg.layers]
+                k_ = len(elig)
+                while k_ > 0 and elig[k_ - 1]:
+                    k_ -= 1
+                inkernel_from = k_ if k_ < len(elig) else None
             if (self._styles_fast and noise_mode == "const" and table is plan.table and n <= 8
                     and (npos is not None or ipos is not None)):
                 # small batches: styles + per-sample noise in one launch (a launch costs more than either computes)
-                _lib.check(lib.nb_styles_noise_f32(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, _p(npos),
+                tbl = plan.table if inkernel_from is None else plan.table_without_noise_from(inkernel_from)
+                _lib.check(lib.nb_styles_noise_f32(_p(tbl), plan.n_layers, _p(ws), self.num_ws, self.w_dim, _p(npos),
                                                    _p(ipos), self.img_resolution, n, stream), "styles_noise")
             else:
                 styles_fn = lib.nb_styles_fast_f32 if self._styles_fast else lib.nb_styles_f32
@@ -433,6 +459,10 @@ class SynthesisNetwork(torch.nn.Module):
                     # needs no 256x256 noise images, the tail pass nothing but those); layers are ordered by resolution
                     lo_ = 0 if resume is None else sum(1 for sp in cfg.layers if sp.block_res <= resume[0])
                     hi_ = plan.n_layers if stop_after is None else sum(1 for sp in cfg.layers if sp.block_res <= stop_after)
+                    # layers on the large split-f16 kernels compute their shifted noise themselves (NbNoiseSrc): the noise
+                    # launch stops at the first of them (layers are ordered by resolution, eligibility grows with it)
+                    if inkernel_from is not None:
+                        hi_ = min(hi_, inkernel_from)
                     if hi_ > lo_:
                         _lib.check(lib.nb_noise_f32(table.data_ptr() + lo_ * ctypes.sizeof(_lib.NbLayerDesc), hi_ - lo_,
                                                     max(sp.block_res for sp in cfg.layers[lo_:hi_]), _p(npos), _p(ipos),
@@ -549,7 +579,12 @@ class SynthesisNetwork(torch.nn.Module):
                     if c1 + c2 != s.in_channels:
                         raise AssertionError(f"{name}: got {c1}+{c2} input channels, expected {s.in_channels}")
                     noise_ptr, nstride = None, 0
-                    if noise_mode == "const":
+                    if noise_mode == "const" and inkernel_from is not None and i >= inkernel_from:
+                        nsrc = _lib.NbNoiseSrc(_p(pk["noise_const_t"]), _p(pk["noise_lin"]), _p(layer.noise_strength), _p(npos), _p(ipos),
+                                               s.block_res, self.img_resolution)
+                        keep_alive.append(nsrc)
+                        noise_ptr, nstride = ctypes.addressof(nsrc), _lib.NB_NOISE_IN_KERNEL
+                    elif noise_mode == "const":
                         noise_ptr = plan.noise[i].data_ptr()
                         nstride = 0 if shared else s.block_res * s.block_res
                     elif noise_mode == "random":

@@ -274,6 +274,22 @@ int nb_modconv3x3_up1_h3_torgb(const void* x_h2, int c_in, const void* w_h3, con
                                int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
                                float alpha, float gain, float clamp, const struct NbTorgbArgs* t, void* stream);
 
+/* Constant noise computed INSIDE the split-f16 convolutions instead of being read from a [n, H, W] tensor that
+ * nb_noise_f32 wrote (networks.py:371-382; the position-shifted bilinear sample of a <= 256 x 256 constant is four
+ * L2-resident loads and a dozen FMAs per output pixel -- cheaper than writing and re-reading 22 MB per batch of 32).
+ * Pass noise_stride_n = NB_NOISE_IN_KERNEL and, as `noise`, a HOST pointer to this struct (copied at launch) to
+ * nb_modconv3x3_up1_h3_ex / nb_modconv3x3_up2_h3_ex.  Same expressions, same order as nb_noise_f32: bit-identical. */
+#define NB_NOISE_IN_KERNEL (-1)
+struct NbNoiseSrc {
+    const float* noise_const_t;   /* [res, res]: the layer's noise_const TRANSPOSED (the sampling grid transposes: SURVEY note C) */
+    const float* noise_lin;       /* [res]: noise_grid[0, :, 0, 0] */
+    const float* noise_strength;  /* [1] */
+    const float* norm_pos;        /* [n, 2] normalised positions, or NULL */
+    const int64_t* positions;     /* [n, 2] integer (y, x) positions (normalised in-kernel like nb_noise_f32), or NULL; exactly one */
+    int res;                      /* resolution of the layer's OUTPUT */
+    int img_resolution;           /* R of (positions % R) / (R - 1) */
+};
+
 /* General forms of the two split-f16 convolutions.  in_fmt / out_fmt: 0 = H2 (hi/lo f16), 1 = "f8" (hi f16 + fp8
  * correction operands, above); the weights must be packed for in_fmt (nb_pack_conv_weight_h3 or the f8 layout).
  * Exactly one destination: y_f32 (fp32 NCHW; out_fmt ignored), y_h2 (the consumer's input tensor [n, c_next, ...] in

@@ -293,6 +293,42 @@ def test_high_dynamic_range_fixture(dev, mode):
     assert e_ft <= {"f32": 2e-3, "h3": 2e-3, "f8": 0.25}[mode] and e_lg <= {"f32": 1e-3, "h3": 1e-3, "f8": 4e-3 * 10}[mode]
 
 
+@pytest.mark.parametrize("mode", ["h3", "f8"])
+@pytest.mark.parametrize("res,n", [(256, 32), (256, 1), (128, 5), (256, 3)])
+def test_noise_in_kernel_equals_noise_tensor(dev, mode, res, n):
+    """The large split-f16 layers compute their position-shifted noise in their own prologue (NbNoiseSrc: transposed
+    constant from L2, same expressions in the same order as nb_noise_f32) instead of reading the [n, res, res] images the
+    noise launch writes: bit-identical outputs, with integer positions (incl. wrap-around and negative ones) and with
+    pre-normalised positions."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic
+    cfg = cfgmod.style1_config(res)
+    G, _ = build(cfg, 4, dev, mode)
+    z = D(synthetic.batch_z(cfg, n, 21), dev)
+    geom = [D(x, dev) for x in synthetic.geom_features(cfg, n, seed=6)]
+    pos = synthetic.positions(cfg, n, seed=8)
+    pos[0] = [-3, res + 5]
+    pos[-1] = [4095, 17]
+    pos = D(pos, dev)
+    outs = {}
+    for inker in (True, False):
+        G.synthesis.noise_in_kernel = inker
+        img, dbg = G(z, None, geom, positions=pos, return_debug_data=True, return_features=[res // 2], noise_mode="const")
+        ws = dbg["ws"]
+        npos = (torch.rand(n, 2, device=dev) * 0.999).to(torch.float32)
+        img2 = G.synthesis(ws, geom, noise_mode="const", norm_noise_positions=npos)
+        outs[inker] = (img.clone(), dbg["uvs"].clone(), dbg[f"features{res // 2}"].clone(), img2.clone(), npos)
+    torch.manual_seed(0)
+    a, b = outs[True], outs[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # (the two runs drew different random normalised positions: compare each against a tensor-path run of ITS positions)
+    G.synthesis.noise_in_kernel = False
+    ref2 = G.synthesis(ws, geom, noise_mode="const", norm_noise_positions=a[4])
+    assert torch.equal(a[3], ref2)
+    G.synthesis.noise_in_kernel = True
+    kinds = set(G.synthesis.layer_kernels.values())
+    assert any("up2_h3" in k for k in kinds)                                   # (the in-kernel path was exercised)
+
+
 @pytest.mark.parametrize("mode", ["f32", "h3", "f8"])
 def test_trained_like_fixture(dev, mode):
     """Trained-like weight statistics (weights.trained_like_state_dict: log-normal per-channel scales, two dominant styles per
