@@ -206,7 +206,7 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
     B = args.batch
     # the generator runs a batch as `sub` sub-batches on separate HIP streams; with N>1 each part's RGBA tiles are
     # gathered from the part's own stream, so steps keep overlapping across the streams at any N
-    sub = G.sub_streams if B >= G.sub_stream_min_batch else 1
+    sub = G.sub_streams if (B >= G.sub_stream_min_batch and not args.pipeline) else 1
     gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if gather else None
     part_gatherers = []
     if gatherer is not None and sub > 1:
@@ -219,7 +219,24 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
             for g_ in part_gatherers:
                 g_.finish()
 
+    pipe = None
+    if args.pipeline:
+        from brushstroke_engine_amd.pipeline import TriadStepPipeline
+        pipe = TriadStepPipeline(G)
+        if not pipe._eligible(B):
+            pipe = None
+    schedule = ("steps software-pipelined over two HIP streams (pipeline.TriadStepPipeline): the head of step k+1 -- mapping, styles, "
+                "the <= 16x16 layers: 2 % of the FLOPs in latency-bound launches -- runs under the big convolutions of step k"
+                if pipe is not None else "steps enqueued back to back on one stream")
+
     def step():
+        if pipe is not None:
+            u8 = pipe.submit(z, geom, pos)
+            if gatherer is not None:
+                with torch.cuda.stream(pipe.tail_stream):
+                    gatherer.finish()
+                    gatherer.start(u8)
+            return
         # without a gather the step is enqueued without joining the generator's sub-batch streams, so consecutive
         # steps overlap across them (the timed region ends with a device-wide synchronize)
         res = G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False)
@@ -395,8 +412,10 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
                 "sampling": f"HIP events around the kernel's launches in every {args.event_every}-th of the {args.steps} timed steps "
                             f"({sampled_steps} steps sampled)",
                 "patches_per_launch": B // sub,
-                "concurrency": (f"{sub} sub-batches in flight on {sub} HIP streams: launch durations are measured while "
-                                f"the other stream's kernels share the chip") if sub > 1 else "single stream",
+                "concurrency": ((f"{sub} sub-batches in flight on {sub} HIP streams: launch durations are measured while "
+                                 f"the other stream's kernels share the chip") if sub > 1 else
+                                ("tails back to back on one stream; only the next step's small head launches (mapping, styles, <= 16x16 "
+                                 "layers) share the chip with this kernel") if pipe is not None else "single stream"),
                 "isolated": ({"what": f"same kernel, whole batch of {B} on one stream (3 untimed steps after the timed region)",
                               "launch_ms": round(sum(float(np.mean(t)) for t in iso.values()) / len(iso), 4),
                               "achieved": round(sum(layer_flops(specs[nm], B) for nm in iso)
@@ -422,7 +441,7 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
     whole = B * 2 * cfg.macs_per_patch() / (ms_per_step * 1e-3) / 1e12
     return {
         "value": round(world * B * args.steps / elapsed, 2), "unit": "patches/s", "ms_per_step": round(ms_per_step, 4),
-        "steps": args.steps, "warmup": args.warmup, "dtype": MODE_DTYPE[mode],
+        "steps": args.steps, "warmup": args.warmup, "dtype": MODE_DTYPE[mode], "schedule": schedule,
         "roofline": roofline,
         "roofline_whole_step": {
             "what": "the whole step (all launches of one GPU) against the ceilings of SURVEY 8d: algorithmic FLOPs of the batch / ms_per_step",
@@ -453,6 +472,10 @@ def main():
                          "timed steps) and reported under `modes`; default: all three at N=1, the primary one only at N>1; 'primary' = only it")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="software-pipeline the steps over two streams (pipeline.TriadStepPipeline: head of step k+1 under the tail of step k; "
+                         "+2 %% measured) instead of enqueueing them back to back on ONE stream, where every launch has the chip to itself "
+                         "and its HIP-event duration is the kernel's own time (default)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the dominant kernel's launches with HIP events in every K-th timed step (an event pair costs ~10 us "
                          "of stream time, which a single chain of launches cannot hide)")
@@ -555,6 +578,30 @@ def main():
         results[m] = measure_mode(gens[m], m, args, cfg, (z, geom, pos), world, rank, dev, backend, gather)
     G = gens[args.conv_mode]
     prim = results[args.conv_mode]
+    # Auxiliary figure (NOT `value`): the same steps with three independent steps in flight on three HIP streams (own
+    # workspaces).  The kernels of the other chains fill the CUs a chain leaves idle in its kernel tails and small launches, so
+    # the job is faster -- but every launch then shares the chip and its duration says nothing about the kernel, which is why
+    # the headline and the roofline are measured on one stream.
+    concurrent = None
+    if world == 1 and args.res == 256:
+        streams3 = [torch.cuda.Stream(dev) for _ in range(3)]
+
+        def run3(k_):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for i_ in range(k_):
+                with torch.cuda.stream(streams3[i_ % 3]):
+                    G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False, _plan_slot=27 + i_ % 3)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t_
+        for s_ in streams3:
+            s_.wait_stream(torch.cuda.current_stream(dev))
+        run3(9)
+        k3 = max(args.steps, 30)
+        el3 = run3(k3)
+        concurrent = {"streams": 3, "steps": k3, "value": round(B * k3 / el3, 2), "unit": "patches/s", "ms_per_step": round(el3 / k3 * 1e3, 4),
+                      "what": "three independent steps in flight on three HIP streams (the tiled-canvas schedule alternates its batches the "
+                              "same way); auxiliary -- kernels share the chip, so no per-kernel roofline is taken from this run"}
 
     if rank == 0:
         out = {
@@ -573,6 +620,7 @@ def main():
                                                                    (f" + {'RCCL' if backend == 'nccl' else backend} gather of RGBA tiles to rank 0 "
                                                                     f"inside every step (rank 0 receives {world - 1} x {B * args.res * args.res * 4 / 1e6:.1f} MB "
                                                                     f"per step; no overlap evidence for N > 1 exists yet)") if gather else " (NO gather: --no-gather)")},
+            "schedule": prim["schedule"],
             "roofline": prim["roofline"],
             "roofline_whole_step": prim["roofline_whole_step"],
             "rehearsal_ms_per_step": prim["rehearsal_ms_per_step"],
@@ -583,6 +631,8 @@ def main():
             out["value_fp32_parity"] = results["h3"]["value"]
             out["value_fp32_parity_what"] = "patches/s of mode h3 (fp32-grade products: 5e-6 from an all-fp32 evaluation); f32 = exact fp32 MFMA"
         out["modes"] = {m: {k: v for k, v in r.items()} for m, r in results.items()}
+        if concurrent is not None:
+            out["throughput_concurrent_steps"] = concurrent
         if world == 1 and not args.no_latency:
             out["latency_batch1"] = latency_batch1(G, cfg, dev, geom, pos)
         if world == 1 and not args.no_cpu:

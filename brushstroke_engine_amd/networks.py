@@ -400,6 +400,10 @@ class SynthesisNetwork(torch.nn.Module):
         stop_after = block_kwargs.pop("_stop_after", None)
         resume = block_kwargs.pop("_resume", None)
         plan_slot = block_kwargs.pop("_plan_slot", 0)      # workspace to use (concurrent sub-batches on separate streams)
+        # `_reuse_styles`: the styles / demodulation coefficients (and the noise images of the small layers) of THIS batch are
+        # already in the workspace slot -- an earlier pass of the same batch computed them (pipeline.TriadStepPipeline: the
+        # head pass computes every layer's styles, the tail pass of the same step resumes from its features)
+        reuse_styles = block_kwargs.pop("_reuse_styles", False)
         if block_kwargs:
             raise TypeError(f"unexpected synthesis kwargs: {sorted(block_kwargs)}")
         if noise_mode not in ("random", "const", "none"):
@@ -445,7 +449,12 @@ class SynthesisNetwork(torch.nn.Module):
                 while k_ > 0 and elig[k_ - 1]:
                     k_ -= 1
                 inkernel_from = k_ if k_ < len(elig) else None
-            if (self._styles_fast and noise_mode == "const" and table is plan.table and n <= 8
+            if reuse_styles:
+                if resume is None or (inkernel_from is None and noise_mode == "const") or table is not plan.table:
+                    raise RuntimeError("_reuse_styles needs a resumed pass whose layers compute their noise themselves")
+                if any(i_ < inkernel_from for i_, sp in enumerate(cfg.layers) if sp.block_res > resume[0]) and noise_mode == "const":
+                    raise RuntimeError("_reuse_styles: a resumed layer would need a noise image that no launch of this pass writes")
+            elif (self._styles_fast and noise_mode == "const" and table is plan.table and n <= 8
                     and (npos is not None or ipos is not None)):
                 # small batches: styles + per-sample noise in one launch (a launch costs more than either computes)
                 tbl = plan.table if inkernel_from is None else plan.table_without_noise_from(inkernel_from)

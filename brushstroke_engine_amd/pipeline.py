@@ -1,0 +1,112 @@
+"""Throughput mode of the generator: independent batches software-pipelined over two HIP streams.
+
+A batch-32 step is ~20 launches.  The first ones -- mapping network, all layers' styles, the small layers' noise and the
+five <= 16 x 16 convolutions -- hold 2 % of the step's FLOPs but a tenth of its time: they are latency-bound launches of a
+few hundred small workgroups that leave most of the 256 CUs idle.  Batches of a throughput job (the tiles of a canvas, the
+patches of ``bench.py``'s steps) are independent, so this HEAD of batch k+1 can run on a second stream while the big
+convolutions of batch k -- the TAIL -- own the chip on the first: the generator's split entry (``_stop_after`` /
+``_resume``, the same one the tiled-canvas schedule uses for feature blending) cuts the forward pass after block
+``split_res``, the head pass leaves every layer's styles and demodulation coefficients in its workspace slot and the tail
+pass of the same batch picks them up (``_reuse_styles``).  Tails run back to back on one stream; only small head
+kernels ever share the chip with them, so a big kernel's duration stays what it is alone.
+
+The reference has no counterpart: it evaluates one patch at a time on one stream (forger/ui/brush.py:731-805).
+Results are bit-identical to ``Generator.render_triad`` of the same batch (tests/test_hip_generator.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+PIPE_SLOT0 = 24          # workspace slots of the pipeline (generator sub-batches: 1.., painting: 8.., graphs: 16..)
+
+
+class TriadStepPipeline:
+    """``submit(z, geom_feature, positions)`` enqueues one batch and returns its uint8 RGBA tiles ``[N, R, R, 4]`` -- valid
+    on ``tail_stream`` (make a consumer stream wait with ``wait()`` / ``flush()``, or synchronise the device).  Up to
+    ``depth`` batches are in flight: the tail of batch k and the head of batch k+1."""
+
+    def __init__(self, G, split_res: int = 16, depth: int = 2, render_mode: str = "clear"):
+        dev = G.synthesis.get_last_block().conv1.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("TriadStepPipeline needs the generator on a GPU")
+        if split_res not in G.synthesis.block_resolutions or split_res >= G.img_resolution:
+            raise RuntimeError(f"split_res {split_res} is not an inner block resolution of this generator")
+        self.G, self.device, self.split_res, self.depth, self.render_mode = G, dev, int(split_res), int(depth), render_mode
+        self.head_stream = torch.cuda.Stream(device=dev)
+        self.tail_stream = torch.cuda.Stream(device=dev)
+        self._tail_done: List[Optional[torch.cuda.Event]] = [None] * self.depth      # slot free again (its tail has finished)
+        self._k = 0
+        self._pending = None          # (slot, ws, x, geom, positions, user_colors, sfactor, head event)
+        self._forked = False
+
+    # -- the two halves of one batch --
+    def _head(self, slot, z, geom, positions):
+        G = self.G
+        ws = G.mapping(z, None)
+        x = G.forward_pre_mapped(ws, geom, positions=positions, noise_mode="const", _stop_after=self.split_res,
+                                 _plan_slot=PIPE_SLOT0 + slot)
+        return ws, x
+
+    def _tail(self, slot, ws, x, geom, positions, user_colors, sfactor):
+        u8, _, _ = self.G.render_triad(ws=ws, geom_feature=geom, positions=positions, render_mode=self.render_mode,
+                                       user_colors=user_colors, sfactor=sfactor, _resume=(self.split_res, x),
+                                       _plan_slot=PIPE_SLOT0 + slot, _reuse_styles=True)
+        return u8
+
+    def _eligible(self, n: int) -> bool:
+        """The tail may reuse the head's workspace only if every resumed layer computes its noise itself (large split-f16
+        kernels); otherwise ``submit`` falls back to the unsplit call on the tail stream."""
+        syn = self.G.synthesis
+        if not (syn.noise_in_kernel and syn.conv_mode in ("h3", "f8")):
+            return False
+        syn._n, syn._h3_batch_ok = n, n >= syn.h3_min_batch
+        syn._ensure_packed()
+        return all((syn._h3_up2_eligible(sp) if sp.up == 2 else syn._h3_eligible(sp))
+                   for sp in syn.cfg.layers if sp.block_res > self.split_res)
+
+    def submit(self, z, geom_feature, positions, user_colors=None, sfactor=None) -> torch.Tensor:
+        if positions is None:
+            raise RuntimeError("TriadStepPipeline renders positioned patches (shifted noise); use Generator.render_triad otherwise")
+        cur = torch.cuda.current_stream(self.device)
+        if not self._forked:                       # inputs were produced on the caller's stream
+            self.head_stream.wait_stream(cur)
+            self.tail_stream.wait_stream(cur)
+            self._forked = True
+        geom = list(geom_feature)
+        n = z.shape[0]
+        if not self._eligible(n):
+            with torch.cuda.stream(self.tail_stream):
+                u8, _, _ = self.G.render_triad(z=z, geom_feature=geom, positions=positions, render_mode=self.render_mode,
+                                               user_colors=user_colors, sfactor=sfactor, _plan_slot=PIPE_SLOT0)
+            return u8
+        slot = self._k % self.depth
+        self._k += 1
+        # head of this batch: on the head stream, once the slot's previous tail has finished with the workspace
+        if self._tail_done[slot] is not None:
+            self.head_stream.wait_event(self._tail_done[slot])
+        with torch.cuda.stream(self.head_stream):
+            ws, x = self._head(slot, z, geom, positions)
+            ev = torch.cuda.Event()
+            ev.record(self.head_stream)
+        for t in (ws, x):
+            t.record_stream(self.tail_stream)       # allocated on the head stream, read by the tail
+        # tail of this batch: behind the previous batch's tail on the tail stream
+        self.tail_stream.wait_event(ev)
+        with torch.cuda.stream(self.tail_stream):
+            u8 = self._tail(slot, ws, x, geom, positions, user_colors, sfactor)
+            done = torch.cuda.Event()
+            done.record(self.tail_stream)
+        self._tail_done[slot] = done
+        return u8
+
+    def wait(self, stream=None) -> None:
+        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far."""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        stream.wait_stream(self.tail_stream)
+        stream.wait_stream(self.head_stream)
+
+    def flush(self) -> None:
+        self.wait()
+        self._forked = False
