@@ -462,7 +462,7 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and with it the live parity of every mode)")
-    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 hipGraph latency leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the auxiliary legs: batch-1 hipGraph latency, three-steps-in-flight throughput")
     ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f32"],
                     help="the PRIMARY arithmetic mode = top-level value; default: the library default (networks.DEFAULT_CONV_MODE = f8). "
                          "f8: f16 main product + two block-scaled fp8 correction products (pixels within 1e-4 of fp32; budget 1e-3); "
@@ -583,7 +583,7 @@ def main():
     # the job is faster -- but every launch then shares the chip and its duration says nothing about the kernel, which is why
     # the headline and the roofline are measured on one stream.
     concurrent = None
-    if world == 1 and args.res == 256:
+    if world == 1 and args.res == 256 and not args.no_latency:            # (auxiliary legs go together: --no-latency skips both)
         streams3 = [torch.cuda.Stream(dev) for _ in range(3)]
 
         def run3(k_):

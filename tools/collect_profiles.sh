@@ -27,7 +27,6 @@ for m in f8 h3; do
 done
 cd $R
 python tools/make_hbm_traffic.py $O/hbm_traffic.json "${GIT_HEAD:-unknown}" f8=$O/pmc_mem_f8.json h3=$O/pmc_mem_h3.json f32=$O/pmc_mem_f32.json > $O/hbm_traffic.log 2>&1
-cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv 2>/dev/null
 NB_PHASE_F8=1 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times.txt 2>&1
 python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
 NB_SUBS="1 2" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1
@@ -37,6 +36,9 @@ python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 --breakdo
 python tools/bench_canvas.py --size 4096 --res 256 --level 0 --steps 3 --breakdown > $O/canvas_4096_r256_l0.json 2>/dev/null
 python tools/bench_canvas.py --size 1024 --res 128 --level 2 --steps 3 --breakdown > $O/canvas_1024_r128_l2.json 2>/dev/null
 python tools/bench_lamali.py > $O/lamali.json 2> $O/lamali.err
+# the N > 1 launch path of the canvas job on this one-GPU box: two ranks share device 0 over gloo (functional evidence: halo
+# exchange, pieces replay, gather; the rate means nothing)
+NB_BENCH_SHARE_GPU=1 NB_BENCH_BACKEND=gloo python tools/bench_lamali.py --gpus 2 --steps 3 > $O/lamali_2ranks_shared_gpu.json 2> $O/lamali_2ranks.err
 python tools/bench_train.py > $O/train_bench.json 2> $O/train_bench.err
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 rm -rf $O/stats_* $O/pmc_hit_* $O/pmc_fetch_* $O/pmc_write_* $O/pmc_mfma_f8 $O/pmc_mfma_h3
