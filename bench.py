@@ -548,7 +548,8 @@ def main():
     sd = wmod.random_state_dict(cfg, seed=0)
     B = args.batch
     # synthetic inputs, resident in HBM before anything is timed (different per rank)
-    z = torch.from_numpy(synthetic.batch_z(cfg, B, first_seed=rank * B)).to(dev)
+    # (z in the dtype the mapping network computes in: the fp32 cast of networks.py:261 is then a no-op instead of a launch)
+    z = torch.from_numpy(synthetic.batch_z(cfg, B, first_seed=rank * B)).to(dev).to(torch.float32)
     geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, seed=rank)]
     pos = torch.from_numpy(synthetic.positions(cfg, B, seed=rank)).to(dev)
     gather = world > 1 and not args.no_gather

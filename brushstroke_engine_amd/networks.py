@@ -194,6 +194,7 @@ class _Plan:
         self.host_descs = descs
         self.pack_stream, self.pack_events = None, {}      # side stream for the early geometry packing of this slot
         self.n_layers = len(specs) + 1
+        self.const_rep = None                              # b4.const repeated over the batch (filled at first use)
         self._noise_cut = {}
         self.table = self._upload(descs)
 
@@ -540,6 +541,10 @@ class SynthesisNetwork(torch.nn.Module):
                         plan.pack_stream = torch.cuda.Stream(device=device)
                         plan.pack_events = {}
                     dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
+                    # (Measured, round 3: this memory-bound pack -- 201 MB per batch of 32 at R=256 -- costs the kernels it runs
+                    #  beside ~45 us wherever it is placed: here, beside the small first layers (b8.conv1 12 -> 58 us), or deferred to
+                    #  the b32 / b64 layers (+30 / +33 us), with its grid capped or not.  The painting engine never runs it: its
+                    #  encoder writes the operand format directly, encoder.LazyGeometry.)
                     if not pack_waited:
                         # the styles (and, on the lazy path, the encoder's fp32 features) are enqueued on `cur`; tracked apart
                         # from pre_h2, which the lazy path may already have filled for another feature
@@ -576,7 +581,11 @@ class SynthesisNetwork(torch.nn.Module):
                     continue
                 names = ([f"synthesis.b{res}.conv0"] if res > 4 else []) + [f"synthesis.b{res}.conv1"]
                 if res == 4:
-                    x = block.const.unsqueeze(0).expand(n, -1, -1, -1).contiguous()     # networks.py:641-643
+                    # networks.py:641-643: the learned constant repeated over the batch -- a constant of the weights, so the
+                    # workspace keeps the repeated tensor (built once per maximum batch, dropped with the plan on a reload)
+                    if plan.const_rep is None:
+                        plan.const_rep = block.const.unsqueeze(0).expand(plan.n_max, -1, -1, -1).contiguous()
+                    x = plan.const_rep[:n]
                 elif x is not None:                  # (None: the previous block handed its output over in H2 format)
                     _assert_shape(x, [None, block.in_channels - (0 if x2 is None else x2.shape[1]), res // 2, res // 2])
                 for name in names:
