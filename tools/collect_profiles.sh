@@ -38,7 +38,7 @@ python tools/bench_canvas.py --size 1024 --res 128 --level 2 --steps 3 --breakdo
 python tools/bench_lamali.py > $O/lamali.json 2> $O/lamali.err
 # the N > 1 launch path of the canvas job on this one-GPU box: two ranks share device 0 over gloo (functional evidence: halo
 # exchange, pieces replay, gather; the rate means nothing)
-NB_BENCH_SHARE_GPU=1 NB_BENCH_BACKEND=gloo python tools/bench_lamali.py --gpus 2 --steps 3 > $O/lamali_2ranks_shared_gpu.json 2> $O/lamali_2ranks.err
+NB_BENCH_SHARE_GPU=1 NB_BENCH_BACKEND=gloo python tools/bench_lamali.py --gpus 2 --steps 3 2> $O/lamali_2ranks.err | grep "^{" > $O/lamali_2ranks_shared_gpu.json
 python tools/bench_train.py > $O/train_bench.json 2> $O/train_bench.err
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 rm -rf $O/stats_* $O/pmc_hit_* $O/pmc_fetch_* $O/pmc_write_* $O/pmc_mfma_f8 $O/pmc_mfma_h3
