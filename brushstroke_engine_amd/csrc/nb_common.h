@@ -31,6 +31,11 @@ static inline int nb_cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- position-shifted constant noise (networks.py:371-382), the per-pixel arithmetic shared by nb_noise_f32's kernels
 //      (nb_ops.hip) and the convolutions that compute their noise themselves (NbNoiseSrc) ----
 #ifdef __HIPCC__
+// fmodf(a, 1.f) without the library's general-divisor loop: a - trunc(a) is exact in fp32 for every finite a (the fraction is
+// the low bits of a; |a| >= 2^23 is an integer) and has a's sign, which is what fmod returns (the two differ only in the sign
+// of a zero result, which the `* 2 - 1` that follows erases).  ~40 VALU instructions per call less in the conv prologues.
+__device__ __forceinline__ float nb_fmod1(float a) { return a - truncf(a); }
+
 struct NbNoiseSrcDev {
     const float* const_t; const float* lin; const float* strength; const float* norm_pos; const long long* positions;
     int res, img_res;
@@ -49,7 +54,7 @@ __device__ __forceinline__ void nb_noise_np(const NbNoiseSrcDev& s, int n, float
 }
 // bilinear parameters of one axis: output index idx -> first source index c0 and the two weights
 __device__ __forceinline__ void nb_noise_axis(const NbNoiseSrcDev& s, int idx, float np, int& c0, float& w0, float& w1) {
-    const float g = fmodf(s.lin[idx] + np, 1.f) * 2.f - 1.f;
+    const float g = nb_fmod1(s.lin[idx] + np) * 2.f - 1.f;
     const float cc = ((g + 1.f) / 2.f) * (float)(s.res - 1);
     const float f0 = floorf(cc);
     c0 = (int)f0; w1 = cc - f0; w0 = (f0 + 1.f) - cc;

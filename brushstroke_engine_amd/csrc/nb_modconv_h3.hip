@@ -108,6 +108,26 @@ __device__ __forceinline__ void nb_stagger(int stagger_ticks, int first_round) {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// s_waitcnt vmcnt(N) as the BUILTIN, not inline assembly: the compiler's own wait bookkeeping (SIInsertWaitcnts) then sees
+// the LDS-DMA operations complete.  With asm waits it never does, keeps every LDS-DMA "pending" for the rest of the kernel and
+// -- because an LDS-DMA counts as a flat access that may touch LDS -- turns every wait for a fragment read into
+// `s_waitcnt lgkmcnt(0)`, also where only the oldest of sixteen outstanding reads is needed.
+// gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+#define NB_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+
+// One LDS-DMA piece (64 lanes x 16 bytes, global -> LDS at lds + 16 * lane) as INLINE ASSEMBLY.  The builtin
+// (__builtin_amdgcn_global_load_lds) is a flat-segment access that may touch LDS as far as the compiler's wait bookkeeping is
+// concerned: while one is pending -- and with counted inline-asm vmcnt waits it never sees them complete -- every wait for an
+// LDS fragment read is forced to `s_waitcnt lgkmcnt(0)`, also where only the oldest of sixteen reads in flight is needed.
+// Hidden in an asm statement the copy is nobody's business but ours (the K loops count their vmcnt themselves anyway) and the
+// fragment reads get counted waits.  M0 (the LDS destination base) is saved and restored around the copy.
+__device__ __forceinline__ void nb_lds_dma16(const void* src, const void* lds) {
+    const unsigned dst = (unsigned)(uintptr_t)NB_LDS_PTR(lds);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
+}
+
 // compile-time loop: f(std::integral_constant<int, K0>{}) ... f(std::integral_constant<int, K1 - 1>{})
 template <int K0, int K1, class F>
 __device__ __forceinline__ void nb_static_for(F&& f) {
@@ -1167,14 +1187,14 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             const int cg = 2 * c + (xpl[k] >> 1);
             const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
             if (xsp[k] >= 0 && cg < p.c8) src = xn + (size_t)(4 * c + xpl[k]) * HW8 + xsp[k];
-            if (xok[k]) __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + xdst[k]), 16, 0, 0);
+            if (xok[k]) nb_lds_dma16(src, st + xdst[k]);
         } else {
             int q = (k - NXPW) * NW + wv;
             q = q < NWP ? q : NWP - 1;
             const int e = q * 64 + lane;
             const int row = e >> 5, j = e & 31;           // row = tap*4 + cg*2 + hl
             const _Float16* src = p.wts + (((size_t)c * 36 + row) * p.co_ld + co0 + j) * 8;
-            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(st + 4 * XPL + q * 64), 16, 0, 0);
+            nb_lds_dma16(src, st + 4 * XPL + q * 64);
         }
     };
     auto issue = [&](int c, h8* st) { nb_static_for<0, NPC>([&](auto k) { issue_piece(k, c, st); }); };
@@ -1247,37 +1267,71 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
             // walked so that the B fragments of input offsets 0 and 1 are loaded once and those of XS / XS+1 replace them.
             const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
             const h8 z8 = {};
-            h8 b0h[NBJ], b0l[NBJ], b1h[NBJ], b1l[NBJ], b2h[NBJ], b2l[NBJ];
-            h8 a1h, a1l, a2h, a2l, n1h, n1l, n2h, n2l;
+            h8 b0h[NBJ] = {}, b0l[NBJ] = {}, b1h[NBJ] = {}, b1l[NBJ] = {}, b2h[NBJ] = {}, b2l[NBJ] = {};
+            h8 a1h = {}, a1l = {}, a2h = {}, a2l = {}, n1h = {}, n1l = {}, n2h = {}, n2l = {};
             using S4 = std::integral_constant<int, 4>;
-#define NB_LDA(tap, hi, lo) { hi = st[aoff + (tap) * 128]; lo = st[aoff + (tap) * 128 + 32]; }
-#define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) { hi[j] = st[boff[j] + (del)]; lo[j] = st[boff[j] + XPL + (del)]; } }
+#ifdef NB_ABL_NOREAD      // developer ablation (tools/build_variants.sh; timing only, wrong results): no fragment reads
+#define NB_RD(dst, src) asm volatile("" : "+v"(dst))
+#else
+#define NB_RD(dst, src) dst = (src)
+#endif
+#define NB_LDA(tap, hi, lo) { NB_RD(hi, st[aoff + (tap) * 128]); NB_RD(lo, st[aoff + (tap) * 128 + 32]); }
+#define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) { NB_RD(hi[j], st[boff[j] + (del)]); NB_RD(lo[j], st[boff[j] + XPL + (del)]); } }
 #define NB_PAIR(ph, ah_a, al_a, bha, bla, ah_b, al_b, bhb, blb)                                                                   \
             { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) {                                                                    \
                 f32x16& a_ = acc[j][ph];                                                                                           \
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_a, bha[j], a_, 0, 0, 0);                                            \
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_b, bhb[j], a_, 0, 0, 0);                                            \
                 a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(al_a, al_b), nb_cat8(bla[j], blb[j]), a_, 0, 0, 0, sa, 0, sb); } }
+#ifdef NB_ABL_NODMA       // developer ablation: no LDS-DMA inside the K loop (the chunks read what the prologue staged)
+#define NB_DMA(slot) {}
+#else
 #define NB_DMA(slot) { if constexpr (DMA) { __builtin_amdgcn_sched_barrier(0); issue_at(std::integral_constant<int, slot>{}, S4{}, cn, sn); __builtin_amdgcn_sched_barrier(0); } }
-            NB_LDB(0, b0h, b0l); NB_LDB(1, b1h, b1l); NB_LDA(8, a1h, a1l); NB_LDA(6, a2h, a2l);
-            NB_LDA(5, n1h, n1l); NB_LDA(3, n2h, n2l);
+#endif
+            // Program order = issue order (a scheduling fence after every group): left to itself the scheduler sinks each
+            // fragment read to just before its first use (register pressure), and every MFMA group then starts with an
+            // exposed `s_waitcnt lgkmcnt(0)`.  With the reads of the NEXT group issued before the current group's MFMAs the
+            // compiler's own wait bookkeeping emits counted waits (lgkmcnt(4), (2), (8), ...) and the reads return under
+            // 256 cycles of matrix work.
+#define NB_FENCE() __builtin_amdgcn_sched_barrier(0)
+            // first group's operands in the order its MFMAs take them (the counted waits then release the first MFMA after
+            // three reads, not after all sixteen), then the second group's A fragments
+            NB_RD(a1h, st[aoff + 8 * 128]);
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) NB_RD(b0h[j], st[boff[j]]);
+            NB_RD(a2h, st[aoff + 6 * 128]);
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) NB_RD(b1h[j], st[boff[j] + 1]);
+            NB_RD(a1l, st[aoff + 8 * 128 + 32]); NB_RD(a2l, st[aoff + 6 * 128 + 32]);
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) { NB_RD(b0l[j], st[boff[j] + XPL]); NB_RD(b1l[j], st[boff[j] + XPL + 1]); }
+            NB_LDA(5, n1h, n1l); NB_LDA(3, n2h, n2l);                             // (for the second group)
+            NB_FENCE();
             NB_PAIR(0, a1h, a1l, b0h, b0l, a2h, a2l, b1h, b1l);                   // taps 8, 6
+            NB_FENCE();
             NB_DMA(0);
-            NB_LDA(4, a1h, a1l);
+            NB_LDA(4, a1h, a1l);                                                  // (for the third group)
+            NB_FENCE();
             NB_PAIR(2, n1h, n1l, b0h, b0l, n2h, n2l, b1h, b1l);                   // taps 5, 3
+            NB_FENCE();
             NB_DMA(1);
-            NB_LDB(XS, b1h, b1l); NB_LDA(7, n1h, n1l); NB_LDA(1, n2h, n2l);
+            NB_LDB(XS, b1h, b1l); NB_LDA(7, n1h, n1l); NB_LDA(1, n2h, n2l);       // (for the fourth group)
+            NB_FENCE();
 #pragma unroll
             for (int j = 0; j < NBJ; ++j) {                                       // tap 4 alone
                 f32x16& a_ = acc[j][3];
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h[j], a_, 0, 0, 0);
                 a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(a1l, z8), nb_cat8(b0l[j], z8), a_, 0, 0, 0, sa, 0, sb);
             }
+            NB_FENCE();
             NB_DMA(2);
-            NB_LDB(XS + 1, b2h, b2l); NB_LDA(2, a1h, a1l); NB_LDA(0, a2h, a2l);
+            NB_LDB(XS + 1, b2h, b2l); NB_LDA(2, a1h, a1l); NB_LDA(0, a2h, a2l);   // (for the fifth group)
+            NB_FENCE();
             NB_PAIR(1, n1h, n1l, b0h, b0l, n2h, n2l, b1h, b1l);                   // taps 7, 1
+            NB_FENCE();
             NB_DMA(3);
             NB_PAIR(0, a1h, a1l, b1h, b1l, a2h, a2l, b2h, b2l);                   // taps 2, 0
+#undef NB_FENCE
 #undef NB_LDA
 #undef NB_LDB
 #undef NB_PAIR
@@ -1333,8 +1387,14 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         // chunk c+1 has landed (the pieces of c+2 may stay in flight); everybody is done reading chunk c
         // (no timestamp reads in here: the branches around them split the loop body into several basic blocks, and the
         //  compiler then sinks MFMAs past the wait and the barrier)
+#ifdef NB_ABL_NODMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
+#endif
+#ifndef NB_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         s_cur = s_cur == 2 ? 0 : s_cur + 1;
     }
     for (; c < NC; ++c) {

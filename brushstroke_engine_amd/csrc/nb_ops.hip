@@ -531,8 +531,8 @@ __device__ __forceinline__ void nb_noise_sample(const NbLayerDesc& L, const floa
     for (int idx = idx0; idx < r * r; idx += stride) {
         const int i = idx / r, j = idx - i * r;
         // grid[i,j] = (lin[i] + pos0, lin[j] + pos1); channel 0 is the COLUMN coordinate, channel 1 the ROW
-        const float g0 = fmodf(L.noise_lin[i] + np0, 1.f) * 2.f - 1.f;
-        const float g1 = fmodf(L.noise_lin[j] + np1, 1.f) * 2.f - 1.f;
+        const float g0 = nb_fmod1(L.noise_lin[i] + np0) * 2.f - 1.f;
+        const float g1 = nb_fmod1(L.noise_lin[j] + np1) * 2.f - 1.f;
         const float cx = ((g0 + 1.f) / 2.f) * (float)(r - 1);
         const float cy = ((g1 + 1.f) / 2.f) * (float)(r - 1);
         const float x0 = floorf(cx), y0 = floorf(cy);
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void noise_kernel(const NbLayerDesc* __restric
         // grid[i,j] = (lin[i] + pos0, lin[j] + pos1); channel 0 is the COLUMN coordinate, channel 1 the ROW
         const int k = t & (NB_NOISE_T - 1), idx = (t < NB_NOISE_T ? i0 : j0) + k;
         if (idx < r) {
-            const float g = fmodf(L.noise_lin[idx] + (t < NB_NOISE_T ? np0 : np1), 1.f) * 2.f - 1.f;
+            const float g = nb_fmod1(L.noise_lin[idx] + (t < NB_NOISE_T ? np0 : np1)) * 2.f - 1.f;
             const float cc = ((g + 1.f) / 2.f) * (float)(r - 1);
             const float c0 = floorf(cc);
             if (t < NB_NOISE_T) { s_x0[k] = (int)c0; s_wx1[k] = cc - c0; s_wx0[k] = (c0 + 1.f) - cc; }
