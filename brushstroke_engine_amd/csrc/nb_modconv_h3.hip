@@ -1144,21 +1144,6 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         s_bias[tid] = co < p.c_out ? p.bias[co] * p.gain : 0.f;
         s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
-    for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
-        const int r = e / (2 * TQW), c = e - r * (2 * TQW);
-        const int oy = 2 * I0 + r, ox = 2 * J0 + c;
-        float v = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
-        if (p.nsrc.const_t && oy < 2 * H) {
-            float np0, np1, wx0, wx1, wy0, wy1;
-            int sx0, sy0;
-            nb_noise_np(p.nsrc, n, np0, np1);
-            nb_noise_axis(p.nsrc, oy, np0, sx0, wx0, wx1);
-            nb_noise_axis(p.nsrc, ox, np1, sy0, wy0, wy1);
-            v = nb_noise_value(p.nsrc, p.nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
-        }
-        s_noise[e] = v * p.gain;
-    }
-
     // LDS-DMA descriptors of this wave's pieces.  Activation piece i: plane xpl (= cg_local*2 + hi/lo), 64 slots from
     // `part`; xsp = element offset of the lane's source slot inside a plane (-1: outside the image -> zero page),
     // xok = the lane's slot belongs to the plane (the last piece of a plane is partial)
@@ -1233,6 +1218,23 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     const int NC = p.nchunks;
     static_assert(NST == 3, "ring indices below are written for three stages");
     issue(0, ring);
+    // the tile's noise values (epilogue operand), computed or fetched while chunk 0 is on its way: with the in-kernel noise
+    // (NbNoiseSrc) that is ~150 VALU instructions per thread, which cost 1 us of prologue when they ran ahead of the first DMA
+    for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
+        const int r = e / (2 * TQW), c = e - r * (2 * TQW);
+        const int oy = 2 * I0 + r, ox = 2 * J0 + c;
+        float v = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
+        if (p.nsrc.const_t && oy < 2 * H) {
+            float np0, np1, wx0, wx1, wy0, wy1;
+            int sx0, sy0;
+            nb_noise_np(p.nsrc, n, np0, np1);
+            nb_noise_axis(p.nsrc, oy, np0, sx0, wx0, wx1);
+            nb_noise_axis(p.nsrc, ox, np1, sy0, wy0, wy1);
+            v = nb_noise_value(p.nsrc, p.nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
+        }
+        s_noise[e] = v * p.gain;
+    }
+
     if (NC > 1) {
         issue(1, ring + STAGE);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
