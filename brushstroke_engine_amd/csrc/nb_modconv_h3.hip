@@ -1849,6 +1849,40 @@ extern "C" int nb_pack_h2_part_f32(const float* x, int c, const float* scale, in
     return NB_OK;
 }
 
+// Device-side weight packing (same layout as the host helper below): one thread per (chunk, tap, cg, co) writes the hi and lo
+// slots of its 8 channels (zero padding included)
+__global__ __launch_bounds__(256) void pack_conv_weight_h3_kernel(const float* __restrict__ w, int c_out, int c_in, int co_ld, int nch,
+                                                                  h8* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;             // ((chunk * 9 + tap) * 2 + cg) * co_ld + co
+    if (idx >= nch * 18 * co_ld) return;
+    const int co = idx % co_ld;
+    int r = idx / co_ld;
+    const int cg = r & 1; r >>= 1;
+    const int tap = r % 9, ch = r / 9;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = ch * 16 + cg * 8 + j;
+        const float v = (co < c_out && ci < c_in) ? w[((size_t)co * c_in + ci) * 9 + tap] : 0.f;
+        const _Float16 hh = (_Float16)v;
+        hi[j] = hh;
+        lo[j] = (_Float16)(v - (float)hh);
+    }
+    const size_t base = ((((size_t)ch * 9 + tap) * 2 + cg) * 2) * co_ld;
+    out[base + co] = hi;
+    out[base + co_ld + co] = lo;
+}
+
+extern "C" int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, void* out, void* stream) {
+    NB_REQUIRE(w && out && c_out > 0 && c_in > 0 && (uintptr_t)out % 16 == 0, "pack_conv_weight_h3_dev: bad arguments");
+    const int nch = (c_in + 15) / 16, co_ld = (c_out + 63) / 64 * 64;
+    const int total = nch * 18 * co_ld;
+    hipLaunchKernelGGL(pack_conv_weight_h3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, c_out, c_in, co_ld, nch,
+                       (h8*)out);
+    NB_CHECK_LAUNCH("pack_conv_weight_h3_dev");
+    return NB_OK;
+}
+
 // Host-side weight packing: W[c_out][c_in][3][3] fp32 -> hi/lo f16 [ceil16(c_in)/16][3][3][2][2][ceil64(c_out)][8]
 extern "C" int nb_pack_conv_weight_h3(const float* w, int c_out, int c_in, void* out) {
     NB_REQUIRE(w && out && c_out > 0 && c_in > 0, "pack_conv_weight_h3: bad arguments");

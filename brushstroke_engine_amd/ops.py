@@ -328,7 +328,7 @@ def _wgrad_launch(u, v, stride, padding):
     a = torch.empty([n, cu, cv, 3, 3], dtype=torch.float32, device=u.device)
     if WGRAD_SPLIT_F16:
         # power-of-two scales that bring each operand's largest magnitude near 2^10 (computed on the device: no sync)
-        mx = torch.stack([u.detach().abs().amax(), v.detach().abs().amax()]).clamp_min(1e-30)
+        mx = torch.stack([_absmax(u), _absmax(v)]).clamp_min(1e-30)
         scales = torch.exp2(torch.floor(torch.log2(1024.0 / mx))).to(torch.float32).contiguous()
         with torch.cuda.device(u.device):
             _lib.check(_lib.lib().nb_conv2d_wgrad_h3(_p(u.contiguous()), _p(v.contiguous()), _p(scales), _p(a), n, cu, hu, wu, cv, hv, wv,
@@ -550,6 +550,41 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                                      fuse_bias_act=fuse_bias_act, x2=x2, wpk=wpk, dcoefs=dcoefs)
 
 
+# The differentiable operators (training path) evaluate their stride-1 / up=2 3x3 convolutions on the split-f16 kernels of the
+# inference path when the shapes allow it (forward passes, input gradients, the discriminator's convolutions through
+# ops.conv2d): hi/lo-f16 operands = 22-bit products, fp32 accumulation -- the grade of an fp32 evaluation, ~4x the fp32-MFMA rate.
+# Operands are brought into the f16 range by a power-of-two scale computed on the device (gradients are tiny, activations can
+# be large) and the result is scaled back in the kernel's output coefficients.  False: the exact-fp32 MFMA kernels.
+TRAIN_SPLIT_F16 = True
+TRAIN_SPLIT_F16_MIN_PIXELS = 128 * 128          # n * h * w from which the large-tile kernels fill the chip
+
+
+def _absmax(t: torch.Tensor) -> torch.Tensor:
+    """max |t| as a 0-dim device tensor in ONE reduction pass (aminmax), no host sync."""
+    lo, hi = torch.aminmax(t.detach())
+    return torch.maximum(hi, -lo)
+
+
+def pack_conv_weight_h3_dev(weight: torch.Tensor) -> torch.Tensor:
+    """:func:`pack_conv_weight_h3` in one HIP launch (weights that change every step)."""
+    o, i, kh, kw = weight.shape
+    assert kh == 3 and kw == 3
+    w = weight.detach().to(torch.float32).contiguous()
+    nch, op = (i + 15) // 16, (o + 63) // 64 * 64
+    out = torch.empty([nch, 3, 3, 2, 2, op, 8], dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().nb_pack_conv_weight_h3_dev(_p(w), o, i, _p(out), _stream(w)), "pack_conv_weight_h3_dev")
+    return out
+
+
+def _split_f16_eligible(n, h, w_, up) -> bool:
+    if not TRAIN_SPLIT_F16 or n * h * w_ * up * up < TRAIN_SPLIT_F16_MIN_PIXELS:
+        return False
+    if up == 1:
+        return w_ % 32 == 0 and h % 16 == 0
+    return (w_ % 32 == 0 or w_ == 16) and h >= 8
+
+
 def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                               flip_weight=True, fused_modconv=True, *, bias=None, act_gain=None, act_clamp=None,
                               fuse_bias_act=False, x2=None, wpk=None, dcoefs=None):
@@ -571,8 +606,10 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
     assert down == 1 and padding == 1
     assert (up == 1 and flip_weight) or (up == 2 and not flip_weight), "unsupported up/flip_weight combination"
     h, w_ = x.shape[2], x.shape[3]
+    wpk_given = wpk
+    use_h3 = wpk is None and _split_f16_eligible(n, h, w_, up)
     if wpk is None:
-        wpk, wsq = pack_conv_weight(weight)
+        wpk, wsq = (None, None) if use_h3 else pack_conv_weight(weight)
     else:
         wsq = None
     styles = styles.contiguous()
@@ -601,6 +638,17 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
         alpha, gain, clamp = 1.0, 1.0, -1.0     # identity epilogue
     x = x.contiguous()
     x2c = None if x2 is None else x2.contiguous()
+    if wpk_given is None and _split_f16_eligible(n, h, w_, up):
+        # split-f16 kernels: (x ++ x2) * styles * 2^k -> H2 operands, weights packed on the device, 2^-k in the output scale
+        mx = _absmax(x)
+        if x2c is not None:
+            mx = torch.maximum(mx, _absmax(x2c))
+        mx = (mx * _absmax(styles)).clamp_min(1e-30)
+        k = torch.exp2(torch.floor(torch.log2(16384.0 / mx)))
+        xh = pack_h2(x, styles * k, x2c)
+        wh = pack_conv_weight_h3_dev(weight)
+        fn = modconv_up1_h3 if up == 1 else modconv_up2_h3
+        return fn(xh, i, wh, dcoefs / k, noise, b, o, act_gain=gain, act_clamp=None if clamp < 0 else clamp, alpha=alpha)
     y = torch.empty([n, o, ho, wo], dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().nb_modconv3x3_f32(_p(x), c1, _p(x2c), c2, _p(wpk), _p(styles), _p(dcoefs.contiguous()),

@@ -199,6 +199,9 @@ int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, const float
 /* Host helper: W[c_out,c_in,3,3] fp32 -> hi/lo f16 [ceil(c_in/16)][3][3][2][2][ceil64(c_out)][8]
  * (bytes: ceil(c_in/16)*9*4*ceil64(c_out)*16). */
 int nb_pack_conv_weight_h3(const float* w, int c_out, int c_in, void* out);
+/* The same packing on the DEVICE (w and out are device pointers): one launch instead of a host loop -- for weights that
+ * change every step (the training path evaluates its 3x3 convolutions on the split-f16 kernels, ops.TRAIN_SPLIT_F16). */
+int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, void* out, void* stream);
 
 /* SynthesisLayer.forward with up = 1 (networks.py:362-391) on an H2 input:
  * y[n,c_out,h,w] (fp32 NCHW) = clamp(lrelu(conv3x3(x_h2, W) * dcoefs + noise + bias, alpha) * gain).
