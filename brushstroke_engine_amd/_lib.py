@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lock = threading.Lock()
 _lib = None
@@ -53,6 +53,10 @@ PROTOTYPES = {
     "nb_conv2d_f32": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
     "nb_conv2d_wgrad_f32": (C.c_int, [vp, vp, vp] + [C.c_int] * 9 + [vp]),
     "nb_conv2d_wgrad_h3": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
+    "nb_conv2d_wgrad_h3_ws_bytes": (C.c_longlong, [C.c_int] * 5),
+    "nb_conv2d_wgrad_h3_ws": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_longlong] + [C.c_int] * 10 + [vp]),
+    "nb_absmax_f32": (C.c_int, [vp, C.c_longlong, vp, C.c_longlong, vp, C.c_longlong, vp, vp]),
+    "nb_pack_h2_ranged_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_int, vp]),
     "nb_mapping_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_mapping_ws_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     "nb_styles_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -5,7 +5,7 @@
 #include <cstdarg>
 #include "../../include/neube_hip.h"
 
-#define NB_ABI_VERSION 9
+#define NB_ABI_VERSION 10
 
 void nb_set_error(const char* fmt, ...);
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // y[n,co,oy,ox] = out_scale[n,co] * sum_{ci,a,b} (x[n,ci,oy*st+a-pad,ox*st+b-pad] * in_scale[n,ci]) * w[co,ci,a,b]
@@ -108,7 +109,18 @@ extern "C" int nb_conv2d_f32(const float* x, const float* w, const float* in_sca
 struct WgradParams {
     const float* u; const float* v; float* a;
     int n, cu, hu, wu, cv, hv, wv, stride, pad, rows_per_wg, nslices;
+    float* part;            // split-f16 kernel: partial results [nslices][n][cu][cv][9] written with plain stores (NULL: atomics into a)
+    int scales_are_absmax;  // split-f16 kernel: `scales` holds max|u|, max|v| (nb_absmax_f32 slots), not the two powers of two
 };
+
+// The power of two that brings a tensor whose largest magnitude is mx near `target` (every thread of every kernel that derives
+// a range scale from the same absmax slot computes the same value: the scale only has to be a power of two, not a particular one).
+__device__ __forceinline__ float nb_pow2_scale(float target, float mx) {
+    mx = fmaxf(mx, 1e-30f);
+    float e = floorf(log2f(target / mx));
+    e = fminf(fmaxf(e, -100.f), 100.f);
+    return ldexpf(1.f, (int)e);
+}
 
 // Workgroup = 4 waves = 32 (cu) x 128 (cv) of all 9 taps (wave w owns cv columns 32w .. 32w+31, so no cross-wave
 // reduction), for one sample and a slice of V's rows.  Per V row and 64-pixel column chunk the operands are staged in
@@ -186,7 +198,7 @@ extern "C" int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int
     NB_REQUIRE(u && v && a, "conv2d_wgrad: null pointer");
     NB_REQUIRE(n >= 1 && cu >= 1 && cv >= 1 && hu >= 1 && wu >= 1 && hv >= 1 && wv >= 1 && (stride == 1 || stride == 2) && pad >= 0,
                "conv2d_wgrad: bad sizes (stride 1 or 2)");
-    WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0};
+    WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0, nullptr, 0};
     // enough workgroups to fill the chip: slice V's rows when there are few (n, tile) combinations
     const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
     static const int wg_target = getenv("NB_WGRAD_WGS") ? atoi(getenv("NB_WGRAD_WGS")) : 256;     // one workgroup per CU: more row slices only add atomic traffic (tools/bench_wgrad.py)
@@ -242,7 +254,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams 
     const int n = blockIdx.z / p.nslices, sl = blockIdx.z - n * p.nslices;
     const float* un = p.u + (size_t)n * p.cu * p.hu * p.wu;
     const float* vn = p.v + (size_t)n * p.cv * p.hv * p.wv;
-    const float scu = scales[0], scv = scales[1];
+    const float scu = p.scales_are_absmax ? nb_pow2_scale(1024.f, scales[0]) : scales[0];
+    const float scv = p.scales_are_absmax ? nb_pow2_scale(1024.f, scales[1]) : scales[1];
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -351,10 +364,48 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams 
             }
         }
     }
+    const float inv = 1.f / (scu * scv);
+    if (p.part) {
+        // Partial results leave through LDS as whole rows of the [cu][cv][9] block (16 cu rows per pass: 16 x 1152 floats),
+        // stored with 16-byte coalesced writes into this (slice, sample)'s own block: no atomics, no zero fill, and the sum over
+        // slices (wgrad_reduce_kernel) has a fixed order.  (The atomic form below issued 144 scattered 36-byte-stride atomic
+        // instructions per lane: ~300 us per call whatever the image size -- most of a training step's wgrad time.)
+        constexpr int RUNP = 128 * 9 + 4;
+        float* so = reinterpret_cast<float*>(smem_wh);                   // [16][RUNP]
+        const int ncv = min(128, p.cv - cv0), run = ncv * 9;
+        float* dst = p.part + (((size_t)sl * p.n + n) * p.cu) * p.cv * 9;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                                              // fragment reads / the previous pass's copies are done
+            if (wave_active) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int ml = (rr & 3) + 8 * (rr >> 2) + 4 * lk;  // row within the pass's 16
+                        so[ml * RUNP + (wvid * 32 + l31) * 9 + t] = acc[t][half * 8 + rr] * inv;
+                    }
+            }
+            __syncthreads();
+            if ((p.cv & 3) == 0 && (ncv & 3) == 0) {
+                const int run4 = run >> 2;
+                for (int e = tid; e < 16 * run4; e += 256) {
+                    const int row = e / run4, q = e - row * run4, m = cu0 + half * 16 + row;
+                    if (m < p.cu)
+                        *reinterpret_cast<f32x4*>(dst + ((size_t)m * p.cv + cv0) * 9 + 4 * q) = *reinterpret_cast<const f32x4*>(so + row * RUNP + 4 * q);
+                }
+            } else {
+                for (int e = tid; e < 16 * run; e += 256) {
+                    const int row = e / run, q = e - row * run, m = cu0 + half * 16 + row;
+                    if (m < p.cu) dst[((size_t)m * p.cv + cv0) * 9 + q] = so[row * RUNP + q];
+                }
+            }
+        }
+        return;
+    }
     if (!wave_active) return;
     const int cvl = cv0 + wvid * 32 + l31;
     if (cvl >= p.cv) return;
-    const float inv = 1.f / (scu * scv);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -364,29 +415,178 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams 
         }
 }
 
-extern "C" int nb_conv2d_wgrad_h3(const float* u, const float* v, const float* scales, float* a, int n, int cu, int hu, int wu,
-                                  int cv, int hv, int wv, int stride, int pad, void* stream) {
-    NB_REQUIRE(u && v && a && scales, "conv2d_wgrad_h3: null pointer");
-    NB_REQUIRE(n >= 1 && cu >= 1 && cv >= 1 && hu >= 1 && wu >= 1 && hv >= 1 && wv >= 1 && (stride == 1 || stride == 2) && pad >= 0,
-               "conv2d_wgrad_h3: bad sizes (stride 1 or 2)");
-    WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0};
+// a[i] = sum over the `parts` partial blocks (each `count` floats apart), in a fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ a, long long count, int parts, int vec) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i * 4 >= count) return;
+        f32x4 s = *reinterpret_cast<const f32x4*>(part + i * 4);
+        for (int k = 1; k < parts; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * count + i * 4);
+        *reinterpret_cast<f32x4*>(a + i * 4) = s;
+    } else {
+        if (i >= count) return;
+        float s = part[i];
+        for (int k = 1; k < parts; ++k) s += part[(size_t)k * count + i];
+        a[i] = s;
+    }
+}
+
+static void nb_wgrad_h3_slices(int n, int cu, int cv, int hv, int* rows_per_wg, int* nslices) {
     const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
-    static const int wg_target = getenv("NB_WGRAD_WGS") ? atoi(getenv("NB_WGRAD_WGS")) : 256;     // one workgroup per CU: more row slices only add atomic traffic (tools/bench_wgrad.py)
+    static const int wg_target = getenv("NB_WGRAD_WGS") ? atoi(getenv("NB_WGRAD_WGS")) : 256;     // one workgroup per CU
     int slices = (int)((wg_target + tiles - 1) / tiles);
     if (slices > hv) slices = hv;
     if (slices < 1) slices = 1;
-    p.rows_per_wg = nb_cdiv(hv, slices);
-    p.nslices = nb_cdiv(hv, p.rows_per_wg);
+    *rows_per_wg = nb_cdiv(hv, slices);
+    *nslices = nb_cdiv(hv, *rows_per_wg);
+}
+
+extern "C" long long nb_conv2d_wgrad_h3_ws_bytes(int n, int cu, int cv, int hv, int sum_n) {
+    if (n < 1 || cu < 1 || cv < 1 || hv < 1) return 0;
+    int rows, nsl;
+    nb_wgrad_h3_slices(n, cu, cv, hv, &rows, &nsl);
+    const long long parts = (long long)nsl * (sum_n ? n : 1);
+    return parts > 1 ? (long long)nsl * n * cu * cv * 9 * (long long)sizeof(float) : 0;
+}
+
+static int nb_wgrad_h3_impl(const float* u, const float* v, const float* scales, int scales_are_absmax, float* a, float* ws, long long ws_bytes, int sum_n, bool staged,
+                            int n, int cu, int hu, int wu, int cv, int hv, int wv, int stride, int pad, void* stream) {
+    NB_REQUIRE(u && v && a && scales, "conv2d_wgrad_h3: null pointer");
+    NB_REQUIRE(n >= 1 && cu >= 1 && cv >= 1 && hu >= 1 && wu >= 1 && hv >= 1 && wv >= 1 && (stride == 1 || stride == 2) && pad >= 0,
+               "conv2d_wgrad_h3: bad sizes (stride 1 or 2)");
+    WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0, nullptr, 0};
+    p.scales_are_absmax = scales_are_absmax;
+    nb_wgrad_h3_slices(n, cu, cv, hv, &p.rows_per_wg, &p.nslices);
     NB_REQUIRE((long)n * p.nslices <= 65535 && nb_cdiv(cv, 128) <= 65535, "conv2d_wgrad_h3: grid too large");
     const size_t lds = (size_t)(2 * 128 + 2 * 12 * 32) * NB_WHP * sizeof(_Float16);
+    static_assert((size_t)(2 * 128 + 2 * 12 * 32) * NB_WHP * sizeof(_Float16) >= (size_t)16 * (128 * 9 + 4) * sizeof(float), "the output staging rows must fit the operand LDS");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv2d_wgrad_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    (void)hipMemsetAsync(a, 0, (size_t)n * cu * cv * 9 * sizeof(float), (hipStream_t)stream);
+    const long long need = nb_conv2d_wgrad_h3_ws_bytes(n, cu, cv, hv, sum_n);
+    const int parts = p.nslices * (sum_n ? n : 1);
+    if (staged) {
+        NB_REQUIRE(need == 0 || (ws && ws_bytes >= need && (uintptr_t)ws % 16 == 0), "conv2d_wgrad_h3: workspace of %lld bytes (16-byte aligned) needed, got %lld", need, ws_bytes);
+        NB_REQUIRE((uintptr_t)a % 16 == 0, "conv2d_wgrad_h3: output must be 16-byte aligned");
+        p.part = parts > 1 ? ws : a;
+    } else {
+        (void)hipMemsetAsync(a, 0, (size_t)n * cu * cv * 9 * sizeof(float), (hipStream_t)stream);
+    }
     dim3 grid(nb_cdiv(cu, 32), nb_cdiv(cv, 128), n * p.nslices);
     hipLaunchKernelGGL(conv2d_wgrad_h3_kernel, grid, dim3(256), lds, (hipStream_t)stream, p, scales);
     NB_CHECK_LAUNCH("conv2d_wgrad_h3");
+    if (p.part && parts > 1) {
+        // partial blocks are [slice][sample][cu][cv][9]: summing over slices only keeps the sample axis (count = n cu cv 9,
+        // blocks one slice apart); summing over samples as well folds it (count = cu cv 9, nslices * n blocks)
+        const long long count = (long long)(sum_n ? 1 : n) * cu * cv * 9;
+        const int vec = count % 4 == 0;
+        const long long items = vec ? count / 4 : count;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, a, count, parts, vec);
+        NB_CHECK_LAUNCH("wgrad_reduce");
+    }
+    return NB_OK;
+}
+
+extern "C" int nb_conv2d_wgrad_h3(const float* u, const float* v, const float* scales, float* a, int n, int cu, int hu, int wu,
+                                  int cv, int hv, int wv, int stride, int pad, void* stream) {
+    return nb_wgrad_h3_impl(u, v, scales, 0, a, nullptr, 0, 0, false, n, cu, hu, wu, cv, hv, wv, stride, pad, stream);
+}
+
+extern "C" int nb_conv2d_wgrad_h3_ws(const float* u, const float* v, const float* scales, int scales_are_absmax, float* a, float* ws, long long ws_bytes,
+                                     int sum_n, int n, int cu, int hu, int wu, int cv, int hv, int wv, int stride, int pad, void* stream) {
+    return nb_wgrad_h3_impl(u, v, scales, scales_are_absmax, a, ws, ws_bytes, sum_n, true, n, cu, hu, wu, cv, hv, wv, stride, pad, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Range scaling of the split-f16 training path without host round trips or strings of small launches: one launch leaves
+// max|.| of the operands in two device slots, and the kernels that consume the operands derive the power-of-two scale from
+// the slots themselves (nb_pow2_scale).
+// ------------------------------------------------------------------------------------------------
+// slots[0] = max(slots[0], max|a|, max|b|), slots[1] = max(slots[1], max|c|) -- as IEEE bit patterns (non-negative floats
+// order like unsigned integers), so the caller zero-fills the slots once and atomicMax does the rest.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ a, long long na, const float* __restrict__ b, long long nb_,
+                                                     const float* __restrict__ c, long long nc, unsigned* __restrict__ slots) {
+    __shared__ float red[2][4];
+    float m0 = 0.f, m1 = 0.f;
+    const long long step = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    auto scan = [&](const float* p, long long count, float& m) {
+        if (!p) return;
+        const long long n4 = ((uintptr_t)p % 16 == 0) ? count / 4 : 0;
+        for (long long i = t0; i < n4; i += step) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        for (long long i = n4 * 4 + t0; i < count; i += step) m = fmaxf(m, fabsf(p[i]));
+    };
+    scan(a, na, m0); scan(b, nb_, m0); scan(c, nc, m1);
+    for (int o = 32; o > 0; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m0; red[1][threadIdx.x >> 6] = m1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m0 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        m1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        if (m0 > 0.f) atomicMax(slots, __float_as_uint(m0));
+        if (m1 > 0.f) atomicMax(slots + 1, __float_as_uint(m1));
+    }
+}
+
+extern "C" int nb_absmax_f32(const float* a, long long na, const float* b, long long nb_, const float* c, long long nc, void* slots, void* stream) {
+    NB_REQUIRE(slots && na >= 0 && nb_ >= 0 && nc >= 0 && (a || na == 0) && (b || nb_ == 0) && (c || nc == 0), "absmax: bad arguments");
+    const long long most = na > nb_ ? (na > nc ? na : nc) : (nb_ > nc ? nb_ : nc);
+    long long blocks = (most / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, na, b, nb_, c, nc, (unsigned*)slots);
+    NB_CHECK_LAUNCH("absmax");
+    return NB_OK;
+}
+
+typedef _Float16 h8r __attribute__((ext_vector_type(8)));
+// nb_pack_h2_f32 with the range scale folded in: out = H2((x1 ++ x2) * scale[n,c] * k), k = the power of two that brings
+// slots[0] * slots[1] (= max|x| max|scale|) near `target`; workgroup (0,0,0) also leaves dco_out = dco_in / k (the consumer
+// kernel's output coefficients undo the scale).
+__global__ __launch_bounds__(256) void pack_h2_ranged_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,
+                                                             const float* __restrict__ scale, _Float16* __restrict__ out, int c8, int hw,
+                                                             const float* __restrict__ slots, float target, const float* __restrict__ dco_in,
+                                                             float* __restrict__ dco_out, int dco_count) {
+    const float k = nb_pow2_scale(target, slots[0] * slots[1]);
+    if (dco_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        const float ik = 1.f / k;
+        for (int i = threadIdx.x; i < dco_count; i += 256) dco_out[i] = dco_in[i] * ik;
+    }
+    const int n = blockIdx.z, cg = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const int c_in = c1 + c2;
+    h8r hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cg * 8 + j;
+        float v = 0.f;
+        if (ch < c_in) {
+            v = ch < c1 ? x1[((size_t)n * c1 + ch) * hw + pix] : x2[((size_t)n * c2 + (ch - c1)) * hw + pix];
+            v *= scale[(size_t)n * c_in + ch] * k;
+        }
+        const _Float16 hh = (_Float16)v;
+        hi[j] = hh;
+        lo[j] = (_Float16)(v - (float)hh);
+    }
+    h8r* o = reinterpret_cast<h8r*>(out) + ((size_t)(n * c8 + cg) * 2) * hw + pix;
+    o[0] = hi;
+    o[hw] = lo;
+}
+
+extern "C" int nb_pack_h2_ranged_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out_h2, int n, int hw,
+                                     const void* slots, float target, const float* dco_in, float* dco_out, int dco_count, void* stream) {
+    NB_REQUIRE(x1 && out_h2 && scale && slots && c1 > 0 && c2 >= 0 && (c2 == 0 || x2) && n > 0 && n <= 65535 && hw > 0 && target > 0.f,
+               "pack_h2_ranged: bad arguments");
+    NB_REQUIRE(dco_count == 0 || (dco_in && dco_out), "pack_h2_ranged: output coefficients need both pointers");
+    const int c8 = (c1 + c2 + 7) / 8;
+    dim3 grid((hw + 255) / 256, c8, n);
+    hipLaunchKernelGGL(pack_h2_ranged_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, c1, x2, c2, scale, (_Float16*)out_h2, c8, hw,
+                       (const float*)slots, target, dco_in, dco_count ? dco_out : nullptr, dco_count);
+    NB_CHECK_LAUNCH("pack_h2_ranged");
     return NB_OK;
 }

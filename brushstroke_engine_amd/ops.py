@@ -234,7 +234,7 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     _dev(x, "x")
     assert x.ndim == 4
     if f is None:
-        f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+        f = _const(1.0, [1, 1], x.device)
     _dev(f, "f")
     assert f.ndim in (1, 2), "f must be rank 1 or 2"
     upx, upy = _parse_scaling(up)
@@ -292,6 +292,18 @@ def pack_conv_weight(weight: torch.Tensor):
     return wpk, wsq
 
 
+_CONSTS = {}
+
+
+def _const(value: float, shape, device) -> torch.Tensor:
+    """Read-only constant tensors (all-zeros bias, all-ones scales) of the operator wrappers, created once per shape."""
+    key = (float(value), tuple(shape), device.type, device.index)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full(list(shape), float(value), dtype=torch.float32, device=device)
+    return t
+
+
 def _pow2(v: int) -> bool:
     return v >= 4 and (v & (v - 1)) == 0
 
@@ -303,7 +315,7 @@ def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
     if kh == 3 and kw == 3 and stride == 1 and padding == 1 and _pow2(h) and _pow2(wd):
         # the tiled fp32-MFMA kernel of the generator (LDS-staged, 5-20x the generic kernel's rate): its styles / demodulation
         # slots carry the optional channel scales (ones otherwise), identity epilogue
-        ones = lambda c: torch.ones([n, c], dtype=torch.float32, device=x.device)
+        ones = lambda c: _const(1.0, [n, c], x.device)
         return _modulated_conv2d_forward(x, w, ones(ci) if in_scale is None else in_scale, None, up=1, padding=1, demodulate=False,
                                          flip_weight=True, dcoefs=ones(co) if out_scale is None else out_scale)
     ho, wo = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
@@ -321,23 +333,55 @@ def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
 WGRAD_SPLIT_F16 = True
 
 
-def _wgrad_launch(u, v, stride, padding):
+class _RangeSlots:
+    """Zero-filled 4-byte device words for nb_absmax_f32, handed out pairwise from a ring that is re-zeroed with ONE fill per
+    lap (stream order keeps a pair's consumers ahead of the fill that recycles it: everything here runs on the current stream)."""
+    SIZE = 8192
+    _rings = {}
+
+    @classmethod
+    def pair(cls, device) -> torch.Tensor:
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ring = cls._rings.get(key)
+        if ring is None or ring[1] + 4 > cls.SIZE:
+            buf = torch.zeros([cls.SIZE], dtype=torch.int32, device=device) if ring is None else ring[0].zero_()
+            ring = cls._rings[key] = [buf, 0]
+        out = ring[0][ring[1]:ring[1] + 2]
+        ring[1] += 4                                                    # 16-byte pitch
+        return out
+
+
+def _absmax_slots(a, b=None, c=None) -> torch.Tensor:
+    """Two device words: max(|a|, |b|) and max|c| as float bit patterns, in one launch (no host sync)."""
+    slots = _RangeSlots.pair(a.device)
+    ts = [None if t is None else t.detach().contiguous() for t in (a, b, c)]
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().nb_absmax_f32(_p(ts[0]), ts[0].numel(), _p(ts[1]), 0 if ts[1] is None else ts[1].numel(),
+                                            _p(ts[2]), 0 if ts[2] is None else ts[2].numel(), _p(slots), _stream(a)), "absmax")
+    return slots
+
+
+def _wgrad_launch(u, v, stride, padding, sum_n=False):
     n, cu, hu, wu = u.shape
     n2, cv, hv, wv = v.shape
     assert n == n2
-    a = torch.empty([n, cu, cv, 3, 3], dtype=torch.float32, device=u.device)
     if WGRAD_SPLIT_F16:
-        # power-of-two scales that bring each operand's largest magnitude near 2^10 (computed on the device: no sync)
-        mx = torch.stack([_absmax(u), _absmax(v)]).clamp_min(1e-30)
-        scales = torch.exp2(torch.floor(torch.log2(1024.0 / mx))).to(torch.float32).contiguous()
+        # each operand is brought near 2^10 by a power of two the kernel derives from its max-abs slot (no sync, 3 launches)
+        u, v = u.contiguous(), v.contiguous()
+        slots = _absmax_slots(u, None, v)
+        a = torch.empty(([] if sum_n else [n]) + [cu, cv, 3, 3], dtype=torch.float32, device=u.device)
+        L = _lib.lib()
+        nbytes = int(L.nb_conv2d_wgrad_h3_ws_bytes(n, cu, cv, hv, int(sum_n)))
+        ws = torch.empty([nbytes // 4], dtype=torch.float32, device=u.device) if nbytes else None
         with torch.cuda.device(u.device):
-            _lib.check(_lib.lib().nb_conv2d_wgrad_h3(_p(u.contiguous()), _p(v.contiguous()), _p(scales), _p(a), n, cu, hu, wu, cv, hv, wv,
-                                                     stride, padding, _stream(u)), "conv2d_wgrad_h3")
+            _lib.check(L.nb_conv2d_wgrad_h3_ws(_p(u), _p(v), _p(slots), 1, _p(a), _p(ws), nbytes, int(sum_n),
+                                               n, cu, hu, wu, cv, hv, wv, stride, padding, _stream(u)), "conv2d_wgrad_h3")
         return a
+    a = torch.empty([n, cu, cv, 3, 3], dtype=torch.float32, device=u.device)
     with torch.cuda.device(u.device):
         _lib.check(_lib.lib().nb_conv2d_wgrad_f32(_p(u.contiguous()), _p(v.contiguous()), _p(a), n, cu, hu, wu, cv, hv, wv,
                                                   stride, padding, _stream(u)), "conv2d_wgrad")
-    return a
+    return a.sum(dim=0) if sum_n else a
 
 
 def _conv2d_input_grad(dy, w, x_shape, stride, padding):
@@ -389,7 +433,7 @@ class _Conv2dWgrad(torch.autograd.Function):
         assert k in (1, 3), "conv2d weight gradient: 1x1 and 3x3 kernels"
         ctx.stride, ctx.padding, ctx.k = stride, padding, k
         ctx.save_for_backward(x, dy)
-        a = _wgrad_launch(x, dy, stride, padding + (1 if k == 1 else 0)).sum(dim=0)          # [ci, co, 3, 3]
+        a = _wgrad_launch(x, dy, stride, padding + (1 if k == 1 else 0), sum_n=True)         # [ci, co, 3, 3]
         a = a.permute(1, 0, 2, 3)
         return a[:, :, 1:2, 1:2].contiguous() if k == 1 else a.contiguous()
 
@@ -442,7 +486,7 @@ class _ModulatedConv2d(torch.autograd.Function):
         if demodulate:
             d = (styles.detach().square() @ wsq.t() + 1e-8).rsqrt()          # [N, O]  (tiny GEMM: plumbing)
         else:
-            d = torch.ones([n, o], dtype=torch.float32, device=x.device)
+            d = _const(1.0, [n, o], x.device)
         y = _modulated_conv2d_forward(x.detach(), weight.detach(), styles.detach(), None if noise is None else noise.detach(),
                                       up=up, padding=1, resample_filter=resample_filter, demodulate=demodulate,
                                       flip_weight=(up == 1), dcoefs=d)
@@ -622,7 +666,7 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
                 _lib.check(_lib.lib().nb_demod_coefs_f32(_p(styles), _p(wsq), _p(dcoefs), n, i, o, _stream(x)),
                            "demod_coefs")
         else:
-            dcoefs = torch.ones([n, o], dtype=torch.float32, device=x.device)
+            dcoefs = _const(1.0, [n, o], x.device)
     ho, wo = h * up, w_ * up
     noise_stride = 0
     if noise is not None:
@@ -634,21 +678,23 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
         b = bias.contiguous()
         alpha, gain, clamp = 0.2, float(math.sqrt(2) if act_gain is None else act_gain), float(-1 if act_clamp is None else act_clamp)
     else:
-        b = torch.zeros([o], dtype=torch.float32, device=x.device)
+        b = _const(0.0, [o], x.device)
         alpha, gain, clamp = 1.0, 1.0, -1.0     # identity epilogue
     x = x.contiguous()
     x2c = None if x2 is None else x2.contiguous()
     if wpk_given is None and _split_f16_eligible(n, h, w_, up):
-        # split-f16 kernels: (x ++ x2) * styles * 2^k -> H2 operands, weights packed on the device, 2^-k in the output scale
-        mx = _absmax(x)
-        if x2c is not None:
-            mx = torch.maximum(mx, _absmax(x2c))
-        mx = (mx * _absmax(styles)).clamp_min(1e-30)
-        k = torch.exp2(torch.floor(torch.log2(16384.0 / mx)))
-        xh = pack_h2(x, styles * k, x2c)
+        # split-f16 kernels: (x ++ x2) * styles * 2^k -> H2 operands (k from the operands' max-abs, on the device), weights
+        # packed on the device, 2^-k folded into the output coefficients: 5 launches
+        slots = _absmax_slots(x, x2c, styles)
+        dco_in = dcoefs.contiguous()
+        dco = torch.empty_like(dco_in)
+        xh = torch.empty(h2_shape(n, i, h, w_), dtype=torch.float16, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().nb_pack_h2_ranged_f32(_p(x), c1, _p(x2c), c2, _p(styles), _p(xh), n, h * w_, _p(slots), 16384.0,
+                                                        _p(dco_in), _p(dco), dco_in.numel(), _stream(x)), "pack_h2_ranged")
         wh = pack_conv_weight_h3_dev(weight)
         fn = modconv_up1_h3 if up == 1 else modconv_up2_h3
-        return fn(xh, i, wh, dcoefs / k, noise, b, o, act_gain=gain, act_clamp=None if clamp < 0 else clamp, alpha=alpha)
+        return fn(xh, i, wh, dco, noise, b, o, act_gain=gain, act_clamp=None if clamp < 0 else clamp, alpha=alpha)
     y = torch.empty([n, o, ho, wo], dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().nb_modconv3x3_f32(_p(x), c1, _p(x2c), c2, _p(wpk), _p(styles), _p(dcoefs.contiguous()),

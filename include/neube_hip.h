@@ -98,6 +98,26 @@ int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int n, int cu,
 int nb_conv2d_wgrad_h3(const float* u, const float* v, const float* scales, float* a, int n, int cu, int hu, int wu, int cv,
                        int hv, int wv, int stride, int pad, void* stream);
 
+/* The same without atomics (the form the training path uses): every workgroup stores its partial block, one more launch
+ * adds the blocks in a fixed order -- the result is reproducible and a is not zero-filled first.  sum_n != 0 also sums over
+ * the samples: a is [cu,cv,3,3] (what a plain convolution's weight gradient needs; conv2d_gradfix.py:129-137).
+ * ws: device scratch of at least nb_conv2d_wgrad_h3_ws_bytes(...) bytes, 16-byte aligned (may be NULL when that is 0). */
+long long nb_conv2d_wgrad_h3_ws_bytes(int n, int cu, int cv, int hv, int sum_n);
+int nb_conv2d_wgrad_h3_ws(const float* u, const float* v, const float* scales, int scales_are_absmax, float* a, float* ws,
+                          long long ws_bytes, int sum_n, int n, int cu, int hu, int wu, int cv, int hv, int wv, int stride, int pad,
+                          void* stream);
+/* scales_are_absmax != 0: `scales` holds max|u|, max|v| (the two slots nb_absmax_f32 fills) and the kernel derives the powers
+ * of two itself. */
+
+/* Range scaling of the split-f16 training operators (no counterpart in the reference, whose cuDNN path computes in fp32 /
+ * fp16 directly): slots = two 4-byte device words, zero-filled by the caller; afterwards slots[0] = max(|a|, |b|) and
+ * slots[1] = max|c| as float bit patterns (a, b, c may be NULL with a zero count). */
+int nb_absmax_f32(const float* a, long long na, const float* b, long long nb, const float* c, long long nc, void* slots, void* stream);
+/* nb_pack_h2_f32 with the scale derived on the device: out = H2((x1 ++ x2) * scale[n,c] * k), k = the power of two that
+ * brings slots[0] * slots[1] near `target`; also dco_out[i] = dco_in[i] / k for i < dco_count (may be 0). */
+int nb_pack_h2_ranged_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out_h2, int n, int hw,
+                          const void* slots, float target, const float* dco_in, float* dco_out, int dco_count, void* stream);
+
 /* ---- generator path ---------------------------------------------------------------------- */
 
 /* MappingNetwork.forward (training/networks.py:255-290) for c_dim = 0, without the broadcast:

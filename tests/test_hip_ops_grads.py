@@ -187,7 +187,7 @@ def _conv2d_and_wgrad_case(dev, ops):
                                          stride=st, padding=pad) * torch.tensor(osc).double()[:, :, None, None]
         got = ops.conv2d(D(x, dev), D(wt, dev), D(isc, dev), D(osc, dev), stride=st, padding=pad)
         close(got, ref.float().numpy(), 2e-5 * float(ref.abs().max()))
-    for n, cu, cv, hv, wv, st, pad in ((2, 5, 7, 6, 9, 1, 1), (1, 40, 33, 5, 4, 2, 0), (3, 33, 2, 8, 8, 1, 1)):
+    for n, cu, cv, hv, wv, st, pad in ((2, 5, 7, 6, 9, 1, 1), (1, 40, 33, 5, 4, 2, 0), (3, 33, 2, 8, 8, 1, 1), (2, 64, 130, 16, 40, 1, 1), (8, 128, 128, 4, 4, 1, 1)):
         hu, wu = (hv, wv) if st == 1 else (2 * hv + 1, 2 * wv + 1)
         u = rs.randn(n, cu, hu, wu).astype(np.float32); v = rs.randn(n, cv, hv, wv).astype(np.float32)
         up_ = torch.nn.functional.pad(torch.tensor(u).double(), (pad, pad, pad, pad))
@@ -198,6 +198,9 @@ def _conv2d_and_wgrad_case(dev, ops):
                 ref[:, :, :, a, b] = torch.einsum("nuij,nvij->nuv", win, torch.tensor(v).double())
         got = ops.conv2d_wgrad(D(u, dev), D(v, dev), stride=st, padding=pad)
         close(got, ref.float().numpy(), 2e-5 * float(ref.abs().max()))
+        # the sum over the samples inside the launch (what a plain convolution's weight gradient takes)
+        got = ops._wgrad_launch(D(u, dev), D(v, dev), st, pad, sum_n=True)
+        close(got, ref.sum(dim=0).float().numpy(), 2e-5 * float(ref.sum(dim=0).abs().max()))
 
 
 @pytest.mark.parametrize("tag", MG_CASES)
