@@ -202,6 +202,101 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirdnParams p) {
     }
 }
 
+// The configurations the networks actually use (4x4 FIR at up / down 1 or 2, zero stuffing, the separable 1-D passes of the
+// augmentation pipe) with the factors -- and for the 4x4 / 1x1 filters the tap loops -- fixed at compile time: one
+// workgroup = 256 consecutive outputs of one image plane, 32-bit index arithmetic, no division per tap.  (The generic
+// kernel above spends most of its time in 64-bit index divisions: 0.45 TB/s on a 256x256 x 512-plane FIR; this form is
+// bound by the cache path.)  FH = FW = 0: filter size at run time.
+template <int UPX, int UPY, int DX, int DY, int FH, int FW>
+__global__ __launch_bounds__(256) void upfirdn2d_t_kernel(const UpfirdnParams p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if constexpr (FH * FW > 0) {
+        // filter taps in registers (uniform loads), "as correlated with the padded input" and times the gain, like sf[] below
+        float w[FH][FW];
+#pragma unroll
+        for (int fy = 0; fy < FH; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < FW; ++fx) w[fy][fx] = p.f[(p.flip ? fy : FH - 1 - fy) * FW + (p.flip ? fx : FW - 1 - fx)] * p.gain;
+        if (idx >= p.out_h * p.out_w) return;
+        const int oy = idx / p.out_w, ox = idx - oy * p.out_w;
+        const int ux0 = ox * DX - p.padx0, uy0 = oy * DY - p.pady0;
+        // taps that meet a sample of the zero-stuffed image: f = phase + UP t; their input pixel (u0 + f) / UP = base + t may
+        // lie outside the image on either side (masked below), which walks the same taps in the same order as the generic kernel
+        const int phx = ((-ux0) % UPX + UPX) % UPX, phy = ((-uy0) % UPY + UPY) % UPY;
+        const int ixb = (ux0 + phx) / UPX, iyb = (uy0 + phy) / UPY;     // (exact divisions)
+        constexpr int NTY = (FH + UPY - 1) / UPY, NTX = (FW + UPX - 1) / UPX;
+        float wt[NTY][NTX];                                               // this output's taps
+        bool okx[NTX], oky[NTY];
+        int cx[NTX], cy[NTY];
+#pragma unroll
+        for (int tx = 0; tx < NTX; ++tx) { okx[tx] = phx + UPX * tx < FW && ixb + tx >= 0 && ixb + tx < p.in_w; cx[tx] = min(max(ixb + tx, 0), p.in_w - 1); }
+#pragma unroll
+        for (int ty = 0; ty < NTY; ++ty) { oky[ty] = phy + UPY * ty < FH && iyb + ty >= 0 && iyb + ty < p.in_h; cy[ty] = min(max(iyb + ty, 0), p.in_h - 1) * p.in_w; }
+#pragma unroll
+        for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < NTX; ++tx) {
+                float t = 0.f;
+#pragma unroll
+                for (int a = 0; a < UPY; ++a)
+#pragma unroll
+                    for (int b = 0; b < UPX; ++b)
+                        if (a + UPY * ty < FH && b + UPX * tx < FW) t = (phy == a && phx == b) ? w[a + UPY * ty][b + UPX * tx] : t;
+                wt[ty][tx] = t;
+            }
+        for (int m = blockIdx.y; m < p.major; m += gridDim.y) {
+            const float* xm = p.x + (size_t)m * p.in_h * p.in_w;
+            float xv[NTY][NTX];
+#pragma unroll
+            for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < NTX; ++tx) xv[ty][tx] = xm[cy[ty] + cx[tx]];
+            float v = 0.f;
+#pragma unroll
+            for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < NTX; ++tx) {
+                    const float t = xv[ty][tx] * wt[ty][tx];
+                    v = (oky[ty] && okx[tx]) ? v + t : v;
+                }
+            p.y[(size_t)m * p.out_h * p.out_w + idx] = v;
+        }
+    } else {
+        __shared__ float sf[1024];
+        const int fh = p.f_h, fw = p.f_w;
+        for (int i = threadIdx.x; i < fh * fw; i += 256) {
+            const int fy = i / fw, fx = i - fy * fw;
+            const int sy = p.flip ? fy : fh - 1 - fy, sx = p.flip ? fx : fw - 1 - fx;
+            sf[i] = p.f[sy * fw + sx] * p.gain;
+        }
+        __syncthreads();
+        if (idx >= p.out_h * p.out_w) return;
+        const int oy = idx / p.out_w, ox = idx - oy * p.out_w;
+        const int ux0 = ox * DX - p.padx0, uy0 = oy * DY - p.pady0;
+        // first tap that meets a sample of the zero-stuffed image (see the generic kernel)
+        const int fy0 = uy0 >= 0 ? (UPY == 1 ? 0 : (UPY - uy0 % UPY) % UPY) : -uy0;
+        const int fx0 = ux0 >= 0 ? (UPX == 1 ? 0 : (UPX - ux0 % UPX) % UPX) : -ux0;
+        const int iy0 = (uy0 + fy0) / UPY, ix0 = (ux0 + fx0) / UPX;      // (numerators >= 0)
+        for (int m = blockIdx.y; m < p.major; m += gridDim.y) {
+            const float* xm = p.x + (size_t)m * p.in_h * p.in_w;
+            float v = 0.f;
+            for (int fy = fy0, iy = iy0; fy < fh && iy < p.in_h; fy += UPY, ++iy)
+                for (int fx = fx0, ix = ix0; fx < fw && ix < p.in_w; fx += UPX, ++ix) v += xm[iy * p.in_w + ix] * sf[fy * fw + fx];
+            p.y[(size_t)m * p.out_h * p.out_w + idx] = v;
+        }
+    }
+}
+
+template <int UPX, int UPY, int DX, int DY, int FH, int FW>
+static void nb_upfirdn2d_launch_t(const UpfirdnParams& p, hipStream_t st) {
+    const int per_plane = (p.out_h * p.out_w + 255) / 256;
+    // each thread walks several planes (set-up amortised) as long as the launch still has a few thousand workgroups
+    int gy = p.major;
+    while (gy > 1 && (long long)per_plane * gy > 8192 && gy * 4 > p.major) gy = (gy + 1) / 2;
+    if (gy > 65535) gy = 65535;
+    hipLaunchKernelGGL((upfirdn2d_t_kernel<UPX, UPY, DX, DY, FH, FW>), dim3(per_plane, gy), dim3(256), 0, st, p);
+}
+
 extern "C" int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int major, int in_h, int in_w, int f_h,
                                 int f_w, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
                                 int pady1, int flip, float gain, void* stream) {
@@ -217,9 +312,33 @@ extern "C" int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int ma
     p.out_h = (in_h * upy + pady0 + pady1 - f_h + downy) / downy;
     NB_REQUIRE(p.out_w >= 1 && p.out_h >= 1, "upfirdn2d: output must be at least 1x1");
     const long long total = (long long)major * p.out_h * p.out_w;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid), dim3(256), f_h * f_w * sizeof(float), (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    static const bool generic_only = getenv("NB_UPFIRDN_GENERIC") != nullptr;      // developer switch: the run-time-everything kernel
+    const long long plane = (long long)p.out_h * p.out_w, in_plane = (long long)in_h * in_w;
+    const int key = generic_only || plane >= (1LL << 30) || in_plane >= (1LL << 30) ? -1 : ((upx * 4 + upy) * 4 + downx) * 4 + downy;
+    const bool f44 = f_h == 4 && f_w == 4, f11 = f_h == 1 && f_w == 1;
+    bool done = true;
+    switch (key) {
+    case ((1 * 4 + 1) * 4 + 1) * 4 + 1:
+        if (f44) nb_upfirdn2d_launch_t<1, 1, 1, 1, 4, 4>(p, st); else nb_upfirdn2d_launch_t<1, 1, 1, 1, 0, 0>(p, st);
+        break;
+    case ((2 * 4 + 2) * 4 + 1) * 4 + 1:
+        if (f44) nb_upfirdn2d_launch_t<2, 2, 1, 1, 4, 4>(p, st); else if (f11) nb_upfirdn2d_launch_t<2, 2, 1, 1, 1, 1>(p, st); else nb_upfirdn2d_launch_t<2, 2, 1, 1, 0, 0>(p, st);
+        break;
+    case ((1 * 4 + 1) * 4 + 2) * 4 + 2:
+        if (f44) nb_upfirdn2d_launch_t<1, 1, 2, 2, 4, 4>(p, st); else nb_upfirdn2d_launch_t<1, 1, 2, 2, 0, 0>(p, st);
+        break;
+    case ((2 * 4 + 1) * 4 + 1) * 4 + 1: nb_upfirdn2d_launch_t<2, 1, 1, 1, 0, 0>(p, st); break;
+    case ((1 * 4 + 2) * 4 + 1) * 4 + 1: nb_upfirdn2d_launch_t<1, 2, 1, 1, 0, 0>(p, st); break;
+    case ((1 * 4 + 1) * 4 + 2) * 4 + 1: nb_upfirdn2d_launch_t<1, 1, 2, 1, 0, 0>(p, st); break;
+    case ((1 * 4 + 1) * 4 + 1) * 4 + 2: nb_upfirdn2d_launch_t<1, 1, 1, 2, 0, 0>(p, st); break;
+    default: done = false;
+    }
+    if (!done) {
+        int grid = (int)((total + 255) / 256);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid), dim3(256), f_h * f_w * sizeof(float), st, p);
+    }
     NB_CHECK_LAUNCH("upfirdn2d");
     return NB_OK;
 }

@@ -51,6 +51,29 @@ def test_bias_act_kats(dev):
         ops.bias_act(torch.from_numpy(xx), None)       # CPU tensor: no CPU path
 
 
+def test_upfirdn2d_configurations_vs_oracle(dev):
+    """Every specialised launch of nb_upfirdn2d_f32 (4x4 / 1x1 / run-time filters at up / down 1 or 2 per axis, the separable
+    1-D passes) and the generic kernel behind them, on odd sizes with positive, zero and negative padding, against the oracle."""
+    from brushstroke_engine_amd import ops
+    from oracle import neube_oracle as orc
+    rs = np.random.RandomState(5)
+    f44 = ops.setup_filter((1, 3, 3, 1), device=dev)
+    f12 = torch.from_numpy(rs.randn(12).astype(np.float32)).to(dev)
+    f35 = torch.from_numpy(rs.randn(3, 5).astype(np.float32)).to(dev)
+    cases = [(f44, 1, 1, [2, 2, 2, 2], False, 1.0), (f44, 1, 1, [1, 1, 1, 1], True, 4.0), (f44, 2, 1, [2, 1, 2, 1], False, 4.0),
+             (f44, 1, 2, [1, 1, 1, 1], False, 1.0), (f44, 1, 2, [2, 2, 2, 2], True, 1.0), (None, 2, 1, [0, -1, 0, -1], False, 1.0),
+             (f12, 2, 1, [6, 5, 6, 5], False, 4.0), (f12, 1, 2, [3, 3, 3, 3], True, 1.0), (f35, 1, 1, [2, 1, 0, 3], False, 1.5),
+             (f35, 2, 1, [-1, 2, 1, 0], True, 1.0), (f35, 1, 2, [1, 1, 1, 1], False, 1.0), (f35, 3, 2, [2, 2, 2, 2], False, 1.0),
+             (f44, (2, 1), 1, [2, 1, 1, 1], False, 2.0), (f44, 1, (1, 2), [1, 1, 1, 1], False, 1.0)]
+    for shape in ((2, 3, 9, 13), (1, 5, 33, 17)):
+        x = rs.randn(*shape).astype(np.float32)
+        for f, up, down, pad, flip, gain in cases:
+            want = orc.upfirdn2d(torch.from_numpy(x), torch.ones(1, 1) if f is None else f.cpu(), up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+            got = ops.upfirdn2d(D(x, dev), f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+            assert tuple(got.shape) == tuple(want.shape), (shape, up, down, pad)
+            close(got, want, 2e-5 * max(1.0, float(want.abs().max())))
+
+
 def test_upfirdn2d_kats(dev):
     from brushstroke_engine_amd import ops
     k = load_golden("ops_kat.npz")
