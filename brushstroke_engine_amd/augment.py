@@ -72,6 +72,18 @@ def _stack_matrix(rows, like: Optional[torch.Tensor], device):
     return torch.stack(flat, dim=-1).reshape(tuple(shape) + (len(rows), len(rows[0])))
 
 
+class _OneHostThread:
+    """The host-side parameter math below works on tensors of a few dozen floats; torch's CPU operators would fan each of them
+    out over the intra-op thread pool (measured: 1.3 ms for a 64-element max with 8 threads, 17 us with one)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.n)
+
+
 class AugmentPipe(torch.nn.Module):
     def __init__(self, xflip=0, rotate90=0, xint=0, xint_max=0.125,
                  scale=0, rotate=0, aniso=0, xfrac=0, scale_std=0.2, rotate_max=1, aniso_std=0.2, xfrac_std=0.125,
@@ -102,18 +114,37 @@ class AugmentPipe(torch.nn.Module):
             c = bank.shape[1] // 2
             bank[i, c - hi2.size // 2: c - hi2.size // 2 + hi2.size] += hi2
         self.register_buffer("Hz_fbank", torch.as_tensor(bank, dtype=torch.float32))
+        self._fbank_host = torch.as_tensor(bank, dtype=torch.float32)          # host copy for the per-sample tap mixing
 
     # -- random choices ----------------------------------------------------------------------------------------------
+    def _p_value(self) -> float:
+        """The augmentation probability as a python float: read from the device buffer only when it has changed (in-place
+        writes bump the tensor's version counter)."""
+        c = getattr(self, "_p_cache", None)
+        if c is None or c[0] is not self.p or c[1] != self.p._version:
+            c = self._p_cache = (self.p, self.p._version, float(self.p))
+        return c[2]
+
     def _gate(self, value, prob, neutral, shape, dev):
         """``value`` where a uniform draw falls below prob * p, ``neutral`` elsewhere."""
-        keep = torch.rand(shape, device=dev) < prob * self.p
+        keep = torch.rand(shape, device=dev) < prob * self._p_value()
         return torch.where(keep, value, torch.full_like(value, neutral))
 
     def forward(self, images: torch.Tensor, debug_percentile=None) -> torch.Tensor:
+        with _OneHostThread():
+            return self._forward(images, debug_percentile)
+
+    def _forward(self, images: torch.Tensor, debug_percentile=None) -> torch.Tensor:
         assert torch.is_tensor(images) and images.ndim == 4
         B, C, H, W = images.shape
-        dev = images.device
-        dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+        img_dev = images.device
+        # The per-sample random parameters and the 3x3 / 4x4 matrices composed from them are a few hundred scalars: they are
+        # drawn and multiplied on the HOST (torch CPU ops, no launches) and only the finished matrices travel to the device --
+        # the reference builds them from dozens of tiny device kernels and then reads the padding margins back
+        # (augment.py:262-263, a device-to-host sync per call); here nothing waits for the device.
+        dev = torch.device("cpu")
+        p_now = self._p_value()
+        dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32).cpu()
         normal_q = (lambda: torch.erfinv(dp * 2 - 1)) if dp is not None else None         # N(0,1)/sqrt(2) quantile as the reference uses it
         M = lambda rows: _stack_matrix(rows, None, dev)
 
@@ -136,7 +167,7 @@ class AugmentPipe(torch.nn.Module):
             compose(M([[torch.cos(th), torch.sin(-th), 0], [torch.sin(th), torch.cos(th), 0], [0, 0, 1]]))
         if self.xint > 0:
             t = (torch.rand([B, 2], device=dev) * 2 - 1) * self.xint_max
-            t = torch.where(torch.rand([B, 1], device=dev) < self.xint * self.p, t, torch.zeros_like(t))
+            t = torch.where(torch.rand([B, 1], device=dev) < self.xint * p_now, t, torch.zeros_like(t))
             if dp is not None:
                 t = torch.full_like(t, float((dp * 2 - 1) * self.xint_max))
             compose(M([[1, 0, -torch.round(t[:, 0] * W)], [0, 1, -torch.round(t[:, 1] * H)], [0, 0, 1]]))
@@ -145,7 +176,7 @@ class AugmentPipe(torch.nn.Module):
             if dp is not None:
                 s = torch.full_like(s, float(torch.exp2(normal_q() * self.scale_std)))
             compose(M([[1 / s, 0, 0], [0, 1 / s, 0], [0, 0, 1]]))
-        p_rot = 1 - torch.sqrt((1 - self.rotate * self.p).clamp(0, 1))          # P(pre OR post) = rotate * p
+        p_rot = 1 - math.sqrt(min(max(1 - self.rotate * p_now, 0.0), 1.0))          # P(pre OR post) = rotate * p
 
         def rotation(debug_value):
             th = (torch.rand([B], device=dev) * 2 - 1) * math.pi * self.rotate_max
@@ -164,12 +195,12 @@ class AugmentPipe(torch.nn.Module):
             rotation(0.0)
         if self.xfrac > 0:
             t = torch.randn([B, 2], device=dev) * self.xfrac_std
-            t = torch.where(torch.rand([B, 1], device=dev) < self.xfrac * self.p, t, torch.zeros_like(t))
+            t = torch.where(torch.rand([B, 1], device=dev) < self.xfrac * p_now, t, torch.zeros_like(t))
             if dp is not None:
                 t = torch.full_like(t, float(normal_q() * self.xfrac_std))
             compose(M([[1, 0, -t[:, 0] * W], [0, 1, -t[:, 1] * H], [0, 0, 1]]))
         if G is not None:
-            images = self._warp(images, G if G.ndim == 3 else G.expand(B, 3, 3), dev)
+            images = self._warp(images, G if G.ndim == 3 else G.expand(B, 3, 3), dev)      # (G on the host)
 
         # ---- colour: homogeneous 4x4 transform, composed left to right (later stages multiply from the left) ----
         Cm = None
@@ -192,7 +223,7 @@ class AugmentPipe(torch.nn.Module):
             ccompose(M([[c, 0, 0, 0], [0, c, 0, 0], [0, 0, c, 0], [0, 0, 0, 1]]))
         if self.lumaflip > 0:
             i = torch.floor(torch.rand([B, 1, 1], device=dev) * 2)
-            i = torch.where(torch.rand([B, 1, 1], device=dev) < self.lumaflip * self.p, i, torch.zeros_like(i))
+            i = torch.where(torch.rand([B, 1, 1], device=dev) < self.lumaflip * p_now, i, torch.zeros_like(i))
             if dp is not None:
                 i = torch.full_like(i, float(torch.floor(dp * 2)))
             ccompose(eye4 - 2 * vv * i)                                            # Householder reflection about the luma axis
@@ -209,13 +240,14 @@ class AugmentPipe(torch.nn.Module):
                         [0, 0, 0, 1]]))
         if self.saturation > 0 and C > 1:
             s = torch.exp2(torch.randn([B, 1, 1], device=dev) * self.saturation_std)
-            s = torch.where(torch.rand([B, 1, 1], device=dev) < self.saturation * self.p, s, torch.ones_like(s))
+            s = torch.where(torch.rand([B, 1, 1], device=dev) < self.saturation * p_now, s, torch.ones_like(s))
             if dp is not None:
                 s = torch.full_like(s, float(torch.exp2(normal_q() * self.saturation_std)))
             ccompose(vv + (eye4 - vv) * s)
         if Cm is not None:
             if Cm.ndim == 2:
                 Cm = Cm.expand(B, 4, 4)
+            Cm = Cm.contiguous().to(img_dev, non_blocking=True)
             flat = images.reshape(B, C, H * W)
             if C == 3:
                 flat = Cm[:, :3, :3] @ flat + Cm[:, :3, 3:]
@@ -239,7 +271,7 @@ class AugmentPipe(torch.nn.Module):
                 t = torch.ones([B, nb], device=dev)
                 t[:, i] = t_i
                 gain = gain * (t / (power * t.square()).sum(dim=-1, keepdim=True).sqrt())
-            taps = gain @ self.Hz_fbank                                            # [B, taps]: one separable filter per sample
+            taps = (gain @ self._fbank_host).to(img_dev)                        # [B, taps]: one separable filter per sample
             pad = self.Hz_fbank.shape[1] // 2
             x = torch.nn.functional.pad(images, [pad, pad, pad, pad], mode="reflect")
             outs = []
@@ -250,19 +282,20 @@ class AugmentPipe(torch.nn.Module):
         # ---- corruptions ----
         if self.noise > 0:
             sigma = torch.randn([B, 1, 1, 1], device=dev).abs() * self.noise_std
-            sigma = torch.where(torch.rand([B, 1, 1, 1], device=dev) < self.noise * self.p, sigma, torch.zeros_like(sigma))
+            sigma = torch.where(torch.rand([B, 1, 1, 1], device=dev) < self.noise * p_now, sigma, torch.zeros_like(sigma))
             if dp is not None:
                 sigma = torch.full_like(sigma, float(torch.erfinv(dp) * self.noise_std))
-            images = images + torch.randn([B, C, H, W], device=dev) * sigma
+            images = images + torch.randn([B, C, H, W], device=img_dev) * sigma.to(img_dev)
         if self.cutout > 0:
             size = torch.full([B, 2, 1, 1, 1], self.cutout_size, device=dev)
-            size = torch.where(torch.rand([B, 1, 1, 1, 1], device=dev) < self.cutout * self.p, size, torch.zeros_like(size))
+            size = torch.where(torch.rand([B, 1, 1, 1, 1], device=dev) < self.cutout * p_now, size, torch.zeros_like(size))
             center = torch.rand([B, 2, 1, 1, 1], device=dev)
             if dp is not None:
                 size = torch.full_like(size, self.cutout_size)
                 center = torch.full_like(center, float(dp))
-            cx = (torch.arange(W, device=dev).reshape(1, 1, 1, -1) + 0.5) / W
-            cy = (torch.arange(H, device=dev).reshape(1, 1, -1, 1) + 0.5) / H
+            size, center = size.to(img_dev), center.to(img_dev)
+            cx = (torch.arange(W, device=img_dev).reshape(1, 1, 1, -1) + 0.5) / W
+            cy = (torch.arange(H, device=img_dev).reshape(1, 1, -1, 1) + 0.5) / H
             outside = torch.logical_or((cx - center[:, 0]).abs() >= size[:, 0] / 2, (cy - center[:, 1]).abs() >= size[:, 1] / 2)
             images = images * outside.to(torch.float32)
         return images
@@ -279,7 +312,7 @@ class AugmentPipe(torch.nn.Module):
         m = torch.cat([-m, m]).max(dim=1).values                                   # [x0, y0, x1, y1]
         m = m + torch.tensor([hz_pad * 2 - cx, hz_pad * 2 - cy] * 2, dtype=torch.float32, device=dev)
         m = m.max(torch.zeros(4, device=dev)).min(torch.tensor([W - 1, H - 1] * 2, dtype=torch.float32, device=dev))
-        mx0, my0, mx1, my1 = (int(t) for t in m.ceil().to(torch.int32))
+        mx0, my0, mx1, my1 = (int(t) for t in m.ceil().to(torch.int32))           # (host tensors: no device sync)
         images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode="reflect")
         T = lambda tx, ty: torch.tensor([[1, 0, tx], [0, 1, ty], [0, 0, 1]], dtype=torch.float32, device=dev)
         S = lambda sx, sy: torch.tensor([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], dtype=torch.float32, device=dev)
@@ -289,6 +322,6 @@ class AugmentPipe(torch.nn.Module):
         G = T(-0.5, -0.5) @ G @ T(0.5, 0.5)
         shape = [B, C, (H + hz_pad * 2) * 2, (W + hz_pad * 2) * 2]
         G = S(2 / images.shape[3], 2 / images.shape[2]) @ G @ S(shape[3] / 2, shape[2] / 2)
-        grid = torch.nn.functional.affine_grid(theta=G[:, :2, :], size=shape, align_corners=False)
+        grid = torch.nn.functional.affine_grid(theta=G[:, :2, :].contiguous().to(images.device, non_blocking=True), size=shape, align_corners=False)
         images = _GridSample.apply(images, grid)
         return ops.downsample2d(images.contiguous(), self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)

@@ -288,6 +288,35 @@ def random_discriminator_state_dict(img_resolution: int, img_channels: int, chan
     return sd
 
 
+class LazyStats(dict):
+    """Loss statistics of a phase.  Values are kept as detached 0-dim DEVICE tensors and become python floats only when they are
+    read -- the reference's ``training_stats.report`` likewise accumulates on the device (torch_utils/training_stats.py:86-101);
+    reading a loss value between the forward and the backward pass would stall the host until the device has caught up and
+    leave the device idle while the backward pass is being issued."""
+
+    @staticmethod
+    def _f(v):
+        return float(v) if torch.is_tensor(v) else v
+
+    def __getitem__(self, k):
+        return self._f(dict.__getitem__(self, k))
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        return [self._f(v) for v in dict.values(self)]
+
+    def items(self):
+        return [(k, self._f(v)) for k, v in dict.items(self)]
+
+    def update(self, other=(), **kw):
+        for k, v in (dict.items(other) if isinstance(other, dict) else other):
+            dict.__setitem__(self, k, v)
+        for k, v in kw.items():
+            dict.__setitem__(self, k, v)
+
+
 class GanLoss:
     """The adversarial phases of ``ForgerLoss.accumulate_gradients`` (loss_modified.py:140-272): non-saturating logistic
     losses for G and D, the R1 penalty on real images and the path-length regulariser of G (second-order gradient of
@@ -342,7 +371,7 @@ class GanLoss:
         """The training loop's ADA heuristic (training_loop_modified.py: adjust p by the sign of E[sign(D(real))] - target)."""
         if self.augment_pipe is None or self.real_sign_count == 0:
             return 0.0
-        sign = self.real_sign_sum / self.real_sign_count
+        sign = float(self.real_sign_sum) / self.real_sign_count
         adjust = float(np.sign(sign - ada_target)) * (batch_size * ada_interval) / (ada_kimg * 1000)
         self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp(min=0))
         self.real_sign_sum, self.real_sign_count = 0.0, 0
@@ -407,14 +436,14 @@ class GanLoss:
                     "patch1": res["patch1"], "patch2": res["patch2"]}
             loss, vals = self.stitch_phase_losses.compute(data, None)
             loss.mul(gain).backward()
-            stats = {f"Loss/forger/Gstitch/{k}": float(v.detach()) for k, v in vals.items()}
-            stats["Loss/forger/Gstitch/total"] = float(loss.detach())
+            stats = LazyStats({f"Loss/forger/Gstitch/{k}": v.detach() for k, v in vals.items()})
+            stats["Loss/forger/Gstitch/total"] = loss.detach()
             return stats
         finally:
             self._unwrap(self._D).requires_grad_(True)
 
     def _accumulate(self, phase, real_img, geom_feature, gen_z, gain, positions, pl_noise, real_geom=None, G_orig=None) -> Dict[str, float]:
-        stats: Dict[str, float] = {}
+        stats = LazyStats()
         softplus = torch.nn.functional.softplus
         if phase in ("Ggeom", "Ggeom-warm"):                              # loss_modified.py:181-203
             losses = self.geom_warmstart_losses if phase == "Ggeom-warm" else self.geom_phase_losses
@@ -430,7 +459,7 @@ class GanLoss:
                                                    noise_mode=self.noise_mode)
                 loss, vals = losses.compute(data, real_geom)
                 loss.mean().backward()                                    # (no gain: loss_modified.py:203)
-                stats.update({f"Loss/forger/{phase}/{k}": float(v.detach()) for k, v in vals.items()})
+                stats.update({f"Loss/forger/{phase}/{k}": v.detach() for k, v in vals.items()})
         if phase == "Greg" and self.pl_weight != 0:                       # path-length regularisation, loss_modified.py:205-221
             b = max(1, gen_z.shape[0] // self.pl_batch_shrink)
             gen_img, data = self.G(gen_z[:b], None, [g[:b] for g in geom_feature],
@@ -443,37 +472,37 @@ class GanLoss:
             self.pl_mean.copy_(pl_mean.detach())
             pl_penalty = (pl_lengths - pl_mean).square()
             (gen_img[:, 0, 0, 0] * 0 + pl_penalty * self.pl_weight).mean().mul(gain).backward()
-            stats["Loss/pl_penalty"] = float(pl_penalty.mean().detach())
+            stats["Loss/pl_penalty"] = pl_penalty.mean().detach()
         if phase == "Gmain":                                              # maximise logits of generated images
             gen_img, gen_data = self.G(gen_z, None, geom_feature, positions=positions, return_debug_data=True)
             loss = softplus(-self.D(gen_img, None))
-            stats["Loss/G/loss"] = float(loss.mean().detach())
+            stats["Loss/G/loss"] = loss.mean().detach()
             if not self.main_phase_losses.is_empty():                     # loss_modified.py:170-175
                 extra, vals = self.main_phase_losses.compute(gen_data, real_geom)
                 loss = loss + extra
-                stats.update({f"Loss/forger/Gmain/{k}": float(v.detach()) for k, v in vals.items()})
+                stats.update({f"Loss/forger/Gmain/{k}": v.detach() for k, v in vals.items()})
             loss.mean().mul(gain).backward()
         if phase in ("Dmain", "Dall"):                                    # minimise logits of generated images
             with torch.no_grad():
                 gen_img = self.G(gen_z, None, geom_feature, positions=positions)
             loss_gen = softplus(self.D(gen_img, None))
             loss_gen.mean().mul(gain).backward()
-            stats["Loss/D/loss_gen"] = float(loss_gen.mean().detach())
+            stats["Loss/D/loss_gen"] = loss_gen.mean().detach()
         if phase in ("Dmain", "Dreg", "Dall"):                            # maximise logits of real images (+ R1)
             do_main, do_r1 = phase in ("Dmain", "Dall"), phase in ("Dreg", "Dall") and self.r1_gamma != 0
             real = real_img.detach().requires_grad_(do_r1)
             real_logits = self.D(real, None)
-            self.real_sign_sum += float(real_logits.detach().sign().sum())
+            self.real_sign_sum = self.real_sign_sum + real_logits.detach().sign().sum()      # (device tensor: no sync here)
             self.real_sign_count += real_logits.numel()
             total = real_logits * 0
             if do_main:
                 loss_real = softplus(-real_logits)
                 total = total + loss_real
-                stats["Loss/D/loss_real"] = float(loss_real.mean().detach())
+                stats["Loss/D/loss_real"] = loss_real.mean().detach()
             if do_r1:
                 r1_grads, = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real], create_graph=True, only_inputs=True)
                 r1_penalty = r1_grads.square().sum([1, 2, 3])
                 total = total + (r1_penalty * (self.r1_gamma / 2))[:, None]
-                stats["Loss/r1_penalty"] = float(r1_penalty.mean().detach())
+                stats["Loss/r1_penalty"] = r1_penalty.mean().detach()
             total.mean().mul(gain).backward()
         return stats

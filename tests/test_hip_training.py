@@ -261,7 +261,7 @@ def test_config5_full_size_iteration():
             stats.update(loss.accumulate_gradients("Ggeom", real, geom, z, real_geom=real_geom))
             assert finite(G)
             optG.step()
-        assert stats and all(np.isfinite(v) for v in stats.values()), stats
+        assert stats and all(np.isfinite(float(v)) for v in stats.values()), stats
         if it == 0:
             assert {"Loss/G/loss", "Loss/pl_penalty", "Loss/r1_penalty"} <= set(stats), sorted(stats)
     moved = [k for k, p in list(G.named_parameters()) + list(D.named_parameters()) if p.requires_grad and not torch.equal(p, before[k])]

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=16); ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--gpus", type=int, default=1, help="> 1 without a torchrun environment: launch the ranks as a child torchrun")
     ap.add_argument("--geom-interval", type=int, default=200, help="Ggeom phase every N iterations (train_flags.txt:12)")
+    ap.add_argument("--hostprof", action="store_true", help="developer: cProfile of the timed iterations (host side) on stderr")
     a = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         import socket, subprocess
@@ -83,9 +84,17 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    if a.hostprof:
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
     t0 = time.perf_counter()
     for it in range(a.iters):
         iteration(it)
+    if a.hostprof:
+        pr.disable()
+        st = pstats.Stats(pr, stream=sys.stderr)
+        st.sort_stats("cumulative").print_stats(60); st.sort_stats("tottime").print_stats(45)
+    t_issue = time.perf_counter() - t0                   # the host is done issuing; the device may still be working
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -95,6 +104,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "training throughput, images/s (G+D fwd/bwd, lazy path-length and R1 regularisation, ADA bgc)",
                           "value": round(world * n * a.iters / dt, 2), "unit": "img/s", "n_gpus": world, "ms_per_iteration": round(dt / a.iters * 1e3, 2),
+                          "host_issue_ms_per_iteration": round(t_issue / a.iters * 1e3, 2),
                           "config": {"resolution": a.res, "batch_per_gpu": n, "schedule": f"Gmain 1/1, Greg 1/4, Dmain 1/1, Dreg 1/16, Ggeom 1/{a.geom_interval}",
                                      "parallelism": f"data-parallel x{world}" + (" (one all-reduce of the flattened gradients per optimiser step, RCCL)" if world > 1 else "")},
                           "dtype": "f32", "data": "synthetic"}))
