@@ -464,6 +464,73 @@ def conv2d_wgrad(u, v, stride=1, padding=0):
     return _wgrad_launch(u, v, stride, padding)
 
 
+_FIR1331 = None
+
+
+def _is_fir1331(f: torch.Tensor) -> bool:
+    """f is the [1,3,3,1] x [1,3,3,1] / 64 filter the fused up=2 kernels have built in (checked once per tensor)."""
+    if f is None or f.ndim != 2 or tuple(f.shape) != (4, 4):
+        return False
+    tag = getattr(f, "_nb_is_fir1331", None)
+    if tag is None or tag[0] != f._version:
+        global _FIR1331
+        if _FIR1331 is None or _FIR1331.device != f.device:
+            t = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=torch.float32, device=f.device)
+            _FIR1331 = torch.outer(t, t) / 64
+        tag = (f._version, bool(torch.equal(f.detach().to(torch.float32), _FIR1331)))
+        f._nb_is_fir1331 = tag
+    return tag[1]
+
+
+class _Down2Conv2d(torch.autograd.Function):
+    """``conv2d_resample(x, w, f, down=2, padding=1)`` for a 3x3 kernel (conv2d_resample.py:96-113: FIR with padding 2, then the
+    stride-2 correlation) -- the discriminator's down-sampling convolution -- as one differentiable operator, so that its input
+    gradient does not have to be assembled from zero-stuffing + a stride-1 correlation over a 3/4-empty image + the FIR adjoint:
+
+      dx = FIR_adj(convT_{s2}(dy, w)) = 1/4 * [up=2 layer of the generator](dy, weight = w^T)
+
+    (the transposed convolution followed by the same symmetric FIR, up to the gain), i.e. ONE launch of the fused 4-phase up=2
+    kernel; dw is the stride-2 weight-gradient correlation of the filtered input with dy.  Under create_graph (R1) the gradient
+    is rebuilt from the generic differentiable operators."""
+
+    @staticmethod
+    def forward(ctx, x, w, f):
+        t = _upfirdn2d_apply(x.contiguous(), f, (1, 1, 1, 1, 2, 2, 2, 2, False, 1.0))
+        y = _conv2d_launch(t, w, None, None, 2, 0)
+        ctx.save_for_backward(x, t, w, f)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, t, w, f = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            inputs = [v for v, need in zip((x, w), ctx.needs_input_grad[:2]) if need]
+            with torch.enable_grad():
+                y2 = conv2d(upfirdn2d(x, f, padding=[2, 2, 2, 2]), w, stride=2, padding=0)
+                grads = list(torch.autograd.grad(y2, inputs, dy, create_graph=True, allow_unused=True))
+            return tuple(grads.pop(0) if need else None for need in ctx.needs_input_grad[:2]) + (None,)
+        dy = dy.contiguous()
+        dx = dw = None
+        n, co = dy.shape[0], dy.shape[1]
+        if ctx.needs_input_grad[0]:
+            wt = w.detach().transpose(0, 1).contiguous()                     # [ci, co, 3, 3]: the up=2 layer's weight
+            dx = _modulated_conv2d_forward(dy, wt, _const(1.0, [n, co], dy.device), None, up=2, padding=1, demodulate=False,
+                                           flip_weight=False, dcoefs=_const(0.25, [n, wt.shape[0]], dy.device))
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad_launch(t, dy, 2, 0, sum_n=True).permute(1, 0, 2, 3).contiguous()
+        return dx, dw, None
+
+
+def conv2d_down2(x, w, f):
+    """FIR (padding 2) + stride-2 3x3 correlation = ``conv2d_resample(x, w, f, down=2, padding=1)`` (conv2d_resample.py:96-113)."""
+    _dev(x, "x"); _dev(w, "w")
+    h, wd = x.shape[2], x.shape[3]
+    fused = (tuple(w.shape[2:]) == (3, 3) and _is_fir1331(f) and h == wd and _pow2(h) and h >= 16)
+    if fused and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _Down2Conv2d.apply(x, w, f)
+    return conv2d(upfirdn2d(x, f, padding=[2, 2, 2, 2]), w, stride=2, padding=0)
+
+
 class _ModulatedConv2d(torch.autograd.Function):
     """First-order gradients of the fused modulated convolution (what autograd + ``conv2d_gradfix`` + the upfirdn2d
     backward give the reference, networks.py:30-88).  With xs = x * s, z = conv_resample(xs, W), y = z * d + noise,

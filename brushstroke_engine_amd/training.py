@@ -221,6 +221,8 @@ class TrainableDiscriminator(torch.nn.Module):
             if k == 1:
                 x = ops.upfirdn2d(x, self.fir, down=down, padding=[p0, p1, p0, p1])
                 x = ops.conv2d(x, w, stride=1, padding=0)
+            elif k == 3 and down == 2 and (p0, p1) == (2, 2):
+                x = ops.conv2d_down2(x, w, self.fir)
             else:
                 x = ops.upfirdn2d(x, self.fir, padding=[p0, p1, p0, p1])
                 x = ops.conv2d(x, w, stride=down, padding=0)
