@@ -69,7 +69,8 @@ PROTOTYPES = {
     "nb_modconv3x3_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nb_pack_h2_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_pack_conv_weight_h3": (C.c_int, [vp, C.c_int, C.c_int, vp]),
-    "nb_pack_conv_weight_h3_dev": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "nb_pack_conv_weight_h3_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "nb_conv3x3_s2_valid_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp] + [C.c_int] * 4 + [vp]),
     "nb_modconv3x3_up1_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_float, C.c_float, vp]),
     "nb_modconv3x3_up2_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -175,6 +175,9 @@ struct EncConvParams {
     // cg0 .. of a tensor with c8_total groups, in H2 (hi/lo f16) or "f8" (hi f16 + fp8 correction operands) format
     const float* oscale;
     int oscale_stride, c8_total, cg0, out_f8;
+    // shift = 1 (stride 2 only): no padding -- the window of output (i, j) starts at input (2i, 2j) of a (2 hout + 1) x (2 wout + 1)
+    // input, i.e. the padded form's taps moved one pixel down / right (the training path's stride-2 correlations)
+    int shift;
 };
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -229,9 +232,9 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             const int pl = e / (TH * PW), rem = e - pl * (TH * PW);
             r = rem / PW;
             const int c = rem - r * PW;
-            ix = pl ? nb_reflect(2 * (x0 + c) - 1, p.win) : 2 * (x0 + c);        // odd columns 2j-1 | even columns 2j
+            ix = pl ? nb_reflect(2 * (x0 + c) - 1 + p.shift, p.win) : 2 * (x0 + c) + p.shift;        // odd columns 2j-1 | even columns 2j  (+ shift)
             valid = valid && (pl ? c <= WT : c < WT);
-            xrow[i] = 2 * (y0 + r) - 1;
+            xrow[i] = 2 * (y0 + r) - 1 + p.shift;
         }
         xcol[i] = valid ? ix * 8 : -1;
     }
@@ -414,7 +417,10 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                     const int col = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const int co = co0 + col;
                     float v = 0.f;
-                    if (co < p.c_out) v = nb_lrelu(acc[mb][nb][r] + p.bias[co], p.slope);
+                    if (co < p.c_out) {
+                        v = nb_lrelu(acc[mb][nb][r] + p.bias[co], p.slope);
+                        if (p.oscale) v *= p.oscale[(size_t)n * p.oscale_stride + co];
+                    }
                     ot[col * PIX_WG + (wn * NBW + nb) * 32 + l31] = v;
                 }
         __syncthreads();
@@ -657,17 +663,19 @@ extern "C" void nb_debug_set_enc_small(int mode) { g_enc_small = mode; }
 
 static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2,
                                const float* oscale, int oscale_stride, int c8_total, int cg0, int out_fmt,
-                               int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream, int in_fmt = 0) {
+                               int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream, int in_fmt = 0, int shift = 0) {
     NB_REQUIRE(in_fmt == 0 || (in_fmt == 1 && c_in % 16 == 0), "enc_conv3x3_h3: operand format must be 0 (H2) or 1 (f8, c_in %% 16 == 0)");
     NB_REQUIRE(x_h2 && w_h3 && bias && ((y_f32 != nullptr) != (y_h2 != nullptr)), "enc_conv3x3_h3: need x, w, bias and exactly one output");
     NB_REQUIRE(n >= 1 && n <= 65535 && c_in >= 1 && c_out >= 1 && (stride == 1 || stride == 2), "enc_conv3x3_h3: bad sizes");
-    NB_REQUIRE(h_in % stride == 0 && w_in % stride == 0 && h_in >= 2 && w_in >= 2, "enc_conv3x3_h3: bad input size %dx%d", h_in, w_in);
-    const int ho = h_in / stride, wo = w_in / stride;
+    NB_REQUIRE(shift == 0 || (shift == 1 && stride == 2 && in_fmt == 0 && y_f32 && h_in % 2 == 1 && w_in % 2 == 1 && h_in >= 3 && w_in >= 3),
+               "conv3x3_s2_valid_h3: needs H2 operands, an fp32 destination and an odd input size (got %dx%d)", h_in, w_in);
+    NB_REQUIRE(shift || (h_in % stride == 0 && w_in % stride == 0 && h_in >= 2 && w_in >= 2), "enc_conv3x3_h3: bad input size %dx%d", h_in, w_in);
+    const int ho = shift ? (h_in - 1) / 2 : h_in / stride, wo = shift ? (w_in - 1) / 2 : w_in / stride;
     const bool wide = wo % 32 == 0 && ho % 8 == 0, narrow = wo == 16 && ho % 16 == 0;
     // the 32-position split-K tiles take any output whose width is a power of two >= 4 (4- and 8-wide images: the encoder's
     // inner layers at patch sizes 32 and 64; rows that do not fill the last tile are masked)
     const bool pow2 = (wo & (wo - 1)) == 0 && wo >= 4;
-    const bool small_ok = pow2 && c_in % 16 == 0 && in_fmt == 0;
+    const bool small_ok = pow2 && c_in % 16 == 0 && in_fmt == 0 && !shift;
     NB_REQUIRE(wide || narrow || small_ok, "enc_conv3x3_h3: output must be a multiple of 32 wide (rows %% 8 == 0), 16 wide (rows %% 16 == 0), or -- H2 "
                "operands, c_in %% 16 == 0 -- a power of two >= 4 wide; got %dx%d", ho, wo);
     NB_REQUIRE(y_f32 || c_out % 8 == 0, "enc_conv3x3_h3: H2 output needs c_out %% 8 == 0");
@@ -678,7 +686,8 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
     NB_REQUIRE(p.zeros, "enc_conv3x3_h3: could not allocate the zero page");
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 127) / 128 * 128;
     p.hin = h_in; p.win = w_in; p.hout = ho; p.wout = wo; p.slope = slope;
-    const bool handoff = oscale != nullptr || c8_total > 0 || out_fmt != 0;
+    const bool handoff = !shift && (oscale != nullptr || c8_total > 0 || out_fmt != 0);
+    p.shift = shift;
     NB_REQUIRE(!handoff || wide || narrow, "enc_conv3x3_h3: the hand-off into a consumer's operand tensor needs the large tiles (output %dx%d)", ho, wo);
     NB_REQUIRE(!handoff || (y_h2 && c8_total >= cg0 + (c_out + 7) / 8 && cg0 >= 0 && (out_fmt == 0 || (out_fmt == 1 && c_out % 16 == 0 && cg0 % 2 == 0))
                             && (!oscale || oscale_stride >= c_out)),
@@ -686,7 +695,7 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
     p.oscale = oscale; p.oscale_stride = oscale_stride; p.c8_total = handoff ? c8_total : (c_out + 7) / 8; p.cg0 = handoff ? cg0 : 0;
     p.out_f8 = out_fmt;
     hipStream_t st = (hipStream_t)stream;
-    if (!handoff && in_fmt == 0) {
+    if (!handoff && in_fmt == 0 && !shift) {
         // under-filled launch (interactive strokes, small batches): the 32 x 32 split-K tiles instead.  Needs whole
         // 16-channel chunks and an output width that is a power of two >= 8 (32 positions = 32 / w rows).
         const long big_wgs = (long)n * (wo / (wide ? 32 : 16)) * (ho / (wide ? 8 : 16)) * ((c_out + 127) / 128);
@@ -738,6 +747,16 @@ extern "C" int nb_enc_conv3x3_h3_handoff(const void* x_h2, int c_in, const void*
     NB_REQUIRE(y_h2 && c8_total > 0, "enc_conv3x3_h3_handoff: needs the consumer's tensor and its channel-group count");
     return nb_enc_conv3x3_impl(x_h2, c_in, w_h3, bias, nullptr, y_h2, oscale, oscale_stride, c8_total, cg0, out_fmt, n, h_in, w_in,
                                c_out, stride, slope, stream);
+}
+
+// Stride-2 3x3 correlation WITHOUT padding on the same kernel (training path: the discriminator's down-sampling convolution
+// after its FIR, and the input gradient of the generator's up=2 layers -- conv2d_resample.py:96-113, :124-147): x H2
+// [n][c8][2][2ho+1][2wo+1][8], y fp32 [n][c_out][ho][wo] = oscale[n][co] * sum x[.., 2i+a, 2j+b] w[co][ci][a][b]; oscale may be NULL.
+extern "C" int nb_conv3x3_s2_valid_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, const float* oscale, int oscale_stride,
+                                      float* y_f32, int n, int h_in, int w_in, int c_out, void* stream) {
+    NB_REQUIRE(!oscale || oscale_stride >= c_out, "conv3x3_s2_valid_h3: output scale rows shorter than c_out");
+    return nb_enc_conv3x3_impl(x_h2, c_in, w_h3, bias, y_f32, nullptr, oscale, oscale_stride, 0, 0, 0, n, h_in, w_in, c_out, 2, 1.0f,
+                               stream, 0, 1);
 }
 
 extern "C" int nb_enc_conv3x3_ex(const void* x, int c_in, const void* wts, const float* bias, float* y_f32, void* y_h2,

@@ -551,7 +551,8 @@ __global__ __launch_bounds__(256) void pack_h2_ranged_kernel(const float* __rest
                                                              const float* __restrict__ scale, _Float16* __restrict__ out, int c8, int hw,
                                                              const float* __restrict__ slots, float target, const float* __restrict__ dco_in,
                                                              float* __restrict__ dco_out, int dco_count) {
-    const float k = nb_pow2_scale(target, slots[0] * slots[1]);
+    const float s1 = slots[1];                                           // (a zero second slot = no second operand)
+    const float k = nb_pow2_scale(target, slots[0] * (s1 > 0.f ? s1 : 1.f));
     if (dco_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
         const float ik = 1.f / k;
         for (int i = threadIdx.x; i < dco_count; i += 256) dco_out[i] = dco_in[i] * ik;

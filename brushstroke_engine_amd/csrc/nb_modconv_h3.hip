@@ -1873,9 +1873,9 @@ __global__ __launch_bounds__(256) void pack_conv_weight_h3_kernel(const float* _
     out[base + co_ld + co] = lo;
 }
 
-extern "C" int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, void* out, void* stream) {
-    NB_REQUIRE(w && out && c_out > 0 && c_in > 0 && (uintptr_t)out % 16 == 0, "pack_conv_weight_h3_dev: bad arguments");
-    const int nch = (c_in + 15) / 16, co_ld = (c_out + 63) / 64 * 64;
+extern "C" int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, int co_align, void* out, void* stream) {
+    NB_REQUIRE(w && out && c_out > 0 && c_in > 0 && (uintptr_t)out % 16 == 0 && (co_align == 64 || co_align == 128), "pack_conv_weight_h3_dev: bad arguments");
+    const int nch = (c_in + 15) / 16, co_ld = (c_out + co_align - 1) / co_align * co_align;
     const int total = nch * 18 * co_ld;
     hipLaunchKernelGGL(pack_conv_weight_h3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, c_out, c_in, co_ld, nch,
                        (h8*)out);

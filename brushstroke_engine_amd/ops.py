@@ -34,7 +34,24 @@ ACT_DEFAULTS = {k: (v[1], v[2]) for k, v in ACT_SPECS.items()}
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return torch._C._cuda_getCurrentRawStream(t.device.index)          # (the handle only: no Stream object per launch)
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _on(device: torch.device):
+    """Context that makes ``device`` current for a launch -- a no-op object when it already is (the usual case: one process per
+    GPU), which saves a device exchange + a context-manager object per launch on the training path's thousands of launches."""
+    return _NOCTX if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -56,7 +73,7 @@ def _bias_act_launch(x, b, xref, yref, dy, grad, dim, cfg):
     act, alpha, gain, clamp = cfg
     size_b, step_b = (b.shape[0], x.stride(dim)) if b is not None else (0, 1)
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().nb_bias_act_grad_f32(_p(x), _p(b), _p(xref), _p(yref), _p(dy), _p(y), x.numel(), size_b, step_b,
                                                    grad, ACT_CODES[act], alpha, gain, clamp, _stream(x)), "bias_act")
     return y
@@ -184,7 +201,7 @@ def _upfirdn2d_launch(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, 
     x = x.contiguous()
     f2d = f2d.contiguous()
     y = torch.empty([n, c, max(oh, 0), max(ow, 0)], dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().nb_upfirdn2d_f32(_p(x), _p(f2d), _p(y), n * c, h, w, fh, fw, upx, upy, downx, downy,
                                                px0, px1, py0, py1, int(bool(flip)), float(gain), _stream(x)),
                    "upfirdn2d")
@@ -318,11 +335,13 @@ def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
         ones = lambda c: _const(1.0, [n, c], x.device)
         return _modulated_conv2d_forward(x, w, ones(ci) if in_scale is None else in_scale, None, up=1, padding=1, demodulate=False,
                                          flip_weight=True, dcoefs=ones(co) if out_scale is None else out_scale)
+    if _s2_valid_h3_eligible(n, ci, h, wd, kh, kw, stride, padding):
+        return _conv2d_s2_valid_h3(x, w, in_scale, out_scale)
     ho, wo = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
     y = torch.empty([n, co, ho, wo], dtype=torch.float32, device=x.device)
     isc = None if in_scale is None else in_scale.contiguous()
     osc = None if out_scale is None else out_scale.contiguous()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().nb_conv2d_f32(_p(x.contiguous()), _p(w.contiguous()), _p(isc), _p(osc), _p(y), n, ci, h, wd, co, kh, kw,
                                             stride, padding, _stream(x)), "conv2d")
     return y
@@ -355,7 +374,7 @@ def _absmax_slots(a, b=None, c=None) -> torch.Tensor:
     """Two device words: max(|a|, |b|) and max|c| as float bit patterns, in one launch (no host sync)."""
     slots = _RangeSlots.pair(a.device)
     ts = [None if t is None else t.detach().contiguous() for t in (a, b, c)]
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _lib.check(_lib.lib().nb_absmax_f32(_p(ts[0]), ts[0].numel(), _p(ts[1]), 0 if ts[1] is None else ts[1].numel(),
                                             _p(ts[2]), 0 if ts[2] is None else ts[2].numel(), _p(slots), _stream(a)), "absmax")
     return slots
@@ -373,12 +392,12 @@ def _wgrad_launch(u, v, stride, padding, sum_n=False):
         L = _lib.lib()
         nbytes = int(L.nb_conv2d_wgrad_h3_ws_bytes(n, cu, cv, hv, int(sum_n)))
         ws = torch.empty([nbytes // 4], dtype=torch.float32, device=u.device) if nbytes else None
-        with torch.cuda.device(u.device):
+        with _on(u.device):
             _lib.check(L.nb_conv2d_wgrad_h3_ws(_p(u), _p(v), _p(slots), 1, _p(a), _p(ws), nbytes, int(sum_n),
                                                n, cu, hu, wu, cv, hv, wv, stride, padding, _stream(u)), "conv2d_wgrad_h3")
         return a
     a = torch.empty([n, cu, cv, 3, 3], dtype=torch.float32, device=u.device)
-    with torch.cuda.device(u.device):
+    with _on(u.device):
         _lib.check(_lib.lib().nb_conv2d_wgrad_f32(_p(u.contiguous()), _p(v.contiguous()), _p(a), n, cu, hu, wu, cv, hv, wv,
                                                   stride, padding, _stream(u)), "conv2d_wgrad")
     return a.sum(dim=0) if sum_n else a
@@ -676,16 +695,47 @@ def _absmax(t: torch.Tensor) -> torch.Tensor:
     return torch.maximum(hi, -lo)
 
 
-def pack_conv_weight_h3_dev(weight: torch.Tensor) -> torch.Tensor:
-    """:func:`pack_conv_weight_h3` in one HIP launch (weights that change every step)."""
+def pack_conv_weight_h3_dev(weight: torch.Tensor, co_align: int = 64) -> torch.Tensor:
+    """:func:`pack_conv_weight_h3` in one HIP launch (weights that change every step); ``co_align`` = 128 gives the
+    encoder-type kernels' container."""
     o, i, kh, kw = weight.shape
     assert kh == 3 and kw == 3
     w = weight.detach().to(torch.float32).contiguous()
-    nch, op = (i + 15) // 16, (o + 63) // 64 * 64
+    nch, op = (i + 15) // 16, (o + co_align - 1) // co_align * co_align
     out = torch.empty([nch, 3, 3, 2, 2, op, 8], dtype=torch.float16, device=w.device)
-    with torch.cuda.device(w.device):
-        _lib.check(_lib.lib().nb_pack_conv_weight_h3_dev(_p(w), o, i, _p(out), _stream(w)), "pack_conv_weight_h3_dev")
+    with _on(w.device):
+        _lib.check(_lib.lib().nb_pack_conv_weight_h3_dev(_p(w), o, i, co_align, _p(out), _stream(w)), "pack_conv_weight_h3_dev")
     return out
+
+
+def _s2_valid_h3_eligible(n, ci, h, wd, kh, kw, stride, padding) -> bool:
+    if not (TRAIN_SPLIT_F16 and kh == 3 and kw == 3 and stride == 2 and padding == 0 and h % 2 == 1 and wd % 2 == 1):
+        return False
+    ho, wo = (h - 1) // 2, (wd - 1) // 2
+    return n * ho * wo >= 4096 and ((wo % 32 == 0 and ho % 8 == 0) or (wo == 16 and ho % 16 == 0))
+
+
+def _conv2d_s2_valid_h3(x, w, in_scale, out_scale):
+    """Stride-2 3x3 correlation without padding on the split-f16 kernel (nb_conv3x3_s2_valid_h3): operands range-scaled and
+    packed on the device as in the modulated convolutions; 4 launches."""
+    n, ci, h, wd = x.shape
+    co = w.shape[0]
+    ho, wo = (h - 1) // 2, (wd - 1) // 2
+    x = x.contiguous()
+    isc = _const(1.0, [n, ci], x.device) if in_scale is None else in_scale.contiguous()
+    slots = _absmax_slots(x, None, None if in_scale is None else isc)
+    dco_in = _const(1.0, [n, co], x.device) if out_scale is None else out_scale.contiguous()
+    dco = torch.empty_like(dco_in)
+    xh = torch.empty(h2_shape(n, ci, h, wd), dtype=torch.float16, device=x.device)
+    y = torch.empty([n, co, ho, wo], dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    with _on(x.device):
+        _lib.check(L.nb_pack_h2_ranged_f32(_p(x), ci, None, 0, _p(isc), _p(xh), n, h * wd, _p(slots), 16384.0, _p(dco_in), _p(dco),
+                                           dco_in.numel(), _stream(x)), "pack_h2_ranged")
+        wh = pack_conv_weight_h3_dev(w, co_align=128)
+        _lib.check(L.nb_conv3x3_s2_valid_h3(_p(xh), ci, _p(wh), _p(_const(0.0, [co], x.device)), _p(dco), co, _p(y), n, h, wd, co,
+                                            _stream(x)), "conv3x3_s2_valid_h3")
+    return y
 
 
 def _split_f16_eligible(n, h, w_, up) -> bool:
@@ -729,7 +779,7 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
             if wsq is None:
                 wsq = weight.square().sum(dim=[2, 3]).t().contiguous()
             dcoefs = torch.empty([n, o], dtype=torch.float32, device=x.device)
-            with torch.cuda.device(x.device):
+            with _on(x.device):
                 _lib.check(_lib.lib().nb_demod_coefs_f32(_p(styles), _p(wsq), _p(dcoefs), n, i, o, _stream(x)),
                            "demod_coefs")
         else:
@@ -756,14 +806,14 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
         dco_in = dcoefs.contiguous()
         dco = torch.empty_like(dco_in)
         xh = torch.empty(h2_shape(n, i, h, w_), dtype=torch.float16, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().nb_pack_h2_ranged_f32(_p(x), c1, _p(x2c), c2, _p(styles), _p(xh), n, h * w_, _p(slots), 16384.0,
                                                         _p(dco_in), _p(dco), dco_in.numel(), _stream(x)), "pack_h2_ranged")
         wh = pack_conv_weight_h3_dev(weight)
         fn = modconv_up1_h3 if up == 1 else modconv_up2_h3
         return fn(xh, i, wh, dco, noise, b, o, act_gain=gain, act_clamp=None if clamp < 0 else clamp, alpha=alpha)
     y = torch.empty([n, o, ho, wo], dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().nb_modconv3x3_f32(_p(x), c1, _p(x2c), c2, _p(wpk), _p(styles), _p(dcoefs.contiguous()),
                                                 _p(noise), noise_stride, _p(b), _p(y), n, h, w_, o, up, alpha, gain,
                                                 clamp, _stream(x)), "modulated_conv2d")
@@ -779,7 +829,7 @@ def blend(features, alpha, x):
     x = x.contiguous()
     y = torch.empty_like(x)
     na = n if alpha.numel() == n * h * w and n > 1 else 1
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().nb_blend_f32(_p(features.contiguous()), features.shape[0], _p(alpha.contiguous()), na,
                                            _p(x), _p(y), n, c, h * w, _stream(x)), "blend")
     return y
@@ -861,7 +911,7 @@ def pack_h2f8(x, scale=None, x2=None):
     c2 = 0 if x2 is None else x2.shape[1]
     out = torch.empty(h2_shape(n, c1 + c2, h, w), dtype=torch.float16, device=x.device)
     sc = None if scale is None else scale.contiguous()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().nb_pack_h2f8_f32(_p(x.contiguous()), c1, _p(None if x2 is None else x2.contiguous()), c2,
                                                _p(sc), _p(out), n, h * w, _stream(x)), "pack_h2f8")
     return out
@@ -878,7 +928,7 @@ def pack_h2(x, scale=None, x2=None):
     c2 = 0 if x2 is None else x2.shape[1]
     out = torch.empty(h2_shape(n, c1 + c2, h, w), dtype=torch.float16, device=x.device)
     sc = None if scale is None else scale.contiguous()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().nb_pack_h2_f32(_p(x.contiguous()), c1, _p(None if x2 is None else x2.contiguous()), c2,
                                              _p(sc), _p(out), n, h * w, _stream(x)), "pack_h2")
     return out
@@ -899,7 +949,7 @@ def modconv_up1_h3(x_h2, c_in, w_h3, dcoefs, noise, bias, c_out, act_gain=math.s
     if noise is not None:
         noise = noise.contiguous()
         ns = h * w if noise.numel() == n * h * w and n > 1 else 0
-    with torch.cuda.device(x_h2.device):
+    with _on(x_h2.device):
         _lib.check(_lib.lib().nb_modconv3x3_up1_h3(_p(x_h2), c_in, _p(w_h3), _p(dcoefs.contiguous()), _p(noise), ns,
                                                    _p(bias.contiguous()), _p(y), n, h, w, c_out, alpha, float(act_gain),
                                                    float(-1 if act_clamp is None else act_clamp), _stream(x_h2)),
@@ -915,7 +965,7 @@ def modconv_up2_h3(x_h2, c_in, w_h3, dcoefs, noise, bias, c_out, act_gain=math.s
     if noise is not None:
         noise = noise.contiguous()
         ns = 4 * h * w if noise.numel() == n * 4 * h * w and n > 1 else 0
-    with torch.cuda.device(x_h2.device):
+    with _on(x_h2.device):
         _lib.check(_lib.lib().nb_modconv3x3_up2_h3(_p(x_h2), c_in, _p(w_h3), _p(dcoefs.contiguous()), _p(noise), ns,
                                                    _p(bias.contiguous()), _p(y), n, h, w, c_out, alpha, float(act_gain),
                                                    float(-1 if act_clamp is None else act_clamp), _stream(x_h2)),

@@ -221,7 +221,7 @@ int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, const float
 int nb_pack_conv_weight_h3(const float* w, int c_out, int c_in, void* out);
 /* The same packing on the DEVICE (w and out are device pointers): one launch instead of a host loop -- for weights that
  * change every step (the training path evaluates its 3x3 convolutions on the split-f16 kernels, ops.TRAIN_SPLIT_F16). */
-int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, void* out, void* stream);
+int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, int co_align, void* out, void* stream);
 
 /* SynthesisLayer.forward with up = 1 (networks.py:362-391) on an H2 input:
  * y[n,c_out,h,w] (fp32 NCHW) = clamp(lrelu(conv3x3(x_h2, W) * dcoefs + noise + bias, alpha) * gain).
@@ -461,6 +461,13 @@ int nb_enc_stem7x7_f32_h2_ex(const float* x, const float* w50, const float* bias
 int nb_enc_conv3x3_ex(const void* x, int c_in, const void* wts, const float* bias, float* y_f32, void* y_h2,
                       const float* oscale, int oscale_stride, int c8_total, int cg0, int in_fmt, int out_fmt,
                       int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream);
+
+/* Stride-2 3x3 correlation WITHOUT padding on the same kernel -- the strided half of conv2d_resample's down-sampling branch
+ * (conv2d_resample.py:96-113) and the input gradient of its up-sampling branch (:124-147), which cuDNN runs for the reference:
+ * x H2 [n][c8][2][2ho+1][2wo+1][8], weights as above, y fp32 [n][c_out][ho][wo] = oscale[n][co] * (bias[co] + sum_{ci,a,b}
+ * x[n,ci,2i+a,2j+b] w[co,ci,a,b]); oscale may be NULL.  Output sizes: wo % 32 == 0 and ho % 8 == 0, or wo == 16 and ho % 16 == 0. */
+int nb_conv3x3_s2_valid_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, const float* oscale, int oscale_stride,
+                           float* y_f32, int n, int h_in, int w_in, int c_out, void* stream);
 int nb_enc_upsample2x_h2_ex(const float* x, void* y_h2, int out_fmt, int n, int c, int h, int w, void* stream);
 
 /* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into the zero-padded
