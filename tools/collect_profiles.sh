@@ -40,6 +40,7 @@ python tools/bench_lamali.py > $O/lamali.json 2> $O/lamali.err
 # exchange, pieces replay, gather; the rate means nothing)
 NB_BENCH_SHARE_GPU=1 NB_BENCH_BACKEND=gloo python tools/bench_lamali.py --gpus 2 --steps 3 2> $O/lamali_2ranks.err | grep "^{" > $O/lamali_2ranks_shared_gpu.json
 python tools/bench_train.py > $O/train_bench.json 2> $O/train_bench.err
+bash tools/trace_train.sh 60 > $O/train_trace.txt 2>&1; python tools/trace_train_agg.py > $O/train_trace_by_kernel.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 rm -rf $O/stats_* $O/pmc_hit_* $O/pmc_fetch_* $O/pmc_write_* $O/pmc_mfma_f8 $O/pmc_mfma_h3
 ls $O; tail -c 400 $O/bench.json; tail -2 $O/smoke.txt
