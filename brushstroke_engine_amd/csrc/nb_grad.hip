@@ -269,16 +269,40 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams 
         hi[0] = ah; hi[1] = bh;
         lo[0] = (_Float16)(a - (float)ah); lo[1] = (_Float16)(b - (float)bh);
     };
-    auto load_v = [&](int i, int jc, float (&r)[VPT][2]) {
+    // Operand fetch without a branch per element: which of a thread's pixel pairs exist (channel tail, image border, padding
+    // columns) depends only on the column chunk, so per chunk every pair gets an always-valid element offset and two mask bits;
+    // the row loop then issues plain loads from (row base + offset) and selects zeros.  (The bounds-checked form compiled to 336
+    // branches per row and was bound by instruction issue: ~6 us per 32-pixel row chunk for 0.8 us of matrix work.)
+    int voff[VPT], uoff0[UPT], uoff1[UPT];
+    unsigned vmask = 0, umask = 0;                                       // bits 2k / 2k+1: first / second pixel of pair k exists
+    auto setup_chunk = [&](int jc) {
+        vmask = 0; umask = 0;
 #pragma unroll
         for (int k = 0; k < VPT; ++k) {
             const int idx = k * 256 + tid, c = idx / HP, j = 2 * (idx - c * HP);
-            r[k][0] = r[k][1] = 0.f;
-            if (cv0 + c < p.cv && i < p.hv) {
-                const float* row = vn + ((size_t)(cv0 + c) * p.hv + i) * p.wv;
-                if (jc + j < p.wv) r[k][0] = row[jc + j];
-                if (jc + j + 1 < p.wv) r[k][1] = row[jc + j + 1];
-            }
+            const bool okc = cv0 + c < p.cv, b0 = okc && jc + j < p.wv, b1 = okc && jc + j + 1 < p.wv;
+            voff[k] = b0 ? (cv0 + c) * p.hv * p.wv + jc + j : 0;
+            vmask |= (b0 ? 1u : 0u) << (2 * k) | (b1 ? 1u : 0u) << (2 * k + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+            const int idx = k * 256 + tid, b = idx / (32 * HP), rem = idx - b * (32 * HP);
+            const int c = rem / HP, j = 2 * (rem - c * HP);
+            const int x0 = (jc + j) * st + b - p.pad, x1 = x0 + st;
+            const bool okc = cu0 + c < p.cu;
+            const bool b0 = okc && x0 >= 0 && x0 < p.wu && jc + j < p.wv, b1 = okc && x1 >= 0 && x1 < p.wu && jc + j + 1 < p.wv;
+            uoff0[k] = b0 ? (cu0 + c) * p.hu * p.wu + x0 : 0;
+            uoff1[k] = b1 ? (cu0 + c) * p.hu * p.wu + x1 : 0;
+            umask |= (b0 ? 1u : 0u) << (2 * k) | (b1 ? 1u : 0u) << (2 * k + 1);
+        }
+    };
+    auto load_v = [&](int i, float (&r)[VPT][2]) {                       // V row i (always inside the image)
+        const float* row = vn + (size_t)i * p.wv;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+            const float a0 = row[voff[k]], a1 = row[voff[k] + ((vmask >> (2 * k + 1)) & 1)];
+            r[k][0] = (vmask >> (2 * k)) & 1 ? a0 : 0.f;
+            r[k][1] = (vmask >> (2 * k + 1)) & 1 ? a1 : 0.f;
         }
     };
     auto store_v = [&](const float (&r)[VPT][2]) {
@@ -291,18 +315,19 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams 
             *reinterpret_cast<h2g*>(svl + c * NB_WHP + j) = lo;
         }
     };
-    auto load_u = [&](int y, int jc, float (&r)[UPT][2]) {               // U row y, its three shifted / decimated copies
+    auto load_u = [&](int y, int part, float (&r)[UPT][2]) {             // U row y (may be a padding row), its three shifted / decimated copies
+        (void)part;
+        if (y >= 0 && y < p.hu) {                                         // (uniform)
+            const float* row = un + (size_t)y * p.wu;
 #pragma unroll
-        for (int k = 0; k < UPT; ++k) {
-            const int idx = k * 256 + tid, b = idx / (32 * HP), rem = idx - b * (32 * HP);
-            const int c = rem / HP, j = 2 * (rem - c * HP);
-            const int x0 = (jc + j) * st + b - p.pad, x1 = x0 + st;
-            r[k][0] = r[k][1] = 0.f;
-            if (cu0 + c < p.cu && y >= 0 && y < p.hu) {
-                const float* row = un + ((size_t)(cu0 + c) * p.hu + y) * p.wu;
-                if (x0 >= 0 && x0 < p.wu && jc + j < p.wv) r[k][0] = row[x0];
-                if (x1 >= 0 && x1 < p.wu && jc + j + 1 < p.wv) r[k][1] = row[x1];
+            for (int k = 0; k < UPT; ++k) {
+                const float a0 = row[uoff0[k]], a1 = row[uoff1[k]];
+                r[k][0] = (umask >> (2 * k)) & 1 ? a0 : 0.f;
+                r[k][1] = (umask >> (2 * k + 1)) & 1 ? a1 : 0.f;
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < UPT; ++k) r[k][0] = r[k][1] = 0.f;
         }
     };
     auto store_u = [&](int y, const float (&r)[UPT][2]) {
@@ -323,15 +348,16 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_h3_kernel(const WgradParams 
         if (i0 >= i1) break;
         __syncthreads();                                                  // previous column chunk's last MFMAs are done
         // prologue of the chunk: V row i0 and the three U rows it needs
-        load_v(i0, jc, rv); store_v(rv);
-        for (int a = 0; a < 3; ++a) { load_u(i0 * st + a - p.pad, jc, ru0); store_u(i0 * st + a - p.pad, ru0); }
+        setup_chunk(jc);
+        load_v(i0, rv); store_v(rv);
+        for (int a = 0; a < 3; ++a) { load_u(i0 * st + a - p.pad, 0, ru0); store_u(i0 * st + a - p.pad, ru0); }
         __syncthreads();
         for (int i = i0; i < i1; ++i) {
             const bool more = i + 1 < i1;
             if (more) {                                                   // next row's operands -> registers (in flight under the MFMAs)
-                load_v(i + 1, jc, rv);
-                if (st == 1) load_u((i + 1) + 2 - p.pad, jc, ru0);
-                else { load_u((i + 1) * 2 + 1 - p.pad, jc, ru0); load_u((i + 1) * 2 + 2 - p.pad, jc, ru1); }
+                load_v(i + 1, rv);
+                if (st == 1) load_u((i + 1) + 2 - p.pad, 0, ru0);
+                else { load_u((i + 1) * 2 + 1 - p.pad, 0, ru0); load_u((i + 1) * 2 + 2 - p.pad, 1, ru1); }
             }
             if (wave_active) {
                 const int vo = (wvid * 32 + l31) * NB_WHP + 8 * lk, uo = l31 * NB_WHP + 8 * lk;
