@@ -1098,12 +1098,16 @@ struct H3Up2Params {
 // positions = 6 blocks, one per wave).
 // (Tried and dropped, DESIGN.md 6: a one-wave-per-SIMD form with 256 accumulators per wave and a hand-ordered K loop, and two
 //  4-wave workgroups per CU on 5-row tiles -- neither was faster.)
-template <bool F8, int TQH, int OUTM = 0, int TQW_ = 32>
-__global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
+// NW_ / NST_ = waves per workgroup / LDS-DMA stages: 8 / 3 (one workgroup per CU), or 4 / 2 on 12 x 16 tiles (14 x 18 = 252
+// positions = 8 column blocks, two per wave; 2 x 36.7 KB of staging) so that TWO workgroups share a CU and one's prologue
+// (first-chunk DMA latency) and epilogue (LDS round trip, FIR, conversions, stores: a quarter to a third of a workgroup's
+// life, no matrix work) run under the other's K loop.
+template <bool F8, int TQH, int OUTM = 0, int TQW_ = 32, int NW_ = 8, int NST_ = NB_H3_STAGES>
+__global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
     if constexpr (OUTM == 2) nb_set_fp16_ovfl();
     nb_stagger(p.stagger_ticks, 256);
-    constexpr int NW = 8, NT = 512, TQW = TQW_, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
+    constexpr int NW = NW_, NT = NW_ * 64, TQW = TQW_, PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;     // 476
     constexpr int NBLK = (NPOS + 31) / 32;            // 15 position blocks
     constexpr int NBJ = (NBLK + NW - 1) / NW;         // blocks per wave (2)
     constexpr int XR = TQH + 3, XS = TQW + 3;         // halo tile 15 x 35 input pixels
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     constexpr int WSLOTS = 36 * 32, NWP = WSLOTS / 64, NWPW = (NWP + NW - 1) / NW;   // 18 -> 3 per wave
     constexpr int NPC = NXPW + NWPW;                  // LDS-DMA pieces a wave issues per chunk (8)
     constexpr int STAGE = 4 * XPL + WSLOTS;           // 16-byte slots per stage
-    constexpr int NST = NB_H3_STAGES;                 // 3
+    constexpr int NST = NST_;                         // 3 (2: the two-workgroups-per-CU form)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
     h8* ring = reinterpret_cast<h8*>(smem_h3);        // [NST][ x: 4 planes x XPL | w: 36 rows x 32 ]
 
@@ -1216,7 +1220,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     //      chunk c+1 (issued a whole chunk ago) has landed; the barrier also frees stage (c-1) % 3 = (c+2) % 3 for the
     //      next chunk's pieces.  The last two chunks issue nothing (own copies of the body: no branch inside it). ----
     const int NC = p.nchunks;
-    static_assert(NST == 3, "ring indices below are written for three stages");
+    static_assert(NST == 3 || NST == 2, "ring indices below are written for three (or two) stages");
     issue(0, ring);
     // the tile's noise values (epilogue operand), computed or fetched while chunk 0 is on its way: with the in-kernel noise
     // (NbNoiseSrc) that is ~150 VALU instructions per thread, which cost 1 us of prologue when they ran ahead of the first DMA
@@ -1235,7 +1239,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         s_noise[e] = v * p.gain;
     }
 
-    if (NC > 1) {
+    if (NC > 1 && NST == 3) {
         issue(1, ring + STAGE);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
     } else {
@@ -1383,7 +1387,17 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
     };
     int c = 0;
     int s_cur = 0;                                    // stage of chunk c
-    for (; c + 2 < NC; ++c) {
+    if constexpr (NST == 2) {
+        // two stages: chunk c+1 lands in the other stage while chunk c is multiplied; the wait at the end of a chunk is for
+        // pieces issued during it -- exposed latency that the co-resident workgroup's matrix work covers
+        for (; c + 1 < NC; ++c) {
+            chunk(std::true_type{}, ring + s_cur * STAGE, c + 1, ring + (s_cur ^ 1) * STAGE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            s_cur ^= 1;
+        }
+    }
+    for (; NST == 3 && c + 2 < NC; ++c) {
         const int s_nn = s_cur == 0 ? 2 : s_cur - 1;  // (c + 2) % 3
         chunk(std::true_type{}, ring + s_cur * STAGE, c + 2, ring + s_nn * STAGE);
         // chunk c+1 has landed (the pieces of c+2 may stay in flight); everybody is done reading chunk c
@@ -1403,7 +1417,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
         chunk(std::false_type{}, ring + s_cur * STAGE, 0, nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        s_cur = s_cur == 2 ? 0 : s_cur + 1;
+        s_cur = s_cur == NST - 1 ? 0 : s_cur + 1;
     }
     if (p.tstamps && tid == 0) {
         unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
@@ -1594,35 +1608,39 @@ __global__ __launch_bounds__(512) void modconv3x3_up2_h3_kernel(const H3Up2Param
 static int g_force_tqh = -1;
 // developer / test hook: 0 = automatic tile choice, NB_H3_TQH or NB_H3_TQH_SMALL = force that tile height
 extern "C" void nb_debug_set_up2_tile(int tqh) { g_force_tqh = tqh; }
-template <int TQH, int TQW, bool F8, int OUTM>
+static int g_force_pair = -1;
+// developer / test hook: -1 = automatic, 0 / 1 = never / always the two-workgroups-per-CU form (4 waves, 12 x 16 tiles, 2 stages)
+extern "C" void nb_debug_set_up2_pair(int mode) { g_force_pair = mode; }
+template <int TQH, int TQW, bool F8, int OUTM, int NW, int NST>
 static int nb_up2_h3_launch1(const H3Up2Params& p, int n, size_t lds, void* stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<F8, TQH, OUTM, TQW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2_h3_kernel<F8, TQH, OUTM, TQW, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<F8, TQH, OUTM, TQW>), grid, dim3(512), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((modconv3x3_up2_h3_kernel<F8, TQH, OUTM, TQW, NW, NST>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2_h3");
     return NB_OK;
 }
 
-template <int TQH, int TQW = 32>
+template <int TQH, int TQW = 32, int NW = 8, int NST = NB_H3_STAGES>
 static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
     p.tiles_x = p.w / TQW;
     p.tiles_y = (p.h + TQH - 1) / TQH;
     p.tstamps = (g_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_tstamps_cap) ? g_tstamps : nullptr;
     constexpr int XPL = (TQH + 3) * (TQW + 3);
     constexpr int NBLK_ = ((TQH + 2) * (TQW + 2) + 31) / 32;
-    constexpr size_t lds_stage = (size_t)NB_H3_STAGES * (4 * XPL + 36 * 32) * 16;
+    constexpr size_t lds_stage = (size_t)NST * (4 * XPL + 36 * 32) * 16;
+    static_assert(NBLK_ <= 2 * NW, "two column blocks per wave at most");
     constexpr size_t lds_epi = (size_t)16 * NBLK_ * 32 * 16;       // epilogue: [2 groups][2 halves][4 phases][positions] x 4 channels fp32
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
     if (in_fmt)
-        return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, true, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, true, 1>(p, n, lds, stream)
-                                                                                              : nb_up2_h3_launch1<TQH, TQW, true, 0>(p, n, lds, stream);
-    return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, false, 2>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, false, 1>(p, n, lds, stream)
-                                                                                           : nb_up2_h3_launch1<TQH, TQW, false, 0>(p, n, lds, stream);
+        return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, true, 2, NW, NST>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, true, 1, NW, NST>(p, n, lds, stream)
+                                                                                              : nb_up2_h3_launch1<TQH, TQW, true, 0, NW, NST>(p, n, lds, stream);
+    return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, false, 2, NW, NST>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, false, 1, NW, NST>(p, n, lds, stream)
+                                                                                           : nb_up2_h3_launch1<TQH, TQW, false, 0, NW, NST>(p, n, lds, stream);
 }
 
 static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
@@ -1659,6 +1677,10 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
     const long wgs_big = (long)n * p.tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * p.slices;
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
+    // two 4-wave workgroups per CU on 12 x 16 tiles (see the kernel's NW_ / NST_) when that launch fills the chip as well
+    static const int env_pair = getenv("NB_UP2_PAIR") ? atoi(getenv("NB_UP2_PAIR")) : 0;
+    const bool pair = g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && wgs_big * 2 >= 1024);
+    if (pair) return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }
 

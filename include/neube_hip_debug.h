@@ -19,6 +19,10 @@ void nb_debug_set_up1_rows(int nbw);
 /* Tile height of the split-f16 up=2 kernel: 0 = automatic, 12 = throughput tiles, 5 = the under-filled (batch-1) tiles. */
 void nb_debug_set_up2_tile(int tqh);
 
+/* Workgroup form of the split-f16 up=2 kernel: -1 = automatic, 0 = 8 waves / 12 x 32 tiles / 3 LDS stages (one workgroup per
+ * CU), 1 = 4 waves / 12 x 16 tiles / 2 stages (two per CU).  tests/test_hip_f8.py asserts both bit-identical. */
+void nb_debug_set_up2_pair(int mode);
+
 /* Tile form of nb_enc_conv3x3_h3: -1 = automatic, 0 = large tiles, 1 = small split-K tiles. */
 void nb_debug_set_enc_small(int mode);
 

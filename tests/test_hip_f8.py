@@ -166,8 +166,9 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for tqh in (12, 5):
-            lib.nb_debug_set_up2_tile(tqh)
+        for tqh in (12, 5, "pair"):
+            lib.nb_debug_set_up2_tile(12 if tqh == "pair" else tqh)
+            lib.nb_debug_set_up2_pair(1 if tqh == "pair" else 0)
             y = torch.empty([n, co, 2 * h, 2 * w], device="cuda")
             out = torch.zeros(ops.h2_shape(n, co, 2 * h, 2 * w), dtype=torch.float16, device="cuda")
             common = (dco.data_ptr(), noise.data_ptr(), 4 * h * w, bias.data_ptr())
@@ -179,8 +180,11 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
             res[tqh] = (y, out)
     finally:
         lib.nb_debug_set_up2_tile(0)
+        lib.nb_debug_set_up2_pair(-1)
     assert torch.equal(res[12][0], res[5][0])
     assert torch.equal(res[12][1], res[5][1])
+    assert torch.equal(res[12][0], res["pair"][0])           # two 4-wave workgroups per CU on 12 x 16 tiles: the same arithmetic
+    assert torch.equal(res[12][1], res["pair"][1])
     # and against float64 (loose: the exact bounds live in test_f8_kernels_vs_float64)
     ref = _conv_ref(x, wt, st, 2) * dco.double().cpu()[:, :, None, None] + noise.double().cpu()[:, None]
     ref = torch.nn.functional.leaky_relu(ref + bias.double().cpu()[None, :, None, None], 0.2) * 1.4142135
