@@ -10,6 +10,7 @@ the CPU or falls back to torch ops.
 from __future__ import annotations
 
 import math
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -357,16 +358,19 @@ class _RangeSlots:
     lap (stream order keeps a pair's consumers ahead of the fill that recycles it: everything here runs on the current stream)."""
     SIZE = 8192
     _rings = {}
+    _lock = threading.Lock()                                            # (forward and autograd threads both come here)
 
     @classmethod
     def pair(cls, device) -> torch.Tensor:
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-        ring = cls._rings.get(key)
-        if ring is None or ring[1] + 4 > cls.SIZE:
-            buf = torch.zeros([cls.SIZE], dtype=torch.int32, device=device) if ring is None else ring[0].zero_()
-            ring = cls._rings[key] = [buf, 0]
-        out = ring[0][ring[1]:ring[1] + 2]
-        ring[1] += 4                                                    # 16-byte pitch
+        key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
+        with cls._lock:
+            ring = cls._rings.get(key)
+            if ring is None or ring[1] + 4 > cls.SIZE:
+                with _on(device):
+                    buf = torch.zeros([cls.SIZE], dtype=torch.int32, device=device) if ring is None else ring[0].zero_()
+                ring = cls._rings[key] = [buf, 0]
+            out = ring[0][ring[1]:ring[1] + 2]
+            ring[1] += 4                                                # 16-byte pitch
         return out
 
 

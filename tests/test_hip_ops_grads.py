@@ -221,3 +221,63 @@ def test_modulated_conv2d_double_backward_golden(dev, mg, tag):
     for got, name in zip(g2, ("pl_dx", "pl_dw", "pl_ds")):
         want = mg[f"{tag}_{name}"]
         close(got, want, 5e-4 * max(1e-6, float(np.abs(want).max())))
+
+
+def test_absmax_slots_and_ranged_pack(dev):
+    """The training path's range scaling: nb_absmax_f32 leaves max|.| of up to three tensors in two device words (16-byte
+    aligned and unaligned inputs, ragged counts, an absent operand), and nb_pack_h2_ranged_f32 = nb_pack_h2_f32 with the power
+    of two derived from them (2^floor(log2(target / (max|x| max|s|))): checked against torch), plus the rescaled coefficients."""
+    from brushstroke_engine_amd import ops, _lib
+    rs = np.random.RandomState(11)
+    a = torch.from_numpy(rs.randn(3, 5, 7, 11).astype(np.float32) * 37).to(dev)
+    big = torch.from_numpy(rs.randn(1 << 20).astype(np.float32)).to(dev)
+    b = big[1:1 + 100003]                                   # 4-byte aligned only
+    c = torch.from_numpy(rs.randn(2, 9).astype(np.float32) * 1e-3).to(dev)
+    got = ops._absmax_slots(a, b, c).view(torch.float32).cpu().numpy()
+    assert got[0] == max(float(a.abs().max()), float(b.abs().max())) and got[1] == float(c.abs().max())
+    got = ops._absmax_slots(big).view(torch.float32).cpu().numpy()
+    assert got[0] == float(big.abs().max()) and got[1] == 0.0
+    # ranged pack vs the plain pack with the scale spelled out
+    n, c1, c2, h, w = 2, 12, 5, 16, 32
+    x = torch.from_numpy(rs.randn(n, c1, h, w).astype(np.float32) * 300).to(dev)
+    x2 = torch.from_numpy(rs.randn(n, c2, h, w).astype(np.float32) * 1e-2).to(dev)
+    st = torch.from_numpy(rs.uniform(0.2, 3.0, (n, c1 + c2)).astype(np.float32)).to(dev)
+    dco = torch.from_numpy(rs.uniform(0.5, 2.0, (n, 24)).astype(np.float32)).to(dev)
+    slots = ops._absmax_slots(x, x2, st)
+    mx = max(float(x.abs().max()), float(x2.abs().max())) * float(st.abs().max())
+    k = 2.0 ** np.floor(np.log2(16384.0 / mx))
+    out = torch.empty(ops.h2_shape(n, c1 + c2, h, w), dtype=torch.float16, device=dev)
+    dco_out = torch.empty_like(dco)
+    _lib.check(_lib.lib().nb_pack_h2_ranged_f32(x.data_ptr(), c1, x2.data_ptr(), c2, st.data_ptr(), out.data_ptr(), n, h * w, slots.data_ptr(),
+                                               16384.0, dco.data_ptr(), dco_out.data_ptr(), dco.numel(), torch.cuda.current_stream().cuda_stream), "ranged")
+    want = ops.pack_h2(x, st * float(k), x2)
+    assert torch.equal(out, want)
+    assert torch.equal(dco_out, dco / float(k))
+    assert float(ops.unpack_h2(out, c1 + c2).abs().max()) <= 16384.0 * 1.001
+
+
+def test_conv2d_down2_is_fir_plus_strided_conv_with_the_same_gradients(dev):
+    """``ops.conv2d_down2`` (one operator: its input gradient is one launch of the fused up=2 kernel) against the composition it
+    replaces -- ``conv2d(upfirdn2d(x, f, padding=2), w, stride=2)`` on the generic differentiable operators: forward, dx, dw, and
+    the R1-type double backward (gradient of |dy/dx|^2 w.r.t. the weight), at a size the split-f16 kernels take and at a small one."""
+    from brushstroke_engine_amd import ops
+    rs = np.random.RandomState(12)
+    f = ops.setup_filter((1, 3, 3, 1), device=dev)
+    for n, ci, co, h in ((8, 32, 48, 64), (2, 8, 24, 16)):
+        x0 = rs.randn(n, ci, h, h).astype(np.float32)
+        w0 = (rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)
+        g0 = rs.randn(n, co, h // 2, h // 2).astype(np.float32)
+        res = []
+        for fused in (True, False):
+            x, w = D(x0, dev, True), D(w0, dev, True)
+            y = ops.conv2d_down2(x, w, f) if fused else ops.conv2d(ops.upfirdn2d(x, f, padding=[2, 2, 2, 2]), w, stride=2, padding=0)
+            dx, dw = torch.autograd.grad(y, [x, w], D(g0, dev), create_graph=False)
+            # second order: d/dw of sum((dy.sum()/dx)^2) as the R1 penalty forms it
+            x2, w2 = D(x0, dev, True), D(w0, dev, True)
+            y2 = ops.conv2d_down2(x2, w2, f) if fused else ops.conv2d(ops.upfirdn2d(x2, f, padding=[2, 2, 2, 2]), w2, stride=2, padding=0)
+            gx, = torch.autograd.grad(y2.sum(), [x2], create_graph=True)
+            ddw, = torch.autograd.grad(gx.square().sum(), [w2])
+            res.append((y.detach(), dx, dw, ddw))
+        for got, want, name in zip(res[0], res[1], ("y", "dx", "dw", "ddw")):
+            tol = 3e-5 * max(1e-6, float(want.abs().max()))
+            close(got, want.cpu().numpy(), tol)
