@@ -1,6 +1,8 @@
 """Developer tool: which operator calls a training iteration spends its time in.  Wraps the launch helpers of
 brushstroke_engine_amd.ops with HIP-event timing (serialises the step: the totals are kernel times, not the step time)
-and prints the calls grouped by (operator, shapes, stride / padding) over a few iterations of tools/bench_train.py."""
+and prints the calls grouped by (operator, shapes, stride / padding) over a few iterations of tools/bench_train.py.
+Caveat: the wrapped step is host-bound, and an event pair also counts the time the device sat idle waiting for the next launch:
+only entries of a millisecond or more are kernel time; for per-kernel figures use tools/trace_train.sh (rocprofv3 kernel trace)."""
 import collections, os, sys, runpy
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
