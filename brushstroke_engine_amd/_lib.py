@@ -55,6 +55,8 @@ PROTOTYPES = {
     "nb_conv2d_wgrad_h3": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 9 + [vp]),
     "nb_conv2d_wgrad_h3_ws_bytes": (C.c_longlong, [C.c_int] * 5),
     "nb_conv2d_wgrad_h3_ws": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_longlong] + [C.c_int] * 10 + [vp]),
+    "nb_modconv_bwd_dot_f32": (C.c_int, [vp, vp, vp, C.c_longlong, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_modconv_bwd_finish_f32": (C.c_int, [vp, C.c_longlong, C.c_longlong, C.c_longlong, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "nb_absmax_f32": (C.c_int, [vp, C.c_longlong, vp, C.c_longlong, vp, C.c_longlong, vp, vp]),
     "nb_pack_h2_ranged_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_int, vp]),
     "nb_mapping_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
@@ -69,7 +71,7 @@ PROTOTYPES = {
     "nb_modconv3x3_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nb_pack_h2_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_pack_conv_weight_h3": (C.c_int, [vp, C.c_int, C.c_int, vp]),
-    "nb_pack_conv_weight_h3_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "nb_pack_conv_weight_h3_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "nb_conv3x3_s2_valid_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp] + [C.c_int] * 4 + [vp]),
     "nb_modconv3x3_up1_h3": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_float, C.c_float, vp]),

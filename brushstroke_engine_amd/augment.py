@@ -68,8 +68,14 @@ def _stack_matrix(rows, like: Optional[torch.Tensor], device):
     if not tens:
         return torch.tensor(rows, dtype=torch.float32, device=device)
     shape = tens[0].shape
-    flat = [e if torch.is_tensor(e) else torch.full(shape, float(e), dtype=torch.float32, device=device) for e in flat]
-    return torch.stack(flat, dim=-1).reshape(tuple(shape) + (len(rows), len(rows[0])))
+    # constants first (one small tensor built from python floats), then the per-sample entries written into their slots
+    r, c = len(rows), len(rows[0])
+    base = torch.tensor([0.0 if torch.is_tensor(e) else float(e) for e in flat], dtype=torch.float32, device=device)
+    out = base.expand(tuple(shape) + (r * c,)).clone()
+    for k, e in enumerate(flat):
+        if torch.is_tensor(e):
+            out[..., k] = e
+    return out.reshape(tuple(shape) + (r, c))
 
 
 class _OneHostThread:

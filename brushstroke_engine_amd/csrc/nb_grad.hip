@@ -617,3 +617,109 @@ extern "C" int nb_pack_h2_ranged_f32(const float* x1, int c1, const float* x2, i
     NB_CHECK_LAUNCH("pack_h2_ranged");
     return NB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The tail of modulated_conv2d's backward pass in three small launches instead of ~40 torch operators per layer
+// (einsum decompositions, element-wise passes over full activation tensors):
+//   dd[n,o]   = sum_pix dy[n,o,p] * (y[n,o,p] - noise[n,p])                       (nb_modconv_bwd_dot_f32)
+//   dW[o,c,t] = sum_n s[n,c] A[n,o,c,t] + 2 W[o,c,t] sum_n dq[n,o] s[n,c]^2       (nb_modconv_bwd_finish_f32)
+//   ds[n,c]   = sum_{o,t} W[o,c,t] A[n,o,c,t] + 2 s[n,c] sum_o dq[n,o] Wsq[o,c]
+// with A the per-sample weight-gradient correlation in either of the two layouts the wgrad kernel leaves it in
+// ([n][c][o][9] for up = 1, [n][o][c][9] for up = 2: strides are arguments).  Fixed summation orders (no atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void modconv_bwd_dot_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ noise,
+                                                              long long noise_stride_n, float* __restrict__ out, int o, int hw) {
+    __shared__ float red[4];
+    const int plane = blockIdx.x, n = plane / o;
+    const float* a = dy + (size_t)plane * hw;
+    const float* b = y + (size_t)plane * hw;
+    const float* nz = noise ? noise + (size_t)n * noise_stride_n : nullptr;
+    float acc = 0.f;
+    if ((hw & 3) == 0) {
+        for (int i = threadIdx.x; i < hw / 4; i += 256) {
+            const f32x4 u = reinterpret_cast<const f32x4*>(a)[i];
+            f32x4 v = reinterpret_cast<const f32x4*>(b)[i];
+            if (nz) v -= reinterpret_cast<const f32x4*>(nz)[i];
+            acc += (u[0] * v[0] + u[1] * v[1]) + (u[2] * v[2] + u[3] * v[3]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += 256) acc += a[i] * (b[i] - (nz ? nz[i] : 0.f));
+    }
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[plane] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int nb_modconv_bwd_dot_f32(const float* dy, const float* y, const float* noise, long long noise_stride_n, float* out,
+                                      int n, int o, int hw, void* stream) {
+    NB_REQUIRE(dy && y && out && n >= 1 && o >= 1 && hw >= 1 && (long long)n * o <= 0x7fffffffLL, "modconv_bwd_dot: bad arguments");
+    NB_REQUIRE(!noise || (hw & 3) || (((uintptr_t)noise | (uintptr_t)(noise_stride_n * 4)) % 16 == 0), "modconv_bwd_dot: noise planes must be 16-byte aligned");
+    NB_REQUIRE((hw & 3) || (((uintptr_t)dy | (uintptr_t)y) % 16 == 0), "modconv_bwd_dot: tensors must be 16-byte aligned");
+    hipLaunchKernelGGL(modconv_bwd_dot_kernel, dim3(n * o), dim3(256), 0, (hipStream_t)stream, dy, y, noise, noise_stride_n, out, o, hw);
+    NB_CHECK_LAUNCH("modconv_bwd_dot");
+    return NB_OK;
+}
+
+// one thread per (o, c): the nine taps of dW
+__global__ __launch_bounds__(256) void modconv_bwd_dw_kernel(const float* __restrict__ A, long long sn, long long so, long long sc, const float* __restrict__ s,
+                                                             const float* __restrict__ W, const float* __restrict__ dq, float* __restrict__ dW, int n, int o, int c) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= o * c) return;
+    const int io = idx / c, ic = idx - io * c;
+    float acc[9] = {};
+    float q = 0.f;
+    for (int in = 0; in < n; ++in) {
+        const float sv = s[(size_t)in * c + ic];
+        const float* a = A + in * sn + io * so + ic * sc;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += sv * a[t];
+        if (dq) q += dq[(size_t)in * o + io] * (sv * sv);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dW[(size_t)idx * 9 + t] = dq ? acc[t] + 2.f * W[(size_t)idx * 9 + t] * q : acc[t];
+}
+
+// ds: one workgroup per (n, 32 channels); 8 threads share a channel, each summing every 8th output channel, then a fixed-order
+// reduction through LDS
+__global__ __launch_bounds__(256) void modconv_bwd_ds_kernel(const float* __restrict__ A, long long sn, long long so, long long sc, const float* __restrict__ s,
+                                                            const float* __restrict__ W, const float* __restrict__ dq, float* __restrict__ ds, int n, int o, int c) {
+    __shared__ float part[2][8][32];
+    const int ctiles = (c + 31) / 32;
+    const int in = blockIdx.x / ctiles, ic = (blockIdx.x - in * ctiles) * 32 + (threadIdx.x & 31), og = threadIdx.x >> 5;
+    float acc = 0.f, q = 0.f;
+    if (ic < c) {
+        for (int io = og; io < o; io += 8) {
+            const float* a = A + in * sn + io * so + ic * sc;
+            const float* w = W + ((size_t)io * c + ic) * 9;
+            float t1 = 0.f, wsq = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { t1 += w[t] * a[t]; wsq += w[t] * w[t]; }
+            acc += t1;
+            if (dq) q += dq[(size_t)in * o + io] * wsq;
+        }
+    }
+    part[0][og][threadIdx.x & 31] = acc; part[1][og][threadIdx.x & 31] = q;
+    __syncthreads();
+    if (og == 0 && ic < c) {
+        float a_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { a_ += part[0][g][threadIdx.x]; q_ += part[1][g][threadIdx.x]; }
+        const size_t idx = (size_t)in * c + ic;
+        ds[idx] = dq ? a_ + 2.f * s[idx] * q_ : a_;
+    }
+}
+
+extern "C" int nb_modconv_bwd_finish_f32(const float* A, long long a_stride_n, long long a_stride_o, long long a_stride_c, const float* s,
+                                         const float* W, const float* dq, float* dW, float* ds, int n, int o, int c, void* stream) {
+    NB_REQUIRE(A && s && W && (dW || ds) && n >= 1 && o >= 1 && c >= 1, "modconv_bwd_finish: bad arguments");
+    if (dW) {
+        hipLaunchKernelGGL(modconv_bwd_dw_kernel, dim3((o * c + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, a_stride_n, a_stride_o, a_stride_c, s, W, dq, dW, n, o, c);
+        NB_CHECK_LAUNCH("modconv_bwd_dw");
+    }
+    if (ds) {
+        hipLaunchKernelGGL(modconv_bwd_ds_kernel, dim3(n * ((c + 31) / 32)), dim3(256), 0, (hipStream_t)stream, A, a_stride_n, a_stride_o, a_stride_c, s, W, dq, ds, n, o, c);
+        NB_CHECK_LAUNCH("modconv_bwd_ds");
+    }
+    return NB_OK;
+}

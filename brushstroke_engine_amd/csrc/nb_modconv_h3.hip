@@ -1873,8 +1873,10 @@ extern "C" int nb_pack_h2_part_f32(const float* x, int c, const float* scale, in
 
 // Device-side weight packing (same layout as the host helper below): one thread per (chunk, tap, cg, co) writes the hi and lo
 // slots of its 8 channels (zero padding included)
+// tf != 0: w is the weight of the convolution whose INPUT gradient is being computed, [c_in][c_out][3][3] in this call's terms; the
+// packed weight is its transpose with the taps reversed (the transposed convolution's kernel) -- no flipped copy in between.
 __global__ __launch_bounds__(256) void pack_conv_weight_h3_kernel(const float* __restrict__ w, int c_out, int c_in, int co_ld, int nch,
-                                                                  h8* __restrict__ out) {
+                                                                  h8* __restrict__ out, int tf) {
     const int idx = blockIdx.x * 256 + threadIdx.x;             // ((chunk * 9 + tap) * 2 + cg) * co_ld + co
     if (idx >= nch * 18 * co_ld) return;
     const int co = idx % co_ld;
@@ -1885,7 +1887,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_h3_kernel(const float* _
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = ch * 16 + cg * 8 + j;
-        const float v = (co < c_out && ci < c_in) ? w[((size_t)co * c_in + ci) * 9 + tap] : 0.f;
+        const float v = (co < c_out && ci < c_in) ? (tf ? w[((size_t)ci * c_out + co) * 9 + 8 - tap] : w[((size_t)co * c_in + ci) * 9 + tap]) : 0.f;
         const _Float16 hh = (_Float16)v;
         hi[j] = hh;
         lo[j] = (_Float16)(v - (float)hh);
@@ -1895,12 +1897,12 @@ __global__ __launch_bounds__(256) void pack_conv_weight_h3_kernel(const float* _
     out[base + co_ld + co] = lo;
 }
 
-extern "C" int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, int co_align, void* out, void* stream) {
+extern "C" int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, int co_align, int transpose_flip, void* out, void* stream) {
     NB_REQUIRE(w && out && c_out > 0 && c_in > 0 && (uintptr_t)out % 16 == 0 && (co_align == 64 || co_align == 128), "pack_conv_weight_h3_dev: bad arguments");
     const int nch = (c_in + 15) / 16, co_ld = (c_out + co_align - 1) / co_align * co_align;
     const int total = nch * 18 * co_ld;
     hipLaunchKernelGGL(pack_conv_weight_h3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, c_out, c_in, co_ld, nch,
-                       (h8*)out);
+                       (h8*)out, transpose_flip);
     NB_CHECK_LAUNCH("pack_conv_weight_h3_dev");
     return NB_OK;
 }

@@ -297,16 +297,20 @@ def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1):
     return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain)
 
 
-def pack_conv_weight(weight: torch.Tensor):
+def pack_conv_weight(weight: torch.Tensor, want_wsq: bool = True):
     """[O,I,3,3] -> (wpk [ceil8(I), 9, ceil32(O)] zero padded, wsq [I,O]) in the kernels' layout
-    (same as the host helper nb_pack_conv_weight)."""
+    (same as the host helper nb_pack_conv_weight).  ``want_wsq=False``: wsq is None (callers that bring their own
+    demodulation coefficients)."""
     o, i, kh, kw = weight.shape
     assert kh == 3 and kw == 3
     w = weight.detach().to(torch.float32)
     ip, op = (i + 7) // 8 * 8, (o + 31) // 32 * 32
-    wpk = torch.zeros([ip, 9, op], dtype=torch.float32, device=w.device)
-    wpk[:i, :, :o] = w.permute(1, 2, 3, 0).reshape(i, 9, o)
-    wsq = w.square().sum(dim=[2, 3]).t().contiguous()
+    if ip == i and op == o:
+        wpk = w.permute(1, 2, 3, 0).reshape(i, 9, o).contiguous()          # (no padding: one copy)
+    else:
+        wpk = torch.zeros([ip, 9, op], dtype=torch.float32, device=w.device)
+        wpk[:i, :, :o] = w.permute(1, 2, 3, 0).reshape(i, 9, o)
+    wsq = w.square().sum(dim=[2, 3]).t().contiguous() if want_wsq else None
     return wpk, wsq
 
 
@@ -377,7 +381,7 @@ class _RangeSlots:
 def _absmax_slots(a, b=None, c=None) -> torch.Tensor:
     """Two device words: max(|a|, |b|) and max|c| as float bit patterns, in one launch (no host sync)."""
     slots = _RangeSlots.pair(a.device)
-    ts = [None if t is None else t.detach().contiguous() for t in (a, b, c)]
+    ts = [None if t is None else (t if t.is_contiguous() else t.contiguous()) for t in (a, b, c)]      # (pointers only: no detach)
     with _on(a.device):
         _lib.check(_lib.lib().nb_absmax_f32(_p(ts[0]), ts[0].numel(), _p(ts[1]), 0 if ts[1] is None else ts[1].numel(),
                                             _p(ts[2]), 0 if ts[2] is None else ts[2].numel(), _p(slots), _stream(a)), "absmax")
@@ -413,6 +417,12 @@ def _conv2d_input_grad(dy, w, x_shape, stride, padding):
     rows / columns where the forward window never reached."""
     kh, kw = w.shape[2], w.shape[3]
     h, wd = x_shape[2], x_shape[3]
+    if (not torch.is_grad_enabled() and stride == 1 and kh == 3 and kw == 3 and padding == 1 and _pow2(h) and _pow2(wd)
+            and tuple(dy.shape[2:]) == (h, wd)):
+        # first-order pass: the tiled kernels take the forward weight and pack its transposed, tap-reversed form themselves
+        n = dy.shape[0]
+        return _modulated_conv2d_forward(dy.contiguous(), w.detach(), _const(1.0, [n, w.shape[0]], dy.device), None, up=1, padding=1,
+                                         demodulate=False, flip_weight=True, dcoefs=_const(1.0, [n, w.shape[1]], dy.device), weight_tf=True)
     if stride > 1:
         dy = upfirdn2d(dy, None, up=stride, padding=[0, -(stride - 1), 0, -(stride - 1)])
     assert kh - 1 - padding >= 0 and kw - 1 - padding >= 0, "conv2d gradient: padding larger than kernel - 1"
@@ -615,11 +625,12 @@ class _ModulatedConv2d(torch.autograd.Function):
         wd = weight.detach()
         if up == 1:
             if need_x:
-                wt = wd.transpose(0, 1).flip([2, 3]).contiguous()           # [C, O, 3, 3]
-                dx = _modulated_conv2d_forward(dy, wt, d, None, up=1, padding=1, demodulate=False, flip_weight=True, dcoefs=s)
+                # the correlation with weight^T, taps reversed ([C, O, 3, 3]): packed straight from ``weight``
+                dx = _modulated_conv2d_forward(dy, wd, d, None, up=1, padding=1, demodulate=False, flip_weight=True, dcoefs=s, weight_tf=True)
             if need_w or need_s:
                 dz = dy * d[:, :, None, None]
-                A = conv2d_wgrad(x.detach(), dz, stride=1, padding=1).permute(0, 2, 1, 3, 4)     # [N, O, C, 3, 3]
+                A = conv2d_wgrad(x.detach(), dz, stride=1, padding=1)        # [N, C, O, 3, 3]
+                a_strides = (c * o * 9, 9, o * 9)                            # element strides of (n, o, c)
         else:
             dz = dy * d[:, :, None, None]
             fh, fw = f.shape
@@ -629,20 +640,29 @@ class _ModulatedConv2d(torch.autograd.Function):
                 dx = conv2d(g1, wd.transpose(0, 1), out_scale=s, stride=2, padding=0)
             if need_w or need_s:
                 A = conv2d_wgrad(g1, x.detach(), stride=2, padding=0)        # [N, O, C, 3, 3]
+                a_strides = (o * c * 9, c * 9, 9)
         if need_w or need_s:
+            # the rest in three small launches (nb_modconv_bwd_dot_f32 / _finish_f32): dd = sum_pix dy (y - noise), then
+            #   dW = sum_n s A + 2 W sum_n dq s^2,   ds = sum_{o,tap} W A + 2 s (dq @ Wsq),   dq = -1/2 d^3 dd / d
+            L = _lib.lib()
+            s_c, w_c = s.contiguous(), wd.contiguous()
             dq = None
-            if ctx.demodulate:
-                z = y if noise is None else y - noise
-                dd = (dy * z).sum(dim=[2, 3]) / d                            # sum_pix dy * (z d) / d
-                dq = -0.5 * d.pow(3) * dd                                    # [N, O]
-            if need_w:
-                dw = torch.einsum("nc,nocab->ocab", s, A)
-                if dq is not None:
-                    dw = dw + 2.0 * wd * torch.einsum("no,nc->oc", dq, s.square())[:, :, None, None]
-            if need_s:
-                ds = torch.einsum("ocab,nocab->nc", wd, A)
-                if dq is not None:
-                    ds = ds + 2.0 * s * (dq @ wd.square().sum(dim=[2, 3]))
+            with _on(x.device):
+                if ctx.demodulate:
+                    dd = torch.empty([n, o], dtype=torch.float32, device=x.device)
+                    yc = y.contiguous()
+                    nz, nz_stride = None, 0
+                    if noise is not None:
+                        nz = noise.detach().contiguous()
+                        assert nz.numel() in (yc.shape[2] * yc.shape[3], n * yc.shape[2] * yc.shape[3]), "noise must be one plane or one per sample"
+                        nz_stride = yc.shape[2] * yc.shape[3] if nz.numel() == n * yc.shape[2] * yc.shape[3] and n > 1 else 0
+                    _lib.check(L.nb_modconv_bwd_dot_f32(_p(dy), _p(yc), _p(nz), nz_stride, _p(dd), n, o, yc.shape[2] * yc.shape[3], _stream(x)),
+                               "modconv_bwd_dot")
+                    dq = (-0.5 * d.square() * dd).contiguous()               # -1/2 d^3 (dd / d)
+                dw = torch.empty_like(w_c) if need_w else None
+                ds = torch.empty_like(s_c) if need_s else None
+                _lib.check(L.nb_modconv_bwd_finish_f32(_p(A), a_strides[0], a_strides[1], a_strides[2], _p(s_c), _p(w_c), _p(dq), _p(dw), _p(ds),
+                                                       n, o, c, _stream(x)), "modconv_bwd_finish")
         return dx, dw, ds, dnz, None, None, None
 
 
@@ -690,7 +710,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
 # Operands are brought into the f16 range by a power-of-two scale computed on the device (gradients are tiny, activations can
 # be large) and the result is scaled back in the kernel's output coefficients.  False: the exact-fp32 MFMA kernels.
 TRAIN_SPLIT_F16 = True
-TRAIN_SPLIT_F16_MIN_PIXELS = 128 * 128          # n * h * w from which the large-tile kernels fill the chip
+TRAIN_SPLIT_F16_MIN_PIXELS = 8192               # n * h * w (x up^2) from which the split-f16 kernels are used (measured: 32 x 32 at batch 8 already pays)
 
 
 def _absmax(t: torch.Tensor) -> torch.Tensor:
@@ -699,16 +719,18 @@ def _absmax(t: torch.Tensor) -> torch.Tensor:
     return torch.maximum(hi, -lo)
 
 
-def pack_conv_weight_h3_dev(weight: torch.Tensor, co_align: int = 64) -> torch.Tensor:
+def pack_conv_weight_h3_dev(weight: torch.Tensor, co_align: int = 64, tf: bool = False) -> torch.Tensor:
     """:func:`pack_conv_weight_h3` in one HIP launch (weights that change every step); ``co_align`` = 128 gives the
-    encoder-type kernels' container."""
+    encoder-type kernels' container; ``tf``: pack ``weight.transpose(0, 1).flip([2, 3])`` without materialising it."""
     o, i, kh, kw = weight.shape
+    if tf:
+        o, i = i, o
     assert kh == 3 and kw == 3
     w = weight.detach().to(torch.float32).contiguous()
     nch, op = (i + 15) // 16, (o + co_align - 1) // co_align * co_align
     out = torch.empty([nch, 3, 3, 2, 2, op, 8], dtype=torch.float16, device=w.device)
     with _on(w.device):
-        _lib.check(_lib.lib().nb_pack_conv_weight_h3_dev(_p(w), o, i, co_align, _p(out), _stream(w)), "pack_conv_weight_h3_dev")
+        _lib.check(_lib.lib().nb_pack_conv_weight_h3_dev(_p(w), o, i, co_align, int(tf), _p(out), _stream(w)), "pack_conv_weight_h3_dev")
     return out
 
 
@@ -752,7 +774,7 @@ def _split_f16_eligible(n, h, w_, up) -> bool:
 
 def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                               flip_weight=True, fused_modconv=True, *, bias=None, act_gain=None, act_clamp=None,
-                              fuse_bias_act=False, x2=None, wpk=None, dcoefs=None):
+                              fuse_bias_act=False, x2=None, wpk=None, dcoefs=None, weight_tf=False):
     """3x3 modulated convolution, reference signature ``networks.modulated_conv2d`` (networks.py:30-88).
 
     Only the generator's two configurations exist: (up=1, padding=1, flip_weight=True) and
@@ -764,7 +786,14 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
     """
     _dev(x, "x"); _dev(weight, "weight"); _dev(styles, "styles")
     n, c1 = x.shape[0], x.shape[1]
+    h, w_ = x.shape[2], x.shape[3]
+    if weight_tf and not (wpk is None and _split_f16_eligible(n, h, w_, up)):
+        # (weight_tf: ``weight`` stands for weight.transpose(0, 1).flip([2, 3]) -- only the device pack of the split-f16 path
+        #  takes it as it is)
+        weight, weight_tf = weight.transpose(0, 1).flip([2, 3]).contiguous(), False
     o, i, kh, kw = weight.shape
+    if weight_tf:
+        o, i = i, o
     c2 = 0 if x2 is None else x2.shape[1]
     assert kh == 3 and kw == 3, "only 3x3 kernels are on the generator path (ToRGB is nb_torgb_triad)"
     assert i == c1 + c2 and styles.shape == (n, i), "shape mismatch"   # misc.assert_shape, networks.py:46-48
@@ -774,7 +803,7 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
     wpk_given = wpk
     use_h3 = wpk is None and _split_f16_eligible(n, h, w_, up)
     if wpk is None:
-        wpk, wsq = (None, None) if use_h3 else pack_conv_weight(weight)
+        wpk, wsq = (None, None) if use_h3 else pack_conv_weight(weight, want_wsq=(dcoefs is None and demodulate))
     else:
         wsq = None
     styles = styles.contiguous()
@@ -813,7 +842,7 @@ def _modulated_conv2d_forward(x, weight, styles, noise=None, up=1, down=1, paddi
         with _on(x.device):
             _lib.check(_lib.lib().nb_pack_h2_ranged_f32(_p(x), c1, _p(x2c), c2, _p(styles), _p(xh), n, h * w_, _p(slots), 16384.0,
                                                         _p(dco_in), _p(dco), dco_in.numel(), _stream(x)), "pack_h2_ranged")
-        wh = pack_conv_weight_h3_dev(weight)
+        wh = pack_conv_weight_h3_dev(weight, tf=weight_tf)
         fn = modconv_up1_h3 if up == 1 else modconv_up2_h3
         return fn(xh, i, wh, dco, noise, b, o, act_gain=gain, act_clamp=None if clamp < 0 else clamp, alpha=alpha)
     y = torch.empty([n, o, ho, wo], dtype=torch.float32, device=x.device)

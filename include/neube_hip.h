@@ -109,6 +109,16 @@ int nb_conv2d_wgrad_h3_ws(const float* u, const float* v, const float* scales, i
 /* scales_are_absmax != 0: `scales` holds max|u|, max|v| (the two slots nb_absmax_f32 fills) and the kernel derives the powers
  * of two itself. */
 
+/* The tail of modulated_conv2d's backward pass (what autograd spells out as einsums and element-wise passes in the reference,
+ * training/networks.py:30-88 differentiated): dd[n,o] = sum_pix dy (y - noise) (noise: NULL, one shared plane with stride 0, or one
+ * plane per sample); and, with A[n,o,c,3,3] the per-sample weight-gradient correlation (element strides given: the wgrad kernels
+ * leave it as [n][c][o][9] for up = 1 and [n][o][c][9] for up = 2), s the styles, dq = d(loss)/d(sum under the demodulation rsqrt)
+ * or NULL:  dW[o,c,t] = sum_n s A + 2 W sum_n dq s^2,   ds[n,c] = sum_{o,t} W A + 2 s sum_o dq sum_t W^2.  dW or ds may be NULL. */
+int nb_modconv_bwd_dot_f32(const float* dy, const float* y, const float* noise, long long noise_stride_n, float* out, int n, int o,
+                           int hw, void* stream);
+int nb_modconv_bwd_finish_f32(const float* A, long long a_stride_n, long long a_stride_o, long long a_stride_c, const float* s,
+                              const float* W, const float* dq, float* dW, float* ds, int n, int o, int c, void* stream);
+
 /* Range scaling of the split-f16 training operators (no counterpart in the reference, whose cuDNN path computes in fp32 /
  * fp16 directly): slots = two 4-byte device words, zero-filled by the caller; afterwards slots[0] = max(|a|, |b|) and
  * slots[1] = max|c| as float bit patterns (a, b, c may be NULL with a zero count). */
@@ -220,8 +230,10 @@ int nb_pack_h2_f32(const float* x1, int c1, const float* x2, int c2, const float
  * (bytes: ceil(c_in/16)*9*4*ceil64(c_out)*16). */
 int nb_pack_conv_weight_h3(const float* w, int c_out, int c_in, void* out);
 /* The same packing on the DEVICE (w and out are device pointers): one launch instead of a host loop -- for weights that
- * change every step (the training path evaluates its 3x3 convolutions on the split-f16 kernels, ops.TRAIN_SPLIT_F16). */
-int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, int co_align, void* out, void* stream);
+ * change every step (the training path evaluates its 3x3 convolutions on the split-f16 kernels, ops.TRAIN_SPLIT_F16).
+ * co_align = 64 (modconv kernels) or 128 (encoder-type kernels); transpose_flip != 0: w is [c_in][c_out][3][3] and the packed
+ * weight is its transpose with reversed taps (the kernel of the input-gradient convolution). */
+int nb_pack_conv_weight_h3_dev(const float* w, int c_out, int c_in, int co_align, int transpose_flip, void* out, void* stream);
 
 /* SynthesisLayer.forward with up = 1 (networks.py:362-391) on an H2 input:
  * y[n,c_out,h,w] (fp32 NCHW) = clamp(lrelu(conv3x3(x_h2, W) * dcoefs + noise + bias, alpha) * gain).
