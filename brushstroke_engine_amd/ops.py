@@ -343,6 +343,19 @@ def _conv2d_launch(x, w, in_scale, out_scale, stride, padding):
     if _s2_valid_h3_eligible(n, ci, h, wd, kh, kw, stride, padding):
         return _conv2d_s2_valid_h3(x, w, in_scale, out_scale)
     ho, wo = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
+    if (TRAIN_SPLIT_F16 and kh == 3 and kw == 3 and stride == 1 and padding in (0, 1, 2) and ho >= 16 and wo >= 16
+            and n * ho * wo >= TRAIN_SPLIT_F16_MIN_PIXELS):
+        # odd-sized stride-1 correlations (the zero-stuffed / (2H+1)-sized grids of the create-graph passes and of transposed
+        # convolutions): embed the image -- shifted by padding - 1, so that a "same" convolution reproduces this padding -- in
+        # zeros of a size the tiled kernels take, run those, and cut the result out.  <= 1.4x the multiply-adds for 10-20x the rate
+        # of the generic kernel.
+        sh, off = max(padding - 1, 0), (1 if padding == 0 else 0)          # image shift inside the canvas, offset of the result
+        hp, wp = (max(ho + off, h + sh) + 15) // 16 * 16, (max(wo + off, wd + sh) + 31) // 32 * 32
+        xp = torch.nn.functional.pad(x, (sh, wp - wd - sh, sh, hp - h - sh))
+        ones = lambda c: _const(1.0, [n, c], x.device)
+        yp = _modulated_conv2d_forward(xp.contiguous(), w, ones(ci) if in_scale is None else in_scale, None, up=1, padding=1,
+                                       demodulate=False, flip_weight=True, dcoefs=ones(co) if out_scale is None else out_scale)
+        return yp[:, :, off:off + ho, off:off + wo].contiguous()
     y = torch.empty([n, co, ho, wo], dtype=torch.float32, device=x.device)
     isc = None if in_scale is None else in_scale.contiguous()
     osc = None if out_scale is None else out_scale.contiguous()

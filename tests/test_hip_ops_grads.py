@@ -182,7 +182,9 @@ def _conv2d_and_wgrad_case(dev, ops):
     rs = np.random.RandomState(3)
     # (the last two: stride 2 without padding at sizes the split-f16 stride-2 kernel takes -- 32-wide and 16-wide output tiles)
     for n, ci, co, h, w_, k, st, pad in ((2, 5, 7, 9, 11, 3, 1, 1), (1, 34, 40, 13, 9, 3, 2, 0), (2, 3, 33, 8, 8, 5, 2, 2), (1, 70, 3, 6, 7, 1, 1, 0),
-                                         (8, 24, 40, 33, 65, 3, 2, 0), (16, 20, 70, 33, 33, 3, 2, 0)):
+                                         (8, 24, 40, 33, 65, 3, 2, 0), (16, 20, 70, 33, 33, 3, 2, 0),
+                                         # odd-sized stride-1 correlations: embedded in a tile-able canvas for the split-f16 kernels
+                                         (2, 20, 24, 63, 67, 3, 1, 2), (4, 16, 8, 49, 50, 3, 1, 0), (2, 8, 9, 70, 70, 3, 1, 1)):
         x = rs.randn(n, ci, h, w_).astype(np.float32); wt = rs.randn(co, ci, k, k).astype(np.float32)
         isc = rs.rand(n, ci).astype(np.float32) + 0.5; osc = rs.rand(n, co).astype(np.float32) + 0.5
         ref = torch.nn.functional.conv2d(torch.tensor(x).double() * torch.tensor(isc).double()[:, :, None, None], torch.tensor(wt).double(),
