@@ -78,6 +78,12 @@ def _stack_matrix(rows, like: Optional[torch.Tensor], device):
     return out.reshape(tuple(shape) + (r, c))
 
 
+def _upload(t: torch.Tensor, device) -> torch.Tensor:
+    """Host tensor -> device through page-locked memory: an asynchronous copy in stream order (a pageable source makes the copy
+    wait for the stream to drain, i.e. a host/device sync per augmentation call)."""
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 class _OneHostThread:
     """The host-side parameter math below works on tensors of a few dozen floats; torch's CPU operators would fan each of them
     out over the intra-op thread pool (measured: 1.3 ms for a 64-element max with 8 threads, 17 us with one)."""
@@ -253,7 +259,7 @@ class AugmentPipe(torch.nn.Module):
         if Cm is not None:
             if Cm.ndim == 2:
                 Cm = Cm.expand(B, 4, 4)
-            Cm = Cm.contiguous().to(img_dev, non_blocking=True)
+            Cm = _upload(Cm, img_dev)
             flat = images.reshape(B, C, H * W)
             if C == 3:
                 flat = Cm[:, :3, :3] @ flat + Cm[:, :3, 3:]
@@ -277,7 +283,7 @@ class AugmentPipe(torch.nn.Module):
                 t = torch.ones([B, nb], device=dev)
                 t[:, i] = t_i
                 gain = gain * (t / (power * t.square()).sum(dim=-1, keepdim=True).sqrt())
-            taps = (gain @ self._fbank_host).to(img_dev)                        # [B, taps]: one separable filter per sample
+            taps = _upload(gain @ self._fbank_host, img_dev)                        # [B, taps]: one separable filter per sample
             pad = self.Hz_fbank.shape[1] // 2
             x = torch.nn.functional.pad(images, [pad, pad, pad, pad], mode="reflect")
             outs = []
@@ -291,7 +297,7 @@ class AugmentPipe(torch.nn.Module):
             sigma = torch.where(torch.rand([B, 1, 1, 1], device=dev) < self.noise * p_now, sigma, torch.zeros_like(sigma))
             if dp is not None:
                 sigma = torch.full_like(sigma, float(torch.erfinv(dp) * self.noise_std))
-            images = images + torch.randn([B, C, H, W], device=img_dev) * sigma.to(img_dev)
+            images = images + torch.randn([B, C, H, W], device=img_dev) * _upload(sigma, img_dev)
         if self.cutout > 0:
             size = torch.full([B, 2, 1, 1, 1], self.cutout_size, device=dev)
             size = torch.where(torch.rand([B, 1, 1, 1, 1], device=dev) < self.cutout * p_now, size, torch.zeros_like(size))
@@ -299,7 +305,7 @@ class AugmentPipe(torch.nn.Module):
             if dp is not None:
                 size = torch.full_like(size, self.cutout_size)
                 center = torch.full_like(center, float(dp))
-            size, center = size.to(img_dev), center.to(img_dev)
+            size, center = _upload(size, img_dev), _upload(center, img_dev)
             cx = (torch.arange(W, device=img_dev).reshape(1, 1, 1, -1) + 0.5) / W
             cy = (torch.arange(H, device=img_dev).reshape(1, 1, -1, 1) + 0.5) / H
             outside = torch.logical_or((cx - center[:, 0]).abs() >= size[:, 0] / 2, (cy - center[:, 1]).abs() >= size[:, 1] / 2)
@@ -328,6 +334,6 @@ class AugmentPipe(torch.nn.Module):
         G = T(-0.5, -0.5) @ G @ T(0.5, 0.5)
         shape = [B, C, (H + hz_pad * 2) * 2, (W + hz_pad * 2) * 2]
         G = S(2 / images.shape[3], 2 / images.shape[2]) @ G @ S(shape[3] / 2, shape[2] / 2)
-        grid = torch.nn.functional.affine_grid(theta=G[:, :2, :].contiguous().to(images.device, non_blocking=True), size=shape, align_corners=False)
+        grid = torch.nn.functional.affine_grid(theta=_upload(G[:, :2, :], images.device), size=shape, align_corners=False)
         images = _GridSample.apply(images, grid)
         return ops.downsample2d(images.contiguous(), self.Hz_geom, down=2, padding=-hz_pad * 2, flip_filter=True)
