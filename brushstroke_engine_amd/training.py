@@ -237,7 +237,10 @@ class TrainableDiscriminator(torch.nn.Module):
             return torch.addmm(b.unsqueeze(0), x, w.t())
         return ops.bias_act(x.matmul(w.t()).contiguous(), b, act=activation)
 
-    def forward(self, img, c=None):
+    def forward(self, img, c=None, sub_batches: int = 1):
+        """``sub_batches`` > 1: ``img`` is that many independent batches stacked along dim 0 (e.g. generated and real images of
+        one discriminator phase); the minibatch-stddev statistics -- the one place where samples of a batch meet -- are taken per
+        sub-batch, so the logits equal those of separate calls."""
         x = None
         img = img.to(torch.float32).contiguous()
         for res in self.block_resolutions:
@@ -249,12 +252,15 @@ class TrainableDiscriminator(torch.nn.Module):
             x = self._conv(x, b + ".conv1", 3, down=2, gain=math.sqrt(0.5), clamp=self.conv_clamp)
             x = y + x
         if self.mbstd_num_channels > 0:                                   # MinibatchStdLayer, networks.py:868-885
-            n, ch, h, w = x.shape
+            nt, ch, h, w = x.shape
+            assert nt % sub_batches == 0
+            n = nt // sub_batches
             g = n if self.mbstd_group_size is None else min(self.mbstd_group_size, n)
             f_, c_ = self.mbstd_num_channels, ch // self.mbstd_num_channels
-            y = x.reshape(g, -1, f_, c_, h, w)
-            y = y - y.mean(dim=0)
-            y = (y.square().mean(dim=0) + 1e-8).sqrt().mean(dim=[2, 3, 4]).reshape(-1, f_, 1, 1).repeat(g, 1, h, w)
+            y = x.reshape(sub_batches, g, -1, f_, c_, h, w)
+            y = y - y.mean(dim=1, keepdim=True)
+            y = (y.square().mean(dim=1) + 1e-8).sqrt().mean(dim=[3, 4, 5])            # [sub, n/g, F]
+            y = y.reshape(sub_batches, 1, -1, f_, 1, 1).expand(sub_batches, g, -1, f_, h, w).reshape(nt, f_, h, w)
             x = torch.cat([x, y], dim=1)
         x = self._conv(x.contiguous(), "b4.conv", 3, clamp=self.conv_clamp)
         x = self._fc(x.flatten(1), "b4.fc", "lrelu")
@@ -338,9 +344,10 @@ class GanLoss:
                  pl_decay: float = 0.01, pl_weight: float = 2.0, augment_pipe=None, style_mixing_prob: float = 0.9,
                  noise_mode: str = "random", geom_phase_losses: str = "", main_phase_losses: str = "",
                  geom_warmstart_losses: Optional[str] = None, stitch_phase_losses: str = "", stitcher=None,
-                 partial_loss_with_triband_input: bool = False):
+                 partial_loss_with_triband_input: bool = False, merge_d_passes: bool = True):
         from .forger_losses import ForgerLosses, RandomStitcher
         self._G, self.r1_gamma = G, r1_gamma
+        self.merge_d_passes = merge_d_passes                # 'Dmain': generated + real images as one stacked discriminator batch
         self._D, self.augment_pipe = D, augment_pipe
         self.style_mixing_prob, self.noise_mode = style_mixing_prob, noise_mode
         self.geom_phase_losses = ForgerLosses.create_from_string(geom_phase_losses)
@@ -363,11 +370,11 @@ class GanLoss:
     def _unwrap(m):
         return getattr(m, "module", m)                                     # DistributedDataParallel wraps the network
 
-    def D(self, img, c=None):
+    def D(self, img, c=None, sub_batches: int = 1):
         """``ForgerLoss.run_D`` (loss_modified.py:102-107): the discriminator sees augmented images."""
         if self.augment_pipe is not None:
             img = self.augment_pipe(img)
-        return self._D(img, c)
+        return self._D(img, c) if sub_batches == 1 else self._D(img, c, sub_batches=sub_batches)
 
     def ada_update(self, ada_target: float, batch_size: int, ada_interval: int, ada_kimg: float) -> float:
         """The training loop's ADA heuristic (training_loop_modified.py: adjust p by the sign of E[sign(D(real))] - target)."""
@@ -484,6 +491,22 @@ class GanLoss:
                 loss = loss + extra
                 stats.update({f"Loss/forger/Gmain/{k}": v.detach() for k, v in vals.items()})
             loss.mean().mul(gain).backward()
+        if phase == "Dmain" and self.merge_d_passes:
+            # Generated and real images through the discriminator as ONE stacked batch (the reference runs two passes,
+            # loss_modified.py:223-238; gradients accumulate linearly, the augmentation draws its parameters per sample and the
+            # minibatch-stddev statistics are taken per half, so the result is the same -- at half the launches)
+            with torch.no_grad():
+                gen_img = self.G(gen_z, None, geom_feature, positions=positions)
+            n_gen = gen_img.shape[0]
+            logits = self.D(torch.cat([gen_img, real_img.detach().to(gen_img.dtype)], dim=0), None, sub_batches=2)
+            gen_logits, real_logits = logits[:n_gen], logits[n_gen:]
+            loss_gen, loss_real = softplus(gen_logits), softplus(-real_logits)
+            self.real_sign_sum = self.real_sign_sum + real_logits.detach().sign().sum()
+            self.real_sign_count += real_logits.numel()
+            (loss_gen.mean() + loss_real.mean()).mul(gain).backward()
+            stats["Loss/D/loss_gen"] = loss_gen.mean().detach()
+            stats["Loss/D/loss_real"] = loss_real.mean().detach()
+            return stats
         if phase in ("Dmain", "Dall"):                                    # minimise logits of generated images
             with torch.no_grad():
                 gen_img = self.G(gen_z, None, geom_feature, positions=positions)

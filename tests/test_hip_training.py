@@ -143,6 +143,38 @@ def test_gan_loss_phases():
     assert abs(st["Loss/r1_penalty"] - float(gr.square().sum([1, 2, 3]).mean())) <= 1e-4 * st["Loss/r1_penalty"]
 
 
+def test_dmain_stacked_batch_equals_two_passes():
+    """'Dmain' with generated and real images stacked into one discriminator batch (GanLoss.merge_d_passes, the default) gives the
+    gradients and statistics of the reference's two passes (loss_modified.py:223-238): gradients add linearly and the
+    minibatch-stddev statistics are taken per half.  Constant noise and no style mixing / augmentation make both runs see the
+    same generated images; the discriminator's stacked forward is also checked against separate calls."""
+    from brushstroke_engine_amd.training import (TrainableGenerator, TrainableDiscriminator, GanLoss,
+                                                 random_discriminator_state_dict)
+    cfg, sd, z, geom, pos = _setup(n=8)
+    dev = torch.device("cuda:0")
+    G = TrainableGenerator(cfg, sd, dev)
+    D = TrainableDiscriminator(random_discriminator_state_dict(32, 3, channel_base=512, channel_max=24, seed=3, bias_std=0.1),
+                               32, 3, channel_base=512, channel_max=24, conv_clamp=256, device=dev)
+    zt = torch.from_numpy(z).to(dev); gt = [torch.from_numpy(g).to(dev) for g in geom]
+    real = torch.tanh(torch.randn(8, 3, 32, 32, device=dev))
+    with torch.no_grad():
+        a, b = torch.randn(8, 3, 32, 32, device=dev), torch.randn(8, 3, 32, 32, device=dev)
+        both = D(torch.cat([a, b]), None, sub_batches=2)
+        assert float((both - torch.cat([D(a, None), D(b, None)])).abs().max()) <= 1e-5 * float(both.abs().max())
+    res = []
+    for merged in (True, False):
+        loss = GanLoss(G, D, noise_mode="const", style_mixing_prob=0.0, merge_d_passes=merged)
+        for p in list(G.parameters()) + list(D.parameters()):
+            p.grad = None
+        st = loss.accumulate_gradients("Dmain", real, gt, zt)
+        res.append((dict(st.items()), [p.grad.clone() for p in D.parameters()], loss.real_sign_count, float(loss.real_sign_sum)))
+    assert res[0][2:] == res[1][2:]
+    for k in ("Loss/D/loss_gen", "Loss/D/loss_real"):
+        assert abs(res[0][0][k] - res[1][0][k]) <= 1e-5 * abs(res[1][0][k])
+    for ga, gb in zip(res[0][1], res[1][1]):
+        assert float((ga - gb).abs().max()) <= 2e-4 * max(1e-8, float(gb.abs().max()))
+
+
 def test_path_length_regulariser_matches_oracle():
     """'Greg' phase: gradients of the path-length penalty (a second-order quantity: it differentiates d(img . noise)/d ws)
     w.r.t. the generator parameters, HIP autograd path vs the oracle under torch.autograd on CPU, same pl noise."""
