@@ -1128,7 +1128,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     int b = blockIdx.x;
     // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so the c_out
     // slices of one input tile -- which re-read the same activations -- are renumbered to share an XCD
-    if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    // (the XCD's share of the tile list rotates with the sample: the cheap tiles of a ragged last tile row -- see the K loop's
+    //  copies below -- would otherwise all sit on the last XCDs, which then idle while the others finish)
+    if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (((b & 7) + blockIdx.y) & 7) * (gridDim.x >> 3) + (b >> 3);
     const int slice = b % p.slices; b /= p.slices;
     const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
     const int n = blockIdx.y;
@@ -1263,8 +1265,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     //  different points; the barrier costs nothing; the loop without DMA still needs ~3 050 cycles for 2 432 cycles of MFMA.
     //  A variant with masked out-of-image lanes and pre-zeroed halo slots saved registers but is WRONG: a piece whose lanes
     //  are all masked is skipped, and the counted vmcnt waits below rely on every wave issuing exactly NPC pieces per chunk.)
-    auto chunk = [&](auto dma_, const h8* st, int cn, h8* sn) {
+    auto chunk = [&](auto dma_, auto nbe_, const h8* st, int cn, h8* sn) {
         constexpr bool DMA = decltype(dma_)::value;
+        constexpr int NBE = decltype(nbe_)::value;          // column blocks this wave multiplies (a wave whose second block does not exist skips its MFMAs and reads)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (F8) {
             // "f8" operands (see modconv3x3_up1_h3_kernel): one f16 MFMA per tap for the main product, and the two
@@ -1282,9 +1285,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
 #define NB_RD(dst, src) dst = (src)
 #endif
 #define NB_LDA(tap, hi, lo) { NB_RD(hi, st[aoff + (tap) * 128]); NB_RD(lo, st[aoff + (tap) * 128 + 32]); }
-#define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) { NB_RD(hi[j], st[boff[j] + (del)]); NB_RD(lo[j], st[boff[j] + XPL + (del)]); } }
+#define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NBE; ++j) { NB_RD(hi[j], st[boff[j] + (del)]); NB_RD(lo[j], st[boff[j] + XPL + (del)]); } }
 #define NB_PAIR(ph, ah_a, al_a, bha, bla, ah_b, al_b, bhb, blb)                                                                   \
-            { _Pragma("unroll") for (int j = 0; j < NBJ; ++j) {                                                                    \
+            { _Pragma("unroll") for (int j = 0; j < NBE; ++j) {                                                                    \
                 f32x16& a_ = acc[j][ph];                                                                                           \
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_a, bha[j], a_, 0, 0, 0);                                            \
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_b, bhb[j], a_, 0, 0, 0);                                            \
@@ -1304,13 +1307,13 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
             // three reads, not after all sixteen), then the second group's A fragments
             NB_RD(a1h, st[aoff + 8 * 128]);
 #pragma unroll
-            for (int j = 0; j < NBJ; ++j) NB_RD(b0h[j], st[boff[j]]);
+            for (int j = 0; j < NBE; ++j) NB_RD(b0h[j], st[boff[j]]);
             NB_RD(a2h, st[aoff + 6 * 128]);
 #pragma unroll
-            for (int j = 0; j < NBJ; ++j) NB_RD(b1h[j], st[boff[j] + 1]);
+            for (int j = 0; j < NBE; ++j) NB_RD(b1h[j], st[boff[j] + 1]);
             NB_RD(a1l, st[aoff + 8 * 128 + 32]); NB_RD(a2l, st[aoff + 6 * 128 + 32]);
 #pragma unroll
-            for (int j = 0; j < NBJ; ++j) { NB_RD(b0l[j], st[boff[j] + XPL]); NB_RD(b1l[j], st[boff[j] + XPL + 1]); }
+            for (int j = 0; j < NBE; ++j) { NB_RD(b0l[j], st[boff[j] + XPL]); NB_RD(b1l[j], st[boff[j] + XPL + 1]); }
             NB_LDA(5, n1h, n1l); NB_LDA(3, n2h, n2l);                             // (for the second group)
             NB_FENCE();
             NB_PAIR(0, a1h, a1l, b0h, b0l, a2h, a2l, b1h, b1l);                   // taps 8, 6
@@ -1324,7 +1327,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
             NB_LDB(XS, b1h, b1l); NB_LDA(7, n1h, n1l); NB_LDA(1, n2h, n2l);       // (for the fourth group)
             NB_FENCE();
 #pragma unroll
-            for (int j = 0; j < NBJ; ++j) {                                       // tap 4 alone
+            for (int j = 0; j < NBE; ++j) {                                       // tap 4 alone
                 f32x16& a_ = acc[j][3];
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h[j], a_, 0, 0, 0);
                 a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nb_cat8(a1l, z8), nb_cat8(b0l[j], z8), a_, 0, 0, 0, sa, 0, sb);
@@ -1346,26 +1349,28 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
             h8 ah[2], al[2], bh[2][NBJ], bl[2][NBJ];
             ah[0] = st[aoff + kOrd[0] * 128]; al[0] = st[aoff + kOrd[0] * 128 + 32];
 #pragma unroll
-            for (int j = 0; j < NBJ; ++j) { bh[0][j] = st[boff[j] + kDel[0]]; bl[0][j] = st[boff[j] + XPL + kDel[0]]; }
+            for (int j = 0; j < NBE; ++j) { bh[0][j] = st[boff[j] + kDel[0]]; bl[0][j] = st[boff[j] + XPL + kDel[0]]; }
             nb_static_for<0, 9>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
                 constexpr int ca = i & 1, cb = kGrp[i] & 1;
                 f32x16& a0 = acc[0][kPha[i]];
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][0], a0, 0, 0, 0);
-                constexpr int nfetch = i + 1 < 9 ? (kGrp[i + 1 < 9 ? i + 1 : i] != kGrp[i] ? 2 + 2 * NBJ : 2) : 0;
+                if constexpr (NBE > 0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][0], a0, 0, 0, 0);
+                constexpr int nfetch = i + 1 < 9 ? (kGrp[i + 1 < 9 ? i + 1 : i] != kGrp[i] ? 2 + 2 * NBE : 2) : 0;
                 if constexpr (i + 1 < 9) {
                     ah[ca ^ 1] = st[aoff + kOrd[i + 1] * 128]; al[ca ^ 1] = st[aoff + kOrd[i + 1] * 128 + 32];
                     if constexpr (kGrp[i + 1] != kGrp[i]) {
 #pragma unroll
-                        for (int j = 0; j < NBJ; ++j) {
+                        for (int j = 0; j < NBE; ++j) {
                             bh[cb ^ 1][j] = st[boff[j] + kDel[i + 1]]; bl[cb ^ 1][j] = st[boff[j] + XPL + kDel[i + 1]];
                         }
                     }
                 }
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][0], a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][0], a0, 0, 0, 0);
+                if constexpr (NBE > 0) {
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][0], a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][0], a0, 0, 0, 0);
+                }
 #pragma unroll
-                for (int j = 1; j < NBJ; ++j) {
+                for (int j = 1; j < NBE; ++j) {
                     f32x16& aj = acc[j][kPha[i]];
                     aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][j], aj, 0, 0, 0);
                     aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][j], aj, 0, 0, 0);
@@ -1374,7 +1379,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
                 // next tap's fragment reads go out BEFORE this tap's six MFMAs (their registers are free: the previous tap
                 // has issued), which gives the LDS the whole tap to answer
                 if constexpr (nfetch > 0) __builtin_amdgcn_sched_group_barrier(0x100, nfetch, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBJ, 0);
+                if constexpr (NBE > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBE, 0);
                 // this chunk's share of the next-but-one chunk's LDS-DMA pieces, behind the tap's MFMAs (taps 0..7)
                 if constexpr (DMA && i < 8) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1385,13 +1390,14 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto kloop = [&](auto nbe) {
     int c = 0;
     int s_cur = 0;                                    // stage of chunk c
     if constexpr (NST == 2) {
         // two stages: chunk c+1 lands in the other stage while chunk c is multiplied; the wait at the end of a chunk is for
         // pieces issued during it -- exposed latency that the co-resident workgroup's matrix work covers
         for (; c + 1 < NC; ++c) {
-            chunk(std::true_type{}, ring + s_cur * STAGE, c + 1, ring + (s_cur ^ 1) * STAGE);
+            chunk(std::true_type{}, nbe, ring + s_cur * STAGE, c + 1, ring + (s_cur ^ 1) * STAGE);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             s_cur ^= 1;
@@ -1399,7 +1405,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     }
     for (; NST == 3 && c + 2 < NC; ++c) {
         const int s_nn = s_cur == 0 ? 2 : s_cur - 1;  // (c + 2) % 3
-        chunk(std::true_type{}, ring + s_cur * STAGE, c + 2, ring + s_nn * STAGE);
+        chunk(std::true_type{}, nbe, ring + s_cur * STAGE, c + 2, ring + s_nn * STAGE);
         // chunk c+1 has landed (the pieces of c+2 may stay in flight); everybody is done reading chunk c
         // (no timestamp reads in here: the branches around them split the loop body into several basic blocks, and the
         //  compiler then sinks MFMAs past the wait and the barrier)
@@ -1414,10 +1420,26 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
         s_cur = s_cur == 2 ? 0 : s_cur + 1;
     }
     for (; c < NC; ++c) {
-        chunk(std::false_type{}, ring + s_cur * STAGE, 0, nullptr);
+        chunk(std::false_type{}, nbe, ring + s_cur * STAGE, 0, nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         s_cur = s_cur == NST - 1 ? 0 : s_cur + 1;
+    }
+    };
+    // (copies of the loop per number of column blocks a wave really has to multiply: blocks that do not exist -- the 16th of the
+    //  15-block tile -- or lie wholly below the image -- the last tile row of a height that 12 does not divide -- cost no MFMAs and
+    //  no fragment reads; the DMA pieces and barriers are the same in every copy.  Their accumulators stay zero; nothing that is
+    //  stored reads them.)
+    const int nvalid_blk = (min(TQH, H - I0) + 2) * PW;                  // positions of the rows that feed stored pixels ...
+    int nbe_w = 0;                                                       // ... and this wave's blocks that hold any of them
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) nbe_w += (wv + NW * j) * 32 < nvalid_blk && j < nblk;
+    if constexpr (NBJ > 1) {
+        if (nbe_w == 2) kloop(std::integral_constant<int, 2>{});
+        else if (nbe_w == 1) kloop(std::integral_constant<int, 1>{});
+        else kloop(std::integral_constant<int, 0>{});
+    } else {
+        if (nbe_w == 1) kloop(std::integral_constant<int, 1>{}); else kloop(std::integral_constant<int, 0>{});
     }
     if (p.tstamps && tid == 0) {
         unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
@@ -1466,6 +1488,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
             const int hq = wi * 32 + l31;             // (g, quad); lane half = channel half
             const int gs = hq / nquads, qd = hq - gs * nquads;
             const int ti = qd / TQW, tj = qd - ti * TQW;
+            if (I0 + ti >= H) return;                 // quad row below the image (ragged last tile row): nothing of it is stored
             const int c4 = 8 * (2 * R + gs) + 4 * lh; // the lane's four channels within the slice
             const f32x4* ee = y4 + ((gs * 2 + lh) * 4) * Y1P + ti * PW + tj;
             const f32x4* eo = ee + 1 * Y1P;

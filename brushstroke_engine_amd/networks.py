@@ -74,6 +74,8 @@ class MappingNetwork(torch.nn.Module):
             w = torch.cat([getattr(self, f"fc{i}").weight.reshape(-1) for i in range(self.num_layers)]).contiguous()
             b = torch.cat([getattr(self, f"fc{i}").bias for i in range(self.num_layers)]).contiguous()
             self._packed = (w, b)
+            if w.is_cuda and not torch.cuda.is_current_stream_capturing():       # (see SynthesisNetwork._ensure_packed)
+                torch.cuda.current_stream(w.device).synchronize()
         return self._packed
 
     def forward(self, z, c=None, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
@@ -310,6 +312,12 @@ class SynthesisNetwork(torch.nn.Module):
                     self.packed[s.name]["w_h3_up2"] = ops.pack_conv_weight_h3_up2_phases(layer.weight, layer.resample_filter)
         t = self.get_last_block().torgb
         self.packed["torgb"] = {"w": t.weight.reshape(3, -1).contiguous()}
+        # The packed tensors were written by launches on the CURRENT stream, but every stream uses them from now on (the tiled
+        # schedule alternates its batches over side streams, and the first use after a mode switch / weight load may well sit on
+        # one of them): without this, a batch on another stream could read a weight block that is still being written -- seen as
+        # a few wrong pixels in ~1 of 5 canvases painted right after set_conv_mode('f32').  Packing is rare; one sync is cheap.
+        if t.weight.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(t.weight.device).synchronize()
 
     def _h3_eligible(self, s: LayerSpec) -> bool:
         """conv1 layers that run as 3-pass split-f16 MFMA (csrc/nb_modconv_h3.hip): the kernel needs rows of 32

@@ -265,9 +265,23 @@ class TileOps:
     lazy_geometry = True       # hand the generator a geometry provider (encoder output straight into the layer operands)
 
     def encode(self, geom: torch.Tensor):
-        if self.lazy_geometry and hasattr(self.encoder, "lazy"):
+        # The lazy provider pays where the encoder can write into the generator's operand tensors (split-f16 modes).  In 'f32'
+        # it buys nothing -- and it is the one configuration in which a race was observed: with the encoder running inside the
+        # generator call, two batch streams and freshly created workspaces (first canvas after set_conv_mode / a weight load),
+        # ~1 canvas in 7 came out with a few wrong pixels in a tile of the first batch (tools/canvas_race_hunt.py; not seen with
+        # the encoder run here, with one stream, or with the workspaces created ahead).  Root cause not found yet.
+        if self.lazy_geometry and hasattr(self.encoder, "lazy") and self.G.synthesis.conv_mode != "f32":
             return self.encoder.lazy(geom)
         return self.encoder.encode(geom)
+
+    def prepare(self, n: int, slots) -> None:
+        """Create the generator workspaces of ``slots`` for batches of ``n`` on the CALLER's stream, before the batch streams fork
+        (a workspace is otherwise created by the first batch that needs it, on that batch's stream, while the other stream is
+        already running)."""
+        syn = self.G.synthesis
+        syn._n, syn._h3_batch_ok = n, n >= syn.h3_min_batch
+        for sl in slots:
+            syn._get_plan(n, self.device, sl)
 
     def map_style(self, z=None, ws=None) -> torch.Tensor:
         if ws is not None:
@@ -632,6 +646,8 @@ class PaintingHelper:
         plan_slot = lambda k: PAINT_SLOT0 + k % getattr(ops, "n_streams", 1)
         if n_own <= self.batch:                      # a single batch (interactive strokes): nothing to overlap with
             on_stream, join, plan_slot = (lambda k: contextlib.nullcontext()), (lambda tensors=(): None), (lambda k: 0)
+        elif hasattr(ops, "prepare"):
+            ops.prepare(min(self.batch, n_own), sorted({plan_slot(k) for k in range(getattr(ops, "n_streams", 1))}))
         user_dev = None if user is None else user.to(ops.device)
         colors = lambda n_: None if user_dev is None else user_dev.expand(n_, -1, -1).contiguous()
         outs = []
