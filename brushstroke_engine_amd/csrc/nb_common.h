@@ -7,6 +7,19 @@
 
 #define NB_ABI_VERSION 10
 
+// Kernels whose scalar fp32 arithmetic the SLP vectoriser pairs into packed instructions are compiled WITHOUT packed fp32 ops.
+// Reason: the pairing produces forms that swizzle register halves -- `v_pk_add_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]`,
+// `v_pk_mul_f32 ... op_sel:[1,0] op_sel_hi:[0,1]` -- and on MI355X those returned, sporadically and only while waves of another
+// kernel shared the SIMD, a result computed from the OTHER half of the pair for 16-32 lanes of a wave: first seen in the up=2
+// split-f16 epilogue (round 3, tools/determinism_up2.py), then as wrong `img` / RGBA values of torgb_triad_kernel<4> (element 2 of a
+// thread's 4 pixels, one channel) in ~1 of 6 rounds of tools/gen_race_hunt.py.  Waits forced to zero and s_nops between the
+// producer and the packed op did not help; not emitting the form does.  Kernels that use packed fp32 on purpose (explicit
+// f32x4 / f32x2 arithmetic in the split-f16 epilogues) only ever use the un-swizzled forms and keep them.  Applied to
+// torgb_triad_kernel, bias_act_kernel and enc_upsample2x_h2_kernel.  NOT applied to modconv3x3_up2_kernel (the exact-fp32 up=2
+// kernel: 4-8 swizzled adds in its FIR code, never seen to misbehave in 300 rounds of bitwise feature comparison): with the
+// attribute its H2-output variant loses the lo halves (test_up2_h2_output_vs_oracle fails at f16 precision) -- left for later.
+#define NB_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+
 void nb_set_error(const char* fmt, ...);
 
 #define NB_REQUIRE(cond, ...)                         \

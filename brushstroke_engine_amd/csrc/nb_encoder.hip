@@ -770,7 +770,7 @@ extern "C" int nb_enc_conv3x3_ex(const void* x, int c_in, const void* wts, const
 // bilinear x2 upsampling, align_corners=True (nn.Upsample in ScaleUp, simple_autoencoder.py:106-121):
 // fp32 NCHW [n,c,h,w] -> H2 [n,c/8,2,2h,2w,8]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void enc_upsample2x_h2_kernel(const float* __restrict__ x, _Float16* __restrict__ y,
+__global__ NB_NO_PACKED_F32 __launch_bounds__(256) void enc_upsample2x_h2_kernel(const float* __restrict__ x, _Float16* __restrict__ y,
                                                                 int c, int h, int w, long long total, int out_f8) {
     const int oh = 2 * h, ow = 2 * w, c8 = c / 8;
     const float sy = (float)(h - 1) / (float)(oh - 1), sx = (float)(w - 1) / (float)(ow - 1);

@@ -265,12 +265,7 @@ class TileOps:
     lazy_geometry = True       # hand the generator a geometry provider (encoder output straight into the layer operands)
 
     def encode(self, geom: torch.Tensor):
-        # The lazy provider pays where the encoder can write into the generator's operand tensors (split-f16 modes).  In 'f32'
-        # it buys nothing -- and it is the one configuration in which a race was observed: with the encoder running inside the
-        # generator call, two batch streams and freshly created workspaces (first canvas after set_conv_mode / a weight load),
-        # ~1 canvas in 7 came out with a few wrong pixels in a tile of the first batch (tools/canvas_race_hunt.py; not seen with
-        # the encoder run here, with one stream, or with the workspaces created ahead).  Root cause not found yet.
-        if self.lazy_geometry and hasattr(self.encoder, "lazy") and self.G.synthesis.conv_mode != "f32":
+        if self.lazy_geometry and hasattr(self.encoder, "lazy"):
             return self.encoder.lazy(geom)
         return self.encoder.encode(geom)
 

@@ -1,3 +1,9 @@
+"""Developer tool: hunt for the wrong pixels that ~1 tiled canvas in 7 showed right after set_conv_mode('f32') (first seen as a
+one-off failure of test_tiled_canvas_matches_reference[f32-0]).  Knobs (environment): NB_SWITCH=0 no mode switch, NB_PREPACK /
+NB_PREPLAN=1..4 weights / workspaces created ahead, NB_UPLOAD, NB_NOFAST, NB_NONOISE, NB_KEEPALL (no temporary freed), NB_EAGER_ENC,
+NB_FORCE_LAZY, NB_NANFILL.  What they showed: not the allocator, not packing, not uninitialised memory -- timing.  The cause
+(tools/gen_race_hunt.py: only `img` / RGBA of the standalone ToRGB kernel differ) is the packed-fp32 op_sel hazard described at
+NB_NO_PACKED_F32 in csrc/nb_common.h; with those kernels compiled without packed fp32 ops this tool finds nothing."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
@@ -47,6 +53,18 @@ if os.environ.get('NB_KEEPALL'):
         t = _to(self, *a, **k); KEEP.append(t); return t
     torch.Tensor.to = to_
 if os.environ.get('NB_EAGER_ENC'): painting.TileOps.lazy_geometry = False
+if os.environ.get('NB_FORCE_LAZY'):
+    painting.TileOps.encode = lambda self, geom: self.encoder.lazy(geom)
+    painting.TileOps.prepare = lambda self, n, slots: None
+if os.environ.get('NB_NANFILL'):
+    _e0, _el0 = torch.empty, torch.empty_like
+    def _fill(t):
+        if t.is_cuda and t.numel():
+            if t.dtype in (torch.float32, torch.float16): t.fill_(float('nan'))
+            elif t.dtype == torch.uint8: t.fill_(77)
+        return t
+    torch.empty = lambda *a, **k: _fill(_e0(*a, **k))
+    torch.empty_like = lambda *a, **k: _fill(_el0(*a, **k))
 ref = None
 for it in range(80):
     KEEP.clear() if False else None
