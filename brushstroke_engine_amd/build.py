@@ -22,6 +22,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+# Per-file additions.  nb_modconv.hip (exact-fp32 kernels): no SLP vectorisation -- it pairs the scalar FIR arithmetic of the up=2
+# epilogue into swizzled packed fp32 instructions (see NB_NO_PACKED_F32 in csrc/nb_common.h); these kernels have no use for
+# packed arithmetic, and the function attribute that removes it elsewhere breaks their H2-output variant.
+FILE_FLAGS = {"nb_modconv.hip": ["-fno-slp-vectorize"]}
 
 
 STAMP = LIB + ".stamp"
@@ -31,7 +35,7 @@ def source_digest() -> str:
     """sha256 over the kernel sources, headers and compiler flags: what the library was (or would be) built from.
     Content, not mtimes -- a source snapshot copied to another machine keeps its digest."""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
@@ -71,11 +75,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         cflags = [f for f in FLAGS if f != "-shared"]
 
         def compile_one(src):
+            extra = FILE_FLAGS.get(src, [])
             with open(os.path.join(CSRC, src), "rb") as f:
-                key = hashlib.sha256(hdr.digest() + f.read()).hexdigest()[:16]
+                key = hashlib.sha256(hdr.digest() + " ".join(extra).encode() + f.read()).hexdigest()[:16]
             obj = os.path.join(objdir, f"{src}.{key}.o")
             if not os.path.exists(obj) or force:
-                cmd = [HIPCC] + cflags + ["-c", os.path.join(CSRC, src), "-o", f"{obj}.{os.getpid()}.tmp"]
+                cmd = [HIPCC] + cflags + extra + ["-c", os.path.join(CSRC, src), "-o", f"{obj}.{os.getpid()}.tmp"]
                 if verbose:
                     print("[build]", " ".join(cmd), flush=True)
                 subprocess.check_call(cmd)

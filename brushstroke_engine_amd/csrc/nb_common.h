@@ -15,9 +15,9 @@
 // thread's 4 pixels, one channel) in ~1 of 6 rounds of tools/gen_race_hunt.py.  Waits forced to zero and s_nops between the
 // producer and the packed op did not help; not emitting the form does.  Kernels that use packed fp32 on purpose (explicit
 // f32x4 / f32x2 arithmetic in the split-f16 epilogues) only ever use the un-swizzled forms and keep them.  Applied to
-// torgb_triad_kernel, bias_act_kernel and enc_upsample2x_h2_kernel.  NOT applied to modconv3x3_up2_kernel (the exact-fp32 up=2
-// kernel: 4-8 swizzled adds in its FIR code, never seen to misbehave in 300 rounds of bitwise feature comparison): with the
-// attribute its H2-output variant loses the lo halves (test_up2_h2_output_vs_oracle fails at f16 precision) -- left for later.
+// torgb_triad_kernel, bias_act_kernel and enc_upsample2x_h2_kernel.  The exact-fp32 conv kernels (nb_modconv.hip: 4-8 swizzled adds
+// in the up=2 FIR code, never seen to misbehave) are instead compiled without SLP vectorisation (build.py FILE_FLAGS), which removes
+// every packed fp32 instruction from that file.
 #define NB_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
 
 void nb_set_error(const char* fmt, ...);

@@ -654,7 +654,11 @@ __global__ __launch_bounds__(256) void modconv3x3_up2_kernel(const ModconvParams
                             h4 hi, lo;
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
-                                const float v = nb_epilogue(o[s4][dy][dx] * d4[s4] + nz, b4[s4], p.alpha, p.gain, p.clamp) * sc4[s4];
+                                float v = nb_epilogue(o[s4][dy][dx] * d4[s4] + nz, b4[s4], p.alpha, p.gain, p.clamp) * sc4[s4];
+                                // (one value, materialised once: the hi and the lo half must be split from the SAME fp32 number --
+                                //  built without SLP vectorisation the two uses were computed separately and disagreed in the last
+                                //  bit on ~5e-5 of the elements, which costs a whole f16 ulp when the rounding of hi flips)
+                                asm volatile("" : "+v"(v));
                                 const _Float16 hh = (_Float16)v;
                                 hi[s4] = hh;
                                 lo[s4] = (_Float16)(v - (float)hh);
