@@ -22,10 +22,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
-# Per-file additions.  nb_modconv.hip (exact-fp32 kernels): no SLP vectorisation -- it pairs the scalar FIR arithmetic of the up=2
-# epilogue into swizzled packed fp32 instructions (see NB_NO_PACKED_F32 in csrc/nb_common.h); these kernels have no use for
-# packed arithmetic, and the function attribute that removes it elsewhere breaks their H2-output variant.
-FILE_FLAGS = {"nb_modconv.hip": ["-fno-slp-vectorize"]}
+# Per-file additions.  nb_ops.hip (ToRGB, bias_act, upfirdn2d, mapping ...) and nb_modconv.hip (exact-fp32 conv kernels): no SLP
+# vectorisation -- it pairs their scalar arithmetic into swizzled packed fp32 instructions, which misbehave on this hardware
+# (NB_NO_PACKED_F32 in csrc/nb_common.h has the story); these kernels have no use for packed arithmetic.  (The function attribute
+# that removes packed fp32 per kernel costs the ToRGB kernel 384 bytes of scratch: helpers are no longer inlined into it.)
+FILE_FLAGS = {"nb_modconv.hip": ["-fno-slp-vectorize"], "nb_ops.hip": ["-fno-slp-vectorize"]}
 
 
 STAMP = LIB + ".stamp"

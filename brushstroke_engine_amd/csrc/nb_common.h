@@ -14,10 +14,10 @@
 // split-f16 epilogue (round 3, tools/determinism_up2.py), then as wrong `img` / RGBA values of torgb_triad_kernel<4> (element 2 of a
 // thread's 4 pixels, one channel) in ~1 of 6 rounds of tools/gen_race_hunt.py.  Waits forced to zero and s_nops between the
 // producer and the packed op did not help; not emitting the form does.  Kernels that use packed fp32 on purpose (explicit
-// f32x4 / f32x2 arithmetic in the split-f16 epilogues) only ever use the un-swizzled forms and keep them.  Applied to
-// torgb_triad_kernel, bias_act_kernel and enc_upsample2x_h2_kernel.  The exact-fp32 conv kernels (nb_modconv.hip: 4-8 swizzled adds
-// in the up=2 FIR code, never seen to misbehave) are instead compiled without SLP vectorisation (build.py FILE_FLAGS), which removes
-// every packed fp32 instruction from that file.
+// f32x4 / f32x2 arithmetic in the split-f16 epilogues) only ever use the un-swizzled forms and keep them.  The attribute
+// below is applied to enc_upsample2x_h2_kernel; nb_ops.hip (ToRGB, bias_act, ...) and nb_modconv.hip (exact-fp32 conv kernels: 4-8
+// swizzled adds in the up=2 FIR code, never seen to misbehave) are compiled without SLP vectorisation instead (build.py FILE_FLAGS),
+// which removes the swizzled forms without costing scratch.
 #define NB_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
 
 void nb_set_error(const char* fmt, ...);

@@ -1659,6 +1659,11 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
     constexpr size_t lds_epi = (size_t)16 * NBLK_ * 32 * 16;       // epilogue: [2 groups][2 halves][4 phases][positions] x 4 channels fp32
     const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
+    if constexpr (NW == 4) {      // the two-per-CU form exists for H2 operands only (its f8 form spills 1-3 registers: not with counted waits)
+        NB_REQUIRE(!in_fmt, "modconv3x3_up2_h3: the two-workgroups-per-CU form takes H2 operands only");
+        return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, false, 2, NW, NST>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, false, 1, NW, NST>(p, n, lds, stream)
+                                                                                               : nb_up2_h3_launch1<TQH, TQW, false, 0, NW, NST>(p, n, lds, stream);
+    } else
     if (in_fmt)
         return outm == 2 ? nb_up2_h3_launch1<TQH, TQW, true, 2, NW, NST>(p, n, lds, stream) : outm == 1 ? nb_up2_h3_launch1<TQH, TQW, true, 1, NW, NST>(p, n, lds, stream)
                                                                                               : nb_up2_h3_launch1<TQH, TQW, true, 0, NW, NST>(p, n, lds, stream);
@@ -1702,7 +1707,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
     // two 4-wave workgroups per CU on 12 x 16 tiles (see the kernel's NW_ / NST_) when that launch fills the chip as well
     static const int env_pair = getenv("NB_UP2_PAIR") ? atoi(getenv("NB_UP2_PAIR")) : 0;
-    const bool pair = g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && wgs_big * 2 >= 1024);
+    const bool pair = !in_fmt && (g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && wgs_big * 2 >= 1024));
     if (pair) return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }

@@ -95,7 +95,7 @@ __device__ __forceinline__ float nb_bias_act_elem(const BiasActParams& p, float 
 }
 
 template <int G, bool VEC>
-__global__ NB_NO_PACKED_F32 __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
+__global__ __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     if (VEC) {
         const long long n4 = p.size_x >> 2;
@@ -768,7 +768,7 @@ extern "C" int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max
 // HBM-bound: reads x once (16 B per lane per channel), writes the 3-channel results.
 // ------------------------------------------------------------------------------------------------
 template <int V>
-__global__ NB_NO_PACKED_F32 __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
+__global__ __launch_bounds__(256) void torgb_triad_kernel(const TorgbParams p) {
     extern __shared__ float sw[];          // [3][c] modulated weights, then 9 colors, 9 col01
     float* scol = sw + 3 * p.c;
     float* scol01 = scol + 9;
