@@ -1267,7 +1267,11 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     //  are all masked is skipped, and the counted vmcnt waits below rely on every wave issuing exactly NPC pieces per chunk.)
     auto chunk = [&](auto dma_, auto nbe_, const h8* st, int cn, h8* sn) {
         constexpr bool DMA = decltype(dma_)::value;
-        constexpr int NBE = decltype(nbe_)::value;          // column blocks this wave multiplies (a wave whose second block does not exist skips its MFMAs and reads)
+        constexpr int NBE = decltype(nbe_)::value & 3;      // column blocks this wave multiplies (a wave whose second block does not exist skips its MFMAs and reads)
+        // ... and how many of them take all four phases.  The LAST block of a full tile lies wholly in the last halo row
+        // (positions 448 .. 475 of the 14 x 34), which the FIR reads in the odd-row phases only (oe, oo: rows ti .. ti+2 of a quad;
+        // ee, eo: ti, ti+1): its six even-row taps and their fragment reads are left out (nbe_ & 4).
+        constexpr int NB01 = (decltype(nbe_)::value & 4) ? NBE - 1 : NBE;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (F8) {
             // "f8" operands (see modconv3x3_up1_h3_kernel): one f16 MFMA per tap for the main product, and the two
@@ -1285,9 +1289,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
 #define NB_RD(dst, src) dst = (src)
 #endif
 #define NB_LDA(tap, hi, lo) { NB_RD(hi, st[aoff + (tap) * 128]); NB_RD(lo, st[aoff + (tap) * 128 + 32]); }
-#define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NBE; ++j) { NB_RD(hi[j], st[boff[j] + (del)]); NB_RD(lo[j], st[boff[j] + XPL + (del)]); } }
+#define NB_LDB(del, hi, lo) { _Pragma("unroll") for (int j = 0; j < NB01; ++j) { NB_RD(hi[j], st[boff[j] + (del)]); NB_RD(lo[j], st[boff[j] + XPL + (del)]); } }
 #define NB_PAIR(ph, ah_a, al_a, bha, bla, ah_b, al_b, bhb, blb)                                                                   \
-            { _Pragma("unroll") for (int j = 0; j < NBE; ++j) {                                                                    \
+            { _Pragma("unroll") for (int j = 0; j < ((ph) >= 2 ? NBE : NB01); ++j) {                                               \
                 f32x16& a_ = acc[j][ph];                                                                                           \
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_a, bha[j], a_, 0, 0, 0);                                            \
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_b, bhb[j], a_, 0, 0, 0);                                            \
@@ -1353,24 +1357,26 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
             nb_static_for<0, 9>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
                 constexpr int ca = i & 1, cb = kGrp[i] & 1;
+                constexpr int NBT = kPha[i] >= 2 ? NBE : NB01;            // blocks that take this tap
+                constexpr int NBF = kGrp[i + 1 < 9 ? i + 1 : i] >= 2 ? NB01 : NBE;      // blocks that need the next offset group's B fragments (groups 2, 3 = taps 1, 2, 0: even-row phases only)
                 f32x16& a0 = acc[0][kPha[i]];
-                if constexpr (NBE > 0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][0], a0, 0, 0, 0);
-                constexpr int nfetch = i + 1 < 9 ? (kGrp[i + 1 < 9 ? i + 1 : i] != kGrp[i] ? 2 + 2 * NBE : 2) : 0;
+                if constexpr (NBT > 0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][0], a0, 0, 0, 0);
+                constexpr int nfetch = i + 1 < 9 ? (kGrp[i + 1 < 9 ? i + 1 : i] != kGrp[i] ? 2 + 2 * NBF : 2) : 0;
                 if constexpr (i + 1 < 9) {
                     ah[ca ^ 1] = st[aoff + kOrd[i + 1] * 128]; al[ca ^ 1] = st[aoff + kOrd[i + 1] * 128 + 32];
                     if constexpr (kGrp[i + 1] != kGrp[i]) {
 #pragma unroll
-                        for (int j = 0; j < NBE; ++j) {
+                        for (int j = 0; j < NBF; ++j) {
                             bh[cb ^ 1][j] = st[boff[j] + kDel[i + 1]]; bl[cb ^ 1][j] = st[boff[j] + XPL + kDel[i + 1]];
                         }
                     }
                 }
-                if constexpr (NBE > 0) {
+                if constexpr (NBT > 0) {
                     a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][0], a0, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cb][0], a0, 0, 0, 0);
                 }
 #pragma unroll
-                for (int j = 1; j < NBE; ++j) {
+                for (int j = 1; j < NBT; ++j) {
                     f32x16& aj = acc[j][kPha[i]];
                     aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cb][j], aj, 0, 0, 0);
                     aj = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cb][j], aj, 0, 0, 0);
@@ -1379,7 +1385,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
                 // next tap's fragment reads go out BEFORE this tap's six MFMAs (their registers are free: the previous tap
                 // has issued), which gives the LDS the whole tap to answer
                 if constexpr (nfetch > 0) __builtin_amdgcn_sched_group_barrier(0x100, nfetch, 0);
-                if constexpr (NBE > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBE, 0);
+                if constexpr (NBT > 0) __builtin_amdgcn_sched_group_barrier(0x008, 3 * NBT, 0);
                 // this chunk's share of the next-but-one chunk's LDS-DMA pieces, behind the tap's MFMAs (taps 0..7)
                 if constexpr (DMA && i < 8) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1434,12 +1440,16 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     int nbe_w = 0;                                                       // ... and this wave's blocks that hold any of them
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) nbe_w += (wv + NW * j) * 32 < nvalid_blk && j < nblk;
+    // the wave whose last multiplied block is the tile's last one, when that block holds nothing but the last halo row
+    constexpr bool LASTROW_BLK = (NBLK - 1) * 32 >= (PH - 1) * PW;
+    const bool half_last = LASTROW_BLK && !(p.dbg & 16) && wv == (NBLK - 1) % NW && nbe_w == (NBLK - 1) / NW + 1;
     if constexpr (NBJ > 1) {
-        if (nbe_w == 2) kloop(std::integral_constant<int, 2>{});
-        else if (nbe_w == 1) kloop(std::integral_constant<int, 1>{});
+        if (nbe_w == 2) { if (half_last) kloop(std::integral_constant<int, 2 | 4>{}); else kloop(std::integral_constant<int, 2>{}); }
+        else if (nbe_w == 1) { if (half_last) kloop(std::integral_constant<int, 1 | 4>{}); else kloop(std::integral_constant<int, 1>{}); }
         else kloop(std::integral_constant<int, 0>{});
     } else {
-        if (nbe_w == 1) kloop(std::integral_constant<int, 1>{}); else kloop(std::integral_constant<int, 0>{});
+        if (nbe_w == 1) { if (half_last) kloop(std::integral_constant<int, 1 | 4>{}); else kloop(std::integral_constant<int, 1>{}); }
+        else kloop(std::integral_constant<int, 0>{});
     }
     if (p.tstamps && tid == 0) {
         unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
