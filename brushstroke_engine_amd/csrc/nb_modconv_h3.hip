@@ -1077,6 +1077,7 @@ extern "C" int nb_modconv3x3_up1_h3_h2(const void* x_h2, int c_in, const void* w
 #define NB_H3_TQH 12
 #endif
 #define NB_H3_TQH_SMALL 5       // tile height of the under-filled (batch-1) launches
+#define NB_H3_TQH_MID 8         // 10 x 34 = 340 positions = 11 blocks (3 / 3 / 3 / 2 per SIMD): for launches whose 12-row tiles end in a mostly empty round of workgroups
 #define NB_H3_STAGES 3          // LDS-DMA stages of the up=2 kernel (planes at their exact size: 3 x 52 032 B for the 12-row tile)
 struct H3Up2Params {
     const _Float16* x;      // H2 [n][c8][2][H][W][8]
@@ -1639,7 +1640,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
 }
 
 static int g_force_tqh = -1;
-// developer / test hook: 0 = automatic tile choice, NB_H3_TQH or NB_H3_TQH_SMALL = force that tile height
+// developer / test hook: 0 = automatic tile choice, NB_H3_TQH, NB_H3_TQH_MID or NB_H3_TQH_SMALL = force that tile height
 extern "C" void nb_debug_set_up2_tile(int tqh) { g_force_tqh = tqh; }
 static int g_force_pair = -1;
 // developer / test hook: -1 = automatic, 0 / 1 = never / always the two-workgroups-per-CU form (4 waves, 12 x 16 tiles, 2 stages)
@@ -1715,10 +1716,21 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
     const long wgs_big = (long)n * p.tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * p.slices;
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
+    // 8-row tiles when the 12-row tiles' last round of workgroups would leave most of the chip idle.  Estimate = rounds of 256
+    // workgroups x cost of one (critical SIMD's position blocks 4 / 3, + prologue and epilogue ~ quads): b64.conv0 at batch 32
+    // (32 input rows) is 384 workgroups = 1.5 rounds of 12-row tiles, but 512 = 2 full rounds of 8-row tiles at 0.73 the cost.
+    bool mid_tiles = force_tqh == NB_H3_TQH_MID;
+    if (!force_tqh && !small_tiles) {
+        constexpr long ncu = 256;                     // MI355X (one workgroup of this kernel per CU)
+        const long wgs_mid = (long)n * p.tiles_x * ((h + NB_H3_TQH_MID - 1) / NB_H3_TQH_MID) * p.slices;
+        const double est_big = (double)((wgs_big + ncu - 1) / ncu) * 5.4, est_mid = (double)((wgs_mid + ncu - 1) / ncu) * 3.93;
+        mid_tiles = est_mid < 0.9 * est_big;
+    }
     // two 4-wave workgroups per CU on 12 x 16 tiles (see the kernel's NW_ / NST_) when that launch fills the chip as well
     static const int env_pair = getenv("NB_UP2_PAIR") ? atoi(getenv("NB_UP2_PAIR")) : 0;
-    const bool pair = !in_fmt && (g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && wgs_big * 2 >= 1024));
+    const bool pair = !in_fmt && (g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && !mid_tiles && wgs_big * 2 >= 1024));
     if (pair) return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
+    if (mid_tiles) return nb_up2_h3_launch<NB_H3_TQH_MID>(p, n, in_fmt, stream);
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }
 

@@ -16,7 +16,8 @@ extern "C" {
  * wave.  tests/test_hip_f8.py asserts both forms bit-identical. */
 void nb_debug_set_up1_rows(int nbw);
 
-/* Tile height of the split-f16 up=2 kernel: 0 = automatic, 12 = throughput tiles, 5 = the under-filled (batch-1) tiles. */
+/* Tile height of the split-f16 up=2 kernel: 0 = automatic, 12 = throughput tiles, 8 = the tiles of launches whose 12-row tiles
+ * would end in a mostly empty round of workgroups, 5 = the under-filled (batch-1) tiles. */
 void nb_debug_set_up2_tile(int tqh);
 
 /* Workgroup form of the split-f16 up=2 kernel: -1 = automatic, 0 = 8 waves / 12 x 32 tiles / 3 LDS stages (one workgroup per

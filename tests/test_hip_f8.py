@@ -148,8 +148,8 @@ def test_f8_tiled_canvas_matches_reference():
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("ci,co,h,w", [(128, 64, 32, 32), (144, 128, 24, 64)])
 def test_up2_tile_heights_agree(fmt, ci, co, h, w):
-    """The up=2 split-f16 kernel has two tile heights (12 quad rows for throughput, 5 for under-filled launches such as
-    batch 1).  Both walk the same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical; 24 rows do
+    """The up=2 split-f16 kernel has three tile heights (12 quad rows for throughput, 8 where those would end in a mostly
+    empty round of workgroups, 5 for under-filled launches such as batch 1).  Both walk the same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical; 24 rows do
     not divide by 5 (overhanging last tile)."""
     from brushstroke_engine_amd import _lib, ops
     rs = np.random.RandomState(ci + h + fmt)
@@ -166,7 +166,7 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for tqh in (12, 5, "pair"):
+        for tqh in (12, 8, 5, "pair"):
             lib.nb_debug_set_up2_tile(12 if tqh == "pair" else tqh)
             lib.nb_debug_set_up2_pair(1 if tqh == "pair" else 0)
             y = torch.empty([n, co, 2 * h, 2 * w], device="cuda")
@@ -183,6 +183,8 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
         lib.nb_debug_set_up2_pair(-1)
     assert torch.equal(res[12][0], res[5][0])
     assert torch.equal(res[12][1], res[5][1])
+    assert torch.equal(res[12][0], res[8][0])                # 8-row tiles (launches that would end in a mostly empty round of 12-row tiles)
+    assert torch.equal(res[12][1], res[8][1])
     assert torch.equal(res[12][0], res["pair"][0])           # two 4-wave workgroups per CU on 12 x 16 tiles: the same arithmetic
     assert torch.equal(res[12][1], res["pair"][1])
     # and against float64 (loose: the exact bounds live in test_f8_kernels_vs_float64)
