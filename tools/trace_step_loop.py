@@ -12,7 +12,7 @@ if os.environ.get("NB_SUB"):
     G.sub_streams = int(os.environ["NB_SUB"])
 if os.environ.get("NB_H3_MIN_PIX"):
     G.synthesis.h3_min_pixels = int(os.environ["NB_H3_MIN_PIX"])
-z = torch.from_numpy(synthetic.batch_z(cfg, B, 0)).to(dev)
+z = torch.from_numpy(synthetic.batch_z(cfg, B, 0)).to(dev).to(torch.float32)       # (as bench.py: no per-step cast)
 geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, 0)]
 pos = torch.from_numpy(synthetic.positions(cfg, B, 0)).to(dev)
 for _ in range(60): G.render_triad(z=z, geom_feature=geom, positions=pos, join=False)
