@@ -59,9 +59,13 @@ __device__ __forceinline__ float nb_sm_epilogue(float v, float bias, float alpha
 // OCC = workgroups per CU the register budget is sized for: 2 (256 VGPRs: 20 of them spill, but two workgroups share a CU
 // when a launch has more than one round of them) or 1 (no spills: 1-2 us less per launch when every CU gets at most one
 // workgroup anyway -- batch 1 and the <= 8x8 layers of a batch)
-template <int OCC>
-__global__ __launch_bounds__(256, OCC) void modconv3x3_up1_small_h3_kernel(const SmallParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 4 * NB_SM_NHP * 16];     // [wave][plane][slot] (26 KB: fits next to a large-tile workgroup)
+// NWV = waves that split K: 4, or 8 (one workgroup per CU) -- with the 128-channel layers' eight chunks every wave then has ONE
+// chunk: one weight round trip per launch instead of two, which is most of what such a launch spends.
+template <int OCC, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(const SmallParams p) {
+    static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
+    constexpr int NT = NWV * 64, RPW = 16 / NWV;                                              // threads; accumulator rows a wave finishes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NWV * 4 * NB_SM_NHP * 16];   // [wave][plane][slot] (4 waves: 26 KB, fits next to a large-tile workgroup)
     __shared__ float s_sty[2 * NB_SM_MAX_CIN];
     __shared__ float s_epi[96];
     const int tid = threadIdx.x;
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(256, OCC) void modconv3x3_up1_small_h3_kernel(const
         __builtin_amdgcn_wave_barrier();
     };
 
-    h8 wa0[9][2], wa1[9][2];
-    float xr0[4][8], xr1[4][8];
+    h8 wa0[9][2];
+    float xr0[4][8];
     const int NC = p.nchunks;
     int c = wv;
     if (c < NC) { load_w(c, wa0); load_x(c, xr0); }
@@ -193,47 +197,68 @@ __global__ __launch_bounds__(256, OCC) void modconv3x3_up1_small_h3_kernel(const
         }
         s_epi[tid] = v;
     }
-    for (int i = tid; i < p.spt * p.c_in; i += 256) {
+    for (int i = tid; i < p.spt * p.c_in; i += NT) {
         const int s = i / p.c_in, cc = i - s * p.c_in;
         s_sty[s * NB_SM_MAX_CIN + cc] = n0 + s < p.n ? p.styles[(size_t)(n0 + s) * p.c_in + cc] : 0.f;
     }
     __syncthreads();
-    while (c < NC) {
-        int cn = c + 4;
-        stage(c, xr0, mybuf);
-        if (cn < NC) { load_w(cn, wa1); load_x(cn, xr1); }
-        wave_sync();
-        mfma_chunk(wa0, mybuf);
-        c = cn;
-        if (c >= NC) break;
-        cn = c + 4;
-        stage(c, xr1, mybuf);
-        if (cn < NC) { load_w(cn, wa0); load_x(cn, xr0); }
-        wave_sync();
-        mfma_chunk(wa1, mybuf);
-        c = cn;
+    if constexpr (NWV == 8) {
+        // one chunk per wave for up to 128 channels; a wider layer's further chunks are fetched after the current one's products
+        // (no second register set: eight waves are two per SIMD, 256 registers each)
+        while (c < NC) {
+            stage(c, xr0, mybuf);
+            wave_sync();
+            mfma_chunk(wa0, mybuf);
+            c += NWV;
+            if (c < NC) { load_w(c, wa0); load_x(c, xr0); }
+        }
+    } else {
+        h8 wa1[9][2];
+        float xr1[4][8];
+        while (c < NC) {
+            int cn = c + NWV;
+            stage(c, xr0, mybuf);
+            if (cn < NC) { load_w(cn, wa1); load_x(cn, xr1); }
+            wave_sync();
+            mfma_chunk(wa0, mybuf);
+            c = cn;
+            if (c >= NC) break;
+            cn = c + NWV;
+            stage(c, xr1, mybuf);
+            if (cn < NC) { load_w(cn, wa0); load_x(cn, xr0); }
+            wave_sync();
+            mfma_chunk(wa1, mybuf);
+            c = cn;
+        }
     }
 
     // ---- split-K reduction through LDS (the staging buffers are dead after the barrier) ----
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);                // [wave 4][reg 16][lane 64]
+    float* red = reinterpret_cast<float*>(smem);                // [wave][reg 16][lane 64]
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wv * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
     if (!ok) return;
     const size_t Po = (size_t)p.up * p.up * P;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = wv * 4 + j;
-        const int co = co0 + j + 8 * wv + 4 * lh;
+    for (int j = 0; j < RPW; ++j) {
+        const int r = wv * RPW + j;                             // accumulator register r <-> c_out row (r & 3) + 8 (r >> 2) + 4 lh
+        const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = co0 + col;
         if (co < p.c_out) {
-            const float sum = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane];
-            const int col = j + 8 * wv + 4 * lh;
+            // (the four-wave sum keeps its association; eight waves add the second four the same way)
+            float sum = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane];
+            if constexpr (NWV == 8)
+                sum += red[(4 * 16 + r) * 64 + lane] + red[(5 * 16 + r) * 64 + lane] + red[(6 * 16 + r) * 64 + lane] + red[(7 * 16 + r) * 64 + lane];
             const float v = nb_sm_epilogue(sum * s_epi[s_ * 32 + col] + nz, s_epi[64 + col], p.alpha, p.gain, p.clamp);
             p.y[((size_t)ns * p.c_out + co) * Po + (size_t)oyo * Wo + oxo] = v;
         }
     }
 }
+
+static int g_force_small_waves = 0;
+// developer / test hook: 0 = automatic, 4 / 8 = that many K-splitting waves per workgroup
+extern "C" void nb_debug_set_small_waves(int waves) { g_force_small_waves = waves; }
 
 static int nb_small_h3_impl(const float* x, int c1, const float* x2, int c2, const void* w_h3, const float* styles, const float* dcoefs,
                             const float* noise, int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
@@ -261,8 +286,16 @@ static int nb_small_h3_impl(const float* x, int c1, const float* x2, int c2, con
     p.slices = (c_out + 31) / 32;
     NB_REQUIRE(p.spt <= 2 && p.spt * (p.rows + 2) * (p.cols + 2) <= NB_SM_NHP, "modconv3x3_small_h3: unsupported image size %dx%d", h, w);
     dim3 grid(p.tiles_x * tiles_y * p.slices, (n + p.spt - 1) / p.spt, up * up);
-    if ((long)grid.x * grid.y * grid.z <= 256) hipLaunchKernelGGL(modconv3x3_up1_small_h3_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(modconv3x3_up1_small_h3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    // eight K-splitting waves when the chunks give every one of them work.  The rule looks at the layer only, never at the batch:
+    // the two forms associate the partial sums differently, and a sample's result must not depend on what it is batched with.
+    // (NB_SMALL_WAVES = 4 / 8 forces the form; 0 = this rule)
+    static const int env_waves = getenv("NB_SMALL_WAVES") ? atoi(getenv("NB_SMALL_WAVES")) : 0;
+    const int force_waves = g_force_small_waves > 0 ? g_force_small_waves : env_waves;
+    const bool eight = force_waves ? force_waves == 8 : p.nchunks >= 8;
+    if (eight) hipLaunchKernelGGL((modconv3x3_up1_small_h3_kernel<1, 8>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    else if (wgs <= 256) hipLaunchKernelGGL((modconv3x3_up1_small_h3_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((modconv3x3_up1_small_h3_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_small_h3");
     return NB_OK;
 }

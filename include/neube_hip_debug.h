@@ -16,6 +16,10 @@ extern "C" {
  * wave.  tests/test_hip_f8.py asserts both forms bit-identical. */
 void nb_debug_set_up1_rows(int nbw);
 
+/* K-splitting waves per workgroup of the small-image kernel (modconv3x3_up1_small_h3): 0 = automatic (8 for layers of >= 8
+ * sixteen-channel chunks), 4 or 8 = force. */
+void nb_debug_set_small_waves(int waves);
+
 /* Tile height of the split-f16 up=2 kernel: 0 = automatic, 12 = throughput tiles, 8 = the tiles of launches whose 12-row tiles
  * would end in a mostly empty round of workgroups, 5 = the under-filled (batch-1) tiles. */
 void nb_debug_set_up2_tile(int tqh);

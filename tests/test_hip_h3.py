@@ -206,10 +206,12 @@ def test_fused_torgb_equals_standalone(res):
 
 # ---------------------------------------------------------------- small-image split-f16 conv1 kernel
 @pytest.mark.parametrize("shape", [(1, 128, 128, 4), (3, 128, 128, 4), (2, 128, 128, 8), (1, 128, 96, 16), (2, 64, 128, 32),
-                                   (1, 128, 128, 64), (5, 48, 40, 8)])
-def test_up1_small_h3_vs_oracle(dev, shape):
-    """nb_modconv3x3_up1_small_h3 (32 x 32 tiles, K split over the waves; 4x4 images two samples per tile, odd batch =
-    half-empty last tile) against the fp32 CPU oracle.  Tolerance 5e-5 on O(1) activations, like the large-tile kernel."""
+                                   (1, 128, 128, 64), (5, 48, 40, 8), (2, 256, 64, 16)])
+@pytest.mark.parametrize("waves", [0, 4, 8])
+def test_up1_small_h3_vs_oracle(dev, shape, waves):
+    """nb_modconv3x3_up1_small_h3 (32 x 32 tiles, K split over 4 or 8 waves -- 0 = the library's rule; 4x4 images two samples
+    per tile, odd batch = half-empty last tile) against the fp32 CPU oracle.  Tolerance 5e-5 on O(1) activations, like the
+    large-tile kernel."""
     from brushstroke_engine_amd import ops, _lib
     from oracle import neube_oracle as orc
     n, ic, oc, h = shape
@@ -228,16 +230,22 @@ def test_up1_small_h3_vs_oracle(dev, shape):
     w_h3 = ops.pack_conv_weight_h3(wd)
     xd, nd, bd = D(x, dev), D(noise, dev), D(b, dev)
     y = torch.full([n, oc, h, h], float("nan"), dtype=torch.float32, device=dev)
-    rc = _lib.lib().nb_modconv3x3_up1_small_h3(xd.data_ptr(), ic, w_h3.data_ptr(), sd_.data_ptr(), d.data_ptr(), nd.data_ptr(),
-                                               h * h, bd.data_ptr(), y.data_ptr(), n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0,
-                                               torch.cuda.current_stream().cuda_stream)
+    _lib.lib().nb_debug_set_small_waves(waves)
+    try:
+        rc = _lib.lib().nb_modconv3x3_up1_small_h3(xd.data_ptr(), ic, w_h3.data_ptr(), sd_.data_ptr(), d.data_ptr(), nd.data_ptr(),
+                                                   h * h, bd.data_ptr(), y.data_ptr(), n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0,
+                                                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().nb_debug_set_small_waves(0)
     _lib.check(rc, "small_h3")
     assert maxerr(y, want) <= 5e-5
 
 
 @pytest.mark.parametrize("shape", [(1, 128, 0, 128, 4), (3, 128, 0, 128, 4), (2, 128, 0, 128, 8), (1, 128, 0, 96, 16),
                                    (1, 128, 16, 128, 32), (2, 32, 16, 40, 8)])
-def test_up2_small_h3_vs_oracle(dev, shape):
+@pytest.mark.parametrize("waves", [0, 8])
+def test_up2_small_h3_vs_oracle(dev, shape, waves):
     """nb_modconv3x3_up2_small_h3 (FIR folded into four per-phase 3x3 kernels, phases as grid.z; optional concatenated
     second input) against the fp32 CPU oracle's conv_transpose2d + upfirdn2d.  Tolerance 5e-5 on O(1) activations."""
     from brushstroke_engine_amd import ops, _lib
@@ -262,8 +270,13 @@ def test_up2_small_h3_vs_oracle(dev, shape):
     x2 = D(x[:, c1:], dev) if c2 else None
     nd, bd = D(noise, dev), D(b, dev)
     y = torch.full([n, oc, 2 * h, 2 * h], float("nan"), dtype=torch.float32, device=dev)
-    rc = _lib.lib().nb_modconv3x3_up2_small_h3(x1.data_ptr(), c1, None if x2 is None else x2.data_ptr(), c2, wph.data_ptr(),
-                                               sd_.data_ptr(), d.data_ptr(), nd.data_ptr(), 4 * h * h, bd.data_ptr(), y.data_ptr(),
-                                               n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0, torch.cuda.current_stream().cuda_stream)
+    _lib.lib().nb_debug_set_small_waves(waves)
+    try:
+        rc = _lib.lib().nb_modconv3x3_up2_small_h3(x1.data_ptr(), c1, None if x2 is None else x2.data_ptr(), c2, wph.data_ptr(),
+                                                   sd_.data_ptr(), d.data_ptr(), nd.data_ptr(), 4 * h * h, bd.data_ptr(), y.data_ptr(),
+                                                   n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().nb_debug_set_small_waves(0)
     _lib.check(rc, "small_h3_up2")
     assert maxerr(y, want) <= 5e-5

@@ -9,7 +9,7 @@ for i in 1 2 3; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['roofline']['calibration']['kernels']; l = d['roofline']['calibration']['layers_ms']
-print('$lib $mode', round(d['value']), 'patches/s', d['ms_per_step'], 'ms/step; up2', k['modconv3x3_up2_h3_kernel']['ms_per_step'], 'ms/step; 144->128@64', l.get('modconv3x3_up2[144->128@64]'))
+print('$lib $mode', round(d['value']), 'patches/s', d['ms_per_step'], 'ms/step; up2', k['modconv3x3_up2_h3_kernel']['ms_per_step'], 'small', k.get('modconv3x3_up1_small_h3_kernel', {}).get('ms_per_step'), 'ms/step; 144->128@64', l.get('modconv3x3_up2[144->128@64]'))
 "
     done
   done
