@@ -315,6 +315,10 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     const int wm = wv / NWN, wn = wv - wm * NWN;  // wave coordinates (c_out, pixel rows)
     const int H = p.h, W = p.w;
     int b = blockIdx.x;
+    // XCD-aware order (as in the up=2 kernel below): hardware workgroup ids go round-robin to the 8 XCDs, each with its own L2;
+    // renumbered, an XCD works on a contiguous run of the row-major tile list -- whole tile rows -- so that the halo columns
+    // and rows neighbouring tiles share are L2 hits instead of second HBM reads
+    if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int slice = b % p.slices; b /= p.slices;
     const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
     const int n = blockIdx.y;

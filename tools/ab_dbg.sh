@@ -1,5 +1,5 @@
 # Same-box A/B of bench.py with one library, a feature switched off through NB_DEBUG (bit mask read by the conv launchers: 8 = no XCD
-# renumbering in the up=2 kernel, 16 = its last-halo-row block takes all four phases), alternating runs:
+# renumbering in the split-f16 kernels, 16 = the up=2 kernel's last-halo-row block takes all four phases), alternating runs:
 #   gpurun -- 'bash tools/ab_dbg.sh 16'
 BIT=${1:-16}
 for i in 1 2 3; do
@@ -10,7 +10,7 @@ for i in 1 2 3; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['roofline']['calibration']['kernels']
-print('$lib $mode', round(d['value']), 'patches/s', d['ms_per_step'], 'ms/step; up2', k['modconv3x3_up2_h3_kernel']['ms_per_step'], 'ms/step')
+print('$lib $mode', round(d['value']), 'patches/s', d['ms_per_step'], 'ms/step;', ' '.join('%s %.4f' % (n.replace('modconv3x3_', ''), v['ms_per_step']) for n, v in k.items()))
 "
     done
   done
