@@ -206,7 +206,7 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
     B = args.batch
     # the generator runs a batch as `sub` sub-batches on separate HIP streams; with N>1 each part's RGBA tiles are
     # gathered from the part's own stream, so steps keep overlapping across the streams at any N
-    sub = G.sub_streams if (B >= G.sub_stream_min_batch and not args.pipeline) else 1
+    sub = G.sub_streams if (B >= G.sub_stream_min_batch and not args.pipeline and not args.prefetch) else 1
     gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if gather else None
     part_gatherers = []
     if gatherer is not None and sub > 1:
@@ -228,12 +228,17 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
     schedule = ("steps software-pipelined over two HIP streams (pipeline.TriadStepPipeline): the head of step k+1 -- mapping, styles, "
                 "the <= 16x16 layers: 2 % of the FLOPs in latency-bound launches -- runs under the big convolutions of step k"
                 if pipe is not None else "steps enqueued back to back on one stream")
+    if args.prefetch and pipe is None:
+        from brushstroke_engine_amd.pipeline import TriadPrefetchPipeline
+        pipe = TriadPrefetchPipeline(G, mark_layer=os.environ.get("NB_PREFETCH_MARK") or None)
+        schedule = ("steps on one stream; what step k+1 needs before its first layer (mapping, styles, small layers' noise, geometry "
+                    "packs: no matrix work) is enqueued on a side stream under the LAST layer of step k (pipeline.TriadPrefetchPipeline)")
 
     def step():
         if pipe is not None:
             u8 = pipe.submit(z, geom, pos)
             if gatherer is not None:
-                with torch.cuda.stream(pipe.tail_stream):
+                with torch.cuda.stream(getattr(pipe, "tail_stream", None) or pipe.main_stream):
                     gatherer.finish()
                     gatherer.start(u8)
             return
@@ -472,6 +477,9 @@ def main():
                          "timed steps) and reported under `modes`; default: all three at N=1, the primary one only at N>1; 'primary' = only it")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="run what a step needs before its first layer (mapping, styles, geometry packs) on a side stream under the "
+                         "last layer of the step before (pipeline.TriadPrefetchPipeline; bit-identical results)")
     ap.add_argument("--pipeline", action="store_true",
                     help="software-pipeline the steps over two streams (pipeline.TriadStepPipeline: head of step k+1 under the tail of step k; "
                          "+2 %% measured) instead of enqueueing them back to back on ONE stream, where every launch has the chip to itself "

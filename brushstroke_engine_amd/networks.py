@@ -413,6 +413,14 @@ class SynthesisNetwork(torch.nn.Module):
         # already in the workspace slot -- an earlier pass of the same batch computed them (pipeline.TriadStepPipeline: the
         # head pass computes every layer's styles, the tail pass of the same step resumes from its features)
         reuse_styles = block_kwargs.pop("_reuse_styles", False)
+        # `_prepare_only`: enqueue what a pass needs BEFORE its first layer -- every layer's styles and demodulation coefficients,
+        # the small layers' noise images (all into the workspace slot) and the early geometry packs -- and return a handle;
+        # `_prepared=handle`: the pass of the same batch on the same slot that starts from it (pipeline.TriadPrefetchPipeline runs
+        # the former for step k+1 under the last layer of step k).  `_mark=(event, layer name)`: record the event on the current
+        # stream right before that layer's launch.
+        prepare_only = block_kwargs.pop("_prepare_only", False)
+        prepared = block_kwargs.pop("_prepared", None)
+        mark = block_kwargs.pop("_mark", None)
         if block_kwargs:
             raise TypeError(f"unexpected synthesis kwargs: {sorted(block_kwargs)}")
         if noise_mode not in ("random", "const", "none"):
@@ -430,6 +438,12 @@ class SynthesisNetwork(torch.nn.Module):
         plan = self._get_plan(n, device, plan_slot)
         lib = _lib.lib()
         lazy_geom = geom_feature if hasattr(geom_feature, "encode_for") else None      # encoder.LazyGeometry
+        if prepare_only or prepared is not None:
+            if (lazy_geom is not None or noise_mode != "const" or noise_buffers or resume is not None or stop_after is not None
+                    or reuse_styles or blended_features):
+                raise RuntimeError("_prepare_only / _prepared: whole passes with constant noise and plain geometry tensors only")
+            if prepared is not None and (prepared["n"] != n or prepared["slot"] != plan_slot or prepared["plan"] is not plan):
+                raise RuntimeError("_prepared: the handle belongs to another batch size or workspace slot")
         if lazy_geom is None:
             geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
         keep_alive = []
@@ -458,7 +472,9 @@ class SynthesisNetwork(torch.nn.Module):
                 while k_ > 0 and elig[k_ - 1]:
                     k_ -= 1
                 inkernel_from = k_ if k_ < len(elig) else None
-            if reuse_styles:
+            if prepared is not None:
+                pass                                # styles, coefficients and noise images are in the workspace slot already
+            elif reuse_styles:
                 if resume is None or (inkernel_from is None and noise_mode == "const") or table is not plan.table:
                     raise RuntimeError("_reuse_styles needs a resumed pass whose layers compute their noise themselves")
                 if any(i_ < inkernel_from for i_, sp in enumerate(cfg.layers) if sp.block_res > resume[0]) and noise_mode == "const":
@@ -491,7 +507,7 @@ class SynthesisNetwork(torch.nn.Module):
             # Geometry channels of the layers that receive their input in H2 / f8 operand format: packed NOW on a side
             # stream (they only need the consumer's styles), under the small first layers, instead of between the
             # producer and the consumer.  pre_h2[res] = (consumer input tensor, event).
-            pre_h2 = {}
+            pre_h2 = {} if prepared is None else dict(prepared["pre_h2"])
             pack_waited = False           # has plan.pack_stream been ordered behind this call's styles launch yet?
             if lazy_geom is not None:
                 # geometry not encoded yet: let the encoder write the features that feed an H2 / f8 layer input straight into
@@ -523,7 +539,7 @@ class SynthesisNetwork(torch.nn.Module):
                     geom_feature = list(lazy_geom.encode_for(targets))
                     if any(geom_feature[k] is None and k not in targets for k in range(len(geom_feature))):
                         raise RuntimeError("geometry provider returned no tensor for a feature the generator needs in fp32")
-            if self.early_geom_pack and self.h2_handoff:
+            if self.early_geom_pack and self.h2_handoff and prepared is None:
                 specs_ = {s_.name: (i_, s_) for i_, s_ in enumerate(cfg.layers)}
                 gi = 0
                 for gres in self.geom_feature_resolutions:
@@ -570,6 +586,8 @@ class SynthesisNetwork(torch.nn.Module):
                     dst.record_stream(plan.pack_stream)
                     pre_h2[gres] = (dst, ev_)
 
+            if prepare_only:
+                return {"pre_h2": pre_h2, "keep": keep_alive, "n": n, "slot": plan_slot, "plan": plan}
             debug_data = {}
             x = img = None
             x2 = None
@@ -600,6 +618,8 @@ class SynthesisNetwork(torch.nn.Module):
                     i, s = specs[name]
                     layer = self.layer_module(s)
                     pk = self.packed[name]
+                    if mark is not None and name == mark[1]:
+                        mark[0].record(torch.cuda.current_stream(device))
                     c2 = 0 if x2 is None else x2.shape[1]
                     c1 = s.in_channels - c2 if x is None else x.shape[1]
                     if c1 + c2 != s.in_channels:

@@ -110,3 +110,82 @@ class TriadStepPipeline:
     def flush(self) -> None:
         self.wait()
         self._forked = False
+
+
+PREFETCH_SLOT0 = 28      # workspace slots of the prefetch pipeline
+
+
+class TriadPrefetchPipeline:
+    """The lighter software pipeline: only what a step needs BEFORE its first layer runs ahead.
+
+    Mapping network, all layers' styles and demodulation coefficients, the small layers' noise images and the early geometry
+    packs (fp32 geometry features x the consumer's styles -> operand format: 265 MB of HBM traffic per batch of 32 at R=256)
+    hold no matrix work; enqueued in front of a step they are 35 us of latency-bound launches plus a memory-bound kernel that
+    costs whatever layers it runs beside ~45 us.  Here they run for step k+1 on a side stream, released by an event recorded
+    right before the LAST layer of step k (64 -> 64 @ 256 with the fused ToRGB: a matrix-bound launch with HBM bandwidth to
+    spare) -- the dominant up=2 launches keep the chip to themselves.  ``Synthesis.forward(_prepare_only=True)`` returns the
+    handle (packed operand tensors + events; styles etc. sit in the workspace slot) that the step's own pass starts from
+    (``_prepared``).  Results are bit-identical to ``Generator.render_triad`` (tests/test_hip_generator.py).
+
+    ``submit`` returns the batch's uint8 RGBA tiles ``[N, R, R, 4]``, valid on ``main_stream`` (``wait()`` / ``flush()``)."""
+
+    def __init__(self, G, depth: int = 2, render_mode: str = "clear", mark_layer: Optional[str] = None):
+        dev = G.synthesis.get_last_block().conv1.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("TriadPrefetchPipeline needs the generator on a GPU")
+        self.G, self.device, self.depth, self.render_mode = G, dev, int(depth), render_mode
+        self.mark_layer = mark_layer or G.synthesis.cfg.layers[-1].name
+        self.prep_stream = torch.cuda.Stream(device=dev)
+        self.main_stream = torch.cuda.Stream(device=dev)
+        self._main_done: List[Optional[torch.cuda.Event]] = [None] * self.depth     # slot free again (its pass has finished)
+        self._mark_prev: Optional[torch.cuda.Event] = None                          # previous step reached its marked layer
+        self._k = 0
+        self._forked = False
+
+    def submit(self, z, geom_feature, positions, user_colors=None, sfactor=None) -> torch.Tensor:
+        if positions is None:
+            raise RuntimeError("TriadPrefetchPipeline renders positioned patches (shifted noise); use Generator.render_triad otherwise")
+        G = self.G
+        cur = torch.cuda.current_stream(self.device)
+        if not self._forked:                       # inputs were produced on the caller's stream
+            self.prep_stream.wait_stream(cur)
+            self.main_stream.wait_stream(cur)
+            self._forked = True
+        geom = list(geom_feature)
+        slot = self._k % self.depth
+        self._k += 1
+        # preparation of this step: once the slot's previous pass has finished with the workspace, and not before the previous
+        # step has reached its last layer
+        if self._main_done[slot] is not None:
+            self.prep_stream.wait_event(self._main_done[slot])
+        if self._mark_prev is not None:
+            self.prep_stream.wait_event(self._mark_prev)
+        with torch.cuda.stream(self.prep_stream):
+            ws = G.mapping(z, None)
+            handle = G.synthesis(ws, geom, noise_mode="const", _positions=positions, _plan_slot=PREFETCH_SLOT0 + slot,
+                                 _prepare_only=True)
+            ready = torch.cuda.Event()
+            ready.record(self.prep_stream)
+        for t in [ws] + [dst for dst, _ in handle["pre_h2"].values()] + [t_ for t_ in handle["keep"] if isinstance(t_, torch.Tensor)]:
+            t.record_stream(self.main_stream)       # allocated on the side stream, read by the step's own pass
+        self.main_stream.wait_event(ready)
+        mark = torch.cuda.Event()
+        with torch.cuda.stream(self.main_stream):
+            u8, _, _ = G.render_triad(ws=ws, geom_feature=geom, positions=positions, render_mode=self.render_mode,
+                                      user_colors=user_colors, sfactor=sfactor, _plan_slot=PREFETCH_SLOT0 + slot,
+                                      _prepared=handle, _mark=(mark, self.mark_layer))
+            done = torch.cuda.Event()
+            done.record(self.main_stream)
+        self._main_done[slot] = done
+        self._mark_prev = mark
+        return u8
+
+    def wait(self, stream=None) -> None:
+        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far."""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        stream.wait_stream(self.main_stream)
+        stream.wait_stream(self.prep_stream)
+
+    def flush(self) -> None:
+        self.wait()
+        self._forked = False

@@ -354,6 +354,29 @@ def test_step_pipeline_equals_plain_steps(dev, mode, res, n):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mode,res,n", [("f8", 256, 32), ("h3", 256, 16), ("f8", 128, 32), ("f32", 128, 8), ("f8", 256, 2)])
+def test_prefetch_pipeline_equals_plain_steps(dev, mode, res, n):
+    """pipeline.TriadPrefetchPipeline -- mapping, styles, noise images and geometry packs of batch k+1 on a side stream under the
+    last layer of batch k, handed to the batch's own pass as a handle -- returns, for a sequence of DIFFERENT batches, exactly
+    the bytes Generator.render_triad returns for each of them (every mode and batch size: nothing in it depends on the kernels)."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic
+    from brushstroke_engine_amd.pipeline import TriadPrefetchPipeline
+    cfg = cfgmod.style1_config(res)
+    G, _ = build(cfg, 0, dev, mode)
+    batches = []
+    for k in range(5):
+        batches.append((D(synthetic.batch_z(cfg, n, 50 + k * n), dev), [D(x, dev) for x in synthetic.geom_features(cfg, n, seed=k)],
+                        D(synthetic.positions(cfg, n, seed=k), dev)))
+    want = [G.render_triad(z=z, geom_feature=g, positions=p)[0].clone() for z, g, p in batches]
+    pipe = TriadPrefetchPipeline(G)
+    for rep in range(3):
+        got = [pipe.submit(z, g, p) for z, g, p in batches]
+        pipe.flush()
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("mode", ["f32", "h3", "f8"])
 def test_trained_like_fixture(dev, mode):
     """Trained-like weight statistics (weights.trained_like_state_dict: log-normal per-channel scales, two dominant styles per
