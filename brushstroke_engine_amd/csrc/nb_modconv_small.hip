@@ -31,6 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define NB_SM_NHP 104            // slots per (channel group, hi/lo) plane of the halo tile (max 3 x 34 = 102)
+#define NB_SM_NHP2 136           // ... of a two-block tile (max 4 x 34 = 136)
 #define NB_SM_MAX_CIN 512
 
 struct SmallParams {
@@ -61,11 +62,16 @@ __device__ __forceinline__ float nb_sm_epilogue(float v, float bias, float alpha
 // workgroup anyway -- batch 1 and the <= 8x8 layers of a batch)
 // NWV = waves that split K: 4, or 8 (one workgroup per CU) -- with the 128-channel layers' eight chunks every wave then has ONE
 // chunk: one weight round trip per launch instead of two, which is most of what such a launch spends.
-template <int OCC, int NWV = 4>
+// TB = 32-position blocks per tile: 1, or 2 (twice the rows; one sample per tile) when the launch has more than a round of
+// workgroups: the weight fragments a wave fetched serve both blocks, half as many workgroups fetch them at all.  Per-position
+// arithmetic is the same in both forms (bit-identical results).
+template <int OCC, int NWV = 4, int TB = 1>
 __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(const SmallParams p) {
     static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
+    static_assert(TB == 1 || TB == 2, "1 or 2 position blocks");
     constexpr int NT = NWV * 64, RPW = 16 / NWV;                                              // threads; accumulator rows a wave finishes
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NWV * 4 * NB_SM_NHP * 16];   // [wave][plane][slot] (4 waves: 26 KB, fits next to a large-tile workgroup)
+    constexpr int NHP = TB == 1 ? NB_SM_NHP : NB_SM_NHP2, NR = (2 * NHP + 63) / 64;           // plane slots; staging rounds of 64 tasks
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NWV * 4 * NHP * 16];         // [wave][plane][slot] (4 waves: 26 KB, fits next to a large-tile workgroup)
     __shared__ float s_sty[2 * NB_SM_MAX_CIN];
     __shared__ float s_epi[96];
     const int tid = threadIdx.x;
@@ -83,13 +89,13 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
     // ---- staging tasks of this lane (chunk-invariant): task = round * 64 + lane -> (channel group, halo slot) ----
     // xoff / xoff2 = 32-bit element offset of the slot's pixel in channel cg*8 of the sample in x / x2, tslot = LDS slot
     // (-1: no such task - the slot lies outside the image or the tile and keeps the zero it is given once below), tsty = style row
-    unsigned xoff[4], xoff2[4];
+    unsigned xoff[NR], xoff2[NR];
     const int c2 = p.c_in - p.c1;
-    int tslot[4], tsty[4];
+    int tslot[NR], tsty[NR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int task = r * 64 + lane;
-        const int cg = task / NB_SM_NHP, hp = task - cg * NB_SM_NHP;
+        const int cg = task / NHP, hp = task - cg * NHP;
         xoff[r] = 0; xoff2[r] = 0; tslot[r] = -1; tsty[r] = 0;
         if (cg < 2) {
             if (hp < NH) {
@@ -100,21 +106,27 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
                     xoff[r] = (unsigned)(((n0 + s) * p.c1 + cg * 8) * P + gy * W + gx);
                     xoff2[r] = (unsigned)(((n0 + s) * c2 + cg * 8) * P + gy * W + gx);
                     tsty[r] = s * NB_SM_MAX_CIN + cg * 8;
-                    tslot[r] = cg * 2 * NB_SM_NHP + hp;         // plane (cg, hi); lo = + NB_SM_NHP
+                    tslot[r] = cg * 2 * NHP + hp;               // plane (cg, hi); lo = + NHP
                 }
             }
         }
     }
-    // ---- this lane's output position and its halo base slot ----
-    const int ps = l31 / RC, prem = l31 - ps * RC;
-    const int pty = prem / p.cols, ptx = prem - pty * p.cols;
-    const int hb = ps * (HR * HC) + pty * HC + ptx;             // + ky * HC + kx
-    const int pbase = lh * 2 * NB_SM_NHP + hb;                  // plane (cg = lh, hi); lo = + NB_SM_NHP
+    // ---- this lane's output position(s) -- block j holds positions 32 j .. 32 j + 31 of the tile -- and their halo base slots ----
+    int ps[TB], pty[TB], ptx[TB], pbase[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int pp = j * 32 + l31;
+        ps[j] = pp / RC;
+        const int prem = pp - ps[j] * RC;
+        pty[j] = prem / p.cols; ptx[j] = prem - pty[j] * p.cols;
+        const int hb = ps[j] * (HR * HC) + pty[j] * HC + ptx[j];        // + ky * HC + kx
+        pbase[j] = lh * 2 * NHP + hb;                                   // plane (cg = lh, hi); lo = + NHP
+    }
 
-    h8* mybuf = reinterpret_cast<h8*>(smem) + wv * (4 * NB_SM_NHP);
+    h8* mybuf = reinterpret_cast<h8*>(smem) + wv * (4 * NHP);
     {   // zero padding: slots outside the image are never staged, they keep this zero
         const h8 z8 = {};
-        for (int i = lane; i < 4 * NB_SM_NHP; i += 64) mybuf[i] = z8;
+        for (int i = lane; i < 4 * NHP; i += 64) mybuf[i] = z8;
     }
     const unsigned wstep = (unsigned)(p.co_ld * 8);
     // + ((chunk*9 + tap)*4 + hl) * co_ld * 8  (halves); one weight set per output phase
@@ -127,20 +139,20 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
             for (int hl = 0; hl < 2; ++hl)
                 wa[tap][hl] = *reinterpret_cast<const h8*>(p.wts + (wl + (unsigned)((c * 9 + tap) * 4 + hl) * wstep));
     };
-    auto load_x = [&](int c, float (&xr)[4][8]) {
+    auto load_x = [&](int c, float (&xr)[NR][8]) {
         const bool second = c * 16 >= p.c1;                      // (wave-uniform: c1 % 16 == 0)
         const float* src = second ? p.x2 : p.x;
         const unsigned cbase = (unsigned)((c * 16 - (second ? p.c1 : 0)) * P);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const unsigned o = (second ? xoff2[r] : xoff[r]) + cbase;       // (tasks without a slot read element 0: unused)
 #pragma unroll
             for (int j = 0; j < 8; ++j) xr[r][j] = src[o + (unsigned)(j * P)];
         }
     };
-    auto stage = [&](int c, const float (&xr)[4][8], h8* buf) {
+    auto stage = [&](int c, const float (&xr)[NR][8], h8* buf) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             if (tslot[r] >= 0) {
                 h8 hi, lo;
 #pragma unroll
@@ -151,21 +163,26 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
                     lo[j] = (_Float16)(v - (float)hh);
                 }
                 buf[tslot[r]] = hi;
-                buf[tslot[r] + NB_SM_NHP] = lo;
+                buf[tslot[r] + NHP] = lo;
             }
         }
     };
-    f32x16 acc;
+    f32x16 acc[TB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     auto mfma_chunk = [&](const h8 (&wa)[9][2], const h8* buf) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int off = pbase + (tap / 3) * HC + (tap % 3);
-            const h8 bh = buf[off], bl = buf[off + NB_SM_NHP];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][0], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][0], bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][1], bh, acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int off = pbase[j] + (tap / 3) * HC + (tap % 3);
+                const h8 bh = buf[off], bl = buf[off + NHP];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][0], bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][0], bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[tap][1], bh, acc[j], 0, 0, 0);
+            }
         }
     };
     // wave-private LDS hand-over: all lanes' slot writes must have landed before any lane's fragment reads.  ONE buffer
@@ -177,17 +194,25 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
     };
 
     h8 wa0[9][2];
-    float xr0[4][8];
+    float xr0[NR][8];
     const int NC = p.nchunks;
     int c = wv;
     if (c < NC) { load_w(c, wa0); load_x(c, xr0); }
     // everything else the workgroup needs from global memory is requested now, under the first chunk's loads: the styles
     // (to LDS) and the epilogue's operands (registers) - a launch of this kernel is a few microseconds, so every exposed
     // round trip counts
-    const int s_ = ps, oy = y0 + pty, ox = x0 + ptx, ns = n0 + s_;
-    const bool ok = ns < p.n && l31 < p.spt * RC && oy < H && ox < W;
-    const int Wo = p.up * W, oyo = p.up * oy + py, oxo = p.up * ox + px;
-    const float nz = (ok && p.noise) ? p.noise[(size_t)ns * p.noise_stride_n + (size_t)oyo * Wo + oxo] : 0.f;
+    const int Wo = p.up * W;
+    bool ok[TB];
+    int ns[TB], oyo[TB], oxo[TB];
+    float nz[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int oy = y0 + pty[j], ox = x0 + ptx[j];
+        ns[j] = n0 + ps[j];
+        ok[j] = ns[j] < p.n && j * 32 + l31 < p.spt * RC && oy < H && ox < W;
+        oyo[j] = p.up * oy + py; oxo[j] = p.up * ox + px;
+        nz[j] = (ok[j] && p.noise) ? p.noise[(size_t)ns[j] * p.noise_stride_n + (size_t)oyo[j] * Wo + oxo[j]] : 0.f;
+    }
     if (tid < 96) {                                             // [2 samples][32 c_out] demodulation, [32] bias
         const int co = co0 + (tid & 31), sidx = tid >> 5;
         float v = 0.f;
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
         }
     } else {
         h8 wa1[9][2];
-        float xr1[4][8];
+        float xr1[NR][8];
         while (c < NC) {
             int cn = c + NWV;
             stage(c, xr0, mybuf);
@@ -234,12 +259,18 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
 
     // ---- split-K reduction through LDS (the staging buffers are dead after the barrier) ----
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);                // [wave][reg 16][lane 64]
+    float* red = reinterpret_cast<float*>(smem);                // [block][wave][reg 16][lane 64]
+    static_assert(TB * NWV * 16 * 64 * 4 <= NWV * 4 * NHP * 16, "the reduction buffer must fit the staging buffers");
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wv * 16 + r) * 64 + lane] = acc[r];
+    for (int jb = 0; jb < TB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((jb * NWV + wv) * 16 + r) * 64 + lane] = acc[jb][r];
     __syncthreads();
-    if (!ok) return;
     const size_t Po = (size_t)p.up * p.up * P;
+#pragma unroll
+    for (int jb = 0; jb < TB; ++jb) {
+    if (!ok[jb]) continue;
+    const float* redb = red + (size_t)jb * NWV * 16 * 64;
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int r = wv * RPW + j;                             // accumulator register r <-> c_out row (r & 3) + 8 (r >> 2) + 4 lh
@@ -247,18 +278,20 @@ __global__ __launch_bounds__(NWV * 64, OCC) void modconv3x3_up1_small_h3_kernel(
         const int co = co0 + col;
         if (co < p.c_out) {
             // (the four-wave sum keeps its association; eight waves add the second four the same way)
-            float sum = red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane];
+            float sum = redb[(0 * 16 + r) * 64 + lane] + redb[(1 * 16 + r) * 64 + lane] + redb[(2 * 16 + r) * 64 + lane] + redb[(3 * 16 + r) * 64 + lane];
             if constexpr (NWV == 8)
-                sum += red[(4 * 16 + r) * 64 + lane] + red[(5 * 16 + r) * 64 + lane] + red[(6 * 16 + r) * 64 + lane] + red[(7 * 16 + r) * 64 + lane];
-            const float v = nb_sm_epilogue(sum * s_epi[s_ * 32 + col] + nz, s_epi[64 + col], p.alpha, p.gain, p.clamp);
-            p.y[((size_t)ns * p.c_out + co) * Po + (size_t)oyo * Wo + oxo] = v;
+                sum += redb[(4 * 16 + r) * 64 + lane] + redb[(5 * 16 + r) * 64 + lane] + redb[(6 * 16 + r) * 64 + lane] + redb[(7 * 16 + r) * 64 + lane];
+            const float v = nb_sm_epilogue(sum * s_epi[ps[jb] * 32 + col] + nz[jb], s_epi[64 + col], p.alpha, p.gain, p.clamp);
+            p.y[((size_t)ns[jb] * p.c_out + co) * Po + (size_t)oyo[jb] * Wo + oxo[jb]] = v;
         }
+    }
     }
 }
 
-static int g_force_small_waves = 0;
-// developer / test hook: 0 = automatic, 4 / 8 = that many K-splitting waves per workgroup
+static int g_force_small_waves = 0, g_force_small_blocks = 0;
+// developer / test hooks: 0 = automatic; 4 / 8 = that many K-splitting waves per workgroup; 1 / 2 = position blocks per tile
 extern "C" void nb_debug_set_small_waves(int waves) { g_force_small_waves = waves; }
+extern "C" void nb_debug_set_small_blocks(int blocks) { g_force_small_blocks = blocks; }
 
 static int nb_small_h3_impl(const float* x, int c1, const float* x2, int c2, const void* w_h3, const float* styles, const float* dcoefs,
                             const float* noise, int64_t noise_stride_n, const float* bias, float* y, int n, int h, int w, int c_out,
@@ -293,6 +326,16 @@ static int nb_small_h3_impl(const float* x, int c1, const float* x2, int c2, con
     static const int env_waves = getenv("NB_SMALL_WAVES") ? atoi(getenv("NB_SMALL_WAVES")) : 0;
     const int force_waves = g_force_small_waves > 0 ? g_force_small_waves : env_waves;
     const bool eight = force_waves ? force_waves == 8 : p.nchunks >= 8;
+    // two position blocks per tile (twice the rows) when the launch is more than a round of workgroups: half as many
+    // workgroups fetch the weights (NB_SMALL_BLOCKS = 1 / 2 forces the form where it exists)
+    static const int env_blocks = getenv("NB_SMALL_BLOCKS") ? atoi(getenv("NB_SMALL_BLOCKS")) : 0;
+    const int force_blocks = g_force_small_blocks > 0 ? g_force_small_blocks : env_blocks;
+    const bool can_two = eight && p.spt == 1 && tiles_y % 2 == 0 && (2 * p.rows + 2) * (p.cols + 2) <= NB_SM_NHP2;
+    if (can_two && (force_blocks ? force_blocks == 2 : wgs > 256)) {
+        p.rows *= 2;
+        grid.x = p.tiles_x * (tiles_y / 2) * p.slices;
+        hipLaunchKernelGGL((modconv3x3_up1_small_h3_kernel<1, 8, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    } else
     if (eight) hipLaunchKernelGGL((modconv3x3_up1_small_h3_kernel<1, 8>), grid, dim3(512), 0, (hipStream_t)stream, p);
     else if (wgs <= 256) hipLaunchKernelGGL((modconv3x3_up1_small_h3_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((modconv3x3_up1_small_h3_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);

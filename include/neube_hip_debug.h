@@ -19,6 +19,9 @@ void nb_debug_set_up1_rows(int nbw);
 /* K-splitting waves per workgroup of the small-image kernel (modconv3x3_up1_small_h3): 0 = automatic (8 for layers of >= 8
  * sixteen-channel chunks), 4 or 8 = force. */
 void nb_debug_set_small_waves(int waves);
+/* ... and 32-position blocks per tile: 0 = automatic (2 when the launch is more than a round of workgroups), 1 or 2 = force
+ * (2 only where the form exists: eight waves, one sample per tile). */
+void nb_debug_set_small_blocks(int blocks);
 
 /* Tile height of the split-f16 up=2 kernel: 0 = automatic, 12 = throughput tiles, 8 = the tiles of launches whose 12-row tiles
  * would end in a mostly empty round of workgroups, 5 = the under-filled (batch-1) tiles. */

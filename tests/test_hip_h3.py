@@ -242,6 +242,42 @@ def test_up1_small_h3_vs_oracle(dev, shape, waves):
     assert maxerr(y, want) <= 5e-5
 
 
+@pytest.mark.parametrize("up", [1, 2])
+@pytest.mark.parametrize("n,ic,oc,h", [(2, 128, 128, 16), (1, 128, 96, 64), (3, 128, 128, 8), (2, 256, 64, 32), (5, 144, 128, 32)])
+def test_small_h3_two_block_tiles_bit_identical(dev, up, n, ic, oc, h):
+    """The small-image kernel's two-block tiles (64 positions per workgroup: the weight fragments serve both blocks; taken when a
+    launch is more than a round of workgroups) compute every position exactly as the one-block tiles do."""
+    from brushstroke_engine_amd import ops, _lib
+    from oracle import neube_oracle as orc
+    rs = np.random.RandomState(ic + oc + h + n + up)
+    x = D(rs.randn(n, ic, h, h).astype(np.float32), dev)
+    wt = D(rs.randn(oc, ic, 3, 3).astype(np.float32), dev)
+    sd_ = D((1 + 0.5 * rs.randn(n, ic)).astype(np.float32), dev)
+    bd = D((0.1 * rs.randn(oc)).astype(np.float32), dev)
+    nd = D((0.1 * rs.randn(n, 1, up * h, up * h)).astype(np.float32), dev)
+    d = (sd_.square() @ wt.square().sum(dim=[2, 3]).t().contiguous() + 1e-8).rsqrt()
+    wp = ops.pack_conv_weight_h3(wt) if up == 1 else ops.pack_conv_weight_h3_up2_phases(wt, orc.setup_filter().to(dev))
+    lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    out = {}
+    try:
+        for blocks in (1, 2):
+            lib.nb_debug_set_small_blocks(blocks)
+            y = torch.full([n, oc, up * h, up * h], float("nan"), dtype=torch.float32, device=dev)
+            if up == 1:
+                rc = lib.nb_modconv3x3_up1_small_h3(x.data_ptr(), ic, wp.data_ptr(), sd_.data_ptr(), d.data_ptr(), nd.data_ptr(), h * h,
+                                                    bd.data_ptr(), y.data_ptr(), n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0, S)
+            else:
+                rc = lib.nb_modconv3x3_up2_small_h3(x.data_ptr(), ic, None, 0, wp.data_ptr(), sd_.data_ptr(), d.data_ptr(), nd.data_ptr(),
+                                                    4 * h * h, bd.data_ptr(), y.data_ptr(), n, h, h, oc, 0.2, float(np.sqrt(2)), 256.0, S)
+            torch.cuda.synchronize()
+            _lib.check(rc, "small_h3")
+            out[blocks] = y
+    finally:
+        lib.nb_debug_set_small_blocks(0)
+    assert not torch.isnan(out[2]).any()
+    assert torch.equal(out[1], out[2])
+
+
 @pytest.mark.parametrize("shape", [(1, 128, 0, 128, 4), (3, 128, 0, 128, 4), (2, 128, 0, 128, 8), (1, 128, 0, 96, 16),
                                    (1, 128, 16, 128, 32), (2, 32, 16, 40, 8)])
 @pytest.mark.parametrize("waves", [0, 8])
