@@ -1097,8 +1097,7 @@ struct H3Up2Params {
 };
 
 // TQH = quad rows per tile: NB_H3_TQH (12) for throughput; 5 (7 x 34 = 238 positions = 8 column blocks, one per wave)
-// when the large tiles would leave most of the chip idle - the batch-1 / interactive configuration; 8 (NB_H3_TQH_MID) where
-// the 12-row tiles would end in a mostly empty round of workgroups (the launcher's estimate).
+// when the large tiles would leave most of the chip idle - the batch-1 / interactive configuration.
 // OUTM = output mode: 0 = fp32 NCHW, 1 = the consumer's H2 tensor, 2 = the consumer's tensor in the "f8" operand format.
 // TQW_ = quad columns per tile: 32, or 16 for 16-wide inputs (b32.conv0 at large batch: 8 x 16 tiles = 10 x 18 = 180
 // positions = 6 blocks, one per wave).
