@@ -36,6 +36,8 @@ python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
 NB_SUBS="1 2" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace -d $O/b1trace -o b1 --output-format csv -- python3 $R/tools/trace_b1.py > $O/b1trace.log 2>&1)
 python tools/trace_b1_summary.py $O/b1trace > $O/b1_trace_summary.txt 2>&1; rm -rf $O/b1trace
+(cd /tmp && rocprofv3 --kernel-trace -d $O/enctrace -o enc --output-format csv -- python3 $R/tools/trace_encoder.py > $O/enctrace.log 2>&1)
+(grep '^encoder' $O/enctrace.log; python tools/trace_encoder_summary.py $O/enctrace) > $O/encoder_trace.txt 2>&1; rm -rf $O/enctrace
 python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 --breakdown > $O/canvas_4096_r256_l2.json 2>/dev/null
 python tools/bench_canvas.py --size 4096 --res 256 --level 0 --steps 3 --breakdown > $O/canvas_4096_r256_l0.json 2>/dev/null
 python tools/bench_canvas.py --size 1024 --res 128 --level 2 --steps 3 --breakdown > $O/canvas_1024_r128_l2.json 2>/dev/null
