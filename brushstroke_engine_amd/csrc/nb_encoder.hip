@@ -6,9 +6,12 @@
 // BatchNorm is folded into the conv weights / bias on the host, so every layer is conv + bias + LeakyReLU.
 //
 // Three kernels:
-//   enc_stem7x7_kernel   C_in = 1: no channel contraction to feed the f16 matrix cores with, so the 49 taps are the
-//                        K dimension of v_mfma_f32_32x32x2_f32 (exact fp32); all weights of a wave live in 50
-//                        registers, B operands are single-dword LDS reads of the reflect-padded image tile.
+//   enc_stem7x7_kernel   C_in = 1: no channel contraction, so the taps are the K dimension -- ordered column by column (K = 8 b + a,
+//                        tap row a and column b padded from 7 to 8 with zero weights), which makes a lane's 8 K-values eight
+//                        vertically adjacent pixels: each wave keeps, per output row, a column-major hi/lo f16 strip of its
+//                        seven input rows in LDS and every B fragment is one aligned ds_read_b128.  Split-f16 products (3
+//                        v_mfma_f32_32x32x16_f16 per K step, fp32-grade) instead of the exact-fp32 MFMA of rounds 1-2, which runs
+//                        at a sixteenth of the rate and was half of the launch: 96 instead of 200 four-times-longer MFMAs per wave.
 //   enc_conv3x3_h3_kernel  3x3, stride 1 or 2, split-f16 products (see nb_modconv_h3.hip for the arithmetic and
 //                        the H2 activation format).  K loop = (16-channel chunk, tap row); per step the activation
 //                        rows that tap row needs are gathered by LDS-DMA with per-lane source addresses -- for
@@ -53,9 +56,11 @@ struct StemParams {
 };
 
 __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
-    constexpr int TR = 16, TC = 32, PR = TR + 6, PC = TC + 6, NBW = 4, KS = 25, CP = 72;   // CP: padded channel pitch (halves)
+    constexpr int TR = 16, TC = 32, PR = TR + 6, PC = TC + 6, NBW = 4, KS = 4, CP = 72;    // CP: padded channel pitch (halves)
+    constexpr int SC = 40;                                                                   // strip columns (38 + the zero-weight tap column 7)
     __shared__ float tile[PR * PC];
     __shared__ __attribute__((aligned(16))) _Float16 stage[4][2][32 * CP];                   // per wave: [hi/lo][pixel][channel]
+    __shared__ __attribute__((aligned(16))) h8 strip[4][NBW][2][SC];                          // per wave and output row: [hi/lo][column] x 8 input rows
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lh = lane >> 5, l31 = lane & 31;
     const int n = blockIdx.y;
     const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
@@ -68,13 +73,38 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
         else if (p.preproc == 2) v = 1.f - v;                   // 'inverse'
         tile[e] = v;
     }
-    // A fragments: lane (row = c_out l31, k = lh) of k-step s holds w[c_out][tap 2s + lh]  (taps 49.. are zero)
-    float wa[2][KS];
+    // A fragments: lane (row = c_out l31, k group lh) of K step s holds w[c_out][tap rows 0..7][tap column 2s + lh] (row / column 7: zero), hi and lo
+    h8 wah[2][KS], wal[2][KS];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) wa[mb][s] = p.w50[(mb * 32 + l31) * 50 + 2 * s + lh];
+        for (int s = 0; s < KS; ++s) {
+            const int b = 2 * s + lh;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float wv_ = (a < 7 && b < 7) ? p.w50[(mb * 32 + l31) * 50 + a * 7 + b] : 0.f;
+                const _Float16 hi = (_Float16)wv_;
+                wah[mb][s][a] = hi; wal[mb][s][a] = (_Float16)(wv_ - (float)hi);
+            }
+        }
     __syncthreads();
+    // this wave's strips: lane = column, eight input rows of output row (wv NBW + nb) as one 16-byte slot per half
+    if (lane < SC) {
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            h8 hi, lo;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float v = (a < 7 && lane < PC) ? tile[(wv * NBW + nb + a) * PC + lane] : 0.f;
+                const _Float16 hh = (_Float16)v;
+                hi[a] = hh; lo[a] = (_Float16)(v - (float)hh);
+            }
+            strip[wv][nb][0][lane] = hi;
+            strip[wv][nb][1][lane] = lo;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): wave-private strips, LDS executes a wave's accesses in order
+    __builtin_amdgcn_wave_barrier();
 
     f32x16 acc[2][NBW];
 #pragma unroll
@@ -83,16 +113,17 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
-    const float* tb = tile + (wv * NBW) * PC + l31;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const int t0 = 2 * s, t1 = 2 * s + 1 < 49 ? 2 * s + 1 : 48;
-        const int off = lh ? (t1 / 7) * PC + (t1 % 7) : (t0 / 7) * PC + (t0 % 7);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-            const float b = tb[nb * PC + off];
-            acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], b, acc[0][nb], 0, 0, 0);
-            acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], b, acc[1][nb], 0, 0, 0);
+            const h8 bh = strip[wv][nb][0][l31 + 2 * s + lh], bl = strip[wv][nb][1][l31 + 2 * s + lh];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah[mb][s], bh, acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah[mb][s], bl, acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wal[mb][s], bh, acc[mb][nb], 0, 0, 0);
+            }
         }
     }
     // epilogue: bias, LeakyReLU, hi/lo split, transpose through LDS to 16-byte H2 slots
