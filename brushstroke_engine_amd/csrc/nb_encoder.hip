@@ -732,7 +732,9 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
         const long big_wgs = (long)n * (wo / (wide ? 32 : 16)) * (ho / (wide ? 8 : 16)) * ((c_out + 127) / 128);
         static const int env_force = getenv("NB_ENC_SMALL") ? atoi(getenv("NB_ENC_SMALL")) : -1;
         const int force = g_enc_small >= 0 ? g_enc_small : env_force;
-        const bool small = !(wide || narrow) || (force >= 0 ? force != 0 : (big_wgs <= 48 && c_in >= 32));
+        // ... and layers with <= 32 output channels at any batch: the large tile has 128 c_out rows, three quarters of them empty then
+        // (256 -> 32 and 32 -> 16 of a batch of 32 at R=256: 82 -> 39 us together)
+        const bool small = !(wide || narrow) || (force >= 0 ? force != 0 : ((big_wgs <= 48 || c_out <= 32) && c_in >= 32));
         if (small && small_ok) {
             EncSmallParams q;
             q.x = p.x; q.wts = p.wts; q.bias = bias; q.y32 = y_f32; q.yh2 = (_Float16*)y_h2;

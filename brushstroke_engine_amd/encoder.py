@@ -178,7 +178,10 @@ class HipGeometryEncoder:
             # fill the chip with the large-tile kernel; H2 (hi/lo f16) otherwise -- the small-tile kernel of interactive
             # strokes reads H2
             fmt = 1 if (self.arith == "f8" and n >= self.f8_min_batch and self.large_tiles_only(h)) else 0
-            W = lambda cv: P(cv[5] if fmt else cv[0])
+            W = lambda cv, f=None: P(cv[5] if (fmt if f is None else f) else cv[0])
+            # layers with <= 32 output channels (256 -> 32, 32 -> 16) leave three quarters of the large tile's 128 c_out rows empty:
+            # the library runs them on the 32 x 32 split-K tiles, which read hi/lo-f16 operands -- so their producers write H2
+            narrow = lambda i: self.convs[i][3] <= 32 and self.convs[i][2] >= 32
             a = f16(64, h)
             check(lib.nb_enc_stem7x7_f32_h2_ex(P(x), P(self.stem[0]), P(self.stem[1]), P(a), fmt, n, h, w,
                                                self._PRE[self.preproc_type], 0.01, st), "enc_stem")
@@ -187,12 +190,15 @@ class HipGeometryEncoder:
                 _, b, ci, co, stride, _ = self.convs[i]
                 r_out = r // stride
                 y = f16(co, r_out)
-                check(lib.nb_enc_conv3x3_ex(P(a), ci, W(self.convs[i]), P(b), None, P(y), None, 0, co // 8 if fmt else 0, 0, fmt, fmt,
+                fin = 0 if narrow(i) else fmt
+                fout = 0 if narrow(i + 1) else fmt
+                check(lib.nb_enc_conv3x3_ex(P(a), ci, W(self.convs[i], fin), P(b), None, P(y), None, 0, co // 8 if fout else 0, 0, fin, fout,
                                             n, r, r, co, stride, 0.01, st), "enc_conv")
                 a, r = y, r_out
             _, b, ci, co, stride, _ = self.convs[4]          # 32 -> 16: the bottleneck the generator consumes
             enc = f32(co, r)
-            check(lib.nb_enc_conv3x3_ex(P(a), ci, W(self.convs[4]), P(b), P(enc), None, None, 0, 0, 0, fmt, 0, n, r, r, co, 1, 0.01, st),
+            fin = 0 if narrow(4) else fmt
+            check(lib.nb_enc_conv3x3_ex(P(a), ci, W(self.convs[4], fin), P(b), P(enc), None, None, 0, 0, 0, fin, 0, n, r, r, co, 1, 0.01, st),
                   "enc_conv")
             up = f16(co, 2 * r)
             check(lib.nb_enc_upsample2x_h2_ex(P(enc), P(up), fmt, n, co, r, r, st), "enc_upsample")
