@@ -303,6 +303,12 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     const int b_base = lh * 2 * XPL + ((wn * NBW) * RPB + (l31 >> LW)) * PW + (l31 & (WT - 1));
     issue(0, 0);
     if constexpr (F8) {
+        // Two buffers, but a step's DMA gets a step and a HALF of flight time (a step is ~0.9 us of matrix work, a gather ~2 us):
+        // step t+2 is issued into step t's own buffer in the MIDDLE of step t, right after the last fragment read of the step and a
+        // barrier (every wave is past its reads), instead of at the start of step t+1.  The wait at the top of a step is counted:
+        // everything but the pieces issued in the middle of the step before.
+        constexpr int NPC = NXPW + NWPW;                       // LDS-DMA pieces a wave issues per step
+        issue(1 < T ? 1 : T - 1, 1);
 #define NB_SB __builtin_amdgcn_sched_barrier(0)
 #define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
         const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;        // E8M0 block scales: fp8(w) fp8(xl 2^9) 2^-9 | fp8(wl 2^11) 2^-11 fp8(x/4) 2^2
@@ -332,9 +338,8 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 }
         };
         auto step = [&](int t, int odd, bool first) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of step t has landed
-            __builtin_amdgcn_s_barrier();                         // ... everybody's has, and step t-1 is fully consumed
-            issue(t + 1 < T ? t + 1 : T - 1, (t + 1) & 1);        // past the end: a harmless re-copy keeps the flow uniform
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");     // my share of step t has landed (step t+1's may be in flight)
+            __builtin_amdgcn_s_barrier();                         // ... everybody's has
             NB_SB;
             const h8* xb = xbuf + (t & 1) * 4 * XPL;
             const h8* wb = wbuf + (t & 1) * WSLOTS;
@@ -366,6 +371,11 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 bh2[nb] = xb[b_base + nb * RPB * PW + KX2];
                 if (odd) { NB_Q(bl2[nb], 1, xb[b_base + XPL + nb * RPB * PW + KX2]); } else { NB_Q(bl2[nb], 0, xb[b_base + XPL + nb * RPB * PW + KX2]); }
             }
+            NB_SB;
+            // the step's last fragment reads are in registers for every wave: its buffers take step t+2 (past the end: a harmless
+            // re-copy keeps the piece counts uniform)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(t + 2 < T ? t + 2 : T - 1, t & 1);
             NB_SB;
             main4(ah1, bh1);
             corr4(al01, bl01);
