@@ -290,6 +290,25 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
         }
     };
 
+    // one LDS-DMA piece of step t into buffer `buf`: k < NXPW activations, else weights (the pieces of issue(), singly)
+    auto piece = [&](auto kk, int t, int buf) {
+        constexpr int k = decltype(kk)::value;
+        if constexpr (k < NXPW) {
+            const int c = t / 3, ky = t - 3 * c;
+            const int cg = 2 * c + (xpl[k] >> 1);
+            const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
+            if (xcol[k] >= 0 && cg < p.c8)
+                src = xn + (size_t)(4 * c + xpl[k]) * HW8 + (size_t)nb_reflect(xrow[k] + ky, p.hin) * p.win * 8 + xcol[k];
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(xbuf + buf * 4 * XPL + xdst[k]), 16, 0, 0);
+        } else {
+            constexpr int i = k - NXPW;
+            const int e = (i * NW + wv) * 64 + lane;
+            const int row = e / CO_WG, j = e - row * CO_WG;
+            const _Float16* src = p.wts + (((size_t)t * 12 + row) * p.co_ld + co0 + j) * 8;
+            __builtin_amdgcn_global_load_lds(NB_GLOBAL_PTR(src), NB_LDS_PTR(wbuf + buf * WSLOTS + (i * NW + wv) * 64), 16, 0, 0);
+        }
+    };
+
     f32x16 acc[MB][NBW];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -303,12 +322,25 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     const int b_base = lh * 2 * XPL + ((wn * NBW) * RPB + (l31 >> LW)) * PW + (l31 & (WT - 1));
     issue(0, 0);
     if constexpr (F8) {
-        // Two buffers, but a step's DMA gets a step and a HALF of flight time (a step is ~0.9 us of matrix work, a gather ~2 us):
-        // step t+2 is issued into step t's own buffer in the MIDDLE of step t, right after the last fragment read of the step and a
-        // barrier (every wave is past its reads), instead of at the start of step t+1.  The wait at the top of a step is counted:
-        // everything but the pieces issued in the middle of the step before.
-        constexpr int NPC = NXPW + NWPW;                       // LDS-DMA pieces a wave issues per step
-        issue(1 < T ? 1 : T - 1, 1);
+        // Two buffers, and the LDS-DMA pieces of a step spread over the MFMA groups of the TWO steps before it -- a burst of eight
+        // pieces right after a barrier stalls both waves of a SIMD at the same moment, with nobody feeding the matrix pipe (the
+        // up=2 generator kernel's finding; there it was a third of the loop).  Step t's buffers are free once every wave has done
+        // the step's last fragment read (mid-step barrier): pieces 0 .. HP-1 of step t+2 follow in the second half of step t,
+        // pieces HP .. of step t+1 went out in its first half, two at a time between groups of four MFMAs.  The wait at the top of
+        // a step is counted: everything but the HP pieces issued in the second half of the step before.
+        constexpr int NPC = NXPW + NWPW, HP = NPC / 2;          // LDS-DMA pieces a wave issues per step; its first half
+        static_assert(NPC % 2 == 0 && NPC <= 8, "the placement below is written for six or eight pieces");
+        constexpr int G1 = (HP + 1) / 2;                       // pieces per group: [0, G1) [G1, HP) | [HP, HP + G1) [HP + G1, NPC)
+        auto pieces = [&](auto lo_, auto hi_, int t, int buf) {
+            constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
+            if constexpr (lo + 0 < hi) piece(std::integral_constant<int, lo + 0>{}, t, buf);
+            if constexpr (lo + 1 < hi) piece(std::integral_constant<int, lo + 1>{}, t, buf);
+            if constexpr (lo + 2 < hi) piece(std::integral_constant<int, lo + 2>{}, t, buf);
+            if constexpr (lo + 3 < hi) piece(std::integral_constant<int, lo + 3>{}, t, buf);
+        };
+        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, G1>; using P2 = std::integral_constant<int, HP>;
+        using P3 = std::integral_constant<int, HP + G1>; using P4 = std::integral_constant<int, NPC>;
+        pieces(P0{}, P2{}, 1 < T ? 1 : T - 1, 1);             // before step 0: all of step 0 is in flight (issue(0, 0) above) and the first half of step 1
 #define NB_SB __builtin_amdgcn_sched_barrier(0)
 #define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
         const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;        // E8M0 block scales: fp8(w) fp8(xl 2^9) 2^-9 | fp8(wl 2^11) 2^-11 fp8(x/4) 2^2
@@ -338,9 +370,10 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 }
         };
         auto step = [&](int t, int odd, bool first) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");     // my share of step t has landed (step t+1's may be in flight)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HP) : "memory");      // my share of step t has landed (the first half of step t+1's may be in flight)
             __builtin_amdgcn_s_barrier();                         // ... everybody's has
             NB_SB;
+            const int tn = t + 1 < T ? t + 1 : T - 1, tnn = t + 2 < T ? t + 2 : T - 1;      // (past the end: harmless re-copies keep the counts uniform)
             const h8* xb = xbuf + (t & 1) * 4 * XPL;
             const h8* wb = wbuf + (t & 1) * WSLOTS;
 #pragma unroll
@@ -359,7 +392,9 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             }
             NB_SB;
             if (!first) main4(ah2, bh2);                           // tap 2 of the previous step
+            pieces(P2{}, P3{}, tn, (t + 1) & 1); NB_SB;             // second half of step t+1's pieces
             if (!odd && !first) corr4(al2, bl2);                   // tap-2 corrections of the two previous steps
+            pieces(P3{}, P4{}, tn, (t + 1) & 1); NB_SB;
             main4(ah0, bh0);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -375,9 +410,9 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             // the step's last fragment reads are in registers for every wave: its buffers take step t+2 (past the end: a harmless
             // re-copy keeps the piece counts uniform)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            issue(t + 2 < T ? t + 2 : T - 1, t & 1);
-            NB_SB;
+            pieces(P0{}, P1{}, tnn, t & 1); NB_SB;                  // first half of step t+2's pieces
             main4(ah1, bh1);
+            pieces(P1{}, P2{}, tnn, t & 1); NB_SB;
             corr4(al01, bl01);
         };
         for (int t = 0; t < T; t += 2) {
