@@ -293,6 +293,10 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     // one LDS-DMA piece of step t into buffer `buf`: k < NXPW activations, else weights (the pieces of issue(), singly)
     auto piece = [&](auto kk, int t, int buf) {
         constexpr int k = decltype(kk)::value;
+#ifdef NB_ENC_ABL_NODMA     // developer ablation (tools/build_variants_enc.sh; timing only, wrong results): the steps re-read what the prologue staged
+        (void)t; (void)buf;
+        return;
+#endif
         if constexpr (k < NXPW) {
             const int c = t / 3, ky = t - 3 * c;
             const int cg = 2 * c + (xpl[k] >> 1);
@@ -355,12 +359,26 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
 #pragma unroll
             for (int r = 0; r < 8; ++r) bl2[nb][r] = 0;
         auto main4 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
+#ifdef NB_ENC_ABL_NOMFMA    // developer ablation: no matrix work (the operands are kept alive)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) asm volatile("" :: "v"(a[mb]));
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) asm volatile("" :: "v"(b[nb]));
+            return;
+#endif
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) { acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0); NB_SB; }
         };
         auto corr4 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
+#ifdef NB_ENC_ABL_NOMFMA
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) asm volatile("" :: "v"(a[mb]));
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) asm volatile("" :: "v"(b[nb]));
+            return;
+#endif
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
