@@ -48,6 +48,16 @@ __device__ __forceinline__ unsigned nb_enc_pk4_fp8(float a, float b, float c, fl
     return (unsigned)w;
 }
 
+// ... in a wave whose MODE.FP16_OVFL is set the conversion itself saturates (nb_pk4_fp8_sat of nb_modconv_h3.hip): the stem's
+// epilogue is bound by its vector instructions, 4 of ~15 per value were these clamps
+__device__ __forceinline__ unsigned nb_enc_pk4_fp8_sat(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ void nb_enc_set_fp16_ovfl() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+
 struct StemParams {
     const float* x; const float* w50; const float* bias; _Float16* y;
     int h, w, tiles_x, preproc;
@@ -58,6 +68,7 @@ struct StemParams {
 __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
     constexpr int TR = 16, TC = 32, PR = TR + 6, PC = TC + 6, NBW = 4, KS = 4, CP = 72;    // CP: padded channel pitch (halves)
     constexpr int SC = 40;                                                                   // strip columns (38 + the zero-weight tap column 7)
+    if (p.out_f8) nb_enc_set_fp16_ovfl();                                                    // the fp8 (and f16) conversions saturate
     __shared__ float tile[PR * PC];
     __shared__ __attribute__((aligned(16))) _Float16 stage[4][2][32 * CP];                   // per wave: [hi/lo][pixel][channel]
     __shared__ __attribute__((aligned(16))) h8 strip[4][NBW][2][SC];                          // per wave and output row: [hi/lo][column] x 8 input rows
@@ -142,7 +153,10 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
                 float vv[4], xl[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float v = nb_lrelu(acc[mb][nb][4 * g + j] + p.bias[co + j], p.slope);
+                    // LeakyReLU = max(t, slope t) for 0 <= slope <= 1 (the launcher checks); med3 with +inf is a max without the NaN
+                    // canonicalisation instructions fmaxf() costs
+                    const float t = acc[mb][nb][4 * g + j] + p.bias[co + j];
+                    const float v = __builtin_amdgcn_fmed3f(t, t * p.slope, __builtin_inff());
                     const _Float16 hi = (_Float16)v;
                     vv[j] = v; xl[j] = v - (float)hi;
                     vh[j] = hi; vl[j] = (_Float16)xl[j];
@@ -151,8 +165,8 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
                 if (p.out_f8) {
                     // lo image as bytes: per 16-channel chunk 16 x fp8(xl 2^9) then 16 x fp8(v/4) (= the chunk's two lo slots)
                     unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)l31 * (CP * 2) + (co >> 4) * 32 + (co & 15);
-                    *reinterpret_cast<unsigned*>(sb) = nb_enc_pk4_fp8(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
-                    *reinterpret_cast<unsigned*>(sb + 16) = nb_enc_pk4_fp8(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
+                    *reinterpret_cast<unsigned*>(sb) = nb_enc_pk4_fp8_sat(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
+                    *reinterpret_cast<unsigned*>(sb + 16) = nb_enc_pk4_fp8_sat(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
                 } else {
                     *reinterpret_cast<h4*>(sl + l31 * CP + co) = vl;
                 }
@@ -183,6 +197,7 @@ extern "C" int nb_enc_stem7x7_f32_h2_ex(const float* x, const float* w50, const 
     NB_REQUIRE(n >= 1 && n <= 65535 && h % 16 == 0 && w % 32 == 0 && h >= 16 && w >= 32,
                "enc_stem7x7: needs h %% 16 == 0 and w %% 32 == 0 (got %dx%d)", h, w);
     NB_REQUIRE(preproc >= 0 && preproc <= 2, "Unknown preprocessing type %d", preproc);
+    NB_REQUIRE(slope >= 0.f && slope <= 1.f, "enc_stem7x7: leaky-ReLU slope must lie in [0, 1] (got %g)", slope);
     NB_REQUIRE((uintptr_t)y_h2 % 16 == 0, "enc_stem7x7: output must be 16-byte aligned");
     StemParams p{x, w50, bias, (_Float16*)y_h2, h, w, w / 32, preproc, slope, out_fmt};
     hipLaunchKernelGGL(enc_stem7x7_kernel, dim3((w / 32) * (h / 16), n), dim3(256), 0, (hipStream_t)stream, p);
@@ -298,6 +313,10 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
         return;
 #endif
         if constexpr (k < NXPW) {
+            // (36 activation pieces over 8 waves: the fifth round exists for waves 0-3 only.  The others skip it instead of re-copying
+            //  the last piece -- allowed for pieces of the SECOND half of a step only: the counted wait at the top of a step counts
+            //  the first-half pieces issued after them, which every wave issues in full)
+            if constexpr (k >= (NXPW + NWPW) / 2 && k * NW + NW - 1 >= NXP) { if (k * NW + wv >= NXP) return; }
             const int c = t / 3, ky = t - 3 * c;
             const int cg = 2 * c + (xpl[k] >> 1);
             const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
