@@ -1121,7 +1121,10 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     constexpr int SLOTS = XR * XS, PP = (SLOTS + 63) / 64, XPL = SLOTS;         // 525 slots -> 9 pieces
     constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;                     // 36 -> 5 per wave
     constexpr int WSLOTS = 36 * 32, NWP = WSLOTS / 64, NWPW = (NWP + NW - 1) / NW;   // 18 -> 3 per wave
-    constexpr int NPC = NXPW + NWPW;                  // LDS-DMA pieces a wave issues per chunk (8)
+    // LDS-DMA pieces a wave issues per chunk: the 36 activation + 18 weight pieces are ONE list dealt round-robin to the waves
+    // (7 each, 2 re-copies; dealt per kind it was 5 + 3 = 8 each with 10 re-copies -- and a piece is a KiB through the CU's
+    // vector-memory path whether anybody needs it or not)
+    constexpr int NPC = (NXP + NWP + NW - 1) / NW;
     constexpr int STAGE = 4 * XPL + WSLOTS;           // 16-byte slots per stage
     constexpr int NST = NST_;                         // 3 (2: the two-workgroups-per-CU form)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h3[];
@@ -1179,18 +1182,32 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     // piece k of chunk c into stage st: k < NXPW activations, else weights
     auto issue_piece = [&](auto kk, int c, h8* st) {
         constexpr int k = decltype(kk)::value;
-        if constexpr (k < NXPW) {
+        // list position u = k NW + wv: activation piece u (descriptor k of this wave) if u < NXP, else weight piece u - NXP
+        constexpr bool ALLX = k * NW + NW - 1 < NXP, ALLW = k * NW >= NXP;
+        const _Float16* xsrc = reinterpret_cast<const _Float16*>(p.zeros);
+        h8* xd = st;
+        bool xo = false;
+        if constexpr (!ALLW) {
             const int cg = 2 * c + (xpl[k] >> 1);
-            const _Float16* src = reinterpret_cast<const _Float16*>(p.zeros);
-            if (xsp[k] >= 0 && cg < p.c8) src = xn + (size_t)(4 * c + xpl[k]) * HW8 + xsp[k];
-            if (xok[k]) nb_lds_dma16(src, st + xdst[k]);
+            if (xsp[k] >= 0 && cg < p.c8) xsrc = xn + (size_t)(4 * c + xpl[k]) * HW8 + xsp[k];
+            xd = st + xdst[k]; xo = xok[k];
+        }
+        if constexpr (ALLX) {
+            if (xo) nb_lds_dma16(xsrc, xd);
         } else {
-            int q = (k - NXPW) * NW + wv;
-            q = q < NWP ? q : NWP - 1;
+            int q = k * NW + wv - NXP;
+            q = q < 0 ? 0 : (q < NWP ? q : NWP - 1);
             const int e = q * 64 + lane;
             const int row = e >> 5, j = e & 31;           // row = tap*4 + cg*2 + hl
-            const _Float16* src = p.wts + (((size_t)c * 36 + row) * p.co_ld + co0 + j) * 8;
-            nb_lds_dma16(src, st + 4 * XPL + q * 64);
+            const _Float16* wsrc = p.wts + (((size_t)c * 36 + row) * p.co_ld + co0 + j) * 8;
+            h8* wd = st + 4 * XPL + q * 64;
+            if constexpr (ALLW) {
+                nb_lds_dma16(wsrc, wd);
+            } else {                                      // the round where the list changes kind: a wave issues ONE of the two (the
+                const bool isx = k * NW + wv < NXP;       // other has no lane enabled, and such an instruction does not exist for vmcnt)
+                if (isx && xo) nb_lds_dma16(xsrc, xd);
+                if (!isx) nb_lds_dma16(wsrc, wd);
+            }
         }
     };
     auto issue = [&](int c, h8* st) { nb_static_for<0, NPC>([&](auto k) { issue_piece(k, c, st); }); };
