@@ -31,6 +31,11 @@ void nb_debug_set_up2_tile(int tqh);
  * CU), 1 = 4 waves / 12 x 16 tiles / 2 stages (two per CU).  tests/test_hip_f8.py asserts both bit-identical. */
 void nb_debug_set_up2_pair(int mode);
 
+/* The one-wave-per-SIMD ("wide") form of the split-f16 up=2 kernel (csrc/nb_modconv_up2w.hip: 4 waves, 64 c_out x 12 x 16 quads,
+ * 256 accumulator registers per wave): -1 = automatic (launches of >= 768 such workgroups), 0 = never, 1 = wherever the shape
+ * allows (f8 operands, c_out % 64 == 0, w % 16 == 0).  tests/test_hip_f8.py asserts it bit-identical to the 8-wave kernel. */
+void nb_debug_set_up2_wide(int mode);
+
 /* Tile form of nb_enc_conv3x3_h3: -1 = automatic, 0 = large tiles, 1 = small split-K tiles. */
 void nb_debug_set_enc_small(int mode);
 

@@ -146,7 +146,7 @@ def test_f8_tiled_canvas_matches_reference():
 
 
 @pytest.mark.parametrize("fmt", [0, 1])
-@pytest.mark.parametrize("ci,co,h,w", [(128, 64, 32, 32), (144, 128, 24, 64)])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 64, 32, 32), (144, 128, 24, 64), (48, 64, 26, 32)])
 def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     """The up=2 split-f16 kernel has three tile heights (12 quad rows for throughput, 8 where those would end in a mostly
     empty round of workgroups, 5 for under-filled launches such as batch 1).  Both walk the same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical; 24 rows do
@@ -166,9 +166,12 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for tqh in (12, 8, 5, "pair"):
-            lib.nb_debug_set_up2_tile(12 if tqh == "pair" else tqh)
+        for tqh in (12, 8, 5, "pair", "wide"):
+            if tqh == "wide" and not fmt:
+                continue                                  # (the wide form exists for f8 operands)
+            lib.nb_debug_set_up2_tile(12 if tqh == "pair" else 0 if tqh == "wide" else tqh)
             lib.nb_debug_set_up2_pair(1 if tqh == "pair" else 0)
+            lib.nb_debug_set_up2_wide(1 if tqh == "wide" else 0)
             y = torch.empty([n, co, 2 * h, 2 * w], device="cuda")
             out = torch.zeros(ops.h2_shape(n, co, 2 * h, 2 * w), dtype=torch.float16, device="cuda")
             common = (dco.data_ptr(), noise.data_ptr(), 4 * h * w, bias.data_ptr())
@@ -181,6 +184,12 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     finally:
         lib.nb_debug_set_up2_tile(0)
         lib.nb_debug_set_up2_pair(-1)
+        lib.nb_debug_set_up2_wide(-1)
+    if fmt:
+        # the one-wave-per-SIMD form (64 c_out x 12 x 16 quads per workgroup; 26 and 32 rows end in ragged tiles whose waves
+        # multiply one or none of their two position blocks)
+        assert torch.equal(res[12][0], res["wide"][0])
+        assert torch.equal(res[12][1], res["wide"][1])
     assert torch.equal(res[12][0], res[5][0])
     assert torch.equal(res[12][1], res[5][1])
     assert torch.equal(res[12][0], res[8][0])                # 8-row tiles (launches that would end in a mostly empty round of 12-row tiles)
