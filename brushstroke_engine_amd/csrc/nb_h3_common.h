@@ -56,6 +56,23 @@ __device__ __forceinline__ void nb_lds_dma16(const void* src, const void* lds) {
                  : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
 }
 
+// LDS-DMA pieces of the one-wave-per-SIMD / software-pipelined up=2 kernels (see nb_lds_dma16): the LDS destination is a byte address (no generic -> LDS pointer cast per
+// piece).  _s: uniform 64-bit base (SGPR pair) + 32-bit lane offset: no per-piece vector address arithmetic.
+__device__ __forceinline__ void nb_lds_dma16_s(const void* sbase, unsigned voff, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+// _m: per-lane 64-bit source, lanes chosen by a uniform mask set INSIDE the statement: an `if` around the copy is a branch, and a
+// K loop of several basic blocks is no longer scheduled as written (the compiler sinks MFMAs across the blocks, past the fences)
+__device__ __forceinline__ void nb_lds_dma16_m(const void* src, unsigned lds_byte, unsigned long long mask) {
+    unsigned keep;
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %4\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex) : "v"(src), "s"(lds_byte), "s"(mask) : "memory");
+}
+
 // compile-time loop: f(std::integral_constant<int, K0>{}) ... f(std::integral_constant<int, K1 - 1>{})
 template <int K0, int K1, class F>
 __device__ __forceinline__ void nb_static_for(F&& f) {

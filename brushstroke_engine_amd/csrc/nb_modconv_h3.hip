@@ -1543,6 +1543,15 @@ int nb_up2w_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long
 static int g_force_wide = -1;
 // developer / test hook: -1 = automatic, 0 / 1 = never / always (where the shape allows) the wide form (64 c_out x 12 x 16 quads, 4 waves)
 extern "C" void nb_debug_set_up2_wide(int mode) { g_force_wide = mode; }
+// the 8-wave form with the software-pipelined K loop (nb_modconv_up2v.hip)
+bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w);
+int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long long* tstamps, int tstamps_cap);
+#ifndef NB_UP2V_AUTO
+#define NB_UP2V_AUTO 1          // 1: f8 launches on the 12-row throughput tiles run on the software-pipelined kernel
+#endif
+static int g_force_v2 = -1;
+// developer / test hook: -1 = automatic, 0 = never, 1 = wherever the shape allows (f8 operands, w % 32 == 0; always 12-row tiles)
+extern "C" void nb_debug_set_up2_v2(int mode) { g_force_v2 = mode; }
 static int g_force_pair = -1;
 // developer / test hook: -1 = automatic, 0 / 1 = never / always the two-workgroups-per-CU form (4 waves, 12 x 16 tiles, 2 stages)
 extern "C" void nb_debug_set_up2_pair(int mode) { g_force_pair = mode; }
@@ -1637,6 +1646,12 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     static const int env_pair = getenv("NB_UP2_PAIR") ? atoi(getenv("NB_UP2_PAIR")) : 0;
     const bool pair = !in_fmt && (g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && !mid_tiles && wgs_big * 2 >= 1024));
     if (pair) return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
+    // the 12-row throughput tiles of an f8 launch: the kernel with the software-pipelined K loop (same tile, same results)
+    static const int env_v2 = getenv("NB_UP2_V2") ? atoi(getenv("NB_UP2_V2")) : -1;
+    const int force_v2 = g_force_v2 >= 0 ? g_force_v2 : env_v2;
+    if (force_v2 != 0 && nb_up2v_eligible(in_fmt, c_in, h, w) &&
+        (force_v2 > 0 ? force_tqh == 0 || force_tqh == NB_H3_TQH : (NB_UP2V_AUTO && !mid_tiles && !small_tiles && (force_tqh == 0 || force_tqh == NB_H3_TQH))))
+        return nb_up2v_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
     if (mid_tiles) return nb_up2_h3_launch<NB_H3_TQH_MID>(p, n, in_fmt, stream);
     return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
 }

@@ -1,0 +1,495 @@
+// up = 2 split-f16 convolution ("f8" operands), 8-wave form with a SOFTWARE-PIPELINED K loop for gfx950.
+//
+// Same math, same tile (12 x 32 quads x 32 c_out, two position blocks and all four output phases per wave = 128 accumulator
+// registers, two waves per SIMD), same three-stage LDS ring and the same epilogue as modconv3x3_up2_h3_kernel
+// (nb_modconv_h3.hip) -- and the same per-output summation order: bit-identical results.  What differs is the K loop, which is the
+// one measured on the one-wave-per-SIMD kernel (nb_modconv_up2w.hip: 97 % of its cycles are matrix work):
+//   * one basic block per chunk: LDS-DMA pieces are issued from statements that set their lane mask themselves (an `if` around a
+//     piece is a branch, and the compiler moves MFMAs across the resulting blocks);
+//   * the pipeline is rotated by one MFMA group: the chunk's barrier stands before its LAST group (taps 2, 0), whose operands are
+//     in registers by then, and the first operands of the next chunk are read under that group -- no chunk opens with both waves
+//     of a SIMD waiting for the same burst of sixteen fragment reads;
+//   * fragment reads and DMA pieces are dealt out between the MFMAs (one or two reads per gap, a piece behind an fp8 MFMA)
+//     instead of in bursts between the groups, a scheduling fence after every statement: program order is issue order;
+//   * the two 16-byte halves of a block-scaled fp8 operand are read straight into one 8-register tuple (no v_mov assembling).
+#include "nb_h3_common.h"
+
+namespace {
+constexpr int TQH = 12, TQW = 32, NW = 8, NT = NW * 64;
+constexpr int PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;            // 14 x 34 = 476 halo'd quad positions
+constexpr int NBLK = (NPOS + 31) / 32, NBJ = 2;                      // 15 position blocks of 32: wave w takes w and w + 8
+constexpr int XR = TQH + 3, XS = TQW + 3, XPL = XR * XS;             // 15 x 35 input pixels = 525 slots per (cg, hi/lo) plane
+constexpr int PP = (XPL + 63) / 64, NXP = 4 * PP;                    // 9 pieces per plane, 36 per chunk
+constexpr int CO_WG = 32, WROWS = 36, WSLOTS = WROWS * CO_WG, NWP = WSLOTS / 64;     // 18 weight pieces per chunk
+constexpr int NPC = (NXP + NWP + NW - 1) / NW;                       // 7 pieces per wave and chunk (54 dealt as one list, 2 re-copies)
+constexpr int STAGE = 4 * XPL + WSLOTS, NST = 3;                     // 3 x 52 032 B
+constexpr int N4 = 2;                                                // pieces of chunk c + 3 issued under the last group of chunk c
+constexpr int KMIX = NXP / NW;                                       // the round of the list where the kind changes (4: waves 0-3 activations)
+static_assert(NBLK <= NBJ * NW && KMIX * NW <= NXP && (KMIX + 1) * NW > NXP && NPC == 7, "piece list layout");
+}
+
+template <int OUTM>
+__global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Params p) {
+    NB_TSTAMP(0);
+    if constexpr (OUTM == 2) nb_set_fp16_ovfl();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_v[];
+    h8* ring = reinterpret_cast<h8*>(smem_v);         // [NST][ x: 4 planes x XPL | w: 36 rows x 32 ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
+    const int H = p.h, W = p.w;
+    int b = blockIdx.x;
+    // XCD-aware order (see modconv3x3_up2_h3_kernel)
+    if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (((b & 7) + blockIdx.y) & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int slice = b % p.slices; b /= p.slices;
+    const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
+    const int n = blockIdx.y;
+    const int I0 = tile_y * TQH, J0 = tile_x * TQW;
+    const int co0 = slice * CO_WG;
+    const size_t HW8 = (size_t)H * W * 8;
+    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+    const int nblk = wv < NBLK - (NBJ - 1) * NW ? NBJ : NBJ - 1;      // blocks wv, wv + 8 (< 15)
+
+    __shared__ __attribute__((aligned(16))) float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
+    __shared__ __attribute__((aligned(16))) float s_noise[2 * TQH * 2 * TQW];
+    if (tid < CO_WG) {
+        const int co = co0 + tid;
+        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] * p.gain : 0.f;
+        s_bias[tid] = co < p.c_out ? p.bias[co] * p.gain : 0.f;
+        s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
+    }
+    // ---- LDS-DMA pieces: position u = 8 k + wv of ONE list per chunk -- activation piece u (plane u / 9, 64 slots from
+    //      (u % 9) 64; per-lane source, out-of-image slots read the zero page with stride 0, the ninth piece of a plane is
+    //      partial: uniform lane mask) if u < 36, else weight piece u - 36 (64 slots = two rows of 32 c_out; uniform base + lane
+    //      offset).  Every wave issues exactly NPC pieces per chunk: the waits below count them. ----
+    const unsigned lds0 = (unsigned)(uintptr_t)NB_LDS_PTR(smem_v);
+    const size_t wchunk = (size_t)WROWS * p.co_ld * 16;               // bytes of a chunk's weights
+    const char* xsrc0[KMIX + 1];
+    unsigned xstr[KMIX + 1];
+#pragma unroll
+    for (int k = 0; k <= KMIX; ++k) {
+        int q = k * NW + wv;
+        q = q < NXP ? q : NXP - 1;
+        const int pl = q / PP, part = q - pl * PP;
+        const int e = part * 64 + lane;
+        xsrc0[k] = reinterpret_cast<const char*>(p.zeros);
+        xstr[k] = 0;
+        if (e < XPL) {
+            const int r = e / XS, c = e - r * XS;
+            const int gy = I0 - 1 + r, gx = J0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                xsrc0[k] = reinterpret_cast<const char*>(xn + (size_t)pl * HW8 + (size_t)(gy * W + gx) * 8);
+                xstr[k] = (unsigned)(4 * HW8 * 2);
+            }
+        }
+    }
+    auto xdst = [&](int k) { int q = k * NW + wv; q = q < NXP ? q : NXP - 1; const int pl = q / PP, part = q - pl * PP; return pl * XPL + part * 64; };
+    auto xmask = [&](int k) -> unsigned long long {
+        int q = k * NW + wv; q = q < NXP ? q : NXP - 1;
+        return q % PP == PP - 1 ? (1ull << (XPL - (PP - 1) * 64)) - 1 : ~0ull;
+    };
+    // weight piece of list round k (k >= KMIX): q = 8 k + wv - 36 (clamped: the list's last two positions re-copy piece 17)
+    auto wq = [&](int k) { int q = k * NW + wv - NXP; return q < 0 ? 0 : (q < NWP ? q : NWP - 1); };
+    unsigned woff[NPC - KMIX];                         // lane's byte offset within a chunk's weights: slot e = q 64 + lane -> row e / 32, c_out e % 32
+#pragma unroll
+    for (int k = KMIX; k < NPC; ++k) {
+        const int e = wq(k) * 64 + lane;
+        woff[k - KMIX] = (unsigned)(((size_t)(e >> 5) * p.co_ld + co0 + (e & 31)) * 16);
+    }
+    // the round of the list where the kind changes (waves 0-3: an activation piece, 4-7: a weight piece): ONE form for both --
+    // per-lane source of chunk 0 and per-chunk stride, uniform destination and mask -- set up here, so that the K loop holds
+    // neither a branch nor a select for it (a uniform `cond ? a : b` of two address computations compiles to a branch, the
+    // branch splits the chunk into two basic blocks, and the compiler sinks MFMAs from the first into the second)
+    const bool mix_isx = KMIX * NW + wv < NXP;
+    const char* msrc0 = mix_isx ? xsrc0[KMIX] : reinterpret_cast<const char*>(p.wts) + woff[0];
+    const unsigned mstr = mix_isx ? xstr[KMIX] : (unsigned)wchunk;
+    const int mdst = mix_isx ? xdst(KMIX) : 4 * XPL + wq(KMIX) * 64;
+    const unsigned long long mmask = mix_isx ? xmask(KMIX) : ~0ull;
+    auto issue_piece = [&](auto kk, int c, int stage_slot) {
+        constexpr int k = decltype(kk)::value;
+        if constexpr (k < KMIX) {
+            nb_lds_dma16_m(xsrc0[k] + (size_t)c * xstr[k], lds0 + (unsigned)(stage_slot + xdst(k)) * 16u, xmask(k));
+        } else if constexpr (k > KMIX) {
+            const char* wbase = reinterpret_cast<const char*>(p.wts) + (size_t)c * wchunk;
+            nb_lds_dma16_s(wbase, woff[k - KMIX], lds0 + (unsigned)(stage_slot + 4 * XPL + wq(k) * 64) * 16u);
+        } else {
+            nb_lds_dma16_m(msrc0 + (size_t)c * mstr, lds0 + (unsigned)(stage_slot + mdst) * 16u, mmask);
+        }
+    };
+
+    // fragment offsets (16-byte slots).  B: position (r, c) of block (wv + 8 j): slot r XS + c of plane (lh 2 + hl);
+    // A: row tap 4 + lh 2 + hl, column l31
+    int boff[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+        int pidx = (wv + NW * j) * 32 + l31;
+        pidx = pidx < NPOS ? pidx : NPOS - 1;
+        const int r = pidx / PW, c = pidx - r * PW;
+        boff[j] = lh * 2 * XPL + r * XS + c;
+    }
+    const int aoff = 4 * XPL + lh * 2 * CO_WG + l31;  // + tap * 128 + hl * 32
+
+    f32x16 acc[NBJ][4];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][ph][r] = 0.f;
+
+    // ---- prologue: chunks 0 and 1, and the two pieces of chunk 2 that the steady state issues under the previous chunk's last
+    //      group; the tile's noise values are computed / fetched while they are on their way ----
+    const int NC = p.nchunks;
+    nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 0, 0); });
+    if (NC > 1) nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 1, STAGE); });
+    if (NC > 2) nb_static_for<0, N4>([&](auto k) { issue_piece(k, 2, 2 * STAGE); });
+    for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
+        const int r = e / (2 * TQW), c = e - r * (2 * TQW);
+        const int oy = 2 * I0 + r, ox = 2 * J0 + c;
+        float v = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
+        if (p.nsrc.const_t && oy < 2 * H) {
+            float np0, np1, wx0, wx1, wy0, wy1;
+            int sx0, sy0;
+            nb_noise_np(p.nsrc, n, np0, np1);
+            nb_noise_axis(p.nsrc, oy, np0, sx0, wx0, wx1);
+            nb_noise_axis(p.nsrc, ox, np1, sy0, wy0, wy1);
+            v = nb_noise_value(p.nsrc, p.nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
+        }
+        s_noise[e] = v * p.gain;
+    }
+    if (NC > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + N4) : "memory");
+    else if (NC > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    NB_TSTAMP(1);
+
+    // ---- fragment registers (loop-carried).  A: sets a / n (a tap pair: two hi fragments + ONE lo tuple), m (the lone tap 4, lo
+    //      tuple = (tap 4 | zeros)).  B: hi fragments at input offsets 0, 1, XS, XS + 1; lo tuples bl01 = (offset 0 | offset 1) --
+    //      whose second half is reloaded with offset XS's bytes once taps 6 and 3 are through: it then is the operand of taps
+    //      (7, 1); the lone tap in between multiplies that half by A's zeros, whatever it holds -- and bl23 = (XS | XS + 1). ----
+    h8 ah_a[2], ah_n[2], ah_m;
+    i32x8 al_a, al_n, al_m;
+    h8 bh0[NBJ], bh1[NBJ], bh2[NBJ], bh3[NBJ];
+    i32x8 bl01[NBJ], bl23[NBJ];
+    ah_m = h8{}; al_a = i32x8{}; al_n = i32x8{}; al_m = i32x8{};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ah_a[i] = h8{}; ah_n[i] = h8{};
+        bh0[i] = h8{}; bh1[i] = h8{}; bh2[i] = h8{}; bh3[i] = h8{}; bl01[i] = i32x8{}; bl23[i] = i32x8{};
+    }
+    const int sa_ = lh ? 116 : 127, sb_ = lh ? 129 : 118;      // E8M0 block scales (see modconv3x3_up1_h3_kernel)
+
+#define NB_FENCE() __builtin_amdgcn_sched_barrier(0)
+    auto set_lo = [](i32x8& t, const h8& v) { const i32x4 x = __builtin_bit_cast(i32x4, v); t[0] = x[0]; t[1] = x[1]; t[2] = x[2]; t[3] = x[3]; };
+    auto set_hi = [](i32x8& t, const h8& v) { const i32x4 x = __builtin_bit_cast(i32x4, v); t[4] = x[0]; t[5] = x[1]; t[6] = x[2]; t[7] = x[3]; };
+    // one chunk.  NBE = position blocks this wave multiplies; MODE = min(3, NC - 1 - c): 3 steady state, 2 / 1 / 0 the last three
+    // chunks.  sa: this chunk's stage, san: the next chunk's; d2 / d3: first slots of the stages of chunks c + 2 / c + 3
+    auto chunk = [&](auto mode_, auto nbe_, int c, const h8* sa, const h8* san, int d2, int d3) {
+        constexpr int MODE = decltype(mode_)::value, NBE = decltype(nbe_)::value;
+        auto rA = [&](int tap, int hl, const h8* s) -> const h8& { return s[aoff + tap * 128 + hl * 32]; };
+        auto rBh = [&](h8 (&bh)[NBJ], auto j_, int del, const h8* s) { constexpr int j = decltype(j_)::value; if constexpr (j < NBE) bh[j] = s[boff[j] + del]; };
+        auto rBl = [&](i32x8 (&bl)[NBJ], int half, auto j_, int del, const h8* s) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j < NBE) { if (half) set_hi(bl[j], s[boff[j] + XPL + del]); else set_lo(bl[j], s[boff[j] + XPL + del]); }
+        };
+        // piece k of the interval: 0 .. N4-1 belong to chunk c + 3 (under this chunk's last group), N4 .. 6 to chunk c + 2
+        auto dma = [&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+#ifndef NB_ABL_NODMA
+            if constexpr (k < N4) { if constexpr (MODE == 3) issue_piece(k_, c + 3, d3); }
+            else { if constexpr (MODE >= 2) issue_piece(k_, c + 2, d2); }
+#endif
+        };
+        using J0_ = std::integral_constant<int, 0>; using J1_ = std::integral_constant<int, 1>;
+        // a tap pair on both blocks: (f16, f16, fp8) x 2; filler(g) behind MFMA g = 3 j + position
+        auto group_pair = [&](auto ph_, h8 (&ah)[2], i32x8& al, h8 (&Ba)[NBJ], h8 (&Bb)[NBJ], i32x8 (&bl)[NBJ], auto&& filler) {
+            constexpr int ph = decltype(ph_)::value;
+            nb_static_for<0, 2>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                f32x16& a_ = acc[j][ph];
+                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], Ba[j], a_, 0, 0, 0);
+                NB_FENCE(); filler(std::integral_constant<int, 3 * j>{}); NB_FENCE();
+                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], Bb[j], a_, 0, 0, 0);
+                NB_FENCE(); filler(std::integral_constant<int, 3 * j + 1>{}); NB_FENCE();
+                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al, bl[j], a_, 0, 0, 0, sa_, 0, sb_);
+                NB_FENCE(); filler(std::integral_constant<int, 3 * j + 2>{}); NB_FENCE();
+            });
+        };
+        NB_FENCE();
+        // G0: taps 8, 6 -> phase 0.  Fillers: the A fragments of G1; pieces 2, 3
+        group_pair(std::integral_constant<int, 0>{}, ah_a, al_a, bh0, bh1, bl01, [&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            if constexpr (g == 0) ah_n[0] = rA(5, 0, sa);
+            else if constexpr (g == 1) ah_n[1] = rA(3, 0, sa);
+            else if constexpr (g == 2) dma(std::integral_constant<int, 2>{});
+            else if constexpr (g == 3) set_lo(al_n, rA(5, 1, sa));
+            else if constexpr (g == 4) set_hi(al_n, rA(3, 1, sa));
+            else dma(std::integral_constant<int, 3>{});
+        });
+        // G1: taps 5, 3 -> phase 2.  Fillers: tap 4, the row-below hi fragments, and -- behind the fp8 MFMA that was the last to
+        // read offset 1's lo bytes of a block -- offset XS's into that half of bl01; piece 4
+        group_pair(std::integral_constant<int, 2>{}, ah_n, al_n, bh0, bh1, bl01, [&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            if constexpr (g == 0) { ah_m = rA(4, 0, sa); set_lo(al_m, rA(4, 1, sa)); }
+            else if constexpr (g == 1) { rBh(bh2, J0_{}, XS, sa); rBh(bh2, J1_{}, XS, sa); }
+            else if constexpr (g == 2) { dma(std::integral_constant<int, 4>{}); rBl(bl01, 1, J0_{}, XS, sa); }
+            else if constexpr (g == 5) rBl(bl01, 1, J1_{}, XS, sa);
+        });
+        // G2: tap 4 -> phase 3: (f16, fp8) x 2; A = (tap 4 | zeros).  Fillers: the A fragments of G3; piece 5
+        nb_static_for<0, 2>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            f32x16& a_ = acc[j][3];
+            if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_m, bh0[j], a_, 0, 0, 0);
+            NB_FENCE();
+            if constexpr (j == 0) { ah_a[0] = rA(7, 0, sa); ah_a[1] = rA(1, 0, sa); } else { set_lo(al_a, rA(7, 1, sa)); set_hi(al_a, rA(1, 1, sa)); }
+            NB_FENCE();
+            if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al_m, bl01[j], a_, 0, 0, 0, sa_, 0, sb_);
+            NB_FENCE();
+            if constexpr (j == 0) dma(std::integral_constant<int, 5>{});
+            NB_FENCE();
+        });
+        // G3: taps 7, 1 -> phase 1 (bl01 = (offset 0 | XS) now).  Fillers: the A fragments of G4, the diagonal fragments; piece 6
+        group_pair(std::integral_constant<int, 1>{}, ah_a, al_a, bh0, bh2, bl01, [&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            if constexpr (g == 0) ah_n[0] = rA(2, 0, sa);
+            else if constexpr (g == 1) ah_n[1] = rA(0, 0, sa);
+            else if constexpr (g == 2) { dma(std::integral_constant<int, 6>{}); rBl(bl23, 0, J0_{}, XS, sa); rBl(bl23, 1, J0_{}, XS + 1, sa); }
+            else if constexpr (g == 3) { set_lo(al_n, rA(2, 1, sa)); set_hi(al_n, rA(0, 1, sa)); }
+            else if constexpr (g == 4) { rBh(bh3, J0_{}, XS + 1, sa); rBh(bh3, J1_{}, XS + 1, sa); }
+            else { rBl(bl23, 0, J1_{}, XS, sa); rBl(bl23, 1, J1_{}, XS + 1, sa); }
+        });
+        // everything of this chunk's stage has been read (G4's operands are on their way: waited for here); the next chunk has
+        // landed: all but the NPC youngest pieces (chunk c + 2)
+        if constexpr (MODE >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPC) : "memory");
+        else if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        NB_FENCE();
+        // G4: taps 2, 0 -> phase 0.  Fillers: the NEXT chunk's first operands in the order G0 takes them; pieces 0, 1 of chunk c + 3
+        group_pair(std::integral_constant<int, 0>{}, ah_n, al_n, bh2, bh3, bl23, [&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            if constexpr (g == 2) dma(std::integral_constant<int, 0>{});
+            if constexpr (g == 5) dma(std::integral_constant<int, 1>{});
+            if constexpr (MODE >= 1) {
+                if constexpr (g == 0) { ah_a[0] = rA(8, 0, san); rBh(bh0, J0_{}, 0, san); }
+                else if constexpr (g == 1) { ah_a[1] = rA(6, 0, san); rBh(bh1, J0_{}, 1, san); }
+                else if constexpr (g == 2) { rBh(bh0, J1_{}, 0, san); rBh(bh1, J1_{}, 1, san); }
+                else if constexpr (g == 3) { set_lo(al_a, rA(8, 1, san)); set_hi(al_a, rA(6, 1, san)); }
+                else if constexpr (g == 4) { rBl(bl01, 0, J0_{}, 0, san); rBl(bl01, 1, J0_{}, 1, san); }
+                else { rBl(bl01, 0, J1_{}, 0, san); rBl(bl01, 1, J1_{}, 1, san); }
+            }
+        });
+        NB_FENCE();
+    };
+    auto kloop = [&](auto nbe) {
+        constexpr int NBE = decltype(nbe)::value;
+        // the first chunk's first operands
+        ah_a[0] = ring[aoff + 8 * 128]; ah_a[1] = ring[aoff + 6 * 128];
+        set_lo(al_a, ring[aoff + 8 * 128 + 32]); set_hi(al_a, ring[aoff + 6 * 128 + 32]);
+#pragma unroll
+        for (int j = 0; j < NBE; ++j) {
+            bh0[j] = ring[boff[j]]; bh1[j] = ring[boff[j] + 1];
+            set_lo(bl01[j], ring[boff[j] + XPL]); set_hi(bl01[j], ring[boff[j] + XPL + 1]);
+        }
+        int c = 0, s = 0;                             // s = stage of chunk c
+        auto nxt = [](int s_) { return s_ == 2 ? 0 : s_ + 1; };
+        for (; c + 3 < NC; ++c) {                     // stage of chunk c + 3 = stage of chunk c (overwritten behind the barrier)
+            chunk(std::integral_constant<int, 3>{}, nbe, c, ring + s * STAGE, ring + nxt(s) * STAGE, nxt(nxt(s)) * STAGE, s * STAGE);
+            s = nxt(s);
+        }
+        if (c + 2 < NC) { chunk(std::integral_constant<int, 2>{}, nbe, c, ring + s * STAGE, ring + nxt(s) * STAGE, nxt(nxt(s)) * STAGE, 0); s = nxt(s); ++c; }
+        if (c + 1 < NC) { chunk(std::integral_constant<int, 1>{}, nbe, c, ring + s * STAGE, ring + nxt(s) * STAGE, 0, 0); s = nxt(s); ++c; }
+        chunk(std::integral_constant<int, 0>{}, nbe, c, ring + s * STAGE, nullptr, 0, 0);
+    };
+    const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
+    // position blocks of this wave that hold rows feeding stored pixels (see modconv3x3_up2_h3_kernel)
+    const int nvalid_blk = (min(TQH, H - I0) + 2) * PW;
+    int nbe_w = 0;
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) nbe_w += (wv + NW * j) * 32 < nvalid_blk && j < nblk;
+    if (nbe_w == 2) kloop(std::integral_constant<int, 2>{});
+    else if (nbe_w == 1) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
+#undef NB_FENCE
+    if (p.tstamps && tid == 0) {
+        unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        ts[6] = 0; ts[7] = (__builtin_amdgcn_s_memtime() - t_loop0) << 32;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain before the staging LDS is reused
+    __builtin_amdgcn_s_barrier();
+
+    NB_TSTAMP(2);
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
+    // ---- epilogue: modconv3x3_up2_h3_kernel's, statement for statement (2 rounds of 16 c_out; comments there) ----
+    const int Wo = 2 * W, Ho = 2 * H;
+    constexpr int nquads = TQH * TQW;
+    constexpr int Y1P = NBLK * 32;
+    f32x4* y4 = reinterpret_cast<f32x4*>(smem_v);
+    const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+    unsigned long long te_w = 0, te_f = 0, te0 = 0;
+#pragma unroll
+    for (int R = 0; R < 2; ++R) {
+        if (p.tstamps) te0 = __builtin_amdgcn_s_memtime();
+        if (R) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int gs = 0; gs < 2; ++gs) {
+            const int r0 = (2 * R + gs) * 4;
+#pragma unroll
+            for (int j = 0; j < NBJ; ++j) {
+                if (j >= nblk) continue;
+                const int pidx = (wv + NW * j) * 32 + l31;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    const f32x16& a_ = acc[j][ph];
+                    y4[((gs * 2 + lh) * 4 + ph) * Y1P + pidx] = f32x4{a_[r0], a_[r0 + 1], a_[r0 + 2], a_[r0 + 3]};
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_w += t_ - te0; te0 = t_; }
+        auto quad_item = [&](const int wi) {
+            const int hq = wi * 32 + l31;
+            const int gs = hq / nquads, qd = hq - gs * nquads;
+            const int ti = qd / TQW, tj = qd - ti * TQW;
+            if (I0 + ti >= H) return;
+            const int c4 = 16 * R + 8 * gs + 4 * lh;  // the lane's four channels within the slice
+            const f32x4* ee = y4 + ((gs * 2 + lh) * 4) * Y1P + ti * PW + tj;
+            const f32x4* eo = ee + 1 * Y1P;
+            const f32x4* oe = ee + 2 * Y1P;
+            const f32x4* oo = ee + 3 * Y1P;
+            auto fir4 = [](f32x4 a, f32x4 b, f32x4 c, f32x4 d) {
+                f32x4 q75, q25;
+                q75 = 0.75f; q25 = 0.25f;
+                return __builtin_elementwise_fma(q25, d, __builtin_elementwise_fma(q75, c, __builtin_elementwise_fma(q75, b, 0.25f * a)));
+            };
+            f32x4 ve[2][2], vo[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < 2) {
+                    const f32x4 e0 = ee[c], e1 = ee[PW + c], o0 = oe[c], o1 = oe[PW + c], o2 = oe[2 * PW + c];
+                    ve[c][0] = fir4(o0, e0, o1, e1); ve[c][1] = fir4(e0, o1, e1, o2);
+                }
+                const f32x4 e0 = eo[c], e1 = eo[PW + c], o0 = oo[c], o1 = oo[PW + c], o2 = oo[2 * PW + c];
+                vo[c][0] = fir4(o0, e0, o1, e1); vo[c][1] = fir4(e0, o1, e1, o2);
+            }
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dco + c4), b4 = *reinterpret_cast<const f32x4*>(s_bias + c4);
+            const int qi = I0 + ti, qj = J0 + tj;
+            auto act4 = [&](f32x4 o, float nz) {
+                f32x4 t = __builtin_elementwise_fma(o, d4, b4 + nz);
+                const f32x4 ta = t * p.alpha;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t[i], ta[i], __builtin_inff()), -clampv, clampv);
+                return t;
+            };
+            f32x4 v[2][2];                            // [dy][px]
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const f32x2 nz = *reinterpret_cast<const f32x2*>(s_noise + (2 * ti + dy) * (2 * TQW) + 2 * tj);
+                // (the two noise values get registers of their own: see the note on v_pk_add_f32 op_sel in modconv3x3_up2_h3_kernel)
+                float nz0 = nz[0], nz1 = nz[1];
+                asm volatile("v_mov_b32 %0, %0" : "+v"(nz0));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(nz1));
+                v[dy][0] = act4(fir4(vo[0][dy], ve[0][dy], vo[1][dy], ve[1][dy]), nz0);
+                v[dy][1] = act4(fir4(ve[0][dy], vo[1][dy], ve[1][dy], vo[2][dy]), nz1);
+            }
+            if constexpr (OUTM == 0) {
+                if (qi < H && !(p.dbg & 1)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co0 + c4 + i;
+                        if (co < p.c_out) {
+                            float* dst = p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)(2 * qi) * Wo + 2 * qj;
+                            *reinterpret_cast<f32x2*>(dst) = f32x2{v[0][0][i], v[0][1][i]};
+                            *reinterpret_cast<f32x2*>(dst + Wo) = f32x2{v[1][0][i], v[1][1][i]};
+                        }
+                    }
+                }
+            } else {
+                const f32x4 ns4 = *reinterpret_cast<const f32x4*>(s_nst + c4);
+                unsigned hi[2][2][2], lo[2][2][2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        f32x4 w = v[dy][px] * ns4;
+                        const h2 h01 = __builtin_convertvector(f32x2{w[0], w[1]}, h2), h23 = __builtin_convertvector(f32x2{w[2], w[3]}, h2);
+                        const f32x4 xl = {nb_sub_f16(w[0], h01, false), nb_sub_f16(w[1], h01, true), nb_sub_f16(w[2], h23, false), nb_sub_f16(w[3], h23, true)};
+                        hi[dy][px][0] = __builtin_bit_cast(unsigned, h01); hi[dy][px][1] = __builtin_bit_cast(unsigned, h23);
+                        if constexpr (OUTM == 1) {
+                            const h2 l01 = __builtin_convertvector(f32x2{xl[0], xl[1]}, h2), l23 = __builtin_convertvector(f32x2{xl[2], xl[3]}, h2);
+                            lo[dy][px][0] = __builtin_bit_cast(unsigned, l01); lo[dy][px][1] = __builtin_bit_cast(unsigned, l23);
+                        } else {
+                            const f32x4 s = xl * 512.f, q = w * 0.25f;
+                            lo[dy][px][0] = nb_pk4_fp8_sat(s[0], s[1], s[2], s[3]);
+                            lo[dy][px][1] = nb_pk4_fp8_sat(q[0], q[1], q[2], q[3]);
+                        }
+                    }
+                unsigned ha[2][2], hb[2][2], la[2][2], lb[2][2];
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        ha[px][k] = hi[0][px][k]; hb[px][k] = hi[1][px][k]; la[px][k] = lo[0][px][k]; lb[px][k] = lo[1][px][k];
+                        nb_swap32(ha[px][k], hb[px][k]);
+                        nb_swap32(la[px][k], lb[px][k]);
+                    }
+                const int cg = co0 / 8 + 2 * R + gs;
+                const int oy = 2 * qi + lh, ox = 2 * qj;
+                if (qi < H && cg * 8 < p.c_out && !(p.dbg & 1)) {
+                    const size_t OHW8 = (size_t)Ho * Wo * 8;
+                    _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
+                    const size_t opix8 = ((size_t)oy * Wo + ox) * 8;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        *reinterpret_cast<u32x4*>(yn + opix8 + px * 8) = u32x4{ha[px][0], ha[px][1], hb[px][0], hb[px][1]};
+                        if constexpr (OUTM == 1) {
+                            *reinterpret_cast<u32x4*>(yn + OHW8 + opix8 + px * 8) = u32x4{la[px][0], la[px][1], lb[px][0], lb[px][1]};
+                        } else {
+                            _Float16* lo_xl = p.yh2 + ((size_t)n * p.c8_next + (cg & ~1)) * 2 * OHW8 + OHW8 + opix8 + px * 8 + (cg & 1) * 4;
+                            *reinterpret_cast<u32x2*>(lo_xl) = u32x2{la[px][0], lb[px][0]};
+                            *reinterpret_cast<u32x2*>(lo_xl + 2 * OHW8) = u32x2{la[px][1], lb[px][1]};
+                        }
+                    }
+                }
+            }
+        };
+        constexpr int NWI = nquads * 2 / 32;          // 24 wave-iterations of 32 quads x both channel halves per round
+        static_assert(nquads * 2 % 32 == 0 && NWI % NW == 0, "tile quads must fill whole waves");
+#pragma unroll
+        for (int k = 0; k < NWI / NW; ++k) quad_item(wv + k * NW);
+        if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_f += t_ - te0; }
+    }
+    NB_TSTAMP(4);
+    if (p.tstamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NB_TSTAMP(5);
+        if (threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 3] = (te_w & 0x1fffff) | ((te_f & 0x1fffff) << 21);
+    }
+}
+
+template <int OUTM>
+static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
+    constexpr size_t lds_ring = (size_t)NST * STAGE * 16, lds_epi = (size_t)16 * NBLK * 32 * 16;
+    constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<OUTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
+    hipLaunchKernelGGL((modconv3x3_up2v_kernel<OUTM>), grid, dim3(NT), lds, (hipStream_t)stream, p);
+    NB_CHECK_LAUNCH("modconv3x3_up2v");
+    return NB_OK;
+}
+
+// shapes this form takes: f8 operands (whole 16-channel chunks), 32-column tiles of 12 quad rows
+bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w) { return in_fmt == 1 && c_in % 16 == 0 && w % TQW == 0 && h >= 8; }
+
+// p as filled in by nb_up2_h3_impl (nb_modconv_h3.hip); tiles are set here
+int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long long* tstamps, int tstamps_cap) {
+    NB_REQUIRE(nb_up2v_eligible(in_fmt, p.nchunks * 16, p.h, p.w) && p.co_ld % CO_WG == 0, "modconv3x3_up2v: shape not supported");
+    p.tiles_x = p.w / TQW;
+    p.tiles_y = (p.h + TQH - 1) / TQH;
+    p.slices = (p.c_out + CO_WG - 1) / CO_WG;
+    p.tstamps = (tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= tstamps_cap) ? tstamps : nullptr;
+    const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
+    return outm == 2 ? nb_up2v_launch1<2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<1>(p, n, stream) : nb_up2v_launch1<0>(p, n, stream);
+}

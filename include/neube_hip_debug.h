@@ -36,6 +36,11 @@ void nb_debug_set_up2_pair(int mode);
  * allows (f8 operands, c_out % 64 == 0, w % 16 == 0).  tests/test_hip_f8.py asserts it bit-identical to the 8-wave kernel. */
 void nb_debug_set_up2_wide(int mode);
 
+/* The 8-wave split-f16 up=2 kernel with the software-pipelined K loop (csrc/nb_modconv_up2v.hip; f8 operands, 12 x 32 tiles):
+ * -1 = automatic (every f8 launch that takes the 12-row tiles), 0 = never (the round-3 kernel), 1 = wherever the shape allows.
+ * tests/test_hip_f8.py asserts the two bit-identical. */
+void nb_debug_set_up2_v2(int mode);
+
 /* Tile form of nb_enc_conv3x3_h3: -1 = automatic, 0 = large tiles, 1 = small split-K tiles. */
 void nb_debug_set_enc_small(int mode);
 

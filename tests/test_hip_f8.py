@@ -166,12 +166,13 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for tqh in (12, 8, 5, "pair", "wide"):
-            if tqh == "wide" and not fmt:
-                continue                                  # (the wide form exists for f8 operands)
-            lib.nb_debug_set_up2_tile(12 if tqh == "pair" else 0 if tqh == "wide" else tqh)
+        for tqh in (12, 8, 5, "pair", "wide", "v2"):
+            if tqh in ("wide", "v2") and not fmt:
+                continue                                  # (these forms exist for f8 operands)
+            lib.nb_debug_set_up2_tile(12 if tqh == "pair" else 0 if tqh in ("wide", "v2") else tqh)
             lib.nb_debug_set_up2_pair(1 if tqh == "pair" else 0)
             lib.nb_debug_set_up2_wide(1 if tqh == "wide" else 0)
+            lib.nb_debug_set_up2_v2(1 if tqh == "v2" else 0)        # (12 = the round-3 kernel on the same tiles)
             y = torch.empty([n, co, 2 * h, 2 * w], device="cuda")
             out = torch.zeros(ops.h2_shape(n, co, 2 * h, 2 * w), dtype=torch.float16, device="cuda")
             common = (dco.data_ptr(), noise.data_ptr(), 4 * h * w, bias.data_ptr())
@@ -185,7 +186,11 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
         lib.nb_debug_set_up2_tile(0)
         lib.nb_debug_set_up2_pair(-1)
         lib.nb_debug_set_up2_wide(-1)
+        lib.nb_debug_set_up2_v2(-1)
     if fmt:
+        # the 8-wave kernel with the software-pipelined K loop (same tiles as 12)
+        assert torch.equal(res[12][0], res["v2"][0])
+        assert torch.equal(res[12][1], res["v2"][1])
         # the one-wave-per-SIMD form (64 c_out x 12 x 16 quads per workgroup; 26 and 32 rows end in ragged tiles whose waves
         # multiply one or none of their two position blocks)
         assert torch.equal(res[12][0], res["wide"][0])
