@@ -57,6 +57,11 @@ def layer_flops(spec, batch):
     return 2.0 * macs * batch
 
 
+def is_split_kernel(kname):
+    """Kernels that multiply in f16 (+ fp8 corrections): the split-f16 family, incl. the two re-tiled up=2 kernels of round 4."""
+    return "_h3_" in kname or "up2v_kernel" in kname or "up2w_kernel" in kname
+
+
 def kernel_label(spec):
     return f"modconv3x3_up{spec.up}[{spec.in_channels}->{spec.out_channels}@{spec.block_res}]"
 
@@ -198,7 +203,7 @@ def traffic_lookup(table, kname):
     return None
 
 
-def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
+def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, sampler=None, calib=None):
     """W warm-up steps, then exactly K timed steps of the hot path in one arithmetic mode, bracketed by barrier +
     synchronize; returns this mode's figures (value, ms_per_step, roofline of its dominant kernel)."""
     from brushstroke_engine_amd.sharding import TileGatherer
@@ -326,22 +331,45 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
         dist.barrier()
     torch.cuda.synchronize()
     G.synthesis.layer_events = []
+    for g_ in [gatherer] + part_gatherers:
+        if g_ is not None:
+            g_.wait_ms()                                 # (reset: count the waits of the timed region only)
+    if sampler is not None:
+        sampler.mark(mode)
     t0 = time.perf_counter()
     for i_ in range(args.steps):
         G.synthesis.event_filter = dom_layers if i_ % args.event_every == 0 else none_
         step()
     finish_gathers()
     torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.unmark(mode)
     events = G.synthesis.layer_events
     G.synthesis.layer_events, G.synthesis.event_filter, G.synthesis.event_pool = None, None, None
+    per_rank_ms, gather_wait = None, None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own time for its K steps (before the closing barrier), and how long rank 0 waited for the tile gathers
+        mine = torch.zeros([world], dtype=torch.float64, device=dev)
+        mine[rank] = elapsed_local / args.steps * 1e3
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(v), 4) for v in mine.tolist()]
+        if gatherer is not None:
+            w_ = [g_.wait_ms() for g_ in [gatherer] + part_gatherers]
+            gather_wait = {"host_ms_per_step": round(sum(x["host_ms"] for x in w_) / args.steps, 4),
+                           "stream_ms_per_step": (round(sum(x["stream_ms"] or 0.0 for x in w_) / args.steps, 4)
+                                                  if any(x["stream_ms"] is not None for x in w_) else None),
+                           "waits": sum(x["waits"] for x in w_),
+                           "what": "time TileGatherer.finish() kept THIS rank (0) waiting inside the timed steps: host wall clock, and "
+                                   "HIP events on the issuing stream around the wait (an RCCL wait stalls the stream, not the host); the "
+                                   "gather of step k is waited for at step k+1, after a whole step of compute"}
 
     # after the timed region: the dominant kernel once more with the whole batch on ONE stream (3 steps), so that its
     # launch duration is also known without another stream's kernels sharing the chip
@@ -375,7 +403,7 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
     dom_ms = sum(float(np.mean(ts)) for ts in timed.values())            # mean launch duration, summed over the kernel's layers
     dom_fl = sum(layer_flops(specs[name], B / sub) for name in timed)
     dom_launches = len(timed)
-    peak_of = lambda kname: PEAK_F16_MATRIX_TFLOPS if "_h3_" in kname else PEAK_F32_MATRIX_TFLOPS
+    peak_of = lambda kname: PEAK_F16_MATRIX_TFLOPS if is_split_kernel(kname) else PEAK_F32_MATRIX_TFLOPS
     dom_peak = peak_of(dom_name)
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12
     # calibration table (all launches bracketed, untimed pass)
@@ -394,7 +422,7 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
     conv_fl = sum(r[2] for r in rows)
     ttable, traffic_note = load_traffic(mode, args.res, B)
     traffic = traffic_lookup(ttable, dom_name)
-    split = "_h3_" in dom_name
+    split = is_split_kernel(dom_name)
     roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": dom_peak,
                 "unit": "TFLOP/s", "frac": round(achieved / dom_peak, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "peak_what": ("dense f16 MFMA (MI355X_MICROARCH.md ~2.5 PFLOP/s): the type this kernel multiplies in" if split else
@@ -442,9 +470,21 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather):
                                             for k, v in kernels.items()},
                                 "layers_ms": {r[1]: round(r[0], 4) for r in rows},
                                 "other_ms": {k: round(float(np.sum(v)) / 3, 4) for k, v in cal.items() if k not in specs}}}
+    if calib and calib.get("mfma_f16_sustained_tflops") and split:
+        roofline["frac_of_sustained"] = round(achieved / calib["mfma_f16_sustained_tflops"], 4)
+        roofline["frac_of_sustained_what"] = ("achieved / box_calibration.mfma_f16_sustained_tflops: against what THIS board holds on a "
+                                              "registers-only f16 MFMA loop at its own clock under load, instead of the nominal 2.5 PFLOP/s")
     ms_per_step = elapsed / args.steps * 1e3
     whole = B * 2 * cfg.macs_per_patch() / (ms_per_step * 1e-3) / 1e12
+    extra = {}
+    if sampler is not None:
+        extra["telemetry"] = sampler.summary(mode)
+    if per_rank_ms is not None:
+        extra["ms_per_step_per_rank"] = per_rank_ms
+    if gather_wait is not None:
+        extra["gather_wait_ms"] = gather_wait
     return {
+        **extra,
         "value": round(world * B * args.steps / elapsed, 2), "unit": "patches/s", "ms_per_step": round(ms_per_step, 4),
         "steps": args.steps, "warmup": args.warmup, "dtype": MODE_DTYPE[mode], "schedule": schedule,
         "roofline": roofline,
@@ -581,10 +621,29 @@ def main():
             dist.destroy_process_group()
             raise SystemExit(3)
 
+    # who is here (N > 1: all-gather of every rank's device; fails unless the ranks sit on N distinct devices)
+    from brushstroke_engine_amd import launch as _launch, telemetry as _tele
+    fabric = _launch.fabric_report(dev, rank, world, backend)
+    # what this board sustains on the instruction the conv kernels are built on (50 ms registers-only f16 MFMA loop), before
+    # anything is timed; then a side thread samples board power and shader clock for the rest of the run
+    calib = None
+    try:
+        import ctypes as _C
+        tf, ms_, clk = _C.c_double(), _C.c_double(), _C.c_double()
+        _nblib.check(_nblib.lib().nb_calibrate_mfma_f16(50.0, _C.byref(tf), _C.byref(ms_), _C.byref(clk), None), "calibrate")
+        calib = {"mfma_f16_sustained_tflops": round(tf.value, 1), "loop_ms": round(ms_.value, 2), "loop_clock_mhz": round(clk.value, 1),
+                 "frac_of_nominal_peak": round(tf.value / PEAK_F16_MATRIX_TFLOPS, 4),
+                 "what": "registers-only loop of back-to-back v_mfma_f32_32x32x16_f16 on random operands, one wave per SIMD on every CU "
+                         "(nb_calibrate_mfma_f16), ~50 ms, run before the first mode; loop_clock_mhz = median in-kernel clock "
+                         "(s_memtime / s_memrealtime)"}
+    except Exception as e:                                       # noqa: BLE001
+        calib = {"mfma_f16_sustained_tflops": None, "what": f"calibration failed: {e}"}
+    sampler = _tele.PowerClockSampler(_tele.find_hwmon(_tele.pci_bus_id_of(local_rank)))
+    sampler.__enter__()
     gens, results = {}, {}
     for m in modes:
         gens[m] = Generator(cfg, sd, conv_mode=m).to(dev)
-        results[m] = measure_mode(gens[m], m, args, cfg, (z, geom, pos), world, rank, dev, backend, gather)
+        results[m] = measure_mode(gens[m], m, args, cfg, (z, geom, pos), world, rank, dev, backend, gather, sampler=sampler, calib=calib)
     G = gens[args.conv_mode]
     prim = results[args.conv_mode]
     # Auxiliary figure (NOT `value`): the same steps with three independent steps in flight on three HIP streams (own
@@ -603,14 +662,34 @@ def main():
                     G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False, _plan_slot=27 + i_ % 3)
             torch.cuda.synchronize()
             return time.perf_counter() - t_
+        def run1(k_):                                   # the same loop on ONE stream (slot 27): the reference of this leg
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            with torch.cuda.stream(streams3[0]):
+                for _ in range(k_):
+                    G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False, _plan_slot=27)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t_
         for s_ in streams3:
             s_.wait_stream(torch.cuda.current_stream(dev))
-        run3(9)
         k3 = max(args.steps, 30)
-        el3 = run3(k3)
+        # warm both forms (workspaces of the three slots, code objects), then interleave them: 1, 3, 1, 3 -- the ratio is taken
+        # between neighbours in time, on this box, in this thermal state (the round-3 driver run saw 3 streams 14 % BELOW the
+        # single-stream headline, measured minutes apart in the run; several boxes since gave +2 .. +10 %)
+        run3(9); run1(6)
+        sampler.mark("concurrent")
+        el1a, el3a, el1b, el3b = run1(k3), run3(k3), run1(k3), run3(k3)
+        sampler.unmark("concurrent")
+        el1, el3 = min(el1a, el1b), min(el3a, el3b)
         concurrent = {"streams": 3, "steps": k3, "value": round(B * k3 / el3, 2), "unit": "patches/s", "ms_per_step": round(el3 / k3 * 1e3, 4),
-                      "what": "three independent steps in flight on three HIP streams (the tiled-canvas schedule alternates its batches the "
-                              "same way); auxiliary -- kernels share the chip, so no per-kernel roofline is taken from this run"}
+                      "single_stream_same_leg": {"value": round(B * k3 / el1, 2), "ms_per_step": round(el1 / k3 * 1e3, 4)},
+                      "ratio_vs_single_stream": round(el1 / el3, 4),
+                      "runs_ms_per_step": {"one_stream": [round(el1a / k3 * 1e3, 4), round(el1b / k3 * 1e3, 4)],
+                                           "three_streams": [round(el3a / k3 * 1e3, 4), round(el3b / k3 * 1e3, 4)]},
+                      "telemetry": sampler.summary("concurrent"),
+                      "what": "three independent steps in flight on three HIP streams against the same loop on one stream, interleaved "
+                              "(1, 3, 1, 3; best of two each); auxiliary -- kernels share the chip, so no per-kernel roofline is taken "
+                              "from this run.  The tiled-canvas schedule no longer assumes the gain: TileOps.choose_streams probes it"}
 
     if rank == 0:
         out = {
@@ -628,13 +707,19 @@ def main():
                        "parallelism": f"patch-parallel x{world}" + ("" if world == 1 else
                                                                    (f" + {'RCCL' if backend == 'nccl' else backend} gather of RGBA tiles to rank 0 "
                                                                     f"inside every step (rank 0 receives {world - 1} x {B * args.res * args.res * 4 / 1e6:.1f} MB "
-                                                                    f"per step; no overlap evidence for N > 1 exists yet)") if gather else " (NO gather: --no-gather)")},
+                                                                    f"per step; see gather_wait_ms / ms_per_step_per_rank / rccl)") if gather else " (NO gather: --no-gather)")},
             "schedule": prim["schedule"],
+            "box_calibration": calib,
+            "telemetry": prim.get("telemetry"),
             "roofline": prim["roofline"],
             "roofline_whole_step": prim["roofline_whole_step"],
             "rehearsal_ms_per_step": prim["rehearsal_ms_per_step"],
             "burn_in_ms_per_step": prim["burn_in_ms_per_step"],
         }
+        if world > 1:
+            out["rccl"] = fabric
+            out["ms_per_step_per_rank"] = prim.get("ms_per_step_per_rank")
+            out["gather_wait_ms"] = prim.get("gather_wait_ms")
         if "h3" in results:
             # SURVEY 8(d)'s "fp32 parity mode": every fp32 product to ~2^-22 (5e-6 on pixels), the same grade as an fp32 evaluation
             out["value_fp32_parity"] = results["h3"]["value"]
@@ -650,6 +735,7 @@ def main():
                 out["modes"][m]["parity"] = pr
             out["cpu_baseline"]["parity"] = out["modes"][args.conv_mode].get("parity")
         print(json.dumps(out), flush=True)
+    sampler.__exit__(None, None, None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

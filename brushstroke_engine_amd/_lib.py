@@ -18,7 +18,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libneube_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lock = threading.Lock()
 _lib = None
@@ -69,6 +69,8 @@ PROTOTYPES = {
     "nb_modconv3x3_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
     "nb_modconv3x3_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "nb_calibrate_mfma_f16": (C.c_int, [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
+    "nb_modconv3x3_up2_h3_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nb_pack_h2_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_pack_conv_weight_h3": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "nb_pack_conv_weight_h3_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -16,7 +16,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libneube_hip.so")
-SOURCES = ["nb_ops.hip", "nb_modconv.hip", "nb_modconv_h3.hip", "nb_modconv_up2w.hip", "nb_modconv_up2v.hip", "nb_modconv_small.hip", "nb_grad.hip", "nb_canvas.hip", "nb_encoder.hip"]
+SOURCES = ["nb_ops.hip", "nb_modconv.hip", "nb_modconv_h3.hip", "nb_modconv_up2w.hip", "nb_modconv_up2v.hip", "nb_modconv_small.hip", "nb_grad.hip", "nb_canvas.hip", "nb_encoder.hip", "nb_calib.hip"]
 HEADERS = ["nb_common.h", "nb_h3_common.h", "nb_torgb.h", os.path.join("..", "..", "include", "neube_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

@@ -5,7 +5,7 @@
 #include <cstdarg>
 #include "../../include/neube_hip.h"
 
-#define NB_ABI_VERSION 10
+#define NB_ABI_VERSION 11
 
 // Kernels whose scalar fp32 arithmetic the SLP vectoriser pairs into packed instructions are compiled WITHOUT packed fp32 ops.
 // Reason: the pairing produces forms that swizzle register halves -- `v_pk_add_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]`,

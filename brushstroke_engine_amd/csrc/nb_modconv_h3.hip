@@ -1592,6 +1592,46 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
                                                                                            : nb_up2_h3_launch1<TQH, TQW, false, 0, NW, NST>(p, n, lds, stream);
 }
 
+// which kernel a split-f16 up=2 launch runs on (the debug hooks / environment switches apply)
+enum Up2Form { UP2_BIG = 0, UP2_MID, UP2_SMALL, UP2_W16, UP2_PAIR, UP2_WIDE, UP2_V2 };
+static Up2Form nb_up2_h3_select(int in_fmt, int c_in, int c_out, int n, int h, int w) {
+    const int tiles_x = w / 32, slices = (c_out + 31) / 32;
+    // the wide form (one wave per SIMD, 64 c_out per workgroup): opt-in
+    static const int env_wide = getenv("NB_UP2_WIDE") ? atoi(getenv("NB_UP2_WIDE")) : -1;
+    const int force_wide = g_force_wide >= 0 ? g_force_wide : env_wide;
+    if (force_wide != 0 && g_force_tqh <= 0 && g_force_pair <= 0 && nb_up2w_eligible(in_fmt, c_in, c_out, h, w) &&
+        (force_wide > 0 || (NB_UP2W_AUTO && nb_up2w_workgroups(n, c_out, h, w) >= 768)))
+        return UP2_WIDE;
+    if (w == 16) return UP2_W16;                      // 16-wide inputs: 8 x 16 quad tiles
+    // tile height: the 12-row tiles unless they leave the chip mostly idle (batch-1 / interactive), then 5-row tiles
+    static const int env_tqh = getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0;
+    const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
+    const long wgs_big = (long)n * tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * slices;
+    const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
+    // 8-row tiles when the 12-row tiles' last round of workgroups would leave most of the chip idle.  Estimate = rounds of 256
+    // workgroups x cost of one (critical SIMD's position blocks 4 / 3, + prologue and epilogue ~ quads): b64.conv0 at batch 32
+    // (32 input rows) is 384 workgroups = 1.5 rounds of 12-row tiles, but 512 = 2 full rounds of 8-row tiles at 0.73 the cost.
+    bool mid_tiles = force_tqh == NB_H3_TQH_MID;
+    if (!force_tqh && !small_tiles) {
+        constexpr long ncu = 256;                     // MI355X (one workgroup of this kernel per CU)
+        const long wgs_mid = (long)n * tiles_x * ((h + NB_H3_TQH_MID - 1) / NB_H3_TQH_MID) * slices;
+        const double est_big = (double)((wgs_big + ncu - 1) / ncu) * 5.4, est_mid = (double)((wgs_mid + ncu - 1) / ncu) * 3.93;
+        mid_tiles = est_mid < 0.9 * est_big;
+    }
+    // two 4-wave workgroups per CU on 12 x 16 tiles (see the kernel's NW_ / NST_) when that launch fills the chip as well
+    static const int env_pair = getenv("NB_UP2_PAIR") ? atoi(getenv("NB_UP2_PAIR")) : 0;
+    const bool pair = !in_fmt && (g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && !mid_tiles && wgs_big * 2 >= 1024));
+    if (pair) return UP2_PAIR;
+    // the 12-row throughput tiles of an f8 launch: the kernel with the software-pipelined K loop (same tile, same results)
+    static const int env_v2 = getenv("NB_UP2_V2") ? atoi(getenv("NB_UP2_V2")) : -1;
+    const int force_v2 = g_force_v2 >= 0 ? g_force_v2 : env_v2;
+    if (force_v2 != 0 && nb_up2v_eligible(in_fmt, c_in, h, w) &&
+        (force_v2 > 0 ? force_tqh == 0 || force_tqh == NB_H3_TQH : (NB_UP2V_AUTO && !mid_tiles && !small_tiles && (force_tqh == 0 || force_tqh == NB_H3_TQH))))
+        return UP2_V2;
+    if (mid_tiles) return UP2_MID;
+    return small_tiles ? UP2_SMALL : UP2_BIG;
+}
+
 static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
@@ -1620,40 +1660,24 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     p.tiles_x = w / 32; p.slices = (c_out + 31) / 32;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.out_f8 = out_fmt;
-    // the wide form (one wave per SIMD, 64 c_out per workgroup) for launches of at least three rounds of workgroups
-    static const int env_wide = getenv("NB_UP2_WIDE") ? atoi(getenv("NB_UP2_WIDE")) : -1;
-    const int force_wide = g_force_wide >= 0 ? g_force_wide : env_wide;
-    if (force_wide != 0 && g_force_tqh <= 0 && g_force_pair <= 0 && nb_up2w_eligible(in_fmt, c_in, c_out, h, w) &&
-        (force_wide > 0 || (NB_UP2W_AUTO && nb_up2w_workgroups(n, c_out, h, w) >= 768)))
-        return nb_up2w_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
-    if (w == 16) return nb_up2_h3_launch<8, 16>(p, n, in_fmt, stream);      // 16-wide inputs: 8 x 16 quad tiles
-    // tile height: the 12-row tiles unless they leave the chip mostly idle (batch-1 / interactive), then 5-row tiles
-    static const int env_tqh = getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0;
-    const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
-    const long wgs_big = (long)n * p.tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * p.slices;
-    const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
-    // 8-row tiles when the 12-row tiles' last round of workgroups would leave most of the chip idle.  Estimate = rounds of 256
-    // workgroups x cost of one (critical SIMD's position blocks 4 / 3, + prologue and epilogue ~ quads): b64.conv0 at batch 32
-    // (32 input rows) is 384 workgroups = 1.5 rounds of 12-row tiles, but 512 = 2 full rounds of 8-row tiles at 0.73 the cost.
-    bool mid_tiles = force_tqh == NB_H3_TQH_MID;
-    if (!force_tqh && !small_tiles) {
-        constexpr long ncu = 256;                     // MI355X (one workgroup of this kernel per CU)
-        const long wgs_mid = (long)n * p.tiles_x * ((h + NB_H3_TQH_MID - 1) / NB_H3_TQH_MID) * p.slices;
-        const double est_big = (double)((wgs_big + ncu - 1) / ncu) * 5.4, est_mid = (double)((wgs_mid + ncu - 1) / ncu) * 3.93;
-        mid_tiles = est_mid < 0.9 * est_big;
+    switch (nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)) {
+        case UP2_WIDE: return nb_up2w_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
+        case UP2_W16: return nb_up2_h3_launch<8, 16>(p, n, in_fmt, stream);
+        case UP2_PAIR: return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
+        case UP2_V2: return nb_up2v_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
+        case UP2_MID: return nb_up2_h3_launch<NB_H3_TQH_MID>(p, n, in_fmt, stream);
+        case UP2_SMALL: return nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream);
+        default: return nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
     }
-    // two 4-wave workgroups per CU on 12 x 16 tiles (see the kernel's NW_ / NST_) when that launch fills the chip as well
-    static const int env_pair = getenv("NB_UP2_PAIR") ? atoi(getenv("NB_UP2_PAIR")) : 0;
-    const bool pair = !in_fmt && (g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && !mid_tiles && wgs_big * 2 >= 1024));
-    if (pair) return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
-    // the 12-row throughput tiles of an f8 launch: the kernel with the software-pipelined K loop (same tile, same results)
-    static const int env_v2 = getenv("NB_UP2_V2") ? atoi(getenv("NB_UP2_V2")) : -1;
-    const int force_v2 = g_force_v2 >= 0 ? g_force_v2 : env_v2;
-    if (force_v2 != 0 && nb_up2v_eligible(in_fmt, c_in, h, w) &&
-        (force_v2 > 0 ? force_tqh == 0 || force_tqh == NB_H3_TQH : (NB_UP2V_AUTO && !mid_tiles && !small_tiles && (force_tqh == 0 || force_tqh == NB_H3_TQH))))
-        return nb_up2v_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
-    if (mid_tiles) return nb_up2_h3_launch<NB_H3_TQH_MID>(p, n, in_fmt, stream);
-    return small_tiles ? nb_up2_h3_launch<NB_H3_TQH_SMALL>(p, n, in_fmt, stream) : nb_up2_h3_launch<NB_H3_TQH>(p, n, in_fmt, stream);
+}
+
+extern "C" int nb_modconv3x3_up2_h3_variant(int in_fmt, int c_in, int c_out, int n, int h, int w, char* buf, int buflen) {
+    NB_REQUIRE(buf && buflen > 0, "modconv3x3_up2_h3_variant: bad buffer");
+    NB_REQUIRE((in_fmt == 0 || in_fmt == 1) && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16), "modconv3x3_up2_h3_variant: bad shape");
+    static const char* const names[] = {"modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel",
+                                        "modconv3x3_up2_h3_kernel", "modconv3x3_up2w_kernel", "modconv3x3_up2v_kernel"};
+    snprintf(buf, buflen, "%s", names[nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)]);
+    return NB_OK;
 }
 
 extern "C" int nb_modconv3x3_up2_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,

@@ -100,6 +100,37 @@ def preflight(dev: torch.device, rank: int, world: int) -> None:
         raise SystemExit(3)
 
 
+def fabric_report(dev: torch.device, rank: int, world: int, backend: str) -> Optional[dict]:
+    """Who is in the process group: every rank contributes (rank, host, pid, device index, PCI address / uuid of its device) through
+    an all-gather; rank 0 returns {"world", "backend", "nccl_version", "ranks_seen", "distinct_devices"} for the benchmark line
+    (None elsewhere, and at world 1 a one-entry report).  N ranks on fewer than N devices is an error unless the one-GPU test
+    hook ``NB_BENCH_SHARE_GPU=1`` is set -- RCCL itself refuses two ranks on one device, gloo would not notice."""
+    import socket
+    p = torch.cuda.get_device_properties(dev)
+    ident = getattr(p, "uuid", None)
+    pci = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    mine = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "device_index": dev.index, "pci": pci,
+            "uuid": str(ident) if ident is not None else None, "name": p.name}
+    seen = [mine]
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+    distinct = len({(s_["host"], s_["uuid"] or s_["pci"]) for s_ in seen})
+    if world > 1 and distinct < world and os.environ.get("NB_BENCH_SHARE_GPU") != "1":        # (every rank sees the same list)
+        raise SystemExit(f"[launch] {world} ranks on {distinct} distinct devices: {seen}")
+    if rank != 0:
+        return None
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                # noqa: BLE001
+            ver = None
+    return {"world": world, "backend": ("RCCL (torch backend nccl)" if backend == "nccl" else backend), "nccl_version": ver,
+            "ranks_seen": [{k: s_[k] for k in ("rank", "host", "device_index", "pci", "name")} for s_ in seen],
+            "distinct_devices": distinct}
+
+
 def finish(world: int) -> None:
     if world > 1 and dist.is_initialized():
         dist.barrier()

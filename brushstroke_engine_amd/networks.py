@@ -359,6 +359,11 @@ class SynthesisNetwork(torch.nn.Module):
         _lib.check(_lib.lib().nb_modconv3x3_variant(n, s.in_res, s.in_res, s.out_channels, s.up, buf, 128), "variant")
         return buf.value.decode()
 
+    def _up2_h3_variant_name(self, in_fmt: int, n: int, s: LayerSpec) -> str:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().nb_modconv3x3_up2_h3_variant(in_fmt, s.in_channels, s.out_channels, n, s.in_res, s.in_res, buf, 128), "variant")
+        return buf.value.decode()
+
     def _get_plan(self, n: int, device, slot: int = 0) -> _Plan:
         self._ensure_packed()
         plan = self._plans.get(slot)
@@ -702,7 +707,7 @@ class SynthesisNetwork(torch.nn.Module):
                         if fuse_rgb:
                             fused_rgb = self._torgb_finish(tg, extra)
                         self.layer_kernels[name] = ("modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
-                                                    if s.up == 1 else "modconv3x3_up2_h3_kernel")
+                                                    if s.up == 1 else self._up2_h3_variant_name(in_fmt, n, s))
                         keep_alive.append(x_h2)
                         self._end_event(ev)
                     elif self._small_h3_eligible(s) and c2 == 0 and x is not None:

@@ -26,6 +26,8 @@ tests inject an oracle-backed ``TileOps`` stand-in to check the host logic and t
 from __future__ import annotations
 
 import contextlib
+import os
+import time
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -358,6 +360,52 @@ class TileOps:
         return out
 
     n_streams = 2
+    # 0 = choose n_streams by a probe the first time a multi-batch canvas is painted (choose_streams); 1 / 2 / 3 = fixed.
+    # Alternating batches over HIP streams lets one batch's kernel tails and small launches run under the other's big ones, which
+    # is worth +5..10 % on most boxes -- and cost 14 % on the box of the round-3 driver run (three chains of 156 KB-LDS workgroups
+    # evicting each other at kernel boundaries), so the schedule measures instead of assuming.
+    stream_policy = int(os.environ.get("NB_CANVAS_STREAMS", "0"))
+    stream_probe = None          # what choose_streams measured: {"ms_per_batch": {1: .., 2: ..}, "chosen": n, "batch": n}
+
+    def choose_streams(self, n: int, render_mode: str = "clear") -> int:
+        """Pick the number of batch streams for batches of ``n`` tiles: the fixed policy, or -- once per TileOps and batch size --
+        whichever of 1 / 2 streams renders four synthetic batches faster (full generator passes with random styles and geometry
+        features, ~10 ms).  Sets ``n_streams``; the probe's figures stay in ``stream_probe`` (tools/bench_canvas.py reports them)."""
+        if self.stream_policy > 0:
+            self.n_streams = self.stream_policy
+            return self.n_streams
+        if self.stream_probe is not None and self.stream_probe.get("batch") == n:
+            return self.n_streams
+        cfg, dev = self.cfg, self.device
+        gen = torch.Generator(device="cpu").manual_seed(1234)
+        ws = torch.randn([n, cfg.num_ws, cfg.w_dim], generator=gen).to(dev)
+        geom = [torch.randn([n, c, r, r], generator=gen).to(dev) for c, r in zip(cfg.geom_feature_channels, cfg.geom_feature_resolutions)]
+        pos = torch.zeros([n, 2], dtype=torch.int64, device=dev)
+        times = {}
+        keep_streams, keep_forked = self._streams, self._forked
+        for k in (1, 2):
+            self.n_streams, self._streams, self._forked = k, None, set()
+            slots = sorted({PAINT_SLOT0 + i % k for i in range(k)})
+            self.prepare(n, slots)
+
+            def run(batches):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                outs = []
+                for b in range(batches):
+                    with self.stream(b):
+                        outs.append(self.full(ws, geom, pos, render_mode, None, None, slot=PAINT_SLOT0 + b % k))
+                self.join_streams(outs)
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) / batches * 1e3
+            run(2 * k)                                   # workspaces, code objects, clocks
+            times[k] = min(run(4), run(4))
+        best = min(times, key=times.get)
+        if times[2] > 0.97 * times[1]:                   # a second stream has to earn its workspace: < 3 % is noise
+            best = 1
+        self.n_streams, self._streams, self._forked = best, (keep_streams if keep_streams is not None and len(keep_streams) == best else None), keep_forked if keep_streams is not None and len(keep_streams) == best else set()
+        self.stream_probe = {"ms_per_batch": {str(k): round(v, 4) for k, v in times.items()}, "chosen": best, "batch": n}
+        return best
 
     def stream(self, k: int):
         """Context manager: work of batch k goes to side stream k % n_streams (which first waits for the caller's)."""
@@ -638,6 +686,8 @@ class PaintingHelper:
         join = getattr(ops, "join_streams", lambda tensors=(): None)
         # workspace slots of the painting schedule: disjoint from the generator's own sub-batch slots (1..sub_streams), whose
         # side-stream kernels of an un-joined throughput call may still be reading theirs
+        if n_own > self.batch and hasattr(ops, "choose_streams"):
+            ops.choose_streams(min(self.batch, n_own), self.render_mode)        # 1 or 2 batch streams: measured, once
         plan_slot = lambda k: PAINT_SLOT0 + k % getattr(ops, "n_streams", 1)
         if n_own <= self.batch:                      # a single batch (interactive strokes): nothing to overlap with
             on_stream, join, plan_slot = (lambda k: contextlib.nullcontext()), (lambda tensors=(): None), (lambda k: 0)
@@ -700,8 +750,13 @@ class PaintingHelper:
                 exchange()                                                        # (a rank without tiles still takes part)
             join()
             if work is not None:
+                # (events on the caller's stream: the first fires when phase 1 is through, the second when the strips are there
+                #  -- what of the exchange was NOT hidden under phase 1; comm_times())
+                ev = self._comm_event_pair("halo_exchange_exposed_ms")
                 work.wait()
                 getattr(ops, "join_comm", lambda tensors=(): None)([recv_buf])
+                if ev is not None:
+                    ev[1].record()
             # phase 2: the sequential canvas blend of my tiles, replayed in one launch
             if world == 1:
                 off, lst = build_cells(rects, hc, wc)
@@ -750,10 +805,38 @@ class PaintingHelper:
         if n_own:
             buf[:n_own] = rgba_own
         recv = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        ev = self._comm_event_pair("tile_gather_ms")
         dist.gather(buf, recv, dst=0, group=self.group)
+        if ev is not None:
+            ev[1].record()
         if rank != 0:
             return None
         return torch.cat([recv[r][:counts[r]] for r in range(world)])
+
+    def _comm_event_pair(self, name: str):
+        """A pair of HIP events around a collective of the sharded schedule (first one recorded here, on the caller's stream)."""
+        dev = getattr(self.ops, "device", None)
+        if dev is None or getattr(dev, "type", "cpu") != "cuda":
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if not hasattr(self, "_comm_events"):
+            self._comm_events = {}
+        self._comm_events.setdefault(name, []).append((e0, e1))
+        return e0, e1
+
+    def comm_times(self, reset: bool = True) -> Dict[str, float]:
+        """Milliseconds this rank's stream spent on the collectives of the sharded calls since the last reset: the part of the
+        halo exchange that phase 1 did not hide, and the gather of the RGBA tiles on rank 0 (synchronises the device)."""
+        evs = getattr(self, "_comm_events", {})
+        if not evs:
+            return {}
+        torch.cuda.synchronize(self.ops.device)
+        out = {k: round(sum(a.elapsed_time(b) for a, b in v), 4) for k, v in evs.items()}
+        out["calls"] = max(len(v) for v in evs.values())
+        if reset:
+            self._comm_events = {}
+        return out
 
     def render_tiles(self, geom_padded: np.ndarray, crops: Sequence[Tuple[int, int]], opts: GanBrushOptions,
                      crop_margin: int = 0, out_canvas: Optional[torch.Tensor] = None):

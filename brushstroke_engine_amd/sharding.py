@@ -103,6 +103,23 @@ class TileGatherer:
             self.recv = [torch.empty(list(shape), dtype=dtype, device=device) for _ in range(self.world)]
         self._work = None
         self._local = None
+        # how long finish() kept its caller waiting: host wall clock (a gloo wait blocks the host) and, on a GPU, HIP events on
+        # the caller's stream around the wait (an RCCL wait blocks the STREAM, not the host) -- from which a reader of the
+        # benchmark line can judge whether the gather was hidden under the next batch
+        self.wait_host_ms = 0.0
+        self._wait_events = []
+        self._cuda = torch.device(device).type == "cuda"
+
+    def wait_ms(self, reset: bool = True) -> dict:
+        """{"host_ms", "stream_ms", "waits"} accumulated by finish() (synchronises the device when events are pending)."""
+        stream_ms = None
+        if self._wait_events:
+            torch.cuda.synchronize()
+            stream_ms = round(sum(a.elapsed_time(b) for a, b in self._wait_events), 4)
+        out = {"host_ms": round(self.wait_host_ms, 4), "stream_ms": stream_ms, "waits": len(self._wait_events)}
+        if reset:
+            self.wait_host_ms, self._wait_events = 0.0, []
+        return out
 
     def start(self, tiles: torch.Tensor) -> None:
         self._local = tiles
@@ -115,7 +132,17 @@ class TileGatherer:
         if self.world == 1:
             return [self._local]
         if self._work is not None:
+            import time as _time
+            ev = None
+            if self._cuda and not torch.cuda.is_current_stream_capturing():
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            t0 = _time.perf_counter()
             self._work.wait()
+            self.wait_host_ms += (_time.perf_counter() - t0) * 1e3
+            if ev is not None:
+                ev[1].record()
+                self._wait_events.append(ev)
             self._work = None
         return self.recv if self.rank == self.dst else None
 

@@ -338,6 +338,11 @@ int nb_modconv3x3_up2_h3_ex(const void* x, int c_in, const void* wts, const floa
                             int next_stride, int c_next, int in_fmt, int out_fmt, int n, int h, int w, int c_out,
                             float alpha, float gain, float clamp, void* stream);
 
+/* Name of the kernel nb_modconv3x3_up2_h3 / _ex launches for this problem shape (the name rocprofv3 reports: the round-3 8-wave
+ * kernel in one of its tile forms, the software-pipelined 8-wave kernel of csrc/nb_modconv_up2v.hip, or the one-wave-per-SIMD form
+ * of csrc/nb_modconv_up2w.hip), so that a benchmark can attribute its per-launch timings to kernels.  in_fmt as in _ex. */
+int nb_modconv3x3_up2_h3_variant(int in_fmt, int c_in, int c_out, int n, int h, int w, char* buf, int buflen);
+
 /* The same layer for SMALL images (csrc/nb_modconv_small.hip; the <= 64x64 conv1 layers): split-f16 products on
  * 32 c_out x 32 position tiles with K split over the 4 waves of a workgroup, fp32 NCHW in and out, the per-sample styles
  * applied to the activations while they are split into hi/lo f16 on their way into LDS.  Replaces nb_modconv3x3_f32
@@ -485,6 +490,14 @@ int nb_enc_upsample2x_h2_ex(const float* x, void* y_h2, int out_fmt, int n, int 
 /* Host-side helper (no GPU): repack W[c_out,c_in,3,3] into the zero-padded
  * wpk[ceil8(c_in)][9][ceil32(c_out)] and wsq[c_in][c_out] = sum_k W^2.  Either output may be NULL. */
 int nb_pack_conv_weight(const float* w, int c_out, int c_in, float* wpk, float* wsq);
+
+/* ---- box calibration (csrc/nb_calib.hip; measurement infrastructure, not on the generator's path) -----------------
+ * A registers-only loop of back-to-back v_mfma_f32_32x32x16_f16 on random operands, one wave per SIMD on every CU of the current
+ * device, for about target_ms (blocking).  *tflops = the dense f16 matrix rate this device sustains, *ms = duration of the measured
+ * launch, *clock_mhz = median in-kernel shader clock during it (may be NULL).  MI355X boards differ by several percent in the
+ * clock they hold under matrix load; bench.py reports the figure beside its own (box_calibration, roofline.frac_of_sustained).
+ * The reference has no counterpart (forger/util/timer.py:11-32 is its only timer). */
+int nb_calibrate_mfma_f16(double target_ms, double* tflops, double* ms, double* clock_mhz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,13 @@ def test_bench_self_spawns_two_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert "gather of RGBA tiles to rank 0" in out["config"]["parallelism"]
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    # the N > 1 line says who took part and what the gather cost: both ranks seen (one device here: the share-GPU hook), every
+    # rank's own step time, and how long rank 0 waited for the tiles
+    assert out["rccl"]["world"] == 2 and out["rccl"]["backend"] == "gloo" and [r_["rank"] for r_ in out["rccl"]["ranks_seen"]] == [0, 1]
+    assert out["rccl"]["distinct_devices"] == 1
+    assert len(out["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in out["ms_per_step_per_rank"])
+    assert out["gather_wait_ms"]["waits"] >= 3 and out["gather_wait_ms"]["host_ms_per_step"] >= 0
+    assert out["box_calibration"]["mfma_f16_sustained_tflops"] > 100
 
 
 def test_bench_line_carries_every_arithmetic_mode():
@@ -50,6 +57,13 @@ def test_bench_line_carries_every_arithmetic_mode():
         assert rec["roofline"]["peak"] == (157.3 if m == "f32" else 2500.0)
         assert rec["parity"]["max_abs_rgba_vs_oracle"] <= tol[m], (m, rec["parity"])
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+    # the box is in the line: what it sustains on a registers-only f16 MFMA loop, and (where the hwmon files are readable) power
+    # and shader clock during each mode's timed region
+    assert 500 < out["box_calibration"]["mfma_f16_sustained_tflops"] < 2600 and out["box_calibration"]["loop_clock_mhz"] > 500
+    for m, rec in out["modes"].items():
+        assert "telemetry" in rec and "power_w_mean" in rec["telemetry"] and "sclk_mhz_mean" in rec["telemetry"]
+        if m != "f32":
+            assert 0 < rec["roofline"]["frac_of_sustained"] < 1
 
 
 def test_bench_fails_nonzero_when_a_rank_dies():

@@ -64,6 +64,9 @@ def parser():
     ap.add_argument("--lamali", action="store_true", help="paint lamali_sm.png (tests/golden/engine_lamali_r256.npz, R=256) instead of the "
                                                             "synthetic drawing and report the distance to the reference-painted canvas")
     ap.add_argument("--encoder", default="hip", choices=["hip"])
+    ap.add_argument("--streams", default="auto", choices=["auto", "1", "2", "3", "ab"],
+                    help="batch streams of the tiled schedule: auto = TileOps.choose_streams' probe (the default of the library), "
+                         "1 / 2 / 3 = fixed, ab = time the job with 1, with 2 and with the probe's choice on this box and report all")
     return ap
 
 
@@ -73,8 +76,23 @@ def main():
         raise SystemExit(launch.self_launch(__file__, sys.argv[1:], a.gpus))
     rank, world, dev, backend = launch.init()
     launch.preflight(dev, rank, world)
-    line = run(a, rank, world, dev, backend)
+    fabric = launch.fabric_report(dev, rank, world, backend)
+    if a.streams == "ab":
+        # the same job with one batch stream, with two, and with what the probe picks -- one box, one process, back to back
+        ab = {}
+        for pol in ("1", "2", "auto"):
+            a.streams = pol
+            l_ = run(a, rank, world, dev, backend)
+            if rank == 0:
+                ab[pol] = {"seconds": l_["seconds"], "tiles_per_s": l_["value"], "stream_probe": l_.get("stream_probe"), "n_streams": l_.get("n_streams")}
+        line = l_
+        if rank == 0:
+            line["stream_ab"] = ab
+    else:
+        line = run(a, rank, world, dev, backend)
     if rank == 0:
+        if world > 1:
+            line["rccl"] = fabric
         print(json.dumps(line), flush=True)
     launch.finish(world)
 
@@ -92,6 +110,7 @@ def run(a, rank, world, dev, backend):
     G = Generator(cfg, wmod.random_state_dict(cfg, seed=int(gold["weights_seed"]) if gold else 0), conv_mode=a.conv_mode).to(dev)
     enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(int(gold["encoder_seed"]) if gold else 5), device=dev)
     ops = painting.TileOps(G, enc)
+    ops.stream_policy = 0 if a.streams == "auto" else int(a.streams)
     helper = painting.PaintingHelper(ops, batch=a.batch)
     helper.set_feature_blending(a.level)
     opts = painting.GanBrushOptions()
@@ -118,11 +137,15 @@ def run(a, rank, world, dev, backend):
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         if i >= a.warmup:
             times.append(float(dt))
-        elif a.breakdown:
-            _TIMES.clear()
+        else:
+            helper.comm_times()                          # (reset: collectives of the timed steps only)
+            if a.breakdown:
+                _TIMES.clear()
     # per-rank figures: halo bytes of the exchange, per-phase device time
     torch.cuda.synchronize()
-    mine = {"rank": rank, "halo_bytes": helper.halo_bytes,
+    comm = helper.comm_times() if world > 1 else {}
+    mine = {"rank": rank, "halo_bytes": helper.halo_bytes, "seconds": float(np.mean(times)) if times else None,
+            "comm_ms_per_step": {k: round(v / max(1, a.steps), 4) for k, v in comm.items() if k != "calls"},
             "breakdown_ms": {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / a.steps, 3) for k, v in _TIMES.items()} if _TIMES else None}
     per_rank = [mine]
     if world > 1:
@@ -141,8 +164,14 @@ def run(a, rank, world, dev, backend):
                                f"tiles in {world} contiguous ranges; halo strips by one all_to_all_single ({'RCCL' if backend == 'nccl' else backend}) "
                                f"under phase 1, RGBA tiles gathered on rank 0",
                 "timing": "max over ranks of the wall clock between barriers, mean over steps"}
+        line["n_streams"] = getattr(ops, "n_streams", None)
+        line["stream_probe"] = getattr(ops, "stream_probe", None)
         if world > 1:
             line["halo_bytes_per_rank"] = [p["halo_bytes"] for p in per_rank]
+            # what the collectives cost each rank's stream per painted canvas: the part of the halo exchange phase 1 did not
+            # hide, and the gather of the RGBA tiles (rank 0 waits for everybody's); HIP events around the waits
+            line["halo_exchange_ms"] = [p["comm_ms_per_step"].get("halo_exchange_exposed_ms") for p in per_rank]
+            line["gather_wait_ms"] = [p["comm_ms_per_step"].get("tile_gather_ms") for p in per_rank]
         if a.breakdown:
             line["breakdown_ms" if world == 1 else "breakdown_ms_per_rank"] = per_rank[0]["breakdown_ms"] if world == 1 else [p["breakdown_ms"] for p in per_rank]
         if gold is not None and a.level in (0, 2) and f"canvas_level{a.level}_clear" in gold and full is not None:
