@@ -140,9 +140,9 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     // ---- prologue: chunks 0 and 1, and the two pieces of chunk 2 that the steady state issues under the previous chunk's last
     //      group; the tile's noise values are computed / fetched while they are on their way ----
     const int NC = p.nchunks;
+    // (chunk 0 goes out alone and FIRST: a CU's LDS-DMA fill rate is ~25-35 GB/s, and pieces in flight together share it -- with
+    //  chunks 1 and 2 issued in the same breath the first MFMA waited 1.5 us longer for chunk 0)
     nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 0, 0); });
-    if (NC > 1) nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 1, STAGE); });
-    if (NC > 2) nb_static_for<0, N4>([&](auto k) { issue_piece(k, 2, 2 * STAGE); });
     for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
         const int r = e / (2 * TQW), c = e - r * (2 * TQW);
         const int oy = 2 * I0 + r, ox = 2 * J0 + c;
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         }
         s_noise[e] = v * p.gain;
     }
+    if (NC > 1) nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 1, STAGE); });
+    if (NC > 2) nb_static_for<0, N4>([&](auto k) { issue_piece(k, 2, 2 * STAGE); });
     if (NC > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + N4) : "memory");
     else if (NC > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

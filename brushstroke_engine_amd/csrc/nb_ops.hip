@@ -316,7 +316,9 @@ extern "C" int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int ma
     hipStream_t st = (hipStream_t)stream;
     static const bool generic_only = getenv("NB_UPFIRDN_GENERIC") != nullptr;      // developer switch: the run-time-everything kernel
     const long long plane = (long long)p.out_h * p.out_w, in_plane = (long long)in_h * in_w;
-    const int key = generic_only || plane >= (1LL << 30) || in_plane >= (1LL << 30) ? -1 : ((upx * 4 + upy) * 4 + downx) * 4 + downy;
+    // (factors of 4 and more would alias the 2-bit fields of the key -- down = (1, 5) reads as <1, 1, 2, 1> -- : generic kernel)
+    const bool small_factors = upx <= 3 && upy <= 3 && downx <= 3 && downy <= 3;
+    const int key = generic_only || !small_factors || plane >= (1LL << 30) || in_plane >= (1LL << 30) ? -1 : ((upx * 4 + upy) * 4 + downx) * 4 + downy;
     const bool f44 = f_h == 4 && f_w == 4, f11 = f_h == 1 && f_w == 1;
     bool done = true;
     switch (key) {

@@ -885,6 +885,19 @@ class _SplitForward:
         return cat(list(parts))
 
 
+def mix_styles(mapping, ws, z, c, style_mixing_prob, **mapping_kwargs):
+    """Style mixing regularisation (networks_modified.py:385-394): with probability ``style_mixing_prob`` the W+ rows from a random
+    cutoff onwards come from a second latent.  Shared by the inference ``Generator`` and ``training.TrainableGenerator``."""
+    cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
+    cutoff = torch.where(torch.rand([], device=ws.device) < style_mixing_prob, cutoff, torch.full_like(cutoff, ws.shape[1]))
+    try:
+        ws2 = mapping(torch.randn_like(z), c, skip_w_avg_update=True, **mapping_kwargs)
+    except TypeError:                                  # (the inference mapping network has no moving average to skip)
+        ws2 = mapping(torch.randn_like(z), c, **mapping_kwargs)
+    sel = (torch.arange(ws.shape[1], device=ws.device) >= cutoff)[None, :, None]
+    return torch.where(sel, ws2.to(ws.dtype), ws)
+
+
 class Generator(torch.nn.Module):
     """``networks_modified.py:227-400``."""
 
@@ -1027,7 +1040,7 @@ class Generator(torch.nn.Module):
                 **synthesis_kwargs):
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
         if style_mixing_prob > 0:
-            raise RuntimeError("style mixing is a training-time feature (networks_modified.py:385-394); not in this build")
+            ws = mix_styles(self.mapping, ws, z, c, style_mixing_prob, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
         return self.forward_pre_mapped(ws, geom_feature, positions=positions, return_debug_data=return_debug_data,
                                        return_features=return_features, blended_features=blended_features,
                                        noise_buffers=noise_buffers, **synthesis_kwargs)

@@ -24,7 +24,8 @@ PIPE_SLOT0 = 24          # workspace slots of the pipeline (generator sub-batche
 
 class TriadStepPipeline:
     """``submit(z, geom_feature, positions)`` enqueues one batch and returns its uint8 RGBA tiles ``[N, R, R, 4]`` -- valid
-    on ``tail_stream`` (make a consumer stream wait with ``wait()`` / ``flush()``, or synchronise the device).  Up to
+    on ``tail_stream`` (make a consumer stream wait with ``wait()`` / ``flush()``, which also record the tiles on that stream, or
+    synchronise the device).  Up to
     ``depth`` batches are in flight: the tail of batch k and the head of batch k+1."""
 
     def __init__(self, G, split_res: int = 16, depth: int = 2, render_mode: str = "clear"):
@@ -40,6 +41,7 @@ class TriadStepPipeline:
         self._k = 0
         self._pending = None          # (slot, ws, x, geom, positions, user_colors, sfactor, head event)
         self._forked = False
+        self._outputs: List[torch.Tensor] = []     # tiles handed out since the last wait(): allocated on the tail stream, read elsewhere
 
     # -- the two halves of one batch --
     def _head(self, slot, z, geom, positions):
@@ -77,9 +79,16 @@ class TriadStepPipeline:
         geom = list(geom_feature)
         n = z.shape[0]
         if not self._eligible(n):
+            # unsplit pass on the tail stream, in workspace slot 0 of the pipeline: like a tail it may start only once the slot's
+            # previous tail is through (stream order) AND it must keep the next HEAD of that slot -- which rewrites the slot's
+            # styles on the head stream -- waiting until it has finished (mixed batch sizes: eligible and ineligible submits)
             with torch.cuda.stream(self.tail_stream):
                 u8, _, _ = self.G.render_triad(z=z, geom_feature=geom, positions=positions, render_mode=self.render_mode,
                                                user_colors=user_colors, sfactor=sfactor, _plan_slot=PIPE_SLOT0)
+                done = torch.cuda.Event()
+                done.record(self.tail_stream)
+            self._tail_done[0] = done
+            self._outputs.append(u8)
             return u8
         slot = self._k % self.depth
         self._k += 1
@@ -99,13 +108,20 @@ class TriadStepPipeline:
             done = torch.cuda.Event()
             done.record(self.tail_stream)
         self._tail_done[slot] = done
+        self._outputs.append(u8)
         return u8
 
     def wait(self, stream=None) -> None:
-        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far."""
+        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far.  The tiles returned by
+        ``submit`` since the last call were allocated on the tail stream; they are recorded on ``stream`` here, so that the
+        caching allocator does not hand their memory to a later step while a read or copy enqueued on ``stream`` is pending
+        (a consumer on yet another stream calls ``tile.record_stream(that_stream)`` itself)."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         stream.wait_stream(self.tail_stream)
         stream.wait_stream(self.head_stream)
+        for t in self._outputs:
+            t.record_stream(stream)
+        self._outputs = []
 
     def flush(self) -> None:
         self.wait()
@@ -141,6 +157,7 @@ class TriadPrefetchPipeline:
         self._mark_prev: Optional[torch.cuda.Event] = None                          # previous step reached its marked layer
         self._k = 0
         self._forked = False
+        self._outputs: List[torch.Tensor] = []     # tiles handed out since the last wait() (see TriadStepPipeline.wait)
 
     def submit(self, z, geom_feature, positions, user_colors=None, sfactor=None) -> torch.Tensor:
         if positions is None:
@@ -178,13 +195,18 @@ class TriadPrefetchPipeline:
             done.record(self.main_stream)
         self._main_done[slot] = done
         self._mark_prev = mark
+        self._outputs.append(u8)
         return u8
 
     def wait(self, stream=None) -> None:
-        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far."""
+        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far; the tiles handed out
+        since the last call are recorded on it (see TriadStepPipeline.wait)."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         stream.wait_stream(self.main_stream)
         stream.wait_stream(self.prep_stream)
+        for t in self._outputs:
+            t.record_stream(stream)
+        self._outputs = []
 
     def flush(self) -> None:
         self.wait()

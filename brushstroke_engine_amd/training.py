@@ -15,6 +15,8 @@ This is the first, unfused training-mode path: correct gradients, not a tuned st
 """
 from __future__ import annotations
 
+import collections.abc
+
 import math
 from typing import Dict, List, Optional
 
@@ -158,12 +160,8 @@ class TrainableGenerator(torch.nn.Module):
                 truncation_psi=1, truncation_cutoff=None, style_mixing_prob=0):
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
         if style_mixing_prob > 0:                                          # networks_modified.py:385-394
-            cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
-            cutoff = torch.where(torch.rand([], device=ws.device) < style_mixing_prob, cutoff, torch.full_like(cutoff, ws.shape[1]))
-            ws2 = self.mapping(torch.randn_like(z), c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff,
-                               skip_w_avg_update=True)
-            sel = (torch.arange(ws.shape[1], device=ws.device) >= cutoff)[None, :, None]
-            ws = torch.where(sel, ws2, ws)
+            from .networks import mix_styles
+            ws = mix_styles(self.mapping, ws, z, c, style_mixing_prob, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
         norm_pos = None
         if positions is not None:                                          # networks_modified.py:351-353
             norm_pos = (positions % self.img_resolution).to(torch.float32) / (self.img_resolution - 1)
@@ -296,33 +294,55 @@ def random_discriminator_state_dict(img_resolution: int, img_channels: int, chan
     return sd
 
 
-class LazyStats(dict):
+class LazyStats(collections.abc.Mapping):
     """Loss statistics of a phase.  Values are kept as detached 0-dim DEVICE tensors and become python floats only when they are
     read -- the reference's ``training_stats.report`` likewise accumulates on the device (torch_utils/training_stats.py:86-101);
     reading a loss value between the forward and the backward pass would stall the host until the device has caught up and
-    leave the device idle while the backward pass is being issued."""
+    leave the device idle while the backward pass is being issued.
+
+    A read-only ``Mapping`` over a private dict (NOT a ``dict`` subclass: CPython's fast paths -- ``dict(stats)``, ``{**stats}``,
+    ``plain.update(stats)``, ``json.dumps`` -- bypass overridden accessors of a dict subclass and would hand out the raw device
+    tensors).  Every access path of the Mapping protocol goes through ``__getitem__`` and yields floats; ``resolve()`` converts
+    all values with ONE device-to-host transfer and is what a stats writer should call."""
+
+    def __init__(self, init=()):
+        self._d = {}
+        self.update(init)
 
     @staticmethod
     def _f(v):
         return float(v) if torch.is_tensor(v) else v
 
     def __getitem__(self, k):
-        return self._f(dict.__getitem__(self, k))
+        return self._f(self._d[k])
 
-    def get(self, k, default=None):
-        return self[k] if k in self else default
+    def __iter__(self):
+        return iter(self._d)
 
-    def values(self):
-        return [self._f(v) for v in dict.values(self)]
+    def __len__(self):
+        return len(self._d)
 
-    def items(self):
-        return [(k, self._f(v)) for k, v in dict.items(self)]
+    def __setitem__(self, k, v):
+        self._d[k] = v
 
     def update(self, other=(), **kw):
-        for k, v in (dict.items(other) if isinstance(other, dict) else other):
-            dict.__setitem__(self, k, v)
-        for k, v in kw.items():
-            dict.__setitem__(self, k, v)
+        if isinstance(other, LazyStats):
+            self._d.update(other._d)
+        else:
+            self._d.update(dict(other))
+        self._d.update(kw)
+
+    def resolve(self) -> Dict[str, float]:
+        """All values as python floats: the device tensors are stacked and fetched in one transfer."""
+        keys = [k for k, v in self._d.items() if torch.is_tensor(v)]
+        out = {k: v for k, v in self._d.items() if not torch.is_tensor(v)}
+        if keys:
+            vals = torch.stack([self._d[k].reshape(()).to(torch.float32) for k in keys]).tolist()
+            out.update(zip(keys, vals))
+        return {k: out[k] for k in self._d}
+
+    def __repr__(self):
+        return f"LazyStats({self.resolve()!r})"
 
 
 class GanLoss:
@@ -491,7 +511,9 @@ class GanLoss:
                 loss = loss + extra
                 stats.update({f"Loss/forger/Gmain/{k}": v.detach() for k, v in vals.items()})
             loss.mean().mul(gain).backward()
-        if phase == "Dmain" and self.merge_d_passes:
+        # (the stacked pass splits the batch in HALVES for the minibatch-stddev statistics: only with as many real as generated
+        #  images are those the two passes' groups -- otherwise the two-pass branch below)
+        if phase == "Dmain" and self.merge_d_passes and real_img.shape[0] == gen_z.shape[0]:
             # Generated and real images through the discriminator as ONE stacked batch (the reference runs two passes,
             # loss_modified.py:223-238; gradients accumulate linearly, the augmentation draws its parameters per sample and the
             # minibatch-stddev statistics are taken per half, so the result is the same -- at half the launches)

@@ -138,3 +138,15 @@ def test_no_packed_f32_high_dword_broadcast(library):
     assert dis.count("v_mfma_") > 100                             # (it is the real disassembly)
     bad = [ln.strip() for ln in dis.splitlines() if re.search(r"v_pk_(add|mul|fma)_f32 .*op_sel:\[0,1\](?! op_sel_hi)", ln)]
     assert not bad, bad[:5]
+    # ... and, more generally, no packed fp32 instruction that SWIZZLES register halves: the only operand forms the kernels are
+    # written to use are the plain one (no op_sel) and the low-dword broadcast `op_sel_hi:[..]` with zeros (a scalar against a
+    # pair).  Forms such as `op_sel:[0,1] op_sel_hi:[1,0]` / `op_sel:[1,0] op_sel_hi:[0,1]` come from the SLP vectoriser pairing
+    # scalar arithmetic and returned wrong halves sporadically on MI355X (csrc/nb_common.h, NB_NO_PACKED_F32).
+    def swizzled(ln):
+        m = re.search(r"v_pk_(?:add|mul|fma)_f32 (.*)", ln)
+        if not m:
+            return False
+        sel = re.search(r"op_sel:\[([01,]+)\]", ln)
+        return bool(sel and "1" in sel.group(1))          # any op_sel bit set = a low result lane reads a HIGH dword
+    bad = [ln.strip() for ln in dis.splitlines() if swizzled(ln)]
+    assert not bad, bad[:5]

@@ -70,3 +70,23 @@ def test_stitcher_matches_reference(g):
     random.seed(5)
     crops = [st.gen_overlapping_square_crop(100, (30, 40, r, r)) for _ in range(8)]
     np.testing.assert_array_equal(np.array(crops), g["st_gen_crops"])
+
+
+def test_lazy_stats_is_a_mapping_of_floats():
+    """LazyStats keeps device tensors until read, and every way of copying it out -- dict(), {**}, update(), json -- yields floats."""
+    import json
+    import torch
+    from brushstroke_engine_amd.training import LazyStats
+    st = LazyStats({"a": torch.tensor(1.5), "b": 2.0})
+    st["c"] = torch.tensor(3)
+    st.update({"d": torch.tensor(0.25)}, e=torch.tensor(4.0))
+    plain = {}
+    plain.update(st)
+    for d in (dict(st), {**st}, plain, st.resolve(), dict(st.items())):
+        assert d == {"a": 1.5, "b": 2.0, "c": 3.0, "d": 0.25, "e": 4.0}
+        assert all(isinstance(v, float) for v in d.values())
+        assert json.loads(json.dumps(d)) == d
+    assert st.get("zz", 7) == 7 and len(st) == 5 and list(st) == ["a", "b", "c", "d", "e"]
+    merged = LazyStats(st)
+    merged.update(LazyStats({"a": torch.tensor(9.0)}))
+    assert merged["a"] == 9.0 and st["a"] == 1.5

@@ -400,7 +400,7 @@ def test_trained_like_fixture(dev, mode):
     assert err(dbg["colors"], g["colors"]) <= 1e-5
     assert e_uvs <= PIX[mode] and e_img <= PIX[mode], (mode, e_uvs, e_img)
     assert e_ft <= {"f32": 2e-5, "h3": 2e-5, "f8": 1e-3}[mode], (mode, e_ft)
-    assert e_lg <= {"f32": 5e-4, "h3": 5e-4, "f8": 2e-2}[mode], (mode, e_lg)
+    assert e_lg <= {"f32": 5e-4, "h3": 5e-4, "f8": 3e-3}[mode], (mode, e_lg)          # f8 observed 9.3e-4: ~3x margin
 
 
 @pytest.mark.parametrize("mode", ["h3", "f8"])
@@ -456,3 +456,24 @@ def test_two_sub_batch_chains_equal_one_chain(dev, mode):
     assert G.sub_stream_min_batch == 64
     assert torch.equal(two_a, two_b)
     assert err(two_a, one) <= {"f32": 2e-5, "h3": 2e-5, "f8": 3e-4}[mode]
+
+
+def test_generator_forward_style_mixing(dev):
+    """``Generator.forward(style_mixing_prob > 0)`` mixes the W+ rows of a second latent in from a random cutoff
+    (networks_modified.py:385-394) -- the same helper the trainable generator uses: with the RNG re-seeded, the call equals
+    ``forward_pre_mapped`` on the mixed W+, and differs from the unmixed image."""
+    from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+    from brushstroke_engine_amd.networks import Generator, mix_styles
+    cfg = cfgmod.tiny_config(32)
+    G = Generator(cfg, wmod.random_state_dict(cfg, seed=2)).to(dev)
+    z = torch.from_numpy(synthetic.batch_z(cfg, 3, 5)).to(dev)
+    geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, 3, seed=1)]
+    torch.manual_seed(11)
+    img = G(z, None, geom, style_mixing_prob=1.0, noise_mode="const")
+    torch.manual_seed(11)
+    ws = G.mapping(z, None)
+    ws_mixed = mix_styles(G.mapping, ws, z, None, 1.0)
+    assert not torch.equal(ws_mixed, ws) and torch.equal(ws_mixed[:, 0], ws[:, 0])       # cutoff >= 1: the first row is never replaced
+    want = G.forward_pre_mapped(ws_mixed, geom, noise_mode="const")
+    assert torch.equal(img, want)
+    assert not torch.equal(img, G(z, None, geom, noise_mode="const"))

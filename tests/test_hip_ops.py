@@ -64,7 +64,10 @@ def test_upfirdn2d_configurations_vs_oracle(dev):
              (f44, 1, 2, [1, 1, 1, 1], False, 1.0), (f44, 1, 2, [2, 2, 2, 2], True, 1.0), (None, 2, 1, [0, -1, 0, -1], False, 1.0),
              (f12, 2, 1, [6, 5, 6, 5], False, 4.0), (f12, 1, 2, [3, 3, 3, 3], True, 1.0), (f35, 1, 1, [2, 1, 0, 3], False, 1.5),
              (f35, 2, 1, [-1, 2, 1, 0], True, 1.0), (f35, 1, 2, [1, 1, 1, 1], False, 1.0), (f35, 3, 2, [2, 2, 2, 2], False, 1.0),
-             (f44, (2, 1), 1, [2, 1, 1, 1], False, 2.0), (f44, 1, (1, 2), [1, 1, 1, 1], False, 1.0)]
+             (f44, (2, 1), 1, [2, 1, 1, 1], False, 2.0), (f44, 1, (1, 2), [1, 1, 1, 1], False, 1.0),
+             # factors >= 4 (they would alias the 2-bit fields of the specialised kernels' dispatch key: down = (1, 5) read as <1,1,2,1>)
+             (f44, 1, (1, 5), [2, 2, 2, 2], False, 1.0), (f44, 1, (5, 1), [2, 2, 2, 2], False, 1.0), (f44, 4, 1, [3, 3, 3, 3], False, 16.0),
+             (f35, (2, 1), (5, 1), [2, 2, 2, 2], True, 1.0)]
     for shape in ((2, 3, 9, 13), (1, 5, 33, 17)):
         x = rs.randn(*shape).astype(np.float32)
         for f, up, down, pad, flip, gain in cases:

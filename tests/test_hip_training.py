@@ -294,6 +294,8 @@ def test_config5_full_size_iteration():
             assert finite(G)
             optG.step()
         assert stats and all(np.isfinite(float(v)) for v in stats.values()), stats
+        import json
+        assert all(isinstance(v, float) for v in stats.values()) and json.loads(json.dumps(stats)).keys() == stats.keys()      # (merged through dict.update: floats, no device tensors)
         if it == 0:
             assert {"Loss/G/loss", "Loss/pl_penalty", "Loss/r1_penalty"} <= set(stats), sorted(stats)
     moved = [k for k, p in list(G.named_parameters()) + list(D.named_parameters()) if p.requires_grad and not torch.equal(p, before[k])]
