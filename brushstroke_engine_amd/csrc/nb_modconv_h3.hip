@@ -172,8 +172,12 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
 
 // NBW_ = 32-pixel rows per wave: 2 for throughput, 1 (half the pixels per workgroup, twice the workgroups) when the
 // launch would otherwise leave most of the chip idle - the batch-1 / interactive configuration.
-template <int MW, bool F8 = false, int NBW_ = 2>
+// V2 (f8 operands only): the K loop in the form of modconv3x3_up2v_kernel (nb_modconv_up2v.hip) -- LDS-DMA from inline assembly
+// (counted lgkmcnt waits), the step's barrier in front of its last two MFMA groups with the next step's first operands read under
+// them, fragment reads and DMA pieces dealt out between the MFMAs.  Same per-accumulator order of products: bit-identical.
+template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
+    static_assert(!V2 || F8, "the software-pipelined K loop exists for f8 operands");
     NB_TSTAMP(0);
     if (p.out_f8) nb_set_fp16_ovfl();             // f8 hand-off: the fp8 (and f16) conversions saturate
     nb_stagger(p.stagger_ticks, 256);
@@ -289,11 +293,50 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 
     const int NC = p.nchunks, T = NC * 3;
     auto clampt = [&](int t) { return t < T ? t : T - 1; };
+    // V2: the same pieces from inline assembly (a builtin LDS-DMA anywhere in the kernel pins every fragment-read wait at
+    // lgkmcnt(0), see nb_lds_dma16): per-lane source of chunk 0 + per-chunk stride (0 for out-of-image slots: the zero page),
+    // weights as a uniform base per step + a lane offset
+    const unsigned lds0_v2 = (unsigned)(uintptr_t)NB_LDS_PTR(smem_h3);
+    const char* xs0_v2[NXPW];
+    unsigned xst_v2[NXPW], wof_v2[NWPW];
+#pragma unroll
+    for (int i = 0; i < NXPW; ++i) {
+        const bool in = xsp[i] >= 0;
+        xs0_v2[i] = in ? reinterpret_cast<const char*>(xn + (size_t)xpl[i] * HW8 + xsp[i]) : reinterpret_cast<const char*>(p.zeros);
+        xst_v2[i] = in ? (unsigned)(4 * HW8 * 2) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NWPW; ++i) {
+        int q = i * NW + wv;
+        q = q < NWP ? q : NWP - 1;
+        const int e = q * 64 + lane;
+        const int row = e / CO_WG, j = e - row * CO_WG;
+        wof_v2[i] = (unsigned)(((size_t)row * p.co_ld + co0 + j) * 16);
+    }
+    const size_t wstep_v2 = (size_t)12 * p.co_ld * 16;                 // bytes of one (chunk, tap row) weight sub-chunk
+    constexpr int WRING_SLOT0 = 2 * 4 * XPL;
+    auto issue_x_v2 = [&](auto ii, int c, int buf) {                   // piece ii of chunk c's halo tile into activation buffer buf
+        constexpr int i = decltype(ii)::value;
+        nb_lds_dma16_m(xs0_v2[i] + (size_t)c * xst_v2[i], lds0_v2 + (unsigned)(buf * 4 * XPL + xdst[i]) * 16u, ~0ull);
+    };
+    auto issue_w_v2 = [&](auto ii, int t, int slot) {                  // piece ii of weight sub-chunk t into ring slot `slot`
+        constexpr int i = decltype(ii)::value;
+        int q = i * NW + wv;
+        q = q < NWP ? q : NWP - 1;
+        nb_lds_dma16_s(reinterpret_cast<const char*>(p.wts) + (size_t)t * wstep_v2, wof_v2[i], lds0_v2 + (unsigned)(WRING_SLOT0 + slot * WSLOTS + q * 64) * 16u);
+    };
     // prologue: chunk 0's halo tile and the first three weight sub-chunks
+    if constexpr (V2) {
+        nb_static_for<0, NXPW>([&](auto i) { issue_x_v2(i, 0, 0); });
+        nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, 0, 0); });
+        nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, clampt(1), 1); });
+        nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, clampt(2), 2); });
+    } else {
     issue_x(0, xbuf);
     issue_w(0, wring);
     issue_w(clampt(1), wring + WSLOTS);
     issue_w(clampt(2), wring + 2 * WSLOTS);
+    }
     // step 0 needs the halo tile and sub-chunk 0 only: sub-chunks 1 and 2 may still be in flight (the loop's invariant)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -305,7 +348,138 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
-    if constexpr (F8) {
+    if constexpr (F8 && V2) {
+        // ---- f8 operands, software-pipelined over the barrier ------------------------------------------------------
+        // Step t = (chunk c, tap row ky) multiplies, per accumulator tile and in this order: tap 2 of step t-1 (f16), on even t
+        // the tap-2 corrections of steps t-2 and t-1 (ONE fp8 K = 64), tap 0 (f16), tap 1 (f16), the corrections of taps 0 + 1
+        // (fp8) -- the order of the loop below.  What differs is where the barrier stands and when operands are read:
+        //   part A:  tap 2 (t-1) | [tap-2 corrections] | tap 0 (t)      fillers: the step's LDS-DMA pieces, its tap-2 fragments
+        //   wait (counted) + barrier: every wave has read ALL of stage t; stage t+1 has landed
+        //   part B:  tap 1 (t) | corrections 0 + 1 (t)                  fillers: hi fragments of taps 0, 1 of step t+1;
+        //            behind the last fp8 MFMA the lo halves of step t+1 (their tuples were its operands)
+        // so no step opens with a burst of sixteen reads behind a barrier that both waves of a SIMD reach together.
+        // All compile-time: the loop body is two chunks = six steps (tap row and the parity that selects the tuple quad).
+#define NB_SB __builtin_amdgcn_sched_barrier(0)
+#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
+        const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;
+        h8 ah0[MB], ah1[MB], ah2[MB], bh0[NBW], bh1[NBW], bh2[NBW];
+        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { ah2[mb] = h8{}; al2[mb] = i32x8{}; al01[mb] = i32x8{}; }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) { bh2[nb] = h8{}; bl2[nb] = i32x8{}; bl01[nb] = i32x8{}; }
+        constexpr int NM = MB * NBW, NF = MB + NBW;       // MFMAs per group; fragment reads per (tap, hi or lo)
+        // one fragment read: index i < MB: weights of block i, else activations of pixel row i - MB; hl = 0 hi, 1 lo
+        auto rd_hi = [&](auto i_, h8 (&a)[MB], h8 (&b)[NBW], const h8* wb, const h8* xb, int ky, int kx) {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (i < MB) a[i] = wb[a_base + kx * 4 * CO_WG + i * 32];
+            else b[i - MB] = xb[b_base + (i - MB + ky) * TWP + kx];
+        };
+        auto rd_lo = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, int ky, int kx) {
+            constexpr int i = decltype(i_)::value, q = decltype(q_)::value;
+            if constexpr (i < MB) { NB_Q(a[i], q, wb[a_base + kx * 4 * CO_WG + CO_WG + i * 32]); }
+            else { NB_Q(b[i - MB], q, xb[b_base + XPL + (i - MB + ky) * TWP + kx]); }
+        };
+        // a group of NM MFMAs (tile k = (k / NBW, k % NBW)) with NFILL fillers dealt evenly into the gaps behind them
+        auto group = [&](auto nfill_, auto&& mf, auto&& ff) {
+            constexpr int NFILL = decltype(nfill_)::value;
+            nb_static_for<0, NM>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                mf(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{});
+                NB_SB;
+                nb_static_for<0, NFILL>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i * NM / (NFILL > 0 ? NFILL : 1) == k) ff(i_);
+                });
+                NB_SB;
+            });
+        };
+        auto mf_f16 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
+            return [&](auto mb_, auto nb_) {
+                constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+            };
+        };
+        auto mf_fp8 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
+            return [&](auto mb_, auto nb_) {
+                constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+                acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 0, 0, 0, sa, 0, sb);
+            };
+        };
+        // step t: KY = tap row, ODD = t & 1 (compile time); reads stage (c, slot t & 3), issues sub-chunk t + 3 (and on KY = 0 the
+        // next chunk's halo tile), pre-reads step t + 1
+        auto step = [&](auto ky_, auto odd_, int t, int c) {
+            constexpr int KY = decltype(ky_)::value, ODD = decltype(odd_)::value;
+            constexpr int NDMA = NWPW + (KY == 0 ? NXPW : 0);
+            const h8* xb = xbuf + (c & 1) * 4 * XPL;
+            const h8* wb = wring + (t & 3) * WSLOTS;
+            const int tn = t + 1, cn = KY == 2 ? c + 1 : c;
+            constexpr int KYN = KY == 2 ? 0 : KY + 1;
+            const h8* xbn = xbuf + (cn & 1) * 4 * XPL;
+            const h8* wbn = wring + (tn & 3) * WSLOTS;
+            const int t3 = clampt(t + 3), c1 = c + 1 < NC ? c + 1 : NC - 1;
+            auto dma = [&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < NWPW) issue_w_v2(i_, t3, (t + 3) & 3);
+                else issue_x_v2(std::integral_constant<int, i - NWPW>{}, c1, (c + 1) & 1);
+            };
+            NB_SB;
+            // part A
+            group(std::integral_constant<int, NDMA>{}, mf_f16(ah2, bh2), dma);                       // tap 2 of step t-1
+            if constexpr (!ODD) {
+                group(std::integral_constant<int, NF>{}, mf_fp8(al2, bl2),                            // tap-2 corrections of t-2, t-1
+                      [&](auto i_) { rd_hi(i_, ah2, bh2, wb, xb, KY, 2); });
+                group(std::integral_constant<int, NF>{}, mf_f16(ah0, bh0),                            // tap 0
+                      [&](auto i_) { rd_lo(i_, std::integral_constant<int, 0>{}, al2, bl2, wb, xb, KY, 2); });
+            } else {
+                group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah0, bh0), [&](auto i_) {         // tap 0
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i < NF) rd_hi(i_, ah2, bh2, wb, xb, KY, 2);
+                    else rd_lo(std::integral_constant<int, i - NF>{}, std::integral_constant<int, 1>{}, al2, bl2, wb, xb, KY, 2);
+                });
+            }
+            // everything issued before sub-chunk t-1 has landed (it is what step t+1 reads); all reads of stage t are done
+            if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW + NXPW) : "memory");
+            NB_SB;
+            // part B
+            group(std::integral_constant<int, NF>{}, mf_f16(ah1, bh1),                                // tap 1
+                  [&](auto i_) { rd_hi(i_, ah0, bh0, wbn, xbn, KYN, 0); });
+            group(std::integral_constant<int, NF>{}, mf_fp8(al01, bl01),                              // corrections of taps 0 + 1
+                  [&](auto i_) { rd_hi(i_, ah1, bh1, wbn, xbn, KYN, 1); });
+            nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 0>{}, al01, bl01, wbn, xbn, KYN, 0); });
+            nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 1>{}, al01, bl01, wbn, xbn, KYN, 1); });
+            NB_SB;
+        };
+        // operands of step 0
+        nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah0, bh0, wring, xbuf, 0, 0); });
+        nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah1, bh1, wring, xbuf, 0, 1); });
+        nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 0>{}, al01, bl01, wring, xbuf, 0, 0); });
+        nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 1>{}, al01, bl01, wring, xbuf, 0, 1); });
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+        int c = 0;
+        for (; c + 1 < NC; c += 2) {                   // t = 3 c is even here
+            step(K0{}, K0{}, 3 * c, c); step(K1{}, K1{}, 3 * c + 1, c); step(K2{}, K0{}, 3 * c + 2, c);
+            step(K0{}, K1{}, 3 * c + 3, c + 1); step(K1{}, K0{}, 3 * c + 4, c + 1); step(K2{}, K1{}, 3 * c + 5, c + 1);
+        }
+        if (c < NC) { step(K0{}, K0{}, 3 * c, c); step(K1{}, K1{}, 3 * c + 1, c); step(K2{}, K0{}, 3 * c + 2, c); }
+        NB_SB;
+        // the last step's tap 2 and the last tuple of tap-2 corrections (an odd number of steps: it holds one tap only)
+        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_f16(ah2, bh2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+        if (T & 1) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) al2[mb][r] = 0;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
+        }
+        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp8(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+#undef NB_Q
+#undef NB_SB
+    } else if constexpr (F8) {
         // ---- f8 operands: explicitly ordered, software-pipelined step -------------------------------------------
         // The compiler, left alone, sinks every fragment read to just before its first use and waits with lgkmcnt(0)
         // right after issuing it (five exposed LDS latencies per step with both waves of a SIMD in lockstep).  Here
@@ -821,7 +995,7 @@ static int launch_h3s(H3Params p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int MW, bool F8 = false, int NBW = 2>
+template <int MW, bool F8 = false, int NBW = 2, bool V2 = false>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * NBW, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
@@ -830,17 +1004,20 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
 }
 
 extern "C" const float* nb_zero_page_ptr(void);
 
+static int g_force_up1_v2 = -1;
+// developer / test hook: -1 = automatic (on), 0 / 1 = the round-3 / the software-pipelined K loop of the f8 up=1 kernel
+extern "C" void nb_debug_set_up1_v2(int mode) { g_force_up1_v2 = mode; }
 static int g_force_nbw = 0;
 // developer / test hook: 0 = automatic, 1 / 2 = force that many 32-pixel rows per wave in the 8-wave up=1 kernel
 extern "C" void nb_debug_set_up1_rows(int nbw) { g_force_nbw = nbw; }
@@ -888,10 +1065,15 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const long wgs_full = (long)n * (w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64));
     const bool half = g_force_nbw ? g_force_nbw == 1 : wgs_full < 160;
     hipStream_t st = (hipStream_t)stream;
+    // f8 operands: the software-pipelined K loop (V2) unless switched off (test hook / NB_UP1_V2=0)
+    static const int env_v2 = getenv("NB_UP1_V2") ? atoi(getenv("NB_UP1_V2")) : -1;
+    const bool v2 = (g_force_up1_v2 >= 0 ? g_force_up1_v2 : env_v2) != 0;
     if (half) {
+        if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 1, true>(p, n, st) : launch_h3<1, true, 1, true>(p, n, st);
         if (f8) return c_out > 64 ? launch_h3<2, true, 1>(p, n, st) : launch_h3<1, true, 1>(p, n, st);
         return c_out > 64 ? launch_h3<2, false, 1>(p, n, st) : launch_h3<1, false, 1>(p, n, st);
     }
+    if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 2, true>(p, n, st) : launch_h3<1, true, 2, true>(p, n, st);
     if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
     if (c_out > 64) return launch_h3<2>(p, n, st);
     return launch_h3<1>(p, n, st);

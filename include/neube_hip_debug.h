@@ -16,6 +16,10 @@ extern "C" {
  * wave.  tests/test_hip_f8.py asserts both forms bit-identical. */
 void nb_debug_set_up1_rows(int nbw);
 
+/* K loop of the 8-wave split-f16 up=1 kernel with f8 operands: -1 = automatic (the software-pipelined loop of round 4), 0 = the
+ * round-3 loop, 1 = the software-pipelined loop.  tests/test_hip_f8.py asserts both bit-identical. */
+void nb_debug_set_up1_v2(int mode);
+
 /* K-splitting waves per workgroup of the small-image kernel (modconv3x3_up1_small_h3): 0 = automatic (8 for layers of >= 8
  * sixteen-channel chunks), 4 or 8 = force. */
 void nb_debug_set_small_waves(int waves);

@@ -208,7 +208,7 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
 
 
 @pytest.mark.parametrize("fmt", [0, 1])
-@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 32, 64), (64, 64, 48, 32)])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 32, 64), (64, 64, 48, 32), (48, 64, 32, 32), (16, 128, 16, 32)])
 def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
     """The 8-wave up=1 split-f16 kernel runs with 2 (throughput) or 1 (under-filled launches, batch 1) pixel rows per
     wave; same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical."""
@@ -227,8 +227,12 @@ def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for rows in (2, 1):
-            lib.nb_debug_set_up1_rows(rows)
+        for rows in (2, 1, "2old", "1old"):
+            # ("old": the round-3 K loop of the f8 kernel; the default is the software-pipelined one)
+            lib.nb_debug_set_up1_rows(int(str(rows)[0]))
+            lib.nb_debug_set_up1_v2(0 if str(rows).endswith("old") else 1)
+            if not fmt and str(rows).endswith("old"):
+                continue
             y = torch.empty([n, co, h, w], device="cuda")
             out = torch.zeros(ops.h2_shape(n, co, h, w), dtype=torch.float16, device="cuda")
             common = (dco.data_ptr(), noise.data_ptr(), h * w, bias.data_ptr())
@@ -240,8 +244,12 @@ def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
             res[rows] = (y, out)
     finally:
         lib.nb_debug_set_up1_rows(0)
+        lib.nb_debug_set_up1_v2(-1)
     assert torch.equal(res[2][0], res[1][0])
     assert torch.equal(res[2][1], res[1][1])
+    if fmt:
+        for k in ("2old", "1old"):
+            assert torch.equal(res[2][0], res[k][0]) and torch.equal(res[2][1], res[k][1]), k
     ref = _conv_ref(x, wt, st, 1) * dco.double().cpu()[:, :, None, None] + noise.double().cpu()[:, None]
     ref = torch.nn.functional.leaky_relu(ref + bias.double().cpu()[None, :, None, None], 0.2) * 1.4142135
     assert float((res[1][0].double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())

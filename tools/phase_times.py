@@ -109,5 +109,6 @@ if __name__ == "__main__":
     if os.environ.get("NB_PHASE_ONLY") != "up2":
         run("up1", n, 64, 64, 256)
         run("up1", n, 128, 128, 128)
-    run("up2", n, 128, 64, 256)
-    run("up2", n, 384, 128, 128)
+    if os.environ.get("NB_PHASE_ONLY") != "up1":
+        run("up2", n, 128, 64, 256)
+        run("up2", n, 384, 128, 128)
