@@ -1775,7 +1775,7 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
 }
 
 // which kernel a split-f16 up=2 launch runs on (the debug hooks / environment switches apply)
-enum Up2Form { UP2_BIG = 0, UP2_MID, UP2_SMALL, UP2_W16, UP2_PAIR, UP2_WIDE, UP2_V2 };
+enum Up2Form { UP2_BIG = 0, UP2_MID, UP2_SMALL, UP2_W16, UP2_PAIR, UP2_WIDE, UP2_V2, UP2_W8 };
 static Up2Form nb_up2_h3_select(int in_fmt, int c_in, int c_out, int n, int h, int w) {
     const int tiles_x = w / 32, slices = (c_out + 31) / 32;
     // the wide form (one wave per SIMD, 64 c_out per workgroup): opt-in
@@ -1785,6 +1785,7 @@ static Up2Form nb_up2_h3_select(int in_fmt, int c_in, int c_out, int n, int h, i
         (force_wide > 0 || (NB_UP2W_AUTO && nb_up2w_workgroups(n, c_out, h, w) >= 768)))
         return UP2_WIDE;
     if (w == 16) return UP2_W16;                      // 16-wide inputs: 8 x 16 quad tiles
+    if (w == 8) return UP2_W8;                        // 8 x 8 inputs: the whole image is one 8 x 8 quad tile (4 position blocks)
     // tile height: the 12-row tiles unless they leave the chip mostly idle (batch-1 / interactive), then 5-row tiles
     static const int env_tqh = getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0;
     const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
@@ -1825,7 +1826,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
                "modconv3x3_up2_h3: H2 output needs the consumer's styles, c_out %% 8 == 0 and c_next >= c_out");
     NB_REQUIRE(n > 0 && n <= 65535 && c_in > 0 && c_out > 0, "modconv3x3_up2_h3: bad sizes");
-    NB_REQUIRE((w % 32 == 0 || w == 16) && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0 or w == 16 (got %dx%d)", h, w);
+    NB_REQUIRE((w % 32 == 0 || w == 16 || w == 8) && h >= 8, "modconv3x3_up2_h3: needs w %% 32 == 0, w == 16 or w == 8 (got %dx%d)", h, w);
     NB_REQUIRE(alpha >= 0.f && alpha <= 1.f && gain > 0.f, "modconv3x3_up2_h3: leaky-ReLU slope must lie in [0, 1] and the gain be positive (got %g, %g)", alpha, gain);
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y) % 16 == 0, "modconv3x3_up2_h3: pointers must be 16-byte aligned");
     H3Up2Params p;
@@ -1845,6 +1846,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     switch (nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)) {
         case UP2_WIDE: return nb_up2w_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
         case UP2_W16: return nb_up2_h3_launch<8, 16>(p, n, in_fmt, stream);
+        case UP2_W8: return nb_up2_h3_launch<8, 8>(p, n, in_fmt, stream);
         case UP2_PAIR: return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
         case UP2_V2: return nb_up2v_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
         case UP2_MID: return nb_up2_h3_launch<NB_H3_TQH_MID>(p, n, in_fmt, stream);
@@ -1855,9 +1857,9 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
 
 extern "C" int nb_modconv3x3_up2_h3_variant(int in_fmt, int c_in, int c_out, int n, int h, int w, char* buf, int buflen) {
     NB_REQUIRE(buf && buflen > 0, "modconv3x3_up2_h3_variant: bad buffer");
-    NB_REQUIRE((in_fmt == 0 || in_fmt == 1) && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16), "modconv3x3_up2_h3_variant: bad shape");
+    NB_REQUIRE((in_fmt == 0 || in_fmt == 1) && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16 || w == 8), "modconv3x3_up2_h3_variant: bad shape");
     static const char* const names[] = {"modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel",
-                                        "modconv3x3_up2_h3_kernel", "modconv3x3_up2w_kernel", "modconv3x3_up2v_kernel"};
+                                        "modconv3x3_up2_h3_kernel", "modconv3x3_up2w_kernel", "modconv3x3_up2v_kernel", "modconv3x3_up2_h3_kernel"};
     snprintf(buf, buflen, "%s", names[nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)]);
     return NB_OK;
 }

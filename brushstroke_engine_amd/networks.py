@@ -266,6 +266,8 @@ class SynthesisNetwork(torch.nn.Module):
         # (tools/layers_b1.py: at batch 1 the >= 128x128 layers gain 25-65 %, the <= 64x64 layers lose 40-100 %)
         self.h3_min_pixels = 128 * 128
         self.h3_up2_w16_min_batch = 16        # 16x16 -> 32x32 conv0 on the large up=2 kernel (8 x 16 quad tiles) from this batch
+        self.h3_up2_w8_min_batch = 16         # 8x8 -> 16x16 conv0 likewise (one 8 x 8 quad tile per sample and c_out slice): the
+                                              # FIR-folded form on the small-image kernel re-reads 147 KB of weights per 32 positions
         self.h3_min_batch = 1
         # the latency-oriented styles / demodulation launch needs 16-byte friendly shapes (every style1 shape has them)
         self._styles_fast = cfg.w_dim % 16 == 0 and all(l.out_channels % 4 == 0 for l in cfg.layers)
@@ -328,9 +330,10 @@ class SynthesisNetwork(torch.nn.Module):
     def _h3_up2_eligible(self, s: LayerSpec) -> bool:
         """conv0 (up=2) layers that run on the split-f16 4-phase kernel: input rows must be multiples of 32 pixels, or 16
         pixels (8 x 16 quad tiles: two workgroups per sample and c_out slice, so only worth it at batch >= 16)."""
+        w8 = s.in_res == 8 and self._n >= self.h3_up2_w8_min_batch
         return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 2
-                and ((s.in_res >= 32 and s.in_res % 32 == 0) or (s.in_res == 16 and self._n >= self.h3_up2_w16_min_batch))
-                and self._n * s.block_res ** 2 >= self.h3_min_pixels
+                and ((s.in_res >= 32 and s.in_res % 32 == 0) or (s.in_res == 16 and self._n >= self.h3_up2_w16_min_batch) or w8)
+                and (w8 or self._n * s.block_res ** 2 >= self.h3_min_pixels)
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     small_h3 = True        # <= 64x64 conv1 layers on the small-tile split-f16 kernel (csrc/nb_modconv_small.hip)

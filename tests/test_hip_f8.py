@@ -146,7 +146,7 @@ def test_f8_tiled_canvas_matches_reference():
 
 
 @pytest.mark.parametrize("fmt", [0, 1])
-@pytest.mark.parametrize("ci,co,h,w", [(128, 64, 32, 32), (144, 128, 24, 64), (48, 64, 26, 32)])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 64, 32, 32), (144, 128, 24, 64), (48, 64, 26, 32), (128, 64, 8, 8), (32, 32, 16, 16)])
 def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     """The up=2 split-f16 kernel has three tile heights (12 quad rows for throughput, 8 where those would end in a mostly
     empty round of workgroups, 5 for under-filled launches such as batch 1).  Both walk the same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical; 24 rows do
