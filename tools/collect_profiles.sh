@@ -2,7 +2,7 @@
 # Collect the round's judged artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1800 -- "bash tools/collect_profiles.sh r03 $(git rev-parse --short HEAD)"   (no git on the GPU box)
 # Writes gpurun_out/<tag>/...; copy what is to be judged into profiles/ (tools/copy_profiles.sh <tag>).
-TAG=${1:-r03}; GIT_HEAD=${2:-unknown}
+TAG=${1:-r04}; GIT_HEAD=${2:-unknown}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # the driver's command (one line carrying all three arithmetic modes), before anything else touches the GPU; it runs once more at the
@@ -32,6 +32,10 @@ cd $R
 python tools/make_hbm_traffic.py $O/hbm_traffic.json "${GIT_HEAD:-unknown}" f8=$O/pmc_mem_f8.json h3=$O/pmc_mem_h3.json f32=$O/pmc_mem_f32.json > $O/hbm_traffic.log 2>&1
 cp $O/hbm_traffic.json $R/profiles/hbm_traffic.json
 NB_PHASE_F8=1 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times.txt 2>&1
+# same-box A/Bs of the round's K loops: round-3 kernels vs software-pipelined ones (up=2: also the one-wave-per-SIMD wide form)
+bash tools/ab_v2.sh $O/ab_v2 > $O/ab_up2_kernels.txt 2>&1; rm -rf $O/ab_v2
+bash tools/ab_up1.sh $O/ab_up1 > $O/ab_up1_kloops.txt 2>&1; rm -rf $O/ab_up1
+$R/tools/microbench/bin/valu_issue > $O/microbench_valu_issue.txt 2>&1
 python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
 NB_SUBS="1 2" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace -d $O/b1trace -o b1 --output-format csv -- python3 $R/tools/trace_b1.py > $O/b1trace.log 2>&1)
@@ -39,6 +43,8 @@ python tools/trace_b1_summary.py $O/b1trace > $O/b1_trace_summary.txt 2>&1; rm -
 (cd /tmp && rocprofv3 --kernel-trace -d $O/enctrace -o enc --output-format csv -- python3 $R/tools/trace_encoder.py > $O/enctrace.log 2>&1)
 (grep '^encoder' $O/enctrace.log; python tools/trace_encoder_summary.py $O/enctrace) > $O/encoder_trace.txt 2>&1; rm -rf $O/enctrace
 python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 --breakdown > $O/canvas_4096_r256_l2.json 2>/dev/null
+# the same job with 1, 2 and the probed number of batch streams, one process
+python tools/bench_canvas.py --size 4096 --res 256 --level 2 --steps 3 --streams ab > $O/canvas_4096_r256_l2_streams_ab.json 2>/dev/null
 python tools/bench_canvas.py --size 4096 --res 256 --level 0 --steps 3 --breakdown > $O/canvas_4096_r256_l0.json 2>/dev/null
 python tools/bench_canvas.py --size 1024 --res 128 --level 2 --steps 3 --breakdown > $O/canvas_1024_r128_l2.json 2>/dev/null
 python tools/bench_lamali.py > $O/lamali.json 2> $O/lamali.err
