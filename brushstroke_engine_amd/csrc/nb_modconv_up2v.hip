@@ -28,7 +28,9 @@ constexpr int KMIX = NXP / NW;                                       // the roun
 static_assert(NBLK <= NBJ * NW && KMIX * NW <= NXP && (KMIX + 1) * NW > NXP && NPC == 7, "piece list layout");
 }
 
-template <int OUTM>
+// F8: "f8" operands (hi f16 + fp8 correction operands: 14 matrix instructions per tap-chunk and block) or H2 operands (hi / lo f16:
+// three f16 MFMAs per tap, 27 per chunk and block -- the `h3` arithmetic mode)
+template <bool F8, int OUTM>
 __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Params p) {
     NB_TSTAMP(0);
     if constexpr (OUTM == 2) nb_set_fp16_ovfl();
@@ -180,6 +182,11 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         bh0[i] = h8{}; bh1[i] = h8{}; bh2[i] = h8{}; bh3[i] = h8{}; bl01[i] = i32x8{}; bl23[i] = i32x8{};
     }
     const int sa_ = lh ? 116 : 127, sb_ = lh ? 129 : 118;      // E8M0 block scales (see modconv3x3_up1_h3_kernel)
+    // H2 operands: separate lo fragments (no tuples): A sets a / n [tap of the pair], m; B lo at the four input offsets
+    h8 hl_a[2], hl_n[2], hl_m, bl0[NBJ], bl1[NBJ], bl2[NBJ], bl3[NBJ];
+    hl_m = h8{};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { hl_a[i] = h8{}; hl_n[i] = h8{}; bl0[i] = h8{}; bl1[i] = h8{}; bl2[i] = h8{}; bl3[i] = h8{}; }
 
 #define NB_FENCE() __builtin_amdgcn_sched_barrier(0)
     auto set_lo = [](i32x8& t, const h8& v) { const i32x4 x = __builtin_bit_cast(i32x4, v); t[0] = x[0]; t[1] = x[1]; t[2] = x[2]; t[3] = x[3]; };
@@ -203,6 +210,103 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
 #endif
         };
         using J0_ = std::integral_constant<int, 0>; using J1_ = std::integral_constant<int, 1>;
+        if constexpr (!F8) {
+            // ---- H2 operands: per tap (hi x hi), (hi x lo), (lo x hi) in that order (the order of modconv3x3_up2_h3_kernel) ----
+            auto rBl1 = [&](h8 (&bl)[NBJ], auto j_, int del, const h8* s_) { constexpr int j = decltype(j_)::value; if constexpr (j < NBE) bl[j] = s_[boff[j] + XPL + del]; };
+            // a tap pair on both blocks: 2 x (3 + 3) f16 MFMAs; filler(g) behind MFMA g = 6 j + position
+            auto group6 = [&](auto ph_, h8 (&ah)[2], h8 (&al)[2], h8 (&Bha)[NBJ], h8 (&Bla)[NBJ], h8 (&Bhb)[NBJ], h8 (&Blb)[NBJ], auto&& filler) {
+                constexpr int ph = decltype(ph_)::value;
+                nb_static_for<0, 2>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    f32x16& a_ = acc[j][ph];
+                    nb_static_for<0, 6>([&](auto q_) {
+                        constexpr int q = decltype(q_)::value;
+                        constexpr int t = q / 3, k = q % 3;
+                        if constexpr (j < NBE) {
+                            h8 (&Bh)[NBJ] = t ? Bhb : Bha;
+                            h8 (&Bl)[NBJ] = t ? Blb : Bla;
+                            if constexpr (k == 0) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], Bh[j], a_, 0, 0, 0);
+                            else if constexpr (k == 1) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], Bl[j], a_, 0, 0, 0);
+                            else a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], Bh[j], a_, 0, 0, 0);
+                        }
+                        NB_FENCE(); filler(std::integral_constant<int, 6 * j + q>{}); NB_FENCE();
+                    });
+                });
+            };
+            NB_FENCE();
+            // G0: taps 8, 6 -> phase 0.  Fillers: the A fragments of G1; pieces 2, 3
+            group6(std::integral_constant<int, 0>{}, ah_a, hl_a, bh0, bl0, bh1, bl1, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 0) ah_n[0] = rA(5, 0, sa);
+                else if constexpr (g == 2) hl_n[0] = rA(5, 1, sa);
+                else if constexpr (g == 4) dma(std::integral_constant<int, 2>{});
+                else if constexpr (g == 6) ah_n[1] = rA(3, 0, sa);
+                else if constexpr (g == 8) hl_n[1] = rA(3, 1, sa);
+                else if constexpr (g == 10) dma(std::integral_constant<int, 3>{});
+            });
+            // G1: taps 5, 3 -> phase 2.  Fillers: tap 4, the row-below fragments; piece 4
+            group6(std::integral_constant<int, 2>{}, ah_n, hl_n, bh0, bl0, bh1, bl1, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 0) ah_m = rA(4, 0, sa);
+                else if constexpr (g == 2) hl_m = rA(4, 1, sa);
+                else if constexpr (g == 4) dma(std::integral_constant<int, 4>{});
+                else if constexpr (g == 6) rBh(bh2, J0_{}, XS, sa);
+                else if constexpr (g == 7) rBl1(bl2, J0_{}, XS, sa);
+                else if constexpr (g == 9) rBh(bh2, J1_{}, XS, sa);
+                else if constexpr (g == 10) rBl1(bl2, J1_{}, XS, sa);
+            });
+            // G2: tap 4 -> phase 3: 3 f16 MFMAs per block.  Fillers: the A fragments of G3; piece 5
+            nb_static_for<0, 2>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                f32x16& a_ = acc[j][3];
+                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_m, bh0[j], a_, 0, 0, 0);
+                NB_FENCE();
+                if constexpr (j == 0) ah_a[0] = rA(7, 0, sa); else ah_a[1] = rA(1, 0, sa);
+                NB_FENCE();
+                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_m, bl0[j], a_, 0, 0, 0);
+                NB_FENCE();
+                if constexpr (j == 0) hl_a[0] = rA(7, 1, sa); else hl_a[1] = rA(1, 1, sa);
+                NB_FENCE();
+                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl_m, bh0[j], a_, 0, 0, 0);
+                NB_FENCE();
+                if constexpr (j == 0) dma(std::integral_constant<int, 5>{});
+                NB_FENCE();
+            });
+            // G3: taps 7, 1 -> phase 1.  Fillers: the A fragments of G4, the diagonal fragments; piece 6
+            group6(std::integral_constant<int, 1>{}, ah_a, hl_a, bh0, bl0, bh2, bl2, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 0) ah_n[0] = rA(2, 0, sa);
+                else if constexpr (g == 2) hl_n[0] = rA(2, 1, sa);
+                else if constexpr (g == 4) dma(std::integral_constant<int, 6>{});
+                else if constexpr (g == 5) ah_n[1] = rA(0, 0, sa);
+                else if constexpr (g == 6) hl_n[1] = rA(0, 1, sa);
+                else if constexpr (g == 7) rBh(bh3, J0_{}, XS + 1, sa);
+                else if constexpr (g == 8) rBl1(bl3, J0_{}, XS + 1, sa);
+                else if constexpr (g == 9) rBh(bh3, J1_{}, XS + 1, sa);
+                else if constexpr (g == 10) rBl1(bl3, J1_{}, XS + 1, sa);
+            });
+            if constexpr (MODE >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPC) : "memory");
+            else if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            NB_FENCE();
+            // G4: taps 2, 0 -> phase 0.  Fillers: the NEXT chunk's first operands; pieces 0, 1 of chunk c + 3
+            group6(std::integral_constant<int, 0>{}, ah_n, hl_n, bh2, bl2, bh3, bl3, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 4) dma(std::integral_constant<int, 0>{});
+                if constexpr (g == 10) dma(std::integral_constant<int, 1>{});
+                if constexpr (MODE >= 1) {
+                    if constexpr (g == 0) ah_a[0] = rA(8, 0, san);
+                    else if constexpr (g == 1) { rBh(bh0, J0_{}, 0, san); rBl1(bl0, J0_{}, 0, san); }
+                    else if constexpr (g == 2) hl_a[0] = rA(8, 1, san);
+                    else if constexpr (g == 3) ah_a[1] = rA(6, 0, san);
+                    else if constexpr (g == 5) { rBh(bh1, J0_{}, 1, san); rBl1(bl1, J0_{}, 1, san); }
+                    else if constexpr (g == 6) hl_a[1] = rA(6, 1, san);
+                    else if constexpr (g == 7) { rBh(bh0, J1_{}, 0, san); rBl1(bl0, J1_{}, 0, san); }
+                    else if constexpr (g == 8) { rBh(bh1, J1_{}, 1, san); rBl1(bl1, J1_{}, 1, san); }
+                }
+            });
+            NB_FENCE();
+            return;
+        }
         // a tap pair on both blocks: (f16, f16, fp8) x 2; filler(g) behind MFMA g = 3 j + position
         auto group_pair = [&](auto ph_, h8 (&ah)[2], i32x8& al, h8 (&Ba)[NBJ], h8 (&Bb)[NBJ], i32x8 (&bl)[NBJ], auto&& filler) {
             constexpr int ph = decltype(ph_)::value;
@@ -285,11 +389,13 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         constexpr int NBE = decltype(nbe)::value;
         // the first chunk's first operands
         ah_a[0] = ring[aoff + 8 * 128]; ah_a[1] = ring[aoff + 6 * 128];
-        set_lo(al_a, ring[aoff + 8 * 128 + 32]); set_hi(al_a, ring[aoff + 6 * 128 + 32]);
+        if constexpr (F8) { set_lo(al_a, ring[aoff + 8 * 128 + 32]); set_hi(al_a, ring[aoff + 6 * 128 + 32]); }
+        else { hl_a[0] = ring[aoff + 8 * 128 + 32]; hl_a[1] = ring[aoff + 6 * 128 + 32]; }
 #pragma unroll
         for (int j = 0; j < NBE; ++j) {
             bh0[j] = ring[boff[j]]; bh1[j] = ring[boff[j] + 1];
-            set_lo(bl01[j], ring[boff[j] + XPL]); set_hi(bl01[j], ring[boff[j] + XPL + 1]);
+            if constexpr (F8) { set_lo(bl01[j], ring[boff[j] + XPL]); set_hi(bl01[j], ring[boff[j] + XPL + 1]); }
+            else { bl0[j] = ring[boff[j] + XPL]; bl1[j] = ring[boff[j] + XPL + 1]; }
         }
         int c = 0, s = 0;                             // s = stage of chunk c
         auto nxt = [](int s_) { return s_ == 2 ? 0 : s_ + 1; };
@@ -467,23 +573,23 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     }
 }
 
-template <int OUTM>
+template <bool F8, int OUTM>
 static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
     constexpr size_t lds_ring = (size_t)NST * STAGE * 16, lds_epi = (size_t)16 * NBLK * 32 * 16;
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<OUTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up2v_kernel<OUTM>), grid, dim3(NT), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM>), grid, dim3(NT), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2v");
     return NB_OK;
 }
 
-// shapes this form takes: f8 operands (whole 16-channel chunks), 32-column tiles of 12 quad rows
-bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w) { return in_fmt == 1 && c_in % 16 == 0 && w % TQW == 0 && h >= 8; }
+// shapes this form takes: whole 16-channel chunks (f8 or H2 operands), 32-column tiles of 12 quad rows
+bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w) { return (in_fmt == 0 || in_fmt == 1) && c_in % 16 == 0 && w % TQW == 0 && h >= 8; }
 
 // p as filled in by nb_up2_h3_impl (nb_modconv_h3.hip); tiles are set here
 int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long long* tstamps, int tstamps_cap) {
@@ -493,5 +599,6 @@ int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long
     p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     p.tstamps = (tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= tstamps_cap) ? tstamps : nullptr;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
-    return outm == 2 ? nb_up2v_launch1<2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<1>(p, n, stream) : nb_up2v_launch1<0>(p, n, stream);
+    if (in_fmt) return outm == 2 ? nb_up2v_launch1<true, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1>(p, n, stream) : nb_up2v_launch1<true, 0>(p, n, stream);
+    return outm == 2 ? nb_up2v_launch1<false, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<false, 1>(p, n, stream) : nb_up2v_launch1<false, 0>(p, n, stream);
 }

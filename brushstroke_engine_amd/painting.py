@@ -400,9 +400,10 @@ class TileOps:
                 return (time.perf_counter() - t0) / batches * 1e3
             run(2 * k)                                   # workspaces, code objects, clocks
             times[k] = min(run(4), run(4))
-        best = min(times, key=times.get)
-        if times[2] > 0.97 * times[1]:                   # a second stream has to earn its workspace: < 3 % is noise
-            best = 1
+        # two streams unless they are not faster HERE (the probe renders generator passes only; in the canvas job, where encoder,
+        # canvas kernels and copies sit between them, the second stream is worth more than in the probe: r04 A/B 44.4 -> 42.2 ms
+        # on a box whose probe said 1.81 -> 1.79 ms per batch)
+        best = 2 if times[2] < 0.995 * times[1] else 1
         self.n_streams, self._streams, self._forked = best, (keep_streams if keep_streams is not None and len(keep_streams) == best else None), keep_forked if keep_streams is not None and len(keep_streams) == best else set()
         self.stream_probe = {"ms_per_batch": {str(k): round(v, 4) for k, v in times.items()}, "chosen": best, "batch": n}
         return best
