@@ -40,12 +40,21 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
     const int H = p.h, W = p.w;
-    int b = blockIdx.x;
-    // XCD-aware order (see modconv3x3_up2_h3_kernel)
-    if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (((b & 7) + blockIdx.y) & 7) * (gridDim.x >> 3) + (b >> 3);
+    int b = blockIdx.x, n = blockIdx.y;
+    // XCD-aware order.  Hardware workgroup ids (x fastest, then y) go round-robin to the 8 XCDs, each with its own L2.  The whole
+    // grid -- [sample][tile][c_out slice] -- is renumbered so that an XCD works through a contiguous eighth of that list: the
+    // c_out slices of a tile (which re-read the same activations) run side by side on one XCD, its neighbours in the image
+    // (shared halo rows, shared 128-byte lines at the tile's left and right edge) right after them, and every XCD gets whole
+    // samples, i.e. the same mix of full and ragged tiles.  (dbg & 32: the round-3 order, per sample with a rotating XCD share --
+    // there 6 or 11 workgroups of a sample per XCD cut through the slices of a tile and the tile was fetched by two L2s.)
+    const unsigned total = gridDim.x * gridDim.y;
+    if (total % 8 == 0 && !(p.dbg & (8 | 32))) {
+        const unsigned l = b + gridDim.x * n;
+        const unsigned q = (l & 7) * (total >> 3) + (l >> 3);
+        n = q / gridDim.x; b = q - n * gridDim.x;
+    } else if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (((b & 7) + n) & 7) * (gridDim.x >> 3) + (b >> 3);
     const int slice = b % p.slices; b /= p.slices;
     const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
-    const int n = blockIdx.y;
     const int I0 = tile_y * TQH, J0 = tile_x * TQW;
     const int co0 = slice * CO_WG;
     const size_t HW8 = (size_t)H * W * 8;

@@ -19,7 +19,7 @@ for arg in sys.argv[3:]:
     data = json.load(open(src))
     detail = {}
     for kname, recs in data.items():
-        m = re.match(r"(?:void )?(modconv3x3_up[12]_h3_kernel|modconv3x3_up1_small_h3_kernel|modconv_small_chain_kernel|modconv3x3_up[12]_kernel)(<[^>]*>)?", kname)
+        m = re.match(r"(?:void )?(modconv3x3_up[12]_h3_kernel|modconv3x3_up2[vw]_kernel|modconv3x3_up1_small_h3_kernel|modconv_small_chain_kernel|modconv3x3_up[12]_kernel)(<[^>]*>)?", kname)
         if not m:
             continue
         key = m.group(1)
