@@ -327,6 +327,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     };
     // prologue: chunk 0's halo tile and the first three weight sub-chunks
     if constexpr (V2) {
+        NB_TSTAMP(5);                              // (the hand-off epilogues leave slot 5 free: time that passes before the first LDS-DMA piece goes out)
         nb_static_for<0, NXPW>([&](auto i) { issue_x_v2(i, 0, 0); });
         nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, 0, 0); });
         nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, clampt(1), 1); });
@@ -1206,8 +1207,13 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
     if (tid < 32) {
         const int co = co0 + tid;
         // the activation gain is folded into the three addends: lrelu(g t) = g lrelu(t) for g > 0 (the launcher checks)
-        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] * p.gain : 0.f;
-        s_bias[tid] = co < p.c_out ? p.bias[co] * p.gain : 0.f;
+        float dg = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] * p.gain : 0.f;
+        float bv = co < p.c_out ? p.bias[co] : 0.f;
+        // (the two `* gain` must not meet in one packed instruction: the SLP vectoriser pairs them as v_pk_mul_f32 with the gain
+        //  broadcast through op_sel:[1,0] in some instantiations -- a swizzled packed form, see NB_NO_PACKED_F32 in nb_common.h)
+        asm volatile("" : "+v"(dg), "+v"(bv));
+        s_dco[tid] = dg;
+        s_bias[tid] = bv * p.gain;
         s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
     }
     // LDS-DMA descriptors of this wave's pieces.  Activation piece i: plane xpl (= cg_local*2 + hi/lo), 64 slots from

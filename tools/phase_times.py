@@ -66,6 +66,9 @@ def run(kind, n, ci, co, res):
         us = us[:, [0, 1, 2, 4, 5]]
         names = ["prologue", "k-loop", "epilogue (4 rounds)", "store drain"]
     elif H2OUT:
+        if (t[:, 5] > 0).all():                              # slot 5: stamped right before the first LDS-DMA of the prologue
+            pre = (t[:, 5] - t[:, 0]) / 100.0
+            print(f"    (set-up before the first LDS-DMA goes out: mean {pre.mean():.2f} us, p10 {np.percentile(pre, 10):.2f}, p90 {np.percentile(pre, 90):.2f})")
         us = us[:, :5]                                       # (the H2-output epilogue returns after stamp 4)
         names = ["prologue", "k-loop", "epilogue(LDS)", "slot stores"]
     else:
