@@ -21,6 +21,7 @@
 //   enc_upsample2x_h2_kernel  bilinear x2, align_corners=True, fp32 NCHW -> H2 (input of the decoder conv).
 // Layer outputs go out as H2 (next layer's input) or fp32 NCHW (what the generator consumes).
 #include "nb_common.h"
+#include "nb_h3_common.h"
 #include <cstdlib>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -224,10 +225,18 @@ struct EncConvParams {
     // shift = 1 (stride 2 only): no padding -- the window of output (i, j) starts at input (2i, 2j) of a (2 hout + 1) x (2 wout + 1)
     // input, i.e. the padded form's taps moved one pixel down / right (the training path's stride-2 correlations)
     int shift;
+    unsigned long long* tstamps;   // debug: per-workgroup phase timestamps [workgroup][8] (nb_debug_set_enc_timestamps), else null
 };
+
+static unsigned long long* g_enc_tstamps = nullptr;
+static int g_enc_tstamps_cap = 0;
+// Debug hook (not part of the product ABI): phase timestamps of the next enc_conv3x3_h3 launches, s_memrealtime ticks (100 MHz):
+// slot 0 start, 1 first step may begin, 2 K loop done, 3 epilogue values in LDS, 4 end
+extern "C" void nb_debug_set_enc_timestamps(void* buf, int capacity_workgroups) { g_enc_tstamps = (unsigned long long*)buf; g_enc_tstamps_cap = capacity_workgroups; }
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 
 // F8: the input activations and the weights carry their corrections as fp8 (the "f8" operand format of nb_modconv_h3.hip:
 // lo slot of an even channel group = fp8(xl 2^9) of the 16-channel chunk, of the odd group = fp8(x/4); weights fp8(w) /
@@ -238,14 +247,22 @@ template <int STRIDE, int LW, int OUT, bool F8 = false>
 __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams p) {
     constexpr int NW = 8, NWN = 4, MB = 2, NBW = 2, CO_WG = 128;
     constexpr int WT = 1 << LW, RPB = 32 / WT, TH = NWN * NBW * RPB, PW = WT + 2;      // output tile TH x WT = 256 pixels
-    constexpr int SLOTS = STRIDE * TH * PW;             // 16-byte slots of one (cgroup, hi/lo) plane of a step
+    // S2F (stride 2, f8 operands): activations are staged per CHUNK, not per step.  The slab of tap row 2 (input rows 2r+1) is the
+    // slab of tap row 0 (rows 2r-1) moved down one row, so a chunk needs 2 TH + 1 distinct input rows -- an "odd" slab of TH + 1 rows
+    // for tap rows 0 and 2 and an "even" slab of TH rows for tap row 1 -- instead of three slabs of TH rows: 76 instead of 108
+    // activation pieces per chunk (the K loop of this kernel is bound by what goes through the CU's LDS).
+    // Slab layout [row][even cols 2j | odd cols 2j-1][c], so that the even slab is a prefix of the same piece list.
+    constexpr bool S2F = F8 && STRIDE == 2;
+    constexpr int ROWPITCH = S2F ? 2 * PW : PW;
+    constexpr int SLOTS = S2F ? (TH + 1) * ROWPITCH : STRIDE * TH * PW;             // 16-byte slots of one (cgroup, hi/lo) plane of a step (S2F: of a slab)
     constexpr int PP = (SLOTS + 63) / 64, XPL = PP * 64;
     constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;
     constexpr int WSLOTS = 12 * CO_WG, NWP = WSLOTS / 64, NWPW = NWP / NW;
-    constexpr int KX0 = STRIDE == 2 ? TH * PW : 0, KX1 = STRIDE == 2 ? 0 : 1, KX2 = STRIDE == 2 ? TH * PW + 1 : 2;
+    constexpr int KX0 = S2F ? PW : (STRIDE == 2 ? TH * PW : 0), KX1 = STRIDE == 2 ? 0 : 1, KX2 = S2F ? PW + 1 : (STRIDE == 2 ? TH * PW + 1 : 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_enc[];
     h8* xbuf = reinterpret_cast<h8*>(smem_enc);         // [2][4][XPL]
     h8* wbuf = xbuf + 2 * 4 * XPL;                      // [2][WSLOTS]
+    NB_TSTAMP(0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
@@ -258,8 +275,23 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     const size_t HW8 = (size_t)p.hin * p.win * 8;
     const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
 
+    // OUT == 1 on 32-wide tiles: the hand-off epilogue of the generator's up=1 kernel (nb_up1_handoff_epilogue: straight from the
+    // accumulators, packed arithmetic, lane-half trade, whole 16-byte slots) with demodulation 1, no noise, gain 1, no clamp --
+    // the same expression as the staged epilogue below.  Its per-channel tables are fetched now, under the first LDS-DMA round trip.
+    constexpr bool DIRECT = OUT == 1 && LW == 5;
+    __shared__ __attribute__((aligned(16))) float s_one[DIRECT ? CO_WG : 1], s_bias[DIRECT ? CO_WG : 1], s_osc[DIRECT ? CO_WG : 1];
+    if constexpr (DIRECT) {
+        if (tid < CO_WG) {
+            const int co = co0 + tid;
+            s_one[tid] = 1.f;
+            s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
+            s_osc[tid] = (p.oscale && co < p.c_out) ? p.oscale[(size_t)n * p.oscale_stride + co] : 1.f;
+        }
+    }
+
     // gather descriptors of this wave's activation pieces
     int xcol[NXPW], xrow[NXPW], xpl[NXPW], xdst[NXPW];
+    [[maybe_unused]] int xcol_e[NXPW];                  // S2F: the column offsets of the even slab (rows < TH only)
 #pragma unroll
     for (int i = 0; i < NXPW; ++i) {
         int q = i * NW + wv;
@@ -270,7 +302,14 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
         xdst[i] = pl4 * XPL + part * 64;
         bool valid = e < SLOTS;
         int r, ix;
-        if (STRIDE == 1) {
+        if constexpr (S2F) {
+            r = e / ROWPITCH;
+            const int rem = e - r * ROWPITCH, pl = rem / PW, c = rem - pl * PW;
+            ix = pl ? nb_reflect(2 * (x0 + c) - 1, p.win) : 2 * (x0 + c);               // odd columns 2j-1 | even columns 2j
+            valid = valid && (pl ? c <= WT : c < WT);
+            xrow[i] = 2 * (y0 + r) - 1;                                                 // odd slab; the even slab is one row below
+            xcol_e[i] = (valid && r < TH) ? ix * 8 : -1;
+        } else if (STRIDE == 1) {
             r = e / PW;
             ix = nb_reflect(x0 + (e - r * PW) - 1, p.win);
             xrow[i] = y0 + r - 1;
@@ -342,9 +381,191 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
 
     const int T = p.nchunks * 3;
     const int a_base = lh * 2 * CO_WG + wm * 64 + l31;
-    const int b_base = lh * 2 * XPL + ((wn * NBW) * RPB + (l31 >> LW)) * PW + (l31 & (WT - 1));
-    issue(0, 0);
-    if constexpr (F8) {
+    const int b_base = lh * 2 * XPL + ((wn * NBW) * RPB + (l31 >> LW)) * ROWPITCH + (l31 & (WT - 1));
+    if constexpr (!S2F) issue(0, 0);
+    if constexpr (S2F) {
+        // ---- stride 2, f8 operands: slabs per chunk ---------------------------------------------------------------------------
+        // Step (c, S), S = tap row: S = 0 reads the odd slab O_c (rows 0 .. TH-1), S = 1 the even slab E_c, S = 2 O_c one row down.
+        // Two slab buffers; O_c lives in buffer c & 1, E_c in the other.  What is issued FOR a step is a list of pieces per wave:
+        //   kind 0 (for a step S = 0):  the NXPW pieces of O + NWPW weight pieces      kind 1: the pieces of E + weights
+        //   kind 2: weights only
+        // and, as in the loop below, a list's first half goes out in the second half of the step two before its consumer (behind the
+        // mid-step barrier that frees the target: E_c's buffer takes O_c+1 once step (c, 1) has read it, O_c's buffer takes E_c+1
+        // once step (c, 2) has), the second half in the first half of the step before.  The counted wait at the top of a step
+        // leaves exactly the first half of the NEXT step's list in flight.  Weight buffers alternate with the step as before.
+        constexpr int NPC = NXPW + NWPW;                               // pieces per wave of kinds 0 and 1
+        constexpr int FH01 = NPC / 2, FH2 = (NWPW + 1) / 2;           // first halves
+        static_assert(NXP == NXPW * NW, "every wave issues the same number of activation pieces (no skipping: counted waits)");
+        const int NC = p.nchunks, T = NC * 3;
+        // The pieces go out from inline assembly (nb_lds_dma16_m / _s, nb_h3_common.h): the builtin pins every later wait for a
+        // fragment read at lgkmcnt(0), i.e. a step could not start its matrix work before ALL of its reads were back.  Per-lane
+        // source of chunk 0 + a per-chunk stride (0 for the lanes that read the zero page); weights: uniform base + lane offset.
+        const unsigned lds0 = (unsigned)(uintptr_t)NB_LDS_PTR(smem_enc);
+        const char* xs_o[NXPW]; const char* xs_e[NXPW];
+        unsigned xst_o[NXPW], xst_e[NXPW], wof[NWPW];
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            const bool vo = xcol[i] >= 0, ve = xcol_e[i] >= 0;
+            const char* base = reinterpret_cast<const char*>(xn + (size_t)xpl[i] * HW8);
+            xs_o[i] = vo ? base + ((size_t)nb_reflect(xrow[i], p.hin) * p.win * 8 + xcol[i]) * 2 : reinterpret_cast<const char*>(p.zeros);
+            xs_e[i] = ve ? base + ((size_t)nb_reflect(xrow[i] + 1, p.hin) * p.win * 8 + xcol_e[i]) * 2 : reinterpret_cast<const char*>(p.zeros);
+            xst_o[i] = vo ? (unsigned)(4 * HW8 * 2) : 0u;
+            xst_e[i] = ve ? (unsigned)(4 * HW8 * 2) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NWPW; ++i) {
+            const int e = (i * NW + wv) * 64 + lane;
+            const int row = e / CO_WG, j = e - row * CO_WG;
+            wof[i] = (unsigned)(((size_t)row * p.co_ld + co0 + j) * 16);
+        }
+        const size_t wstep = (size_t)12 * p.co_ld * 16;               // bytes of one (chunk, tap row) weight sub-chunk
+        // piece k of the list of kind KIND for step (cc, KIND); past the end: the last chunk again (harmless re-copies keep the counts uniform)
+        auto piece2 = [&](auto kind_, auto kk, int cc) {
+            constexpr int KIND = decltype(kind_)::value, k = decltype(kk)::value;
+            constexpr int NA = KIND == 2 ? 0 : NXPW;
+            const int src_c = cc < NC ? cc : NC - 1;
+            const int t = 3 * cc + KIND, src_t = 3 * src_c + KIND;
+            if constexpr (k < NA) {
+                const int buf = KIND == 0 ? (cc & 1) : ((cc + 1) & 1);
+                if constexpr (KIND == 0) nb_lds_dma16_m(xs_o[k] + (size_t)src_c * xst_o[k], lds0 + (unsigned)(buf * 4 * XPL + xdst[k]) * 16u, ~0ull);
+                else nb_lds_dma16_m(xs_e[k] + (size_t)src_c * xst_e[k], lds0 + (unsigned)(buf * 4 * XPL + xdst[k]) * 16u, ~0ull);
+            } else {
+                constexpr int i = k - NA;
+                nb_lds_dma16_s(reinterpret_cast<const char*>(p.wts) + (size_t)src_t * wstep, wof[i],
+                               lds0 + (unsigned)(2 * 4 * XPL + (t & 1) * WSLOTS + (i * NW + wv) * 64) * 16u);
+            }
+        };
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+        // before step 0: all of list 0 of chunk 0 and the first half of list 1
+        nb_static_for<0, NPC>([&](auto k) { piece2(K0{}, k, 0); });
+        nb_static_for<0, FH01>([&](auto k) { piece2(K1{}, k, 0); });
+#define NB_SB __builtin_amdgcn_sched_barrier(0)
+#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
+        const int sa = lh ? 116 : 127, sb = lh ? 129 : 118;        // E8M0 block scales: fp8(w) fp8(xl 2^9) 2^-9 | fp8(wl 2^11) 2^-11 fp8(x/4) 2^2
+        h8 ah0[MB], ah1[MB], ah2[MB], bh0[NBW], bh1[NBW], bh2[NBW];
+        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];          // fp8 tuples: (tap 0 | tap 1), (tap 2 of an even step | of the odd step after it)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { ah2[mb] = h8{}; al2[mb] = i32x8{}; al01[mb] = i32x8{}; }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) { bh2[nb] = h8{}; bl2[nb] = i32x8{}; bl01[nb] = i32x8{}; }
+        constexpr int NM = MB * NBW, NF = MB + NBW;       // MFMAs per group; fragment reads per (tap, hi or lo)
+        // one fragment read: i < MB: weights of block i, else activations of pixel block i - MB; KX = the tap's slot offset in the slab
+        auto rd_hi = [&](auto i_, h8 (&a)[MB], h8 (&b)[NBW], const h8* wb, const h8* xb, auto kx_) {
+            constexpr int i = decltype(i_)::value, kx = decltype(kx_)::value;
+            constexpr int ko = kx == 0 ? KX0 : (kx == 1 ? KX1 : KX2);
+            if constexpr (i < MB) a[i] = wb[a_base + kx * 4 * CO_WG + i * 32];
+            else b[i - MB] = xb[b_base + (i - MB) * RPB * ROWPITCH + ko];
+        };
+        auto rd_lo = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, auto kx_) {
+            constexpr int i = decltype(i_)::value, q = decltype(q_)::value, kx = decltype(kx_)::value;
+            constexpr int ko = kx == 0 ? KX0 : (kx == 1 ? KX1 : KX2);
+            if constexpr (i < MB) { NB_Q(a[i], q, wb[a_base + kx * 4 * CO_WG + CO_WG + i * 32]); }
+            else { NB_Q(b[i - MB], q, xb[b_base + XPL + (i - MB) * RPB * ROWPITCH + ko]); }
+        };
+        // a group of NM MFMAs (tile k = (k / NBW, k % NBW)) with NFILL fillers dealt evenly into the gaps behind them
+        auto group = [&](auto nfill_, auto&& mf, auto&& ff) {
+            constexpr int NFILL = decltype(nfill_)::value;
+            nb_static_for<0, NM>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                mf(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{});
+                NB_SB;
+                nb_static_for<0, NFILL>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i * NM / (NFILL > 0 ? NFILL : 1) == k) ff(i_);
+                });
+                NB_SB;
+            });
+        };
+        auto mf_f16 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
+            return [&](auto mb_, auto nb_) {
+                constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+            };
+        };
+        auto mf_fp8 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
+            return [&](auto mb_, auto nb_) {
+                constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+                acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 0, 0, 0, sa, 0, sb);
+            };
+        };
+        auto no_mf = [&](auto, auto) {};
+        using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+        // step (c, S); ODD = parity of t = 3 c + S (selects the half of the tap-2 tuple).  Per accumulator tile the products arrive in the
+        // order of the per-step loop below: tap 2 of step t-1, on even t the tap-2 corrections of t-2 and t-1, tap 0, tap 1, corrections
+        // of taps 0 + 1.  Reads and pieces ride behind the MFMAs: a step opens with matrix work on registers it already holds.
+        auto step = [&](auto s_, auto odd_, auto first_, int c) {
+            constexpr int S = decltype(s_)::value, ODD = decltype(odd_)::value, FIRST = decltype(first_)::value;
+            using KN = std::integral_constant<int, (S + 1) % 3>;          // kind of the next step's list, of the one after
+            using KNN = std::integral_constant<int, (S + 2) % 3>;
+            constexpr int LEN_N = KN::value == 2 ? NWPW : NPC, FH_N = KN::value == 2 ? FH2 : FH01;
+            constexpr int FH_NN = KNN::value == 2 ? FH2 : FH01;
+            const int cn = S == 2 ? c + 1 : c, cnn = S == 0 ? c : c + 1;  // their chunks
+            const int t = 3 * c + S;
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // this step's data has landed, everybody's
+            NB_SB;
+            const h8* xb = xbuf + (S == 1 ? ((c + 1) & 1) : (c & 1)) * 4 * XPL + (S == 2 ? ROWPITCH : 0);
+            const h8* wb = wbuf + (t & 1) * WSLOTS;
+            auto rd_a = [&](auto i_) {                      // 2 NF reads: hi fragments of taps 0 and 1
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < NF) rd_hi(i_, ah0, bh0, wb, xb, T0{});
+                else rd_hi(std::integral_constant<int, i - NF>{}, ah1, bh1, wb, xb, T1{});
+            };
+            auto rd_b = [&](auto i_) {                      // 2 NF reads: lo tuples of taps 0 and 1
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < NF) rd_lo(i_, T0{}, al01, bl01, wb, xb, T0{});
+                else rd_lo(std::integral_constant<int, i - NF>{}, T1{}, al01, bl01, wb, xb, T1{});
+            };
+            auto dma_n = [&](auto i_) { piece2(KN{}, std::integral_constant<int, FH_N + decltype(i_)::value>{}, cn); };
+            auto dma_nn = [&](auto i_) { piece2(KNN{}, i_, cnn); };
+            if constexpr (FIRST) {
+                nb_static_for<0, 2 * NF>(rd_a); nb_static_for<0, 2 * NF>(rd_b); NB_SB;
+            } else {
+                group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah2, bh2), rd_a);                       // tap 2 of step t-1
+                if constexpr (!ODD) group(std::integral_constant<int, 2 * NF>{}, mf_fp8(al2, bl2), rd_b);   // tap-2 corrections of t-2, t-1
+            }
+            if constexpr (!FIRST && ODD) {
+                group(std::integral_constant<int, 2 * NF + LEN_N - FH_N>{}, mf_f16(ah0, bh0), [&](auto i_) {  // tap 0
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i < 2 * NF) rd_b(i_); else dma_n(std::integral_constant<int, i - 2 * NF>{});
+                });
+            } else {
+                group(std::integral_constant<int, LEN_N - FH_N>{}, mf_f16(ah0, bh0), dma_n);                // tap 0 | second half of the next list
+            }
+            group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah1, bh1), [&](auto i_) {                   // tap 1 | this step's tap-2 operands
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < NF) rd_hi(i_, ah2, bh2, wb, xb, T2{});
+                else rd_lo(std::integral_constant<int, i - NF>{}, std::integral_constant<int, ODD>{}, al2, bl2, wb, xb, T2{});
+            });
+            // the step's last fragment reads are in registers for every wave: the buffers it was the last reader of take new data
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            NB_SB;
+            group(std::integral_constant<int, FH_NN>{}, mf_fp8(al01, bl01), dma_nn);                        // corrections 0 + 1 | first half of the list after the next
+            (void)no_mf;
+        };
+        using O0 = std::integral_constant<int, 0>; using O1 = std::integral_constant<int, 1>;
+        if (p.tstamps) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH01) : "memory"); NB_TSTAMP(1); }      // (debug: when the first step could begin)
+        step(K0{}, O0{}, O1{}, 0); step(K1{}, O1{}, O0{}, 0); step(K2{}, O0{}, O0{}, 0);
+        for (int c = 1; c < NC; c += 2) {
+            step(K0{}, O1{}, O0{}, c); step(K1{}, O0{}, O0{}, c); step(K2{}, O1{}, O0{}, c);
+            if (c + 1 < NC) { step(K0{}, O0{}, O0{}, c + 1); step(K1{}, O1{}, O0{}, c + 1); step(K2{}, O0{}, O0{}, c + 1); }
+        }
+        NB_SB;
+        // the last step's tap 2 and the last tuple of tap-2 corrections (an odd number of steps: it holds one tap only)
+        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_f16(ah2, bh2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+        if (T & 1) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) al2[mb][r] = 0;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
+        }
+        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp8(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+#undef NB_Q
+#undef NB_SB
+    } else if constexpr (F8) {
         // Two buffers, and the LDS-DMA pieces of a step spread over the MFMA groups of the TWO steps before it -- a burst of eight
         // pieces right after a barrier stalls both waves of a SIMD at the same moment, with nobody feeding the matrix pipe (the
         // up=2 generator kernel's finding; there it was a third of the loop).  Step t's buffers are free once every wave has done
@@ -516,9 +737,17 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                              // staging buffers are dead from here on
+    NB_TSTAMP(2);
 
     // ---- epilogue: + bias, LeakyReLU; D[row = c_out, col = pixel]; tile pixel index = block * 32 + l31 ----
-    if (OUT == 0) {
+    if constexpr (DIRECT) {
+        if (p.out_f8) nb_set_fp16_ovfl();                         // f8 hand-off: the fp8 (and f16) conversions saturate
+        const float nz0[NBW] = {};
+        const size_t OHW8 = (size_t)p.hout * p.wout * 8;
+        nb_up1_handoff_epilogue<MB, NBW>(nb_handoff_args(p.yh2 + (size_t)p.cg0 * 2 * OHW8, p.c8_total, p.c_out, p.hout, p.wout, p.out_f8, 0, p.slope, 1.f, -1.f),
+                                         acc, nz0, s_one, s_bias, s_osc, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
+        NB_TSTAMP(3);
+    } else if (OUT == 0) {
         constexpr int PIX_WG = 256;
         float* ot = reinterpret_cast<float*>(smem_enc);           // [CO_WG][PIX_WG]
 #pragma unroll
@@ -537,6 +766,7 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                     ot[col * PIX_WG + (wn * NBW + nb) * 32 + l31] = v;
                 }
         __syncthreads();
+        NB_TSTAMP(3);
         for (int e = tid; e < CO_WG * (PIX_WG / 4); e += 512) {
             const int col = e / (PIX_WG / 4), q4 = e - col * (PIX_WG / 4);
             const int co = co0 + col;
@@ -584,6 +814,7 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 }
         }
         __syncthreads();
+        NB_TSTAMP(3);
         const int c8o = (p.c_out + 7) / 8;
         const size_t OHW8 = (size_t)p.hout * p.wout * 8;
         _Float16* yn = p.yh2 + ((size_t)n * p.c8_total + p.cg0) * 2 * OHW8;
@@ -597,19 +828,21 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             }
         }
     }
+    NB_TSTAMP(4);
 }
 
 template <int STRIDE, int LW, int OUT, bool F8 = false>
 static int launch_enc_conv(EncConvParams p, int n, hipStream_t st) {
-    constexpr int WT = 1 << LW, TH = 8 * (32 / WT), PW = WT + 2, SLOTS = STRIDE * TH * PW, XPL = ((SLOTS + 63) / 64) * 64;
+    constexpr int WT = 1 << LW, TH = 8 * (32 / WT), PW = WT + 2, SLOTS = (F8 && STRIDE == 2) ? (TH + 1) * 2 * PW : STRIDE * TH * PW, XPL = ((SLOTS + 63) / 64) * 64;
     constexpr size_t staging = (size_t)(2 * 4 * XPL + 2 * 12 * 128) * 16;
-    constexpr size_t epi = OUT == 0 ? (size_t)128 * 256 * 4 : (size_t)2 * 256 * (128 + 8) * 2;
+    constexpr size_t epi = OUT == 0 ? (size_t)128 * 256 * 4 : (LW == 5 ? 0 : (size_t)2 * 256 * (128 + 8) * 2);       // (32-wide hand-off tiles: no staging)
     constexpr size_t lds = staging > epi ? staging : epi;
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(lds + 3 * 128 * 4 <= 160 * 1024, "LDS budget (dynamic staging + the hand-off epilogue's static tables)");
     p.tiles_x = p.wout / WT; p.tiles_y = p.hout / TH; p.slices = (p.c_out + 127) / 128;
+    p.tstamps = (g_enc_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_enc_tstamps_cap) ? g_enc_tstamps : nullptr;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (+ static tables: the sum must fit 160 KB)
         attr_set = true;
     }
     hipLaunchKernelGGL((enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8>), dim3(p.tiles_x * p.tiles_y * p.slices, n), dim3(512), lds, st, p);

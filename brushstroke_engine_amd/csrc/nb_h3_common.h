@@ -142,6 +142,97 @@ __device__ __forceinline__ unsigned nb_pk4_fp8(float a, float b, float c, float 
     return (unsigned)w;
 }
 
+// Hand-off epilogue of the up=1 kernels (H2 or "f8" output into the consumer's operand tensor), straight from the
+// accumulators: no LDS image, no barrier.  D[row = c_out, col = pixel]: a lane holds, for ITS pixel, four consecutive
+// channels (4 lh .. 4 lh + 3) of each 8-channel group g; activation / consumer style / hi-lo split run packed over those
+// four; then lanes l and l+32 (same pixel, the two halves of every group) trade groups with v_permlane32_swap -- the lower
+// lane ends up with all 8 channels of the even groups, the upper lane with the odd ones -- and every lane stores whole
+// 16-byte slots (8-byte halves of the f8 lo slots) at consecutive pixels: 512 contiguous bytes per half-wave.
+// s_dco / s_bias / s_nst: the workgroup's per-channel tables (16-byte aligned); colbase = first channel of the wave's
+// 64-row band within them; trow0 = the wave's first tile row.
+// (The kernel parameters it needs come by value: handing the __global__ function's parameter struct on by reference makes
+//  the compiler keep a copy of it in scratch memory.)
+struct H3HandoffArgs {
+    _Float16* yh2;
+    int c8_next, c_out, h, w, out_f8, dbg;
+    float alpha, gain, clamp;
+};
+__device__ __forceinline__ H3HandoffArgs nb_handoff_args(_Float16* yh2, int c8_next, int c_out, int h, int w, int out_f8, int dbg, float alpha, float gain,
+                                                         float clamp) {
+    return H3HandoffArgs{yh2, c8_next, c_out, h, w, out_f8, dbg, alpha, gain, clamp};
+}
+template <int MB, int NBW>
+__device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, const f32x16 (&acc)[MB][NBW], const float (&nzr)[NBW], const float* s_dco,
+                                                        const float* s_bias, const float* s_nst, int colbase, int trow0, int co0, int n, int y0, int x0,
+                                                        int lh, int l31) {
+    const int W = p.w;
+    const size_t HW8 = (size_t)p.h * W * 8;
+    const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+    _Float16* yn = p.yh2 + (size_t)n * p.c8_next * 2 * HW8;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            // g (acc d + noise + bias), lrelu, clamp with the gain g folded into d, noise and bias (lrelu(g t) = g lrelu(t))
+            f32x4 d4[2], b4[2], ns4[2];
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int col = colbase + mb * 32 + 8 * (2 * gp + gi) + 4 * lh;
+                d4[gi] = *reinterpret_cast<const f32x4*>(s_dco + col) * p.gain;
+                b4[gi] = *reinterpret_cast<const f32x4*>(s_bias + col) * p.gain;
+                ns4[gi] = *reinterpret_cast<const f32x4*>(s_nst + col);
+            }
+            const int cg = (co0 + colbase + mb * 32) / 8 + 2 * gp + lh;     // the group this lane owns after the trade
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const float nzg = nzr[nb] * p.gain;
+                unsigned hi[2][2], lo[2][2];              // [group of the pair][dword]
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int r0 = 4 * (2 * gp + gi);
+                    const f32x4 a4 = {acc[mb][nb][r0], acc[mb][nb][r0 + 1], acc[mb][nb][r0 + 2], acc[mb][nb][r0 + 3]};
+                    f32x4 t = __builtin_elementwise_fma(a4, d4[gi], b4[gi] + nzg);
+                    const f32x4 ta = t * p.alpha;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t[i], ta[i], __builtin_inff()), -clampv, clampv);
+                    const f32x4 w = t * ns4[gi];
+                    const h2 h01 = __builtin_convertvector(f32x2{w[0], w[1]}, h2), h23 = __builtin_convertvector(f32x2{w[2], w[3]}, h2);
+                    const f32x4 xl = {nb_sub_f16(w[0], h01, false), nb_sub_f16(w[1], h01, true), nb_sub_f16(w[2], h23, false), nb_sub_f16(w[3], h23, true)};
+                    hi[gi][0] = __builtin_bit_cast(unsigned, h01); hi[gi][1] = __builtin_bit_cast(unsigned, h23);
+                    if (p.out_f8) {
+                        // (conversions saturate: FP16_OVFL is set when out_f8)
+                        const f32x4 s = xl * 512.f, q = w * 0.25f;
+                        lo[gi][0] = nb_pk4_fp8_sat(s[0], s[1], s[2], s[3]);
+                        lo[gi][1] = nb_pk4_fp8_sat(q[0], q[1], q[2], q[3]);
+                    } else {
+                        const h2 l01 = __builtin_convertvector(f32x2{xl[0], xl[1]}, h2), l23 = __builtin_convertvector(f32x2{xl[2], xl[3]}, h2);
+                        lo[gi][0] = __builtin_bit_cast(unsigned, l01); lo[gi][1] = __builtin_bit_cast(unsigned, l23);
+                    }
+                }
+                unsigned ha[2], hb[2], la[2], lb[2];      // a = channels 0-3, b = channels 4-7 of the owned group
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    ha[k] = hi[0][k]; hb[k] = hi[1][k]; la[k] = lo[0][k]; lb[k] = lo[1][k];
+                    nb_swap32(ha[k], hb[k]);
+                    nb_swap32(la[k], lb[k]);
+                }
+                if (cg * 8 < p.c_out && !(p.dbg & 1)) {
+                    const size_t pix8 = ((size_t)(y0 + trow0 + nb) * W + x0 + l31) * 8;
+                    *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2) * HW8 + pix8) = u32x4{ha[0], ha[1], hb[0], hb[1]};
+                    if (p.out_f8) {
+                        // the 16-channel chunk's two lo slots: (even group, lo) = fp8(xl 2^9), (odd group, lo) = fp8(v/4); this
+                        // group's 8 channels are bytes 8 (cg & 1) .. + 7 of both
+                        _Float16* lo_xl = yn + (size_t)((cg & ~1) * 2 + 1) * HW8 + pix8 + (cg & 1) * 4;
+                        *reinterpret_cast<u32x2*>(lo_xl) = u32x2{la[0], lb[0]};
+                        *reinterpret_cast<u32x2*>(lo_xl + 2 * HW8) = u32x2{la[1], lb[1]};
+                    } else {
+                        *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2 + 1) * HW8 + pix8) = u32x4{la[0], la[1], lb[0], lb[1]};
+                    }
+                }
+            }
+        }
+}
+
 struct H3Up2Params {
     const _Float16* x;      // H2 [n][c8][2][H][W][8]
     const _Float16* wts;    // [nchunks][9][2][2][co_ld][8]

@@ -52,6 +52,9 @@ void nb_debug_set_enc_small(int mode);
  * capacity_workgroups x 8 uint64 (s_memrealtime ticks; layout: tools/phase_times.py), NULL = off. */
 void nb_debug_set_timestamps(void* buf, int capacity_workgroups);
 void nb_debug_set_timestamps_f32(void* buf, int capacity_workgroups);
+/* The same for nb_enc_conv3x3_h3's large-tile kernel (slots: 0 start, 1 first step may begin -- f8 operands, stride 2 only --, 2 K loop
+ * done, 3 epilogue values staged in LDS, 4 end; tools/phase_times_enc.py). */
+void nb_debug_set_enc_timestamps(void* buf, int capacity_workgroups);
 
 /* The library's 64 KiB device page of zeros (source of out-of-image halo slots for the LDS-DMA staging); lazily
  * allocated, one per process. */
