@@ -67,17 +67,18 @@ struct StemParams {
 };
 
 __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
-    constexpr int TR = 16, TC = 32, PR = TR + 6, PC = TC + 6, NBW = 4, KS = 4, CP = 72;    // CP: padded channel pitch (halves)
+    constexpr int TR = 16, TC = 32, PR = TR + 6, PC = TC + 6, NBW = 4, KS = 4;
     constexpr int SC = 40;                                                                   // strip columns (38 + the zero-weight tap column 7)
-    if (p.out_f8) nb_enc_set_fp16_ovfl();                                                    // the fp8 (and f16) conversions saturate
+    if (p.out_f8) nb_set_fp16_ovfl();                                                        // the fp8 (and f16) conversions saturate
     __shared__ float tile[PR * PC];
-    __shared__ __attribute__((aligned(16))) _Float16 stage[4][2][32 * CP];                   // per wave: [hi/lo][pixel][channel]
+    __shared__ __attribute__((aligned(16))) float s_one[64], s_bias[64];                     // the epilogue's per-channel tables
     __shared__ __attribute__((aligned(16))) h8 strip[4][NBW][2][SC];                          // per wave and output row: [hi/lo][column] x 8 input rows
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lh = lane >> 5, l31 = lane & 31;
     const int n = blockIdx.y;
     const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
     const int y0 = ty * TR, x0 = tx * TC;
     const float* xn = p.x + (size_t)n * p.h * p.w;
+    if (tid < 64) { s_one[tid] = 1.f; s_bias[tid] = p.bias[tid]; }
     for (int e = tid; e < PR * PC; e += 256) {
         const int r = e / PC, c = e - r * PC;
         float v = xn[(size_t)nb_reflect(y0 + r - 3, p.h) * p.w + nb_reflect(x0 + c - 3, p.w)];
@@ -138,51 +139,10 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
             }
         }
     }
-    // epilogue: bias, LeakyReLU, hi/lo split, transpose through LDS to 16-byte H2 slots
-    _Float16* sh = stage[wv][0];
-    _Float16* sl = stage[wv][1];
-    const size_t HW8 = (size_t)p.h * p.w * 8;
-    _Float16* yn = p.y + (size_t)n * 8 * 2 * HW8;
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = mb * 32 + 8 * g + 4 * lh;
-                h4 vh, vl;
-                float vv[4], xl[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // LeakyReLU = max(t, slope t) for 0 <= slope <= 1 (the launcher checks); med3 with +inf is a max without the NaN
-                    // canonicalisation instructions fmaxf() costs
-                    const float t = acc[mb][nb][4 * g + j] + p.bias[co + j];
-                    const float v = __builtin_amdgcn_fmed3f(t, t * p.slope, __builtin_inff());
-                    const _Float16 hi = (_Float16)v;
-                    vv[j] = v; xl[j] = v - (float)hi;
-                    vh[j] = hi; vl[j] = (_Float16)xl[j];
-                }
-                *reinterpret_cast<h4*>(sh + l31 * CP + co) = vh;
-                if (p.out_f8) {
-                    // lo image as bytes: per 16-channel chunk 16 x fp8(xl 2^9) then 16 x fp8(v/4) (= the chunk's two lo slots)
-                    unsigned char* sb = reinterpret_cast<unsigned char*>(sl) + (size_t)l31 * (CP * 2) + (co >> 4) * 32 + (co & 15);
-                    *reinterpret_cast<unsigned*>(sb) = nb_enc_pk4_fp8_sat(xl[0] * 512.f, xl[1] * 512.f, xl[2] * 512.f, xl[3] * 512.f);
-                    *reinterpret_cast<unsigned*>(sb + 16) = nb_enc_pk4_fp8_sat(vv[0] * 0.25f, vv[1] * 0.25f, vv[2] * 0.25f, vv[3] * 0.25f);
-                } else {
-                    *reinterpret_cast<h4*>(sl + l31 * CP + co) = vl;
-                }
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes are done (wave-private stage)
-        const int oy = y0 + wv * NBW + nb;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = i * 64 + lane;             // 512 slots: [cg 8][hl 2][px 32]
-            const int cg = q >> 6, hl = (q >> 5) & 1, px = q & 31;
-            const h8 v = *reinterpret_cast<const h8*>((hl ? sl : sh) + px * CP + cg * 8);
-            *reinterpret_cast<h8*>(yn + (size_t)(cg * 2 + hl) * HW8 + ((size_t)oy * p.w + x0 + px) * 8) = v;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    }
+    // epilogue: bias, LeakyReLU, hi/lo split -- the generator's hand-off epilogue (nb_h3_common.h: straight from the accumulators, packed
+    // arithmetic, lane halves trade channel groups, whole 16-byte slots) with demodulation 1, no noise, gain 1, no clamp, scale 1
+    const float nz0[NBW] = {};
+    nb_up1_handoff_epilogue<2, NBW>(nb_handoff_args(p.y, 8, 64, p.h, p.w, p.out_f8, 0, p.slope, 1.f, -1.f), acc, nz0, s_one, s_bias, s_one, 0, wv * NBW, 0, n, y0, x0, lh, l31);
 }
 
 extern "C" int nb_enc_stem7x7_f32_h2_ex(const float* x, const float* w50, const float* bias, void* y_h2, int out_fmt, int n, int h, int w,
@@ -279,8 +239,8 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     // accumulators, packed arithmetic, lane-half trade, whole 16-byte slots) with demodulation 1, no noise, gain 1, no clamp --
     // the same expression as the staged epilogue below.  Its per-channel tables are fetched now, under the first LDS-DMA round trip.
     constexpr bool DIRECT = OUT == 1 && LW == 5;
-    __shared__ __attribute__((aligned(16))) float s_one[DIRECT ? CO_WG : 1], s_bias[DIRECT ? CO_WG : 1], s_osc[DIRECT ? CO_WG : 1];
-    if constexpr (DIRECT) {
+    __shared__ __attribute__((aligned(16))) float s_one[CO_WG], s_bias[CO_WG], s_osc[CO_WG];
+    {
         if (tid < CO_WG) {
             const int co = co0 + tid;
             s_one[tid] = 1.f;
@@ -760,8 +720,8 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                     const int co = co0 + col;
                     float v = 0.f;
                     if (co < p.c_out) {
-                        v = nb_lrelu(acc[mb][nb][r] + p.bias[co], p.slope);
-                        if (p.oscale) v *= p.oscale[(size_t)n * p.oscale_stride + co];
+                        v = nb_lrelu(acc[mb][nb][r] + s_bias[col], p.slope);
+                        if (p.oscale) v *= s_osc[col];
                     }
                     ot[col * PIX_WG + (wn * NBW + nb) * 32 + l31] = v;
                 }
@@ -795,8 +755,8 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                         const int co = co0 + col + j;
                         float v = 0.f;
                         if (co < p.c_out) {
-                            v = nb_lrelu(acc[mb][nb][4 * g + j] + p.bias[co], p.slope);
-                            if (p.oscale) v *= p.oscale[(size_t)n * p.oscale_stride + co];
+                            v = nb_lrelu(acc[mb][nb][4 * g + j] + s_bias[col + j], p.slope);
+                            if (p.oscale) v *= s_osc[col + j];
                         }
                         const _Float16 hi = (_Float16)v;
                         vv[j] = v; xl[j] = v - (float)hi;
