@@ -32,6 +32,9 @@ cd $R
 python tools/make_hbm_traffic.py $O/hbm_traffic.json "${GIT_HEAD:-unknown}" f8=$O/pmc_mem_f8.json h3=$O/pmc_mem_h3.json f32=$O/pmc_mem_f32.json > $O/hbm_traffic.log 2>&1
 cp $O/hbm_traffic.json $R/profiles/hbm_traffic.json
 NB_PHASE_F8=1 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times.txt 2>&1
+python tools/phase_times_enc.py > $O/phase_times_encoder.txt 2>&1
+# up=2 launches: L2-boundary reads with the round-3 workgroup order (NB_DEBUG=32) and the whole-grid XCD order, then the timing A/B
+bash tools/ab_xcd_traffic.sh > $O/ab_xcd_order.txt 2>&1
 # same-box A/Bs of the round's K loops: round-3 kernels vs software-pipelined ones (up=2: also the one-wave-per-SIMD wide form)
 bash tools/ab_v2.sh $O/ab_v2 > $O/ab_up2_kernels.txt 2>&1; rm -rf $O/ab_v2
 bash tools/ab_up1.sh $O/ab_up1 > $O/ab_up1_kloops.txt 2>&1; rm -rf $O/ab_up1
