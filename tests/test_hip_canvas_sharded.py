@@ -89,3 +89,22 @@ def test_bench_canvas_self_launches_ranks():
     assert out["n_streams"] in (1, 2) and out["stream_probe"]["chosen"] == out["n_streams"]
     r = subprocess.run(cmd, env=dict(env, NB_BENCH_FAIL_RANK="1"), cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_lamali_two_ranks_line_names_its_ranks():
+    """`tools/bench_lamali.py --gpus 2` (BASELINE config 3 on its named input): the N > 1 line says who took part (`rccl`) and what the
+    halo exchange and the tile gather cost each rank, beside the distance from the reference-painted canvas."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"NB_BENCH_SHARE_GPU": "1", "NB_BENCH_BACKEND": "gloo"})
+    cmd = [sys.executable, os.path.join(REPO, "tools", "bench_lamali.py"), "--gpus", "2", "--steps", "2"]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl"]["world"] == 2 and out["rccl"]["distinct_devices"] == 1
+    assert [r_["rank"] for r_ in out["rccl"]["ranks_seen"]] == [0, 1]
+    l2 = out["feature_blending_2"]
+    assert l2["vs_reference_canvas"]["max_lsb"] <= 1 and len(l2["halo_exchange_ms"]) == 2 and len(l2["gather_wait_ms"]) == 2
+    assert all(v is not None and v >= 0 for v in l2["gather_wait_ms"])

@@ -23,16 +23,20 @@ def main():
         raise SystemExit(launch.self_launch(__file__, sys.argv[1:], a.gpus))
     rank, world, dev, backend = launch.init()
     launch.preflight(dev, rank, world)
+    fabric = launch.fabric_report(dev, rank, world, backend)
     res = {}
     for level in (2, 0):
         a.level = level
         res[level] = bench_canvas.run(a, rank, world, dev, backend)
     if rank == 0:
         keep = lambda r: {k: r[k] for k in ("value", "unit", "seconds", "tiles", "halo_bytes_per_rank", "vs_reference_canvas", "breakdown_ms",
-                                             "breakdown_ms_per_rank") if k in r}
-        print(json.dumps({"metric": "lamali_sm.png end to end (host geometry -> host RGBA), 12 tiles of 256x256", "n_gpus": world,
-                          "conv_mode": a.conv_mode, "parallelism": res[2]["parallelism"], "image": res[2]["canvas"],
-                          "feature_blending_2": keep(res[2]), "feature_blending_0": keep(res[0])}), flush=True)
+                                             "breakdown_ms_per_rank", "n_streams", "halo_exchange_ms", "gather_wait_ms", "ms_per_step_per_rank") if k in r}
+        line = {"metric": "lamali_sm.png end to end (host geometry -> host RGBA), 12 tiles of 256x256", "n_gpus": world,
+                "conv_mode": a.conv_mode, "parallelism": res[2]["parallelism"], "image": res[2]["canvas"],
+                "feature_blending_2": keep(res[2]), "feature_blending_0": keep(res[0])}
+        if world > 1:
+            line["rccl"] = fabric                           # who took part (launch.fabric_report): world, backend, ranks seen, distinct devices
+        print(json.dumps(line), flush=True)
     launch.finish(world)
 
 
