@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
     if (p.out_f8) nb_set_fp16_ovfl();                                                        // the fp8 (and f16) conversions saturate
     __shared__ float tile[PR * PC];
     __shared__ __attribute__((aligned(16))) float s_one[64], s_bias[64];                     // the epilogue's per-channel tables
+    __shared__ __attribute__((aligned(16))) h8 wfrag[2][KS][2][64];                          // weight fragments [mb][K step][hi/lo][lane]
     __shared__ __attribute__((aligned(16))) h8 strip[4][NBW][2][SC];                          // per wave and output row: [hi/lo][column] x 8 input rows
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lh = lane >> 5, l31 = lane & 31;
     const int n = blockIdx.y;
@@ -86,21 +87,31 @@ __global__ __launch_bounds__(256) void enc_stem7x7_kernel(const StemParams p) {
         else if (p.preproc == 2) v = 1.f - v;                   // 'inverse'
         tile[e] = v;
     }
-    // A fragments: lane (row = c_out l31, k group lh) of K step s holds w[c_out][tap rows 0..7][tap column 2s + lh] (row / column 7: zero), hi and lo
-    h8 wah[2][KS], wal[2][KS];
+    // A fragments: lane (row = c_out l31, k group lh) of K step s holds w[c_out][tap rows 0..7][tap column 2s + lh] (row / column 7: zero), hi and lo.
+    // All four waves need the same 16 fragments per lane: each wave builds a quarter (one (mb, s-pair): 16 loads + splits per lane instead
+    // of 64) and they trade through LDS.
+    {
+        const int mb = wv >> 1, s0 = (wv & 1) * 2;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int b = 2 * s + lh;
+        for (int ss = 0; ss < 2; ++ss) {
+            const int b = 2 * (s0 + ss) + lh;
+            h8 hi8, lo8;
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 const float wv_ = (a < 7 && b < 7) ? p.w50[(mb * 32 + l31) * 50 + a * 7 + b] : 0.f;
                 const _Float16 hi = (_Float16)wv_;
-                wah[mb][s][a] = hi; wal[mb][s][a] = (_Float16)(wv_ - (float)hi);
+                hi8[a] = hi; lo8[a] = (_Float16)(wv_ - (float)hi);
             }
+            wfrag[mb][s0 + ss][0][lane] = hi8;
+            wfrag[mb][s0 + ss][1][lane] = lo8;
         }
+    }
     __syncthreads();
+    h8 wah[2][KS], wal[2][KS];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { wah[mb][s] = wfrag[mb][s][0][lane]; wal[mb][s] = wfrag[mb][s][1][lane]; }
     // this wave's strips: lane = column, eight input rows of output row (wv NBW + nb) as one 16-byte slot per half
     if (lane < SC) {
 #pragma unroll
