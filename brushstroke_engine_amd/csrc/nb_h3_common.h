@@ -111,6 +111,17 @@ __device__ __forceinline__ unsigned nb_pk4_fp8_sat(float a, float b, float c, fl
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (unsigned)w;
 }
+// ... of a x 2^k, b x 2^k, ... with the scaling inside the conversion (v_cvt_scalef32_pk_fp8_f32 divides by its scale operand: pass
+// 2^-k).  Bit-identical to "multiply, then nb_pk4_fp8_sat" for every finite input, denormal results and saturation included
+// (tools/microbench/cvt_scale_fp8.hip: 1M random pairs per scaling, with and without FP16_OVFL; only +-inf differs -- 448 here, NaN
+// there -- and the epilogues' values are clamped), at two packed multiplies less per four values.
+typedef short nb_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned nb_pk4_fp8_sat_scaled(float a, float b, float c, float d, float inv_scale) {
+    nb_s16x2 w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, a, b, inv_scale, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c, d, inv_scale, true);
+    return __builtin_bit_cast(unsigned, w);
+}
 __device__ __forceinline__ void nb_set_fp16_ovfl() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 // v_permlane32_swap: exchanges a[lanes 32..63] with b[lanes 0..31] in place.  Afterwards lanes 0..31 hold (a, b) = (their
@@ -201,9 +212,9 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
                     hi[gi][0] = __builtin_bit_cast(unsigned, h01); hi[gi][1] = __builtin_bit_cast(unsigned, h23);
                     if (p.out_f8) {
                         // (conversions saturate: FP16_OVFL is set when out_f8)
-                        const f32x4 s = xl * 512.f, q = w * 0.25f;
-                        lo[gi][0] = nb_pk4_fp8_sat(s[0], s[1], s[2], s[3]);
-                        lo[gi][1] = nb_pk4_fp8_sat(q[0], q[1], q[2], q[3]);
+                        // (x 2^9 and x 2^-2 inside the conversions: nb_pk4_fp8_sat_scaled)
+                        lo[gi][0] = nb_pk4_fp8_sat_scaled(xl[0], xl[1], xl[2], xl[3], 0x1p-9f);
+                        lo[gi][1] = nb_pk4_fp8_sat_scaled(w[0], w[1], w[2], w[3], 4.f);
                     } else {
                         const h2 l01 = __builtin_convertvector(f32x2{xl[0], xl[1]}, h2), l23 = __builtin_convertvector(f32x2{xl[2], xl[3]}, h2);
                         lo[gi][0] = __builtin_bit_cast(unsigned, l01); lo[gi][1] = __builtin_bit_cast(unsigned, l23);

@@ -1572,9 +1572,9 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
                             lo[dy][px][0] = __builtin_bit_cast(unsigned, l01); lo[dy][px][1] = __builtin_bit_cast(unsigned, l23);
                         } else {
                             // (conversions saturate: FP16_OVFL is set for this kernel)
-                            const f32x4 s = xl * 512.f, q = w * 0.25f;
-                            lo[dy][px][0] = nb_pk4_fp8_sat(s[0], s[1], s[2], s[3]);
-                            lo[dy][px][1] = nb_pk4_fp8_sat(q[0], q[1], q[2], q[3]);
+                            // (x 2^9 and x 2^-2 inside the conversions: nb_pk4_fp8_sat_scaled)
+                            lo[dy][px][0] = nb_pk4_fp8_sat_scaled(xl[0], xl[1], xl[2], xl[3], 0x1p-9f);
+                            lo[dy][px][1] = nb_pk4_fp8_sat_scaled(w[0], w[1], w[2], w[3], 4.f);
                         }
                     }
                 // lanes l (channels 0-3 of the group) and l+32 (channels 4-7) trade rows: afterwards a lane holds output row

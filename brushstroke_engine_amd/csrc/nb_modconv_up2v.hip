@@ -534,9 +534,9 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                             const h2 l01 = __builtin_convertvector(f32x2{xl[0], xl[1]}, h2), l23 = __builtin_convertvector(f32x2{xl[2], xl[3]}, h2);
                             lo[dy][px][0] = __builtin_bit_cast(unsigned, l01); lo[dy][px][1] = __builtin_bit_cast(unsigned, l23);
                         } else {
-                            const f32x4 s = xl * 512.f, q = w * 0.25f;
-                            lo[dy][px][0] = nb_pk4_fp8_sat(s[0], s[1], s[2], s[3]);
-                            lo[dy][px][1] = nb_pk4_fp8_sat(q[0], q[1], q[2], q[3]);
+                            // (x 2^9 and x 2^-2 inside the conversions: nb_pk4_fp8_sat_scaled)
+                            lo[dy][px][0] = nb_pk4_fp8_sat_scaled(xl[0], xl[1], xl[2], xl[3], 0x1p-9f);
+                            lo[dy][px][1] = nb_pk4_fp8_sat_scaled(w[0], w[1], w[2], w[3], 4.f);
                         }
                     }
                 unsigned ha[2][2], hb[2][2], la[2][2], lb[2][2];
