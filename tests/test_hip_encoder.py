@@ -247,7 +247,11 @@ def _f8_decode(t, c):
 
 @pytest.mark.parametrize("stride,ci,co,h,w,h2out", [(1, 16, 256, 32, 32, False), (2, 64, 128, 64, 64, True),
                                                      (2, 256, 256, 32, 32, True), (1, 256, 32, 16, 16, True),
-                                                     (2, 128, 256, 64, 128, False), (1, 48, 16, 16, 32, False)])
+                                                     (2, 128, 256, 64, 128, False), (1, 48, 16, 16, 32, False),
+                                                     # stride 2 with per-chunk slabs (round 4): odd chunk counts, ONE chunk, ragged c_out slices,
+                                                     # 16-wide tiles, a single tile row
+                                                     (2, 48, 136, 32, 64, False), (2, 80, 48, 64, 64, True), (2, 16, 16, 32, 32, True),
+                                                     (2, 16, 24, 16, 64, False), (2, 112, 272, 48, 64, True)])
 def test_enc_conv_layer_f8(stride, ci, co, h, w, h2out):
     """The same layer with "f8" operands (one f16 + half an fp8 MFMA per tap; the third tap's corrections paired across
     K steps -- odd and even step counts are both here) against torch fp64: the fp8 correction terms leave
