@@ -694,8 +694,10 @@ class PaintingHelper:
         join = getattr(ops, "join_streams", lambda tensors=(): None)
         # workspace slots of the painting schedule: disjoint from the generator's own sub-batch slots (1..sub_streams), whose
         # side-stream kernels of an un-joined throughput call may still be reading theirs
-        if n_own > self.batch and hasattr(ops, "choose_streams"):
-            ops.choose_streams(min(self.batch, n_own), self.render_mode)        # 1 or 2 batch streams: measured, once
+        # 1 or 2 batch streams: measured, once per TileOps -- by jobs long enough for the ~80 ms probe to be noise (smaller ones keep the
+        # default of two: what they could gain or lose is a fraction of a millisecond)
+        if n_own >= 6 * self.batch and hasattr(ops, "choose_streams"):
+            ops.choose_streams(min(self.batch, n_own), self.render_mode)
         plan_slot = lambda k: PAINT_SLOT0 + k % getattr(ops, "n_streams", 1)
         if n_own <= self.batch:                      # a single batch (interactive strokes): nothing to overlap with
             on_stream, join, plan_slot = (lambda k: contextlib.nullcontext()), (lambda tensors=(): None), (lambda k: 0)

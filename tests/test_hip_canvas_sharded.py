@@ -86,7 +86,8 @@ def test_bench_canvas_self_launches_ranks():
     assert out["rccl"]["world"] == 2 and [r_["rank"] for r_ in out["rccl"]["ranks_seen"]] == [0, 1]
     assert len(out["halo_exchange_ms"]) == 2 and len(out["gather_wait_ms"]) == 2
     assert all(v is not None and v >= 0 for v in out["gather_wait_ms"]) and out["halo_exchange_ms"][1] is not None
-    assert out["n_streams"] in (1, 2) and out["stream_probe"]["chosen"] == out["n_streams"]
+    # (the stream probe runs for jobs of >= 6 batches per rank only: this one keeps the default of two streams)
+    assert out["n_streams"] in (1, 2) and (out["stream_probe"] is None or out["stream_probe"]["chosen"] == out["n_streams"])
     r = subprocess.run(cmd, env=dict(env, NB_BENCH_FAIL_RANK="1"), cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
