@@ -85,11 +85,14 @@ __global__ __launch_bounds__(256) void canvas_replay_kernel(ReplayParams p) {
         const float a = 1.f - (m ? a0 : 1.f);
         const float na = 1.f - a;
         float* tp = p.tiles + ((size_t)t * p.c + c0) * tplane + (size_t)ly * p.hw + lx;
+        // (where nothing was painted before -- m false: a = 0, na = 1 -- the blend returns the tile's own value: nothing to write back,
+        //  and nothing to read unless the tile updates the canvas here.  Most pixels of a fresh canvas: ~3 GB less traffic per 400 tiles)
+        if (!m && !upd) continue;
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
             if (c0 + c < p.c) {
                 const float f = a * cv[c] + na * tp[(size_t)c * tplane];
-                tp[(size_t)c * tplane] = f;
+                if (m) tp[(size_t)c * tplane] = f;
                 if (upd) cv[c] = f;
             }
         }
@@ -185,11 +188,12 @@ __global__ __launch_bounds__(256) void canvas_replay_pieces_kernel(ReplayPiecesP
         const float a = 1.f - (m ? a0 : 1.f);
         const float na = 1.f - a;
         float* tp = (float*)pc.data + (size_t)c0 * pc.cstride + (size_t)py * pc.rstride + px;
+        if (!m && !upd) continue;                // (as in canvas_replay_kernel: the blend is the identity where nothing was painted before)
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
             if (c0 + c < p.c) {
                 const float f = a * cv[c] + na * tp[(size_t)c * pc.cstride];
-                tp[(size_t)c * pc.cstride] = f;
+                if (m) tp[(size_t)c * pc.cstride] = f;
                 if (upd) cv[c] = f;
             }
         }
