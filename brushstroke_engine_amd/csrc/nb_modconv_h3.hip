@@ -83,12 +83,11 @@ __device__ __forceinline__ float nb_h3_act(float a, float dg, float nbg, float a
 
 // NBW_ = 32-pixel rows per wave: 2 for throughput, 1 (half the pixels per workgroup, twice the workgroups) when the
 // launch would otherwise leave most of the chip idle - the batch-1 / interactive configuration.
-// V2 (f8 operands only): the K loop in the form of modconv3x3_up2v_kernel (nb_modconv_up2v.hip) -- LDS-DMA from inline assembly
+// V2: the K loop in the form of modconv3x3_up2v_kernel (nb_modconv_up2v.hip) -- LDS-DMA from inline assembly
 // (counted lgkmcnt waits), the step's barrier in front of its last two MFMA groups with the next step's first operands read under
 // them, fragment reads and DMA pieces dealt out between the MFMAs.  Same per-accumulator order of products: bit-identical.
 template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
-    static_assert(!V2 || F8, "the software-pipelined K loop exists for f8 operands");
     NB_TSTAMP(0);
     if (p.out_f8) nb_set_fp16_ovfl();             // f8 hand-off: the fp8 (and f16) conversions saturate
     nb_stagger(p.stagger_ticks, 256);
@@ -390,6 +389,96 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         }
         nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp8(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
 #undef NB_Q
+#undef NB_SB
+    } else if constexpr (V2) {
+        // ---- H2 operands (the `h3` arithmetic: hi x hi, hi x lo, lo x hi per tap), software-pipelined over the barrier like the
+        //      f8 loop above.  Per accumulator tile the nine products of a step arrive in the order of the loop below (tap by tap:
+        //      hh, hl, lh): bit-identical.  Step t:
+        //   part A:  taps 0 and 1 (six groups of four MFMAs: one product kind of one tap over the four tiles -- no two MFMAs in a row on
+        //            one accumulator)            fillers: the step's LDS-DMA pieces, its tap-2 fragments
+        //   wait (counted) + barrier: every wave has read ALL of stage t; stage t+1 has landed
+        //   part B:  tap 2 (three groups)         fillers: the sixteen fragments of taps 0 and 1 of step t+1
+#define NB_SB __builtin_amdgcn_sched_barrier(0)
+        h8 ah[3][MB], al[3][MB], bh[3][NBW], bl[3][NBW];           // [tap][block]
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) { ah[k][mb] = h8{}; al[k][mb] = h8{}; }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) { bh[k][nb] = h8{}; bl[k][nb] = h8{}; }
+        }
+        constexpr int NM = MB * NBW, NF = MB + NBW;
+        // fragment read j of a tap (0 .. 2 NF - 1): hi fragments (weights of block i, then activations of pixel row i - MB), then lo
+        auto rd = [&](auto j_, auto kx_, const h8* wb, const h8* xb, int ky) {
+            constexpr int j = decltype(j_)::value, kx = decltype(kx_)::value, hl = j / NF, i = j % NF;
+            if constexpr (i < MB) (hl ? al : ah)[kx][i] = wb[a_base + kx * 4 * CO_WG + hl * CO_WG + i * 32];
+            else (hl ? bl : bh)[kx][i - MB] = xb[b_base + hl * XPL + (i - MB + ky) * TWP + kx];
+        };
+        // group g of NG: NM MFMAs of one product kind with the fillers [g L / NG, (g + 1) L / NG) of a list of L dealt into its gaps
+        auto group = [&](auto g_, auto ng_, auto l_, auto&& mf, auto&& item) {
+            constexpr int g = decltype(g_)::value, NG = decltype(ng_)::value, L = decltype(l_)::value;
+            constexpr int lo = g * L / NG, hi = (g + 1) * L / NG, NFILL = hi - lo;
+            nb_static_for<0, NM>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                mf(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{});
+                NB_SB;
+                nb_static_for<0, NFILL>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i * NM / (NFILL > 0 ? NFILL : 1) == k) item(std::integral_constant<int, lo + i>{});
+                });
+                NB_SB;
+            });
+        };
+        // product kind q of tap kx: 0 = hi x hi, 1 = hi x lo, 2 = lo x hi
+        auto mf = [&](auto kx_, auto q_) {
+            return [&](auto mb_, auto nb_) {
+                constexpr int kx = decltype(kx_)::value, q = decltype(q_)::value, mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q == 2 ? al[kx][mb] : ah[kx][mb], q == 1 ? bl[kx][nb] : bh[kx][nb], acc[mb][nb], 0, 0, 0);
+            };
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+        using I6 = std::integral_constant<int, 6>;
+        auto step = [&](auto ky_, int t, int c) {
+            constexpr int KY = decltype(ky_)::value;
+            constexpr int NDMA = NWPW + (KY == 0 ? NXPW : 0);
+            const h8* xb = xbuf + (c & 1) * 4 * XPL;
+            const h8* wb = wring + (t & 3) * WSLOTS;
+            const int tn = t + 1, cn = KY == 2 ? c + 1 : c;
+            constexpr int KYN = KY == 2 ? 0 : KY + 1;
+            const h8* xbn = xbuf + (cn & 1) * 4 * XPL;
+            const h8* wbn = wring + (tn & 3) * WSLOTS;
+            const int t3 = clampt(t + 3), c1 = c + 1 < NC ? c + 1 : NC - 1;
+            // part A's fillers: the pieces, then this step's tap-2 fragments
+            using LA = std::integral_constant<int, NDMA + 2 * NF>;
+            auto item_a = [&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < NWPW) issue_w_v2(i_, t3, (t + 3) & 3);
+                else if constexpr (i < NDMA) issue_x_v2(std::integral_constant<int, i - NWPW>{}, c1, (c + 1) & 1);
+                else rd(std::integral_constant<int, i - NDMA>{}, I2{}, wb, xb, KY);
+            };
+            // part B's: taps 0 and 1 of step t + 1
+            using LB = std::integral_constant<int, 4 * NF>;
+            auto item_b = [&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < 2 * NF) rd(i_, I0{}, wbn, xbn, KYN);
+                else rd(std::integral_constant<int, i - 2 * NF>{}, I1{}, wbn, xbn, KYN);
+            };
+            NB_SB;
+            group(I0{}, I6{}, LA{}, mf(I0{}, I0{}), item_a); group(I1{}, I6{}, LA{}, mf(I0{}, I1{}), item_a); group(I2{}, I6{}, LA{}, mf(I0{}, I2{}), item_a);
+            group(I3{}, I6{}, LA{}, mf(I1{}, I0{}), item_a); group(I4{}, I6{}, LA{}, mf(I1{}, I1{}), item_a); group(I5{}, I6{}, LA{}, mf(I1{}, I2{}), item_a);
+            // everything issued before sub-chunk t-1 has landed (it is what step t+1 reads); all reads of stage t are done
+            if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW + NXPW) : "memory");
+            NB_SB;
+            group(I0{}, I3{}, LB{}, mf(I2{}, I0{}), item_b); group(I1{}, I3{}, LB{}, mf(I2{}, I1{}), item_b); group(I2{}, I3{}, LB{}, mf(I2{}, I2{}), item_b);
+            NB_SB;
+        };
+        // operands of step 0
+        nb_static_for<0, 2 * NF>([&](auto j_) { rd(j_, I0{}, wring, xbuf, 0); });
+        nb_static_for<0, 2 * NF>([&](auto j_) { rd(j_, I1{}, wring, xbuf, 0); });
+        for (int c = 0; c < NC; ++c) { step(I0{}, 3 * c, c); step(I1{}, 3 * c + 1, c); step(I2{}, 3 * c + 2, c); }
+        NB_SB;
 #undef NB_SB
     } else if constexpr (F8) {
         // ---- f8 operands: explicitly ordered, software-pipelined step -------------------------------------------
@@ -977,16 +1066,18 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const long wgs_full = (long)n * (w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64));
     const bool half = g_force_nbw ? g_force_nbw == 1 : wgs_full < 160;
     hipStream_t st = (hipStream_t)stream;
-    // f8 operands: the software-pipelined K loop (V2) unless switched off (test hook / NB_UP1_V2=0)
+    // the software-pipelined K loop (V2; both operand formats) unless switched off (test hook / NB_UP1_V2=0)
     static const int env_v2 = getenv("NB_UP1_V2") ? atoi(getenv("NB_UP1_V2")) : -1;
     const bool v2 = (g_force_up1_v2 >= 0 ? g_force_up1_v2 : env_v2) != 0;
     if (half) {
         if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 1, true>(p, n, st) : launch_h3<1, true, 1, true>(p, n, st);
         if (f8) return c_out > 64 ? launch_h3<2, true, 1>(p, n, st) : launch_h3<1, true, 1>(p, n, st);
+        if (v2) return c_out > 64 ? launch_h3<2, false, 1, true>(p, n, st) : launch_h3<1, false, 1, true>(p, n, st);
         return c_out > 64 ? launch_h3<2, false, 1>(p, n, st) : launch_h3<1, false, 1>(p, n, st);
     }
     if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 2, true>(p, n, st) : launch_h3<1, true, 2, true>(p, n, st);
     if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
+    if (v2) return c_out > 64 ? launch_h3<2, false, 2, true>(p, n, st) : launch_h3<1, false, 2, true>(p, n, st);
     if (c_out > 64) return launch_h3<2>(p, n, st);
     return launch_h3<1>(p, n, st);
 }

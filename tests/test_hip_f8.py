@@ -229,11 +229,9 @@ def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
     res = {}
     try:
         for rows in (2, 1, "2old", "1old"):
-            # ("old": the round-3 K loop of the f8 kernel; the default is the software-pipelined one)
+            # ("old": the round-3 K loop; the default is the software-pipelined one, in both operand formats)
             lib.nb_debug_set_up1_rows(int(str(rows)[0]))
             lib.nb_debug_set_up1_v2(0 if str(rows).endswith("old") else 1)
-            if not fmt and str(rows).endswith("old"):
-                continue
             y = torch.empty([n, co, h, w], device="cuda")
             out = torch.zeros(ops.h2_shape(n, co, h, w), dtype=torch.float16, device="cuda")
             common = (dco.data_ptr(), noise.data_ptr(), h * w, bias.data_ptr())
@@ -248,9 +246,8 @@ def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
         lib.nb_debug_set_up1_v2(-1)
     assert torch.equal(res[2][0], res[1][0])
     assert torch.equal(res[2][1], res[1][1])
-    if fmt:
-        for k in ("2old", "1old"):
-            assert torch.equal(res[2][0], res[k][0]) and torch.equal(res[2][1], res[k][1]), k
+    for k in ("2old", "1old"):
+        assert torch.equal(res[2][0], res[k][0]) and torch.equal(res[2][1], res[k][1]), k
     ref = _conv_ref(x, wt, st, 1) * dco.double().cpu()[:, :, None, None] + noise.double().cpu()[:, None]
     ref = torch.nn.functional.leaky_relu(ref + bias.double().cpu()[None, :, None, None], 0.2) * 1.4142135
     assert float((res[1][0].double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
