@@ -1068,7 +1068,9 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     hipStream_t st = (hipStream_t)stream;
     // the software-pipelined K loop (V2; both operand formats) unless switched off (test hook / NB_UP1_V2=0)
     static const int env_v2 = getenv("NB_UP1_V2") ? atoi(getenv("NB_UP1_V2")) : -1;
-    const bool v2 = (g_force_up1_v2 >= 0 ? g_force_up1_v2 : env_v2) != 0;
+    // (its pieces walk the chunks with a fixed per-chunk stride: whole 16-channel chunks only -- f8 operands always are; H2 operands
+    //  with an odd number of channel groups keep the round-3 loop, whose last chunk reads the missing group from the zero page)
+    const bool v2 = (g_force_up1_v2 >= 0 ? g_force_up1_v2 : env_v2) != 0 && (f8 || p.c8 % 2 == 0);
     if (half) {
         if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 1, true>(p, n, st) : launch_h3<1, true, 1, true>(p, n, st);
         if (f8) return c_out > 64 ? launch_h3<2, true, 1>(p, n, st) : launch_h3<1, true, 1>(p, n, st);
