@@ -209,11 +209,14 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
 
 
 @pytest.mark.parametrize("fmt", [0, 1])
-@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 32, 64), (64, 64, 48, 32), (48, 64, 32, 32), (16, 128, 16, 32)])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 32, 64), (64, 64, 48, 32), (48, 64, 32, 32), (16, 128, 16, 32), (40, 64, 32, 32)])
 def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
     """The 8-wave up=1 split-f16 kernel runs with 2 (throughput) or 1 (under-filled launches, batch 1) pixel rows per
     wave; same per-pixel arithmetic, so fp32 and hand-off outputs must be bit-identical."""
     from brushstroke_engine_amd import _lib, ops
+    if fmt and ci % 16:
+        pytest.skip("f8 operands need whole 16-channel chunks (an odd number of channel groups is an H2 case: the last chunk's missing group "
+                    "comes from the zero page, and the software-pipelined loop leaves such layers to the round-3 loop)")
     rs = np.random.RandomState(ci + h + fmt)
     n = 2
     x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32)).cuda()
