@@ -499,6 +499,66 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
     }
 
 
+MAX_LINE_BYTES = 4096               # the final stdout line: the driver keeps the last 8 KB of stdout
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None} if isinstance(d, dict) else None
+
+
+def compact_roofline(r):
+    """The roofline object without its tables and prose (those are in bench_detail.json)."""
+    c = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_sustained", "traffic", "launch_ms", "launches_per_step",
+                  "flops_per_launch", "patches_per_launch"))
+    c.setdefault("traffic", None)
+    if r.get("hbm"):
+        c["hbm"] = _pick(r["hbm"], ("achieved", "peak", "unit", "frac"))
+    return c
+
+
+def compact_line(out):
+    """What goes to stdout: the contract's keys, numbers only (no calibration tables, no per-layer times, no explanatory strings)."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "conv_mode", "data"))
+    c["vs_baseline"] = None
+    c["dtype"] = out["dtype"].split(",")[0].split(":")[0][:90]
+    cfg_ = out["config"]
+    c["config"] = {"workload": cfg_["workload"].split(";")[0], "batch_per_gpu": cfg_["batch_per_gpu"], "resolution": cfg_["resolution"],
+                   "gflop_per_patch": cfg_["gflop_per_patch"], "parallelism": cfg_["parallelism"].split(" inside every step")[0]}
+    c["roofline"] = compact_roofline(out["roofline"])
+    ws = out.get("roofline_whole_step") or {}
+    c["roofline_whole_step"] = _pick(ws, ("achieved", "unit", "scheme_ceiling", "frac_of_scheme_ceiling"))
+    if out.get("cpu_baseline"):
+        c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        c["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "").split(" (")[0]
+        par = out["cpu_baseline"].get("parity")
+        if par:
+            c["parity"] = _pick(par, ("max_abs_rgba_vs_oracle", "max_u8_diff", "tolerance", "patches"))
+    c["box_calibration"] = _pick(out.get("box_calibration") or {}, ("mfma_f16_sustained_tflops", "loop_clock_mhz"))
+    c["telemetry"] = _pick(out.get("telemetry") or {}, ("power_w_mean", "sclk_mhz_mean", "power_cap_w"))
+    if out.get("latency_batch1"):
+        c["latency_batch1"] = _pick(out["latency_batch1"], ("unit", "p50", "p99", "p50_incl_d2h", "p99_incl_d2h"))
+    if out.get("throughput_concurrent_steps"):
+        t3 = out["throughput_concurrent_steps"]
+        c["throughput_concurrent_steps"] = {"streams": t3["streams"], "value": t3["value"], "ratio_vs_single_stream": t3["ratio_vs_single_stream"],
+                                            "single_stream_value": t3["single_stream_same_leg"]["value"]}
+    if "value_fp32_parity" in out:
+        c["value_fp32_parity"] = out["value_fp32_parity"]
+    modes = {}
+    for m, r in (out.get("modes") or {}).items():
+        modes[m] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
+                    "roofline": _pick(r["roofline"], ("kernel", "achieved", "peak", "frac", "frac_of_sustained", "launch_ms")),
+                    "parity": (r.get("parity") or {}).get("max_abs_rgba_vs_oracle")}
+    c["modes"] = modes
+    if out.get("rccl"):
+        f = out["rccl"]
+        c["rccl"] = _pick(f, ("world", "backend", "nccl_version", "distinct_devices"))
+        c["rccl"]["ranks_seen"] = [r_.get("rank") for r_ in f.get("ranks_seen", [])]
+        c["ms_per_step_per_rank"] = out.get("ms_per_step_per_rank")
+        c["gather_wait_ms"] = _pick(out.get("gather_wait_ms") or {}, ("host_ms_per_step", "stream_ms_per_step", "waits"))
+    c["detail_file"] = out.get("detail_file")
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -524,6 +584,9 @@ def main():
                     help="software-pipeline the steps over two streams (pipeline.TriadStepPipeline: head of step k+1 under the tail of step k; "
                          "+2 %% measured) instead of enqueueing them back to back on ONE stream, where every launch has the chip to itself "
                          "and its HIP-event duration is the kernel's own time (default)")
+    ap.add_argument("--full-line", action="store_true", help="print the FULL record on stdout instead of the compact line (the A/B scripts under "
+                                                             "tools/ read its calibration tables); never what the driver runs")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json next to this file)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the dominant kernel's launches with HIP events in every K-th timed step (an event pair costs ~10 us "
                          "of stream time, which a single chain of launches cannot hide)")
@@ -734,7 +797,22 @@ def main():
             for m, pr in out["cpu_baseline"].pop("parity_by_mode", {}).items():
                 out["modes"][m]["parity"] = pr
             out["cpu_baseline"]["parity"] = out["modes"][args.conv_mode].get("parity")
-        print(json.dumps(out), flush=True)
+        # The full record (calibration tables, per-layer times, every explanatory string: ~20 KB) goes to a FILE; stdout gets ONE
+        # compact line (< 4 KB) with the contract's keys -- the driver keeps only the last 8 KB of stdout, and a 20 KB line
+        # left its round-4 record unparseable.
+        detail_path = args.detail or os.path.join(REPO, "bench_detail.json")
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(out, f)
+            out["detail_file"] = os.path.relpath(detail_path, REPO)
+        except OSError as e:
+            out["detail_file"] = f"(not written: {e})"
+        if args.full_line:
+            print(json.dumps(out), flush=True)
+        else:
+            line = json.dumps(compact_line(out), separators=(",", ":"))
+            assert len(line) < MAX_LINE_BYTES, f"bench line is {len(line)} bytes (limit {MAX_LINE_BYTES})"
+            print(line, flush=True)
     sampler.__exit__(None, None, None)
     if world > 1:
         dist.barrier()

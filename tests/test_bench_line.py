@@ -1,0 +1,53 @@
+"""bench.py's final stdout line (CPU-side check of the reduction): the driver keeps the last 8 KB of stdout, and round 4's 20 KB line
+left its record unparseable.  The compact form of a real full record must stay under 4 KB -- also with eight ranks in it -- and carry
+the contract's keys."""
+import copy
+import importlib.util
+import json
+import os
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_compact_line_of_a_full_record_is_small_and_complete():
+    b = _bench()
+    full = json.load(open(os.path.join(REPO, "profiles", "r04_bench.json")))       # a full one-GPU record (20 KB)
+    assert len(json.dumps(full)) > 15000
+    c = b.compact_line(full)
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < b.MAX_LINE_BYTES
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "box_calibration", "telemetry", "latency_batch1", "modes"):
+        assert k in c, k
+    assert c["value"] == full["value"] and c["ms_per_step"] == full["ms_per_step"]
+    r = c["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_per_step", "flops_per_launch"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert set(c["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert set(c["modes"]) == {"f8", "h3", "f32"}
+    assert not any(isinstance(v, str) and len(v) > 200 for v in c.values())
+
+
+def test_compact_line_with_eight_ranks():
+    b = _bench()
+    full = copy.deepcopy(json.load(open(os.path.join(REPO, "profiles", "r04_bench.json"))))
+    full["n_gpus"] = 8
+    full["rccl"] = {"world": 8, "backend": "nccl", "nccl_version": "2.22.3", "distinct_devices": 8,
+                    "ranks_seen": [{"rank": i, "host": "node-with-a-long-name-0123456789", "pid": 100000 + i, "device": i,
+                                    "pci_bus_id": f"0000:{i:02x}:00.0", "uuid": "GPU-" + "ab" * 16} for i in range(8)]}
+    full["ms_per_step_per_rank"] = [1.8321] * 8
+    full["gather_wait_ms"] = {"host_ms_per_step": 0.0123, "stream_ms_per_step": 0.0456, "waits": 160, "what": "x" * 400}
+    full["modes"] = {"f8": full["modes"]["f8"]}
+    c = b.compact_line(full)
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < b.MAX_LINE_BYTES
+    assert c["rccl"]["ranks_seen"] == list(range(8)) and c["rccl"]["distinct_devices"] == 8
+    assert len(c["ms_per_step_per_rank"]) == 8 and c["gather_wait_ms"]["waits"] == 160

@@ -13,6 +13,31 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "box_calibration", "telemetry", "modes", "detail_file")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_per_step", "flops_per_launch")
+
+
+def _last_line(stdout):
+    """The driver keeps the last 8 KB of stdout and parses its last line: that line must be small and complete."""
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    assert stdout.rstrip().splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 4096, len(lines[0])
+    out = json.loads(lines[0])
+    for k in COMPACT_KEYS:
+        assert k in out, k
+    for k in ROOFLINE_KEYS:
+        assert k in out["roofline"], k
+    assert set(out["config"]) >= {"workload", "batch_per_gpu", "resolution"} and "model" not in out["config"]
+    return out
+
+
+def _detail(out):
+    with open(os.path.join(REPO, out["detail_file"])) as f:
+        return json.load(f)
+
+
 def _run(args, extra_env=None, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
@@ -24,15 +49,14 @@ def test_bench_self_spawns_two_ranks():
     r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--res", "128", "--batch", "16", "--no-cpu", "--no-latency"],
              {"NB_BENCH_SHARE_GPU": "1", "NB_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    out = _last_line(r.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert "gather of RGBA tiles to rank 0" in out["config"]["parallelism"]
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
     # the N > 1 line says who took part and what the gather cost: both ranks seen (one device here: the share-GPU hook), every
     # rank's own step time, and how long rank 0 waited for the tiles
-    assert out["rccl"]["world"] == 2 and out["rccl"]["backend"] == "gloo" and [r_["rank"] for r_ in out["rccl"]["ranks_seen"]] == [0, 1]
+    assert out["rccl"]["world"] == 2 and out["rccl"]["backend"] == "gloo" and out["rccl"]["ranks_seen"] == [0, 1]
+    assert [r_["rank"] for r_ in _detail(out)["rccl"]["ranks_seen"]] == [0, 1]
     assert out["rccl"]["distinct_devices"] == 1
     assert len(out["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in out["ms_per_step_per_rank"])
     assert out["gather_wait_ms"]["waits"] >= 3 and out["gather_wait_ms"]["host_ms_per_step"] >= 0
@@ -45,18 +69,21 @@ def test_bench_line_carries_every_arithmetic_mode():
     a split mode never claims "f32"."""
     r = _run(["--steps", "2", "--warmup", "1", "--res", "128", "--batch", "8", "--no-latency", "--cpu-seconds", "1"])
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    out = _last_line(r.stdout)
     assert set(out["modes"]) == {"f8", "h3", "f32"} and out["conv_mode"] == "f8"
     assert out["value"] == out["modes"]["f8"]["value"] and out["value_fp32_parity"] == out["modes"]["h3"]["value"]
-    assert not out["dtype"].startswith("f32") and not out["modes"]["h3"]["dtype"].startswith("f32")
+    assert not out["dtype"].startswith("f32")
     tol = {"f8": 3e-4, "h3": 2e-5, "f32": 2e-5}
     for m, rec in out["modes"].items():
         assert rec["value"] > 0 and rec["roofline"]["frac"] > 0
         assert rec["roofline"]["peak"] == (157.3 if m == "f32" else 2500.0)
-        assert rec["parity"]["max_abs_rgba_vs_oracle"] <= tol[m], (m, rec["parity"])
-    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+        assert rec["parity"] <= tol[m], (m, rec["parity"])
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1
+    assert out["parity"]["max_abs_rgba_vs_oracle"] <= tol["f8"] and out["parity"]["tolerance"] == 1e-3
+    # the full record (tables, per-layer times, explanatory strings) is in the detail file, same numbers
+    out_c, out = out, _detail(out)
+    assert out["value"] == out_c["value"] and out["roofline"]["frac"] == out_c["roofline"]["frac"]
+    assert not out["modes"]["h3"]["dtype"].startswith("f32") and "calibration" in out["roofline"]
     # the box is in the line: what it sustains on a registers-only f16 MFMA loop, and (where the hwmon files are readable) power
     # and shader clock during each mode's timed region
     assert 500 < out["box_calibration"]["mfma_f16_sustained_tflops"] < 2600 and out["box_calibration"]["loop_clock_mhz"] > 500

@@ -5,7 +5,7 @@ for i in 1 2 3; do
   for lib in base cur; do
     if [ $lib = base ]; then export $VAR=$VAL; else unset $VAR; fi
     for mode in f8 h3; do
-      python bench.py --modes primary --conv-mode $mode --no-cpu --no-latency 2>/dev/null | python -c "
+      python bench.py --full-line --modes primary --conv-mode $mode --no-cpu --no-latency 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['roofline']['calibration']['kernels']; l = d['roofline']['calibration']['layers_ms']

@@ -7,7 +7,7 @@ for i in 1 2 3; do
   for lib in $V cur; do
     if [ $lib = cur ]; then unset NEUBE_LIB_PATH; else export NEUBE_LIB_PATH=$PWD/brushstroke_engine_amd/csrc/libneube_$lib.so; fi
     for mode in $MODES; do
-      python bench.py --modes primary --conv-mode $mode --no-cpu --no-latency 2>/dev/null | python -c "
+      python bench.py --full-line --modes primary --conv-mode $mode --no-cpu --no-latency 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['roofline']['calibration']['kernels']

@@ -12,7 +12,7 @@ cd $R
 for i in 1 2 3; do
   for v in cur $V; do
     if [ $v = cur ]; then unset NEUBE_LIB_PATH; else export NEUBE_LIB_PATH=$R/brushstroke_engine_amd/csrc/libneube_$v.so; fi
-    python bench.py --modes primary --conv-mode f8 --no-cpu --no-latency 2>/dev/null | python -c "
+    python bench.py --full-line --modes primary --conv-mode f8 --no-cpu --no-latency 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['roofline']['calibration']['kernels']

@@ -3,7 +3,7 @@
 for i in 1 2 3; do
   for pair in 0 1; do
     for mode in f8 h3; do
-      NB_UP2_PAIR=$pair python bench.py --modes primary --conv-mode $mode --no-cpu --no-latency 2>/dev/null | python -c "
+      NB_UP2_PAIR=$pair python bench.py --full-line --modes primary --conv-mode $mode --no-cpu --no-latency 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['roofline']['calibration']['kernels']

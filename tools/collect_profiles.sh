@@ -2,15 +2,15 @@
 # Collect the round's judged artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1800 -- "bash tools/collect_profiles.sh r03 $(git rev-parse --short HEAD)"   (no git on the GPU box)
 # Writes gpurun_out/<tag>/...; copy what is to be judged into profiles/ (tools/copy_profiles.sh <tag>).
-TAG=${1:-r04}; GIT_HEAD=${2:-unknown}
+TAG=${1:-r05}; GIT_HEAD=${2:-unknown}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # the driver's command (one line carrying all three arithmetic modes), before anything else touches the GPU; it runs once more at the
 # very end, when the counter passes have written the traffic file for THESE kernel sources (a bench.py run right after the
 # rocprofv3 --pmc passes measured its auxiliary three-streams leg 19 % low, twice: the counters leave the clocks in a state of
 # their own for a while)
-(cd /tmp && python3 $R/bench.py > $O/bench_pre.json 2> $O/bench_pre.err)
-python3 $R/bench.py --res 128 --no-cpu --modes primary > $O/bench_r128_f8.json 2> $O/bench_r128.err
+(cd /tmp && python3 $R/bench.py --detail $O/bench_pre_detail.json > $O/bench_pre.json 2> $O/bench_pre.err)
+python3 $R/bench.py --res 128 --no-cpu --modes primary --detail $O/bench_r128_f8_detail.json > $O/bench_r128_f8.json 2> $O/bench_r128.err
 # per-kernel averages of the same command (timing pass: kernel trace + stats only), per mode
 for m in f8 h3 f32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode $m > $O/stats_$m.log 2>&1
@@ -57,6 +57,6 @@ NB_BENCH_SHARE_GPU=1 NB_BENCH_BACKEND=gloo python tools/bench_lamali.py --gpus 2
 python tools/bench_train.py > $O/train_bench.json 2> $O/train_bench.err
 bash tools/trace_train.sh 400 > /dev/null 2>&1; head -70 gpurun_out/train_trace_summary.txt > $O/train_trace.txt; python tools/trace_train_agg.py > $O/train_trace_by_kernel.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
-(cd /tmp && python3 $R/bench.py > $O/bench.json 2> $O/bench.err)
+(cd /tmp && python3 $R/bench.py --detail $O/bench_detail.json > $O/bench.json 2> $O/bench.err)
 rm -rf $O/stats_* $O/pmc_hit_* $O/pmc_fetch_* $O/pmc_write_* $O/pmc_mfma_f8 $O/pmc_mfma_h3
 ls $O; tail -c 400 $O/bench.json; tail -2 $O/smoke.txt
