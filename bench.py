@@ -212,11 +212,11 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
     # the generator runs a batch as `sub` sub-batches on separate HIP streams; with N>1 each part's RGBA tiles are
     # gathered from the part's own stream, so steps keep overlapping across the streams at any N
     sub = G.sub_streams if (B >= G.sub_stream_min_batch and not args.pipeline and not args.prefetch) else 1
-    gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev) if gather else None
+    gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev, timing=True) if gather else None
     part_gatherers = []
     if gatherer is not None and sub > 1:
         bounds = [(i * B // sub, (i + 1) * B // sub) for i in range(sub)]
-        part_gatherers = [TileGatherer([b - a, args.res, args.res, 4], torch.uint8, dev) for a, b in bounds]
+        part_gatherers = [TileGatherer([b - a, args.res, args.res, 4], torch.uint8, dev, timing=True) for a, b in bounds]
 
     def finish_gathers():
         if gatherer is not None:
@@ -701,7 +701,8 @@ def main():
                          "(s_memtime / s_memrealtime)"}
     except Exception as e:                                       # noqa: BLE001
         calib = {"mfma_f16_sustained_tflops": None, "what": f"calibration failed: {e}"}
-    sampler = _tele.PowerClockSampler(_tele.find_hwmon(_tele.pci_bus_id_of(local_rank)))
+    # (NB_TELEMETRY=0: no sampler thread at all -- the switch of the sampler-on/off A/B, tools/ab_env.sh NB_TELEMETRY=0)
+    sampler = _tele.PowerClockSampler(_tele.find_hwmon(_tele.pci_bus_id_of(local_rank)) if os.environ.get("NB_TELEMETRY", "1") != "0" else None)
     sampler.__enter__()
     gens, results = {}, {}
     for m in modes:

@@ -122,6 +122,63 @@ __device__ __forceinline__ unsigned nb_pk4_fp8_sat_scaled(float a, float b, floa
     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c, d, inv_scale, true);
     return __builtin_bit_cast(unsigned, w);
 }
+// ---- "f6" operand format (round 5): the two correction products on ONE block-scaled fp6 (e2m3) MFMA per tap pair, at the f16
+// instruction's cycles (the fp8 form takes twice as many).  e2m3 has the three mantissa bits of e4m3 but a range of only 2^6, so
+// every 16-channel chunk of a pixel carries its own power-of-two scale S (E8M0 byte), chosen so that the chunk's largest |x| lands
+// in [4, 8) (7.5 is the format's top: values in (7.5 S, 8 S) saturate -- an error of at most one step at the top of the range):
+//   lo slots of a chunk (32 bytes per pixel: (cg 2k, lo) ++ (cg 2k+1, lo)) = six dwords of 32 six-bit fields, the scale byte, zeros;
+//   field 2 i = e2m3(xl[ch(i)] 2^11 / S),  field 2 i + 1 = e2m3(x[ch(i)] / S),   ch(i) = channels 0-3, 8-11, 4-7, 12-15 of the chunk
+//   (the order in which the two lane halves of a 32x32 accumulator hold a chunk's rows);
+//   weights likewise per (c_out, tap, chunk): field 2 i = e2m3(w[ch(i)] / Sw), field 2 i + 1 = e2m3(wl[ch(i)] 2^11 / Sw), byte = Sw 2^-11.
+// v_mfma_scale_f32_32x32x64_f8f6f4 (cbsz = blgp = 2): a lane's 32 K values = ONE pixel / c_out, ONE tap, both terms (the hardware
+// applies one scale per lane); lane half 0 contracts the first tap of a pair, lane half 1 the second.  The operand tuple is read
+// straight from the two slots (8 registers: six fields, the scale dword -- the instruction's scale operand --, one unused).
+// Layouts, scale semantics and the cycle count are checked by tools/microbench/mfma_f6_check.hip.
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+// 32 floats -> 32 e2m3 codes: field 2 i = a[i] / 2^e, field 2 i + 1 = b[i] / 2^e (e = the exponent of `scale`; round to nearest even,
+// saturating at +-7.5).  Inline assembly with an EARLY-CLOBBER destination: through the builtin, hipcc (ROCm 7.2) allocated the six
+// result registers on top of the last two registers of the second source (v[32:37] <- v[2:17], v[18:33]) and the last two inputs
+// came out as garbage (tools/microbench/mfma_f6_check.hip, first version).
+__device__ __forceinline__ u32x6 nb_cvt_fp6x32(f32x16 a, f32x16 b, float scale) {
+    u32x6 r;
+    asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(scale));
+    return r;
+}
+// ... of 8 + 8 values (fields 0 .. 15 = the first three dwords; the upper halves of the sources are left undefined)
+__device__ __forceinline__ u32x6 nb_cvt_fp6x16(f32x8 a, f32x8 b, float scale) {
+    return nb_cvt_fp6x32(__builtin_shufflevector(a, a, 0, 1, 2, 3, 4, 5, 6, 7, -1, -1, -1, -1, -1, -1, -1, -1),
+                         __builtin_shufflevector(b, b, 0, 1, 2, 3, 4, 5, 6, 7, -1, -1, -1, -1, -1, -1, -1, -1), scale);
+}
+// the converter's scale operand for a block whose largest magnitude is m (only its exponent counts: m / 2^e lands in [4, 8)), and the
+// E8M0 byte that undoes it in the MFMA
+__device__ __forceinline__ float nb_f6_scale(float maxabs) { return maxabs * 0.25f; }
+__device__ __forceinline__ unsigned nb_f6_scale_byte(float scale) { return (__builtin_bit_cast(unsigned, scale) >> 23) & 0xffu; }
+// channel of a 16-channel chunk behind field pair i
+__device__ __forceinline__ constexpr int nb_f6_ch(int i) { return (i & 3) + 8 * ((i >> 2) & 1) + 4 * (i >> 3); }
+// 16 channels of one pixel (already times the consumer's style) -> the chunk's four slots: hi f16 of channels 0-7 / 8-15, lo slots
+__device__ __forceinline__ void nb_f6_encode16(const float (&v)[16], h8& hi0, h8& hi1, i32x4& l0, i32x4& l1) {
+    f32x16 a, b;
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const _Float16 hh = (_Float16)v[j];
+        if (j < 8) hi0[j & 7] = hh; else hi1[j & 7] = hh;
+        m = fmaxf(m, fabsf(v[j]));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ch = nb_f6_ch(i);
+        const _Float16 hh = ch < 8 ? hi0[ch & 7] : hi1[ch & 7];
+        a[i] = (v[ch] - (float)hh) * 2048.f;
+        b[i] = v[ch];
+    }
+    const float sc = nb_f6_scale(m);
+    const u32x6 r = nb_cvt_fp6x32(a, b, sc);
+    l0 = i32x4{(int)r[0], (int)r[1], (int)r[2], (int)r[3]};
+    l1 = i32x4{(int)r[4], (int)r[5], (int)nb_f6_scale_byte(sc), 0};
+}
+
 __device__ __forceinline__ void nb_set_fp16_ovfl() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 // v_permlane32_swap: exchanges a[lanes 32..63] with b[lanes 0..31] in place.  Afterwards lanes 0..31 hold (a, b) = (their

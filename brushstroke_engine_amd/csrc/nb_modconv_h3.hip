@@ -86,8 +86,10 @@ __device__ __forceinline__ float nb_h3_act(float a, float dg, float nbg, float a
 // V2: the K loop in the form of modconv3x3_up2v_kernel (nb_modconv_up2v.hip) -- LDS-DMA from inline assembly
 // (counted lgkmcnt waits), the step's barrier in front of its last two MFMA groups with the next step's first operands read under
 // them, fragment reads and DMA pieces dealt out between the MFMAs.  Same per-accumulator order of products: bit-identical.
-template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false>
+// F6 (with F8 and V2): the "f6" operand format (nb_h3_common.h) -- the K loop of the f8 V2 form with fp6 correction products.
+template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false, bool F6 = false>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
+    static_assert(!F6 || (F8 && V2), "the f6 form is a variant of the software-pipelined f8 loop");
     NB_TSTAMP(0);
     if (p.out_f8) nb_set_fp16_ovfl();             // f8 hand-off: the fp8 (and f16) conversions saturate
     nb_stagger(p.stagger_ticks, 256);
@@ -259,7 +261,125 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 
     unsigned long long t_dma = 0, t_bar = 0;
     const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
-    if constexpr (F8 && V2) {
+    if constexpr (F6) {
+        // ---- f6 operands: the f8 loop below with the correction products on fp6 MFMAs (32 instead of 64 cycles each) -----------
+        // A lane's 32 K values of a correction instruction = ONE tap of ONE pixel / c_out, both terms (one block scale per lane):
+        // lane half 0 takes tap 0 of the pair (0, 1), lane half 1 tap 1 -- the lo-slot addresses are per lane --, and its operand
+        // tuple is the chunk's two lo slots as they stand (quad 0 = slot (cg 0, lo), quad 1 = slot (cg 1, lo): six dwords of fields,
+        // the scale dword = the instruction's scale operand, one unused).  Tap 2 has no partner in its step: its corrections run
+        // alone every step, lane half 1 multiplying a zero slot (weights side).  Per step and tile 3 f16 + 2 fp6 MFMAs = 160 cycles
+        // (f8: 3 x 32 + 1.5 x 64 = 192).  Step t:
+        //   part A:  tap 2 main (t-1) | tap-2 corrections (t-1) | tap 0 (t)      fillers: the step's LDS-DMA pieces, its tap-2 fragments
+        //   wait (counted) + barrier
+        //   part B:  tap 1 (t) | corrections 0 + 1 (t)                           fillers: hi fragments of taps 0, 1 of step t+1;
+        //            behind the last fp6 MFMA the lo slots of step t+1
+#define NB_SB __builtin_amdgcn_sched_barrier(0)
+#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
+        __shared__ __attribute__((aligned(16))) h8 s_zero6;
+        if (tid == 0) s_zero6 = h8{};
+        __builtin_amdgcn_s_barrier();
+        h8 ah0[MB], ah1[MB], ah2[MB], bh0[NBW], bh1[NBW], bh2[NBW];
+        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { ah2[mb] = h8{}; al2[mb] = i32x8{}; al01[mb] = i32x8{}; }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) { bh2[nb] = h8{}; bl2[nb] = i32x8{}; bl01[nb] = i32x8{}; }
+        constexpr int NM = MB * NBW, NF = MB + NBW;
+        const int a6 = wm * 64 + l31, a6_01 = a6 + lh * 4 * CO_WG;          // lo slots: + (2 q + 1) CO_WG + mb 32 (+ 8 CO_WG for tap 2)
+        const int b6 = (wn * NBW) * TWP + l31, b6_01 = b6 + lh;             // + (2 q + 1) XPL + (nb + ky) TWP (+ 2 for tap 2)
+        auto rd_hi = [&](auto i_, h8 (&a)[MB], h8 (&b)[NBW], const h8* wb, const h8* xb, int ky, int kx) {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (i < MB) a[i] = wb[a_base + kx * 4 * CO_WG + i * 32];
+            else b[i - MB] = xb[b_base + (i - MB + ky) * TWP + kx];
+        };
+        // lo slot q of fragment i: the pair (0, 1) -- the lane's own tap -- or the lone tap 2 (weights of lane half 1: the zero slot)
+        auto rd_lo01 = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, int ky) {
+            constexpr int i = decltype(i_)::value, q = decltype(q_)::value;
+            if constexpr (i < MB) { NB_Q(a[i], q, wb[a6_01 + (2 * q + 1) * CO_WG + i * 32]); }
+            else { NB_Q(b[i - MB], q, xb[b6_01 + (2 * q + 1) * XPL + (i - MB + ky) * TWP]); }
+        };
+        auto rd_lo2 = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, int ky) {
+            constexpr int i = decltype(i_)::value, q = decltype(q_)::value;
+            if constexpr (i < MB) { const h8* src = lh ? &s_zero6 : wb + a6 + 8 * CO_WG + (2 * q + 1) * CO_WG + i * 32; NB_Q(a[i], q, *src); }
+            else { NB_Q(b[i - MB], q, xb[b6 + (2 * q + 1) * XPL + (i - MB + ky) * TWP + 2]); }
+        };
+        auto group = [&](auto nfill_, auto&& mf, auto&& ff) {
+            constexpr int NFILL = decltype(nfill_)::value;
+            nb_static_for<0, NM>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                mf(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{});
+                NB_SB;
+                nb_static_for<0, NFILL>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i * NM / (NFILL > 0 ? NFILL : 1) == k) ff(i_);
+                });
+                NB_SB;
+            });
+        };
+        auto mf_f16 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
+            return [&](auto mb_, auto nb_) {
+                constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+            };
+        };
+        auto mf_fp6 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
+            return [&](auto mb_, auto nb_) {
+                constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+                acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 2, 2, 0, a[mb][6], 0, b[nb][6]);
+            };
+        };
+        using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+        auto step = [&](auto ky_, int t, int c) {
+            constexpr int KY = decltype(ky_)::value;
+            constexpr int NDMA = NWPW + (KY == 0 ? NXPW : 0);
+            const h8* xb = xbuf + (c & 1) * 4 * XPL;
+            const h8* wb = wring + (t & 3) * WSLOTS;
+            const int tn = t + 1, cn = KY == 2 ? c + 1 : c;
+            constexpr int KYN = KY == 2 ? 0 : KY + 1;
+            const h8* xbn = xbuf + (cn & 1) * 4 * XPL;
+            const h8* wbn = wring + (tn & 3) * WSLOTS;
+            const int t3 = clampt(t + 3), c1 = c + 1 < NC ? c + 1 : NC - 1;
+            auto dma = [&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < NWPW) issue_w_v2(i_, t3, (t + 3) & 3);
+                else issue_x_v2(std::integral_constant<int, i - NWPW>{}, c1, (c + 1) & 1);
+            };
+            NB_SB;
+            // part A
+            group(std::integral_constant<int, NDMA>{}, mf_f16(ah2, bh2), dma);                       // tap 2 of step t-1
+            group(std::integral_constant<int, NF>{}, mf_fp6(al2, bl2),                                // its corrections
+                  [&](auto i_) { rd_hi(i_, ah2, bh2, wb, xb, KY, 2); });
+            group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah0, bh0), [&](auto i_) {             // tap 0
+                constexpr int i = decltype(i_)::value;
+                if constexpr (i < NF) rd_lo2(i_, Q0{}, al2, bl2, wb, xb, KY);
+                else rd_lo2(std::integral_constant<int, i - NF>{}, Q1{}, al2, bl2, wb, xb, KY);
+            });
+            if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW + NXPW) : "memory");
+            NB_SB;
+            // part B
+            group(std::integral_constant<int, NF>{}, mf_f16(ah1, bh1),                                // tap 1
+                  [&](auto i_) { rd_hi(i_, ah0, bh0, wbn, xbn, KYN, 0); });
+            group(std::integral_constant<int, NF>{}, mf_fp6(al01, bl01),                              // corrections of taps 0 + 1
+                  [&](auto i_) { rd_hi(i_, ah1, bh1, wbn, xbn, KYN, 1); });
+            nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q0{}, al01, bl01, wbn, xbn, KYN); });
+            nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q1{}, al01, bl01, wbn, xbn, KYN); });
+            NB_SB;
+        };
+        // operands of step 0
+        nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah0, bh0, wring, xbuf, 0, 0); });
+        nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah1, bh1, wring, xbuf, 0, 1); });
+        nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q0{}, al01, bl01, wring, xbuf, 0); });
+        nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q1{}, al01, bl01, wring, xbuf, 0); });
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+        for (int c = 0; c < NC; ++c) { step(K0{}, 3 * c, c); step(K1{}, 3 * c + 1, c); step(K2{}, 3 * c + 2, c); }
+        NB_SB;
+        // the last step's tap 2 and its corrections
+        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_f16(ah2, bh2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp6(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+#undef NB_Q
+#undef NB_SB
+    } else if constexpr (F8 && V2) {
         // ---- f8 operands, software-pipelined over the barrier ------------------------------------------------------
         // Step t = (chunk c, tap row ky) multiplies, per accumulator tile and in this order: tap 2 of step t-1 (f16), on even t
         // the tap-2 corrections of steps t-2 and t-1 (ONE fp8 K = 64), tap 0 (f16), tap 1 (f16), the corrections of taps 0 + 1
@@ -996,7 +1116,7 @@ static int launch_h3s(H3Params p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int MW, bool F8 = false, int NBW = 2, bool V2 = false>
+template <int MW, bool F8 = false, int NBW = 2, bool V2 = false, bool F6 = false>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * NBW, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
@@ -1005,11 +1125,11 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
 }
@@ -1026,9 +1146,10 @@ extern "C" void nb_debug_set_up1_rows(int nbw) { g_force_nbw = nbw; }
 static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
-                          void* stream, const TorgbParams* tg = nullptr, bool f8 = false, int out_fmt = 0) {
-    NB_REQUIRE(out_fmt == 0 || (out_fmt == 1 && y_h2 && c_out % 16 == 0 && c_next % 16 == 0),
-               "modconv3x3_up1_h3: f8 output needs an H2 destination and c_out, c_next %% 16 == 0");
+                          void* stream, const TorgbParams* tg = nullptr, int in_fmt = 0, int out_fmt = 0) {
+    const bool f8 = in_fmt != 0, f6 = in_fmt == 2;          // (the f6 form is a variant of the f8 loop: same containers, same staging)
+    NB_REQUIRE(out_fmt == 0 || ((out_fmt == 1 || out_fmt == 2) && y_h2 && c_out % 16 == 0 && c_next % 16 == 0),
+               "modconv3x3_up1_h3: f8 / f6 output needs an H2 destination and c_out, c_next %% 16 == 0");
     NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && (tg ? !y_h2 : ((y != nullptr) != (y_h2 != nullptr))), "modconv3x3_up1_h3: null pointer");
     NB_REQUIRE(!f8 || c_in % 16 == 0, "modconv3x3_up1_h3: the f8 operand format needs c_in %% 16 == 0 (got %d)", c_in);
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
@@ -1071,6 +1192,10 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     // (its pieces walk the chunks with a fixed per-chunk stride: whole 16-channel chunks only -- f8 operands always are; H2 operands
     //  with an odd number of channel groups keep the round-3 loop, whose last chunk reads the missing group from the zero page)
     const bool v2 = (g_force_up1_v2 >= 0 ? g_force_up1_v2 : env_v2) != 0 && (f8 || p.c8 % 2 == 0);
+    if (f6) {                                               // (the software-pipelined loop only)
+        if (half) return c_out > 64 ? launch_h3<2, true, 1, true, true>(p, n, st) : launch_h3<1, true, 1, true, true>(p, n, st);
+        return c_out > 64 ? launch_h3<2, true, 2, true, true>(p, n, st) : launch_h3<1, true, 2, true, true>(p, n, st);
+    }
     if (half) {
         if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 1, true>(p, n, st) : launch_h3<1, true, 1, true>(p, n, st);
         if (f8) return c_out > 64 ? launch_h3<2, true, 1>(p, n, st) : launch_h3<1, true, 1>(p, n, st);
@@ -1089,10 +1214,10 @@ extern "C" int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts,
                                       const float* next_styles, int next_stride, int c_next, const NbTorgbArgs* t, int in_fmt,
                                       int out_fmt, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
                                       void* stream) {
-    NB_REQUIRE(in_fmt == 0 || in_fmt == 1, "modconv3x3_up1_h3: operand format must be 0 (H2) or 1 (f8)");
+    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 2, "modconv3x3_up1_h3: operand format must be 0 (H2), 1 (f8) or 2 (f6)");
     if (!t)
         return nb_up1_h3_impl(x, c_in, wts, dcoefs, noise, noise_stride_n, bias, y_f32, y_h2, next_styles, next_stride, c_next,
-                              n, h, w, c_out, alpha, gain, clamp, stream, nullptr, in_fmt == 1, out_fmt);
+                              n, h, w, c_out, alpha, gain, clamp, stream, nullptr, in_fmt, out_fmt);
     NB_REQUIRE(t->styles && t->w && t->bias && t->color_bias && !y_h2, "modconv3x3_up1_h3_ex: bad ToRGB arguments");
     NB_REQUIRE(c_out <= 128, "modconv3x3_up1_h3_ex: the fused ToRGB needs all channels in one workgroup (c_out <= 128)");
     NB_REQUIRE(t->styles_stride_n >= c_out + 9, "torgb_triad: styles rows must hold 9 color scalars + c styles");
@@ -1103,7 +1228,7 @@ extern "C" int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts,
     tg.sfactor = t->sfactor; tg.rgba_f32 = t->rgba_f32; tg.rgba_u8 = t->rgba_u8;
     tg.styles_stride_n = t->styles_stride_n; tg.c = c_out; tg.hw = h * w; tg.render_mode = t->render_mode; tg.clamp = t->clamp;
     return nb_up1_h3_impl(x, c_in, wts, dcoefs, noise, noise_stride_n, bias, y_f32, nullptr, nullptr, 0, 0, n, h, w, c_out,
-                          alpha, gain, clamp, stream, &tg, in_fmt == 1, 0);
+                          alpha, gain, clamp, stream, &tg, in_fmt, 0);
 }
 
 extern "C" int nb_modconv3x3_up1_h3(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
@@ -1982,6 +2107,59 @@ extern "C" int nb_pack_h2f8_f32(const float* x1, int c1, const float* x2, int c2
     dim3 grid((hw + 255) / 256, c8 / 2, n);
     hipLaunchKernelGGL(pack_h2f8_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, c1, x2, c2, scale, (_Float16*)out, c8, hw);
     NB_CHECK_LAUNCH("pack_h2f8");
+    return NB_OK;
+}
+
+// fp32 NCHW (x1 ++ x2) * scale -> the "f6" activation format (nb_h3_common.h): per 16-channel chunk the f16 high halves of both channel
+// groups and, in the two lo slots, 32 e2m3 fields (xl 2^11 / S, x / S interleaved) + the chunk's scale byte.  With cg0 / c8_total:
+// into channel groups cg0.. of a tensor with c8_total groups (the geometry features behind a producer that wrote its own groups).
+__global__ __launch_bounds__(256) void pack_h2f6_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,
+                                                        const float* __restrict__ scale, int scale_stride, _Float16* __restrict__ out,
+                                                        int c8_total, int cg0, int hw) {
+    const int n = blockIdx.z, chunk = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const int c_in = c1 + c2;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ch = chunk * 16 + j;
+        float t = 0.f;
+        if (ch < c_in) {
+            t = ch < c1 ? x1[((size_t)n * c1 + ch) * hw + pix] : x2[((size_t)n * c2 + (ch - c1)) * hw + pix];
+            if (scale) t *= scale[(size_t)n * scale_stride + ch];
+        }
+        v[j] = t;
+    }
+    h8 hi0, hi1;
+    i32x4 l0, l1;
+    nb_f6_encode16(v, hi0, hi1, l0, l1);
+    h8* o = reinterpret_cast<h8*>(out) + ((size_t)(n * c8_total + cg0 + 2 * chunk) * 2) * hw + pix;
+    o[0] = hi0;
+    o[hw] = __builtin_bit_cast(h8, l0);
+    o[2 * (size_t)hw] = hi1;
+    o[3 * (size_t)hw] = __builtin_bit_cast(h8, l1);
+}
+
+extern "C" int nb_pack_h2f6_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out, int n, int hw,
+                                void* stream) {
+    NB_REQUIRE(x1 && out && c1 > 0 && c2 >= 0 && (c2 == 0 || x2) && n > 0 && n <= 65535 && hw > 0, "pack_h2f6: bad arguments");
+    NB_REQUIRE((c1 + c2) % 16 == 0, "pack_h2f6: the f6 operand format needs a multiple of 16 channels (got %d)", c1 + c2);
+    const int c8 = (c1 + c2) / 8;
+    dim3 grid((hw + 255) / 256, c8 / 2, n);
+    hipLaunchKernelGGL(pack_h2f6_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, c1, x2, c2, scale, c1 + c2, (_Float16*)out, c8, 0, hw);
+    NB_CHECK_LAUNCH("pack_h2f6");
+    return NB_OK;
+}
+
+extern "C" int nb_pack_h2f6_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out, int c8_total,
+                                     int cg0, int n, int hw, void* stream) {
+    NB_REQUIRE(x && out && c > 0 && c % 16 == 0 && cg0 % 2 == 0 && n > 0 && n <= 65535 && hw > 0 && cg0 >= 0 && cg0 + c / 8 <= c8_total,
+               "pack_h2f6_part: bad arguments (whole 16-channel chunks only)");
+    dim3 grid((hw + 255) / 256, c / 16, n);
+    hipLaunchKernelGGL(pack_h2f6_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c, (const float*)nullptr, 0, scale, scale_stride, (_Float16*)out,
+                       c8_total, cg0, hw);
+    NB_CHECK_LAUNCH("pack_h2f6_part");
     return NB_OK;
 }
 

@@ -363,9 +363,14 @@ class SynthesisNetwork(torch.nn.Module):
         return buf.value.decode()
 
     def _up2_h3_variant_name(self, in_fmt: int, n: int, s: LayerSpec) -> str:
-        buf = ctypes.create_string_buffer(128)
-        _lib.check(_lib.lib().nb_modconv3x3_up2_h3_variant(in_fmt, s.in_channels, s.out_channels, n, s.in_res, s.in_res, buf, 128), "variant")
-        return buf.value.decode()
+        """Which up=2 kernel the library picks for this problem (a label for layer_kernels; resolved once per problem)."""
+        key = (in_fmt, n, s.name)
+        cache = self.__dict__.setdefault("_up2_variant_names", {})
+        if key not in cache:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(_lib.lib().nb_modconv3x3_up2_h3_variant(in_fmt, s.in_channels, s.out_channels, n, s.in_res, s.in_res, buf, 128), "variant")
+            cache[key] = buf.value.decode()
+        return cache[key]
 
     def _get_plan(self, n: int, device, slot: int = 0) -> _Plan:
         self._ensure_packed()

@@ -963,6 +963,105 @@ def pack_h2f8(x, scale=None, x2=None):
     return out
 
 
+F6_CH = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]      # channel of a 16-channel chunk behind field pair i ("f6" format)
+_E2M3_GRID = [0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1.375, 1.5, 1.625, 1.75, 1.875,
+              2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5]
+
+
+def e2m3_encode(t: torch.Tensor) -> torch.Tensor:
+    """float -> 6-bit e2m3 codes (sign | 2 exponent bits | 3 mantissa bits), round to nearest even, saturating at +-7.5
+    (what v_cvt_scalef32_2xpk16_fp6_f32 does: tools/microbench/mfma_f6_check.hip)."""
+    a = t.abs().clamp(max=7.5)
+    step = torch.where(a < 2, 0.125, torch.where(a < 4, 0.25, 0.5))
+    q = torch.round(a / step) * step
+    code = torch.where(q < 2, q * 8, torch.where(q < 4, 8 + q * 4, 16 + q * 2)).to(torch.int64)
+    return code | (torch.signbit(t).to(torch.int64) << 5)
+
+
+def e2m3_decode(code: torch.Tensor) -> torch.Tensor:
+    grid = torch.tensor(_E2M3_GRID, dtype=torch.float32, device=code.device)
+    v = grid[(code & 31).long()]
+    return torch.where((code & 32) != 0, -v, v)
+
+
+def f6_block_exponent(m: torch.Tensor) -> torch.Tensor:
+    """Exponent e of a block's scale 2^e: the exponent of the block's largest magnitude minus 2 (0 for an all-zero block)."""
+    e = torch.floor(torch.log2(m.clamp(min=2.0 ** -100)))
+    return torch.where(m > 0, e - 2, torch.zeros_like(e))
+
+
+def pack_f6_fields(fields: torch.Tensor) -> torch.Tensor:
+    """[..., 32] six-bit codes -> [..., 24] bytes (little-endian bit stream, field f at bits 6f .. 6f+5)."""
+    f = fields.to(torch.int64).reshape(*fields.shape[:-1], 8, 4)
+    w = f[..., 0] | (f[..., 1] << 6) | (f[..., 2] << 12) | (f[..., 3] << 18)
+    return torch.stack([w & 255, (w >> 8) & 255, (w >> 16) & 255], dim=-1).reshape(*fields.shape[:-1], 24).to(torch.uint8)
+
+
+def unpack_f6_fields(b: torch.Tensor) -> torch.Tensor:
+    """[..., 24] bytes -> [..., 32] six-bit codes."""
+    t = b.to(torch.int64).reshape(*b.shape[:-1], 8, 3)
+    w = t[..., 0] | (t[..., 1] << 8) | (t[..., 2] << 16)
+    return torch.stack([w & 63, (w >> 6) & 63, (w >> 12) & 63, (w >> 18) & 63], dim=-1).reshape(*b.shape[:-1], 32)
+
+
+def pack_conv_weight_h3f6(weight: torch.Tensor) -> torch.Tensor:
+    """[O,I,3,3] fp32 -> the "f6" weight format: container of pack_conv_weight_h3; the two lo slots of a (chunk, tap, c_out) hold 32
+    e2m3 fields (field 2i = w[ch(i)] / Sw, field 2i+1 = (w - f16(w))[ch(i)] * 2^11 / Sw), the byte of Sw * 2^-11 and zeros
+    (include/neube_hip.h)."""
+    o, i, kh, kw = weight.shape
+    assert kh == 3 and kw == 3
+    w = weight.detach().to(torch.float32)
+    nch, op = (i + 15) // 16, (o + 63) // 64 * 64
+    wp = torch.zeros([nch * 16, 3, 3, op], dtype=torch.float32, device=w.device)
+    wp[:i, :, :, :o] = w.permute(1, 2, 3, 0)
+    hi = wp.to(torch.float16)
+    lo2048 = (wp - hi.to(torch.float32)) * 2048.0
+    out = torch.zeros([nch, 3, 3, 2, 2, op, 16], dtype=torch.uint8, device=w.device)
+    hi_b = hi.reshape(nch, 2, 8, 3, 3, op).permute(0, 3, 4, 1, 5, 2).contiguous().view(torch.uint8)      # [chunk,ky,kx,cg,o,16]
+    out[:, :, :, :, 0] = hi_b.reshape(nch, 3, 3, 2, op, 16)
+    a = wp.reshape(nch, 16, 3, 3, op).permute(0, 2, 3, 4, 1)                  # [chunk,ky,kx,o,16 ch]
+    b = lo2048.reshape(nch, 16, 3, 3, op).permute(0, 2, 3, 4, 1)
+    e = f6_block_exponent(torch.maximum(a.abs(), b.abs()).amax(dim=-1, keepdim=True))
+    sw = torch.exp2(e)
+    ch = torch.tensor(F6_CH, device=w.device)
+    fields = torch.stack([e2m3_encode(a[..., ch] / sw), e2m3_encode(b[..., ch] / sw)], dim=-1).reshape(nch, 3, 3, op, 32)
+    by = pack_f6_fields(fields)                                               # [chunk,ky,kx,o,24]
+    out[:, :, :, 0, 1] = by[..., :16]
+    out[:, :, :, 1, 1, :, :8] = by[..., 16:]
+    out[:, :, :, 1, 1, :, 8] = (e[..., 0] + (127 - 11)).clamp(0, 254).to(torch.uint8)
+    return out.view(torch.float16).reshape(nch, 3, 3, 2, 2, op, 8)
+
+
+def pack_h2f6(x, scale=None, x2=None):
+    """fp32 NCHW (x ++ x2) * scale[n,c] -> the "f6" activation format (same container as H2)."""
+    _dev(x, "x")
+    n, c1, h, w = x.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    out = torch.empty(h2_shape(n, c1 + c2, h, w), dtype=torch.float16, device=x.device)
+    sc = None if scale is None else scale.contiguous()
+    with _on(x.device):
+        _lib.check(_lib.lib().nb_pack_h2f6_f32(_p(x.contiguous()), c1, _p(None if x2 is None else x2.contiguous()), c2,
+                                               _p(sc), _p(out), n, h * w, _stream(x)), "pack_h2f6")
+    return out
+
+
+def unpack_h2f6(t: torch.Tensor, c: int):
+    """f6-format tensor [n, c8, 2, h, w, 8] -> (hi f32 [n,c,h,w], xl*2^11 decoded [n,c,h,w], x decoded [n,c,h,w], scale [n,c/16,h,w]):
+    the inverse of the format, for tests."""
+    nn, c8, _, h, w_, _ = t.shape
+    hi = t[:, :, 0].float().permute(0, 1, 4, 2, 3).reshape(nn, c8 * 8, h, w_)[:, :c]
+    lo = t[:, :, 1].contiguous().view(torch.uint8).reshape(nn, c8 // 2, 2, h, w_, 16)
+    by = torch.cat([lo[:, :, 0], lo[:, :, 1, ..., :8]], dim=-1)              # [n, chunk, h, w, 24]
+    codes = unpack_f6_fields(by).reshape(nn, c8 // 2, h, w_, 16, 2)
+    sc = torch.exp2(lo[:, :, 1, ..., 8].float() - 127.0)                     # [n, chunk, h, w]
+    dec = e2m3_decode(codes) * sc[..., None, None]
+    inv = torch.argsort(torch.tensor(F6_CH, device=t.device))
+    dec = dec[..., inv, :]                                                   # field-pair order -> channel order
+    xl = dec[..., 0].permute(0, 1, 4, 2, 3).reshape(nn, c8 * 8, h, w_)[:, :c]
+    xv = dec[..., 1].permute(0, 1, 4, 2, 3).reshape(nn, c8 * 8, h, w_)[:, :c]
+    return hi, xl, xv, sc
+
+
 def h2_shape(n, c, h, w):
     return [n, (c + 7) // 8, 2, h, w, 8]
 

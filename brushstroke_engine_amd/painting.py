@@ -367,12 +367,18 @@ class TileOps:
     stream_policy = int(os.environ.get("NB_CANVAS_STREAMS", "0"))
     stream_probe = None          # what choose_streams measured: {"ms_per_batch": {1: .., 2: ..}, "chosen": n, "batch": n}
 
+    def _set_n_streams(self, k: int) -> None:
+        """Change the number of batch streams; side streams created for another count are dropped (stream(k) indexes them)."""
+        if k != self.n_streams or (self._streams is not None and len(self._streams) != k):
+            self._streams, self._forked = None, set()
+        self.n_streams = k
+
     def choose_streams(self, n: int, render_mode: str = "clear") -> int:
         """Pick the number of batch streams for batches of ``n`` tiles: the fixed policy, or -- once per TileOps and batch size --
         two streams unless a probe -- three interleaved rounds of six synthetic batches on 1 and on 2 streams, best of three each, full
         generator passes with random styles and geometry features, ~80 ms -- shows them more than 3 % slower.  Sets ``n_streams``; the probe's figures stay in ``stream_probe`` (tools/bench_canvas.py reports them)."""
         if self.stream_policy > 0:
-            self.n_streams = self.stream_policy
+            self._set_n_streams(self.stream_policy)
             return self.n_streams
         if self.stream_probe is not None and self.stream_probe.get("batch") == n:
             return self.n_streams
@@ -696,8 +702,8 @@ class PaintingHelper:
         # side-stream kernels of an un-joined throughput call may still be reading theirs
         # 1 or 2 batch streams: measured, once per TileOps -- by jobs long enough for the ~80 ms probe to be noise (smaller ones keep the
         # default of two: what they could gain or lose is a fraction of a millisecond)
-        if n_own >= 6 * self.batch and hasattr(ops, "choose_streams"):
-            ops.choose_streams(min(self.batch, n_own), self.render_mode)
+        if hasattr(ops, "choose_streams") and (n_own >= 6 * self.batch or getattr(ops, "stream_policy", 0) > 0):
+            ops.choose_streams(min(self.batch, n_own), self.render_mode)          # (a fixed policy applies to every canvas size)
         plan_slot = lambda k: PAINT_SLOT0 + k % getattr(ops, "n_streams", 1)
         if n_own <= self.batch:                      # a single batch (interactive strokes): nothing to overlap with
             on_stream, join, plan_slot = (lambda k: contextlib.nullcontext()), (lambda tensors=(): None), (lambda k: 0)
@@ -824,9 +830,10 @@ class PaintingHelper:
         return torch.cat([recv[r][:counts[r]] for r in range(world)])
 
     def _comm_event_pair(self, name: str):
-        """A pair of HIP events around a collective of the sharded schedule (first one recorded here, on the caller's stream)."""
+        """A pair of HIP events around a collective of the sharded schedule (first one recorded here, on the caller's stream).
+        Only when ``self.comm_timing`` is set (benchmarks: tools/bench_canvas.py): the product path records nothing."""
         dev = getattr(self.ops, "device", None)
-        if dev is None or getattr(dev, "type", "cpu") != "cuda":
+        if not getattr(self, "comm_timing", False) or dev is None or getattr(dev, "type", "cpu") != "cuda":
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -24,8 +24,8 @@ PIPE_SLOT0 = 24          # workspace slots of the pipeline (generator sub-batche
 
 class TriadStepPipeline:
     """``submit(z, geom_feature, positions)`` enqueues one batch and returns its uint8 RGBA tiles ``[N, R, R, 4]`` -- valid
-    on ``tail_stream`` (make a consumer stream wait with ``wait()`` / ``flush()``, which also record the tiles on that stream, or
-    synchronise the device).  Up to
+    on ``tail_stream`` (make a consumer stream wait with ``wait()`` / ``flush()``, or synchronise the device; the tiles are
+    recorded on the submitting stream for the caching allocator and the pipeline keeps no reference to them).  Up to
     ``depth`` batches are in flight: the tail of batch k and the head of batch k+1."""
 
     def __init__(self, G, split_res: int = 16, depth: int = 2, render_mode: str = "clear"):
@@ -41,7 +41,6 @@ class TriadStepPipeline:
         self._k = 0
         self._pending = None          # (slot, ws, x, geom, positions, user_colors, sfactor, head event)
         self._forked = False
-        self._outputs: List[torch.Tensor] = []     # tiles handed out since the last wait(): allocated on the tail stream, read elsewhere
 
     # -- the two halves of one batch --
     def _head(self, slot, z, geom, positions):
@@ -88,7 +87,7 @@ class TriadStepPipeline:
                 done = torch.cuda.Event()
                 done.record(self.tail_stream)
             self._tail_done[0] = done
-            self._outputs.append(u8)
+            u8.record_stream(cur)
             return u8
         slot = self._k % self.depth
         self._k += 1
@@ -108,20 +107,19 @@ class TriadStepPipeline:
             done = torch.cuda.Event()
             done.record(self.tail_stream)
         self._tail_done[slot] = done
-        self._outputs.append(u8)
+        u8.record_stream(cur)                      # allocated on the pipeline's stream, consumed on the caller's (see wait())
         return u8
 
     def wait(self, stream=None) -> None:
         """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far.  The tiles returned by
-        ``submit`` since the last call were allocated on the tail stream; they are recorded on ``stream`` here, so that the
-        caching allocator does not hand their memory to a later step while a read or copy enqueued on ``stream`` is pending
-        (a consumer on yet another stream calls ``tile.record_stream(that_stream)`` itself)."""
+        ``submit`` were allocated on the tail stream; ``submit`` itself records each of them on the stream it was called from
+        (``Tensor.record_stream``), so the caching allocator does not hand their memory to a later step while a read or copy
+        enqueued on that stream is pending, and the pipeline keeps NO reference to them (a caller that drops a tile without ever
+        calling ``wait`` -- e.g. a benchmark loop that only synchronises the device -- frees it).  A consumer on yet another
+        stream calls ``tile.record_stream(that_stream)`` itself."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         stream.wait_stream(self.tail_stream)
         stream.wait_stream(self.head_stream)
-        for t in self._outputs:
-            t.record_stream(stream)
-        self._outputs = []
 
     def flush(self) -> None:
         self.wait()
@@ -157,7 +155,6 @@ class TriadPrefetchPipeline:
         self._mark_prev: Optional[torch.cuda.Event] = None                          # previous step reached its marked layer
         self._k = 0
         self._forked = False
-        self._outputs: List[torch.Tensor] = []     # tiles handed out since the last wait() (see TriadStepPipeline.wait)
 
     def submit(self, z, geom_feature, positions, user_colors=None, sfactor=None) -> torch.Tensor:
         if positions is None:
@@ -195,18 +192,15 @@ class TriadPrefetchPipeline:
             done.record(self.main_stream)
         self._main_done[slot] = done
         self._mark_prev = mark
-        self._outputs.append(u8)
+        u8.record_stream(cur)                      # allocated on the pipeline's stream, consumed on the caller's (see wait())
         return u8
 
     def wait(self, stream=None) -> None:
-        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far; the tiles handed out
-        since the last call are recorded on it (see TriadStepPipeline.wait)."""
+        """Make ``stream`` (default: the caller's current stream) wait for everything submitted so far (the tiles were recorded
+        on the submitting stream by ``submit``; see TriadStepPipeline.wait)."""
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         stream.wait_stream(self.main_stream)
         stream.wait_stream(self.prep_stream)
-        for t in self._outputs:
-            t.record_stream(stream)
-        self._outputs = []
 
     def flush(self) -> None:
         self.wait()

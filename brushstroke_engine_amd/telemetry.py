@@ -23,7 +23,8 @@ def _read_int(path: str) -> Optional[int]:
 
 
 def find_hwmon(pci_bus_id: Optional[str] = None) -> Optional[str]:
-    """hwmon directory of the amdgpu device with that PCI address ("0000:05:00.0"), or of the first device that has one."""
+    """hwmon directory of the amdgpu device with that PCI address ("0000:05:00.0"); without an address, of the first device that
+    has one.  An address that matches no device gives None (no telemetry) rather than another GPU's sensors."""
     first = None
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
         dev = os.path.join(card, "device")
@@ -37,7 +38,7 @@ def find_hwmon(pci_bus_id: Optional[str] = None) -> Optional[str]:
                     return mons[0]
             except OSError:
                 pass
-    return first if not pci_bus_id or first is None else first
+    return None if pci_bus_id else first
 
 
 def pci_bus_id_of(device_index: int) -> Optional[str]:
@@ -54,7 +55,7 @@ class PowerClockSampler:
     """``with PowerClockSampler(hwmon) as s: ...; s.mark("f8"); run; s.unmark()`` -- samples (time, watts, MHz) every
     ``period`` seconds in a daemon thread; ``summary(name)`` gives the means over the marked window."""
 
-    def __init__(self, hwmon: Optional[str], period: float = 0.002):
+    def __init__(self, hwmon: Optional[str], period: float = 0.01):
         self.hwmon = hwmon
         self.period = period
         self.samples: List[tuple] = []

@@ -287,6 +287,19 @@ int nb_pack_h2f8_f32(const float* x1, int c1, const float* x2, int c2, const flo
 int nb_pack_h2f8_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out, int c8_total, int cg0,
                           int n, int hw, void* stream);
 
+/* ---- "f6" operand format (round 5): the two correction products on one block-scaled fp6 (e2m3) MFMA per tap pair, at the f16
+ * instruction's cycles.  Same containers; the two lo slots of a 16-channel chunk (32 bytes per pixel / per (c_out, tap)) hold 32
+ * six-bit fields (24 bytes), the chunk's E8M0 scale byte and zeros: activations field 2i = e2m3(xl[ch(i)]*2^11/S), field 2i+1 =
+ * e2m3(x[ch(i)]/S), S = 2^(exponent of the chunk's largest |x| - 2), byte = S; weights field 2i = e2m3(w[ch(i)]/Sw), field 2i+1 =
+ * e2m3((w - f16(w))[ch(i)]*2^11/Sw), byte = Sw*2^-11; ch(i) = channels 0-3, 8-11, 4-7, 12-15 of the chunk.  c_in % 16 == 0.
+ * Operand format number 2 of nb_modconv3x3_up1_h3_ex / nb_modconv3x3_up2_h3_ex (0 = H2, 1 = f8).  Replaces nothing in the reference
+ * (its convolutions are cuDNN calls, torch_utils/ops/conv2d_gradfix.py:35-43); the math it serves is training/networks.py:30-88. */
+int nb_pack_h2f6_f32(const float* x1, int c1, const float* x2, int c2, const float* scale, void* out, int n, int hw,
+                     void* stream);
+/* c % 16 == 0 channels into the 16-channel chunks starting at channel group cg0 (even) of an f6-format tensor */
+int nb_pack_h2f6_part_f32(const float* x, int c, const float* scale, int scale_stride, void* out, int c8_total, int cg0,
+                          int n, int hw, void* stream);
+
 /* Arguments of the triad ToRGB epilogue when it is fused into the last conv (same meaning as the parameters of
  * nb_torgb_triad_f32; any output pointer may be NULL). */
 struct NbTorgbArgs {

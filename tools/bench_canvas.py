@@ -112,6 +112,7 @@ def run(a, rank, world, dev, backend):
     ops = painting.TileOps(G, enc)
     ops.stream_policy = 0 if a.streams == "auto" else int(a.streams)
     helper = painting.PaintingHelper(ops, batch=a.batch)
+    helper.comm_timing = True                            # (HIP events around the collectives: benchmark only)
     helper.set_feature_blending(a.level)
     opts = painting.GanBrushOptions()
     opts.set_style(torch.from_numpy(np.random.RandomState(int(gold["style_seed"]) if gold else 594).randn(1, cfg.z_dim)), 594)

@@ -38,7 +38,7 @@ bash tools/ab_xcd_traffic.sh > $O/ab_xcd_order.txt 2>&1
 # same-box A/Bs of the round's K loops: round-3 kernels vs software-pipelined ones (up=2: also the one-wave-per-SIMD wide form)
 bash tools/ab_v2.sh $O/ab_v2 > $O/ab_up2_kernels.txt 2>&1; rm -rf $O/ab_v2
 bash tools/ab_up1.sh $O/ab_up1 > $O/ab_up1_kloops.txt 2>&1; rm -rf $O/ab_up1
-$R/tools/microbench/bin/valu_issue > $O/microbench_valu_issue.txt 2>&1
+bash $R/tools/microbench/run_all.sh > $O/microbench.txt 2>&1
 python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
 NB_SUBS="1 2" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace -d $O/b1trace -o b1 --output-format csv -- python3 $R/tools/trace_b1.py > $O/b1trace.log 2>&1)
