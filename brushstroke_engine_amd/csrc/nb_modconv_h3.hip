@@ -289,17 +289,26 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         const int b6 = (wn * NBW) * TWP + l31, b6_01 = b6 + lh;             // + (2 q + 1) XPL + (nb + ky) TWP (+ 2 for tap 2)
         auto rd_hi = [&](auto i_, h8 (&a)[MB], h8 (&b)[NBW], const h8* wb, const h8* xb, int ky, int kx) {
             constexpr int i = decltype(i_)::value;
+#ifdef NB_ABL6_NOREAD
+            return;
+#endif
             if constexpr (i < MB) a[i] = wb[a_base + kx * 4 * CO_WG + i * 32];
             else b[i - MB] = xb[b_base + (i - MB + ky) * TWP + kx];
         };
         // lo slot q of fragment i: the pair (0, 1) -- the lane's own tap -- or the lone tap 2 (weights of lane half 1: the zero slot)
         auto rd_lo01 = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, int ky) {
             constexpr int i = decltype(i_)::value, q = decltype(q_)::value;
+#ifdef NB_ABL6_NOREAD
+            return;
+#endif
             if constexpr (i < MB) { NB_Q(a[i], q, wb[a6_01 + (2 * q + 1) * CO_WG + i * 32]); }
             else { NB_Q(b[i - MB], q, xb[b6_01 + (2 * q + 1) * XPL + (i - MB + ky) * TWP]); }
         };
         auto rd_lo2 = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, int ky) {
             constexpr int i = decltype(i_)::value, q = decltype(q_)::value;
+#ifdef NB_ABL6_NOREAD
+            return;
+#endif
             if constexpr (i < MB) { const h8* src = lh ? &s_zero6 : wb + a6 + 8 * CO_WG + (2 * q + 1) * CO_WG + i * 32; NB_Q(a[i], q, *src); }
             else { NB_Q(b[i - MB], q, xb[b6 + (2 * q + 1) * XPL + (i - MB + ky) * TWP + 2]); }
         };
@@ -319,12 +328,18 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         auto mf_f16 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
             return [&](auto mb_, auto nb_) {
                 constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+#ifdef NB_ABL6_NOMFMA
+                return;
+#endif
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
             };
         };
         auto mf_fp6 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
             return [&](auto mb_, auto nb_) {
                 constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
+#if defined(NB_ABL6_NOFP6) || defined(NB_ABL6_NOMFMA)
+                return;
+#endif
                 acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 2, 2, 0, a[mb][6], 0, b[nb][6]);
             };
         };
@@ -341,6 +356,12 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             const int t3 = clampt(t + 3), c1 = c + 1 < NC ? c + 1 : NC - 1;
             auto dma = [&](auto i_) {
                 constexpr int i = decltype(i_)::value;
+#ifdef NB_ABL6_NODMA
+                return;
+#endif
+#ifdef NB_ABL6_NOWDMA
+                if constexpr (i < NWPW) return;
+#endif
                 if constexpr (i < NWPW) issue_w_v2(i_, t3, (t + 3) & 3);
                 else issue_x_v2(std::integral_constant<int, i - NWPW>{}, c1, (c + 1) & 1);
             };
@@ -354,8 +375,20 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 if constexpr (i < NF) rd_lo2(i_, Q0{}, al2, bl2, wb, xb, KY);
                 else rd_lo2(std::integral_constant<int, i - NF>{}, Q1{}, al2, bl2, wb, xb, KY);
             });
+#if defined(NB_ABL6_NODMA) || defined(NB_ABL6_NOWDMA)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#elif defined(NB_ABL6_NOBAR)
+            if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWPW + NXPW) : "memory");
+#elif defined(NB_ABL6_NOLGKM0)
+            if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NWPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NWPW + NXPW) : "memory");
+#elif defined(NB_ABL6_NOVMCNT)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
             if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW + NXPW) : "memory");
+#endif
             NB_SB;
             // part B
             group(std::integral_constant<int, NF>{}, mf_f16(ah1, bh1),                                // tap 1
@@ -1954,8 +1987,9 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
                           void* stream, int in_fmt = 0, int out_fmt = 0) {
-    NB_REQUIRE((in_fmt == 0 || in_fmt == 1) && (out_fmt == 0 || out_fmt == 1), "modconv3x3_up2_h3: operand format must be 0 (H2) or 1 (f8)");
-    NB_REQUIRE(in_fmt == 0 || c_in % 16 == 0, "modconv3x3_up2_h3: the f8 operand format needs c_in %% 16 == 0 (got %d)", c_in);
+    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 2 && (out_fmt == 0 || out_fmt == 1), "modconv3x3_up2_h3: input operand format must be 0 (H2), 1 (f8) or 2 (f6), "
+               "output format 0 or 1 (the up=2 epilogue does not write the f6 format)");
+    NB_REQUIRE(in_fmt == 0 || c_in % 16 == 0, "modconv3x3_up2_h3: the f8 / f6 operand formats need c_in %% 16 == 0 (got %d)", c_in);
     NB_REQUIRE(out_fmt == 0 || (y_h2 && c_out % 16 == 0 && c_next % 16 == 0), "modconv3x3_up2_h3: f8 output needs an H2 destination and c_out, c_next %% 16 == 0");
     NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && ((y != nullptr) != (y_h2 != nullptr)), "modconv3x3_up2_h3: null pointer");
     NB_REQUIRE(!y_h2 || (next_styles && c_out % 8 == 0 && c_next >= c_out && next_stride >= c_out && (uintptr_t)y_h2 % 16 == 0),
@@ -1978,7 +2012,9 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     p.tiles_x = w / 32; p.slices = (c_out + 31) / 32;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.out_f8 = out_fmt;
-    switch (nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)) {
+    const Up2Form form = nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w);
+    NB_REQUIRE(in_fmt != 2 || form == UP2_V2, "modconv3x3_up2_h3: f6 operands are taken by the 12-row software-pipelined kernel only (this launch: %dx%d, batch %d)", h, w, n);
+    switch (form) {
         case UP2_WIDE: return nb_up2w_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
         case UP2_W16: return nb_up2_h3_launch<8, 16>(p, n, in_fmt, stream);
         case UP2_W8: return nb_up2_h3_launch<8, 8>(p, n, in_fmt, stream);
@@ -1992,7 +2028,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
 
 extern "C" int nb_modconv3x3_up2_h3_variant(int in_fmt, int c_in, int c_out, int n, int h, int w, char* buf, int buflen) {
     NB_REQUIRE(buf && buflen > 0, "modconv3x3_up2_h3_variant: bad buffer");
-    NB_REQUIRE((in_fmt == 0 || in_fmt == 1) && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16 || w == 8), "modconv3x3_up2_h3_variant: bad shape");
+    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 2 && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16 || w == 8), "modconv3x3_up2_h3_variant: bad shape");
     static const char* const names[] = {"modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel",
                                         "modconv3x3_up2_h3_kernel", "modconv3x3_up2w_kernel", "modconv3x3_up2v_kernel", "modconv3x3_up2_h3_kernel"};
     snprintf(buf, buflen, "%s", names[nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)]);

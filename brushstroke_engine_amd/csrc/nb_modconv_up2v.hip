@@ -14,6 +14,19 @@
 //   * the two 16-byte halves of a block-scaled fp8 operand are read straight into one 8-register tuple (no v_mov assembling).
 #include "nb_h3_common.h"
 
+#ifdef NB_ABL6_NOMFMA
+#define NB_ABL6_F16 false
+#define NB_ABL6_FP6 false
+#elif defined(NB_ABL6_NOFP6)
+#define NB_ABL6_F16 true
+#define NB_ABL6_FP6 false
+#else
+#define NB_ABL6_F16 true
+#define NB_ABL6_FP6 true
+#endif
+#ifdef NB_ABL6_NODMA
+#define NB_ABL_NODMA 1
+#endif
 namespace {
 constexpr int TQH = 12, TQW = 32, NW = 8, NT = NW * 64;
 constexpr int PH = TQH + 2, PW = TQW + 2, NPOS = PH * PW;            // 14 x 34 = 476 halo'd quad positions
@@ -30,8 +43,14 @@ static_assert(NBLK <= NBJ * NW && KMIX * NW <= NXP && (KMIX + 1) * NW > NXP && N
 
 // F8: "f8" operands (hi f16 + fp8 correction operands: 14 matrix instructions per tap-chunk and block) or H2 operands (hi / lo f16:
 // three f16 MFMAs per tap, 27 per chunk and block -- the `h3` arithmetic mode)
-template <bool F8, int OUTM>
+// F6 (with F8): the "f6" operand format (nb_h3_common.h): the correction products on fp6 MFMAs, 14 x 32 = 448 matrix cycles per chunk and block
+// instead of 9 x 32 + 5 x 64 = 608.  A lane's 32 K values of a correction instruction = ONE tap at ONE position, both terms (one block
+// scale per lane): lane half 0 takes the first tap of a pair, lane half 1 the second -- per-lane lo-slot addresses --, and the operand
+// tuple is the chunk's two lo slots as they stand (quad 0 = (cg 0, lo), quad 1 = (cg 1, lo): six dwords of fields, the scale dword =
+// the instruction's scale operand).  The lone tap 4: lane half 1 multiplies a zero slot on the weights side.
+template <bool F8, int OUTM, bool F6 = false>
 __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Params p) {
+    static_assert(!F6 || F8, "the f6 form is a variant of the f8 loop");
     NB_TSTAMP(0);
     if constexpr (OUTM == 2) nb_set_fp16_ovfl();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_v[];
@@ -139,6 +158,13 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         boff[j] = lh * 2 * XPL + r * XS + c;
     }
     const int aoff = 4 * XPL + lh * 2 * CO_WG + l31;  // + tap * 128 + hl * 32
+    // f6: lo slot q of tap t = row 4 t + 2 q + 1 of the weights; of position offset d = plane 2 q + 1 of the activations
+    const int a6 = 4 * XPL + CO_WG + l31;             // + tap * 128 + q * 64
+    int b6[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) b6[j] = boff[j] - lh * 2 * XPL + XPL;     // + q * 2 XPL + offset
+    __shared__ __attribute__((aligned(16))) h8 s_zero6;
+    if constexpr (F6) { if (tid == 0) s_zero6 = h8{}; }
 
     f32x16 acc[NBJ][4];
 #pragma unroll
@@ -204,8 +230,14 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     // chunks.  sa: this chunk's stage, san: the next chunk's; d2 / d3: first slots of the stages of chunks c + 2 / c + 3
     auto chunk = [&](auto mode_, auto nbe_, int c, const h8* sa, const h8* san, int d2, int d3) {
         constexpr int MODE = decltype(mode_)::value, NBE = decltype(nbe_)::value;
+#ifdef NB_ABL6_NOREAD
+        const h8 zero_frag = h8{};
+        auto rA = [&](int tap, int hl, const h8* s) -> const h8& { return zero_frag; };
+        auto rBh = [&](h8 (&bh)[NBJ], auto j_, int del, const h8* s) {};
+#else
         auto rA = [&](int tap, int hl, const h8* s) -> const h8& { return s[aoff + tap * 128 + hl * 32]; };
         auto rBh = [&](h8 (&bh)[NBJ], auto j_, int del, const h8* s) { constexpr int j = decltype(j_)::value; if constexpr (j < NBE) bh[j] = s[boff[j] + del]; };
+#endif
         auto rBl = [&](i32x8 (&bl)[NBJ], int half, auto j_, int del, const h8* s) {
             constexpr int j = decltype(j_)::value;
             if constexpr (j < NBE) { if (half) set_hi(bl[j], s[boff[j] + XPL + del]); else set_lo(bl[j], s[boff[j] + XPL + del]); }
@@ -316,6 +348,111 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
             NB_FENCE();
             return;
         }
+        if constexpr (F6) {
+            // lo slots of the weights of pair (ta, tb) -> tuple `al` quad q (the lane's own tap); of the lone tap 4 (lane half 1: zeros)
+            auto rA6 = [&](i32x8& al, int q, int ta, int tb, const h8* s_) {
+#ifdef NB_ABL6_NOREAD
+                return;
+#endif
+                const h8& v = s_[a6 + (lh ? tb : ta) * 128 + q * 64];
+                if (q) set_hi(al, v); else set_lo(al, v);
+            };
+            auto rA6m = [&](i32x8& al, int q, const h8* s_) {
+#ifdef NB_ABL6_NOREAD
+                return;
+#endif
+                const h8* src = lh ? &s_zero6 : s_ + a6 + 4 * 128 + q * 64;
+                if (q) set_hi(al, *src); else set_lo(al, *src);
+            };
+            // lo slots of the activations at offsets (da | db) -> tuple bl[j] quad q
+            auto rB6 = [&](i32x8 (&bl)[NBJ], int q, auto j_, int da, int db, const h8* s_) {
+                constexpr int j = decltype(j_)::value;
+#ifdef NB_ABL6_NOREAD
+                return;
+#endif
+                if constexpr (j < NBE) {
+                    const h8& v = s_[b6[j] + q * 2 * XPL + (lh ? db : da)];
+                    if (q) set_hi(bl[j], v); else set_lo(bl[j], v);
+                }
+            };
+            auto group_pair6 = [&](auto ph_, h8 (&ah)[2], i32x8& al, h8 (&Ba)[NBJ], h8 (&Bb)[NBJ], i32x8 (&bl)[NBJ], auto&& filler) {
+                constexpr int ph = decltype(ph_)::value;
+                nb_static_for<0, 2>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
+                    f32x16& a_ = acc[j][ph];
+                    if constexpr (j < NBE && NB_ABL6_F16) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], Ba[j], a_, 0, 0, 0);
+                    NB_FENCE(); filler(std::integral_constant<int, 3 * j>{}); NB_FENCE();
+                    if constexpr (j < NBE && NB_ABL6_F16) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], Bb[j], a_, 0, 0, 0);
+                    NB_FENCE(); filler(std::integral_constant<int, 3 * j + 1>{}); NB_FENCE();
+                    if constexpr (j < NBE && NB_ABL6_FP6) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al, bl[j], a_, 2, 2, 0, al[6], 0, bl[j][6]);
+                    NB_FENCE(); filler(std::integral_constant<int, 3 * j + 2>{}); NB_FENCE();
+                });
+            };
+            NB_FENCE();
+            // G0: taps 8, 6 -> phase 0 (positions 0 | 1).  Fillers: the A fragments of G1; pieces 2, 3
+            group_pair6(std::integral_constant<int, 0>{}, ah_a, al_a, bh0, bh1, bl01, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 0) ah_n[0] = rA(5, 0, sa);
+                else if constexpr (g == 1) ah_n[1] = rA(3, 0, sa);
+                else if constexpr (g == 2) dma(std::integral_constant<int, 2>{});
+                else if constexpr (g == 3) rA6(al_n, 0, 5, 3, sa);
+                else if constexpr (g == 4) rA6(al_n, 1, 5, 3, sa);
+                else dma(std::integral_constant<int, 3>{});
+            });
+            // G1: taps 5, 3 -> phase 2 (positions 0 | 1).  Fillers: tap 4, the row-below hi fragments; piece 4
+            group_pair6(std::integral_constant<int, 2>{}, ah_n, al_n, bh0, bh1, bl01, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 0) ah_m = rA(4, 0, sa);
+                else if constexpr (g == 1) rA6m(al_m, 0, sa);
+                else if constexpr (g == 2) { dma(std::integral_constant<int, 4>{}); rA6m(al_m, 1, sa); }
+                else if constexpr (g == 3) rBh(bh2, J0_{}, XS, sa);
+                else if constexpr (g == 4) rBh(bh2, J1_{}, XS, sa);
+            });
+            // G2: tap 4 -> phase 3: (f16, fp6) x 2; lane half 1 of A = zeros.  Fillers: the A fragments of G3; piece 5; behind the fp6
+            // MFMA that was the last to read a block's (0 | 1) tuple, the (0 | XS) slots into it
+            nb_static_for<0, 2>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                f32x16& a_ = acc[j][3];
+                if constexpr (j < NBE && NB_ABL6_F16) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_m, bh0[j], a_, 0, 0, 0);
+                NB_FENCE();
+                if constexpr (j == 0) { ah_a[0] = rA(7, 0, sa); ah_a[1] = rA(1, 0, sa); } else { rA6(al_a, 0, 7, 1, sa); rA6(al_a, 1, 7, 1, sa); }
+                NB_FENCE();
+                if constexpr (j < NBE && NB_ABL6_FP6) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al_m, bl01[j], a_, 2, 2, 0, al_m[6], 0, bl01[j][6]);
+                NB_FENCE();
+                if constexpr (j == 0) dma(std::integral_constant<int, 5>{});
+                rB6(bl01, 0, j_, 0, XS, sa); rB6(bl01, 1, j_, 0, XS, sa);
+                NB_FENCE();
+            });
+            // G3: taps 7, 1 -> phase 1 (positions 0 | XS).  Fillers: the A fragments of G4, the diagonal fragments, the (XS | XS + 1) slots; piece 6
+            group_pair6(std::integral_constant<int, 1>{}, ah_a, al_a, bh0, bh2, bl01, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 0) { ah_n[0] = rA(2, 0, sa); ah_n[1] = rA(0, 0, sa); }
+                else if constexpr (g == 1) { rB6(bl23, 0, J0_{}, XS, XS + 1, sa); rB6(bl23, 1, J0_{}, XS, XS + 1, sa); }
+                else if constexpr (g == 2) { dma(std::integral_constant<int, 6>{}); rA6(al_n, 0, 2, 0, sa); }
+                else if constexpr (g == 3) { rA6(al_n, 1, 2, 0, sa); rBh(bh3, J0_{}, XS + 1, sa); }
+                else if constexpr (g == 4) { rBh(bh3, J1_{}, XS + 1, sa); rB6(bl23, 0, J1_{}, XS, XS + 1, sa); }
+                else rB6(bl23, 1, J1_{}, XS, XS + 1, sa);
+            });
+            if constexpr (MODE >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPC) : "memory");
+            else if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            NB_FENCE();
+            // G4: taps 2, 0 -> phase 0 (positions XS | XS + 1).  Fillers: the NEXT chunk's first operands; pieces 0, 1 of chunk c + 3
+            group_pair6(std::integral_constant<int, 0>{}, ah_n, al_n, bh2, bh3, bl23, [&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                if constexpr (g == 2) dma(std::integral_constant<int, 0>{});
+                if constexpr (g == 5) dma(std::integral_constant<int, 1>{});
+                if constexpr (MODE >= 1) {
+                    if constexpr (g == 0) { ah_a[0] = rA(8, 0, san); rBh(bh0, J0_{}, 0, san); }
+                    else if constexpr (g == 1) { ah_a[1] = rA(6, 0, san); rBh(bh1, J0_{}, 1, san); }
+                    else if constexpr (g == 2) { rBh(bh0, J1_{}, 0, san); rBh(bh1, J1_{}, 1, san); }
+                    else if constexpr (g == 3) { rA6(al_a, 0, 8, 6, san); rA6(al_a, 1, 8, 6, san); }
+                    else if constexpr (g == 4) { rB6(bl01, 0, J0_{}, 0, 1, san); rB6(bl01, 1, J0_{}, 0, 1, san); }
+                    else { rB6(bl01, 0, J1_{}, 0, 1, san); rB6(bl01, 1, J1_{}, 0, 1, san); }
+                }
+            });
+            NB_FENCE();
+            return;
+        }
         // a tap pair on both blocks: (f16, f16, fp8) x 2; filler(g) behind MFMA g = 3 j + position
         auto group_pair = [&](auto ph_, h8 (&ah)[2], i32x8& al, h8 (&Ba)[NBJ], h8 (&Bb)[NBJ], i32x8 (&bl)[NBJ], auto&& filler) {
             constexpr int ph = decltype(ph_)::value;
@@ -398,12 +535,14 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         constexpr int NBE = decltype(nbe)::value;
         // the first chunk's first operands
         ah_a[0] = ring[aoff + 8 * 128]; ah_a[1] = ring[aoff + 6 * 128];
-        if constexpr (F8) { set_lo(al_a, ring[aoff + 8 * 128 + 32]); set_hi(al_a, ring[aoff + 6 * 128 + 32]); }
+        if constexpr (F6) { const int t_ = lh ? 6 : 8; set_lo(al_a, ring[a6 + t_ * 128]); set_hi(al_a, ring[a6 + t_ * 128 + 64]); }
+        else if constexpr (F8) { set_lo(al_a, ring[aoff + 8 * 128 + 32]); set_hi(al_a, ring[aoff + 6 * 128 + 32]); }
         else { hl_a[0] = ring[aoff + 8 * 128 + 32]; hl_a[1] = ring[aoff + 6 * 128 + 32]; }
 #pragma unroll
         for (int j = 0; j < NBE; ++j) {
             bh0[j] = ring[boff[j]]; bh1[j] = ring[boff[j] + 1];
-            if constexpr (F8) { set_lo(bl01[j], ring[boff[j] + XPL]); set_hi(bl01[j], ring[boff[j] + XPL + 1]); }
+            if constexpr (F6) { set_lo(bl01[j], ring[b6[j] + lh]); set_hi(bl01[j], ring[b6[j] + 2 * XPL + lh]); }
+            else if constexpr (F8) { set_lo(bl01[j], ring[boff[j] + XPL]); set_hi(bl01[j], ring[boff[j] + XPL + 1]); }
             else { bl0[j] = ring[boff[j] + XPL]; bl1[j] = ring[boff[j] + XPL + 1]; }
         }
         int c = 0, s = 0;                             // s = stage of chunk c
@@ -582,23 +721,23 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     }
 }
 
-template <bool F8, int OUTM>
+template <bool F8, int OUTM, bool F6 = false>
 static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
     constexpr size_t lds_ring = (size_t)NST * STAGE * 16, lds_epi = (size_t)16 * NBLK * 32 * 16;
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM, F6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM>), grid, dim3(NT), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM, F6>), grid, dim3(NT), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2v");
     return NB_OK;
 }
 
 // shapes this form takes: whole 16-channel chunks (f8 or H2 operands), 32-column tiles of 12 quad rows
-bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w) { return (in_fmt == 0 || in_fmt == 1) && c_in % 16 == 0 && w % TQW == 0 && h >= 8; }
+bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w) { return in_fmt >= 0 && in_fmt <= 2 && c_in % 16 == 0 && w % TQW == 0 && h >= 8; }
 
 // p as filled in by nb_up2_h3_impl (nb_modconv_h3.hip); tiles are set here
 int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long long* tstamps, int tstamps_cap) {
@@ -608,6 +747,7 @@ int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long
     p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     p.tstamps = (tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= tstamps_cap) ? tstamps : nullptr;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
+    if (in_fmt == 2) return outm == 2 ? nb_up2v_launch1<true, 2, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1, true>(p, n, stream) : nb_up2v_launch1<true, 0, true>(p, n, stream);
     if (in_fmt) return outm == 2 ? nb_up2v_launch1<true, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1>(p, n, stream) : nb_up2v_launch1<true, 0>(p, n, stream);
     return outm == 2 ? nb_up2v_launch1<false, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<false, 1>(p, n, stream) : nb_up2v_launch1<false, 0>(p, n, stream);
 }

@@ -44,7 +44,8 @@ def test_f6_pack_matches_host_format():
     assert float((xv - v).abs().max() / v.abs().max()) < 0.07
 
 
-@pytest.mark.parametrize("up,ci,co,res", [(1, 64, 64, 64), (1, 128, 128, 32), (1, 144, 96, 64), (1, 32, 64, 32)])
+@pytest.mark.parametrize("up,ci,co,res", [(1, 64, 64, 64), (1, 128, 128, 32), (1, 144, 96, 64), (1, 32, 64, 32),
+                                           (2, 128, 64, 128), (2, 384, 128, 64), (2, 144, 128, 64), (2, 64, 32, 256)])
 def test_f6_kernels_vs_float64(up, ci, co, res):
     """One layer, f6 operands, fp32 output: error against float64 at the level of the correction terms (2^-11 x 2^-4 relative per
     product, relative to the chunk's largest element): within 2x of the f8 kernel's and ~15x below a plain f16 evaluation."""
@@ -52,6 +53,7 @@ def test_f6_kernels_vs_float64(up, ci, co, res):
     rs = np.random.RandomState(up * 1000 + ci + co)
     n = 2
     hin = res if up == 1 else res // 2
+    lib = _lib.lib()
     x = torch.from_numpy((rs.randn(n, ci, hin, hin) * 2).astype(np.float32)).cuda()
     w = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
     st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
@@ -59,17 +61,23 @@ def test_f6_kernels_vs_float64(up, ci, co, res):
     ref = _conv_ref(x, w, st, up)
     S = torch.cuda.current_stream().cuda_stream
     errs = {}
-    for fmt, pack_x, pack_w in ((1, ops.pack_h2f8, ops.pack_conv_weight_h3f8), (2, ops.pack_h2f6, ops.pack_conv_weight_h3f6)):
-        xh, wp = pack_x(x, st), pack_w(w)
-        y = torch.empty([n, co, res, res], device="cuda")
-        if up == 1:
-            rc = _lib.lib().nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(),
-                                                    y.data_ptr(), None, None, 0, 0, None, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
-        else:
-            rc = _lib.lib().nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(),
-                                                    y.data_ptr(), None, None, 0, 0, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
-        _lib.check(rc, "conv")
-        errs[fmt] = float((y.cpu().double() - ref).abs().max())
+    if up == 2:
+        lib.nb_debug_set_up2_v2(1)              # the 12-row software-pipelined kernel (the up = 2 form that takes f6), whatever the launch size
+    try:
+        for fmt, pack_x, pack_w in ((1, ops.pack_h2f8, ops.pack_conv_weight_h3f8), (2, ops.pack_h2f6, ops.pack_conv_weight_h3f6)):
+            xh, wp = pack_x(x, st), pack_w(w)
+            y = torch.empty([n, co, res, res], device="cuda")
+            if up == 1:
+                rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(),
+                                                 y.data_ptr(), None, None, 0, 0, None, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
+            else:
+                rc = lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(),
+                                                 y.data_ptr(), None, None, 0, 0, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
+            _lib.check(rc, "conv")
+            errs[fmt] = float((y.cpu().double() - ref).abs().max())
+    finally:
+        if up == 2:
+            lib.nb_debug_set_up2_v2(-1)
     scale = float(ref.abs().max())
     print(f"[f6 kernel up{up} {ci}->{co}@{res}] max err / max |ref|: f8 {errs[1] / scale:.2e}  f6 {errs[2] / scale:.2e}")
     assert errs[1] <= 4e-5 * scale and errs[2] <= 8e-5 * scale, (errs, scale)

@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib, ops  # noqa: E402
 
 
-F8 = os.environ.get("NB_PHASE_F8") == "1"
+FMT = int(os.environ.get("NB_PHASE_FMT", "1" if os.environ.get("NB_PHASE_F8") == "1" else "0"))      # operand format: 0 H2, 1 f8, 2 f6
+F8 = FMT != 0
 H2OUT = os.environ.get("NB_PHASE_H2OUT") == "1"          # write the consumer's H2 / f8 tensor instead of fp32 NCHW
 
 
@@ -29,8 +30,8 @@ def run(kind, n, ci, co, res):
     styles = torch.ones(n, ci, device="cuda")
     dco = torch.ones(n, co, device="cuda")
     bias = torch.zeros(co, device="cuda")
-    xh = (ops.pack_h2f8 if F8 else ops.pack_h2)(x, styles)
-    wp = (ops.pack_conv_weight_h3f8 if F8 else ops.pack_conv_weight_h3)(w)
+    xh = (ops.pack_h2f6 if FMT == 2 else ops.pack_h2f8 if F8 else ops.pack_h2)(x, styles)
+    wp = (ops.pack_conv_weight_h3f6 if FMT == 2 else ops.pack_conv_weight_h3f8 if F8 else ops.pack_conv_weight_h3)(w)
     cap = 1 << 16
     ts = torch.zeros([cap, 8], dtype=torch.int64, device="cuda")
     y = torch.empty([n, co, res, res], device="cuda")
@@ -42,10 +43,10 @@ def run(kind, n, ci, co, res):
     def launch():
         if kind == "up1":
             rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), yp,
-                                             hp, sp, cn, cn, None, int(F8), int(F8 and H2OUT), n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
+                                             hp, sp, cn, cn, None, FMT, int(F8 and H2OUT), n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
         else:
             rc = lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), yp,
-                                             hp, sp, cn, cn, int(F8), int(F8 and H2OUT), n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
+                                             hp, sp, cn, cn, FMT, int(F8 and H2OUT), n, hin, hin, co, 0.2, 1.4142135, 256.0, st)
         _lib.check(rc, kind)
     for _ in range(3):
         launch()
