@@ -87,9 +87,14 @@ __device__ __forceinline__ float nb_h3_act(float a, float dg, float nbg, float a
 // (counted lgkmcnt waits), the step's barrier in front of its last two MFMA groups with the next step's first operands read under
 // them, fragment reads and DMA pieces dealt out between the MFMAs.  Same per-accumulator order of products: bit-identical.
 // F6 (with F8 and V2): the "f6" operand format (nb_h3_common.h) -- the K loop of the f8 V2 form with fp6 correction products.
-template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false, bool F6 = false>
+// PP (with F8 and V2, round 5): the f8 K loop as a PING-PONG of the two waves of a SIMD (waves w and w + 4): a step is a LOAD segment -- all
+// of the step's fragment reads and its LDS-DMA pieces, no matrix instruction -- and a COMPUTE segment -- the step's 18 MFMAs back to back,
+// every operand in registers --, waves 4-7 run one segment behind waves 0-3, a barrier after every segment: while one wave of a SIMD
+// computes, its partner loads.  Same per-accumulator order of products as the other f8 loops: bit-identical.
+template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false, bool F6 = false, bool PPK = false>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
     static_assert(!F6 || (F8 && V2), "the f6 form is a variant of the software-pipelined f8 loop");
+    static_assert(!PPK || (F8 && V2 && !F6), "the ping-pong form is a variant of the software-pipelined f8 loop");
     NB_TSTAMP(0);
     if (p.out_f8) nb_set_fp16_ovfl();             // f8 hand-off: the fp8 (and f16) conversions saturate
     nb_stagger(p.stagger_ticks, 256);
@@ -470,6 +475,113 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 0, 0, 0, sa, 0, sb);
             };
         };
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+        if constexpr (PPK) {
+            // ---- ping-pong: LOAD(t) = the pieces of sub-chunk t + 3 (on KY = 0 also the next chunk's halo tile), then every fragment of
+            //      step t; COMPUTE(t) = tap 0, tap 1, corrections 0 + 1, tap 2, on odd t the tap-2 corrections of steps t-1 and t.
+            //   segment      0        1        2        3        4
+            //   waves 0-3   LOAD 0   COMP 0   LOAD 1   COMP 1   LOAD 2  ...        (one barrier after every segment)
+            //   waves 4-7   (wait)   LOAD 0   COMP 0   LOAD 1   COMP 1  ...
+            // Stage t (weight ring slot t & 3, halo tile of its chunk) is read in segments 2t (waves 0-3) and 2t + 1 (waves 4-7); the
+            // barrier that ends segment 2t + 1 is the one in front of which every wave waits for its pieces up to sub-chunk t + 1
+            // (all but the youngest two sub-chunks, + the halo tile unless it is due), so stage t + 1 has landed when segment 2t + 2
+            // starts to read it, and slot (t + 3) & 3 = (t - 1) & 3, which LOAD(t) refills, was last read in segment 2t - 1.
+            auto load_seg = [&](auto ky_, auto odd_, int t, int c) {
+                constexpr int KY = decltype(ky_)::value, ODD = decltype(odd_)::value;
+                const h8* xb = xbuf + (c & 1) * 4 * XPL;
+                const h8* wb = wring + (t & 3) * WSLOTS;
+                NB_SB;
+                nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah0, bh0, wb, xb, KY, 0); });
+                nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah1, bh1, wb, xb, KY, 1); });
+                nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 0>{}, al01, bl01, wb, xb, KY, 0); });
+                nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 1>{}, al01, bl01, wb, xb, KY, 1); });
+                nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah2, bh2, wb, xb, KY, 2); });
+                nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, ODD>{}, al2, bl2, wb, xb, KY, 2); });
+                NB_SB;
+            };
+            // COMPUTE(t): the step's MFMAs; its LDS-DMA pieces (sub-chunk t + 3, on KY = 0 the next chunk's halo tile) ride in the gaps
+            // behind the first two groups (slot (t + 3) & 3 was last read in segment 2t - 1; this is segment 2t + 1 or 2t + 2)
+            auto comp_seg = [&](auto ky_, auto odd_, int t, int c) {
+                constexpr int KY = decltype(ky_)::value, ODD = decltype(odd_)::value;
+                constexpr int NDMA = NWPW + (KY == 0 ? NXPW : 0);
+                const int t3 = clampt(t + 3), c1 = c + 1 < NC ? c + 1 : NC - 1;
+                auto dma = [&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i < NWPW) issue_w_v2(i_, t3, (t + 3) & 3);
+                    else issue_x_v2(std::integral_constant<int, i - NWPW>{}, c1, (c + 1) & 1);
+                };
+                NB_SB;
+                // (a piece costs the wave ~60 cycles of issue: behind a 64-cycle fp8 MFMA it is hidden, behind a 32-cycle f16 one the pipe waits)
+                constexpr int N1 = NDMA < NM ? NDMA : NM, R = NDMA - N1;
+                auto dma_r = [&](auto i_) { dma(std::integral_constant<int, decltype(i_)::value + N1>{}); };
+                group(std::integral_constant<int, 0>{}, mf_f16(ah0, bh0), [](auto) {});
+                group(std::integral_constant<int, 0>{}, mf_f16(ah1, bh1), [](auto) {});
+                group(std::integral_constant<int, N1>{}, mf_fp8(al01, bl01), dma);
+                group(std::integral_constant<int, ODD ? 0 : R>{}, mf_f16(ah2, bh2), dma_r);
+                if constexpr (ODD) group(std::integral_constant<int, R>{}, mf_fp8(al2, bl2), dma_r);
+                NB_SB;
+            };
+            const bool grp_b = wv >= 4;
+            // one step of a wave: LOAD, sync, COMPUTE, sync.  The counted vmcnt wait stands in front of the barrier that ends an ODD
+            // segment -- behind COMPUTE(t) for waves 0-3 (pieces up to sub-chunk t + 3 issued: the youngest two sub-chunks may be in flight,
+            // and the halo tile unless it is due), behind LOAD(t) for waves 4-7 (issued up to t + 2: the youngest one).
+            auto pp_step = [&](auto b_, auto ky_, auto odd_, int t, int c) {
+                constexpr bool B = decltype(b_)::value;
+                constexpr int KY = decltype(ky_)::value;
+                constexpr int NVA = KY == 2 ? 2 * NWPW : 2 * NWPW + NXPW, NVB = KY == 1 ? NWPW + NXPW : NWPW;
+#ifdef NB_PP_STAMPS
+                const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
+                load_seg(ky_, odd_, t, c);
+#ifdef NB_PP_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
+                if constexpr (B) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NVB) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef NB_PP_STAMPS
+                const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+#endif
+                comp_seg(ky_, odd_, t, c);
+#ifdef NB_PP_STAMPS
+                const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+#endif
+                if constexpr (B) asm volatile("s_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NVA) : "memory");
+#ifdef NB_PP_STAMPS
+                const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+                t_dma += ((s1 - s0) & 0xffffffffull) | ((s3 - s2) << 32);          // (load | compute) cycles
+                t_bar += ((s2 - s1) & 0xffffffffull) | ((s4 - s3) << 32);          // (wait behind load | wait behind compute)
+#endif
+            };
+            auto pp_loop = [&](auto b_) {
+                int c = 0;
+                for (; c + 1 < NC; c += 2) {
+                    pp_step(b_, K0{}, K0{}, 3 * c, c); pp_step(b_, K1{}, K1{}, 3 * c + 1, c); pp_step(b_, K2{}, K0{}, 3 * c + 2, c);
+                    pp_step(b_, K0{}, K1{}, 3 * c + 3, c + 1); pp_step(b_, K1{}, K0{}, 3 * c + 4, c + 1); pp_step(b_, K2{}, K1{}, 3 * c + 5, c + 1);
+                }
+                if (c < NC) { pp_step(b_, K0{}, K0{}, 3 * c, c); pp_step(b_, K1{}, K1{}, 3 * c + 1, c); pp_step(b_, K2{}, K0{}, 3 * c + 2, c); }
+            };
+            if (grp_b) {
+                asm volatile("s_barrier" ::: "memory");
+                pp_loop(std::true_type{});
+            } else {
+                pp_loop(std::false_type{});
+                asm volatile("s_barrier" ::: "memory");
+            }
+            NB_SB;
+            if (T & 1) {                                   // an odd number of steps: the last tuple of tap-2 corrections holds one tap only
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int r = 4; r < 8; ++r) al2[mb][r] = 0;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
+                group(std::integral_constant<int, 0>{}, mf_fp8(al2, bl2), [](auto) {});
+            }
+        } else {
         // step t: KY = tap row, ODD = t & 1 (compile time); reads stage (c, slot t & 3), issues sub-chunk t + 3 (and on KY = 0 the
         // next chunk's halo tile), pre-reads step t + 1
         auto step = [&](auto ky_, auto odd_, int t, int c) {
@@ -520,7 +632,6 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah1, bh1, wring, xbuf, 0, 1); });
         nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 0>{}, al01, bl01, wring, xbuf, 0, 0); });
         nb_static_for<0, NF>([&](auto i_) { rd_lo(i_, std::integral_constant<int, 1>{}, al01, bl01, wring, xbuf, 0, 1); });
-        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
         int c = 0;
         for (; c + 1 < NC; c += 2) {                   // t = 3 c is even here
             step(K0{}, K0{}, 3 * c, c); step(K1{}, K1{}, 3 * c + 1, c); step(K2{}, K0{}, 3 * c + 2, c);
@@ -541,6 +652,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
         }
         nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp8(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+        }
 #undef NB_Q
 #undef NB_SB
     } else if constexpr (V2) {
@@ -839,10 +951,17 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             if (p.tstamps) t_bar += __builtin_amdgcn_s_memtime() - tw0;
         }
     }
+#ifdef NB_PP_STAMPS
+    if (p.tstamps && tid == 0) {
+        unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        ts[6] = t_dma; ts[7] = t_bar;
+    }
+#else
     if (p.tstamps && tid == 0) {
         unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
         ts[6] = t_dma; ts[7] = t_bar | ((__builtin_amdgcn_s_memtime() - t_loop0) << 32);
     }
+#endif
     // drain the tail re-copies before the staging LDS is reused: every wave waits for ITS pieces, and the barrier makes
     // sure no other wave's late piece lands on top of epilogue data (without it the outcome depended on DMA timing)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1149,7 +1268,7 @@ static int launch_h3s(H3Params p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int MW, bool F8 = false, int NBW = 2, bool V2 = false, bool F6 = false>
+template <int MW, bool F8 = false, int NBW = 2, bool V2 = false, bool F6 = false, bool PP = false>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * NBW, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
@@ -1158,11 +1277,11 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
 }
@@ -1172,6 +1291,12 @@ extern "C" const float* nb_zero_page_ptr(void);
 static int g_force_up1_v2 = -1;
 // developer / test hook: -1 = automatic (on), 0 / 1 = the round-3 / the software-pipelined K loop of the f8 up=1 kernel
 extern "C" void nb_debug_set_up1_v2(int mode) { g_force_up1_v2 = mode; }
+#ifndef NB_UP1_PP_DEFAULT
+#define NB_UP1_PP_DEFAULT 0
+#endif
+static int g_force_up1_pp = -1;
+// developer / test hook: -1 = automatic, 0 / 1 = the software-pipelined / the ping-pong K loop of the f8 up=1 kernel
+extern "C" void nb_debug_set_up1_pp(int mode) { g_force_up1_pp = mode; }
 static int g_force_nbw = 0;
 // developer / test hook: 0 = automatic, 1 / 2 = force that many 32-pixel rows per wave in the 8-wave up=1 kernel
 extern "C" void nb_debug_set_up1_rows(int nbw) { g_force_nbw = nbw; }
@@ -1235,6 +1360,10 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
         if (v2) return c_out > 64 ? launch_h3<2, false, 1, true>(p, n, st) : launch_h3<1, false, 1, true>(p, n, st);
         return c_out > 64 ? launch_h3<2, false, 1>(p, n, st) : launch_h3<1, false, 1>(p, n, st);
     }
+    // the ping-pong form of that loop (full-height tiles): NB_UP1_PP / nb_debug_set_up1_pp
+    static const int env_pp = getenv("NB_UP1_PP") ? atoi(getenv("NB_UP1_PP")) : NB_UP1_PP_DEFAULT;
+    const bool pp = (g_force_up1_pp >= 0 ? g_force_up1_pp : env_pp) != 0;
+    if (f8 && v2 && pp) return c_out > 64 ? launch_h3<2, true, 2, true, false, true>(p, n, st) : launch_h3<1, true, 2, true, false, true>(p, n, st);
     if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 2, true>(p, n, st) : launch_h3<1, true, 2, true>(p, n, st);
     if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
     if (v2) return c_out > 64 ? launch_h3<2, false, 2, true>(p, n, st) : launch_h3<1, false, 2, true>(p, n, st);

@@ -231,10 +231,12 @@ def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for rows in (2, 1, "2old", "1old"):
-            # ("old": the round-3 K loop; the default is the software-pipelined one, in both operand formats)
+        for rows in (2, 1, "2old", "1old") + (("2pp",) if fmt else ()):
+            # ("old": the round-3 K loop; the default is the software-pipelined one, in both operand formats; "pp": round 5's ping-pong
+            #  form of the f8 loop -- waves 4-7 one segment behind waves 0-3, loads against matrix work)
             lib.nb_debug_set_up1_rows(int(str(rows)[0]))
             lib.nb_debug_set_up1_v2(0 if str(rows).endswith("old") else 1)
+            lib.nb_debug_set_up1_pp(1 if str(rows).endswith("pp") else 0)
             y = torch.empty([n, co, h, w], device="cuda")
             out = torch.zeros(ops.h2_shape(n, co, h, w), dtype=torch.float16, device="cuda")
             common = (dco.data_ptr(), noise.data_ptr(), h * w, bias.data_ptr())
@@ -247,9 +249,10 @@ def test_up1_rows_per_wave_agree(fmt, ci, co, h, w):
     finally:
         lib.nb_debug_set_up1_rows(0)
         lib.nb_debug_set_up1_v2(-1)
+        lib.nb_debug_set_up1_pp(-1)
     assert torch.equal(res[2][0], res[1][0])
     assert torch.equal(res[2][1], res[1][1])
-    for k in ("2old", "1old"):
+    for k in ("2old", "1old") + (("2pp",) if fmt else ()):
         assert torch.equal(res[2][0], res[k][0]) and torch.equal(res[2][1], res[k][1]), k
     ref = _conv_ref(x, wt, st, 1) * dco.double().cpu()[:, :, None, None] + noise.double().cpu()[:, None]
     ref = torch.nn.functional.leaky_relu(ref + bias.double().cpu()[None, :, None, None], 0.2) * 1.4142135
