@@ -35,6 +35,8 @@ __device__ __forceinline__ void nb_stagger(int stagger_ticks, int first_round) {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int v6i __attribute__((ext_vector_type(6)));
 
 // s_waitcnt vmcnt(N) as the BUILTIN, not inline assembly: the compiler's own wait bookkeeping (SIInsertWaitcnts) then sees
 // the LDS-DMA operations complete.  With asm waits it never does, keeps every LDS-DMA "pending" for the rest of the kernel and

@@ -269,29 +269,29 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     if constexpr (F6) {
         // ---- f6 operands: the f8 loop below with the correction products on fp6 MFMAs (32 instead of 64 cycles each) -----------
         // A lane's 32 K values of a correction instruction = ONE tap of ONE pixel / c_out, both terms (one block scale per lane):
-        // lane half 0 takes tap 0 of the pair (0, 1), lane half 1 tap 1 -- the lo-slot addresses are per lane --, and its operand
-        // tuple is the chunk's two lo slots as they stand (quad 0 = slot (cg 0, lo), quad 1 = slot (cg 1, lo): six dwords of fields,
-        // the scale dword = the instruction's scale operand, one unused).  Tap 2 has no partner in its step: its corrections run
-        // alone every step, lane half 1 multiplying a zero slot (weights side).  Per step and tile 3 f16 + 2 fp6 MFMAs = 160 cycles
-        // (f8: 3 x 32 + 1.5 x 64 = 192).  Step t:
+        // lane half 0 takes tap 0 of the pair (0, 1), lane half 1 tap 1 -- the lo-slot addresses are per lane --, and its operand is
+        // the chunk's two lo slots: six registers of fields (read as 16 + 8 bytes) and the scale dword (4 bytes) = the instruction's
+        // scale operand.  Tap 2 has no partner in its step: its corrections run alone every step, lane half 1 multiplying a zero slot
+        // (weights side).  Per step and tile 3 f16 + 2 fp6 MFMAs = 160 cycles (f8: 3 x 32 + 1.5 x 64 = 192).  Step t:
         //   part A:  tap 2 main (t-1) | tap-2 corrections (t-1) | tap 0 (t)      fillers: the step's LDS-DMA pieces, its tap-2 fragments
         //   wait (counted) + barrier
         //   part B:  tap 1 (t) | corrections 0 + 1 (t)                           fillers: hi fragments of taps 0, 1 of step t+1;
         //            behind the last fp6 MFMA the lo slots of step t+1
+        // Measured (profiles/r05_f6_ab.txt): not faster than the f8 loop -- neither loop is bound by the matrix pipe.
 #define NB_SB __builtin_amdgcn_sched_barrier(0)
-#define NB_Q(v, q, src) { const i32x4 t_ = __builtin_bit_cast(i32x4, (src)); v[4 * (q)] = t_[0]; v[4 * (q) + 1] = t_[1]; v[4 * (q) + 2] = t_[2]; v[4 * (q) + 3] = t_[3]; }
-        __shared__ __attribute__((aligned(16))) h8 s_zero6;
-        if (tid == 0) s_zero6 = h8{};
+        __shared__ __attribute__((aligned(16))) h8 s_zero6[1];
+        if (tid == 0) s_zero6[0] = h8{};
         __builtin_amdgcn_s_barrier();
         h8 ah0[MB], ah1[MB], ah2[MB], bh0[NBW], bh1[NBW], bh2[NBW];
-        i32x8 al01[MB], bl01[NBW], al2[MB], bl2[NBW];
+        v6i al01[MB], bl01[NBW], al2[MB], bl2[NBW];
+        int sa01[MB], sb01[NBW], sa2[MB], sb2[NBW];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) { ah2[mb] = h8{}; al2[mb] = i32x8{}; al01[mb] = i32x8{}; }
+        for (int mb = 0; mb < MB; ++mb) { ah2[mb] = h8{}; al2[mb] = v6i{}; al01[mb] = v6i{}; sa01[mb] = 0; sa2[mb] = 0; }
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) { bh2[nb] = h8{}; bl2[nb] = i32x8{}; bl01[nb] = i32x8{}; }
+        for (int nb = 0; nb < NBW; ++nb) { bh2[nb] = h8{}; bl2[nb] = v6i{}; bl01[nb] = v6i{}; sb01[nb] = 0; sb2[nb] = 0; }
         constexpr int NM = MB * NBW, NF = MB + NBW;
-        const int a6 = wm * 64 + l31, a6_01 = a6 + lh * 4 * CO_WG;          // lo slots: + (2 q + 1) CO_WG + mb 32 (+ 8 CO_WG for tap 2)
-        const int b6 = (wn * NBW) * TWP + l31, b6_01 = b6 + lh;             // + (2 q + 1) XPL + (nb + ky) TWP (+ 2 for tap 2)
+        const int a6 = wm * 64 + l31 + CO_WG, a6_01 = a6 + lh * 4 * CO_WG;          // slot (cg 0, lo) of tap 0 / of the lane's tap; (cg 1, lo) = + 2 CO_WG
+        const int b6 = (wn * NBW) * TWP + l31 + XPL, b6_01 = b6 + lh;                 // plane (cg 0, lo); (cg 1, lo) = + 2 XPL
         auto rd_hi = [&](auto i_, h8 (&a)[MB], h8 (&b)[NBW], const h8* wb, const h8* xb, int ky, int kx) {
             constexpr int i = decltype(i_)::value;
 #ifdef NB_ABL6_NOREAD
@@ -300,22 +300,33 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             if constexpr (i < MB) a[i] = wb[a_base + kx * 4 * CO_WG + i * 32];
             else b[i - MB] = xb[b_base + (i - MB + ky) * TWP + kx];
         };
-        // lo slot q of fragment i: the pair (0, 1) -- the lane's own tap -- or the lone tap 2 (weights of lane half 1: the zero slot)
-        auto rd_lo01 = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, int ky) {
-            constexpr int i = decltype(i_)::value, q = decltype(q_)::value;
-#ifdef NB_ABL6_NOREAD
-            return;
-#endif
-            if constexpr (i < MB) { NB_Q(a[i], q, wb[a6_01 + (2 * q + 1) * CO_WG + i * 32]); }
-            else { NB_Q(b[i - MB], q, xb[b6_01 + (2 * q + 1) * XPL + (i - MB + ky) * TWP]); }
+        // an fp6 operand: 16 + 8 bytes of fields, 4 bytes of scale (volatile: the compiler must not fuse them into a 16-byte read, which
+        // cannot land across the end of the six-register operand)
+        auto rd6 = [](v6i& t, int& sc, const h8* slot0, const h8* slot1) {
+            // (explicit LDS address space: through a generic pointer the volatile reads become flat loads, which count in vmcnt)
+            typedef const volatile __attribute__((address_space(3))) int* lds_vint;
+            typedef const volatile __attribute__((address_space(3))) i32x2* lds_vint2;
+            const i32x4 q0 = __builtin_bit_cast(i32x4, *slot0);
+            const i32x2 q1 = *(lds_vint2)NB_LDS_PTR(slot1);
+            sc = ((lds_vint)NB_LDS_PTR(slot1))[2];
+            t[0] = q0[0]; t[1] = q0[1]; t[2] = q0[2]; t[3] = q0[3]; t[4] = q1[0]; t[5] = q1[1];
         };
-        auto rd_lo2 = [&](auto i_, auto q_, i32x8 (&a)[MB], i32x8 (&b)[NBW], const h8* wb, const h8* xb, int ky) {
-            constexpr int i = decltype(i_)::value, q = decltype(q_)::value;
+        // fragment i of the pair (0, 1) -- the lane's own tap -- or of the lone tap 2 (weights of lane half 1: the zero slot)
+        auto rd_lo01 = [&](auto i_, const h8* wb, const h8* xb, int ky) {
+            constexpr int i = decltype(i_)::value;
 #ifdef NB_ABL6_NOREAD
             return;
 #endif
-            if constexpr (i < MB) { const h8* src = lh ? &s_zero6 : wb + a6 + 8 * CO_WG + (2 * q + 1) * CO_WG + i * 32; NB_Q(a[i], q, *src); }
-            else { NB_Q(b[i - MB], q, xb[b6 + (2 * q + 1) * XPL + (i - MB + ky) * TWP + 2]); }
+            if constexpr (i < MB) { const h8* s_ = wb + a6_01 + i * 32; rd6(al01[i], sa01[i], s_, s_ + 2 * CO_WG); }
+            else { const h8* s_ = xb + b6_01 + (i - MB + ky) * TWP; rd6(bl01[i - MB], sb01[i - MB], s_, s_ + 2 * XPL); }
+        };
+        auto rd_lo2 = [&](auto i_, const h8* wb, const h8* xb, int ky) {
+            constexpr int i = decltype(i_)::value;
+#ifdef NB_ABL6_NOREAD
+            return;
+#endif
+            if constexpr (i < MB) { const h8* s_ = wb + a6 + 8 * CO_WG + i * 32; rd6(al2[i], sa2[i], lh ? &s_zero6[0] : s_, lh ? &s_zero6[0] : s_ + 2 * CO_WG); }
+            else { const h8* s_ = xb + b6 + (i - MB + ky) * TWP + 2; rd6(bl2[i - MB], sb2[i - MB], s_, s_ + 2 * XPL); }
         };
         auto group = [&](auto nfill_, auto&& mf, auto&& ff) {
             constexpr int NFILL = decltype(nfill_)::value;
@@ -339,16 +350,16 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
             };
         };
-        auto mf_fp6 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
+        auto wide = [](const v6i& t) { return i32x8{t[0], t[1], t[2], t[3], t[4], t[5], 0, 0}; };
+        auto mf_fp6 = [&](v6i (&a)[MB], int (&sa6)[MB], v6i (&b)[NBW], int (&sb6)[NBW]) {
             return [&](auto mb_, auto nb_) {
                 constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
 #if defined(NB_ABL6_NOFP6) || defined(NB_ABL6_NOMFMA)
                 return;
 #endif
-                acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 2, 2, 0, a[mb][6], 0, b[nb][6]);
+                acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(a[mb]), wide(b[nb]), acc[mb][nb], 2, 2, 0, sa6[mb], 0, sb6[nb]);
             };
         };
-        using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
         auto step = [&](auto ky_, int t, int c) {
             constexpr int KY = decltype(ky_)::value;
             constexpr int NDMA = NWPW + (KY == 0 ? NXPW : 0);
@@ -364,31 +375,16 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
 #ifdef NB_ABL6_NODMA
                 return;
 #endif
-#ifdef NB_ABL6_NOWDMA
-                if constexpr (i < NWPW) return;
-#endif
                 if constexpr (i < NWPW) issue_w_v2(i_, t3, (t + 3) & 3);
                 else issue_x_v2(std::integral_constant<int, i - NWPW>{}, c1, (c + 1) & 1);
             };
             NB_SB;
             // part A
             group(std::integral_constant<int, NDMA>{}, mf_f16(ah2, bh2), dma);                       // tap 2 of step t-1
-            group(std::integral_constant<int, NF>{}, mf_fp6(al2, bl2),                                // its corrections
+            group(std::integral_constant<int, NF>{}, mf_fp6(al2, sa2, bl2, sb2),                      // its corrections
                   [&](auto i_) { rd_hi(i_, ah2, bh2, wb, xb, KY, 2); });
-            group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah0, bh0), [&](auto i_) {             // tap 0
-                constexpr int i = decltype(i_)::value;
-                if constexpr (i < NF) rd_lo2(i_, Q0{}, al2, bl2, wb, xb, KY);
-                else rd_lo2(std::integral_constant<int, i - NF>{}, Q1{}, al2, bl2, wb, xb, KY);
-            });
-#if defined(NB_ABL6_NODMA) || defined(NB_ABL6_NOWDMA)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#elif defined(NB_ABL6_NOBAR)
-            if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWPW + NXPW) : "memory");
-#elif defined(NB_ABL6_NOLGKM0)
-            if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NWPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NWPW + NXPW) : "memory");
-#elif defined(NB_ABL6_NOVMCNT)
+            group(std::integral_constant<int, NF>{}, mf_f16(ah0, bh0), [&](auto i_) { rd_lo2(i_, wb, xb, KY); });       // tap 0
+#ifdef NB_ABL6_NODMA
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
             if constexpr (KY == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NWPW) : "memory");
@@ -398,24 +394,21 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             // part B
             group(std::integral_constant<int, NF>{}, mf_f16(ah1, bh1),                                // tap 1
                   [&](auto i_) { rd_hi(i_, ah0, bh0, wbn, xbn, KYN, 0); });
-            group(std::integral_constant<int, NF>{}, mf_fp6(al01, bl01),                              // corrections of taps 0 + 1
+            group(std::integral_constant<int, NF>{}, mf_fp6(al01, sa01, bl01, sb01),                  // corrections of taps 0 + 1
                   [&](auto i_) { rd_hi(i_, ah1, bh1, wbn, xbn, KYN, 1); });
-            nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q0{}, al01, bl01, wbn, xbn, KYN); });
-            nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q1{}, al01, bl01, wbn, xbn, KYN); });
+            nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, wbn, xbn, KYN); });
             NB_SB;
         };
         // operands of step 0
         nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah0, bh0, wring, xbuf, 0, 0); });
         nb_static_for<0, NF>([&](auto i_) { rd_hi(i_, ah1, bh1, wring, xbuf, 0, 1); });
-        nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q0{}, al01, bl01, wring, xbuf, 0); });
-        nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, Q1{}, al01, bl01, wring, xbuf, 0); });
+        nb_static_for<0, NF>([&](auto i_) { rd_lo01(i_, wring, xbuf, 0); });
         using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
         for (int c = 0; c < NC; ++c) { step(K0{}, 3 * c, c); step(K1{}, 3 * c + 1, c); step(K2{}, 3 * c + 2, c); }
         NB_SB;
         // the last step's tap 2 and its corrections
         nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_f16(ah2, bh2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
-        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp6(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
-#undef NB_Q
+        nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp6(al2, sa2, bl2, sb2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
 #undef NB_SB
     } else if constexpr (F8 && V2) {
         // ---- f8 operands, software-pipelined over the barrier ------------------------------------------------------

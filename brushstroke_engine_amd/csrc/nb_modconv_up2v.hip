@@ -163,8 +163,8 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     int b6[NBJ];
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) b6[j] = boff[j] - lh * 2 * XPL + XPL;     // + q * 2 XPL + offset
-    __shared__ __attribute__((aligned(16))) h8 s_zero6;
-    if constexpr (F6) { if (tid == 0) s_zero6 = h8{}; }
+    __shared__ __attribute__((aligned(16))) h8 s_zero6[1];
+    if constexpr (F6) { if (tid == 0) s_zero6[0] = h8{}; }
 
     f32x16 acc[NBJ][4];
 #pragma unroll
@@ -217,6 +217,11 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         bh0[i] = h8{}; bh1[i] = h8{}; bh2[i] = h8{}; bh3[i] = h8{}; bl01[i] = i32x8{}; bl23[i] = i32x8{};
     }
     const int sa_ = lh ? 116 : 127, sb_ = lh ? 129 : 118;      // E8M0 block scales (see modconv3x3_up1_h3_kernel)
+    // f6 operands: six registers + the scale dword each (A: pairs a / n, the lone tap m; B: positions (0 | 1) -- later (0 | XS) --, (XS | XS + 1))
+    v6i al6_a = v6i{}, al6_n = v6i{}, al6_m = v6i{}, bl6_01[NBJ], bl6_23[NBJ];
+    int sa6_a = 0, sa6_n = 0, sa6_m = 0, sb6_01[NBJ], sb6_23[NBJ];
+#pragma unroll
+    for (int i = 0; i < NBJ; ++i) { bl6_01[i] = v6i{}; bl6_23[i] = v6i{}; sb6_01[i] = 0; sb6_23[i] = 0; }
     // H2 operands: separate lo fragments (no tuples): A sets a / n [tap of the pair], m; B lo at the four input offsets
     h8 hl_a[2], hl_n[2], hl_m, bl0[NBJ], bl1[NBJ], bl2[NBJ], bl3[NBJ];
     hl_m = h8{};
@@ -349,33 +354,46 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
             return;
         }
         if constexpr (F6) {
-            // lo slots of the weights of pair (ta, tb) -> tuple `al` quad q (the lane's own tap); of the lone tap 4 (lane half 1: zeros)
-            auto rA6 = [&](i32x8& al, int q, int ta, int tb, const h8* s_) {
+            // An fp6 operand = SIX registers + the scale dword.  Read as 16 + 8 + 4 bytes (ds_read_b128 / b64 / b32, volatile so that
+            // the compiler does not fuse them): a 16-byte read cannot land across the end of the six-register operand, and two
+            // 16-byte reads into an eight-register tuple cost two v_mov per operand and enough extra live registers to spill.
+            auto rd6 = [](v6i& t, int& sc, const h8* slot0, const h8* slot1) {
+                // (explicit LDS address space: through a generic pointer the volatile reads become flat loads, which count in vmcnt)
+                typedef const volatile __attribute__((address_space(3))) int* lds_vint;
+                typedef const volatile __attribute__((address_space(3))) i32x2* lds_vint2;
+                const i32x4 q0 = __builtin_bit_cast(i32x4, *slot0);
+                const i32x2 q1 = *(lds_vint2)NB_LDS_PTR(slot1);
+                sc = ((lds_vint)NB_LDS_PTR(slot1))[2];
+                t[0] = q0[0]; t[1] = q0[1]; t[2] = q0[2]; t[3] = q0[3]; t[4] = q1[0]; t[5] = q1[1];
+            };
+            // weights of pair (ta, tb): the lane's own tap; of the lone tap 4 (lane half 1: the zero slot)
+            auto rA6 = [&](v6i& al, int& sc, int ta, int tb, const h8* s_) {
 #ifdef NB_ABL6_NOREAD
                 return;
 #endif
-                const h8& v = s_[a6 + (lh ? tb : ta) * 128 + q * 64];
-                if (q) set_hi(al, v); else set_lo(al, v);
+                const h8* b_ = s_ + a6 + (lh ? tb : ta) * 128;
+                rd6(al, sc, b_, b_ + 64);
             };
-            auto rA6m = [&](i32x8& al, int q, const h8* s_) {
+            auto rA6m = [&](v6i& al, int& sc, const h8* s_) {
 #ifdef NB_ABL6_NOREAD
                 return;
 #endif
-                const h8* src = lh ? &s_zero6 : s_ + a6 + 4 * 128 + q * 64;
-                if (q) set_hi(al, *src); else set_lo(al, *src);
+                const h8* b_ = lh ? &s_zero6[0] : s_ + a6 + 4 * 128;
+                rd6(al, sc, b_, lh ? &s_zero6[0] : b_ + 64);
             };
-            // lo slots of the activations at offsets (da | db) -> tuple bl[j] quad q
-            auto rB6 = [&](i32x8 (&bl)[NBJ], int q, auto j_, int da, int db, const h8* s_) {
+            // activations of block j at offsets (da | db)
+            auto rB6 = [&](v6i (&bl)[NBJ], int (&sc)[NBJ], auto j_, int da, int db, const h8* s_) {
                 constexpr int j = decltype(j_)::value;
 #ifdef NB_ABL6_NOREAD
                 return;
 #endif
                 if constexpr (j < NBE) {
-                    const h8& v = s_[b6[j] + q * 2 * XPL + (lh ? db : da)];
-                    if (q) set_hi(bl[j], v); else set_lo(bl[j], v);
+                    const h8* b_ = s_ + b6[j] + (lh ? db : da);
+                    rd6(bl[j], sc[j], b_, b_ + 2 * XPL);
                 }
             };
-            auto group_pair6 = [&](auto ph_, h8 (&ah)[2], i32x8& al, h8 (&Ba)[NBJ], h8 (&Bb)[NBJ], i32x8 (&bl)[NBJ], auto&& filler) {
+            auto wide = [](const v6i& t) { return i32x8{t[0], t[1], t[2], t[3], t[4], t[5], 0, 0}; };
+            auto group_pair6 = [&](auto ph_, h8 (&ah)[2], v6i& al, int sa6, h8 (&Ba)[NBJ], h8 (&Bb)[NBJ], v6i (&bl)[NBJ], int (&sb6)[NBJ], auto&& filler) {
                 constexpr int ph = decltype(ph_)::value;
                 nb_static_for<0, 2>([&](auto j_) {
                     constexpr int j = decltype(j_)::value;
@@ -384,60 +402,59 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                     NB_FENCE(); filler(std::integral_constant<int, 3 * j>{}); NB_FENCE();
                     if constexpr (j < NBE && NB_ABL6_F16) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], Bb[j], a_, 0, 0, 0);
                     NB_FENCE(); filler(std::integral_constant<int, 3 * j + 1>{}); NB_FENCE();
-                    if constexpr (j < NBE && NB_ABL6_FP6) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al, bl[j], a_, 2, 2, 0, al[6], 0, bl[j][6]);
+                    if constexpr (j < NBE && NB_ABL6_FP6) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(al), wide(bl[j]), a_, 2, 2, 0, sa6, 0, sb6[j]);
                     NB_FENCE(); filler(std::integral_constant<int, 3 * j + 2>{}); NB_FENCE();
                 });
             };
             NB_FENCE();
             // G0: taps 8, 6 -> phase 0 (positions 0 | 1).  Fillers: the A fragments of G1; pieces 2, 3
-            group_pair6(std::integral_constant<int, 0>{}, ah_a, al_a, bh0, bh1, bl01, [&](auto g_) {
+            group_pair6(std::integral_constant<int, 0>{}, ah_a, al6_a, sa6_a, bh0, bh1, bl6_01, sb6_01, [&](auto g_) {
                 constexpr int g = decltype(g_)::value;
                 if constexpr (g == 0) ah_n[0] = rA(5, 0, sa);
                 else if constexpr (g == 1) ah_n[1] = rA(3, 0, sa);
                 else if constexpr (g == 2) dma(std::integral_constant<int, 2>{});
-                else if constexpr (g == 3) rA6(al_n, 0, 5, 3, sa);
-                else if constexpr (g == 4) rA6(al_n, 1, 5, 3, sa);
-                else dma(std::integral_constant<int, 3>{});
+                else if constexpr (g == 3) rA6(al6_n, sa6_n, 5, 3, sa);
+                else if constexpr (g == 5) dma(std::integral_constant<int, 3>{});
             });
             // G1: taps 5, 3 -> phase 2 (positions 0 | 1).  Fillers: tap 4, the row-below hi fragments; piece 4
-            group_pair6(std::integral_constant<int, 2>{}, ah_n, al_n, bh0, bh1, bl01, [&](auto g_) {
+            group_pair6(std::integral_constant<int, 2>{}, ah_n, al6_n, sa6_n, bh0, bh1, bl6_01, sb6_01, [&](auto g_) {
                 constexpr int g = decltype(g_)::value;
                 if constexpr (g == 0) ah_m = rA(4, 0, sa);
-                else if constexpr (g == 1) rA6m(al_m, 0, sa);
-                else if constexpr (g == 2) { dma(std::integral_constant<int, 4>{}); rA6m(al_m, 1, sa); }
+                else if constexpr (g == 1) rA6m(al6_m, sa6_m, sa);
+                else if constexpr (g == 2) dma(std::integral_constant<int, 4>{});
                 else if constexpr (g == 3) rBh(bh2, J0_{}, XS, sa);
                 else if constexpr (g == 4) rBh(bh2, J1_{}, XS, sa);
             });
             // G2: tap 4 -> phase 3: (f16, fp6) x 2; lane half 1 of A = zeros.  Fillers: the A fragments of G3; piece 5; behind the fp6
-            // MFMA that was the last to read a block's (0 | 1) tuple, the (0 | XS) slots into it
+            // MFMA that was the last to read a block's (0 | 1) operand, the (0 | XS) slots into it
             nb_static_for<0, 2>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
                 f32x16& a_ = acc[j][3];
                 if constexpr (j < NBE && NB_ABL6_F16) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_m, bh0[j], a_, 0, 0, 0);
                 NB_FENCE();
-                if constexpr (j == 0) { ah_a[0] = rA(7, 0, sa); ah_a[1] = rA(1, 0, sa); } else { rA6(al_a, 0, 7, 1, sa); rA6(al_a, 1, 7, 1, sa); }
+                if constexpr (j == 0) { ah_a[0] = rA(7, 0, sa); ah_a[1] = rA(1, 0, sa); } else rA6(al6_a, sa6_a, 7, 1, sa);
                 NB_FENCE();
-                if constexpr (j < NBE && NB_ABL6_FP6) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al_m, bl01[j], a_, 2, 2, 0, al_m[6], 0, bl01[j][6]);
+                if constexpr (j < NBE && NB_ABL6_FP6) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(al6_m), wide(bl6_01[j]), a_, 2, 2, 0, sa6_m, 0, sb6_01[j]);
                 NB_FENCE();
                 if constexpr (j == 0) dma(std::integral_constant<int, 5>{});
-                rB6(bl01, 0, j_, 0, XS, sa); rB6(bl01, 1, j_, 0, XS, sa);
+                rB6(bl6_01, sb6_01, j_, 0, XS, sa);
                 NB_FENCE();
             });
             // G3: taps 7, 1 -> phase 1 (positions 0 | XS).  Fillers: the A fragments of G4, the diagonal fragments, the (XS | XS + 1) slots; piece 6
-            group_pair6(std::integral_constant<int, 1>{}, ah_a, al_a, bh0, bh2, bl01, [&](auto g_) {
+            group_pair6(std::integral_constant<int, 1>{}, ah_a, al6_a, sa6_a, bh0, bh2, bl6_01, sb6_01, [&](auto g_) {
                 constexpr int g = decltype(g_)::value;
                 if constexpr (g == 0) { ah_n[0] = rA(2, 0, sa); ah_n[1] = rA(0, 0, sa); }
-                else if constexpr (g == 1) { rB6(bl23, 0, J0_{}, XS, XS + 1, sa); rB6(bl23, 1, J0_{}, XS, XS + 1, sa); }
-                else if constexpr (g == 2) { dma(std::integral_constant<int, 6>{}); rA6(al_n, 0, 2, 0, sa); }
-                else if constexpr (g == 3) { rA6(al_n, 1, 2, 0, sa); rBh(bh3, J0_{}, XS + 1, sa); }
-                else if constexpr (g == 4) { rBh(bh3, J1_{}, XS + 1, sa); rB6(bl23, 0, J1_{}, XS, XS + 1, sa); }
-                else rB6(bl23, 1, J1_{}, XS, XS + 1, sa);
+                else if constexpr (g == 1) rB6(bl6_23, sb6_23, J0_{}, XS, XS + 1, sa);
+                else if constexpr (g == 2) dma(std::integral_constant<int, 6>{});
+                else if constexpr (g == 3) { rA6(al6_n, sa6_n, 2, 0, sa); rBh(bh3, J0_{}, XS + 1, sa); }
+                else if constexpr (g == 4) rBh(bh3, J1_{}, XS + 1, sa);
+                else rB6(bl6_23, sb6_23, J1_{}, XS, XS + 1, sa);
             });
             if constexpr (MODE >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPC) : "memory");
             else if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             NB_FENCE();
             // G4: taps 2, 0 -> phase 0 (positions XS | XS + 1).  Fillers: the NEXT chunk's first operands; pieces 0, 1 of chunk c + 3
-            group_pair6(std::integral_constant<int, 0>{}, ah_n, al_n, bh2, bh3, bl23, [&](auto g_) {
+            group_pair6(std::integral_constant<int, 0>{}, ah_n, al6_n, sa6_n, bh2, bh3, bl6_23, sb6_23, [&](auto g_) {
                 constexpr int g = decltype(g_)::value;
                 if constexpr (g == 2) dma(std::integral_constant<int, 0>{});
                 if constexpr (g == 5) dma(std::integral_constant<int, 1>{});
@@ -445,9 +462,9 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                     if constexpr (g == 0) { ah_a[0] = rA(8, 0, san); rBh(bh0, J0_{}, 0, san); }
                     else if constexpr (g == 1) { ah_a[1] = rA(6, 0, san); rBh(bh1, J0_{}, 1, san); }
                     else if constexpr (g == 2) { rBh(bh0, J1_{}, 0, san); rBh(bh1, J1_{}, 1, san); }
-                    else if constexpr (g == 3) { rA6(al_a, 0, 8, 6, san); rA6(al_a, 1, 8, 6, san); }
-                    else if constexpr (g == 4) { rB6(bl01, 0, J0_{}, 0, 1, san); rB6(bl01, 1, J0_{}, 0, 1, san); }
-                    else { rB6(bl01, 0, J1_{}, 0, 1, san); rB6(bl01, 1, J1_{}, 0, 1, san); }
+                    else if constexpr (g == 3) rA6(al6_a, sa6_a, 8, 6, san);
+                    else if constexpr (g == 4) rB6(bl6_01, sb6_01, J0_{}, 0, 1, san);
+                    else rB6(bl6_01, sb6_01, J1_{}, 0, 1, san);
                 }
             });
             NB_FENCE();
@@ -535,14 +552,20 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         constexpr int NBE = decltype(nbe)::value;
         // the first chunk's first operands
         ah_a[0] = ring[aoff + 8 * 128]; ah_a[1] = ring[aoff + 6 * 128];
-        if constexpr (F6) { const int t_ = lh ? 6 : 8; set_lo(al_a, ring[a6 + t_ * 128]); set_hi(al_a, ring[a6 + t_ * 128 + 64]); }
-        else if constexpr (F8) { set_lo(al_a, ring[aoff + 8 * 128 + 32]); set_hi(al_a, ring[aoff + 6 * 128 + 32]); }
+        if constexpr (F6) {
+            const h8* b_ = ring + a6 + (lh ? 6 : 8) * 128;
+            const i32x4 q0 = __builtin_bit_cast(i32x4, b_[0]); const i32x4 q1 = __builtin_bit_cast(i32x4, b_[64]);
+            al6_a = v6i{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1]}; sa6_a = q1[2];
+        } else if constexpr (F8) { set_lo(al_a, ring[aoff + 8 * 128 + 32]); set_hi(al_a, ring[aoff + 6 * 128 + 32]); }
         else { hl_a[0] = ring[aoff + 8 * 128 + 32]; hl_a[1] = ring[aoff + 6 * 128 + 32]; }
 #pragma unroll
         for (int j = 0; j < NBE; ++j) {
             bh0[j] = ring[boff[j]]; bh1[j] = ring[boff[j] + 1];
-            if constexpr (F6) { set_lo(bl01[j], ring[b6[j] + lh]); set_hi(bl01[j], ring[b6[j] + 2 * XPL + lh]); }
-            else if constexpr (F8) { set_lo(bl01[j], ring[boff[j] + XPL]); set_hi(bl01[j], ring[boff[j] + XPL + 1]); }
+            if constexpr (F6) {
+                const h8* b_ = ring + b6[j] + lh;
+                const i32x4 q0 = __builtin_bit_cast(i32x4, b_[0]); const i32x4 q1 = __builtin_bit_cast(i32x4, b_[2 * XPL]);
+                bl6_01[j] = v6i{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1]}; sb6_01[j] = q1[2];
+            } else if constexpr (F8) { set_lo(bl01[j], ring[boff[j] + XPL]); set_hi(bl01[j], ring[boff[j] + XPL + 1]); }
             else { bl0[j] = ring[boff[j] + XPL]; bl1[j] = ring[boff[j] + XPL + 1]; }
         }
         int c = 0, s = 0;                             // s = stage of chunk c

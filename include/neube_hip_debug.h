@@ -19,6 +19,9 @@ void nb_debug_set_up1_rows(int nbw);
 /* K loop of the 8-wave split-f16 up=1 kernel with f8 operands: -1 = automatic (the software-pipelined loop of round 4), 0 = the
  * round-3 loop, 1 = the software-pipelined loop.  tests/test_hip_f8.py asserts both bit-identical. */
 void nb_debug_set_up1_v2(int mode);
+/* ... its ping-pong form (round 5: waves 4-7 one segment behind waves 0-3, a load segment against a compute segment on every SIMD):
+ * -1 = automatic (NB_UP1_PP, default off: launches -2.5 %, step within noise), 0 / 1 = off / on.  Bit-identical (tests/test_hip_f8.py). */
+void nb_debug_set_up1_pp(int mode);
 
 /* K-splitting waves per workgroup of the small-image kernel (modconv3x3_up1_small_h3): 0 = automatic (8 for layers of >= 8
  * sixteen-channel chunks), 4 or 8 = force. */
