@@ -157,13 +157,16 @@ MODE_DTYPE = {
           "relative per product, ~5e-6 from an all-fp32 evaluation on pixels",
     "f8": "f16 hi x f16 hi MFMA + 2 block-scaled fp8 (e4m3) correction products per fp32 product, fp32 accumulate: ~2^-15 relative "
           "per product, ~1e-4 from an all-fp32 evaluation on pixels (north_star budget 1e-3)",
+    "f6": "f8 with fp6 (e2m3) correction products (per-pixel 16-channel block scales) in the two large up=2 launches: the round-5 experiment, "
+          "not faster than f8 (profiles/r05_f6_ab.txt); everything else as f8",
 }
 
 
 def scheme_ceiling(mode):
     """Matrix work a mode executes per algorithmic FLOP, at the nominal dense peaks."""
     return {"f32": PEAK_F32_MATRIX_TFLOPS, "h3": PEAK_F16_MATRIX_TFLOPS / 3,
-            "f8": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS)}[mode]
+            "f8": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS),
+            "f6": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS)}[mode]         # (priced as f8: most of its launches are)
 
 
 def load_traffic(mode, res, batch):
@@ -182,6 +185,8 @@ def load_traffic(mode, res, batch):
         if stamp.get("source_digest") != _b.source_digest():
             return {}, "profiles/hbm_traffic.json was measured on other kernel sources (stale): not used"
         table = tj.get("modes", {}).get(mode)
+        if table is None and mode == "f6":
+            table = tj.get("modes", {}).get("f8")                      # (the same kernels; the f6 template forms read the same bytes)
         if table is None and mode == "f8" and "modes" not in tj:
             table = {k: v for k, v in tj.items() if not k.startswith("_")}
         if table is None:
@@ -568,7 +573,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and with it the live parity of every mode)")
     ap.add_argument("--no-latency", action="store_true", help="skip the auxiliary legs: batch-1 hipGraph latency, three-steps-in-flight throughput")
-    ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f32"],
+    ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f6", "f32"],
                     help="the PRIMARY arithmetic mode = top-level value; default: the library default (networks.DEFAULT_CONV_MODE = f8). "
                          "f8: f16 main product + two block-scaled fp8 correction products (pixels within 1e-4 of fp32; budget 1e-3); "
                          "h3: three f16 products on hi/lo-split operands (5e-6); f32: all layers on the fp32 MFMA kernels")
@@ -646,7 +651,7 @@ def main():
     if args.conv_mode is None:
         args.conv_mode = DEFAULT_CONV_MODE
     if args.modes in (None, "all"):
-        modes = ["f8", "h3", "f32"] if (world == 1 or args.modes == "all") else [args.conv_mode]
+        modes = ["f8", "h3", "f32", "f6"] if (world == 1 or args.modes == "all") else [args.conv_mode]
     elif args.modes == "primary":
         modes = [args.conv_mode]
     else:

@@ -257,6 +257,7 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
             for (int nb = 0; nb < NBW; ++nb) {
                 const float nzg = nzr[nb] * p.gain;
                 unsigned hi[2][2], lo[2][2];              // [group of the pair][dword]
+                f32x4 wv[2], xlv[2];                      // the values themselves (f6 output converts both groups at once)
 #pragma unroll
                 for (int gi = 0; gi < 2; ++gi) {
                     const int r0 = 4 * (2 * gp + gi);
@@ -269,7 +270,10 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
                     const h2 h01 = __builtin_convertvector(f32x2{w[0], w[1]}, h2), h23 = __builtin_convertvector(f32x2{w[2], w[3]}, h2);
                     const f32x4 xl = {nb_sub_f16(w[0], h01, false), nb_sub_f16(w[1], h01, true), nb_sub_f16(w[2], h23, false), nb_sub_f16(w[3], h23, true)};
                     hi[gi][0] = __builtin_bit_cast(unsigned, h01); hi[gi][1] = __builtin_bit_cast(unsigned, h23);
-                    if (p.out_f8) {
+                    wv[gi] = w; xlv[gi] = xl;
+                    if (p.out_f8 == 2) {
+                        lo[gi][0] = 0; lo[gi][1] = 0;             // (assembled below, once both groups are known)
+                    } else if (p.out_f8) {
                         // (conversions saturate: FP16_OVFL is set when out_f8)
                         // (x 2^9 and x 2^-2 inside the conversions: nb_pk4_fp8_sat_scaled)
                         lo[gi][0] = nb_pk4_fp8_sat_scaled(xl[0], xl[1], xl[2], xl[3], 0x1p-9f);
@@ -279,17 +283,41 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
                         lo[gi][0] = __builtin_bit_cast(unsigned, l01); lo[gi][1] = __builtin_bit_cast(unsigned, l23);
                     }
                 }
+                if (p.out_f8 == 2) {
+                    // f6 output: this lane holds 8 of the chunk's 16 channels (4 lh .. + 3 and 8 + 4 lh .. + 3: field pairs 8 lh .. 8 lh + 7
+                    // of the chunk's 32-field stream), lane l ^ 32 the other 8.  Chunk maximum over both lanes, one conversion of the lane's
+                    // 8 + 8 values (three dwords), one dword handed to the lower lane: it stores slot (cg even, lo) = dwords 0-3, the upper
+                    // lane slot (cg odd, lo) = dwords 4, 5, the scale byte.
+                    float m = 0.f;
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(wv[gi][i]));
+                    unsigned m0 = __builtin_bit_cast(unsigned, m), m1 = m0;
+                    nb_swap32(m0, m1);                            // (own, partner's) on both halves
+                    const float sc = nb_f6_scale(fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1)));
+                    const u32x6 r = nb_cvt_fp6x16(f32x8{xlv[0][0] * 2048.f, xlv[0][1] * 2048.f, xlv[0][2] * 2048.f, xlv[0][3] * 2048.f,
+                                                        xlv[1][0] * 2048.f, xlv[1][1] * 2048.f, xlv[1][2] * 2048.f, xlv[1][3] * 2048.f},
+                                                  f32x8{wv[0][0], wv[0][1], wv[0][2], wv[0][3], wv[1][0], wv[1][1], wv[1][2], wv[1][3]}, sc);
+                    unsigned d3 = r[0], dummy = 0;                // the upper lane's first dword = dword 3 of the stream
+                    nb_swap32(d3, dummy);                         // lower lanes: dummy = the upper lane's r[0]
+                    lo[0][0] = lh ? r[1] : r[0]; lo[0][1] = lh ? r[2] : r[1];
+                    lo[1][0] = lh ? nb_f6_scale_byte(sc) : r[2]; lo[1][1] = lh ? 0u : dummy;
+                }
                 unsigned ha[2], hb[2], la[2], lb[2];      // a = channels 0-3, b = channels 4-7 of the owned group
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     ha[k] = hi[0][k]; hb[k] = hi[1][k]; la[k] = lo[0][k]; lb[k] = lo[1][k];
                     nb_swap32(ha[k], hb[k]);
-                    nb_swap32(la[k], lb[k]);
+                    if (p.out_f8 != 2) nb_swap32(la[k], lb[k]);
                 }
                 if (cg * 8 < p.c_out && !(p.dbg & 1)) {
                     const size_t pix8 = ((size_t)(y0 + trow0 + nb) * W + x0 + l31) * 8;
                     *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2) * HW8 + pix8) = u32x4{ha[0], ha[1], hb[0], hb[1]};
-                    if (p.out_f8) {
+                    if (p.out_f8 == 2) {
+                        // (this lane's own four dwords: lo[0][0], lo[0][1], lo[1][0], lo[1][1] as assembled above)
+                        *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2 + 1) * HW8 + pix8) = u32x4{la[0], la[1], lb[0], lb[1]};
+                    } else if (p.out_f8) {
                         // the 16-channel chunk's two lo slots: (even group, lo) = fp8(xl 2^9), (odd group, lo) = fp8(v/4); this
                         // group's 8 channels are bytes 8 (cg & 1) .. + 7 of both
                         _Float16* lo_xl = yn + (size_t)((cg & ~1) * 2 + 1) * HW8 + pix8 + (cg & 1) * 4;

@@ -278,6 +278,7 @@ class SynthesisNetwork(torch.nn.Module):
         self.fuse_torgb = True            # last conv1 + ToRGB + compositing in one launch (split-f16 path)
         self.noise_in_kernel = True       # large split-f16 layers compute their (position-shifted) noise themselves
         self.layer_kernels: Dict[str, str] = {}
+        self.layer_formats: Dict[str, int] = {}      # operand format each split-f16 layer last ran with (0 H2, 1 f8, 2 f6)
 
     # -- helpers --
     def get_last_block(self):
@@ -306,10 +307,12 @@ class SynthesisNetwork(torch.nn.Module):
                                    "noise_lin": layer.noise_grid[0, :, 0, 0].contiguous(),
                                    # transposed copy for the convolutions that compute their noise themselves (NbNoiseSrc)
                                    "noise_const_t": layer.noise_const.t().contiguous()}
-            if self.conv_mode in ("h3", "f8") and self.cfg.conv_clamp is not None:
+            if self.conv_mode in ("h3", "f8", "f6") and self.cfg.conv_clamp is not None:
                 self.packed[s.name]["w_h3"] = ops.pack_conv_weight_h3(layer.weight)
-                if self.conv_mode == "f8" and s.in_channels % 16 == 0:
+                if self.conv_mode in ("f8", "f6") and s.in_channels % 16 == 0:
                     self.packed[s.name]["w_f8"] = ops.pack_conv_weight_h3f8(layer.weight)
+                    if self.conv_mode == "f6" and s.up == 2:
+                        self.packed[s.name]["w_f6"] = ops.pack_conv_weight_h3f6(layer.weight)
                 if s.up == 2 and s.in_res <= 32 and s.in_channels % 16 == 0:
                     self.packed[s.name]["w_h3_up2"] = ops.pack_conv_weight_h3_up2_phases(layer.weight, layer.resample_filter)
         t = self.get_last_block().torgb
@@ -324,14 +327,14 @@ class SynthesisNetwork(torch.nn.Module):
     def _h3_eligible(self, s: LayerSpec) -> bool:
         """conv1 layers that run as 3-pass split-f16 MFMA (csrc/nb_modconv_h3.hip): the kernel needs rows of 32
         pixels and 16-row tiles, and a conv_clamp so that activations are bounded inside the f16 range."""
-        return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 1 and s.block_res >= 32
+        return (self.conv_mode in ("h3", "f8", "f6") and self._h3_batch_ok and s.up == 1 and s.block_res >= 32
                 and self._n * s.block_res ** 2 >= self.h3_min_pixels and s.block_res % 32 == 0 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _h3_up2_eligible(self, s: LayerSpec) -> bool:
         """conv0 (up=2) layers that run on the split-f16 4-phase kernel: input rows must be multiples of 32 pixels, or 16
         pixels (8 x 16 quad tiles: two workgroups per sample and c_out slice, so only worth it at batch >= 16)."""
         w8 = s.in_res == 8 and self._n >= self.h3_up2_w8_min_batch
-        return (self.conv_mode in ("h3", "f8") and self._h3_batch_ok and s.up == 2
+        return (self.conv_mode in ("h3", "f8", "f6") and self._h3_batch_ok and s.up == 2
                 and ((s.in_res >= 32 and s.in_res % 32 == 0) or (s.in_res == 16 and self._n >= self.h3_up2_w16_min_batch) or w8)
                 and (w8 or self._n * s.block_res ** 2 >= self.h3_min_pixels)
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
@@ -341,21 +344,28 @@ class SynthesisNetwork(torch.nn.Module):
     def _small_h3_eligible(self, s: LayerSpec) -> bool:
         """conv1 layers too small for the large-tile split-f16 kernel: same hi/lo products on 32 x 32 tiles with K split
         over the waves, fp32 in and out (needs whole 16-channel chunks and the conv_clamp bound like the other f16 paths)."""
-        return (self.small_h3 and self.conv_mode in ("h3", "f8") and s.up == 1 and s.block_res <= 64
+        return (self.small_h3 and self.conv_mode in ("h3", "f8", "f6") and s.up == 1 and s.block_res <= 64
                 and s.in_channels % 16 == 0 and s.in_channels <= 512
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _small_h3_up2_eligible(self, s: LayerSpec) -> bool:
         """conv0 (up = 2) layers with inputs <= 32x32 that the large-tile up=2 kernel does not take."""
-        return (self.small_h3 and self.conv_mode in ("h3", "f8") and s.up == 2 and s.in_res <= 32
+        return (self.small_h3 and self.conv_mode in ("h3", "f8", "f6") and s.up == 2 and s.in_res <= 32
                 and s.in_channels % 16 == 0 and s.in_channels <= 512 and s.name in self.packed
                 and "w_h3_up2" in self.packed[s.name]
                 and self.cfg.conv_clamp is not None and self.cfg.conv_clamp <= 1024)
 
     def _operand_fmt(self, s: Optional[LayerSpec]) -> int:
         """Operand format of a split-f16 layer's input: 1 = "f8" (correction products on block-scaled fp8 MFMAs; whole
-        16-channel chunks only), 0 = H2 (hi/lo f16)."""
-        return 1 if (s is not None and self.conv_mode == "f8" and s.in_channels % 16 == 0) else 0
+        16-channel chunks only), 0 = H2 (hi/lo f16); 2 = "f6" (round 5: fp6 correction products with per-pixel block scales) -- in
+        conv_mode "f6", for the layers whose kernel takes it: the up=2 launches that run on the 12-row software-pipelined kernel
+        (their producers, an up=1 kernel and the geometry pack, write the format; the up=2 epilogue does not, so the up=1 layers
+        behind an up=2 layer stay on f8 operands)."""
+        if s is None or self.conv_mode not in ("f8", "f6") or s.in_channels % 16:
+            return 0
+        if self.conv_mode == "f6" and s.up == 2 and s.in_res % 32 == 0 and self._up2_h3_variant_name(2, self._n, s) == "modconv3x3_up2v_kernel":
+            return 2
+        return 1
 
     def _variant_name(self, n: int, s: LayerSpec) -> str:
         buf = ctypes.create_string_buffer(128)
@@ -587,7 +597,7 @@ class SynthesisNetwork(torch.nn.Module):
                         # from pre_h2, which the lazy path may already have filled for another feature
                         plan.pack_stream.wait_stream(cur)
                         pack_waited = True
-                    part = lib.nb_pack_h2f8_part_f32 if ofmt else lib.nb_pack_h2_part_f32
+                    part = (lib.nb_pack_h2_part_f32, lib.nb_pack_h2f8_part_f32, lib.nb_pack_h2f6_part_f32)[ofmt]
                     c_prod = sc_.in_channels - gch
                     _lib.check(part(_p(g), gch, plan.styles[ic].data_ptr() + 4 * c_prod, sc_.in_channels, _p(dst),
                                     (sc_.in_channels + 7) // 8, c_prod // 8, n, gres * gres, plan.pack_stream.cuda_stream), "pack_h2_part")
@@ -675,12 +685,12 @@ class SynthesisNetwork(torch.nn.Module):
                             evp = self._begin_event("pack_h2")
                             x_h2 = torch.empty(ops.h2_shape(n, s.in_channels, s.in_res, s.in_res), dtype=torch.float16,
                                                device=device)
-                            pack = lib.nb_pack_h2f8_f32 if in_fmt else lib.nb_pack_h2_f32
+                            pack = (lib.nb_pack_h2_f32, lib.nb_pack_h2f8_f32, lib.nb_pack_h2f6_f32)[in_fmt]
                             _lib.check(pack(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(x_h2), n, s.in_res * s.in_res, stream),
                                        "pack_h2")
                             self._end_event(evp)
                         ev = self._begin_event(name)
-                        wts = pk["w_f8"] if in_fmt else pk["w_h3"]
+                        wts = pk["w_f6"] if in_fmt == 2 else pk["w_f8"] if in_fmt else pk["w_h3"]
                         fuse_rgb = (self.fuse_torgb and block.is_last and s.up == 1 and s.out_channels <= 128
                                     and res not in blended_features)
                         targs = None
@@ -714,6 +724,7 @@ class SynthesisNetwork(torch.nn.Module):
                                 s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
                         if fuse_rgb:
                             fused_rgb = self._torgb_finish(tg, extra)
+                        self.layer_formats[name] = in_fmt
                         self.layer_kernels[name] = ("modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
                                                     if s.up == 1 else self._up2_h3_variant_name(in_fmt, n, s))
                         keep_alive.append(x_h2)
@@ -912,7 +923,7 @@ class Generator(torch.nn.Module):
     def __init__(self, cfg: GeneratorConfig = None, state_dict: Optional[StateDict] = None,
                  conv_mode: str = DEFAULT_CONV_MODE, **kwargs):
         super().__init__()
-        if conv_mode not in ("h3", "f8", "f32"):
+        if conv_mode not in ("h3", "f8", "f6", "f32"):
             raise RuntimeError(f"unknown conv_mode {conv_mode!r}")
         if cfg is None:
             cfg = GeneratorConfig(**kwargs)
@@ -934,7 +945,7 @@ class Generator(torch.nn.Module):
     def set_conv_mode(self, conv_mode: str):
         """'h3': layers >= 32x32 as 3-pass split-f16 MFMA (5e-6 from fp32); 'f8': the two correction passes on one
         block-scaled fp8 MFMA per tap pair (1e-4 from fp32, ~1.4x faster layers); 'f32': exact-fp32 MFMA kernels."""
-        if conv_mode not in ("h3", "f8", "f32"):
+        if conv_mode not in ("h3", "f8", "f6", "f32"):
             raise RuntimeError(f"unknown conv_mode {conv_mode!r}")
         self.synthesis.conv_mode = conv_mode
         self._invalidate()
