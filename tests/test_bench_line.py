@@ -32,7 +32,7 @@ def test_compact_line_of_a_full_record_is_small_and_complete():
         assert k in r, k
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert set(c["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
-    assert set(c["modes"]) == {"f8", "h3", "f32"}
+    assert set(c["modes"]) == {"f8", "h3", "f32"}                     # (the round-4 record; round 5 adds "f6")
     assert not any(isinstance(v, str) and len(v) > 200 for v in c.values())
 
 
