@@ -31,16 +31,17 @@ done
 cd $R
 python tools/make_hbm_traffic.py $O/hbm_traffic.json "${GIT_HEAD:-unknown}" f8=$O/pmc_mem_f8.json h3=$O/pmc_mem_h3.json f32=$O/pmc_mem_f32.json > $O/hbm_traffic.log 2>&1
 cp $O/hbm_traffic.json $R/profiles/hbm_traffic.json
-NB_PHASE_F8=1 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times.txt 2>&1
+NB_PHASE_FMT=1 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times.txt 2>&1
+NB_PHASE_FMT=2 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times_f6.txt 2>&1
 python tools/phase_times_enc.py > $O/phase_times_encoder.txt 2>&1
-# up=2 launches: L2-boundary reads with the round-3 workgroup order (NB_DEBUG=32) and the whole-grid XCD order, then the timing A/B
-bash tools/ab_xcd_traffic.sh > $O/ab_xcd_order.txt 2>&1
-# same-box A/Bs of the round's K loops: round-3 kernels vs software-pipelined ones (up=2: also the one-wave-per-SIMD wide form)
-bash tools/ab_v2.sh $O/ab_v2 > $O/ab_up2_kernels.txt 2>&1; rm -rf $O/ab_v2
-bash tools/ab_up1.sh $O/ab_up1 > $O/ab_up1_kloops.txt 2>&1; rm -rf $O/ab_up1
+# round 5: the large launches with f8 and f6 operands (same box, alternating), the ping-pong up=1 K loop against the software-pipelined one
+python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/f6_layers.txt
+(for pp in 0 1 0 1; do echo "== NB_UP1_PP=$pp"; NB_UP1_PP=$pp NB_LAYERS=0,1 NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up"; done) > $O/ab_up1_pingpong_layers.txt 2>&1
+bash tools/ab_env.sh NB_UP1_PP=1 2>&1 | grep f8 > $O/ab_up1_pingpong_step.txt
 bash $R/tools/microbench/run_all.sh > $O/microbench.txt 2>&1
 python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
-NB_SUBS="1 2" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1
+NB_SUBS="1" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && cd $R && NB_SUB=1 NB_STEPS=40 rocprofv3 --kernel-trace -d $O/steptl -o st --output-format csv -- python3 tools/trace_step_loop.py > /dev/null 2>&1; python3 tools/trace_step_timeline.py $O/steptl 20 > $O/step_timeline.txt 2>&1; rm -rf $O/steptl)
 (cd /tmp && rocprofv3 --kernel-trace -d $O/b1trace -o b1 --output-format csv -- python3 $R/tools/trace_b1.py > $O/b1trace.log 2>&1)
 python tools/trace_b1_summary.py $O/b1trace > $O/b1_trace_summary.txt 2>&1; rm -rf $O/b1trace
 (cd /tmp && rocprofv3 --kernel-trace -d $O/enctrace -o enc --output-format csv -- python3 $R/tools/trace_encoder.py > $O/enctrace.log 2>&1)
