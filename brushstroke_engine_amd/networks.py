@@ -605,6 +605,7 @@ class SynthesisNetwork(torch.nn.Module):
                     if ev_ is None:
                         ev_ = plan.pack_events[gres] = torch.cuda.Event()
                     ev_.record(plan.pack_stream)
+                    plan.pack_last_event = ev_
                     g.record_stream(plan.pack_stream)
                     dst.record_stream(plan.pack_stream)
                     pre_h2[gres] = (dst, ev_)
@@ -615,6 +616,7 @@ class SynthesisNetwork(torch.nn.Module):
             x = img = None
             x2 = None
             x_h2 = None
+            packs_waited = False
             geo_idx = 0
             specs = {s.name: (i, s) for i, s in enumerate(cfg.layers)}
             for res in self.block_resolutions:
@@ -791,8 +793,15 @@ class SynthesisNetwork(torch.nn.Module):
                     x2 = g.to(torch.float32).contiguous()
                     _assert_shape(x2, [n, self.geom_feature_channels[self.geom_feature_resolutions.index(res)], res, res])
                     if x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
-                        if pre_h2[res][1] is not None:
-                            torch.cuda.current_stream(device).wait_event(pre_h2[res][1])     # packed early on the side stream
+                        if pre_h2[res][1] is not None and not packs_waited:
+                            # packed early on the side stream.  ONE wait, at the first consumer, for the LAST pack enqueued there (the
+                            # stream runs them in order, and all of them are through long before this point: 131 us into a step whose
+                            # first consumer starts at 168): a cross-stream wait costs ~6 us of idle chip each time, whether or not
+                            # the event has fired (tools/trace_step_timeline.py)
+                            last_ = getattr(plan, "pack_last_event", None)
+                            covers_all = any(v[1] is last_ for v in pre_h2.values())        # (the last pack of THIS pass)
+                            torch.cuda.current_stream(device).wait_event(last_ if covers_all else pre_h2[res][1])
+                            packs_waited = covers_all
                         keep_alive.append(x2)
                         x2 = None
                     elif x_h2 is not None:
