@@ -231,7 +231,9 @@ __device__ __forceinline__ H3HandoffArgs nb_handoff_args(_Float16* yh2, int c8_n
                                                          float clamp) {
     return H3HandoffArgs{yh2, c8_next, c_out, h, w, out_f8, dbg, alpha, gain, clamp};
 }
-template <int MB, int NBW>
+// F6OUT: the f6 output format is a compile-time form (its extra live values cost the encoder's stem, which shares this epilogue and never
+// writes f6, 135 -> 205 us when it was a run-time branch)
+template <int MB, int NBW, bool F6OUT = false>
 __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, const f32x16 (&acc)[MB][NBW], const float (&nzr)[NBW], const float* s_dco,
                                                         const float* s_bias, const float* s_nst, int colbase, int trow0, int co0, int n, int y0, int x0,
                                                         int lh, int l31) {
@@ -270,8 +272,8 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
                     const h2 h01 = __builtin_convertvector(f32x2{w[0], w[1]}, h2), h23 = __builtin_convertvector(f32x2{w[2], w[3]}, h2);
                     const f32x4 xl = {nb_sub_f16(w[0], h01, false), nb_sub_f16(w[1], h01, true), nb_sub_f16(w[2], h23, false), nb_sub_f16(w[3], h23, true)};
                     hi[gi][0] = __builtin_bit_cast(unsigned, h01); hi[gi][1] = __builtin_bit_cast(unsigned, h23);
-                    wv[gi] = w; xlv[gi] = xl;
-                    if (p.out_f8 == 2) {
+                    if constexpr (F6OUT) { wv[gi] = w; xlv[gi] = xl; }
+                    if constexpr (F6OUT) {
                         lo[gi][0] = 0; lo[gi][1] = 0;             // (assembled below, once both groups are known)
                     } else if (p.out_f8) {
                         // (conversions saturate: FP16_OVFL is set when out_f8)
@@ -283,7 +285,7 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
                         lo[gi][0] = __builtin_bit_cast(unsigned, l01); lo[gi][1] = __builtin_bit_cast(unsigned, l23);
                     }
                 }
-                if (p.out_f8 == 2) {
+                if constexpr (F6OUT) {
                     // f6 output: this lane holds 8 of the chunk's 16 channels (4 lh .. + 3 and 8 + 4 lh .. + 3: field pairs 8 lh .. 8 lh + 7
                     // of the chunk's 32-field stream), lane l ^ 32 the other 8.  Chunk maximum over both lanes, one conversion of the lane's
                     // 8 + 8 values (three dwords), one dword handed to the lower lane: it stores slot (cg even, lo) = dwords 0-3, the upper
@@ -309,12 +311,12 @@ __device__ __forceinline__ void nb_up1_handoff_epilogue(const H3HandoffArgs p, c
                 for (int k = 0; k < 2; ++k) {
                     ha[k] = hi[0][k]; hb[k] = hi[1][k]; la[k] = lo[0][k]; lb[k] = lo[1][k];
                     nb_swap32(ha[k], hb[k]);
-                    if (p.out_f8 != 2) nb_swap32(la[k], lb[k]);
+                    if constexpr (!F6OUT) nb_swap32(la[k], lb[k]);
                 }
                 if (cg * 8 < p.c_out && !(p.dbg & 1)) {
                     const size_t pix8 = ((size_t)(y0 + trow0 + nb) * W + x0 + l31) * 8;
                     *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2) * HW8 + pix8) = u32x4{ha[0], ha[1], hb[0], hb[1]};
-                    if (p.out_f8 == 2) {
+                    if constexpr (F6OUT) {
                         // (this lane's own four dwords: lo[0][0], lo[0][1], lo[1][0], lo[1][1] as assembled above)
                         *reinterpret_cast<u32x4*>(yn + (size_t)(cg * 2 + 1) * HW8 + pix8) = u32x4{la[0], la[1], lb[0], lb[1]};
                     } else if (p.out_f8) {

@@ -968,7 +968,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     // the accumulator registers directly, and whole 512-byte row segments per wave-instruction.
     constexpr int PIX_WG = TH * 32;
     if (p.yh2) {
-        nb_up1_handoff_epilogue<MB, NBW>(nb_handoff_args(p.yh2, p.c8_next, p.c_out, p.h, p.w, p.out_f8, p.dbg, p.alpha, p.gain, p.clamp), acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
+        const H3HandoffArgs ha_ = nb_handoff_args(p.yh2, p.c8_next, p.c_out, p.h, p.w, p.out_f8, p.dbg, p.alpha, p.gain, p.clamp);
+        if constexpr (F8 && V2) {          // (the f6 output form exists for the software-pipelined f8 / f6 kernels only: the launcher checks)
+            if (p.out_f8 == 2) nb_up1_handoff_epilogue<MB, NBW, true>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
+            else nb_up1_handoff_epilogue<MB, NBW, false>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
+        } else nb_up1_handoff_epilogue<MB, NBW, false>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
         NB_TSTAMP(3);
         NB_TSTAMP(4);
         return;
@@ -1285,7 +1289,7 @@ static int g_force_up1_v2 = -1;
 // developer / test hook: -1 = automatic (on), 0 / 1 = the round-3 / the software-pipelined K loop of the f8 up=1 kernel
 extern "C" void nb_debug_set_up1_v2(int mode) { g_force_up1_v2 = mode; }
 #ifndef NB_UP1_PP_DEFAULT
-#define NB_UP1_PP_DEFAULT 0
+#define NB_UP1_PP_DEFAULT 1          // round 5: +1.0 % / +0.5 % per step on a slow / fast box (three alternating pairs each), bit-identical
 #endif
 static int g_force_up1_pp = -1;
 // developer / test hook: -1 = automatic, 0 / 1 = the software-pipelined / the ping-pong K loop of the f8 up=1 kernel
@@ -1343,6 +1347,7 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     // (its pieces walk the chunks with a fixed per-chunk stride: whole 16-channel chunks only -- f8 operands always are; H2 operands
     //  with an odd number of channel groups keep the round-3 loop, whose last chunk reads the missing group from the zero page)
     const bool v2 = (g_force_up1_v2 >= 0 ? g_force_up1_v2 : env_v2) != 0 && (f8 || p.c8 % 2 == 0);
+    NB_REQUIRE(out_fmt != 2 || (f8 && v2), "modconv3x3_up1_h3: the f6 output format is written by the software-pipelined f8 / f6 kernels only");
     if (f6) {                                               // (the software-pipelined loop only)
         if (half) return c_out > 64 ? launch_h3<2, true, 1, true, true>(p, n, st) : launch_h3<1, true, 1, true, true>(p, n, st);
         return c_out > 64 ? launch_h3<2, true, 2, true, true>(p, n, st) : launch_h3<1, true, 2, true, true>(p, n, st);

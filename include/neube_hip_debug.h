@@ -20,7 +20,8 @@ void nb_debug_set_up1_rows(int nbw);
  * round-3 loop, 1 = the software-pipelined loop.  tests/test_hip_f8.py asserts both bit-identical. */
 void nb_debug_set_up1_v2(int mode);
 /* ... its ping-pong form (round 5: waves 4-7 one segment behind waves 0-3, a load segment against a compute segment on every SIMD):
- * -1 = automatic (NB_UP1_PP, default off: launches -2.5 %, step within noise), 0 / 1 = off / on.  Bit-identical (tests/test_hip_f8.py). */
+ * -1 = automatic (NB_UP1_PP, default ON since the end of round 5: launches -2.5 %, step +0.5 ... +1.0 %), 0 / 1 = off / on.  Bit-identical
+ * (tests/test_hip_f8.py). */
 void nb_debug_set_up1_pp(int mode);
 
 /* K-splitting waves per workgroup of the small-image kernel (modconv3x3_up1_small_h3): 0 = automatic (8 for layers of >= 8
