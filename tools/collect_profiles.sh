@@ -37,7 +37,7 @@ python tools/phase_times_enc.py > $O/phase_times_encoder.txt 2>&1
 # round 5: the large launches with f8 and f6 operands (same box, alternating), the ping-pong up=1 K loop against the software-pipelined one
 python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/f6_layers.txt
 (for pp in 0 1 0 1; do echo "== NB_UP1_PP=$pp"; NB_UP1_PP=$pp NB_LAYERS=0,1 NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up"; done) > $O/ab_up1_pingpong_layers.txt 2>&1
-bash tools/ab_env.sh NB_UP1_PP=1 2>&1 | grep f8 > $O/ab_up1_pingpong_step.txt
+bash tools/ab_env.sh NB_UP1_PP=0 2>&1 | grep f8 > $O/ab_up1_pingpong_step.txt    # (base = the variable set = ping-pong OFF, cur = the default = on)
 bash $R/tools/microbench/run_all.sh > $O/microbench.txt 2>&1
 python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
 NB_SUBS="1" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1
