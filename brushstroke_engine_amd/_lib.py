@@ -116,6 +116,7 @@ PROTOTYPES = {
     "nb_enc_conv3x3_ex": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_enc_upsample2x_h2_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "nb_enc_stem_conv3x3_f8": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "nb_pack_conv_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
 }
 

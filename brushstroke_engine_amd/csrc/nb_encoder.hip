@@ -197,6 +197,10 @@ struct EncConvParams {
     // input, i.e. the padded form's taps moved one pixel down / right (the training path's stride-2 correlations)
     int shift;
     unsigned long long* tstamps;   // debug: per-workgroup phase timestamps [workgroup][8] (nb_debug_set_enc_timestamps), else null
+    // FUSED (stem + first stride-2 stage in one kernel): the fp32 image [n][1][hin][win], the stem's weights [64][50] and bias [64], its
+    // input preprocessing and LeakyReLU slope; x is unused
+    const float* img; const float* stem_w; const float* stem_b;
+    int preproc;
 };
 
 static unsigned long long* g_enc_tstamps = nullptr;
@@ -214,8 +218,23 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // fp8(wl 2^11)); per tap one f16 MFMA for the main product and, per PAIR of taps, one block-scaled K=64 fp8 MFMA for both
 // correction products (the third tap of a step pairs with the third tap of the next step): 768 instead of 1152 matrix
 // cycles per step and tile row.
-template <int STRIDE, int LW, int OUT, bool F8 = false>
+// FUSED (with F8, stride 2, 32-wide tiles, hand-off output; round 5): the 64-channel input is not read -- it is the STEM's output (1 -> 64,
+// 7 x 7, reflect padding 3, LeakyReLU), and the workgroup computes the slab of it a chunk needs itself, on the matrix pipe, straight into the slab
+// buffers in operand format: the stem's output is the largest tensor of the encoder (16.8 MB per 256 x 256 tile in "f8" format), written once
+// and read once -- 1.1 GB of HBM traffic per batch of 32 that bounded the stem launch (133 us) and cost this one its cold reads.
+//   * prologue: the (2 TH + 7) x 71 window of the image the tile's stem outputs need, split into f16 hi / lo and stored COLUMN-major (26 halves
+//     per column, twice: starting at window row 0 and at row 1), so that the eight vertically adjacent pixels of a stem row's taps are 16 bytes
+//     at a 4-byte-aligned address whatever the row: K = (tap column b, tap row a) as in enc_stem7x7_kernel, b = 4 s + (lane >> 4).
+//   * a stem phase = one slab (odd rows: TH + 1, even rows: TH) of one 16-channel chunk: v_mfma_f32_16x16x32_f16 tiles of 16 c_out x 16 slab
+//     positions (one row, one column parity, half a row; the 33rd odd column of all rows is one more tile), three split-f16 products x two K
+//     steps; a lane then holds four consecutive channels of one position: bias, LeakyReLU, f16 hi + the fp8 correction operands, three LDS
+//     stores into the slab.  O_c+1 is computed behind step (c, 1) -- into the buffer E_c has just left --, E_c+1 behind step (c, 2).
+//   * the K loop is the S2F loop below with weight pieces only.
+// Per stem output the sum runs in another order than enc_stem7x7_kernel's (three accumulators of 16x16x32 products): not bit-identical to the
+// two-kernel path, same fp32-grade products (tests/test_hip_encoder.py compares both with the oracle).
+template <int STRIDE, int LW, int OUT, bool F8 = false, bool FUSED = false>
 __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams p) {
+    static_assert(!FUSED || (F8 && STRIDE == 2 && LW == 5 && OUT == 1), "the fused stem feeds the stride-2 f8 loop with the hand-off epilogue");
     constexpr int NW = 8, NWN = 4, MB = 2, NBW = 2, CO_WG = 128;
     constexpr int WT = 1 << LW, RPB = 32 / WT, TH = NWN * NBW * RPB, PW = WT + 2;      // output tile TH x WT = 256 pixels
     // S2F (stride 2, f8 operands): activations are staged per CHUNK, not per step.  The slab of tap row 2 (input rows 2r+1) is the
@@ -226,13 +245,19 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     constexpr bool S2F = F8 && STRIDE == 2;
     constexpr int ROWPITCH = S2F ? 2 * PW : PW;
     constexpr int SLOTS = S2F ? (TH + 1) * ROWPITCH : STRIDE * TH * PW;             // 16-byte slots of one (cgroup, hi/lo) plane of a step (S2F: of a slab)
-    constexpr int PP = (SLOTS + 63) / 64, XPL = PP * 64;
+    constexpr int PP = (SLOTS + 63) / 64, XPL = FUSED ? SLOTS : PP * 64;                // (FUSED: no 1-KiB pieces to pad a plane for)
     constexpr int NXP = 4 * PP, NXPW = (NXP + NW - 1) / NW;
+    constexpr int NXA = FUSED ? 0 : NXPW;                                               // activation pieces per wave and slab (S2F loop)
     constexpr int WSLOTS = 12 * CO_WG, NWP = WSLOTS / 64, NWPW = NWP / NW;
     constexpr int KX0 = S2F ? PW : (STRIDE == 2 ? TH * PW : 0), KX1 = STRIDE == 2 ? 0 : 1, KX2 = S2F ? PW + 1 : (STRIDE == 2 ? TH * PW + 1 : 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_enc[];
     h8* xbuf = reinterpret_cast<h8*>(smem_enc);         // [2][4][XPL]
     h8* wbuf = xbuf + 2 * 4 * XPL;                      // [2][WSLOTS]
+    // FUSED: the image window as column-major f16 strips [start row parity][hi/lo][column][26 halves] and the stem's weight fragments
+    constexpr int SCOLS = 2 * WT + 8, SPITCH = 52, STRIP_BYTES = 4 * SCOLS * SPITCH;
+    static_assert(!FUSED || (STRIP_BYTES % 16 == 0 && 2 * TH + 7 + 1 <= SPITCH / 2), "strip geometry");
+    [[maybe_unused]] unsigned char* strips = reinterpret_cast<unsigned char*>(wbuf + 2 * WSLOTS);
+    [[maybe_unused]] h8* stemw = reinterpret_cast<h8*>(strips + STRIP_BYTES);           // [chunk 4][K step 2][hi/lo][lane]
     NB_TSTAMP(0);
 
     const int tid = threadIdx.x;
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
         // mid-step barrier that frees the target: E_c's buffer takes O_c+1 once step (c, 1) has read it, O_c's buffer takes E_c+1
         // once step (c, 2) has), the second half in the first half of the step before.  The counted wait at the top of a step
         // leaves exactly the first half of the NEXT step's list in flight.  Weight buffers alternate with the step as before.
-        constexpr int NPC = NXPW + NWPW;                               // pieces per wave of kinds 0 and 1
+        constexpr int NPC = NXA + NWPW;                                // pieces per wave of kinds 0 and 1
         constexpr int FH01 = NPC / 2, FH2 = (NWPW + 1) / 2;           // first halves
         static_assert(NXP == NXPW * NW, "every wave issues the same number of activation pieces (no skipping: counted waits)");
         const int NC = p.nchunks, T = NC * 3;
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
         // piece k of the list of kind KIND for step (cc, KIND); past the end: the last chunk again (harmless re-copies keep the counts uniform)
         auto piece2 = [&](auto kind_, auto kk, int cc) {
             constexpr int KIND = decltype(kind_)::value, k = decltype(kk)::value;
-            constexpr int NA = KIND == 2 ? 0 : NXPW;
+            constexpr int NA = KIND == 2 ? 0 : NXA;
             const int src_c = cc < NC ? cc : NC - 1;
             const int t = 3 * cc + KIND, src_t = 3 * src_c + KIND;
             if constexpr (k < NA) {
@@ -460,10 +485,148 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             };
         };
         auto no_mf = [&](auto, auto) {};
+        // ---- FUSED: the stem on the matrix pipe (see the kernel's header) ----
+        __shared__ __attribute__((aligned(16))) float s_bias0[64];
+        [[maybe_unused]] auto fused_prologue = [&]() {
+            if (tid < 64) s_bias0[tid] = p.stem_b[tid];
+            const float* img = p.img + (size_t)n * p.hin * p.win;
+            // window row j <-> image row 2 y0 - 4 + j, column w <-> image column 2 x0 - 4 + w (the stem's reflect padding); row 23 = zeros (the
+            // zero-weight eighth tap of the last slab row)
+            constexpr int NE = (SCOLS * 24 + 511) / 512;
+            float v_[NE];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {                                  // (all loads first: one round trip)
+                const int e = tid + 512 * q, j = e / SCOLS, w = e - j * SCOLS;
+                v_[q] = 0.f;
+                if (e < SCOLS * 24 && j < 2 * TH + 7)
+                    v_[q] = img[(size_t)nb_reflect(2 * y0 - 4 + j, p.hin) * p.win + nb_reflect(2 * x0 - 4 + w, p.win)];
+            }
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int e = tid + 512 * q, j = e / SCOLS, w = e - j * SCOLS;
+                if (e < SCOLS * 24) {
+                    float v = v_[q];
+                    if (j < 2 * TH + 7) {
+                        if (p.preproc == 1) v = (1.f - v) * 2.f - 1.f;          // '-11inverse' (autoenc/base.py:30-52)
+                        else if (p.preproc == 2) v = 1.f - v;                   // 'inverse'
+                    }
+                    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                    *reinterpret_cast<_Float16*>(strips + (0 * SCOLS + w) * SPITCH + 2 * j) = hi;
+                    *reinterpret_cast<_Float16*>(strips + (1 * SCOLS + w) * SPITCH + 2 * j) = lo;
+                    if (j >= 1) {
+                        *reinterpret_cast<_Float16*>(strips + (2 * SCOLS + w) * SPITCH + 2 * (j - 1)) = hi;
+                        *reinterpret_cast<_Float16*>(strips + (3 * SCOLS + w) * SPITCH + 2 * (j - 1)) = lo;
+                    }
+                }
+            }
+            // A fragments of v_mfma_f32_16x16x32_f16: lane (row = c_out l15, K group kg) of K step s holds w[c_out][tap rows 0..7][tap column 4 s + kg]
+            {
+                const int chunk = tid >> 7, s_ = (tid >> 6) & 1, l15 = lane & 15, kg = lane >> 4;
+                const int b = 4 * s_ + kg;
+                h8 hi8, lo8;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const float wv_ = (a < 7 && b < 7) ? p.stem_w[(chunk * 16 + l15) * 50 + a * 7 + b] : 0.f;
+                    const _Float16 hi = (_Float16)wv_;
+                    hi8[a] = hi; lo8[a] = (_Float16)(wv_ - (float)hi);
+                }
+                stemw[((chunk * 2 + s_) * 2 + 0) * 64 + lane] = hi8;
+                stemw[((chunk * 2 + s_) * 2 + 1) * 64 + lane] = lo8;
+            }
+        };
+        // one slab of chunk c: KIND 0 = the odd slab O_c (image rows 2 (y0 + r) - 1, r = 0 .. TH) into buffer c & 1, KIND 1 = the even slab E_c
+        // (rows 2 (y0 + r), r < TH) into the other.  Tiles (16 slab positions) go round-robin over the waves; a wave's tiles run as a three-stage
+        // pipeline -- fragment reads of tile k + 2, matrix products of tile k + 1, conversion + stores of tile k -- in one basic block.
+        [[maybe_unused]] auto stem_phase = [&](auto kind_, int c) {
+            constexpr int KIND = decltype(kind_)::value;
+            constexpr int NR = KIND == 0 ? TH + 1 : TH, NBLKS = 4 * NR + 1, NIT = (NBLKS + NW - 1) / NW;
+            static_assert((NIT - 1) * NW <= 4 * NR, "only a wave's last tile can be the extra one (the 33rd odd column of all rows) or missing");
+            typedef int i32x4a __attribute__((ext_vector_type(4), aligned(4)));
+            const int l15 = lane & 15, kg = lane >> 4;
+            h8* sb = xbuf + (KIND == 0 ? (c & 1) : ((c + 1) & 1)) * 4 * XPL;
+            h8 wh[2], wl[2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) { wh[s_] = stemw[((c * 2 + s_) * 2 + 0) * 64 + lane]; wl[s_] = stemw[((c * 2 + s_) * 2 + 1) * 64 + lane]; }
+            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(s_bias0 + 16 * c + 4 * kg);
+            const unsigned char* sbase = strips + (KIND * 2 * SCOLS) * SPITCH;      // start rows: even (odd slab) | odd (even slab)
+            // tile k of this wave: column parity, column and row of the lane's position, whether the lane stores
+            auto geom = [&](auto k_, int& par, int& cl, int& rl, bool& ok) {
+                constexpr int k = decltype(k_)::value;
+                const int blk = wv + NW * k;
+                if constexpr (k < NIT - 1) {
+                    par = (blk >> 1) & 1; cl = 16 * (blk & 1) + l15; rl = blk >> 2; ok = true;
+                } else {
+                    const bool sp = blk >= 4 * NR;                                  // the extra tile (or none: nothing is stored)
+                    par = sp ? 1 : (blk >> 1) & 1;
+                    cl = sp ? WT : 16 * (blk & 1) + l15;
+                    rl = sp ? (l15 < NR ? l15 : NR - 1) : (blk >> 2);
+                    ok = blk < NBLKS && (!sp || l15 < NR);
+                }
+            };
+            h8 fh[2], fl[2];
+            f32x4 ac0[2], ac1[2];
+            auto load = [&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                int par, cl, rl; bool ok;
+                geom(k_, par, cl, rl, ok);
+                // the conv's own reflect padding: image row -1 = row 1 (odd slab of the first tile row), image column -1 = column 1
+                const int re = (KIND == 0 && y0 == 0 && rl == 0) ? 1 : rl;
+                int col0 = 2 * cl + (par ? 0 : 1);
+                if (par && cl == 0 && x0 == 0) col0 += 2;
+                const unsigned char* bp = sbase + (col0 + kg) * SPITCH + 4 * re;
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    fh[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH));
+                    fl[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH + SCOLS * SPITCH));
+                }
+            };
+            auto mma = [&](auto k_) {
+                constexpr int b_ = decltype(k_)::value & 1;
+                f32x4 a0 = bias4, a1 = {0.f, 0.f, 0.f, 0.f};
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], fl[0], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], fh[0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0], fh[0], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], fh[1], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], fl[1], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1], fh[1], a1, 0, 0, 0);
+                ac0[b_] = a0; ac1[b_] = a1;
+            };
+            auto store = [&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                int par, cl, rl; bool ok;
+                geom(k_, par, cl, rl, ok);
+                f32x4 t = ac0[k & 1] + ac1[k & 1];
+                const f32x4 ta = t * p.slope;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = fmaxf(t[i], ta[i]);               // LeakyReLU, 0 <= slope <= 1
+                const h2 h01 = __builtin_convertvector(f32x2{t[0], t[1]}, h2), h23 = __builtin_convertvector(f32x2{t[2], t[3]}, h2);
+                const f32x4 xl = {nb_sub_f16(t[0], h01, false), nb_sub_f16(t[1], h01, true), nb_sub_f16(t[2], h23, false), nb_sub_f16(t[3], h23, true)};
+                const unsigned lo_xl = nb_pk4_fp8_sat_scaled(xl[0], xl[1], xl[2], xl[3], 0x1p-9f);       // (FP16_OVFL is set: the conversions saturate)
+                const unsigned lo_w = nb_pk4_fp8_sat_scaled(t[0], t[1], t[2], t[3], 4.f);
+                if (ok) {
+                    const int slot = rl * ROWPITCH + par * PW + cl;
+                    // channels 4 kg .. + 3 of the chunk: half of a hi slot of group kg >> 1, bytes 4 kg .. of the chunk's two lo slots
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(sb + 2 * (kg >> 1) * XPL + slot) + 8 * (kg & 1)) =
+                        u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sb + 1 * XPL + slot) + 4 * kg) = lo_xl;
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sb + 3 * XPL + slot) + 4 * kg) = lo_w;
+                }
+            };
+            // (fences: left alone the scheduler puts every tile's reads right in front of its products again.  ONE fragment buffer: the reads of
+            //  tile t follow the products of tile t - 1 and land under the conversion of tile t - 2)
+            load(std::integral_constant<int, 0>{}); NB_SB;
+            nb_static_for<1, NIT + 2>([&](auto t_) {
+                constexpr int t = decltype(t_)::value;
+                if constexpr (t <= NIT) { mma(std::integral_constant<int, t - 1>{}); NB_SB; }
+                if constexpr (t < NIT) { load(t_); NB_SB; }
+                if constexpr (t >= 2) { store(std::integral_constant<int, t - 2>{}); NB_SB; }
+            });
+        };
         using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
         // step (c, S); ODD = parity of t = 3 c + S (selects the half of the tap-2 tuple).  Per accumulator tile the products arrive in the
         // order of the per-step loop below: tap 2 of step t-1, on even t the tap-2 corrections of t-2 and t-1, tap 0, tap 1, corrections
         // of taps 0 + 1.  Reads and pieces ride behind the MFMAs: a step opens with matrix work on registers it already holds.
+        [[maybe_unused]] unsigned long long t_stem = 0;        // (debug: wave 0's time in the stem phases behind the steps, slot 6)
         auto step = [&](auto s_, auto odd_, auto first_, int c) {
             constexpr int S = decltype(s_)::value, ODD = decltype(odd_)::value, FIRST = decltype(first_)::value;
             using KN = std::integral_constant<int, (S + 1) % 3>;          // kind of the next step's list, of the one after
@@ -472,7 +635,8 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             constexpr int FH_NN = KNN::value == 2 ? FH2 : FH01;
             const int cn = S == 2 ? c + 1 : c, cnn = S == 0 ? c : c + 1;  // their chunks
             const int t = 3 * c + S;
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // this step's data has landed, everybody's
+            if constexpr (FUSED) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // (+ the slab stores of the stem phases)
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // this step's data has landed, everybody's
             NB_SB;
             const h8* xb = xbuf + (S == 1 ? ((c + 1) & 1) : (c & 1)) * 4 * XPL + (S == 2 ? ROWPITCH : 0);
             const h8* wb = wbuf + (t & 1) * WSLOTS;
@@ -512,8 +676,25 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             NB_SB;
             group(std::integral_constant<int, FH_NN>{}, mf_fp8(al01, bl01), dma_nn);                        // corrections 0 + 1 | first half of the list after the next
             (void)no_mf;
+            if constexpr (FUSED && S != 0) {
+                if (c + 1 < NC) {
+                    const unsigned long long t0_ = p.tstamps ? __builtin_amdgcn_s_memrealtime() : 0;
+                    if constexpr (S == 1) stem_phase(K0{}, c + 1);       // E_c has been read: its buffer takes O_c+1
+                    else stem_phase(K1{}, c + 1);                        // O_c has been read: its buffer takes E_c+1
+                    if (p.tstamps) t_stem += __builtin_amdgcn_s_memrealtime() - t0_;
+                }
+            }
+            NB_SB;
         };
         using O0 = std::integral_constant<int, 0>; using O1 = std::integral_constant<int, 1>;
+        if constexpr (FUSED) {
+            nb_set_fp16_ovfl();
+            fused_prologue();
+            __syncthreads();
+            NB_TSTAMP(5);                              // (debug: the image strips and the stem's weight fragments are in LDS)
+            stem_phase(K0{}, 0); stem_phase(K1{}, 0);
+            NB_SB;
+        }
         if (p.tstamps) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH01) : "memory"); NB_TSTAMP(1); }      // (debug: when the first step could begin)
         step(K0{}, O0{}, O1{}, 0); step(K1{}, O1{}, O0{}, 0); step(K2{}, O0{}, O0{}, 0);
         for (int c = 1; c < NC; c += 2) {
@@ -534,6 +715,7 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
         }
         nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp8(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
+        if constexpr (FUSED) { if (p.tstamps && tid == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 6] = t_stem; }
 #undef NB_Q
 #undef NB_SB
     } else if constexpr (F8) {
@@ -802,21 +984,23 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     NB_TSTAMP(4);
 }
 
-template <int STRIDE, int LW, int OUT, bool F8 = false>
+template <int STRIDE, int LW, int OUT, bool F8 = false, bool FUSED = false>
 static int launch_enc_conv(EncConvParams p, int n, hipStream_t st) {
-    constexpr int WT = 1 << LW, TH = 8 * (32 / WT), PW = WT + 2, SLOTS = (F8 && STRIDE == 2) ? (TH + 1) * 2 * PW : STRIDE * TH * PW, XPL = ((SLOTS + 63) / 64) * 64;
-    constexpr size_t staging = (size_t)(2 * 4 * XPL + 2 * 12 * 128) * 16;
+    constexpr int WT = 1 << LW, TH = 8 * (32 / WT), PW = WT + 2, SLOTS = (F8 && STRIDE == 2) ? (TH + 1) * 2 * PW : STRIDE * TH * PW;
+    constexpr int XPL = FUSED ? SLOTS : ((SLOTS + 63) / 64) * 64;
+    constexpr size_t fused = FUSED ? (size_t)4 * (2 * WT + 8) * 52 + (size_t)4 * 2 * 2 * 64 * 16 : 0;      // image strips + stem weight fragments
+    constexpr size_t staging = (size_t)(2 * 4 * XPL + 2 * 12 * 128) * 16 + fused;
     constexpr size_t epi = OUT == 0 ? (size_t)128 * 256 * 4 : (LW == 5 ? 0 : (size_t)2 * 256 * (128 + 8) * 2);       // (32-wide hand-off tiles: no staging)
     constexpr size_t lds = staging > epi ? staging : epi;
-    static_assert(lds + 3 * 128 * 4 <= 160 * 1024, "LDS budget (dynamic staging + the hand-off epilogue's static tables)");
+    static_assert(lds + 3 * 128 * 4 + 64 * 4 <= 160 * 1024, "LDS budget (dynamic staging + the hand-off epilogue's static tables + the stem's bias)");
     p.tiles_x = p.wout / WT; p.tiles_y = p.hout / TH; p.slices = (p.c_out + 127) / 128;
     p.tstamps = (g_enc_tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= g_enc_tstamps_cap) ? g_enc_tstamps : nullptr;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (+ static tables: the sum must fit 160 KB)
+        (void)hipFuncSetAttribute((const void*)enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (+ static tables: the sum must fit 160 KB)
         attr_set = true;
     }
-    hipLaunchKernelGGL((enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8>), dim3(p.tiles_x * p.tiles_y * p.slices, n), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((enc_conv3x3_h3_kernel<STRIDE, LW, OUT, F8, FUSED>), dim3(p.tiles_x * p.tiles_y * p.slices, n), dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("enc_conv3x3_h3");
     return NB_OK;
 }
@@ -1000,6 +1184,7 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
     EncConvParams p;
     p.x = (const _Float16*)x_h2; p.wts = (const _Float16*)w_h3; p.bias = bias; p.y32 = y_f32; p.yh2 = (_Float16*)y_h2;
     p.zeros = nb_zero_page_ptr();
+    p.img = nullptr; p.stem_w = nullptr; p.stem_b = nullptr; p.preproc = 0;
     NB_REQUIRE(p.zeros, "enc_conv3x3_h3: could not allocate the zero page");
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 127) / 128 * 128;
     p.hin = h_in; p.win = w_in; p.hout = ho; p.wout = wo; p.slope = slope;
@@ -1083,6 +1268,31 @@ extern "C" int nb_enc_conv3x3_ex(const void* x, int c_in, const void* wts, const
                                  int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream) {
     return nb_enc_conv3x3_impl(x, c_in, wts, bias, y_f32, y_h2, oscale, oscale_stride, c8_total, cg0, out_fmt, n, h_in, w_in, c_out,
                                stride, slope, stream, in_fmt);
+}
+
+// Stem (1 -> 64, 7 x 7, reflect padding 3, LeakyReLU) + the first stride-2 stage (64 -> c_out, 3 x 3, reflect padding 1, LeakyReLU) in ONE
+// launch (enc_conv3x3_h3_kernel<.., FUSED>): what nb_enc_stem7x7_f32_h2_ex(out_fmt 1) followed by nb_enc_conv3x3_ex(in_fmt 1, stride 2) computes,
+// without the 64-channel full-resolution tensor between them.  x fp32 [n][1][h][w]; w50 / bias0: the stem's parameters as nb_enc_stem7x7 takes
+// them; wts1: the stage's weights in "f8" format (c_in = 64); y_h2: its output [n][c_out / 8][2][h / 2][w / 2][8] in format out_fmt
+// (0 = H2, 1 = f8).  Needs h %% 16 == 0, w %% 64 == 0, c_out %% 16 == 0.
+extern "C" int nb_enc_stem_conv3x3_f8(const float* x, const float* w50, const float* bias0, int preproc, const void* wts1, const float* bias1,
+                                      void* y_h2, int out_fmt, int n, int h, int w, int c_out, float slope, void* stream) {
+    NB_REQUIRE(x && w50 && bias0 && wts1 && bias1 && y_h2, "enc_stem_conv3x3_f8: null pointer");
+    NB_REQUIRE(out_fmt == 0 || out_fmt == 1, "enc_stem_conv3x3_f8: output format must be 0 (H2) or 1 (f8)");
+    NB_REQUIRE(n >= 1 && n <= 65535 && h >= 16 && w >= 64 && h % 16 == 0 && w % 64 == 0, "enc_stem_conv3x3_f8: needs h %% 16 == 0 and w %% 64 == 0 (got %dx%d)", h, w);
+    NB_REQUIRE(c_out >= 16 && c_out % 16 == 0, "enc_stem_conv3x3_f8: c_out %% 16 == 0 (got %d)", c_out);
+    NB_REQUIRE(preproc >= 0 && preproc <= 2, "Unknown preprocessing type %d", preproc);
+    NB_REQUIRE(slope >= 0.f && slope <= 1.f, "enc_stem_conv3x3_f8: leaky-ReLU slope must lie in [0, 1] (got %g)", slope);
+    NB_REQUIRE(((uintptr_t)wts1 | (uintptr_t)y_h2) % 16 == 0, "enc_stem_conv3x3_f8: pointers must be 16-byte aligned");
+    EncConvParams p;
+    p.x = nullptr; p.wts = (const _Float16*)wts1; p.bias = bias1; p.y32 = nullptr; p.yh2 = (_Float16*)y_h2;
+    p.zeros = nb_zero_page_ptr();
+    NB_REQUIRE(p.zeros, "enc_stem_conv3x3_f8: could not allocate the zero page");
+    p.c8 = 8; p.nchunks = 4; p.c_out = c_out; p.co_ld = (c_out + 127) / 128 * 128;
+    p.hin = h; p.win = w; p.hout = h / 2; p.wout = w / 2; p.slope = slope;
+    p.shift = 0; p.oscale = nullptr; p.oscale_stride = 0; p.c8_total = c_out / 8; p.cg0 = 0; p.out_f8 = out_fmt;
+    p.img = x; p.stem_w = w50; p.stem_b = bias0; p.preproc = preproc;
+    return launch_enc_conv<2, 5, 1, true, true>(p, n, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
 import numpy as np
 import torch
 
@@ -101,13 +102,15 @@ def pack_enc_weight_f8(w: np.ndarray) -> np.ndarray:
 
 class HipGeometryEncoder:
     """``AutoEncoder.encode(geom, res=[0, 1])`` on the hand-written gfx950 kernels: 8 launches per batch
-    (stem, 3 stride-2 convs, 2 bottleneck convs, bilinear x2, decoder conv), BatchNorm folded on the host.
+    (stem, 3 stride-2 convs, 2 bottleneck convs, bilinear x2, decoder conv; 7 for f8 batches, whose stem is computed inside
+    the first stride-2 launch), BatchNorm folded on the host.
     Interface of the reference's ``AutoEncoder`` as the engine uses it (``encode``, ``feature_channels``,
     ``featuremap_resolution``).  Patch sizes: 32, 64 and multiples of 128 (``supports``)."""
 
     _PRE = {None: 0, "none": 0, "-11inverse": 1, "inverse": 2}
     arith = "f8"           # operand format between the layers for large batches ("h3": hi/lo f16 everywhere)
     f8_min_batch = 8       # below this the launches are under-filled and the H2-reading small-tile kernel takes over
+    fuse_stem = os.environ.get("NB_ENC_FUSE_STEM", "1") != "0"      # f8 batches: stem + first stride-2 stage in one launch
 
     def __init__(self, state_dict: Dict[str, np.ndarray], preproc_type=None, device="cuda"):
         from . import _lib
@@ -182,11 +185,21 @@ class HipGeometryEncoder:
             # layers with <= 32 output channels (256 -> 32, 32 -> 16) leave three quarters of the large tile's 128 c_out rows empty:
             # the library runs them on the 32 x 32 split-K tiles, which read hi/lo-f16 operands -- so their producers write H2
             narrow = lambda i: self.convs[i][3] <= 32 and self.convs[i][2] >= 32
-            a = f16(64, h)
-            check(lib.nb_enc_stem7x7_f32_h2_ex(P(x), P(self.stem[0]), P(self.stem[1]), P(a), fmt, n, h, w,
-                                               self._PRE[self.preproc_type], 0.01, st), "enc_stem")
-            r = h
-            for i in range(4):                               # three stride-2 stages + 256 -> 32
+            # stem + first stride-2 stage: ONE launch for f8 batches (the 64-channel full-resolution tensor between them -- the largest
+            # of the pass, written once and read once -- never exists); else the stem kernel and the general conv kernel
+            fused = bool(fmt and self.fuse_stem and h % 64 == 0)
+            if fused:
+                _, b, ci, co, stride, wf8 = self.convs[0]
+                a = f16(co, h // 2)
+                check(lib.nb_enc_stem_conv3x3_f8(P(x), P(self.stem[0]), P(self.stem[1]), self._PRE[self.preproc_type], P(wf8), P(b), P(a),
+                                                 0 if narrow(1) else fmt, n, h, w, co, 0.01, st), "enc_stem_conv")
+                r = h // 2
+            else:
+                a = f16(64, h)
+                check(lib.nb_enc_stem7x7_f32_h2_ex(P(x), P(self.stem[0]), P(self.stem[1]), P(a), fmt, n, h, w,
+                                                   self._PRE[self.preproc_type], 0.01, st), "enc_stem")
+                r = h
+            for i in range(1 if fused else 0, 4):            # three stride-2 stages + 256 -> 32
                 _, b, ci, co, stride, _ = self.convs[i]
                 r_out = r // stride
                 y = f16(co, r_out)

@@ -492,6 +492,16 @@ int nb_enc_conv3x3_ex(const void* x, int c_in, const void* wts, const float* bia
                       const float* oscale, int oscale_stride, int c8_total, int cg0, int in_fmt, int out_fmt,
                       int n, int h_in, int w_in, int c_out, int stride, float slope, void* stream);
 
+/* Stem + first stride-2 stage in ONE launch (simple_autoencoder.py:155-176: _SingleConvolution 1 -> 64, 7 x 7, followed by the first
+ * _Downsample stage 64 -> c_out, stride 2): the result of nb_enc_stem7x7_f32_h2_ex(out_fmt 1) followed by nb_enc_conv3x3_ex(in_fmt 1,
+ * stride 2) without the 64-channel full-resolution tensor between them -- each workgroup computes the stem outputs its tile needs on the
+ * matrix pipe, chunk by chunk, straight into LDS in operand format.  x fp32 [n,1,h,w] (h % 16 == 0, w % 64 == 0); w50 / bias0 / preproc
+ * as nb_enc_stem7x7_f32_h2; wts1: the stage's weights in "f8" format (c_in = 64), bias1 [c_out], c_out % 16 == 0; y_h2
+ * [n, c_out, h/2, w/2] in format out_fmt (0 = H2, 1 = f8).  Same split-f16 products; per stem output the summation order differs
+ * from the stem kernel's (results agree to fp32 rounding, not bit for bit). */
+int nb_enc_stem_conv3x3_f8(const float* x, const float* w50, const float* bias0, int preproc, const void* wts1, const float* bias1,
+                           void* y_h2, int out_fmt, int n, int h, int w, int c_out, float slope, void* stream);
+
 /* Stride-2 3x3 correlation WITHOUT padding on the same kernel -- the strided half of conv2d_resample's down-sampling branch
  * (conv2d_resample.py:96-113) and the input gradient of its up-sampling branch (:124-147), which cuDNN runs for the reference:
  * x H2 [n][c8][2][2ho+1][2wo+1][8], weights as above, y fp32 [n][c_out][ho][wo] = oscale[n][co] * (bias[co] + sum_{ci,a,b}

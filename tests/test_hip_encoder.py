@@ -303,3 +303,42 @@ def test_encoder_f8_matches_oracle(res, n, pre):
         assert float((a.cpu() - b).abs().max()) <= 5e-4, float((a.cpu() - b).abs().max())
         assert float((c.cpu() - b).abs().max()) <= TOL
         assert not torch.equal(a, c)                              # (the f8 path really ran)
+
+
+@pytest.mark.parametrize("n,h,w,co,pre,out_fmt", [(2, 64, 64, 128, 0, 1), (1, 32, 128, 128, 1, 1), (2, 16, 64, 48, 2, 0), (1, 128, 192, 144, 0, 1),
+                                                  (3, 256, 256, 128, 0, 1)])
+def test_enc_fused_stem_conv(n, h, w, co, pre, out_fmt):
+    """Stem + first stride-2 stage in one launch (nb_enc_stem_conv3x3_f8: the stem's outputs are computed per 16-channel chunk on the
+    matrix pipe, straight into the slab buffers) against torch fp64 of both layers and against the two-kernel path it replaces
+    (nb_enc_stem7x7_f32_h2_ex -> nb_enc_conv3x3_ex): one tile and many, the first / last tile rows and columns (both reflect
+    paddings), ragged c_out slices, every preprocessing type, both output formats."""
+    rs = np.random.RandomState(n + h + w + co)
+    x = torch.from_numpy(rs.rand(n, 1, h, w).astype(np.float32))
+    w0 = (rs.randn(64, 1, 7, 7) / 7).astype(np.float32)
+    b0 = rs.randn(64).astype(np.float32)
+    w1 = (rs.randn(co, 64, 3, 3) / np.sqrt(9 * 64)).astype(np.float32)
+    b1 = rs.randn(co).astype(np.float32)
+    xp = x.double()
+    xp = (1 - xp) * 2 - 1 if pre == 1 else (1 - xp if pre == 2 else xp)
+    F = torch.nn.functional
+    s = F.leaky_relu(F.conv2d(F.pad(xp, (3, 3, 3, 3), mode="reflect"), torch.from_numpy(w0).double(), torch.from_numpy(b0).double()), 0.01)
+    ref = F.leaky_relu(F.conv2d(F.pad(s, (1, 1, 1, 1), mode="reflect"), torch.from_numpy(w1).double(), torch.from_numpy(b1).double(), stride=2), 0.01)
+    w50 = np.zeros([64, 50], np.float32)
+    w50[:, :49] = w0.reshape(64, 49)
+    xd, w50d, b0d = x.cuda(), torch.from_numpy(w50).cuda(), torch.from_numpy(b0).cuda()
+    w1d, b1d = torch.from_numpy(encmod.pack_enc_weight_f8(w1)).cuda(), torch.from_numpy(b1).cuda()
+    S = torch.cuda.current_stream().cuda_stream
+    lib = _lib.lib()
+    y = torch.zeros([n, co // 8, 2, h // 2, w // 2, 8], dtype=torch.float16, device="cuda")
+    _lib.check(lib.nb_enc_stem_conv3x3_f8(_p(xd), _p(w50d), _p(b0d), pre, _p(w1d), _p(b1d), _p(y), out_fmt, n, h, w, co, 0.01, S), "fused")
+    dec = (lambda t: _f8_decode(t, co)) if out_fmt else _h2_to_nchw
+    out = dec(y).cpu().double()
+    tol = 4e-5 + 2e-5 * float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= tol, (float((out - ref).abs().max()), tol)
+    # the two-kernel path
+    a = torch.empty([n, 8, 2, h, w, 8], dtype=torch.float16, device="cuda")
+    y2 = torch.zeros_like(y)
+    _lib.check(lib.nb_enc_stem7x7_f32_h2_ex(_p(xd), _p(w50d), _p(b0d), _p(a), 1, n, h, w, pre, 0.01, S), "stem")
+    _lib.check(lib.nb_enc_conv3x3_ex(_p(a), 64, _p(w1d), _p(b1d), None, _p(y2), None, 0, co // 8, 0, 1, out_fmt, n, h, w, co, 2, 0.01, S), "conv")
+    d = float((dec(y2).cpu().double() - out).abs().max())
+    assert d <= 2 * tol, (d, tol)                                 # (each within tol of the truth; not bit-identical: another summation order in the stem)
