@@ -459,7 +459,8 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             else { NB_Q(b[i - MB], q, xb[b_base + XPL + (i - MB) * RPB * ROWPITCH + ko]); }
         };
         // a group of NM MFMAs (tile k = (k / NBW, k % NBW)) with NFILL fillers dealt evenly into the gaps behind them
-        auto group = [&](auto nfill_, auto&& mf, auto&& ff) {
+        // (sf: what else rides in gap k of the group -- the fused stem's operations, see stem_op)
+        auto group = [&](auto nfill_, auto&& mf, auto&& ff, auto&& sf) {
             constexpr int NFILL = decltype(nfill_)::value;
             nb_static_for<0, NM>([&](auto k_) {
                 constexpr int k = decltype(k_)::value;
@@ -469,6 +470,8 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                     constexpr int i = decltype(i_)::value;
                     if constexpr (i * NM / (NFILL > 0 ? NFILL : 1) == k) ff(i_);
                 });
+                NB_SB;
+                sf(k_);
                 NB_SB;
             });
         };
@@ -534,26 +537,29 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 stemw[((chunk * 2 + s_) * 2 + 1) * 64 + lane] = lo8;
             }
         };
-        // one slab of chunk c: KIND 0 = the odd slab O_c (image rows 2 (y0 + r) - 1, r = 0 .. TH) into buffer c & 1, KIND 1 = the even slab E_c
-        // (rows 2 (y0 + r), r < TH) into the other.  Tiles (16 slab positions) go round-robin over the waves; a wave's tiles run as a three-stage
-        // pipeline -- fragment reads of tile k + 2, matrix products of tile k + 1, conversion + stores of tile k -- in one basic block.
-        [[maybe_unused]] auto stem_phase = [&](auto kind_, int c) {
-            constexpr int KIND = decltype(kind_)::value;
+        // One slab of chunk C: KIND 0 = the odd slab O_C (image rows 2 (y0 + r) - 1, r = 0 .. TH) into buffer C & 1, KIND 1 = the even slab E_C (rows
+        // 2 (y0 + r), r < TH) into the other.  Tiles (16 slab positions) go round-robin over the waves; a wave's five tiles are a pipeline of
+        // NSOPS = 15 operations on registers that live across the steps -- L(k): the fragment reads of tile k (+ the chunk's weight fragments
+        // before the first); M(k): its six products; S(k): bias (the accumulator's initial value), LeakyReLU, conversion, three LDS stores --
+        // in the order  L0 M0 L1 | S0 M1 L2 | S1 M2 L3 | S2 M3 L4 | S3 M4 S4  (one fragment buffer, one accumulator pair).  The chunk-0 slabs run
+        // them back to back in the prologue; the others are dealt into the gaps behind the matrix instructions of the steps (see step()).
+        constexpr int NSOPS = 15;
+        [[maybe_unused]] h8 st_wh[2], st_wl[2], st_fh[2], st_fl[2];
+        [[maybe_unused]] f32x4 st_a0, st_a1, st_bias;
+        [[maybe_unused]] auto stem_op = [&](auto kind_, auto c_, auto j_) {
+            constexpr int KIND = decltype(kind_)::value, C = decltype(c_)::value, J = decltype(j_)::value;
             constexpr int NR = KIND == 0 ? TH + 1 : TH, NBLKS = 4 * NR + 1, NIT = (NBLKS + NW - 1) / NW;
-            static_assert((NIT - 1) * NW <= 4 * NR, "only a wave's last tile can be the extra one (the 33rd odd column of all rows) or missing");
+            static_assert(NIT == 5 && (NIT - 1) * NW <= 4 * NR, "five tiles per wave; only the last can be the extra one (the 33rd odd column of all rows) or missing");
+            // operation J: type (0 = L, 1 = M, 2 = S) and tile
+            constexpr int TYPE = J == 14 ? 2 : (J < 3 ? (J == 1 ? 1 : 0) : ((J - 3) % 3 == 0 ? 2 : ((J - 3) % 3 == 1 ? 1 : 0)));
+            constexpr int K = J == 14 ? 4 : (J < 3 ? (J == 2 ? 1 : 0) : (TYPE == 2 ? (J - 3) / 3 : (TYPE == 1 ? (J - 3) / 3 + 1 : (J - 3) / 3 + 2)));
             typedef int i32x4a __attribute__((ext_vector_type(4), aligned(4)));
             const int l15 = lane & 15, kg = lane >> 4;
-            h8* sb = xbuf + (KIND == 0 ? (c & 1) : ((c + 1) & 1)) * 4 * XPL;
-            h8 wh[2], wl[2];
-#pragma unroll
-            for (int s_ = 0; s_ < 2; ++s_) { wh[s_] = stemw[((c * 2 + s_) * 2 + 0) * 64 + lane]; wl[s_] = stemw[((c * 2 + s_) * 2 + 1) * 64 + lane]; }
-            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(s_bias0 + 16 * c + 4 * kg);
-            const unsigned char* sbase = strips + (KIND * 2 * SCOLS) * SPITCH;      // start rows: even (odd slab) | odd (even slab)
-            // tile k of this wave: column parity, column and row of the lane's position, whether the lane stores
-            auto geom = [&](auto k_, int& par, int& cl, int& rl, bool& ok) {
-                constexpr int k = decltype(k_)::value;
-                const int blk = wv + NW * k;
-                if constexpr (k < NIT - 1) {
+            // tile K of this wave: column parity, column and row of the lane's position, whether the lane stores
+            int par, cl, rl; bool ok;
+            {
+                const int blk = wv + NW * K;
+                if constexpr (K < NIT - 1) {
                     par = (blk >> 1) & 1; cl = 16 * (blk & 1) + l15; rl = blk >> 2; ok = true;
                 } else {
                     const bool sp = blk >= 4 * NR;                                  // the extra tile (or none: nothing is stored)
@@ -562,13 +568,14 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                     rl = sp ? (l15 < NR ? l15 : NR - 1) : (blk >> 2);
                     ok = blk < NBLKS && (!sp || l15 < NR);
                 }
-            };
-            h8 fh[2], fl[2];
-            f32x4 ac0[2], ac1[2];
-            auto load = [&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-                int par, cl, rl; bool ok;
-                geom(k_, par, cl, rl, ok);
+            }
+            if constexpr (J == 0) {
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) { st_wh[s_] = stemw[((C * 2 + s_) * 2 + 0) * 64 + lane]; st_wl[s_] = stemw[((C * 2 + s_) * 2 + 1) * 64 + lane]; }
+                st_bias = *reinterpret_cast<const f32x4*>(s_bias0 + 16 * C + 4 * kg);
+            }
+            if constexpr (TYPE == 0) {
+                const unsigned char* sbase = strips + (KIND * 2 * SCOLS) * SPITCH;  // start rows: even (odd slab) | odd (even slab)
                 // the conv's own reflect padding: image row -1 = row 1 (odd slab of the first tile row), image column -1 = column 1
                 const int re = (KIND == 0 && y0 == 0 && rl == 0) ? 1 : rl;
                 int col0 = 2 * cl + (par ? 0 : 1);
@@ -576,26 +583,21 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 const unsigned char* bp = sbase + (col0 + kg) * SPITCH + 4 * re;
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
-                    fh[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH));
-                    fl[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH + SCOLS * SPITCH));
+                    st_fh[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH));
+                    st_fl[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH + SCOLS * SPITCH));
                 }
-            };
-            auto mma = [&](auto k_) {
-                constexpr int b_ = decltype(k_)::value & 1;
-                f32x4 a0 = bias4, a1 = {0.f, 0.f, 0.f, 0.f};
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], fl[0], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], fh[0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0], fh[0], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], fh[1], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], fl[1], a1, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1], fh[1], a1, 0, 0, 0);
-                ac0[b_] = a0; ac1[b_] = a1;
-            };
-            auto store = [&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-                int par, cl, rl; bool ok;
-                geom(k_, par, cl, rl, ok);
-                f32x4 t = ac0[k & 1] + ac1[k & 1];
+            } else if constexpr (TYPE == 1) {
+                f32x4 a0 = st_bias, a1 = {0.f, 0.f, 0.f, 0.f};
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[0], st_fl[0], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[0], st_fh[0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wl[0], st_fh[0], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[1], st_fh[1], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[1], st_fl[1], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wl[1], st_fh[1], a1, 0, 0, 0);
+                st_a0 = a0; st_a1 = a1;
+            } else {
+                h8* sb = xbuf + (KIND == 0 ? (C & 1) : ((C + 1) & 1)) * 4 * XPL;
+                f32x4 t = st_a0 + st_a1;
                 const f32x4 ta = t * p.slope;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) t[i] = fmaxf(t[i], ta[i]);               // LeakyReLU, 0 <= slope <= 1
@@ -611,31 +613,51 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                     *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sb + 1 * XPL + slot) + 4 * kg) = lo_xl;
                     *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sb + 3 * XPL + slot) + 4 * kg) = lo_w;
                 }
-            };
-            // (fences: left alone the scheduler puts every tile's reads right in front of its products again.  ONE fragment buffer: the reads of
-            //  tile t follow the products of tile t - 1 and land under the conversion of tile t - 2)
-            load(std::integral_constant<int, 0>{}); NB_SB;
-            nb_static_for<1, NIT + 2>([&](auto t_) {
-                constexpr int t = decltype(t_)::value;
-                if constexpr (t <= NIT) { mma(std::integral_constant<int, t - 1>{}); NB_SB; }
-                if constexpr (t < NIT) { load(t_); NB_SB; }
-                if constexpr (t >= 2) { store(std::integral_constant<int, t - 2>{}); NB_SB; }
-            });
+            }
+        };
+        // a whole slab, back to back (fences: left alone the scheduler puts every tile's reads right in front of its products)
+        [[maybe_unused]] auto stem_phase = [&](auto kind_, auto c_) {
+            nb_static_for<0, NSOPS>([&](auto j_) { stem_op(kind_, c_, j_); NB_SB; });
         };
         using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
         // step (c, S); ODD = parity of t = 3 c + S (selects the half of the tap-2 tuple).  Per accumulator tile the products arrive in the
         // order of the per-step loop below: tap 2 of step t-1, on even t the tap-2 corrections of t-2 and t-1, tap 0, tap 1, corrections
         // of taps 0 + 1.  Reads and pieces ride behind the MFMAs: a step opens with matrix work on registers it already holds.
-        [[maybe_unused]] unsigned long long t_stem = 0;        // (debug: wave 0's time in the stem phases behind the steps, slot 6)
-        auto step = [&](auto s_, auto odd_, auto first_, int c) {
-            constexpr int S = decltype(s_)::value, ODD = decltype(odd_)::value, FIRST = decltype(first_)::value;
+        // FUSED: CC = the chunk as a constant (else -1).  The stem's slabs of the NEXT chunk ride in the gaps of the steps: O_c+1 -- into the buffer
+        // E_c leaves at the mid-step barrier of (c, 1) -- operations 0-2 behind the last group of step (c, 1), 3-14 in the groups of step (c, 2) before
+        // its barrier; E_c+1 -- into the buffer O_c leaves at the barrier of (c, 2) -- operations 0-2 behind the last group of (c, 2), 3-14 in step
+        // (c + 1, 0).  Each is complete (stores counted out at the top barrier) a step before its first reader; E_0 runs whole in step (0, 0).
+        auto no_sf = [](auto) {};
+        auto step = [&](auto s_, auto odd_, auto first_, int c, auto cc_) {
+            constexpr int S = decltype(s_)::value, ODD = decltype(odd_)::value, FIRST = decltype(first_)::value, CC = decltype(cc_)::value;
+            static_assert(!FUSED || CC >= 0, "the fused loop is unrolled over its four chunks");
+            constexpr bool PRE = FUSED && ((S == 2 && CC + 1 < 4) || S == 0);                  // operations 3-14 of O_CC+1 (S = 2) / E_CC (S = 0; all 15 of E_0)
+            constexpr int PRE0 = (S == 0 && CC == 0) ? 0 : 3;
+            constexpr bool POST = FUSED && CC + 1 < 4 && S != 0;                               // operations 0-2 of O_CC+1 (S = 1) / E_CC+1 (S = 2)
+            using PRE_K = std::integral_constant<int, S == 2 ? 0 : 1>; using PRE_C = std::integral_constant<int, S == 2 ? CC + 1 : CC>;
+            using POST_K = std::integral_constant<int, S == 1 ? 0 : 1>; using POST_C = std::integral_constant<int, CC + 1>;
+            constexpr int G3B = FIRST ? 0 : (ODD ? 4 : 8), NGPRE = G3B + 8;                    // gaps before the mid-step barrier (four per group)
+            auto sf_pre = [&](auto base_) {
+                return [&](auto k_) {
+                    if constexpr (PRE) {
+                        constexpr int g = decltype(base_)::value + decltype(k_)::value;
+                        nb_static_for<0, NSOPS - PRE0>([&](auto q_) {
+                            constexpr int q = decltype(q_)::value;
+                            if constexpr (q * NGPRE / (NSOPS - PRE0) == g) { stem_op(PRE_K{}, PRE_C{}, std::integral_constant<int, PRE0 + q>{}); NB_SB; }
+                        });
+                    }
+                };
+            };
+            auto sf_post = [&](auto k_) {
+                if constexpr (POST && decltype(k_)::value < 3) { stem_op(POST_K{}, POST_C{}, k_); NB_SB; }
+            };
             using KN = std::integral_constant<int, (S + 1) % 3>;          // kind of the next step's list, of the one after
             using KNN = std::integral_constant<int, (S + 2) % 3>;
             constexpr int LEN_N = KN::value == 2 ? NWPW : NPC, FH_N = KN::value == 2 ? FH2 : FH01;
             constexpr int FH_NN = KNN::value == 2 ? FH2 : FH01;
             const int cn = S == 2 ? c + 1 : c, cnn = S == 0 ? c : c + 1;  // their chunks
             const int t = 3 * c + S;
-            if constexpr (FUSED) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // (+ the slab stores of the stem phases)
+            if constexpr (FUSED) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // (+ the slab stores of the stem's operations)
             else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // this step's data has landed, everybody's
             NB_SB;
             const h8* xb = xbuf + (S == 1 ? ((c + 1) & 1) : (c & 1)) * 4 * XPL + (S == 2 ? ROWPITCH : 0);
@@ -655,51 +677,52 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             if constexpr (FIRST) {
                 nb_static_for<0, 2 * NF>(rd_a); nb_static_for<0, 2 * NF>(rd_b); NB_SB;
             } else {
-                group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah2, bh2), rd_a);                       // tap 2 of step t-1
-                if constexpr (!ODD) group(std::integral_constant<int, 2 * NF>{}, mf_fp8(al2, bl2), rd_b);   // tap-2 corrections of t-2, t-1
+                group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah2, bh2), rd_a, sf_pre(std::integral_constant<int, 0>{}));                       // tap 2 of step t-1
+                if constexpr (!ODD) group(std::integral_constant<int, 2 * NF>{}, mf_fp8(al2, bl2), rd_b, sf_pre(std::integral_constant<int, 4>{}));   // tap-2 corrections of t-2, t-1
             }
             if constexpr (!FIRST && ODD) {
                 group(std::integral_constant<int, 2 * NF + LEN_N - FH_N>{}, mf_f16(ah0, bh0), [&](auto i_) {  // tap 0
                     constexpr int i = decltype(i_)::value;
                     if constexpr (i < 2 * NF) rd_b(i_); else dma_n(std::integral_constant<int, i - 2 * NF>{});
-                });
+                }, sf_pre(std::integral_constant<int, G3B>{}));
             } else {
-                group(std::integral_constant<int, LEN_N - FH_N>{}, mf_f16(ah0, bh0), dma_n);                // tap 0 | second half of the next list
+                group(std::integral_constant<int, LEN_N - FH_N>{}, mf_f16(ah0, bh0), dma_n, sf_pre(std::integral_constant<int, G3B>{}));                // tap 0 | second half of the next list
             }
             group(std::integral_constant<int, 2 * NF>{}, mf_f16(ah1, bh1), [&](auto i_) {                   // tap 1 | this step's tap-2 operands
                 constexpr int i = decltype(i_)::value;
                 if constexpr (i < NF) rd_hi(i_, ah2, bh2, wb, xb, T2{});
                 else rd_lo(std::integral_constant<int, i - NF>{}, std::integral_constant<int, ODD>{}, al2, bl2, wb, xb, T2{});
-            });
+            }, sf_pre(std::integral_constant<int, G3B + 4>{}));
             // the step's last fragment reads are in registers for every wave: the buffers it was the last reader of take new data
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             NB_SB;
-            group(std::integral_constant<int, FH_NN>{}, mf_fp8(al01, bl01), dma_nn);                        // corrections 0 + 1 | first half of the list after the next
-            (void)no_mf;
-            if constexpr (FUSED && S != 0) {
-                if (c + 1 < NC) {
-                    const unsigned long long t0_ = p.tstamps ? __builtin_amdgcn_s_memrealtime() : 0;
-                    if constexpr (S == 1) stem_phase(K0{}, c + 1);       // E_c has been read: its buffer takes O_c+1
-                    else stem_phase(K1{}, c + 1);                        // O_c has been read: its buffer takes E_c+1
-                    if (p.tstamps) t_stem += __builtin_amdgcn_s_memrealtime() - t0_;
-                }
-            }
-            NB_SB;
+            group(std::integral_constant<int, FH_NN>{}, mf_fp8(al01, bl01), dma_nn, sf_post);              // corrections 0 + 1 | first half of the list after the next
+            (void)no_mf; (void)no_sf;
         };
         using O0 = std::integral_constant<int, 0>; using O1 = std::integral_constant<int, 1>;
+        using CN = std::integral_constant<int, -1>;
         if constexpr (FUSED) {
             nb_set_fp16_ovfl();
             fused_prologue();
             __syncthreads();
             NB_TSTAMP(5);                              // (debug: the image strips and the stem's weight fragments are in LDS)
-            stem_phase(K0{}, 0); stem_phase(K1{}, 0);
+            stem_phase(K0{}, std::integral_constant<int, 0>{});          // O_0; E_0 rides in step (0, 0), whose buffers it does not touch
             NB_SB;
         }
         if (p.tstamps) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH01) : "memory"); NB_TSTAMP(1); }      // (debug: when the first step could begin)
-        step(K0{}, O0{}, O1{}, 0); step(K1{}, O1{}, O0{}, 0); step(K2{}, O0{}, O0{}, 0);
+        if constexpr (FUSED) {
+            using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
+            using C3 = std::integral_constant<int, 3>;
+            step(K0{}, O0{}, O1{}, 0, C0{}); step(K1{}, O1{}, O0{}, 0, C0{}); step(K2{}, O0{}, O0{}, 0, C0{});
+            step(K0{}, O1{}, O0{}, 1, C1{}); step(K1{}, O0{}, O0{}, 1, C1{}); step(K2{}, O1{}, O0{}, 1, C1{});
+            step(K0{}, O0{}, O0{}, 2, C2{}); step(K1{}, O1{}, O0{}, 2, C2{}); step(K2{}, O0{}, O0{}, 2, C2{});
+            step(K0{}, O1{}, O0{}, 3, C3{}); step(K1{}, O0{}, O0{}, 3, C3{}); step(K2{}, O1{}, O0{}, 3, C3{});
+        } else {
+        step(K0{}, O0{}, O1{}, 0, CN{}); step(K1{}, O1{}, O0{}, 0, CN{}); step(K2{}, O0{}, O0{}, 0, CN{});
         for (int c = 1; c < NC; c += 2) {
-            step(K0{}, O1{}, O0{}, c); step(K1{}, O0{}, O0{}, c); step(K2{}, O1{}, O0{}, c);
-            if (c + 1 < NC) { step(K0{}, O0{}, O0{}, c + 1); step(K1{}, O1{}, O0{}, c + 1); step(K2{}, O0{}, O0{}, c + 1); }
+            step(K0{}, O1{}, O0{}, c, CN{}); step(K1{}, O0{}, O0{}, c, CN{}); step(K2{}, O1{}, O0{}, c, CN{});
+            if (c + 1 < NC) { step(K0{}, O0{}, O0{}, c + 1, CN{}); step(K1{}, O1{}, O0{}, c + 1, CN{}); step(K2{}, O0{}, O0{}, c + 1, CN{}); }
+        }
         }
         NB_SB;
         // the last step's tap 2 and the last tuple of tap-2 corrections (an odd number of steps: it holds one tap only)
@@ -715,7 +738,6 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 for (int r = 4; r < 8; ++r) bl2[nb][r] = 0;
         }
         nb_static_for<0, NM>([&](auto k_) { constexpr int k = decltype(k_)::value; mf_fp8(al2, bl2)(std::integral_constant<int, k / NBW>{}, std::integral_constant<int, k % NBW>{}); NB_SB; });
-        if constexpr (FUSED) { if (p.tstamps && tid == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 6] = t_stem; }
 #undef NB_Q
 #undef NB_SB
     } else if constexpr (F8) {

@@ -44,8 +44,8 @@ for (ci, co, r, stride) in [(64, 128, 256, 2), (128, 256, 128, 2), (256, 256, 64
         print(f"    prologue + k-loop {(us[:, 2] - us[:, 0]).mean():6.2f} us")
     print(f"    epilogue to LDS {(us[:, 3] - us[:, 2]).mean():6.2f} us   stores {(us[:, 4] - us[:, 3]).mean():6.2f} us")
 
-# the fused stem + first stride-2 stage (nb_enc_stem_conv3x3_f8): slot 5 = strips built, slot 1 = chunk 0's slabs computed, slot 6 = ticks in the
-# stem phases behind the steps (wave 0)
+# the fused stem + first stride-2 stage (nb_enc_stem_conv3x3_f8): slot 5 = strips built, slot 1 = chunk 0's slabs computed (the other chunks'
+# slabs ride in the gaps of the steps)
 r, co = 256, 128
 img = torch.rand(n, 1, r, r, device=dev)
 w50 = torch.randn(64, 50, device=dev) * 0.1
@@ -72,5 +72,5 @@ us = (t - t[:, 0].min()) / 100.0
 print(f"fused stem + conv 64->{co} in {r}^2 stride 2 n={n}: {t.shape[0]} workgroups, kernel {plain * 1e3:.1f} us, span {us[:, 4].max():.1f} us, "
       f"workgroup mean {(us[:, 4] - us[:, 0]).mean():.1f} us; steps 12")
 print(f"    strips + stem weights {(us[:, 5] - us[:, 0]).mean():6.2f} us   chunk 0's slabs {(us[:, 1] - us[:, 5]).mean():6.2f} us   "
-      f"k-loop {(us[:, 2] - us[:, 1]).mean():6.2f} us, of it stem phases {t[:, 6].mean() / 100.0:6.2f} us (6 of them)")
+      f"k-loop {(us[:, 2] - us[:, 1]).mean():6.2f} us = {(us[:, 2] - us[:, 1]).mean() / 12:.3f} us per step (with the stem of the next chunk in its gaps)")
 print(f"    epilogue {(us[:, 3] - us[:, 2]).mean():6.2f} us")
