@@ -253,9 +253,9 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_enc[];
     h8* xbuf = reinterpret_cast<h8*>(smem_enc);         // [2][4][XPL]
     h8* wbuf = xbuf + 2 * 4 * XPL;                      // [2][WSLOTS]
-    // FUSED: the image window as column-major f16 strips [start row parity][hi/lo][column][26 halves] and the stem's weight fragments
-    constexpr int SCOLS = 2 * WT + 8, SPITCH = 52, STRIP_BYTES = 4 * SCOLS * SPITCH;
-    static_assert(!FUSED || (STRIP_BYTES % 16 == 0 && 2 * TH + 7 + 1 <= SPITCH / 2), "strip geometry");
+    // FUSED: the image window as column-major f16 strips [start row parity][column][hi | lo: 26 halves each] and the stem's weight fragments
+    constexpr int SCOLS = 2 * WT + 8, SLO = 52, SPITCH = 108, STRIP_BYTES = 2 * SCOLS * SPITCH;     // column = 26 halves hi | 26 halves lo | 4 bytes: 27 dwords
+    static_assert(!FUSED || (STRIP_BYTES % 16 == 0 && 2 * TH + 7 + 1 <= SLO / 2), "strip geometry");
     [[maybe_unused]] unsigned char* strips = reinterpret_cast<unsigned char*>(wbuf + 2 * WSLOTS);
     [[maybe_unused]] h8* stemw = reinterpret_cast<h8*>(strips + STRIP_BYTES);           // [chunk 4][K step 2][hi/lo][lane]
     NB_TSTAMP(0);
@@ -514,11 +514,11 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                         else if (p.preproc == 2) v = 1.f - v;                   // 'inverse'
                     }
                     const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-                    *reinterpret_cast<_Float16*>(strips + (0 * SCOLS + w) * SPITCH + 2 * j) = hi;
-                    *reinterpret_cast<_Float16*>(strips + (1 * SCOLS + w) * SPITCH + 2 * j) = lo;
+                    *reinterpret_cast<_Float16*>(strips + w * SPITCH + 2 * j) = hi;
+                    *reinterpret_cast<_Float16*>(strips + w * SPITCH + SLO + 2 * j) = lo;
                     if (j >= 1) {
-                        *reinterpret_cast<_Float16*>(strips + (2 * SCOLS + w) * SPITCH + 2 * (j - 1)) = hi;
-                        *reinterpret_cast<_Float16*>(strips + (3 * SCOLS + w) * SPITCH + 2 * (j - 1)) = lo;
+                        *reinterpret_cast<_Float16*>(strips + (SCOLS + w) * SPITCH + 2 * (j - 1)) = hi;
+                        *reinterpret_cast<_Float16*>(strips + (SCOLS + w) * SPITCH + SLO + 2 * (j - 1)) = lo;
                     }
                 }
             }
@@ -541,63 +541,97 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
         // 2 (y0 + r), r < TH) into the other.  Tiles (16 slab positions) go round-robin over the waves; a wave's five tiles are a pipeline of
         // NSOPS = 15 operations on registers that live across the steps -- L(k): the fragment reads of tile k (+ the chunk's weight fragments
         // before the first); M(k): its six products; S(k): bias (the accumulator's initial value), LeakyReLU, conversion, three LDS stores --
-        // in the order  L0 M0 L1 | S0 M1 L2 | S1 M2 L3 | S2 M3 L4 | S3 M4 S4  (one fragment buffer, one accumulator pair).  The chunk-0 slabs run
+        // in the order  L0 L1 M0 | L2 M1 S0 | L3 M2 S1 | L4 M3 S2 | M4 S3 S4  (two fragment buffers, two accumulators: a tile's reads are two or
+        // three operations ahead of its products, its conversion two or three behind them -- an operation that waits stalls the wave's K loop).  The chunk-0 slabs run
         // them back to back in the prologue; the others are dealt into the gaps behind the matrix instructions of the steps (see step()).
         constexpr int NSOPS = 15;
-        [[maybe_unused]] h8 st_wh[2], st_wl[2], st_fh[2], st_fl[2];
-        [[maybe_unused]] f32x4 st_a0, st_a1, st_bias;
+        [[maybe_unused]] h8 st_wh[2], st_wl[2];                          // the chunk's weight fragments of the two K steps
+        [[maybe_unused]] h8 st_fh[2][2], st_fl[2][2];                    // image fragments (hi, lo) [tile & 1][K step]
+        [[maybe_unused]] f32x4 st_a[2], st_bias;
+        // a wave's tiles 0-3 are rows r0 + 2 k of ONE (column parity, half row): their addresses are those of tile 0 + constants
+        [[maybe_unused]] const unsigned char* st_bp = nullptr;
+        [[maybe_unused]] unsigned char* st_hi = nullptr;
+        [[maybe_unused]] unsigned char* st_lo = nullptr;
         [[maybe_unused]] auto stem_op = [&](auto kind_, auto c_, auto j_) {
             constexpr int KIND = decltype(kind_)::value, C = decltype(c_)::value, J = decltype(j_)::value;
             constexpr int NR = KIND == 0 ? TH + 1 : TH, NBLKS = 4 * NR + 1, NIT = (NBLKS + NW - 1) / NW;
             static_assert(NIT == 5 && (NIT - 1) * NW <= 4 * NR, "five tiles per wave; only the last can be the extra one (the 33rd odd column of all rows) or missing");
-            // operation J: type (0 = L, 1 = M, 2 = S) and tile
-            constexpr int TYPE = J == 14 ? 2 : (J < 3 ? (J == 1 ? 1 : 0) : ((J - 3) % 3 == 0 ? 2 : ((J - 3) % 3 == 1 ? 1 : 0)));
-            constexpr int K = J == 14 ? 4 : (J < 3 ? (J == 2 ? 1 : 0) : (TYPE == 2 ? (J - 3) / 3 : (TYPE == 1 ? (J - 3) / 3 + 1 : (J - 3) / 3 + 2)));
+            // operation J: type (0 = L, 1 = M, 2 = S) and tile:  L0 L1 M0 | L2 M1 S0 | L3 M2 S1 | L4 M3 S2 | M4 S3 S4
+            constexpr int TYPES[NSOPS] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2, 1, 2, 2}, TILES[NSOPS] = {0, 1, 0, 2, 1, 0, 3, 2, 1, 4, 3, 2, 4, 3, 4};
+            constexpr int TYPE = TYPES[J], K = TILES[J];
             typedef int i32x4a __attribute__((ext_vector_type(4), aligned(4)));
             const int l15 = lane & 15, kg = lane >> 4;
-            // tile K of this wave: column parity, column and row of the lane's position, whether the lane stores
-            int par, cl, rl; bool ok;
-            {
-                const int blk = wv + NW * K;
-                if constexpr (K < NIT - 1) {
-                    par = (blk >> 1) & 1; cl = 16 * (blk & 1) + l15; rl = blk >> 2; ok = true;
-                } else {
-                    const bool sp = blk >= 4 * NR;                                  // the extra tile (or none: nothing is stored)
-                    par = sp ? 1 : (blk >> 1) & 1;
-                    cl = sp ? WT : 16 * (blk & 1) + l15;
-                    rl = sp ? (l15 < NR ? l15 : NR - 1) : (blk >> 2);
-                    ok = blk < NBLKS && (!sp || l15 < NR);
-                }
-            }
+            h8* sb = xbuf + (KIND == 0 ? (C & 1) : ((C + 1) & 1)) * 4 * XPL;
+            const unsigned char* sbase = strips + (KIND * SCOLS) * SPITCH;          // start rows: even (odd slab) | odd (even slab)
+            // the conv's own reflect padding: image row -1 = row 1 (odd slab of the first tile row), image column -1 = column 1
             if constexpr (J == 0) {
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) { st_wh[s_] = stemw[((C * 2 + s_) * 2 + 0) * 64 + lane]; st_wl[s_] = stemw[((C * 2 + s_) * 2 + 1) * 64 + lane]; }
                 st_bias = *reinterpret_cast<const f32x4*>(s_bias0 + 16 * C + 4 * kg);
-            }
-            if constexpr (TYPE == 0) {
-                const unsigned char* sbase = strips + (KIND * 2 * SCOLS) * SPITCH;  // start rows: even (odd slab) | odd (even slab)
-                // the conv's own reflect padding: image row -1 = row 1 (odd slab of the first tile row), image column -1 = column 1
-                const int re = (KIND == 0 && y0 == 0 && rl == 0) ? 1 : rl;
+                const int par = (wv >> 1) & 1, cl = 16 * (wv & 1) + l15, r0 = wv >> 2;
                 int col0 = 2 * cl + (par ? 0 : 1);
                 if (par && cl == 0 && x0 == 0) col0 += 2;
-                const unsigned char* bp = sbase + (col0 + kg) * SPITCH + 4 * re;
+                st_bp = sbase + (col0 + kg) * SPITCH + 4 * r0;
+                const int slot = r0 * ROWPITCH + par * PW + cl;
+                // channels 4 kg .. + 3 of the chunk: half of a hi slot of group kg >> 1, bytes 4 kg .. of the chunk's two lo slots
+                st_hi = reinterpret_cast<unsigned char*>(sb + 2 * (kg >> 1) * XPL + slot) + 8 * (kg & 1);
+                st_lo = reinterpret_cast<unsigned char*>(sb + 1 * XPL + slot) + 4 * kg;
+            }
+            // the last tile of a wave (regular, the extra one, or none): column parity, column and row of the lane's position, whether it stores
+            [[maybe_unused]] int par4 = 0, cl4 = 0, rl4 = 0; [[maybe_unused]] bool ok4 = false;
+            if constexpr (K == NIT - 1) {
+                const int blk = wv + NW * K;
+                const bool sp = blk >= 4 * NR;
+                par4 = sp ? 1 : (blk >> 1) & 1;
+                cl4 = sp ? WT : 16 * (blk & 1) + l15;
+                rl4 = sp ? (l15 < NR ? l15 : NR - 1) : (blk >> 2);
+                ok4 = blk < NBLKS && (!sp || l15 < NR);
+            }
+#if defined(NB_ENC_ABL_ST_NOREAD) || defined(NB_ENC_ABL_ST_NOMMA) || defined(NB_ENC_ABL_ST_NOSTORE) || defined(NB_ENC_ABL_ST_NONE)
+            // developer ablations of the fused stem (tools/build_variant.sh; timing only, wrong results)
+            if constexpr (J == 0) {
+                for (int b_ = 0; b_ < 2; ++b_) { st_fh[b_][0] = st_wh[0]; st_fh[b_][1] = st_wh[1]; st_fl[b_][0] = st_wl[0]; st_fl[b_][1] = st_wl[1]; st_a[b_] = st_bias; }
+            }
+#endif
+#ifdef NB_ENC_ABL_ST_NONE
+            return;
+#endif
+            if constexpr (TYPE == 0) {
+#ifdef NB_ENC_ABL_ST_NOREAD
+                return;
+#endif
+                const unsigned char* bp;
+                if constexpr (K < NIT - 1) {
+                    bp = st_bp + 8 * K;
+                    if constexpr (KIND == 0 && K == 0) bp += (y0 == 0 && wv < 4) ? 4 : 0;
+                } else {
+                    const int re = (KIND == 0 && y0 == 0 && rl4 == 0) ? 1 : rl4;
+                    int col0 = 2 * cl4 + (par4 ? 0 : 1);
+                    if (par4 && cl4 == 0 && x0 == 0) col0 += 2;
+                    bp = sbase + (col0 + kg) * SPITCH + 4 * re;
+                }
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
-                    st_fh[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH));
-                    st_fl[s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH + SCOLS * SPITCH));
+                    st_fh[K & 1][s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH));
+                    st_fl[K & 1][s_] = __builtin_bit_cast(h8, *reinterpret_cast<const i32x4a*>(bp + s_ * 4 * SPITCH + SLO));
                 }
             } else if constexpr (TYPE == 1) {
-                f32x4 a0 = st_bias, a1 = {0.f, 0.f, 0.f, 0.f};
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[0], st_fl[0], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[0], st_fh[0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wl[0], st_fh[0], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[1], st_fh[1], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[1], st_fl[1], a1, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wl[1], st_fh[1], a1, 0, 0, 0);
-                st_a0 = a0; st_a1 = a1;
+#ifdef NB_ENC_ABL_ST_NOMMA
+                return;
+#endif
+                f32x4 a = st_bias;
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[s_], st_fh[K & 1][s_], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wh[s_], st_fl[K & 1][s_], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(st_wl[s_], st_fh[K & 1][s_], a, 0, 0, 0);
+                }
+                st_a[K & 1] = a;
             } else {
-                h8* sb = xbuf + (KIND == 0 ? (C & 1) : ((C + 1) & 1)) * 4 * XPL;
-                f32x4 t = st_a0 + st_a1;
+#ifdef NB_ENC_ABL_ST_NOSTORE
+                return;
+#endif
+                f32x4 t = st_a[K & 1];
                 const f32x4 ta = t * p.slope;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) t[i] = fmaxf(t[i], ta[i]);               // LeakyReLU, 0 <= slope <= 1
@@ -605,11 +639,15 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
                 const f32x4 xl = {nb_sub_f16(t[0], h01, false), nb_sub_f16(t[1], h01, true), nb_sub_f16(t[2], h23, false), nb_sub_f16(t[3], h23, true)};
                 const unsigned lo_xl = nb_pk4_fp8_sat_scaled(xl[0], xl[1], xl[2], xl[3], 0x1p-9f);       // (FP16_OVFL is set: the conversions saturate)
                 const unsigned lo_w = nb_pk4_fp8_sat_scaled(t[0], t[1], t[2], t[3], 4.f);
-                if (ok) {
-                    const int slot = rl * ROWPITCH + par * PW + cl;
-                    // channels 4 kg .. + 3 of the chunk: half of a hi slot of group kg >> 1, bytes 4 kg .. of the chunk's two lo slots
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(sb + 2 * (kg >> 1) * XPL + slot) + 8 * (kg & 1)) =
-                        u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                const u32x2 hi2 = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                if constexpr (K < NIT - 1) {
+                    constexpr int OFF = K * 2 * ROWPITCH * 16;
+                    *reinterpret_cast<u32x2*>(st_hi + OFF) = hi2;
+                    *reinterpret_cast<unsigned*>(st_lo + OFF) = lo_xl;
+                    *reinterpret_cast<unsigned*>(st_lo + OFF + 2 * XPL * 16) = lo_w;
+                } else if (ok4) {
+                    const int slot = rl4 * ROWPITCH + par4 * PW + cl4;
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(sb + 2 * (kg >> 1) * XPL + slot) + 8 * (kg & 1)) = hi2;
                     *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sb + 1 * XPL + slot) + 4 * kg) = lo_xl;
                     *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(sb + 3 * XPL + slot) + 4 * kg) = lo_w;
                 }
@@ -617,7 +655,19 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
         };
         // a whole slab, back to back (fences: left alone the scheduler puts every tile's reads right in front of its products)
         [[maybe_unused]] auto stem_phase = [&](auto kind_, auto c_) {
+#ifdef NB_ENC_STEM_STAMPS   // developer build: wave 0's clock ticks (s_memtime) per operation type of this slab -> stamp slots 5 (L), 6 (M), 7 (S)
+            unsigned long long tt[3] = {0, 0, 0};
+            constexpr int TYPES_[NSOPS] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2, 1, 2, 2};
+            nb_static_for<0, NSOPS>([&](auto j_) {
+                const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+                NB_SB; stem_op(kind_, c_, j_); NB_SB;
+                tt[TYPES_[decltype(j_)::value]] += __builtin_amdgcn_s_memtime() - t0_;
+            });
+            if (p.tstamps && tid == 0)
+                for (int i = 0; i < 3; ++i) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 5 + i] = tt[i];
+#else
             nb_static_for<0, NSOPS>([&](auto j_) { stem_op(kind_, c_, j_); NB_SB; });
+#endif
         };
         using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
         // step (c, S); ODD = parity of t = 3 c + S (selects the half of the tap-2 tuple).  Per accumulator tile the products arrive in the
@@ -1010,7 +1060,7 @@ template <int STRIDE, int LW, int OUT, bool F8 = false, bool FUSED = false>
 static int launch_enc_conv(EncConvParams p, int n, hipStream_t st) {
     constexpr int WT = 1 << LW, TH = 8 * (32 / WT), PW = WT + 2, SLOTS = (F8 && STRIDE == 2) ? (TH + 1) * 2 * PW : STRIDE * TH * PW;
     constexpr int XPL = FUSED ? SLOTS : ((SLOTS + 63) / 64) * 64;
-    constexpr size_t fused = FUSED ? (size_t)4 * (2 * WT + 8) * 52 + (size_t)4 * 2 * 2 * 64 * 16 : 0;      // image strips + stem weight fragments
+    constexpr size_t fused = FUSED ? (size_t)2 * (2 * WT + 8) * 108 + (size_t)4 * 2 * 2 * 64 * 16 : 0;     // image strips + stem weight fragments
     constexpr size_t staging = (size_t)(2 * 4 * XPL + 2 * 12 * 128) * 16 + fused;
     constexpr size_t epi = OUT == 0 ? (size_t)128 * 256 * 4 : (LW == 5 ? 0 : (size_t)2 * 256 * (128 + 8) * 2);       // (32-wide hand-off tiles: no staging)
     constexpr size_t lds = staging > epi ? staging : epi;
