@@ -707,8 +707,9 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
             constexpr int FH_NN = KNN::value == 2 ? FH2 : FH01;
             const int cn = S == 2 ? c + 1 : c, cnn = S == 0 ? c : c + 1;  // their chunks
             const int t = 3 * c + S;
-            if constexpr (FUSED) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // (+ the slab stores of the stem's operations)
-            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // this step's data has landed, everybody's
+            if constexpr (FUSED) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // (+ the slab stores of the stem's operations)
+            } else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(FH_N) : "memory");      // this step's data has landed, everybody's
             NB_SB;
             const h8* xb = xbuf + (S == 1 ? ((c + 1) & 1) : (c & 1)) * 4 * XPL + (S == 2 ? ROWPITCH : 0);
             const h8* wb = wbuf + (t & 1) * WSLOTS;
