@@ -5,7 +5,9 @@ path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 steps = int(os.environ.get("NB_STEPS", "40"))
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-stems = [i for i, r in enumerate(rows) if "stem" in r["Kernel_Name"]]
+# a pass starts with the stem kernel or, for f8 batches, with the launch that computes the stem itself (enc_conv3x3_h3_kernel<2, 5, 1, true, true>)
+first = lambda r: "stem" in r["Kernel_Name"] or re.search(r"enc_conv3x3_h3_kernel<2, 5, 1, (true|1), (true|1)>", r["Kernel_Name"]) is not None
+stems = [i for i, r in enumerate(rows) if first(r)]
 rows = rows[stems[-steps]:]
 span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e3
 acc, order = {}, []
