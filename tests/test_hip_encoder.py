@@ -342,3 +342,23 @@ def test_enc_fused_stem_conv(n, h, w, co, pre, out_fmt):
     _lib.check(lib.nb_enc_conv3x3_ex(_p(a), 64, _p(w1d), _p(b1d), None, _p(y2), None, 0, co // 8, 0, 1, out_fmt, n, h, w, co, 2, 0.01, S), "conv")
     d = float((dec(y2).cpu().double() - out).abs().max())
     assert d <= 2 * tol, (d, tol)                                 # (each within tol of the truth; not bit-identical: another summation order in the stem)
+
+
+@pytest.mark.parametrize("res,n,pre", [(128, 8, "inverse"), (256, 9, None)])
+def test_encoder_fused_stem_equals_two_launches(res, n, pre):
+    """HipGeometryEncoder with the stem inside the first stride-2 launch (the default for f8 batches) against the same encoder with the two
+    launches (fuse_stem = False): both features agree to the f8 path's own tolerance against the oracle, and they are not the same bits (the
+    fused launch really ran: another summation order in the stem)."""
+    rs = np.random.RandomState(res + n)
+    esd = encmod.random_encoder_state_dict(13)
+    geom = torch.from_numpy((rs.rand(n, 1, res, res) ** 3).astype(np.float32)).cuda()
+    enc = encmod.HipGeometryEncoder(esd, preproc_type=pre)
+    assert enc.fuse_stem and enc.arith == "f8"
+    a = enc.encode(geom)
+    enc.fuse_stem = False
+    b = enc.encode(geom)
+    ref = po.encoder_encode(esd, geom.cpu(), pre)
+    for x, y, r in zip(a, b, ref):
+        assert float((x.cpu() - r).abs().max()) <= 5e-4 and float((y.cpu() - r).abs().max()) <= 5e-4
+        assert float((x - y).abs().max()) <= 2e-4
+    assert not all(torch.equal(x, y) for x, y in zip(a, b))
