@@ -1245,12 +1245,13 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
                "conv3x3_s2_valid_h3: needs H2 operands, an fp32 destination and an odd input size (got %dx%d)", h_in, w_in);
     NB_REQUIRE(shift || (h_in % stride == 0 && w_in % stride == 0 && h_in >= 2 && w_in >= 2), "enc_conv3x3_h3: bad input size %dx%d", h_in, w_in);
     const int ho = shift ? (h_in - 1) / 2 : h_in / stride, wo = shift ? (w_in - 1) / 2 : w_in / stride;
-    const bool wide = wo % 32 == 0 && ho % 8 == 0, narrow = wo == 16 && ho % 16 == 0;
+    // (16-wide tiles for every width that is a multiple of 16 but not of 32: 16 itself -- R = 128 -- and e.g. 48 = the inner layers at R = 384)
+    const bool wide = wo % 32 == 0 && ho % 8 == 0, narrow = !wide && wo % 16 == 0 && ho % 16 == 0;
     // the 32-position split-K tiles take any output whose width is a power of two >= 4 (4- and 8-wide images: the encoder's
     // inner layers at patch sizes 32 and 64; rows that do not fill the last tile are masked)
     const bool pow2 = (wo & (wo - 1)) == 0 && wo >= 4;
     const bool small_ok = pow2 && c_in % 16 == 0 && in_fmt == 0 && !shift;
-    NB_REQUIRE(wide || narrow || small_ok, "enc_conv3x3_h3: output must be a multiple of 32 wide (rows %% 8 == 0), 16 wide (rows %% 16 == 0), or -- H2 "
+    NB_REQUIRE(wide || narrow || small_ok, "enc_conv3x3_h3: output must be a multiple of 32 wide (rows %% 8 == 0), a multiple of 16 wide (rows %% 16 == 0), or -- H2 "
                "operands, c_in %% 16 == 0 -- a power of two >= 4 wide; got %dx%d", ho, wo);
     NB_REQUIRE(y_f32 || c_out % 8 == 0, "enc_conv3x3_h3: H2 output needs c_out %% 8 == 0");
     NB_REQUIRE(((uintptr_t)x_h2 | (uintptr_t)w_h3 | (uintptr_t)y_f32 | (uintptr_t)y_h2) % 16 == 0, "enc_conv3x3_h3: pointers must be 16-byte aligned");

@@ -462,7 +462,7 @@ int nb_enc_stem7x7_f32_h2(const float* x, const float* w50, const float* bias, v
 
 /* 3x3 conv, stride 1 or 2, reflect padding 1, split-f16 products.  x_h2: H2 [n, c_in, h_in, w_in]; w_h3: hi/lo f16
  * [ceil(c_in/16)][3][3][2][2][ceil128(c_out)][8]; exactly one of y_f32 (fp32 NCHW [n,c_out,h_in/stride,w_in/stride])
- * and y_h2 (H2, c_out % 8 == 0) is non-NULL.  Output must be 16 wide (rows % 16 == 0) or a multiple of 32 wide
+ * and y_h2 (H2, c_out % 8 == 0) is non-NULL.  Output must be a multiple of 16 wide (rows % 16 == 0) or a multiple of 32 wide
  * (rows % 8 == 0). */
 int nb_enc_conv3x3_h3(const void* x_h2, int c_in, const void* w_h3, const float* bias, float* y_f32, void* y_h2, int n,
                       int h_in, int w_in, int c_out, int stride, float slope, void* stream);

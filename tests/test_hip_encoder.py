@@ -38,7 +38,7 @@ def test_encoder_matches_reference_golden():
     np.testing.assert_allclose(f[1].cpu().numpy()[:, ::8], g["enc_f1"], atol=TOL)
 
 
-@pytest.mark.parametrize("res,n,pre", [(128, 3, None), (256, 2, None), (128, 1, "-11inverse"), (256, 1, "inverse")])
+@pytest.mark.parametrize("res,n,pre", [(128, 3, None), (256, 2, None), (128, 1, "-11inverse"), (256, 1, "inverse"), (384, 2, None)])
 def test_encoder_matches_oracle(res, n, pre):
     rs = np.random.RandomState(res + n)
     esd = encmod.random_encoder_state_dict(11)
@@ -54,7 +54,9 @@ def test_encoder_matches_oracle(res, n, pre):
 
 @pytest.mark.parametrize("stride,ci,co,h,w,h2out", [(1, 16, 256, 32, 32, False), (2, 64, 128, 64, 64, True),
                                                      (2, 256, 256, 32, 32, True), (1, 32, 16, 16, 16, False),
-                                                     (1, 256, 32, 16, 16, True), (2, 128, 256, 64, 128, False)])
+                                                     (1, 256, 32, 16, 16, True), (2, 128, 256, 64, 128, False),
+                                                     # 48-wide outputs (the inner layers of a 384 x 384 patch): 16-wide tiles, three per row
+                                                     (2, 32, 48, 96, 96, True), (1, 32, 16, 48, 48, False)])
 @pytest.mark.parametrize("small", [0, 1])
 def test_enc_conv_layer(stride, ci, co, h, w, h2out, small):
     """One layer against torch fp64 (reflect pad, cross-correlation), both output formats, both tile shapes, and both
@@ -251,7 +253,8 @@ def _f8_decode(t, c):
                                                      # stride 2 with per-chunk slabs (round 4): odd chunk counts, ONE chunk, ragged c_out slices,
                                                      # 16-wide tiles, a single tile row
                                                      (2, 48, 136, 32, 64, False), (2, 80, 48, 64, 64, True), (2, 16, 16, 32, 32, True),
-                                                     (2, 16, 24, 16, 64, False), (2, 112, 272, 48, 64, True)])
+                                                     (2, 16, 24, 16, 64, False), (2, 112, 272, 48, 64, True),
+                                                     (2, 64, 128, 96, 96, True), (1, 48, 40, 48, 48, False)])
 def test_enc_conv_layer_f8(stride, ci, co, h, w, h2out):
     """The same layer with "f8" operands (one f16 + half an fp8 MFMA per tap; the third tap's corrections paired across
     K steps -- odd and even step counts are both here) against torch fp64: the fp8 correction terms leave
@@ -285,7 +288,7 @@ def test_enc_conv_layer_f8(stride, ci, co, h, w, h2out):
     assert float((out.double() - ref).abs().max()) <= tol, (float((out.double() - ref).abs().max()), tol)
 
 
-@pytest.mark.parametrize("res,n,pre", [(128, 9, None), (256, 8, "-11inverse")])
+@pytest.mark.parametrize("res,n,pre", [(128, 9, None), (256, 8, "-11inverse"), (384, 8, None)])
 def test_encoder_f8_matches_oracle(res, n, pre):
     """Batches >= f8_min_batch run the encoder with f8 operands between its layers: features within 5e-4 of the fp32 oracle
     (O(1) values; 2e-4 for the hi/lo-f16 path), and the two formats agree to the same level."""
