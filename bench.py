@@ -216,7 +216,8 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
     B = args.batch
     # the generator runs a batch as `sub` sub-batches on separate HIP streams; with N>1 each part's RGBA tiles are
     # gathered from the part's own stream, so steps keep overlapping across the streams at any N
-    sub = G.sub_streams if (B >= G.sub_stream_min_batch and not args.pipeline and not args.prefetch) else 1
+    sub = G.sub_streams if (B >= G.sub_stream_min_batch and args.schedule in ("concurrent", "single")) else 1
+    use_pg = args.use_pg                 # a process group exists: N > 1, or NB_FORCE_PG=1 at N = 1 (the collectives of the N > 1 path through RCCL on one GPU)
     gatherer = TileGatherer([B, args.res, args.res, 4], torch.uint8, dev, timing=True) if gather else None
     part_gatherers = []
     if gatherer is not None and sub > 1:
@@ -230,19 +231,19 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
                 g_.finish()
 
     pipe = None
-    if args.pipeline:
+    if args.schedule == "pipeline":
         from brushstroke_engine_amd.pipeline import TriadStepPipeline
         pipe = TriadStepPipeline(G)
         if not pipe._eligible(B):
             pipe = None
-    schedule = ("steps software-pipelined over two HIP streams (pipeline.TriadStepPipeline): the head of step k+1 -- mapping, styles, "
-                "the <= 16x16 layers: 2 % of the FLOPs in latency-bound launches -- runs under the big convolutions of step k"
-                if pipe is not None else "steps enqueued back to back on one stream")
-    if args.prefetch and pipe is None:
+    schedule_single = ("steps software-pipelined over two HIP streams (pipeline.TriadStepPipeline): the head of step k+1 -- mapping, styles, "
+                       "the <= 16x16 layers: 2 % of the FLOPs in latency-bound launches -- runs under the big convolutions of step k"
+                       if pipe is not None else "steps enqueued back to back on one stream")
+    if args.schedule == "prefetch" and pipe is None:
         from brushstroke_engine_amd.pipeline import TriadPrefetchPipeline
         pipe = TriadPrefetchPipeline(G, mark_layer=os.environ.get("NB_PREFETCH_MARK") or None)
-        schedule = ("steps on one stream; what step k+1 needs before its first layer (mapping, styles, small layers' noise, geometry "
-                    "packs: no matrix work) is enqueued on a side stream under the LAST layer of step k (pipeline.TriadPrefetchPipeline)")
+        schedule_single = ("steps on one stream; what step k+1 needs before its first layer (mapping, styles, small layers' noise, geometry "
+                           "packs: no matrix work) is enqueued on a side stream under the LAST layer of step k (pipeline.TriadPrefetchPipeline)")
 
     def step():
         if pipe is not None:
@@ -265,11 +266,41 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
                 gatherer.finish()
                 gatherer.start(res[0])
 
+    # The library's throughput schedule (pipeline.ConcurrentTriadSteps; the headline since round 6): independent steps dealt round-robin
+    # to k HIP streams with a workspace slot each -- the other chains' kernels fill the CUs one chain leaves idle in its kernel tails
+    # and in its small launches.  k = --streams, 0 = the library's own probe (1 or 3).  With N > 1 every stream has its own gatherer:
+    # the tiles of step i are gathered from the stream that rendered them, the gather of step i - k is waited for first.
+    conc, conc_gatherers = None, []
+    if args.schedule == "concurrent":
+        from brushstroke_engine_amd.pipeline import ConcurrentTriadSteps
+        conc = ConcurrentTriadSteps(G, streams=args.streams)
+        if args.streams == 0:
+            conc.choose(z, geom, pos)
+        if gather:
+            conc_gatherers = [TileGatherer([B, args.res, args.res, 4], torch.uint8, dev, timing=True) for _ in range(conc.streams)]
+
+    def step_conc():
+        u8 = conc.submit(z, geom, pos)
+        if conc_gatherers:
+            g_ = conc_gatherers[(conc._i - 1) % conc.streams]
+            with torch.cuda.stream(conc.last_stream):
+                g_.finish()
+                g_.start(u8)
+
+    def finish_conc():
+        for g_ in conc_gatherers:
+            g_.finish()
+        conc.wait()
+
     # Burn-in (untimed, before the W warmup steps): a fresh process on a fresh box runs its first steps well below
     # steady state (host-side first-touch costs: lazily loaded code objects, allocator growth, cold Python paths, clock
     # ramp), and one step is only ~2 ms.  Run chunks of 5 steps until two consecutive chunks agree within 3 %
     # (at least 0.5 s, at most 8 s); the chunk times are reported as "burn_in_ms_per_step".
     burn_in = []
+    if sampler is not None:
+        # board power / shader clock of this mode: sampled from here to the end of its last timed region (burn-in + warm-up + rehearsals
+        # + timed legs: the same steps throughout) -- the timed K steps alone are ~40 ms, four ticks of the 10 ms sampler
+        sampler.mark(mode)
     t_burn = time.perf_counter()
     while True:
         tb = time.perf_counter()
@@ -280,7 +311,7 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
         burn_in.append((time.perf_counter() - tb) / 5 * 1e3)
         spent = time.perf_counter() - t_burn
         stable = len(burn_in) >= 2 and abs(burn_in[-1] - burn_in[-2]) <= 0.03 * burn_in[-2]
-        if world > 1:                       # all ranks must leave the loop together
+        if use_pg:                          # all ranks must leave the loop together
             flag = torch.tensor([1.0 if (stable and spent >= 0.5) or spent >= 8.0 else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if flag.item() > 0:
@@ -332,15 +363,13 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
     torch.cuda.synchronize()
     rehearsal_ms = (time.perf_counter() - t_reh) / args.steps * 1e3
     G.synthesis.event_pool = make_pool()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     G.synthesis.layer_events = []
     for g_ in [gatherer] + part_gatherers:
         if g_ is not None:
             g_.wait_ms()                                 # (reset: count the waits of the timed region only)
-    if sampler is not None:
-        sampler.mark(mode)
     t0 = time.perf_counter()
     for i_ in range(args.steps):
         G.synthesis.event_filter = dom_layers if i_ % args.event_every == 0 else none_
@@ -348,33 +377,81 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
     finish_gathers()
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if sampler is not None:
-        sampler.unmark(mode)
+        sampler.unmark(mode)                    # (moved on below when the concurrent leg follows)
     events = G.synthesis.layer_events
     G.synthesis.layer_events, G.synthesis.event_filter, G.synthesis.event_pool = None, None, None
-    per_rank_ms, gather_wait = None, None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+
+    def reduce_times(el, el_local):
+        """MAX over ranks of the timed region, and every rank's own time for its K steps (before the closing barrier)."""
+        if not use_pg:
+            return el, None
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # every rank's own time for its K steps (before the closing barrier), and how long rank 0 waited for the tile gathers
         mine = torch.zeros([world], dtype=torch.float64, device=dev)
-        mine[rank] = elapsed_local / args.steps * 1e3
+        mine[rank] = el_local / args.steps * 1e3
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-        per_rank_ms = [round(float(v), 4) for v in mine.tolist()]
-        if gatherer is not None:
-            w_ = [g_.wait_ms() for g_ in [gatherer] + part_gatherers]
-            gather_wait = {"host_ms_per_step": round(sum(x["host_ms"] for x in w_) / args.steps, 4),
-                           "stream_ms_per_step": (round(sum(x["stream_ms"] or 0.0 for x in w_) / args.steps, 4)
-                                                  if any(x["stream_ms"] is not None for x in w_) else None),
-                           "waits": sum(x["waits"] for x in w_),
-                           "what": "time TileGatherer.finish() kept THIS rank (0) waiting inside the timed steps: host wall clock, and "
-                                   "HIP events on the issuing stream around the wait (an RCCL wait stalls the stream, not the host); the "
-                                   "gather of step k is waited for at step k+1, after a whole step of compute"}
+        return float(t.item()), [round(float(v), 4) for v in mine.tolist()]
+
+    def gather_wait_of(gs):
+        """How long rank 0 waited for the tile gathers inside the timed steps."""
+        gs = [g_ for g_ in gs if g_ is not None]
+        if not gs:
+            return None
+        w_ = [g_.wait_ms() for g_ in gs]
+        return {"host_ms_per_step": round(sum(x["host_ms"] for x in w_) / args.steps, 4),
+                "stream_ms_per_step": (round(sum(x["stream_ms"] or 0.0 for x in w_) / args.steps, 4)
+                                       if any(x["stream_ms"] is not None for x in w_) else None),
+                "waits": sum(x["waits"] for x in w_),
+                "what": "time TileGatherer.finish() kept THIS rank (0) waiting inside the timed steps: host wall clock, and "
+                        "HIP events on the issuing stream around the wait (an RCCL wait stalls the stream, not the host); the "
+                        "gather of a step is waited for when its stream's next step has been enqueued, after a whole step of compute"}
+
+    elapsed, per_rank_ms = reduce_times(elapsed, elapsed_local)
+    gather_wait = gather_wait_of([gatherer] + part_gatherers)
+    single = {"value": round(world * B * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "schedule": schedule_single}
+    schedule = schedule_single
+    if conc is not None:
+        # the headline leg: the same K steps on the concurrent schedule -- W warm-up steps, one untimed rehearsal of the timed loop,
+        # then exactly K steps between barrier + synchronize on both sides; no events inside (launches overlap: their durations say
+        # nothing about a kernel, which is why the roofline comes from the single-stream leg above)
+        for _ in range(args.warmup):
+            step_conc()
+        finish_conc()
+        torch.cuda.synchronize()
+        t_reh = time.perf_counter()
+        for _ in range(args.steps):
+            step_conc()
+        finish_conc()
+        torch.cuda.synchronize()
+        rehearsal_ms = (time.perf_counter() - t_reh) / args.steps * 1e3
+        for g_ in conc_gatherers:
+            g_.wait_ms()
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_conc()
+        finish_conc()
+        torch.cuda.synchronize()
+        elapsed_local = time.perf_counter() - t0
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if sampler is not None:
+            sampler.unmark(mode)
+        elapsed, per_rank_ms = reduce_times(elapsed, elapsed_local)
+        gather_wait = gather_wait_of(conc_gatherers)
+        schedule = (f"{conc.streams} independent steps in flight, dealt round-robin to {conc.streams} HIP streams with a workspace slot each "
+                    f"(pipeline.ConcurrentTriadSteps, the library's throughput schedule"
+                    + (f"; stream count chosen by its probe: {conc.probe}" if conc.probe else "") + "); every step is the plain "
+                    "Generator.render_triad pass: bit-identical to the serial loop (tests/test_hip_generator.py)")
 
     # after the timed region: the dominant kernel once more with the whole batch on ONE stream (3 steps), so that its
     # launch duration is also known without another stream's kernels sharing the chip
@@ -462,11 +539,14 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
                                             / (sum(float(np.mean(t)) for t in iso.values()) * 1e-3) / 1e12 / dom_peak, 4)}
                              if iso else None),
                 "flops_per_launch": dom_fl / dom_launches,
-                "note": ("fp32 MFMA" if not split else
-                         "split-f16 kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
-                         if mode == "h3" else
-                         "split-f16 + fp8-correction kernels spend 2 f16-MFMA-equivalents of matrix time per algorithmic fp32 FLOP: "
-                         "frac (against the f16 peak) <= 1/2 by construction"),
+                "note": (("fp32 MFMA" if not split else
+                          "split-f16 kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
+                          if mode == "h3" else
+                          "split-f16 + fp8-correction kernels spend 2 f16-MFMA-equivalents of matrix time per algorithmic fp32 FLOP: "
+                          "frac (against the f16 peak) <= 1/2 by construction")
+                         + ("; launch durations are from this mode's SINGLE-STREAM timed leg (value_single_stream: the same K steps "
+                            "back to back on one stream, HIP events on that stream), not from the headline leg, where the steps of "
+                            "several streams share the chip and a launch's duration says nothing about the kernel" if conc is not None else "")),
                 "calibration": {"what": "untimed pass with every launch bracketed by HIP events",
                                 "all_conv_launches": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4)},
                                 "kernels": {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
@@ -484,6 +564,11 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
     extra = {}
     if sampler is not None:
         extra["telemetry"] = sampler.summary(mode)
+    if conc is not None:
+        extra["value_single_stream"] = single["value"]
+        extra["single_stream"] = single
+        extra["streams"] = conc.streams
+        extra["stream_probe"] = conc.probe
     if per_rank_ms is not None:
         extra["ms_per_step_per_rank"] = per_rank_ms
     if gather_wait is not None:
@@ -521,6 +606,35 @@ def compact_roofline(r):
     return c
 
 
+def fit_line(c):
+    """The compact record as ONE JSON line below MAX_LINE_BYTES: optional keys are dropped, least important first, until it fits --
+    a line is ALWAYS printed (an assertion here once stood between a finished measurement and its record, and at N > 1 would have
+    left the other ranks waiting in the closing barrier)."""
+    dumps = lambda d: json.dumps(d, separators=(",", ":"))
+    line = dumps(c)
+    droppable = ["stream_probe", "telemetry", "box_calibration", "ms_per_step_per_rank", "gather_wait_ms", "latency_batch1",
+                 "roofline_whole_step", "parity", "modes", "rccl", "value_fp32_parity", "detail_file"]
+    dropped = []
+    for k in droppable:
+        if len(line) < MAX_LINE_BYTES:
+            break
+        if k == "modes" and isinstance(c.get("modes"), dict):          # first without the per-mode rooflines, then without the modes
+            c["modes"] = {m: _pick(r, ("value", "ms_per_step", "parity")) for m, r in c["modes"].items()}
+            dropped.append("modes.*.roofline")
+            line = dumps({**c, "dropped": dropped})
+            if len(line) < MAX_LINE_BYTES:
+                break
+        if k in c:
+            del c[k]
+            dropped.append(k)
+            line = dumps({**c, "dropped": dropped})
+    if len(line) >= MAX_LINE_BYTES:                                     # (cannot happen with the contract's keys alone: < 1.5 KB)
+        c = _pick(c, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "data"))
+        line = dumps({**c, "dropped": "everything but the contract's scalar keys"})
+    return line
+
+
 def compact_line(out):
     """What goes to stdout: the contract's keys, numbers only (no calibration tables, no per-layer times, no explanatory strings)."""
     c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "conv_mode", "data"))
@@ -539,18 +653,21 @@ def compact_line(out):
         if par:
             c["parity"] = _pick(par, ("max_abs_rgba_vs_oracle", "max_u8_diff", "tolerance", "patches"))
     c["box_calibration"] = _pick(out.get("box_calibration") or {}, ("mfma_f16_sustained_tflops", "loop_clock_mhz"))
-    c["telemetry"] = _pick(out.get("telemetry") or {}, ("power_w_mean", "sclk_mhz_mean", "power_cap_w"))
+    tele = _pick(out.get("telemetry") or {}, ("power_w_mean", "sclk_mhz_mean", "power_cap_w", "samples"))
+    if tele and tele.get("power_w_mean") is not None:          # (absent when the window held too few samples to mean anything)
+        c["telemetry"] = tele
     if out.get("latency_batch1"):
         c["latency_batch1"] = _pick(out["latency_batch1"], ("unit", "p50", "p99", "p50_incl_d2h", "p99_incl_d2h"))
-    if out.get("throughput_concurrent_steps"):
-        t3 = out["throughput_concurrent_steps"]
-        c["throughput_concurrent_steps"] = {"streams": t3["streams"], "value": t3["value"], "ratio_vs_single_stream": t3["ratio_vs_single_stream"],
-                                            "single_stream_value": t3["single_stream_same_leg"]["value"]}
+    for k_ in ("value_single_stream", "streams"):
+        if out.get(k_) is not None:
+            c[k_] = out[k_]
+    if out.get("stream_probe"):
+        c["stream_probe"] = out["stream_probe"].get("ms_per_step")
     if "value_fp32_parity" in out:
         c["value_fp32_parity"] = out["value_fp32_parity"]
     modes = {}
     for m, r in (out.get("modes") or {}).items():
-        modes[m] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
+        modes[m] = {"value": r["value"], "ms_per_step": r["ms_per_step"], **_pick(r, ("value_single_stream", "streams")),
                     "roofline": _pick(r["roofline"], ("kernel", "achieved", "peak", "frac", "frac_of_sustained", "launch_ms")),
                     "parity": (r.get("parity") or {}).get("max_abs_rgba_vs_oracle")}
     c["modes"] = modes
@@ -582,13 +699,15 @@ def main():
                          "timed steps) and reported under `modes`; default: all three at N=1, the primary one only at N>1; 'primary' = only it")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RGBA gather to rank 0")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="run what a step needs before its first layer (mapping, styles, geometry packs) on a side stream under the "
-                         "last layer of the step before (pipeline.TriadPrefetchPipeline; bit-identical results)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="software-pipeline the steps over two streams (pipeline.TriadStepPipeline: head of step k+1 under the tail of step k; "
-                         "+2 %% measured) instead of enqueueing them back to back on ONE stream, where every launch has the chip to itself "
-                         "and its HIP-event duration is the kernel's own time (default)")
+    ap.add_argument("--schedule", default="concurrent", choices=["concurrent", "single", "pipeline", "prefetch"],
+                    help="how the K steps are enqueued.  concurrent (default; the library's throughput schedule, pipeline.ConcurrentTriadSteps): "
+                         "independent steps dealt round-robin to --streams HIP streams with a workspace slot each -- `value` is measured on it, "
+                         "`roofline` and `value_single_stream` on the same K steps back to back on ONE stream (measured in the same run, where "
+                         "every launch has the chip to itself and its HIP-event duration is the kernel's own time).  single: only that leg.  "
+                         "pipeline / prefetch: the two-stream software pipelines of pipeline.py (+2 %% / -0.3 %%; kept for A/Bs)")
+    ap.add_argument("--streams", type=int, default=0, help="streams of the concurrent schedule; 0 = the library's probe picks 1 or 3")
+    ap.add_argument("--prefetch", action="store_true", help="= --schedule prefetch")
+    ap.add_argument("--pipeline", action="store_true", help="= --schedule pipeline")
     ap.add_argument("--full-line", action="store_true", help="print the FULL record on stdout instead of the compact line (the A/B scripts under "
                                                              "tools/ read its calibration tables); never what the driver runs")
     ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json next to this file)")
@@ -600,6 +719,10 @@ def main():
         ap.error("--event-every must be >= 1")
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps must be >= 1 and --warmup >= 0")
+    if args.pipeline or args.prefetch:
+        args.schedule = "pipeline" if args.pipeline else "prefetch"
+    if args.streams < 0 or args.streams > 8:
+        ap.error("--streams must lie in 0..8")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # self-launch: N ranks as a child torchrun.  Nothing in this process has touched the GPU (importing torch does
@@ -635,8 +758,21 @@ def main():
     _nblib.lib()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NB_FORCE_PG=1: create the process group (RCCL) at ANY world size and take every `N > 1` branch below -- pre-flight, fabric report,
+    # the gather of RGBA tiles inside the step, barriers and reductions around the timed regions -- so that the collectives of the
+    # multi-GPU path run through RCCL on a one-GPU box (`torchrun --nproc-per-node=1`, or plain `python bench.py`: the rendezvous
+    # variables are filled in here)
+    force_pg = os.environ.get("NB_FORCE_PG") == "1"
+    use_pg = world > 1 or force_pg
+    args.use_pg = use_pg
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk_:
+                sk_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk_.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import datetime
         tmo = datetime.timedelta(seconds=300)            # a wedged collective should fail the run, not hang it
@@ -651,7 +787,8 @@ def main():
     if args.conv_mode is None:
         args.conv_mode = DEFAULT_CONV_MODE
     if args.modes in (None, "all"):
-        modes = ["f8", "h3", "f32", "f6"] if (world == 1 or args.modes == "all") else [args.conv_mode]
+        # (f6 -- the round-5 experiment, not faster and less accurate than f8 -- only on request: --modes f6 or all)
+        modes = (["f8", "h3", "f32", "f6"] if args.modes == "all" else ["f8", "h3", "f32"]) if (world == 1 or args.modes == "all") else [args.conv_mode]
     elif args.modes == "primary":
         modes = [args.conv_mode]
     else:
@@ -668,7 +805,7 @@ def main():
     z = torch.from_numpy(synthetic.batch_z(cfg, B, first_seed=rank * B)).to(dev).to(torch.float32)
     geom = [torch.from_numpy(g).to(dev) for g in synthetic.geom_features(cfg, B, seed=rank)]
     pos = torch.from_numpy(synthetic.positions(cfg, B, seed=rank)).to(dev)
-    gather = world > 1 and not args.no_gather
+    gather = use_pg and not args.no_gather
     if gather:
         # pre-flight: one small RCCL gather, checked on rank 0.  The gather IS part of the measured job (north_star: "RCCL
         # gather over xGMI to assemble the stylized canvas"): if the fabric refuses it the run fails, non-zero.
@@ -691,7 +828,7 @@ def main():
 
     # who is here (N > 1: all-gather of every rank's device; fails unless the ranks sit on N distinct devices)
     from brushstroke_engine_amd import launch as _launch, telemetry as _tele
-    fabric = _launch.fabric_report(dev, rank, world, backend)
+    fabric = _launch.fabric_report(dev, rank, world, backend, collective=use_pg)
     # what this board sustains on the instruction the conv kernels are built on (50 ms registers-only f16 MFMA loop), before
     # anything is timed; then a side thread samples board power and shader clock for the rest of the run
     calib = None
@@ -715,51 +852,6 @@ def main():
         results[m] = measure_mode(gens[m], m, args, cfg, (z, geom, pos), world, rank, dev, backend, gather, sampler=sampler, calib=calib)
     G = gens[args.conv_mode]
     prim = results[args.conv_mode]
-    # Auxiliary figure (NOT `value`): the same steps with three independent steps in flight on three HIP streams (own
-    # workspaces).  The kernels of the other chains fill the CUs a chain leaves idle in its kernel tails and small launches, so
-    # the job is faster -- but every launch then shares the chip and its duration says nothing about the kernel, which is why
-    # the headline and the roofline are measured on one stream.
-    concurrent = None
-    if world == 1 and args.res == 256 and not args.no_latency:            # (auxiliary legs go together: --no-latency skips both)
-        streams3 = [torch.cuda.Stream(dev) for _ in range(3)]
-
-        def run3(k_):
-            torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            for i_ in range(k_):
-                with torch.cuda.stream(streams3[i_ % 3]):
-                    G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False, _plan_slot=27 + i_ % 3)
-            torch.cuda.synchronize()
-            return time.perf_counter() - t_
-        def run1(k_):                                   # the same loop on ONE stream (slot 27): the reference of this leg
-            torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            with torch.cuda.stream(streams3[0]):
-                for _ in range(k_):
-                    G.render_triad(z=z, geom_feature=geom, positions=pos, render_mode="clear", join=False, _plan_slot=27)
-            torch.cuda.synchronize()
-            return time.perf_counter() - t_
-        for s_ in streams3:
-            s_.wait_stream(torch.cuda.current_stream(dev))
-        k3 = max(args.steps, 30)
-        # warm both forms (workspaces of the three slots, code objects), then interleave them: 1, 3, 1, 3 -- the ratio is taken
-        # between neighbours in time, on this box, in this thermal state (the round-3 driver run saw 3 streams 14 % BELOW the
-        # single-stream headline, measured minutes apart in the run; several boxes since gave +2 .. +10 %)
-        run3(9); run1(6)
-        sampler.mark("concurrent")
-        el1a, el3a, el1b, el3b = run1(k3), run3(k3), run1(k3), run3(k3)
-        sampler.unmark("concurrent")
-        el1, el3 = min(el1a, el1b), min(el3a, el3b)
-        concurrent = {"streams": 3, "steps": k3, "value": round(B * k3 / el3, 2), "unit": "patches/s", "ms_per_step": round(el3 / k3 * 1e3, 4),
-                      "single_stream_same_leg": {"value": round(B * k3 / el1, 2), "ms_per_step": round(el1 / k3 * 1e3, 4)},
-                      "ratio_vs_single_stream": round(el1 / el3, 4),
-                      "runs_ms_per_step": {"one_stream": [round(el1a / k3 * 1e3, 4), round(el1b / k3 * 1e3, 4)],
-                                           "three_streams": [round(el3a / k3 * 1e3, 4), round(el3b / k3 * 1e3, 4)]},
-                      "telemetry": sampler.summary("concurrent"),
-                      "what": "three independent steps in flight on three HIP streams against the same loop on one stream, interleaved "
-                              "(1, 3, 1, 3; best of two each); auxiliary -- kernels share the chip, so no per-kernel roofline is taken "
-                              "from this run.  The tiled-canvas schedule no longer assumes the gain: TileOps.choose_streams probes it"}
-
     if rank == 0:
         out = {
             "metric": "stylized 256x256 stroke patches/sec at batch=32" if args.res == 256 and B == 32
@@ -773,7 +865,7 @@ def main():
                                    f"style1 checkpoint shapes (BASELINE.json configs[1]); generator + triad compositing "
                                    f"to uint8 RGBA; geometry features precomputed",
                        "batch_per_gpu": B, "resolution": args.res, "gflop_per_patch": round(2 * cfg.macs_per_patch() / 1e9, 3),
-                       "parallelism": f"patch-parallel x{world}" + ("" if world == 1 else
+                       "parallelism": f"patch-parallel x{world}" + ("" if not use_pg else
                                                                    (f" + {'RCCL' if backend == 'nccl' else backend} gather of RGBA tiles to rank 0 "
                                                                     f"inside every step (rank 0 receives {world - 1} x {B * args.res * args.res * 4 / 1e6:.1f} MB "
                                                                     f"per step; see gather_wait_ms / ms_per_step_per_rank / rccl)") if gather else " (NO gather: --no-gather)")},
@@ -785,7 +877,10 @@ def main():
             "rehearsal_ms_per_step": prim["rehearsal_ms_per_step"],
             "burn_in_ms_per_step": prim["burn_in_ms_per_step"],
         }
-        if world > 1:
+        for k_ in ("value_single_stream", "single_stream", "streams", "stream_probe"):
+            if k_ in prim:
+                out[k_] = prim[k_]
+        if use_pg:
             out["rccl"] = fabric
             out["ms_per_step_per_rank"] = prim.get("ms_per_step_per_rank")
             out["gather_wait_ms"] = prim.get("gather_wait_ms")
@@ -794,8 +889,6 @@ def main():
             out["value_fp32_parity"] = results["h3"]["value"]
             out["value_fp32_parity_what"] = "patches/s of mode h3 (fp32-grade products: 5e-6 from an all-fp32 evaluation); f32 = exact fp32 MFMA"
         out["modes"] = {m: {k: v for k, v in r.items()} for m, r in results.items()}
-        if concurrent is not None:
-            out["throughput_concurrent_steps"] = concurrent
         if world == 1 and not args.no_latency:
             out["latency_batch1"] = latency_batch1(G, cfg, dev, geom, pos)
         if world == 1 and not args.no_cpu:
@@ -816,11 +909,9 @@ def main():
         if args.full_line:
             print(json.dumps(out), flush=True)
         else:
-            line = json.dumps(compact_line(out), separators=(",", ":"))
-            assert len(line) < MAX_LINE_BYTES, f"bench line is {len(line)} bytes (limit {MAX_LINE_BYTES})"
-            print(line, flush=True)
+            print(fit_line(compact_line(out)), flush=True)
     sampler.__exit__(None, None, None)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512) void enc_conv3x3_h3_kernel(const EncConvParams
     // one LDS-DMA piece of step t into buffer `buf`: k < NXPW activations, else weights (the pieces of issue(), singly)
     auto piece = [&](auto kk, int t, int buf) {
         constexpr int k = decltype(kk)::value;
-#ifdef NB_ENC_ABL_NODMA     // developer ablation (tools/build_variants_enc.sh; timing only, wrong results): the steps re-read what the prologue staged
+#ifdef NB_ENC_ABL_NODMA     // developer ablation (tools/build_variant.sh; timing only, wrong results): the steps re-read what the prologue staged
         (void)t; (void)buf;
         return;
 #endif

@@ -1652,7 +1652,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
             h8 b0h[NBJ] = {}, b0l[NBJ] = {}, b1h[NBJ] = {}, b1l[NBJ] = {}, b2h[NBJ] = {}, b2l[NBJ] = {};
             h8 a1h = {}, a1l = {}, a2h = {}, a2l = {}, n1h = {}, n1l = {}, n2h = {}, n2l = {};
             using S4 = std::integral_constant<int, 4>;
-#ifdef NB_ABL_NOREAD      // developer ablation (tools/build_variants.sh; timing only, wrong results): no fragment reads
+#ifdef NB_ABL_NOREAD      // developer ablation (tools/build_variant.sh; timing only, wrong results): no fragment reads
 #define NB_RD(dst, src) asm volatile("" : "+v"(dst))
 #else
 #define NB_RD(dst, src) dst = (src)

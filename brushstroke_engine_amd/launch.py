@@ -13,7 +13,10 @@ compiles for minutes while the others wait in a collective would run into their 
 and the group created.
 
 Test hooks for a one-GPU box (numbers from such a run mean nothing): ``NB_BENCH_SHARE_GPU=1`` puts every rank on
-device 0, ``NB_BENCH_BACKEND=gloo`` swaps RCCL out (RCCL refuses two ranks on one device).
+device 0, ``NB_BENCH_BACKEND=gloo`` swaps RCCL out (RCCL refuses two ranks on one device).  ``NB_FORCE_PG=1`` creates the process
+group at ANY world size and makes every entry point take its ``world > 1`` branches (``collective``): with one rank on one GPU
+the pre-flight, the fabric report, the tile gather, the halo all-to-all, the canvas all-reduce and the gradient all-reduce all run
+through RCCL -- so that the first multi-GPU run is not RCCL's first contact with this code (tests/test_hip_rccl_world1.py).
 """
 from __future__ import annotations
 
@@ -29,6 +32,18 @@ import torch.distributed as dist
 
 def under_torchrun() -> bool:
     return "WORLD_SIZE" in os.environ
+
+
+def force_pg() -> bool:
+    return os.environ.get("NB_FORCE_PG") == "1"
+
+
+def collective(world: Optional[int] = None) -> bool:
+    """Do the multi-rank branches run?  With more than one rank, or with ``NB_FORCE_PG=1`` once the process group exists."""
+    up = dist.is_available() and dist.is_initialized()
+    if world is None:
+        world = dist.get_world_size() if up else 1
+    return world > 1 or (force_pg() and up)
 
 
 def self_launch(script: str, argv: List[str], gpus: int) -> int:
@@ -60,8 +75,15 @@ def init(timeout_s: int = 300) -> Tuple[int, int, torch.device, str]:
         raise _lib.NeubeHipError("no GPU: the painting / generator path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_pg()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not under_torchrun():                       # NB_FORCE_PG=1 in a plain `python script.py`: a one-rank rendezvous on a free port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         tmo = datetime.timedelta(seconds=timeout_s)            # a wedged collective should fail the run, not hang it
         if backend == "nccl":
@@ -74,7 +96,7 @@ def init(timeout_s: int = 300) -> Tuple[int, int, torch.device, str]:
 def preflight(dev: torch.device, rank: int, world: int) -> None:
     """One small all-to-all + gather through the fabric, checked; raises SystemExit(3) on every rank if it fails (a job
     whose exchange does not work must not print a number)."""
-    if world == 1:
+    if not collective(world):
         return
     try:
         send = torch.full([world * 4], float(rank), device=dev)
@@ -100,7 +122,7 @@ def preflight(dev: torch.device, rank: int, world: int) -> None:
         raise SystemExit(3)
 
 
-def fabric_report(dev: torch.device, rank: int, world: int, backend: str) -> Optional[dict]:
+def fabric_report(dev: torch.device, rank: int, world: int, backend: str, collective: Optional[bool] = None) -> Optional[dict]:
     """Who is in the process group: every rank contributes (rank, host, pid, device index, PCI address / uuid of its device) through
     an all-gather; rank 0 returns {"world", "backend", "nccl_version", "ranks_seen", "distinct_devices"} for the benchmark line
     (None elsewhere, and at world 1 a one-entry report).  N ranks on fewer than N devices is an error unless the one-GPU test
@@ -112,7 +134,7 @@ def fabric_report(dev: torch.device, rank: int, world: int, backend: str) -> Opt
     mine = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "device_index": dev.index, "pci": pci,
             "uuid": str(ident) if ident is not None else None, "name": p.name}
     seen = [mine]
-    if world > 1:
+    if (globals()["collective"](world) if collective is None else collective):
         seen = [None] * world
         dist.all_gather_object(seen, mine)
     distinct = len({(s_["host"], s_["uuid"] or s_["pci"]) for s_ in seen})
@@ -132,6 +154,6 @@ def fabric_report(dev: torch.device, rank: int, world: int, backend: str) -> Opt
 
 
 def finish(world: int) -> None:
-    if world > 1 and dist.is_initialized():
+    if collective(world) and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -547,7 +547,9 @@ class SynthesisNetwork(torch.nn.Module):
                         ic, sc_ = specs_[f"synthesis.b{2 * gres}.conv0"]
                         gch = self.geom_feature_channels[g_idx]
                         ofmt = self._operand_fmt(sc_)
-                        if (self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 16 == 0 and gch % 16 == 0
+                        # (the encoder's hand-off epilogue writes H2 / f8 operands only: an f6 consumer gets the feature back in
+                        #  fp32 and the pack path below writes its operands)
+                        if (ofmt != 2 and self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 16 == 0 and gch % 16 == 0
                                 and tuple(lazy_geom.feature_shape(g_idx)) == (n, gch, gres, gres)
                                 and getattr(lazy_geom, "can_handoff", lambda i_: True)(g_idx)):
                             dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
@@ -677,8 +679,11 @@ class SynthesisNetwork(torch.nn.Module):
                     out_fmt = self._operand_fmt(nxt) if nxt_h3 else 0
                     geo_after = (self.geom_feature_channels[self.geom_feature_resolutions.index(res)]
                                  if at_block_end and res in self.geom_feature_resolutions else 0)
+                    # (the f6 operand format is written by the f8 / f6 up=1 loops only: a producer on H2 operands -- c_in not a
+                    #  multiple of 16 -- hands its output over in fp32 and the pack launch writes the consumer's operands)
                     fuse_out = (self.h2_handoff and me_h3 and nxt_h3 and not tapped and s.out_channels % 8 == 0
-                                and (out_fmt == 0 or (s.out_channels % 16 == 0 and geo_after % 16 == 0)))
+                                and (out_fmt == 0 or (s.out_channels % 16 == 0 and geo_after % 16 == 0))
+                                and (out_fmt != 2 or (in_fmt != 0 and s.up == 1)))
                     y = next_h2 = None
                     fused_rgb = None
                     if me_h3:
@@ -810,7 +815,7 @@ class SynthesisNetwork(torch.nn.Module):
                         inext, snext = specs[f"synthesis.b{2 * res}.conv0"]
                         c_prod = snext.in_channels - x2.shape[1]
                         evp = self._begin_event("pack_h2")
-                        part = lib.nb_pack_h2f8_part_f32 if self._operand_fmt(snext) else lib.nb_pack_h2_part_f32
+                        part = (lib.nb_pack_h2_part_f32, lib.nb_pack_h2f8_part_f32, lib.nb_pack_h2f6_part_f32)[self._operand_fmt(snext)]
                         _lib.check(part(_p(x2), x2.shape[1], plan.styles[inext].data_ptr() + 4 * c_prod, snext.in_channels,
                                         _p(x_h2), (snext.in_channels + 7) // 8, c_prod // 8, n, res * res, stream),
                                    "pack_h2_part")

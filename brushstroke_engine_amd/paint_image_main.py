@@ -107,7 +107,7 @@ def main(argv=None) -> str:
         Image.fromarray(result).save(output_file)
         logger.info(f"Saved result to: {output_file}")
         print(output_file)
-    if world > 1:
+    if launch.collective(world):
         dist.barrier()
     return output_file
 

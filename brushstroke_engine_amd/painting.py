@@ -237,8 +237,7 @@ class TileOps:
         # itself runs "f8" (its features then carry ~3e-4 instead of ~2e-5 absolute error on O(5) values)
         if hasattr(encoder, "arith"):
             encoder.arith = "f8" if getattr(G.synthesis, "conv_mode", None) == "f8" else "h3"
-        self._streams = None
-        self._forked = set()
+        self._rr = {}                # stream count -> pipeline.RoundRobinStreams (created at first use, kept across probes)
         self._graphs, self._graph_epoch, self._capturing = {}, None, False
 
     def _stream(self):
@@ -368,10 +367,17 @@ class TileOps:
     stream_probe = None          # what choose_streams measured: {"ms_per_batch": {1: .., 2: ..}, "chosen": n, "batch": n}
 
     def _set_n_streams(self, k: int) -> None:
-        """Change the number of batch streams; side streams created for another count are dropped (stream(k) indexes them)."""
-        if k != self.n_streams or (self._streams is not None and len(self._streams) != k):
-            self._streams, self._forked = None, set()
+        """Change the number of batch streams (every count keeps its own ``RoundRobinStreams``; ``stream(k)`` indexes the current one)."""
         self.n_streams = k
+
+    def _round_robin(self):
+        """The scheduler of the generator's throughput mode (``pipeline.RoundRobinStreams``, also behind ``ConcurrentTriadSteps`` /
+        ``bench.py``): batch b runs on stream b % n_streams with workspace slot PAINT_SLOT0 + b % n_streams."""
+        from .pipeline import RoundRobinStreams
+        rr = self._rr.get(self.n_streams)
+        if rr is None:
+            rr = self._rr[self.n_streams] = RoundRobinStreams(self.device, self.n_streams, PAINT_SLOT0)
+        return rr
 
     def choose_streams(self, n: int, render_mode: str = "clear") -> int:
         """Pick the number of batch streams for batches of ``n`` tiles: the fixed policy, or -- once per TileOps and batch size --
@@ -388,13 +394,10 @@ class TileOps:
         geom = [torch.randn([n, c, r, r], generator=gen).to(dev) for c, r in zip(cfg.geom_feature_channels, cfg.geom_feature_resolutions)]
         pos = torch.zeros([n, 2], dtype=torch.int64, device=dev)
         times = {1: [], 2: []}
-        keep_streams, keep_forked = self._streams, self._forked
-        state = {}
 
         def run(k, batches):
             # (each stream count keeps its own side streams across the interleaved rounds)
             self.n_streams = k
-            self._streams, self._forked = state.get(k, (None, set()))
             self.prepare(n, sorted({PAINT_SLOT0 + i % k for i in range(k)}))
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -404,7 +407,6 @@ class TileOps:
                     outs.append(self.full(ws, geom, pos, render_mode, None, None, slot=PAINT_SLOT0 + b % k))
             self.join_streams(outs)
             torch.cuda.synchronize(dev)
-            state[k] = (self._streams, self._forked)
             return (time.perf_counter() - t0) / batches * 1e3
         run(1, 2); run(2, 4)                             # workspaces, code objects, clocks
         for _ in range(3):                               # interleaved, best of three each: a single pair of short runs was off by
@@ -417,31 +419,24 @@ class TileOps:
         # 1.85 -> 1.87 ms per batch: a probe within noise must not cost the job its overlap; a box that loses with concurrent chains
         # (the round-3 driver run saw three streams 14 % below one) shows it as > 3 % here
         best = 1 if times[2] > 1.03 * times[1] else 2
-        self.n_streams, self._streams, self._forked = best, (keep_streams if keep_streams is not None and len(keep_streams) == best else None), keep_forked if keep_streams is not None and len(keep_streams) == best else set()
+        self.n_streams = best
         self.stream_probe = {"ms_per_batch": {str(k): round(v, 4) for k, v in times.items()}, "chosen": best, "batch": n}
         return best
 
     def stream(self, k: int):
         """Context manager: work of batch k goes to side stream k % n_streams (which first waits for the caller's)."""
-        if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)]
-            self._forked = set()
-        st = self._streams[k % self.n_streams]
-        if k % self.n_streams not in self._forked:
-            st.wait_stream(torch.cuda.current_stream(self.device))
-            self._forked.add(k % self.n_streams)
-        return torch.cuda.stream(st)
+        return self._round_robin().stream(k)
 
     def join_streams(self, tensors=()):
         """The caller's stream waits for the side streams; ``tensors`` produced there are about to be read here."""
-        main = torch.cuda.current_stream(self.device)
-        if self._streams is not None:
-            for st in self._streams:
-                main.wait_stream(st)
-            self._forked = set()
-        for t in tensors:
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(main)
+        rr = self._rr.get(self.n_streams)
+        if rr is not None:
+            rr.join(tensors)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            for t in tensors:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
 
     def comm_stream(self):
         """Context manager for the halo exchange: a side stream that first waits for everything enqueued so far on the
@@ -449,7 +444,8 @@ class TileOps:
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=self.device)
         self._comm.wait_stream(torch.cuda.current_stream(self.device))
-        for st in (self._streams or []):
+        rr = self._rr.get(self.n_streams)
+        for st in (rr.streams if rr is not None else []):
             self._comm.wait_stream(st)
         return torch.cuda.stream(self._comm)
 
@@ -614,7 +610,7 @@ class PaintingHelper:
         rank, world = self._world()
         rects, bounds = self._sync_layout
         self._canvas_rank_local, self._sync_layout = False, None
-        if world == 1 or self.features is None:
+        if not self._sharded(world) or self.features is None:
             return
         hc, wc = self.mask.shape
         y0, x0 = max(0, int(rects[:, 0].min())), max(0, int(rects[:, 1].min()))
@@ -657,6 +653,12 @@ class PaintingHelper:
             return dist.get_rank(self.group), dist.get_world_size(self.group)
         return 0, 1
 
+    def _sharded(self, world: int) -> bool:
+        """Does the call take the multi-rank schedule (halo exchange, pieces replay, tile gather)?  With more than one rank -- or at
+        world size 1 under ``NB_FORCE_PG=1`` once the process group exists (launch.py: the very collectives of the N > 1 job, through
+        RCCL, on a one-GPU box; same canvases as the single-process schedule)."""
+        return world > 1 or (os.environ.get("NB_FORCE_PG") == "1" and dist.is_available() and dist.is_initialized())
+
     # -- the schedule --
     def _schedule(self, geom_img: np.ndarray, geom_yx: np.ndarray, areas_yx: np.ndarray, positions: Optional[np.ndarray],
                   opts: GanBrushOptions, crop_margin: int) -> Optional[torch.Tensor]:
@@ -666,9 +668,10 @@ class PaintingHelper:
         and leaves the feature canvas updated -- the result of the reference's tile-by-tile loop."""
         ops, R = self.ops, self.patch_width
         rank, world = self._world()
+        sharded = self._sharded(world)
         T = areas_yx.shape[0]
         level, df = self.feature_blending_level, self.down_factor
-        if world > 1 and level > 0 and self._canvas_rank_local:
+        if sharded and level > 0 and self._canvas_rank_local:
             self.sync_canvas()                   # the previous sharded call left every rank with ITS tiles' paint sequence only
         t0, t1 = shard_bounds(T, rank, world)
         n_own = t1 - t0
@@ -730,9 +733,18 @@ class PaintingHelper:
             alpha0 = self._alpha0(bres, margin, crop_sc)
             # halo plan: the strips of earlier foreign tiles under my tiles (recv) and of my tiles under later ranks' (send)
             bounds = [shard_bounds(T, r, world) for r in range(world)]
-            plan = halo_plan(rects, bounds) if world > 1 else {}
+            plan = halo_plan(rects, bounds) if sharded else {}
             send = {d: plan[(rank, d)] for d in range(world) if (rank, d) in plan}
             recv = {s_: plan[(s_, rank)] for s_ in range(world) if (s_, rank) in plan}
+            # one rank under NB_FORCE_PG=1: nothing to exchange, so the all-to-all would carry no bytes -- let it carry ONE strip of
+            # my first tile to myself (checked bit for bit after the exchange, not replayed): the packing, the split lists and the
+            # collective itself then run as they do between ranks
+            self_probe = None
+            if sharded and world == 1 and n_own:
+                r0 = rects[t0]
+                self_probe = (t0, (int(r0[0]), int(r0[1]), int(r0[0]) + min(bres, 20), int(r0[3])))
+                send = {0: [self_probe]}
+                recv_probe = {0: [self_probe]}
             first_send = min((f for lst in send.values() for f, _ in lst), default=t1) - t0
             # phase 1: everything up to the blending resolution, own tiles.  The batches run last-to-first: the tiles the
             # later ranks need (the end of my range) finish first, and their strips travel under the rest of phase 1.
@@ -741,7 +753,7 @@ class PaintingHelper:
             work = recv_buf = send_buf = None
             nfl = lambda lst: sum(C * (q[2] - q[0]) * (q[3] - q[1]) for _, q in lst)
             in_split = [nfl(send.get(d, [])) for d in range(world)]
-            out_split = [nfl(recv.get(s_, [])) for s_ in range(world)]
+            out_split = [nfl((recv if self_probe is None else recv_probe).get(s_, [])) for s_ in range(world)]
             comm = getattr(ops, "comm_stream", lambda: contextlib.nullcontext())
 
             def exchange():
@@ -760,9 +772,9 @@ class PaintingHelper:
                     gf = ops.encode(ops.geom_tiles(geom_dev, own_yx[b0:b1]))
                     geom_feats_own[k] = gf
                     mine[b0:b1] = ops.head(style(b1 - b0), gf, pos(b0, b1), bres, slot=plan_slot(k))
-                if world > 1 and work is None and b0 <= first_send:
+                if sharded and work is None and b0 <= first_send:
                     exchange()
-            if world > 1 and work is None:
+            if sharded and work is None:
                 exchange()                                                        # (a rank without tiles still takes part)
             join()
             if work is not None:
@@ -773,8 +785,13 @@ class PaintingHelper:
                 getattr(ops, "join_comm", lambda tensors=(): None)([recv_buf])
                 if ev is not None:
                     ev[1].record()
+                if self_probe is not None:
+                    f, q = self_probe
+                    src = mine[f - t0, :, q[0] - rects[f, 0]:q[2] - rects[f, 0], q[1] - rects[f, 1]:q[3] - rects[f, 1]].reshape(-1)
+                    if recv_buf.numel() != src.numel() or not torch.equal(recv_buf, src):
+                        raise RuntimeError("NB_FORCE_PG: the strip sent to myself through all_to_all_single came back changed")
             # phase 2: the sequential canvas blend of my tiles, replayed in one launch
-            if world == 1:
+            if not sharded:
                 off, lst = build_cells(rects, hc, wc)
                 # few tiles on a large canvas (interactive strokes): replay only the cells inside their bounding box
                 box = None
@@ -803,7 +820,7 @@ class PaintingHelper:
                 box = (int(own_r[:, 0].min()), int(own_r[:, 1].min()), int(own_r[:, 2].max()), int(own_r[:, 3].max()))
                 self.mask = ops.replay_pieces(pieces, bres, alpha0, crop_sc, self.features, self.mask,
                                               ops.to_device(off), ops.to_device(lst), box)
-            if world > 1:
+            if sharded:
                 # my canvas now holds the paint sequence under MY tiles only; what it takes to make it whole again
                 # (sync_canvas, run lazily by the next sharded call on this canvas) is the tile layout of this call
                 self._canvas_rank_local = True
@@ -815,7 +832,7 @@ class PaintingHelper:
                                          self.render_mode, colors(b1 - b0), sfac, slot=plan_slot(i)))
             join(outs)
         rgba_own = torch.cat(outs) if outs else None
-        if world == 1:
+        if not sharded:
             return rgba_own
         buf = torch.zeros([n_pad, R, R, 4], dtype=torch.uint8, device=ops.device)
         if n_own:

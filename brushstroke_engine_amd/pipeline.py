@@ -205,3 +205,119 @@ class TriadPrefetchPipeline:
     def flush(self) -> None:
         self.wait()
         self._forked = False
+
+
+ROUND_SLOT0 = 32         # workspace slots of the round-robin schedule (one per stream)
+
+
+class RoundRobinStreams:
+    """``k`` HIP streams that independent work items are dealt to in turn: item ``i`` runs on stream ``i % k`` with the generator
+    workspace slot ``slot0 + i % k`` (a slot's styles / coefficient / noise buffers are rewritten by every pass, so passes that may
+    overlap need their own; passes on ONE stream are ordered by it).  The kernels of the other chains fill the CUs a chain leaves idle
+    in its kernel tails and in its small, latency-bound launches (a fifth of a batch-32 step at R=256).  Shared by the throughput
+    schedule of whole steps (``ConcurrentTriadSteps``, ``bench.py``) and the tiled-canvas schedule (``painting.TileOps``)."""
+
+    def __init__(self, device, k: int, slot0: int = ROUND_SLOT0):
+        if k < 1:
+            raise RuntimeError("RoundRobinStreams needs at least one stream")
+        self.device, self.k, self.slot0 = device, int(k), int(slot0)
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.k)]
+        self._forked = set()
+
+    def slot(self, i: int) -> int:
+        return self.slot0 + i % self.k
+
+    def stream_of(self, i: int) -> "torch.cuda.Stream":
+        return self.streams[i % self.k]
+
+    def stream(self, i: int):
+        """Context manager: work of item ``i`` goes to stream ``i % k``, which first (once per fork) waits for the caller's stream."""
+        j = i % self.k
+        if j not in self._forked:
+            self.streams[j].wait_stream(torch.cuda.current_stream(self.device))
+            self._forked.add(j)
+        return torch.cuda.stream(self.streams[j])
+
+    def join(self, tensors=(), stream=None) -> None:
+        """``stream`` (default: the caller's current one) waits for all k streams; ``tensors`` produced there are about to be read
+        here.  The next ``stream(i)`` forks from the caller's stream again."""
+        main = torch.cuda.current_stream(self.device) if stream is None else stream
+        for st in self.streams:
+            main.wait_stream(st)
+        self._forked = set()
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
+
+
+class ConcurrentTriadSteps:
+    """The default throughput schedule of whole generator steps: up to ``streams`` independent batches in flight, dealt round-robin to
+    that many HIP streams, each with its own workspace slot (``RoundRobinStreams``).  Every batch is the plain
+    ``Generator.render_triad`` pass, so results are bit-identical to the serial loop (tests/test_hip_generator.py).  The reference's
+    counterpart is the batched generate loop of ``forger/metrics/util.py:280-292`` (one batch after the other on one stream).
+
+    ``submit`` returns the batch's uint8 RGBA tiles ``[N, R, R, 4]``, valid on the stream they were rendered on (``last_stream``);
+    ``wait()`` makes the caller's stream wait for everything submitted.  ``streams=0`` picks 1 or 3 streams by a probe
+    (``choose``): concurrent chains gain 4-9 % on most boxes and lost 14 % on one (three chains of 156 KB-LDS workgroups evicting each
+    other at kernel boundaries), so the schedule measures instead of assuming."""
+
+    def __init__(self, G, streams: int = 3, render_mode: str = "clear", slot0: int = ROUND_SLOT0):
+        dev = G.synthesis.get_last_block().conv1.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("ConcurrentTriadSteps needs the generator on a GPU")
+        self.G, self.device, self.render_mode, self.slot0 = G, dev, render_mode, slot0
+        self.probe = None
+        self._rr = {}
+        self._set_streams(max(1, int(streams)) if streams else 3)
+        self._auto = not streams
+        self._i = 0
+        self.last_stream = None
+
+    def _set_streams(self, k: int) -> None:
+        if k not in self._rr:
+            self._rr[k] = RoundRobinStreams(self.device, k, self.slot0)
+        self.rr = self._rr[k]
+        self.streams = k
+
+    def choose(self, z, geom_feature, positions, rounds: int = 3, steps: int = 6) -> int:
+        """1 or 3 streams for batches like this one: ``rounds`` interleaved pairs of ``steps`` steps each, best of each; three unless
+        they are more than 3 % slower HERE.  ~15 steps' worth of time; the figures stay in ``probe``."""
+        import time
+        times = {1: [], 3: []}
+
+        def run(k, nsteps):
+            self._set_streams(k)
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                self.submit(z, geom_feature, positions)
+            self.wait()
+            torch.cuda.synchronize(self.device)
+            return (time.perf_counter() - t0) / nsteps * 1e3
+        run(1, 2); run(3, 3)                              # workspaces of the slots, code objects
+        for _ in range(rounds):
+            times[1].append(run(1, steps))
+            times[3].append(run(3, steps))
+        best = {k: min(v) for k, v in times.items()}
+        pick = 1 if best[3] > 1.03 * best[1] else 3
+        self._set_streams(pick)
+        self.probe = {"ms_per_step": {str(k): round(v, 4) for k, v in best.items()}, "chosen": pick, "batch": int(z.shape[0])}
+        return pick
+
+    def submit(self, z=None, geom_feature=None, positions=None, ws=None, user_colors=None, sfactor=None) -> torch.Tensor:
+        if self._auto and self.probe is None:
+            self._auto = False                              # (choose() itself submits)
+            if z is not None and ws is None:
+                self.choose(z, geom_feature, positions)
+        i, self._i = self._i, self._i + 1
+        cur = torch.cuda.current_stream(self.device)
+        with self.rr.stream(i):
+            u8, _, _ = self.G.render_triad(z=z, ws=ws, geom_feature=geom_feature, positions=positions, render_mode=self.render_mode,
+                                           user_colors=user_colors, sfactor=sfactor, _plan_slot=self.rr.slot(i))
+        self.last_stream = self.rr.stream_of(i)
+        u8.record_stream(cur)             # allocated on a side stream, consumed on the caller's (after wait()); no reference is kept
+        return u8
+
+    def wait(self, stream=None) -> None:
+        """Make ``stream`` (default: the caller's current one) wait for every step submitted so far."""
+        self.rr.join(stream=stream)

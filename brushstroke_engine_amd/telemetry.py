@@ -101,14 +101,20 @@ class PowerClockSampler:
         self.windows[name] = [time.perf_counter(), float("inf")]
 
     def unmark(self, name: str):
+        """Close (or move on) the end of window ``name``; its start stays where ``mark`` put it."""
         if name in self.windows:
             self.windows[name][1] = time.perf_counter()
+
+    MIN_SAMPLES = 20          # means over fewer ticks are noise (a 36 ms window sees 3-4): summary() then reports the count only
 
     def summary(self, name: str) -> dict:
         if not self.available:
             return {"power_w_mean": None, "sclk_mhz_mean": None, "samples": 0, "source": "no readable amdgpu hwmon files on this box"}
         t0, t1 = self.windows.get(name, [0.0, 0.0])
         sel = [s for s in list(self.samples) if t0 <= s[0] <= t1]
+        if len(sel) < self.MIN_SAMPLES:
+            return {"samples": len(sel), "window_ms": round((t1 - t0) * 1e3, 2),
+                    "source": f"fewer than {self.MIN_SAMPLES} samples in the window: no power / clock means reported"}
         ws = [s[1] for s in sel if s[1] is not None]
         fs = [s[2] for s in sel if s[2] is not None]
         return {"power_w_mean": round(sum(ws) / len(ws), 1) if ws else None, "power_w_max": round(max(ws), 1) if ws else None,

@@ -15,6 +15,8 @@ This is the first, unfused training-mode path: correct gradients, not a tuned st
 """
 from __future__ import annotations
 
+import os
+
 import collections.abc
 
 import math
@@ -415,7 +417,7 @@ class GanLoss:
         touches (the path-length phase differentiates w.r.t. an intermediate tensor, frozen networks take no gradient).
         Returns the number of gradient elements reduced."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and os.environ.get("NB_FORCE_PG") != "1"):
             return 0
         params = [p for p in module.parameters() if p.requires_grad]
         for p in params:                                  # every rank must contribute the same tensors

@@ -14,7 +14,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                "data", "config", "roofline", "box_calibration", "telemetry", "modes", "detail_file")
+                "data", "config", "roofline", "box_calibration", "modes", "detail_file")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_per_step", "flops_per_launch")
 
 
@@ -61,6 +61,18 @@ def test_bench_self_spawns_two_ranks():
     assert len(out["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in out["ms_per_step_per_rank"])
     assert out["gather_wait_ms"]["waits"] >= 3 and out["gather_wait_ms"]["host_ms_per_step"] >= 0
     assert out["box_calibration"]["mfma_f16_sustained_tflops"] > 100
+    assert out["streams"] in (1, 3) and out["value_single_stream"] > 0
+
+
+def test_bench_single_schedule_and_f6_on_request():
+    """`--schedule single` is the one-stream loop alone (what the A/B tools and the profiler passes run); `--modes f6` still
+    measures the round-5 experiment when asked."""
+    r = _run(["--steps", "2", "--warmup", "1", "--res", "128", "--batch", "8", "--no-latency", "--no-cpu", "--schedule", "single",
+              "--modes", "f8,f6"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_line(r.stdout)
+    assert set(out["modes"]) == {"f8", "f6"} and "value_single_stream" not in out and "streams" not in out
+    assert "one stream" in _detail(out)["schedule"]
 
 
 def test_bench_line_carries_every_arithmetic_mode():
@@ -70,7 +82,9 @@ def test_bench_line_carries_every_arithmetic_mode():
     r = _run(["--steps", "2", "--warmup", "1", "--res", "128", "--batch", "8", "--no-latency", "--cpu-seconds", "1"])
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_line(r.stdout)
-    assert set(out["modes"]) == {"f8", "h3", "f32", "f6"} and out["conv_mode"] == "f8"
+    assert set(out["modes"]) == {"f8", "h3", "f32"} and out["conv_mode"] == "f8"         # (f6, the round-5 experiment: only with --modes f6 / all)
+    # the headline is the library's concurrent schedule; the single-stream figure the roofline comes from rides along
+    assert out["streams"] in (1, 3) and out["value_single_stream"] > 0 and out["modes"]["h3"]["value_single_stream"] > 0
     assert out["value"] == out["modes"]["f8"]["value"] and out["value_fp32_parity"] == out["modes"]["h3"]["value"]
     assert not out["dtype"].startswith("f32")
     tol = {"f8": 3e-4, "h3": 2e-5, "f32": 2e-5, "f6": 6e-4}             # (f6: the round-5 experiment, tests/test_hip_f6.py)
@@ -88,7 +102,10 @@ def test_bench_line_carries_every_arithmetic_mode():
     # and shader clock during each mode's timed region
     assert 500 < out["box_calibration"]["mfma_f16_sustained_tflops"] < 2600 and out["box_calibration"]["loop_clock_mhz"] > 500
     for m, rec in out["modes"].items():
-        assert "telemetry" in rec and "power_w_mean" in rec["telemetry"] and "sclk_mhz_mean" in rec["telemetry"]
+        # (means only over >= 20 sampler ticks: the window runs from the mode's burn-in to the end of its last timed region)
+        assert "telemetry" in rec and ("power_w_mean" in rec["telemetry"] or rec["telemetry"]["samples"] < 20)
+        assert "single-stream" in rec["schedule"] or "in flight" in rec["schedule"]
+        assert rec["single_stream"]["ms_per_step"] > 0 and "SINGLE-STREAM" in rec["roofline"]["note"]
         if m != "f32":
             assert 0 < rec["roofline"]["frac_of_sustained"] < 1
 

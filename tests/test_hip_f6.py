@@ -168,3 +168,46 @@ def _f6_generator_mode_body(load_golden, cfgmod, synthetic, wmod, Generator):
                 assert 2 in G.synthesis.layer_formats.values(), G.synthesis.layer_formats
         print(f"[f6 mode {name}] pixel error vs the reference: f8 {errs['f8']:.2e}  f6 {errs['f6']:.2e}")
         assert errs["f6"] <= tol and errs["f8"] <= 3e-4, errs
+
+
+def test_f6_inline_geometry_pack_and_lazy_geometry():
+    """The two paths the round-5 review found wrong in conv_mode "f6" (ADVICE r05): (a) the IN-LINE geometry pack -- taken when the early
+    side-stream pack is off or the geometry tensors are not contiguous fp32 -- must write the f6 layout the consuming up=2 kernel decodes
+    (it wrote f8 fields, scale byte arbitrary); (b) a LazyGeometry provider must not be asked for an f6 hand-off the encoder's epilogue
+    cannot write (it raised for every batch): the feature comes back in fp32 and the pack writes the operands.  Both must give the pixels
+    of the default path."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic, weights as wmod, encoder as encmod, _lib
+    from brushstroke_engine_amd.networks import Generator
+    _lib.lib().nb_debug_set_up2_v2(1)
+    try:
+        cfg = cfgmod.style1_config(128)
+        n = 8
+        G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode="f6").to("cuda")
+        z = torch.from_numpy(synthetic.batch_z(cfg, n, 3)).cuda()
+        geom = [torch.from_numpy(x).cuda() for x in synthetic.geom_features(cfg, n, seed=2)]
+        pos = torch.from_numpy(synthetic.positions(cfg, n, seed=2)).cuda()
+        _, want = G(z, None, geom, positions=pos, return_debug_data=True, noise_mode="const")
+        assert 2 in G.synthesis.layer_formats.values()
+        # (a) in-line pack: switched off early pack, then fp16 geometry (the early pack skips non-fp32 tensors)
+        G.synthesis.early_geom_pack = False
+        _, got = G(z, None, geom, positions=pos, return_debug_data=True, noise_mode="const")
+        assert torch.equal(got["uvs"], want["uvs"])                       # same pack kernel, same operands: bit-identical
+        G.synthesis.early_geom_pack = True
+        geom16 = [g.half() for g in geom]
+        _, want16 = G(z, None, [g.float() for g in geom16], positions=pos, return_debug_data=True, noise_mode="const")
+        _, got16 = G(z, None, geom16, positions=pos, return_debug_data=True, noise_mode="const")
+        assert torch.equal(got16["uvs"], want16["uvs"]) and bool(torch.isfinite(got16["uvs"]).all())
+        # (b) lazy geometry in f6 mode at R=256 (the encoder's hand-off target is the 64x64 -> b128.conv0 input, an f6 consumer)
+        cfg = cfgmod.style1_config(256)
+        G = Generator(cfg, wmod.random_state_dict(cfg, seed=0), conv_mode="f6").to("cuda")
+        enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5))
+        n = 8
+        rs = np.random.RandomState(3)
+        gimg = torch.from_numpy((rs.rand(n, 1, 256, 256) > 0.1).astype(np.float32)).cuda()
+        ws = G.mapping(torch.from_numpy(synthetic.batch_z(cfg, n, 7)).cuda(), None)
+        pos = torch.from_numpy(synthetic.positions(cfg, n, seed=1)).cuda()
+        _, want = G.forward_pre_mapped(ws, enc.encode(gimg), positions=pos, return_debug_data=True, noise_mode="const")
+        _, got = G.forward_pre_mapped(ws, enc.lazy(gimg), positions=pos, return_debug_data=True, noise_mode="const")
+        assert float((got["uvs"] - want["uvs"]).abs().max()) <= 2e-5
+    finally:
+        _lib.lib().nb_debug_set_up2_v2(-1)

@@ -377,6 +377,38 @@ def test_prefetch_pipeline_equals_plain_steps(dev, mode, res, n):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mode,res,n,streams", [("f8", 256, 32, 3), ("h3", 256, 32, 3), ("f8", 128, 32, 2), ("f32", 128, 8, 3), ("f8", 256, 1, 3),
+                                                ("f8", 256, 32, 0)])
+def test_concurrent_steps_equal_serial_steps(dev, mode, res, n, streams):
+    """pipeline.ConcurrentTriadSteps -- the library's throughput schedule and bench.py's headline: independent steps dealt round-robin
+    to k HIP streams with a workspace slot each -- returns, for a sequence of DIFFERENT batches, exactly the bytes the serial loop of
+    Generator.render_triad returns for each of them (batch 32 at R=256 is BASELINE.json configs[1]); streams=0 = the probe."""
+    from brushstroke_engine_amd import config as cfgmod, synthetic
+    from brushstroke_engine_amd.pipeline import ConcurrentTriadSteps
+    cfg = cfgmod.style1_config(res)
+    G, _ = build(cfg, 0, dev, mode)
+    batches = []
+    for k in range(5):
+        batches.append((D(synthetic.batch_z(cfg, n, 50 + k * n), dev), [D(x, dev) for x in synthetic.geom_features(cfg, n, seed=k)],
+                        D(synthetic.positions(cfg, n, seed=k), dev)))
+    want = [G.render_triad(z=z, geom_feature=g, positions=p)[0].clone() for z, g, p in batches]
+    sched = ConcurrentTriadSteps(G, streams=streams)
+    for rep in range(3):
+        got = [sched.submit(z, g, p) for z, g, p in batches]
+        sched.wait()
+        for a, b in zip(got, want):                       # (read on the caller's stream, which wait() ordered behind the side streams)
+            assert torch.equal(a, b)
+    if streams == 0:
+        assert sched.probe is not None and sched.probe["chosen"] == sched.streams and sched.streams in (1, 3)
+    else:
+        assert sched.streams == streams and sched.probe is None
+    # the W+ entry (StyleUVSMapper / brush libraries with stored W+ codes) goes through the same schedule
+    ws = G.mapping(batches[0][0], None)
+    got = sched.submit(ws=ws, geom_feature=batches[0][1], positions=batches[0][2])
+    sched.wait()
+    assert torch.equal(got, want[0])
+
+
 @pytest.mark.parametrize("mode", ["f32", "h3", "f8"])
 def test_trained_like_fixture(dev, mode):
     """Trained-like weight statistics (weights.trained_like_state_dict: log-normal per-channel scales, two dominant styles per

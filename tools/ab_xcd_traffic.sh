@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab_xcd; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in old new; do
   if [ $v = old ]; then export NB_DEBUG=32; else unset NB_DEBUG; fi
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$v -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode f8 > $O/fetch_$v.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$v -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --schedule single --modes primary --conv-mode f8 > $O/fetch_$v.log 2>&1
   echo "== $v"; python3 $R/tools/pmc_mem_summary.py $O/fetch_$v /nonexistent /nonexistent | grep up2
 done
 unset NB_DEBUG

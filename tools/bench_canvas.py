@@ -91,7 +91,7 @@ def main():
     else:
         line = run(a, rank, world, dev, backend)
     if rank == 0:
-        if world > 1:
+        if launch.collective(world):
             line["rccl"] = fabric
         print(json.dumps(line), flush=True)
     launch.finish(world)
@@ -100,6 +100,7 @@ def main():
 def run(a, rank, world, dev, backend):
     """One configuration on an initialised process (group); returns the JSON-able result on rank 0, None elsewhere."""
     _TIMES.clear()
+    multi = launch.collective(world)             # N > 1, or NB_FORCE_PG=1 at N = 1 (the same branches through RCCL on one GPU)
     gold = None
     if a.lamali:
         a.res = 256
@@ -121,7 +122,7 @@ def run(a, rank, world, dev, backend):
         _wrap_timers(ops)
     full = line = None
     for i in range(a.warmup + a.steps):
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -131,10 +132,10 @@ def run(a, rank, world, dev, backend):
         else:
             helper.paint_image(geom, opts, crop_margin=a.crop_margin)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         dt = torch.tensor([time.perf_counter() - t0], device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         if i >= a.warmup:
             times.append(float(dt))
@@ -144,12 +145,12 @@ def run(a, rank, world, dev, backend):
                 _TIMES.clear()
     # per-rank figures: halo bytes of the exchange, per-phase device time
     torch.cuda.synchronize()
-    comm = helper.comm_times() if world > 1 else {}
+    comm = helper.comm_times() if multi else {}
     mine = {"rank": rank, "halo_bytes": helper.halo_bytes, "seconds": float(np.mean(times)) if times else None,
             "comm_ms_per_step": {k: round(v / max(1, a.steps), 4) for k, v in comm.items() if k != "calls"},
             "breakdown_ms": {k: round(sum(e0.elapsed_time(e1) for e0, e1 in v) / a.steps, 3) for k, v in _TIMES.items()} if _TIMES else None}
     per_rank = [mine]
-    if world > 1:
+    if multi:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     if rank == 0:
@@ -161,13 +162,13 @@ def run(a, rank, world, dev, backend):
                 "res": a.res, "feature_blending_level": a.level,
                 "crop_margin": a.crop_margin, "batch": a.batch, "conv_mode": a.conv_mode, "encoder": a.encoder, "steps": a.steps,
                 "stroke_fraction": float((geom == 0).mean()),
-                "parallelism": "single GPU" if world == 1 else
+                "parallelism": "single GPU" if not multi else
                                f"tiles in {world} contiguous ranges; halo strips by one all_to_all_single ({'RCCL' if backend == 'nccl' else backend}) "
                                f"under phase 1, RGBA tiles gathered on rank 0",
                 "timing": "max over ranks of the wall clock between barriers, mean over steps"}
         line["n_streams"] = getattr(ops, "n_streams", None)
         line["stream_probe"] = getattr(ops, "stream_probe", None)
-        if world > 1:
+        if multi:
             line["halo_bytes_per_rank"] = [p["halo_bytes"] for p in per_rank]
             # what the collectives cost each rank's stream per painted canvas: the part of the halo exchange phase 1 did not
             # hide, and the gather of the RGBA tiles (rank 0 waits for everybody's); HIP events around the waits

@@ -34,7 +34,7 @@ def main():
         line = {"metric": "lamali_sm.png end to end (host geometry -> host RGBA), 12 tiles of 256x256", "n_gpus": world,
                 "conv_mode": a.conv_mode, "parallelism": res[2]["parallelism"], "image": res[2]["canvas"],
                 "feature_blending_2": keep(res[2]), "feature_blending_0": keep(res[0])}
-        if world > 1:
+        if launch.collective(world):
             line["rccl"] = fabric                           # who took part (launch.fabric_report): world, backend, ranks seen, distinct devices
         print(json.dumps(line), flush=True)
     launch.finish(world)

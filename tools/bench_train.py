@@ -35,15 +35,22 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # NB_FORCE_PG=1: the process group (RCCL) at any world size, and every `world > 1` branch below with it (launch.py)
+    multi = world > 1 or os.environ.get("NB_FORCE_PG") == "1"
+    backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
+        if "WORLD_SIZE" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     cfg = cfgmod.style1_config(a.res)
     G = TrainableGenerator(cfg, wmod.random_state_dict(cfg, 0), dev)
     D = TrainableDiscriminator(random_discriminator_state_dict(a.res, 3, channel_base=16384, channel_max=128), a.res, 3,
                                channel_base=16384, channel_max=128, conv_clamp=256, device=dev)
-    if world > 1:                                        # same initial weights everywhere (they are seeded: a cheap check)
+    if multi:                                        # same initial weights everywhere (they are seeded: a cheap check)
         chk = torch.stack([next(G.parameters()).flatten()[:8].sum(), next(D.parameters()).flatten()[:8].sum()])
         ref = chk.clone(); dist.broadcast(ref, 0)
         assert torch.equal(chk, ref)
@@ -59,30 +66,33 @@ def main():
     real = torch.tanh(torch.nn.functional.interpolate(torch.randn(n, 3, 8, 8, device=dev), size=a.res, mode="bilinear"))
     real_geom = (torch.rand(n, 1, a.res, a.res, device=dev) > 0.08).float()
 
+    reduced = [0]
+
     def iteration(it):
+        reduced[0] = 0
         z = torch.randn(n, cfg.z_dim, device=dev)
         optG.zero_grad(set_to_none=True)
         loss.accumulate_gradients("Gmain", real, geom, z)
         if it % 4 == 0:
             loss.accumulate_gradients("Greg", real, geom, z, gain=4)
-        loss.all_reduce_gradients(G)
+        reduced[0] += loss.all_reduce_gradients(G)
         optG.step()
         optD.zero_grad(set_to_none=True)
         loss.accumulate_gradients("Dmain", real, geom, z)
         if it % 16 == 0:
             loss.accumulate_gradients("Dreg", real, geom, z, gain=16)
-        loss.all_reduce_gradients(D)
+        reduced[0] += loss.all_reduce_gradients(D)
         optD.step()
         if a.geom_interval > 0 and it % a.geom_interval == 0:
             optGeom.zero_grad(set_to_none=True)
             loss.accumulate_gradients("Ggeom", real, geom, z, real_geom=real_geom)
-            loss.all_reduce_gradients(G)
+            reduced[0] += loss.all_reduce_gradients(G)
             optGeom.step()
 
     for it in range(a.warmup):
         iteration(it)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     if a.hostprof:
         import cProfile, pstats
@@ -96,19 +106,22 @@ def main():
         st.sort_stats("cumulative").print_stats(60); st.sort_stats("tottime").print_stats(45)
     t_issue = time.perf_counter() - t0                   # the host is done issuing; the device may still be working
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t)
     if rank == 0:
         print(json.dumps({"metric": "training throughput, images/s (G+D fwd/bwd, lazy path-length and R1 regularisation, ADA bgc)",
                           "value": round(world * n * a.iters / dt, 2), "unit": "img/s", "n_gpus": world, "ms_per_iteration": round(dt / a.iters * 1e3, 2),
                           "host_issue_ms_per_iteration": round(t_issue / a.iters * 1e3, 2),
                           "config": {"resolution": a.res, "batch_per_gpu": n, "schedule": f"Gmain 1/1, Greg 1/4, Dmain 1/1, Dreg 1/16, Ggeom 1/{a.geom_interval}",
-                                     "parallelism": f"data-parallel x{world}" + (" (one all-reduce of the flattened gradients per optimiser step, RCCL)" if world > 1 else "")},
+                                     "parallelism": f"data-parallel x{world}" + (" (one all-reduce of the flattened gradients per optimiser step, RCCL)" if multi else "")},
+                          **({"rccl": {"backend": ("RCCL (torch backend nccl)" if backend == "nccl" else backend), "world": world,
+                                       "nccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None),
+                                       "gradient_elements_reduced_per_step": reduced[0]}} if multi else {}),
                           "dtype": "f32", "data": "synthetic"}))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -13,19 +13,19 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --res 128 --no-cpu --modes primary --detail $O/bench_r128_f8_detail.json > $O/bench_r128_f8.json 2> $O/bench_r128.err
 # per-kernel averages of the same command (timing pass: kernel trace + stats only), per mode
 for m in f8 h3 f32; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode $m > $O/stats_$m.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-latency --schedule single --modes primary --conv-mode $m > $O/stats_$m.log 2>&1
   cp $(ls $O/stats_$m/*/*kernel_stats.csv | head -1) $O/kernel_stats_$m.csv 2>/dev/null
 done
 # counters: each group in its own pass, with the kernel trace only; memory counters per mode, MFMA-busy for the split modes
 for m in f8 h3 f32; do
   for c in "hit:TCC_HIT_sum TCC_MISS_sum" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
     n=${c%%:*}
-    rocprofv3 --kernel-trace --pmc ${c#*:} --output-format csv -d $O/pmc_${n}_$m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode $m > $O/pmc_${n}_$m.log 2>&1
+    rocprofv3 --kernel-trace --pmc ${c#*:} --output-format csv -d $O/pmc_${n}_$m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --schedule single --modes primary --conv-mode $m > $O/pmc_${n}_$m.log 2>&1
   done
   (cd $R && python tools/pmc_mem_summary.py $O/pmc_hit_$m $O/pmc_fetch_$m $O/pmc_write_$m $O/pmc_mem_$m.json > $O/pmc_mem_$m.txt 2>&1)
 done
 for m in f8 h3; do
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --modes primary --conv-mode $m > $O/pmc_mfma_$m.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-latency --schedule single --modes primary --conv-mode $m > $O/pmc_mfma_$m.log 2>&1
   (cd $R && python tools/pmc_summary.py $O/pmc_mfma_$m > $O/pmc_mfma_busy_$m.txt 2>&1)
 done
 cd $R
