@@ -59,7 +59,7 @@ def layer_flops(spec, batch):
 
 def is_split_kernel(kname):
     """Kernels that multiply in f16 (+ fp8 corrections): the split-f16 family, incl. the two re-tiled up=2 kernels of round 4."""
-    return "_h3_" in kname or "up2v_kernel" in kname or "up2w_kernel" in kname
+    return "_h3_" in kname or "up2v_kernel" in kname
 
 
 def kernel_label(spec):
@@ -756,6 +756,12 @@ def main():
     from brushstroke_engine_amd import build as _build, _lib as _nblib
     _build.build(verbose=False)
     _nblib.lib()
+    try:                                                  # developer A/B switches (NB_UP1_PP=0 ...): the library itself reads no environment
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import nb_debug_env
+        dbg_env = nb_debug_env.apply(_nblib.lib())
+    except ImportError:
+        dbg_env = {}
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # NB_FORCE_PG=1: create the process group (RCCL) at ANY world size and take every `N > 1` branch below -- pre-flight, fabric report,
@@ -870,6 +876,7 @@ def main():
                                                                     f"inside every step (rank 0 receives {world - 1} x {B * args.res * args.res * 4 / 1e6:.1f} MB "
                                                                     f"per step; see gather_wait_ms / ms_per_step_per_rank / rccl)") if gather else " (NO gather: --no-gather)")},
             "schedule": prim["schedule"],
+            **({"debug_switches": dbg_env} if dbg_env else {}),
             "box_calibration": calib,
             "telemetry": prim.get("telemetry"),
             "roofline": prim["roofline"],

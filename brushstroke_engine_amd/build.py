@@ -16,7 +16,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libneube_hip.so")
-SOURCES = ["nb_ops.hip", "nb_modconv.hip", "nb_modconv_h3.hip", "nb_modconv_up2w.hip", "nb_modconv_up2v.hip", "nb_modconv_small.hip", "nb_grad.hip", "nb_canvas.hip", "nb_encoder.hip", "nb_calib.hip"]
+SOURCES = ["nb_ops.hip", "nb_modconv.hip", "nb_modconv_h3.hip", "nb_modconv_up2v.hip", "nb_modconv_small.hip", "nb_grad.hip", "nb_canvas.hip", "nb_encoder.hip", "nb_calib.hip"]
 HEADERS = ["nb_common.h", "nb_h3_common.h", "nb_torgb.h", os.path.join("..", "..", "include", "neube_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
@@ -26,10 +26,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fn
 # vectorisation -- it pairs their scalar arithmetic into swizzled packed fp32 instructions, which misbehave on this hardware
 # (NB_NO_PACKED_F32 in csrc/nb_common.h has the story); these kernels have no use for packed arithmetic.  (The function attribute
 # that removes packed fp32 per kernel costs the ToRGB kernel 384 bytes of scratch: helpers are no longer inlined into it.)
-# nb_modconv_up2v.hip / nb_modconv_up2w.hip (round 4): their packed fp32 arithmetic is explicit (f32x4 / f32x2 vector types); SLP paired
+# nb_modconv_up2v.hip (round 4): their packed fp32 arithmetic is explicit (f32x4 / f32x2 vector types); SLP paired
 # the two scalar `x * gain` of the prologue into a swizzled v_pk_mul_f32 (tests/test_abi.py scans for any such form).
 FILE_FLAGS = {"nb_modconv.hip": ["-fno-slp-vectorize"], "nb_ops.hip": ["-fno-slp-vectorize"],
-              "nb_modconv_up2v.hip": ["-fno-slp-vectorize"], "nb_modconv_up2w.hip": ["-fno-slp-vectorize"]}
+              "nb_modconv_up2v.hip": ["-fno-slp-vectorize"]}
 
 
 STAMP = LIB + ".stamp"

@@ -41,6 +41,10 @@ void nb_set_error(const char* fmt, ...);
 
 static inline int nb_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// developer / test hooks (include/neube_hip_debug.h; defined in nb_ops.hip, both 0 on the product path): feature-off bit mask of the conv
+// kernels (p.dbg) and their first-round stagger in s_sleep ticks
+extern int g_nb_debug_flags, g_nb_stagger_ticks;
+
 // ---- position-shifted constant noise (networks.py:371-382), the per-pixel arithmetic shared by nb_noise_f32's kernels
 //      (nb_ops.hip) and the convolutions that compute their noise themselves (NbNoiseSrc) ----
 #ifdef __HIPCC__

@@ -1275,8 +1275,7 @@ static int nb_enc_conv3x3_impl(const void* x_h2, int c_in, const void* w_h3, con
         // under-filled launch (interactive strokes, small batches): the 32 x 32 split-K tiles instead.  Needs whole
         // 16-channel chunks and an output width that is a power of two >= 8 (32 positions = 32 / w rows).
         const long big_wgs = (long)n * (wo / (wide ? 32 : 16)) * (ho / (wide ? 8 : 16)) * ((c_out + 127) / 128);
-        static const int env_force = getenv("NB_ENC_SMALL") ? atoi(getenv("NB_ENC_SMALL")) : -1;
-        const int force = g_enc_small >= 0 ? g_enc_small : env_force;
+        const int force = g_enc_small;                 // (test hook nb_debug_set_enc_small: -1 = this rule)
         // ... and layers with <= 32 output channels at any batch: the large tile has 128 c_out rows, three quarters of them empty then
         // (256 -> 32 and 32 -> 16 of a batch of 32 at R=256: 82 -> 39 us together)
         const bool small = !(wide || narrow) || (force >= 0 ? force != 0 : ((big_wgs <= 48 || c_out <= 32) && c_in >= 32));

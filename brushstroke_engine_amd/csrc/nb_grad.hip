@@ -9,6 +9,10 @@
 #include "nb_common.h"
 #include <cstdlib>
 
+static int g_wgrad_wgs = 256;
+// developer hook (tools/bench_wgrad.py): workgroups the weight-gradient launches aim for (256 = one per CU; <= 0 restores it)
+extern "C" void nb_debug_set_wgrad_wgs(int wgs) { g_wgrad_wgs = wgs > 0 ? wgs : 256; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -201,7 +205,7 @@ extern "C" int nb_conv2d_wgrad_f32(const float* u, const float* v, float* a, int
     WgradParams p{u, v, a, n, cu, hu, wu, cv, hv, wv, stride, pad, 0, 0, nullptr, 0};
     // enough workgroups to fill the chip: slice V's rows when there are few (n, tile) combinations
     const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
-    static const int wg_target = getenv("NB_WGRAD_WGS") ? atoi(getenv("NB_WGRAD_WGS")) : 256;     // one workgroup per CU: more row slices only add atomic traffic (tools/bench_wgrad.py)
+    const int wg_target = g_wgrad_wgs;     // 256 = one workgroup per CU: more row slices only add atomic traffic (tools/bench_wgrad.py)
     int slices = (int)((wg_target + tiles - 1) / tiles);
     if (slices > hv) slices = hv;
     if (slices < 1) slices = 1;
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static void nb_wgrad_h3_slices(int n, int cu, int cv, int hv, int* rows_per_wg, int* nslices) {
     const long tiles = (long)n * nb_cdiv(cu, 32) * nb_cdiv(cv, 128);
-    static const int wg_target = getenv("NB_WGRAD_WGS") ? atoi(getenv("NB_WGRAD_WGS")) : 256;     // one workgroup per CU
+    const int wg_target = g_wgrad_wgs;     // 256 = one workgroup per CU
     int slices = (int)((wg_target + tiles - 1) / tiles);
     if (slices > hv) slices = hv;
     if (slices < 1) slices = 1;

@@ -1,5 +1,5 @@
 // Shared device helpers of the split-f16 ("h3" / "f8") convolution kernels: vector types, LDS-DMA, counted waits, fp8 packing,
-// lane-half exchange, the up=2 kernels' parameter block.  Included by nb_modconv_h3.hip and nb_modconv_up2w.hip.
+// lane-half exchange, the up=2 kernels' parameter block.  Included by nb_modconv_h3.hip and nb_modconv_up2v.hip.
 #pragma once
 #include "nb_common.h"
 #include <cstdlib>

@@ -828,7 +828,7 @@ static int nb_modconv3x3_impl(const float* x1, int c1, const float* x2, int c2, 
     p.zeros = nb_zero_page_ptr();
     NB_REQUIRE(p.zeros, "modconv3x3: could not allocate the zero page");
     p.c1 = c1; p.c2 = c2; p.c_in = c1 + c2; p.c_out = c_out; p.c_out_ld = (c_out + 31) / 32 * 32; p.h = h; p.w = w;
-    { static const int v = getenv("NB_DEBUG") ? atoi(getenv("NB_DEBUG")) : 0; p.dbg = v; }            // (read once per process)
+    p.dbg = g_nb_debug_flags;            // (developer hook: nb_debug_set_flags)
     p.sty_floats = 0; p.log2_tw = 0; p.th = 0; p.tw = 0; p.tiles_x = p.tiles_y = p.slices = 1;
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tstamps = g_ts32;

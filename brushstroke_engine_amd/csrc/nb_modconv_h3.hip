@@ -1297,6 +1297,9 @@ extern "C" void nb_debug_set_up1_pp(int mode) { g_force_up1_pp = mode; }
 static int g_force_nbw = 0;
 // developer / test hook: 0 = automatic, 1 / 2 = force that many 32-pixel rows per wave in the 8-wave up=1 kernel
 extern "C" void nb_debug_set_up1_rows(int nbw) { g_force_nbw = nbw; }
+static int g_force_up1_small = -1;
+// developer / test hook: -1 = automatic (images <= 32 x 32), 0 / 1 = never / always the 4-wave two-workgroups-per-CU form of the H2 up=1 kernel
+extern "C" void nb_debug_set_up1_small(int mode) { g_force_up1_small = mode; }
 
 static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const float* dcoefs, const float* noise,
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
@@ -1321,8 +1324,7 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     NB_REQUIRE(nb_noise_src_setup(noise, noise_stride_n, h, w, &p.noise, &p.noise_stride_n, &p.nsrc) == NB_OK, "modconv3x3_up1_h3: bad NbNoiseSrc (needs the "
                "transposed constant, the grid row, the strength, exactly one of norm_pos / positions, and res = the %dx%d output)", h, w);
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
-    { static const int v = getenv("NB_DEBUG") ? atoi(getenv("NB_DEBUG")) : 0; p.dbg = v; }            // (read once per process)
-    { static const int v = getenv("NB_STAGGER") ? atoi(getenv("NB_STAGGER")) : 0; p.stagger_ticks = v; }
+    p.dbg = g_nb_debug_flags; p.stagger_ticks = g_nb_stagger_ticks;            // (developer hooks: nb_debug_set_flags / nb_debug_set_stagger)
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
     p.out_f8 = out_fmt;
@@ -1335,18 +1337,16 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     }
     // the 4-wave / 2-workgroups-per-CU form wins on small images (fewer, larger workgroups leave CUs idle there); on the
     // large layers both forms run at the same rate -- the chip is power-limited in these loops, not latency-limited
-    { static const int env_small = getenv("NB_UP1_SMALL") ? atoi(getenv("NB_UP1_SMALL")) : -1;
-      const bool small = env_small >= 0 ? env_small != 0 : (h * w <= 32 * 32);
+    { const bool small = g_force_up1_small >= 0 ? g_force_up1_small != 0 : (h * w <= 32 * 32);
       if (small && !f8 && (!tg || c_out <= 64)) return launch_h3s(p, n, (hipStream_t)stream); }
     // half-height tiles when the full ones leave the chip mostly idle (batch 1); g_force_nbw: test hook
     const long wgs_full = (long)n * (w / 32) * (h / (c_out > 64 ? 8 : 16)) * ((c_out + (c_out > 64 ? 127 : 63)) / (c_out > 64 ? 128 : 64));
     const bool half = g_force_nbw ? g_force_nbw == 1 : wgs_full < 160;
     hipStream_t st = (hipStream_t)stream;
-    // the software-pipelined K loop (V2; both operand formats) unless switched off (test hook / NB_UP1_V2=0)
-    static const int env_v2 = getenv("NB_UP1_V2") ? atoi(getenv("NB_UP1_V2")) : -1;
+    // the software-pipelined K loop (V2; both operand formats) unless switched off (test hook nb_debug_set_up1_v2)
     // (its pieces walk the chunks with a fixed per-chunk stride: whole 16-channel chunks only -- f8 operands always are; H2 operands
     //  with an odd number of channel groups keep the round-3 loop, whose last chunk reads the missing group from the zero page)
-    const bool v2 = (g_force_up1_v2 >= 0 ? g_force_up1_v2 : env_v2) != 0 && (f8 || p.c8 % 2 == 0);
+    const bool v2 = g_force_up1_v2 != 0 && (f8 || p.c8 % 2 == 0);
     NB_REQUIRE(out_fmt != 2 || (f8 && v2), "modconv3x3_up1_h3: the f6 output format is written by the software-pipelined f8 / f6 kernels only");
     if (f6) {                                               // (the software-pipelined loop only)
         if (half) return c_out > 64 ? launch_h3<2, true, 1, true, true>(p, n, st) : launch_h3<1, true, 1, true, true>(p, n, st);
@@ -1358,9 +1358,8 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
         if (v2) return c_out > 64 ? launch_h3<2, false, 1, true>(p, n, st) : launch_h3<1, false, 1, true>(p, n, st);
         return c_out > 64 ? launch_h3<2, false, 1>(p, n, st) : launch_h3<1, false, 1>(p, n, st);
     }
-    // the ping-pong form of that loop (full-height tiles): NB_UP1_PP / nb_debug_set_up1_pp
-    static const int env_pp = getenv("NB_UP1_PP") ? atoi(getenv("NB_UP1_PP")) : NB_UP1_PP_DEFAULT;
-    const bool pp = (g_force_up1_pp >= 0 ? g_force_up1_pp : env_pp) != 0;
+    // the ping-pong form of that loop (full-height tiles): nb_debug_set_up1_pp
+    const bool pp = (g_force_up1_pp >= 0 ? g_force_up1_pp : NB_UP1_PP_DEFAULT) != 0;
     if (f8 && v2 && pp) return c_out > 64 ? launch_h3<2, true, 2, true, false, true>(p, n, st) : launch_h3<1, true, 2, true, false, true>(p, n, st);
     if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 2, true>(p, n, st) : launch_h3<1, true, 2, true>(p, n, st);
     if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
@@ -2010,16 +2009,6 @@ __global__ __launch_bounds__(NW_ * 64, 2) void modconv3x3_up2_h3_kernel(const H3
 static int g_force_tqh = -1;
 // developer / test hook: 0 = automatic tile choice, NB_H3_TQH, NB_H3_TQH_MID or NB_H3_TQH_SMALL = force that tile height
 extern "C" void nb_debug_set_up2_tile(int tqh) { g_force_tqh = tqh; }
-// the one-wave-per-SIMD form (nb_modconv_up2w.hip)
-bool nb_up2w_eligible(int in_fmt, int c_in, int c_out, int h, int w);
-long nb_up2w_workgroups(int n, int c_out, int h, int w);
-int nb_up2w_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long long* tstamps, int tstamps_cap);
-#ifndef NB_UP2W_AUTO
-#define NB_UP2W_AUTO 0          // 1: the wide form is chosen automatically for launches of >= 768 of its workgroups
-#endif
-static int g_force_wide = -1;
-// developer / test hook: -1 = automatic, 0 / 1 = never / always (where the shape allows) the wide form (64 c_out x 12 x 16 quads, 4 waves)
-extern "C" void nb_debug_set_up2_wide(int mode) { g_force_wide = mode; }
 // the 8-wave form with the software-pipelined K loop (nb_modconv_up2v.hip)
 bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w);
 int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long long* tstamps, int tstamps_cap);
@@ -2069,21 +2058,14 @@ static int nb_up2_h3_launch(H3Up2Params p, int n, int in_fmt, void* stream) {
                                                                                            : nb_up2_h3_launch1<TQH, TQW, false, 0, NW, NST>(p, n, lds, stream);
 }
 
-// which kernel a split-f16 up=2 launch runs on (the debug hooks / environment switches apply)
+// which kernel a split-f16 up=2 launch runs on (the debug hooks apply; UP2_WIDE: the one-wave-per-SIMD form of round 4, removed in round 6)
 enum Up2Form { UP2_BIG = 0, UP2_MID, UP2_SMALL, UP2_W16, UP2_PAIR, UP2_WIDE, UP2_V2, UP2_W8 };
 static Up2Form nb_up2_h3_select(int in_fmt, int c_in, int c_out, int n, int h, int w) {
     const int tiles_x = w / 32, slices = (c_out + 31) / 32;
-    // the wide form (one wave per SIMD, 64 c_out per workgroup): opt-in
-    static const int env_wide = getenv("NB_UP2_WIDE") ? atoi(getenv("NB_UP2_WIDE")) : -1;
-    const int force_wide = g_force_wide >= 0 ? g_force_wide : env_wide;
-    if (force_wide != 0 && g_force_tqh <= 0 && g_force_pair <= 0 && nb_up2w_eligible(in_fmt, c_in, c_out, h, w) &&
-        (force_wide > 0 || (NB_UP2W_AUTO && nb_up2w_workgroups(n, c_out, h, w) >= 768)))
-        return UP2_WIDE;
     if (w == 16) return UP2_W16;                      // 16-wide inputs: 8 x 16 quad tiles
     if (w == 8) return UP2_W8;                        // 8 x 8 inputs: the whole image is one 8 x 8 quad tile (4 position blocks)
     // tile height: the 12-row tiles unless they leave the chip mostly idle (batch-1 / interactive), then 5-row tiles
-    static const int env_tqh = getenv("NB_UP2_TQH") ? atoi(getenv("NB_UP2_TQH")) : 0;
-    const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : env_tqh;
+    const int force_tqh = g_force_tqh >= 0 ? g_force_tqh : 0;
     const long wgs_big = (long)n * tiles_x * ((h + NB_H3_TQH - 1) / NB_H3_TQH) * slices;
     const bool small_tiles = force_tqh ? force_tqh == NB_H3_TQH_SMALL : wgs_big < 160;
     // 8-row tiles when the 12-row tiles' last round of workgroups would leave most of the chip idle.  Estimate = rounds of 256
@@ -2097,12 +2079,10 @@ static Up2Form nb_up2_h3_select(int in_fmt, int c_in, int c_out, int n, int h, i
         mid_tiles = est_mid < 0.9 * est_big;
     }
     // two 4-wave workgroups per CU on 12 x 16 tiles (see the kernel's NW_ / NST_) when that launch fills the chip as well
-    static const int env_pair = getenv("NB_UP2_PAIR") ? atoi(getenv("NB_UP2_PAIR")) : 0;
-    const bool pair = !in_fmt && (g_force_pair >= 0 ? g_force_pair != 0 : (env_pair && !small_tiles && !mid_tiles && wgs_big * 2 >= 1024));
+    const bool pair = !in_fmt && g_force_pair > 0;          // (opt-in through nb_debug_set_up2_pair: not faster than one 8-wave workgroup per CU)
     if (pair) return UP2_PAIR;
     // the 12-row throughput tiles of an f8 launch: the kernel with the software-pipelined K loop (same tile, same results)
-    static const int env_v2 = getenv("NB_UP2_V2") ? atoi(getenv("NB_UP2_V2")) : -1;
-    const int force_v2 = g_force_v2 >= 0 ? g_force_v2 : env_v2;
+    const int force_v2 = g_force_v2;
     if (force_v2 != 0 && nb_up2v_eligible(in_fmt, c_in, h, w) &&
         (force_v2 > 0 ? force_tqh == 0 || force_tqh == NB_H3_TQH : (NB_UP2V_AUTO && !mid_tiles && !small_tiles && (force_tqh == 0 || force_tqh == NB_H3_TQH))))
         return UP2_V2;
@@ -2133,8 +2113,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     NB_REQUIRE(nb_noise_src_setup(noise, noise_stride_n, 2 * h, 2 * w, &p.noise, &p.noise_stride_n, &p.nsrc) == NB_OK, "modconv3x3_up2_h3: bad NbNoiseSrc (needs the "
                "transposed constant, the grid row, the strength, exactly one of norm_pos / positions, and res = the %dx%d output)", 2 * h, 2 * w);
     p.c8 = (c_in + 7) / 8; p.nchunks = (c_in + 15) / 16; p.c_out = c_out; p.co_ld = (c_out + 63) / 64 * 64; p.h = h; p.w = w;
-    { static const int v = getenv("NB_DEBUG") ? atoi(getenv("NB_DEBUG")) : 0; p.dbg = v; }            // (read once per process)
-    { static const int v = getenv("NB_STAGGER") ? atoi(getenv("NB_STAGGER")) : 0; p.stagger_ticks = v; }
+    p.dbg = g_nb_debug_flags; p.stagger_ticks = g_nb_stagger_ticks;            // (developer hooks: nb_debug_set_flags / nb_debug_set_stagger)
     p.alpha = alpha; p.gain = gain; p.clamp = clamp;
     p.tiles_x = w / 32; p.slices = (c_out + 31) / 32;
     p.yh2 = (_Float16*)y_h2; p.next_styles = next_styles; p.next_stride = next_stride; p.c8_next = (c_next + 7) / 8;
@@ -2142,7 +2121,6 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     const Up2Form form = nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w);
     NB_REQUIRE(in_fmt != 2 || form == UP2_V2, "modconv3x3_up2_h3: f6 operands are taken by the 12-row software-pipelined kernel only (this launch: %dx%d, batch %d)", h, w, n);
     switch (form) {
-        case UP2_WIDE: return nb_up2w_launch(p, n, in_fmt, stream, g_tstamps, g_tstamps_cap);
         case UP2_W16: return nb_up2_h3_launch<8, 16>(p, n, in_fmt, stream);
         case UP2_W8: return nb_up2_h3_launch<8, 8>(p, n, in_fmt, stream);
         case UP2_PAIR: return nb_up2_h3_launch<NB_H3_TQH, 16, 4, 2>(p, n, in_fmt, stream);
@@ -2157,7 +2135,7 @@ extern "C" int nb_modconv3x3_up2_h3_variant(int in_fmt, int c_in, int c_out, int
     NB_REQUIRE(buf && buflen > 0, "modconv3x3_up2_h3_variant: bad buffer");
     NB_REQUIRE(in_fmt >= 0 && in_fmt <= 2 && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16 || w == 8), "modconv3x3_up2_h3_variant: bad shape");
     static const char* const names[] = {"modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel",
-                                        "modconv3x3_up2_h3_kernel", "modconv3x3_up2w_kernel", "modconv3x3_up2v_kernel", "modconv3x3_up2_h3_kernel"};
+                                        "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2v_kernel", "modconv3x3_up2_h3_kernel"};
     snprintf(buf, buflen, "%s", names[nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)]);
     return NB_OK;
 }

@@ -322,14 +322,12 @@ static int nb_small_h3_impl(const float* x, int c1, const float* x2, int c2, con
     const long wgs = (long)grid.x * grid.y * grid.z;
     // eight K-splitting waves when the chunks give every one of them work.  The rule looks at the layer only, never at the batch:
     // the two forms associate the partial sums differently, and a sample's result must not depend on what it is batched with.
-    // (NB_SMALL_WAVES = 4 / 8 forces the form; 0 = this rule)
-    static const int env_waves = getenv("NB_SMALL_WAVES") ? atoi(getenv("NB_SMALL_WAVES")) : 0;
-    const int force_waves = g_force_small_waves > 0 ? g_force_small_waves : env_waves;
+    // (nb_debug_set_small_waves(4 / 8) forces the form; 0 = this rule)
+    const int force_waves = g_force_small_waves > 0 ? g_force_small_waves : 0;
     const bool eight = force_waves ? force_waves == 8 : p.nchunks >= 8;
     // two position blocks per tile (twice the rows) when the launch is more than a round of workgroups: half as many
-    // workgroups fetch the weights (NB_SMALL_BLOCKS = 1 / 2 forces the form where it exists)
-    static const int env_blocks = getenv("NB_SMALL_BLOCKS") ? atoi(getenv("NB_SMALL_BLOCKS")) : 0;
-    const int force_blocks = g_force_small_blocks > 0 ? g_force_small_blocks : env_blocks;
+    // workgroups fetch the weights (nb_debug_set_small_blocks(1 / 2) forces the form where it exists)
+    const int force_blocks = g_force_small_blocks > 0 ? g_force_small_blocks : 0;
     const bool can_two = eight && p.spt == 1 && tiles_y % 2 == 0 && (2 * p.rows + 2) * (p.cols + 2) <= NB_SM_NHP2;
     if (can_two && (force_blocks ? force_blocks == 2 : wgs > 256)) {
         p.rows *= 2;

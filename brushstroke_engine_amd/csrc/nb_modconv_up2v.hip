@@ -3,7 +3,7 @@
 // Same math, same tile (12 x 32 quads x 32 c_out, two position blocks and all four output phases per wave = 128 accumulator
 // registers, two waves per SIMD), same three-stage LDS ring and the same epilogue as modconv3x3_up2_h3_kernel
 // (nb_modconv_h3.hip) -- and the same per-output summation order: bit-identical results.  What differs is the K loop, which is the
-// one measured on the one-wave-per-SIMD kernel (nb_modconv_up2w.hip: 97 % of its cycles are matrix work):
+// one measured on the one-wave-per-SIMD kernel of round 4 (nb_modconv_up2w.hip, removed in round 6 -- docs/perf_history.md: 97 % of its cycles were matrix work):
 //   * one basic block per chunk: LDS-DMA pieces are issued from statements that set their lane mask themselves (an `if` around a
 //     piece is a branch, and the compiler moves MFMAs across the resulting blocks);
 //   * the pipeline is rotated by one MFMA group: the chunk's barrier stands before its LAST group (taps 2, 0), whose operands are

@@ -8,6 +8,15 @@
 #include <cmath>
 #include <cstring>
 
+// developer / test hooks shared by the conv launchers (declared in nb_common.h; include/neube_hip_debug.h): a bit mask that switches
+// single features of the kernels off for A/B runs (8 = no XCD-aware workgroup order, 32 = the round-3 order of the up=2 launches, ...:
+// the uses of p.dbg), and the first-round stagger of the large kernels in s_sleep ticks.  Both 0 on the product path.
+int g_nb_debug_flags = 0, g_nb_stagger_ticks = 0;
+extern "C" void nb_debug_set_flags(int flags) { g_nb_debug_flags = flags; }
+extern "C" void nb_debug_set_stagger(int ticks) { g_nb_stagger_ticks = ticks; }
+static bool g_upfirdn_generic = false;
+extern "C" void nb_debug_set_upfirdn_generic(int on) { g_upfirdn_generic = on != 0; }
+
 
 static thread_local char g_err[512] = "";
 
@@ -314,7 +323,7 @@ extern "C" int nb_upfirdn2d_f32(const float* x, const float* f, float* y, int ma
     NB_REQUIRE(p.out_w >= 1 && p.out_h >= 1, "upfirdn2d: output must be at least 1x1");
     const long long total = (long long)major * p.out_h * p.out_w;
     hipStream_t st = (hipStream_t)stream;
-    static const bool generic_only = getenv("NB_UPFIRDN_GENERIC") != nullptr;      // developer switch: the run-time-everything kernel
+    const bool generic_only = g_upfirdn_generic;      // developer switch (nb_debug_set_upfirdn_generic): the run-time-everything kernel
     const long long plane = (long long)p.out_h * p.out_w, in_plane = (long long)in_h * in_w;
     // (factors of 4 and more would alias the 2-bit fields of the key -- down = (1, 5) reads as <1, 1, 2, 1> -- : generic kernel)
     const bool small_factors = upx <= 3 && upy <= 3 && downx <= 3 && downy <= 3;

@@ -19,6 +19,7 @@ launches per patch: SURVEY 3.3.)
 from __future__ import annotations
 
 import ctypes
+import dataclasses
 import math
 from typing import Dict, Optional
 
@@ -234,6 +235,83 @@ class _Plan:
         return self._upload(descs), keep
 
 
+@dataclasses.dataclass
+class _PassOptions:
+    """The private options of one synthesis pass -- the underscore keywords of ``SynthesisNetwork.forward`` that this build's
+    schedules use (the public keywords are the reference's).  One place for their meaning and for the illegal combinations."""
+    noise_mode: str = "random"                     # SynthesisLayer default, networks.py:362
+    norm_noise_positions: Optional[torch.Tensor] = None
+    positions: Optional[torch.Tensor] = None       # `_positions`: integer (y, x) patch positions, normalised in-kernel
+    extra: Optional[dict] = None                   # `_extra_outputs`: logits / RGBA / uint8 compositing of the fused ToRGB launch
+    # split entry of the tiled-canvas schedule (painting.py): `_stop_after=res` returns the output of block `res` before any
+    # blending; `_resume=(res, x)` continues after block `res` from (blended) features x
+    stop_after: Optional[int] = None
+    resume: Optional[tuple] = None
+    plan_slot: int = 0                             # `_plan_slot`: workspace to use (passes that may overlap on different streams)
+    # `_reuse_styles`: the styles / demodulation coefficients (and the noise images of the small layers) of THIS batch are already
+    # in the workspace slot -- an earlier pass of the same batch computed them (pipeline.TriadStepPipeline: the head pass computes
+    # every layer's styles, the tail pass of the same step resumes from its features)
+    reuse_styles: bool = False
+    # `_prepare_only`: enqueue what a pass needs BEFORE its first layer -- every layer's styles and demodulation coefficients, the
+    # small layers' noise images (all into the workspace slot) and the early geometry packs -- and return a handle;
+    # `_prepared=handle`: the pass of the same batch on the same slot that starts from it (pipeline.TriadPrefetchPipeline runs the
+    # former for step k+1 under the last layer of step k).  `_mark=(event, layer name)`: record the event on the current stream
+    # right before that layer's launch.
+    prepare_only: bool = False
+    prepared: Optional[dict] = None
+    mark: Optional[tuple] = None
+
+    _KEYS = {"noise_mode": "noise_mode", "norm_noise_positions": "norm_noise_positions", "_positions": "positions",
+             "_extra_outputs": "extra", "_stop_after": "stop_after", "_resume": "resume", "_plan_slot": "plan_slot",
+             "_reuse_styles": "reuse_styles", "_prepare_only": "prepare_only", "_prepared": "prepared", "_mark": "mark"}
+
+    @classmethod
+    def from_kwargs(cls, kw: dict) -> "_PassOptions":
+        kw = dict(kw)
+        kw.pop("force_fp32", None)       # always fp32 here (SURVEY note B)
+        kw.pop("fused_modconv", None)    # one arithmetic form (csrc/nb_modconv.hip)
+        o = cls(**{field: kw.pop(key) for key, field in cls._KEYS.items() if key in kw})
+        if kw:
+            raise TypeError(f"unexpected synthesis kwargs: {sorted(kw)}")
+        if o.noise_mode not in ("random", "const", "none"):
+            raise AssertionError(f"noise_mode {o.noise_mode!r}")
+        return o
+
+
+@dataclasses.dataclass
+class _Pass:
+    """State of one synthesis pass: what ``_begin_pass`` validated, what ``_prepare`` enqueued, and the activations as they move
+    through ``_run_layers`` (x: fp32 NCHW, x2: the geometry feature still to be concatenated, x_h2: the next layer's complete input
+    in operand format when its producer wrote it)."""
+    opts: _PassOptions
+    ws: torch.Tensor
+    n: int
+    device: torch.device
+    plan: "_Plan"
+    lazy_geom: object
+    geom_feature: list
+    return_debug_data: bool
+    return_features: list
+    blended_features: dict
+    noise_buffers: Optional[dict]
+    table: torch.Tensor
+    stream: int = 0
+    npos: Optional[torch.Tensor] = None
+    ipos: Optional[torch.Tensor] = None
+    shared: bool = False                     # constant noise without positions: one image for the whole batch
+    inkernel_from: Optional[int] = None      # first layer (resolution order) from which every layer computes its noise itself
+    pre_h2: dict = dataclasses.field(default_factory=dict)
+    keep_alive: list = dataclasses.field(default_factory=list)
+    x: Optional[torch.Tensor] = None
+    x2: Optional[torch.Tensor] = None
+    x_h2: Optional[torch.Tensor] = None
+    geo_idx: int = 0
+    packs_waited: bool = False
+    fused_rgb: Optional[tuple] = None
+    img: Optional[torch.Tensor] = None
+    debug_data: dict = dataclasses.field(default_factory=dict)
+
+
 class SynthesisNetwork(torch.nn.Module):
     """``networks_modified.py:28-223`` on the HIP kernels."""
 
@@ -418,38 +496,23 @@ class SynthesisNetwork(torch.nn.Module):
     # -- forward --
     def forward(self, ws, geom_feature, pos_encoding=None, return_debug_data=False, return_features=None,
                 blended_features=None, noise_buffers=None, **block_kwargs):
-        cfg = self.cfg
-        return_features = [] if return_features is None else return_features
-        blended_features = {} if blended_features is None else blended_features
-        noise_mode = block_kwargs.pop("noise_mode", "random")      # SynthesisLayer default, networks.py:362
-        norm_noise_positions = block_kwargs.pop("norm_noise_positions", None)
-        int_positions = block_kwargs.pop("_positions", None)   # integer (y,x) positions: normalised in-kernel
-        block_kwargs.pop("force_fp32", None)       # always fp32 here (SURVEY note B)
-        block_kwargs.pop("fused_modconv", None)    # one arithmetic form (csrc/nb_modconv.hip)
-        extra = block_kwargs.pop("_extra_outputs", None)
-        # split entry for the tiled-canvas schedule (painting.py): `_stop_after=res` returns the output of block
-        # `res` before any blending; `_resume=(res, x)` continues after block `res` from (blended) features x
-        stop_after = block_kwargs.pop("_stop_after", None)
-        resume = block_kwargs.pop("_resume", None)
-        plan_slot = block_kwargs.pop("_plan_slot", 0)      # workspace to use (concurrent sub-batches on separate streams)
-        # `_reuse_styles`: the styles / demodulation coefficients (and the noise images of the small layers) of THIS batch are
-        # already in the workspace slot -- an earlier pass of the same batch computed them (pipeline.TriadStepPipeline: the
-        # head pass computes every layer's styles, the tail pass of the same step resumes from its features)
-        reuse_styles = block_kwargs.pop("_reuse_styles", False)
-        # `_prepare_only`: enqueue what a pass needs BEFORE its first layer -- every layer's styles and demodulation coefficients,
-        # the small layers' noise images (all into the workspace slot) and the early geometry packs -- and return a handle;
-        # `_prepared=handle`: the pass of the same batch on the same slot that starts from it (pipeline.TriadPrefetchPipeline runs
-        # the former for step k+1 under the last layer of step k).  `_mark=(event, layer name)`: record the event on the current
-        # stream right before that layer's launch.
-        prepare_only = block_kwargs.pop("_prepare_only", False)
-        prepared = block_kwargs.pop("_prepared", None)
-        mark = block_kwargs.pop("_mark", None)
-        if block_kwargs:
-            raise TypeError(f"unexpected synthesis kwargs: {sorted(block_kwargs)}")
-        if noise_mode not in ("random", "const", "none"):
-            raise AssertionError(f"noise_mode {noise_mode!r}")
+        """``networks_modified.py:123-223``.  Public keywords as the reference; the underscore keywords are the private options of
+        this build's schedules (``_PassOptions``).  Three steps: ``_begin_pass`` (validation, workspace), ``_prepare`` (styles,
+        noise images, geometry operands: everything a pass needs before its first layer), ``_run_layers``."""
+        opts = _PassOptions.from_kwargs(block_kwargs)
         if pos_encoding is not None:
             raise RuntimeError("positional encodings are not part of the shipped configuration (SG/train.py:680)")
+        ps = self._begin_pass(ws, geom_feature, opts, return_debug_data, return_features, blended_features, noise_buffers)
+        with torch.cuda.device(ps.device):
+            ps.stream = ops._stream(ps.ws)
+            self._prepare(ps)
+            if opts.prepare_only:
+                return {"pre_h2": ps.pre_h2, "keep": ps.keep_alive, "n": ps.n, "slot": opts.plan_slot, "plan": ps.plan}
+            return self._run_layers(ps)
+
+    def _begin_pass(self, ws, geom_feature, opts: "_PassOptions", return_debug_data, return_features, blended_features,
+                    noise_buffers) -> "_Pass":
+        """Validate the call (networks_modified.py:145), pick the workspace slot and collect the state of one pass."""
         _assert_shape(ws, [None, self.num_ws, self.w_dim])          # networks_modified.py:145
         device = self.get_last_block().conv1.weight.device
         if ws.device != device:
@@ -458,373 +521,406 @@ class SynthesisNetwork(torch.nn.Module):
         n = ws.shape[0]
         self._h3_batch_ok = n >= self.h3_min_batch
         self._n = n
-        plan = self._get_plan(n, device, plan_slot)
-        lib = _lib.lib()
+        plan = self._get_plan(n, device, opts.plan_slot)
         lazy_geom = geom_feature if hasattr(geom_feature, "encode_for") else None      # encoder.LazyGeometry
-        if prepare_only or prepared is not None:
-            if (lazy_geom is not None or noise_mode != "const" or noise_buffers or resume is not None or stop_after is not None
-                    or reuse_styles or blended_features):
+        return_features = [] if return_features is None else return_features
+        blended_features = {} if blended_features is None else blended_features
+        if opts.prepare_only or opts.prepared is not None:
+            if (lazy_geom is not None or opts.noise_mode != "const" or noise_buffers or opts.resume is not None
+                    or opts.stop_after is not None or opts.reuse_styles or blended_features):
                 raise RuntimeError("_prepare_only / _prepared: whole passes with constant noise and plain geometry tensors only")
-            if prepared is not None and (prepared["n"] != n or prepared["slot"] != plan_slot or prepared["plan"] is not plan):
+            h = opts.prepared
+            if h is not None and (h["n"] != n or h["slot"] != opts.plan_slot or h["plan"] is not plan):
                 raise RuntimeError("_prepared: the handle belongs to another batch size or workspace slot")
         if lazy_geom is None:
             geom_feature = list(geom_feature) if isinstance(geom_feature, (list, tuple)) else [geom_feature]
-        keep_alive = []
-        with torch.cuda.device(device):
-            stream = ops._stream(ws)
-            noise_stride = {}
-            table, npos, ipos = plan.table, None, None
-            if noise_mode == "const":
-                if noise_buffers:
-                    table, keep = plan.table_with_noise_overrides(self, noise_buffers)
-                    keep_alive += [table] + keep
-                if int_positions is not None:
-                    ipos = int_positions.to(device=device, dtype=torch.int64).contiguous()
-                    _assert_shape(ipos, [n, 2])
-                    keep_alive.append(ipos)
-                elif norm_noise_positions is not None:
-                    npos = norm_noise_positions.to(device=device, dtype=torch.float32).contiguous()
-                    _assert_shape(npos, [n, 2])
-                    keep_alive.append(npos)
-            # first layer (in resolution order) from which every layer runs on the large split-f16 kernels: those compute their
-            # position-shifted noise in their own prologue.  Not with per-call noise buffers (their transposes do not exist).
-            inkernel_from = None
-            if (self.noise_in_kernel and noise_mode == "const" and table is plan.table and (npos is not None or ipos is not None)):
-                elig = [(self._h3_up2_eligible(sp) if sp.up == 2 else self._h3_eligible(sp)) for sp in cfg.layers]
-                k_ = len(elig)
-                while k_ > 0 and elig[k_ - 1]:
-                    k_ -= 1
-                inkernel_from = k_ if k_ < len(elig) else None
-            if prepared is not None:
-                pass                                # styles, coefficients and noise images are in the workspace slot already
-            elif reuse_styles:
-                if resume is None or (inkernel_from is None and noise_mode == "const") or table is not plan.table:
-                    raise RuntimeError("_reuse_styles needs a resumed pass whose layers compute their noise themselves")
-                if any(i_ < inkernel_from for i_, sp in enumerate(cfg.layers) if sp.block_res > resume[0]) and noise_mode == "const":
-                    raise RuntimeError("_reuse_styles: a resumed layer would need a noise image that no launch of this pass writes")
-            elif (self._styles_fast and noise_mode == "const" and table is plan.table and n <= 8
-                    and (npos is not None or ipos is not None)):
-                # small batches: styles + per-sample noise in one launch (a launch costs more than either computes)
-                tbl = plan.table if inkernel_from is None else plan.table_without_noise_from(inkernel_from)
-                _lib.check(lib.nb_styles_noise_f32(_p(tbl), plan.n_layers, _p(ws), self.num_ws, self.w_dim, _p(npos),
-                                                   _p(ipos), self.img_resolution, n, stream), "styles_noise")
-            else:
-                styles_fn = lib.nb_styles_fast_f32 if self._styles_fast else lib.nb_styles_f32
-                _lib.check(styles_fn(_p(plan.table), plan.n_layers, _p(ws), self.num_ws, self.w_dim, n, stream), "styles")
-                if noise_mode == "const":
-                    # only the layers this pass runs (the tiled-canvas schedule splits the generator at R/2: the head pass
-                    # needs no 256x256 noise images, the tail pass nothing but those); layers are ordered by resolution
-                    lo_ = 0 if resume is None else sum(1 for sp in cfg.layers if sp.block_res <= resume[0])
-                    hi_ = plan.n_layers if stop_after is None else sum(1 for sp in cfg.layers if sp.block_res <= stop_after)
-                    # layers on the large split-f16 kernels compute their shifted noise themselves (NbNoiseSrc): the noise
-                    # launch stops at the first of them (layers are ordered by resolution, eligibility grows with it)
-                    if inkernel_from is not None:
-                        hi_ = min(hi_, inkernel_from)
-                    if hi_ > lo_:
-                        _lib.check(lib.nb_noise_f32(table.data_ptr() + lo_ * ctypes.sizeof(_lib.NbLayerDesc), hi_ - lo_,
-                                                    max(sp.block_res for sp in cfg.layers[lo_:hi_]), _p(npos), _p(ipos),
-                                                    self.img_resolution, n, stream), "noise")
-            if noise_mode == "const":
-                shared = npos is None and ipos is None
+        return _Pass(opts=opts, ws=ws, n=n, device=device, plan=plan, lazy_geom=lazy_geom, geom_feature=geom_feature,
+                     return_debug_data=return_debug_data, return_features=return_features, blended_features=blended_features,
+                     noise_buffers=noise_buffers, table=plan.table)
 
-            # Geometry channels of the layers that receive their input in H2 / f8 operand format: packed NOW on a side
-            # stream (they only need the consumer's styles), under the small first layers, instead of between the
-            # producer and the consumer.  pre_h2[res] = (consumer input tensor, event).
-            pre_h2 = {} if prepared is None else dict(prepared["pre_h2"])
-            pack_waited = False           # has plan.pack_stream been ordered behind this call's styles launch yet?
-            if lazy_geom is not None:
-                # geometry not encoded yet: let the encoder write the features that feed an H2 / f8 layer input straight into
-                # that layer's operand tensor (x the consumer's styles, which exist now); the rest comes back as fp32
-                targets = {}
-                if self.h2_handoff:
-                    specs_ = {s_.name: (i_, s_) for i_, s_ in enumerate(cfg.layers)}
-                    for g_idx, gres in enumerate(self.geom_feature_resolutions):
-                        if g_idx != 1 or (resume is not None and gres <= resume[0]) or gres >= cfg.img_resolution:
-                            continue                        # (feature 0 also feeds the encoder's own decoder: it stays fp32)
-                        if gres in return_features or gres in blended_features or stop_after == gres:
-                            continue
-                        ip, sp_ = specs_[f"synthesis.b{gres}.conv1"]
-                        ic, sc_ = specs_[f"synthesis.b{2 * gres}.conv0"]
-                        gch = self.geom_feature_channels[g_idx]
-                        ofmt = self._operand_fmt(sc_)
-                        # (the encoder's hand-off epilogue writes H2 / f8 operands only: an f6 consumer gets the feature back in
-                        #  fp32 and the pack path below writes its operands)
-                        if (ofmt != 2 and self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 16 == 0 and gch % 16 == 0
-                                and tuple(lazy_geom.feature_shape(g_idx)) == (n, gch, gres, gres)
-                                and getattr(lazy_geom, "can_handoff", lambda i_: True)(g_idx)):
-                            dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
-                            c_prod = sc_.in_channels - gch
-                            targets[g_idx] = dict(dst=dst, scale_ptr=plan.styles[ic].data_ptr() + 4 * c_prod, scale_stride=sc_.in_channels,
-                                                  c8_total=sc_.in_channels // 8, cg0=c_prod // 8, fmt=ofmt)
-                            pre_h2[gres] = (dst, None)
-                needed = [gres for gres in self.geom_feature_resolutions if resume is None or gres >= resume[0]]
-                if not needed:
-                    geom_feature = [None] * len(self.geom_feature_resolutions)      # a resumed pass past the last injection
-                else:
-                    geom_feature = list(lazy_geom.encode_for(targets))
-                    if any(geom_feature[k] is None and k not in targets for k in range(len(geom_feature))):
-                        raise RuntimeError("geometry provider returned no tensor for a feature the generator needs in fp32")
-            if self.early_geom_pack and self.h2_handoff and prepared is None:
-                specs_ = {s_.name: (i_, s_) for i_, s_ in enumerate(cfg.layers)}
-                gi = 0
-                for gres in self.geom_feature_resolutions:
-                    g_idx, gi = gi, gi + 1
-                    if (resume is not None and gres <= resume[0]) or gres >= cfg.img_resolution:
-                        continue
-                    if gres in return_features or gres in blended_features or stop_after == gres or g_idx >= len(geom_feature):
-                        continue
-                    if gres in pre_h2 or geom_feature[g_idx] is None:
-                        continue
-                    ip, sp_ = specs_[f"synthesis.b{gres}.conv1"]
-                    ic, sc_ = specs_[f"synthesis.b{2 * gres}.conv0"]
-                    gch = self.geom_feature_channels[g_idx]
-                    ofmt = self._operand_fmt(sc_)
-                    if not (self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 8 == 0
-                            and (ofmt == 0 or (sp_.out_channels % 16 == 0 and gch % 16 == 0))):
-                        continue
-                    g = geom_feature[g_idx]
-                    if g.device != device or g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != (n, gch, gres, gres):
-                        continue                                           # (the in-line path validates and converts)
-                    cur = torch.cuda.current_stream(device)
-                    if plan.pack_stream is None:
-                        plan.pack_stream = torch.cuda.Stream(device=device)
-                        plan.pack_events = {}
+    # ---- step 1: what a pass needs before its first layer ----
+    def _prepare(self, ps: "_Pass") -> None:
+        self._prepare_noise_sources(ps)
+        self._launch_styles_and_noise(ps)
+        # Geometry channels of the layers that receive their input in H2 / f8 operand format: packed NOW on a side
+        # stream (they only need the consumer's styles), under the small first layers, instead of between the
+        # producer and the consumer.  pre_h2[res] = (consumer input tensor, event).
+        ps.pre_h2 = {} if ps.opts.prepared is None else dict(ps.opts.prepared["pre_h2"])
+        if ps.lazy_geom is not None:
+            self._encode_lazy_geometry(ps)
+        if self.early_geom_pack and self.h2_handoff and ps.opts.prepared is None:
+            self._pack_geometry_early(ps)
+
+    def _prepare_noise_sources(self, ps: "_Pass") -> None:
+        """Per-call noise overrides, the patch positions in the form the kernels take them, and the first layer from which every
+        layer computes its (position-shifted) noise itself."""
+        cfg, opts, plan, n, device = self.cfg, ps.opts, ps.plan, ps.n, ps.device
+        if opts.noise_mode == "const":
+            if ps.noise_buffers:
+                ps.table, keep = plan.table_with_noise_overrides(self, ps.noise_buffers)
+                ps.keep_alive += [ps.table] + keep
+            if opts.positions is not None:
+                ps.ipos = opts.positions.to(device=device, dtype=torch.int64).contiguous()
+                _assert_shape(ps.ipos, [n, 2])
+                ps.keep_alive.append(ps.ipos)
+            elif opts.norm_noise_positions is not None:
+                ps.npos = opts.norm_noise_positions.to(device=device, dtype=torch.float32).contiguous()
+                _assert_shape(ps.npos, [n, 2])
+                ps.keep_alive.append(ps.npos)
+            ps.shared = ps.npos is None and ps.ipos is None
+        # first layer (in resolution order) from which every layer runs on the large split-f16 kernels: those compute their
+        # position-shifted noise in their own prologue.  Not with per-call noise buffers (their transposes do not exist).
+        if (self.noise_in_kernel and opts.noise_mode == "const" and ps.table is plan.table and (ps.npos is not None or ps.ipos is not None)):
+            elig = [(self._h3_up2_eligible(sp) if sp.up == 2 else self._h3_eligible(sp)) for sp in cfg.layers]
+            k_ = len(elig)
+            while k_ > 0 and elig[k_ - 1]:
+                k_ -= 1
+            ps.inkernel_from = k_ if k_ < len(elig) else None
+
+    def _launch_styles_and_noise(self, ps: "_Pass") -> None:
+        """Every layer's affine + demodulation coefficients (one launch) and the small layers' noise images (one launch), into the
+        workspace slot -- unless an earlier pass of the same batch left them there."""
+        cfg, opts, plan, n, lib, stream = self.cfg, ps.opts, ps.plan, ps.n, _lib.lib(), ps.stream
+        table, npos, ipos, inkernel_from, noise_mode = ps.table, ps.npos, ps.ipos, ps.inkernel_from, opts.noise_mode
+        resume, stop_after = opts.resume, opts.stop_after
+        if opts.prepared is not None:
+            return                                  # styles, coefficients and noise images are in the workspace slot already
+        if opts.reuse_styles:
+            if resume is None or (inkernel_from is None and noise_mode == "const") or table is not plan.table:
+                raise RuntimeError("_reuse_styles needs a resumed pass whose layers compute their noise themselves")
+            if any(i_ < inkernel_from for i_, sp in enumerate(cfg.layers) if sp.block_res > resume[0]) and noise_mode == "const":
+                raise RuntimeError("_reuse_styles: a resumed layer would need a noise image that no launch of this pass writes")
+            return
+        if (self._styles_fast and noise_mode == "const" and table is plan.table and n <= 8 and (npos is not None or ipos is not None)):
+            # small batches: styles + per-sample noise in one launch (a launch costs more than either computes)
+            tbl = plan.table if inkernel_from is None else plan.table_without_noise_from(inkernel_from)
+            _lib.check(lib.nb_styles_noise_f32(_p(tbl), plan.n_layers, _p(ps.ws), self.num_ws, self.w_dim, _p(npos),
+                                               _p(ipos), self.img_resolution, n, stream), "styles_noise")
+            return
+        styles_fn = lib.nb_styles_fast_f32 if self._styles_fast else lib.nb_styles_f32
+        _lib.check(styles_fn(_p(plan.table), plan.n_layers, _p(ps.ws), self.num_ws, self.w_dim, n, stream), "styles")
+        if noise_mode == "const":
+            # only the layers this pass runs (the tiled-canvas schedule splits the generator at R/2: the head pass
+            # needs no 256x256 noise images, the tail pass nothing but those); layers are ordered by resolution
+            lo_ = 0 if resume is None else sum(1 for sp in cfg.layers if sp.block_res <= resume[0])
+            hi_ = plan.n_layers if stop_after is None else sum(1 for sp in cfg.layers if sp.block_res <= stop_after)
+            # layers on the large split-f16 kernels compute their shifted noise themselves (NbNoiseSrc): the noise
+            # launch stops at the first of them (layers are ordered by resolution, eligibility grows with it)
+            if inkernel_from is not None:
+                hi_ = min(hi_, inkernel_from)
+            if hi_ > lo_:
+                _lib.check(lib.nb_noise_f32(table.data_ptr() + lo_ * ctypes.sizeof(_lib.NbLayerDesc), hi_ - lo_,
+                                            max(sp.block_res for sp in cfg.layers[lo_:hi_]), _p(npos), _p(ipos),
+                                            self.img_resolution, n, stream), "noise")
+
+    def _geometry_consumers(self, ps: "_Pass"):
+        """(g_idx, gres, producer index / spec, consumer index / spec, geometry channels, consumer operand format) of every geometry
+        feature that could be handed to its consumer in operand format: injected below the image resolution, in a block this pass
+        runs, and neither tapped nor blended at its resolution."""
+        cfg, opts = self.cfg, ps.opts
+        specs_ = {s_.name: (i_, s_) for i_, s_ in enumerate(cfg.layers)}
+        for g_idx, gres in enumerate(self.geom_feature_resolutions):
+            if (opts.resume is not None and gres <= opts.resume[0]) or gres >= cfg.img_resolution:
+                continue
+            if gres in ps.return_features or gres in ps.blended_features or opts.stop_after == gres:
+                continue
+            ip, sp_ = specs_[f"synthesis.b{gres}.conv1"]
+            ic, sc_ = specs_[f"synthesis.b{2 * gres}.conv0"]
+            yield g_idx, gres, ip, sp_, ic, sc_, self.geom_feature_channels[g_idx], self._operand_fmt(sc_)
+
+    def _encode_lazy_geometry(self, ps: "_Pass") -> None:
+        """Geometry not encoded yet (encoder.LazyGeometry): let the encoder write the features that feed an H2 / f8 layer input
+        straight into that layer's operand tensor (x the consumer's styles, which exist now); the rest comes back as fp32."""
+        opts, plan, n, device, lazy_geom = ps.opts, ps.plan, ps.n, ps.device, ps.lazy_geom
+        targets = {}
+        if self.h2_handoff:
+            for g_idx, gres, ip, sp_, ic, sc_, gch, ofmt in self._geometry_consumers(ps):
+                if g_idx != 1:
+                    continue                        # (feature 0 also feeds the encoder's own decoder: it stays fp32)
+                # (the encoder's hand-off epilogue writes H2 / f8 operands only: an f6 consumer gets the feature back in
+                #  fp32 and the pack path writes its operands)
+                if (ofmt != 2 and self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 16 == 0 and gch % 16 == 0
+                        and tuple(lazy_geom.feature_shape(g_idx)) == (n, gch, gres, gres)
+                        and getattr(lazy_geom, "can_handoff", lambda i_: True)(g_idx)):
                     dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
-                    # (Measured, round 3: this memory-bound pack -- 201 MB per batch of 32 at R=256 -- costs the kernels it runs
-                    #  beside ~45 us wherever it is placed: here, beside the small first layers (b8.conv1 12 -> 58 us), or deferred to
-                    #  the b32 / b64 layers (+30 / +33 us), with its grid capped or not.  The painting engine never runs it: its
-                    #  encoder writes the operand format directly, encoder.LazyGeometry.)
-                    if not pack_waited:
-                        # the styles (and, on the lazy path, the encoder's fp32 features) are enqueued on `cur`; tracked apart
-                        # from pre_h2, which the lazy path may already have filled for another feature
-                        plan.pack_stream.wait_stream(cur)
-                        pack_waited = True
-                    part = (lib.nb_pack_h2_part_f32, lib.nb_pack_h2f8_part_f32, lib.nb_pack_h2f6_part_f32)[ofmt]
                     c_prod = sc_.in_channels - gch
-                    _lib.check(part(_p(g), gch, plan.styles[ic].data_ptr() + 4 * c_prod, sc_.in_channels, _p(dst),
-                                    (sc_.in_channels + 7) // 8, c_prod // 8, n, gres * gres, plan.pack_stream.cuda_stream), "pack_h2_part")
-                    ev_ = plan.pack_events.get(gres)
-                    if ev_ is None:
-                        ev_ = plan.pack_events[gres] = torch.cuda.Event()
-                    ev_.record(plan.pack_stream)
-                    plan.pack_last_event = ev_
-                    g.record_stream(plan.pack_stream)
-                    dst.record_stream(plan.pack_stream)
-                    pre_h2[gres] = (dst, ev_)
+                    targets[g_idx] = dict(dst=dst, scale_ptr=plan.styles[ic].data_ptr() + 4 * c_prod, scale_stride=sc_.in_channels,
+                                          c8_total=sc_.in_channels // 8, cg0=c_prod // 8, fmt=ofmt)
+                    ps.pre_h2[gres] = (dst, None)
+        needed = [gres for gres in self.geom_feature_resolutions if opts.resume is None or gres >= opts.resume[0]]
+        if not needed:
+            ps.geom_feature = [None] * len(self.geom_feature_resolutions)      # a resumed pass past the last injection
+        else:
+            ps.geom_feature = list(lazy_geom.encode_for(targets))
+            if any(ps.geom_feature[k] is None and k not in targets for k in range(len(ps.geom_feature))):
+                raise RuntimeError("geometry provider returned no tensor for a feature the generator needs in fp32")
 
-            if prepare_only:
-                return {"pre_h2": pre_h2, "keep": keep_alive, "n": n, "slot": plan_slot, "plan": plan}
-            debug_data = {}
-            x = img = None
-            x2 = None
-            x_h2 = None
-            packs_waited = False
-            geo_idx = 0
-            specs = {s.name: (i, s) for i, s in enumerate(cfg.layers)}
-            for res in self.block_resolutions:
-                block = getattr(self, f"b{res}")
-                if resume is not None and res <= resume[0]:
-                    if res == resume[0]:
-                        x = resume[1].to(device=device, dtype=torch.float32).contiguous()
-                        _assert_shape(x, [n, cfg.channels(res), res, res])
-                    if res in self.geom_feature_resolutions:
-                        if res == resume[0]:
-                            x2 = geom_feature[geo_idx].to(torch.float32).contiguous()
-                        geo_idx += 1
-                    continue
-                names = ([f"synthesis.b{res}.conv0"] if res > 4 else []) + [f"synthesis.b{res}.conv1"]
-                if res == 4:
-                    # networks.py:641-643: the learned constant repeated over the batch -- a constant of the weights, so the
-                    # workspace keeps the repeated tensor (built once per maximum batch, dropped with the plan on a reload)
-                    if plan.const_rep is None:
-                        plan.const_rep = block.const.unsqueeze(0).expand(plan.n_max, -1, -1, -1).contiguous()
-                    x = plan.const_rep[:n]
-                elif x is not None:                  # (None: the previous block handed its output over in H2 format)
-                    _assert_shape(x, [None, block.in_channels - (0 if x2 is None else x2.shape[1]), res // 2, res // 2])
-                for name in names:
-                    i, s = specs[name]
-                    layer = self.layer_module(s)
-                    pk = self.packed[name]
-                    if mark is not None and name == mark[1]:
-                        mark[0].record(torch.cuda.current_stream(device))
-                    c2 = 0 if x2 is None else x2.shape[1]
-                    c1 = s.in_channels - c2 if x is None else x.shape[1]
-                    if c1 + c2 != s.in_channels:
-                        raise AssertionError(f"{name}: got {c1}+{c2} input channels, expected {s.in_channels}")
-                    noise_ptr, nstride = None, 0
-                    if noise_mode == "const" and inkernel_from is not None and i >= inkernel_from:
-                        nsrc = _lib.NbNoiseSrc(_p(pk["noise_const_t"]), _p(pk["noise_lin"]), _p(layer.noise_strength), _p(npos), _p(ipos),
-                                               s.block_res, self.img_resolution)
-                        keep_alive.append(nsrc)
-                        noise_ptr, nstride = ctypes.addressof(nsrc), _lib.NB_NOISE_IN_KERNEL
-                    elif noise_mode == "const":
-                        noise_ptr = plan.noise[i].data_ptr()
-                        nstride = 0 if shared else s.block_res * s.block_res
-                    elif noise_mode == "random":
-                        rnd = torch.randn([n, s.block_res, s.block_res], device=device) * layer.noise_strength
-                        keep_alive.append(rnd)
-                        noise_ptr, nstride = rnd.data_ptr(), s.block_res * s.block_res
-                    clamp = -1.0 if layer.conv_clamp is None else float(layer.conv_clamp)
-                    # split-f16 layers hand activations over in H2 format (pre-multiplied by the consumer's styles).
-                    # `x_h2` is this layer's complete H2 input if the previous layer produced it; `next_h2` is the
-                    # consumer's input tensor this layer writes into directly when both ends are split-f16 kernels
-                    # and nothing taps the fp32 activations in between (feature taps, blending, ToRGB, stop_after).
-                    nxt = cfg.layers[i + 1] if i + 1 < len(cfg.layers) else None
-                    at_block_end = s.up == 1
-                    tapped = at_block_end and (block.is_last or res in return_features or res in blended_features
-                                               or stop_after == res)
-                    me_h3 = self._h3_up2_eligible(s) if s.up == 2 else self._h3_eligible(s)
-                    nxt_h3 = nxt is not None and (self._h3_eligible(nxt) if nxt.up == 1 else self._h3_up2_eligible(nxt))
-                    in_fmt = self._operand_fmt(s)                       # 0 = H2 (hi/lo f16), 1 = f8 corrections
-                    out_fmt = self._operand_fmt(nxt) if nxt_h3 else 0
-                    geo_after = (self.geom_feature_channels[self.geom_feature_resolutions.index(res)]
-                                 if at_block_end and res in self.geom_feature_resolutions else 0)
-                    # (the f6 operand format is written by the f8 / f6 up=1 loops only: a producer on H2 operands -- c_in not a
-                    #  multiple of 16 -- hands its output over in fp32 and the pack launch writes the consumer's operands)
-                    fuse_out = (self.h2_handoff and me_h3 and nxt_h3 and not tapped and s.out_channels % 8 == 0
-                                and (out_fmt == 0 or (s.out_channels % 16 == 0 and geo_after % 16 == 0))
-                                and (out_fmt != 2 or (in_fmt != 0 and s.up == 1)))
-                    y = next_h2 = None
-                    fused_rgb = None
-                    if me_h3:
-                        if x_h2 is None:
-                            # producer was not a split-f16 kernel: (x ++ geometry) * styles -> H2 / f8 operands
-                            evp = self._begin_event("pack_h2")
-                            x_h2 = torch.empty(ops.h2_shape(n, s.in_channels, s.in_res, s.in_res), dtype=torch.float16,
-                                               device=device)
-                            pack = (lib.nb_pack_h2_f32, lib.nb_pack_h2f8_f32, lib.nb_pack_h2f6_f32)[in_fmt]
-                            _lib.check(pack(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(x_h2), n, s.in_res * s.in_res, stream),
-                                       "pack_h2")
-                            self._end_event(evp)
-                        ev = self._begin_event(name)
-                        wts = pk["w_f6"] if in_fmt == 2 else pk["w_f8"] if in_fmt else pk["w_h3"]
-                        fuse_rgb = (self.fuse_torgb and block.is_last and s.up == 1 and s.out_channels <= 128
-                                    and res not in blended_features)
-                        targs = None
-                        if fuse_rgb:
-                            # last conv + ToRGB + compositing in one launch; the fp32 activations are only written
-                            # when a caller taps them
-                            tg = self._torgb_setup(plan, n, device, extra)
-                            targs = self._torgb_args(plan, tg, s.out_channels)
-                            if res in return_features or stop_after == res:
-                                y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                        elif fuse_out:
-                            if at_block_end and res in pre_h2:
-                                next_h2 = pre_h2[res][0]                    # geometry channels are (being) packed into it
-                            else:
-                                next_h2 = torch.empty(ops.h2_shape(n, nxt.in_channels, s.block_res, s.block_res),
-                                                      dtype=torch.float16, device=device)
-                        else:
-                            y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                        nst = _p(plan.styles[i + 1]) if next_h2 is not None else None
-                        c_next = nxt.in_channels if next_h2 is not None else 0
-                        if s.up == 1:
-                            _lib.check(lib.nb_modconv3x3_up1_h3_ex(
-                                _p(x_h2), s.in_channels, _p(wts), _p(plan.dcoefs[i]), noise_ptr, nstride, _p(layer.bias),
-                                _p(y), _p(next_h2), nst, c_next, c_next, None if targs is None else ctypes.byref(targs),
-                                in_fmt, out_fmt if next_h2 is not None else 0, n, s.in_res, s.in_res, s.out_channels, 0.2,
-                                layer.act_gain, clamp, stream), name)
-                        else:
-                            _lib.check(lib.nb_modconv3x3_up2_h3_ex(
-                                _p(x_h2), s.in_channels, _p(wts), _p(plan.dcoefs[i]), noise_ptr, nstride, _p(layer.bias),
-                                _p(y), _p(next_h2), nst, c_next, c_next, in_fmt, out_fmt if next_h2 is not None else 0, n,
-                                s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
-                        if fuse_rgb:
-                            fused_rgb = self._torgb_finish(tg, extra)
-                        self.layer_formats[name] = in_fmt
-                        self.layer_kernels[name] = ("modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
-                                                    if s.up == 1 else self._up2_h3_variant_name(in_fmt, n, s))
-                        keep_alive.append(x_h2)
-                        self._end_event(ev)
-                    elif self._small_h3_eligible(s) and c2 == 0 and x is not None:
-                        # small conv1 layer: split-f16 products on 32 x 32 tiles with K split over the waves
-                        ev = self._begin_event(name)
-                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                        _lib.check(lib.nb_modconv3x3_up1_small_h3(
-                            _p(x), c1, _p(pk["w_h3"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr, nstride,
-                            _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
-                        self.layer_kernels[name] = "modconv3x3_up1_small_h3_kernel"
-                        self._end_event(ev)
-                    elif self._small_h3_up2_eligible(s) and c1 % 16 == 0 and c2 % 16 == 0 and x is not None:
-                        # small conv0 layer: the FIR is folded into four per-phase 3x3 kernels (ops.fold_up2_fir), the
-                        # phases run through the same small-tile split-f16 kernel
-                        ev = self._begin_event(name)
-                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                        _lib.check(lib.nb_modconv3x3_up2_small_h3(
-                            _p(x), c1, _p(x2), c2, _p(pk["w_h3_up2"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr, nstride,
-                            _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
-                        self.layer_kernels[name] = "modconv3x3_up1_small_h3_kernel"
-                        self._end_event(ev)
-                    else:
-                        ev = self._begin_event(name)
-                        y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
-                        _lib.check(lib.nb_modconv3x3_f32(
-                            _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
-                            nstride, _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, s.up, 0.2,
-                            layer.act_gain, clamp, stream), name)
-                        self.layer_kernels[name] = self._variant_name(n, s)
-                        self._end_event(ev)
-                    x_h2 = next_h2
-                    keep_alive += [x, x2]
-                    x, x2 = y, None
+    def _pack_geometry_early(self, ps: "_Pass") -> None:
+        """fp32 geometry features x the consumer's styles -> the consumer's operand tensor, on the slot's side stream."""
+        plan, n, device, lib, geom_feature = ps.plan, ps.n, ps.device, _lib.lib(), ps.geom_feature
+        pack_waited = False           # has plan.pack_stream been ordered behind this call's styles launch yet?
+        for g_idx, gres, ip, sp_, ic, sc_, gch, ofmt in self._geometry_consumers(ps):
+            if g_idx >= len(geom_feature) or gres in ps.pre_h2 or geom_feature[g_idx] is None:
+                continue
+            if not (self._h3_eligible(sp_) and self._h3_up2_eligible(sc_) and sp_.out_channels % 8 == 0
+                    and (ofmt == 0 or (sp_.out_channels % 16 == 0 and gch % 16 == 0))):
+                continue
+            g = geom_feature[g_idx]
+            if g.device != device or g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != (n, gch, gres, gres):
+                continue                                           # (the in-line path validates and converts)
+            cur = torch.cuda.current_stream(device)
+            if plan.pack_stream is None:
+                plan.pack_stream = torch.cuda.Stream(device=device)
+                plan.pack_events = {}
+            dst = torch.empty(ops.h2_shape(n, sc_.in_channels, gres, gres), dtype=torch.float16, device=device)
+            # (Measured, round 3: this memory-bound pack -- 201 MB per batch of 32 at R=256 -- costs the kernels it runs
+            #  beside ~45 us wherever it is placed: here, beside the small first layers (b8.conv1 12 -> 58 us), or deferred to
+            #  the b32 / b64 layers (+30 / +33 us), with its grid capped or not.  The painting engine never runs it: its
+            #  encoder writes the operand format directly, encoder.LazyGeometry.)
+            if not pack_waited:
+                # the styles (and, on the lazy path, the encoder's fp32 features) are enqueued on `cur`; tracked apart
+                # from pre_h2, which the lazy path may already have filled for another feature
+                plan.pack_stream.wait_stream(cur)
+                pack_waited = True
+            part = (lib.nb_pack_h2_part_f32, lib.nb_pack_h2f8_part_f32, lib.nb_pack_h2f6_part_f32)[ofmt]
+            c_prod = sc_.in_channels - gch
+            _lib.check(part(_p(g), gch, plan.styles[ic].data_ptr() + 4 * c_prod, sc_.in_channels, _p(dst),
+                            (sc_.in_channels + 7) // 8, c_prod // 8, n, gres * gres, plan.pack_stream.cuda_stream), "pack_h2_part")
+            ev_ = plan.pack_events.get(gres)
+            if ev_ is None:
+                ev_ = plan.pack_events[gres] = torch.cuda.Event()
+            ev_.record(plan.pack_stream)
+            plan.pack_last_event = ev_
+            g.record_stream(plan.pack_stream)
+            dst.record_stream(plan.pack_stream)
+            ps.pre_h2[gres] = (dst, ev_)
 
-                if stop_after is not None and res == stop_after:
-                    return x
-                if block.is_last:
-                    img, triad = fused_rgb if fused_rgb is not None else self._torgb(plan, x, n, stream, extra)
-                    if return_debug_data:
-                        debug_data.update(triad)
-                if res in return_features:
-                    debug_data["features%d_preblend" % res] = x
-                if res in blended_features:
-                    bf = blended_features[res]
-                    x = ops.blend(bf.features.to(device=device, dtype=torch.float32),
-                                  bf.alpha.to(device=device, dtype=torch.float32), x)
-                    if block.is_last:                                   # networks_modified.py:182-185
-                        img, triad = self._torgb(plan, x, n, stream, extra)
-                        debug_data.update(triad)
-                if res in return_features:
-                    debug_data["features%d" % res] = x
+    # ---- step 2: the blocks ----
+    def _run_layers(self, ps: "_Pass"):
+        cfg, opts, plan, n, device = self.cfg, ps.opts, ps.plan, ps.n, ps.device
+        resume = opts.resume
+        specs = {s.name: (i, s) for i, s in enumerate(cfg.layers)}
+        for res in self.block_resolutions:
+            block = getattr(self, f"b{res}")
+            if resume is not None and res <= resume[0]:
+                if res == resume[0]:
+                    ps.x = resume[1].to(device=device, dtype=torch.float32).contiguous()
+                    _assert_shape(ps.x, [n, cfg.channels(res), res, res])
                 if res in self.geom_feature_resolutions:
-                    g = geom_feature[geo_idx]
-                    if g is None and x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
-                        geo_idx += 1                                    # the encoder wrote these channels into x_h2 itself
-                        continue
-                    if g is None:                                       # (the producer did not take the hand-off after all)
-                        g = lazy_geom.plain()[geo_idx]
-                    geo_idx += 1
-                    if g.device != device:
-                        raise RuntimeError(f"geom_feature is on {g.device} but the generator is on {device}")
-                    x2 = g.to(torch.float32).contiguous()
-                    _assert_shape(x2, [n, self.geom_feature_channels[self.geom_feature_resolutions.index(res)], res, res])
-                    if x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
-                        if pre_h2[res][1] is not None and not packs_waited:
-                            # packed early on the side stream.  ONE wait, at the first consumer, for the LAST pack enqueued there (the
-                            # stream runs them in order, and all of them are through long before this point: 131 us into a step whose
-                            # first consumer starts at 168): a cross-stream wait costs ~6 us of idle chip each time, whether or not
-                            # the event has fired (tools/trace_step_timeline.py)
-                            last_ = getattr(plan, "pack_last_event", None)
-                            covers_all = any(v[1] is last_ for v in pre_h2.values())        # (the last pack of THIS pass)
-                            torch.cuda.current_stream(device).wait_event(last_ if covers_all else pre_h2[res][1])
-                            packs_waited = covers_all
-                        keep_alive.append(x2)
-                        x2 = None
-                    elif x_h2 is not None:
-                        # the block's last layer already wrote its channels into the consumer's H2 input: add the
-                        # geometry channels (x the consumer's styles) behind them
-                        inext, snext = specs[f"synthesis.b{2 * res}.conv0"]
-                        c_prod = snext.in_channels - x2.shape[1]
-                        evp = self._begin_event("pack_h2")
-                        part = (lib.nb_pack_h2_part_f32, lib.nb_pack_h2f8_part_f32, lib.nb_pack_h2f6_part_f32)[self._operand_fmt(snext)]
-                        _lib.check(part(_p(x2), x2.shape[1], plan.styles[inext].data_ptr() + 4 * c_prod, snext.in_channels,
-                                        _p(x_h2), (snext.in_channels + 7) // 8, c_prod // 8, n, res * res, stream),
-                                   "pack_h2_part")
-                        self._end_event(evp)
-                        keep_alive.append(x2)
-                        x2 = None
-        if len(debug_data) > 0:
-            return img, debug_data
-        return img
+                    if res == resume[0]:
+                        ps.x2 = ps.geom_feature[ps.geo_idx].to(torch.float32).contiguous()
+                    ps.geo_idx += 1
+                continue
+            names = ([f"synthesis.b{res}.conv0"] if res > 4 else []) + [f"synthesis.b{res}.conv1"]
+            if res == 4:
+                # networks.py:641-643: the learned constant repeated over the batch -- a constant of the weights, so the
+                # workspace keeps the repeated tensor (built once per maximum batch, dropped with the plan on a reload)
+                if plan.const_rep is None:
+                    plan.const_rep = block.const.unsqueeze(0).expand(plan.n_max, -1, -1, -1).contiguous()
+                ps.x = plan.const_rep[:n]
+            elif ps.x is not None:                  # (None: the previous block handed its output over in H2 format)
+                _assert_shape(ps.x, [None, block.in_channels - (0 if ps.x2 is None else ps.x2.shape[1]), res // 2, res // 2])
+            for name in names:
+                self._run_layer(ps, block, res, *specs[name])
+            if opts.stop_after is not None and res == opts.stop_after:
+                return ps.x
+            self._finish_block(ps, block, res, specs)
+        if len(ps.debug_data) > 0:
+            return ps.img, ps.debug_data
+        return ps.img
+
+    def _run_layer(self, ps: "_Pass", block, res: int, i: int, s: LayerSpec) -> None:
+        """One SynthesisLayer (networks.py:362-391) = one fused launch (+ a pack launch in front of a split-f16 layer whose
+        producer was not one).  Reads ps.x / ps.x2 / ps.x_h2, leaves the layer's output there."""
+        cfg, opts, plan, n, device, lib, stream = self.cfg, ps.opts, ps.plan, ps.n, ps.device, _lib.lib(), ps.stream
+        name, noise_mode, extra = s.name, opts.noise_mode, opts.extra
+        x, x2, x_h2 = ps.x, ps.x2, ps.x_h2
+        return_features, blended_features, stop_after = ps.return_features, ps.blended_features, opts.stop_after
+        layer = self.layer_module(s)
+        pk = self.packed[name]
+        if opts.mark is not None and name == opts.mark[1]:
+            opts.mark[0].record(torch.cuda.current_stream(device))
+        c2 = 0 if x2 is None else x2.shape[1]
+        c1 = s.in_channels - c2 if x is None else x.shape[1]
+        if c1 + c2 != s.in_channels:
+            raise AssertionError(f"{name}: got {c1}+{c2} input channels, expected {s.in_channels}")
+        noise_ptr, nstride = None, 0
+        if noise_mode == "const" and ps.inkernel_from is not None and i >= ps.inkernel_from:
+            nsrc = _lib.NbNoiseSrc(_p(pk["noise_const_t"]), _p(pk["noise_lin"]), _p(layer.noise_strength), _p(ps.npos), _p(ps.ipos),
+                                   s.block_res, self.img_resolution)
+            ps.keep_alive.append(nsrc)
+            noise_ptr, nstride = ctypes.addressof(nsrc), _lib.NB_NOISE_IN_KERNEL
+        elif noise_mode == "const":
+            noise_ptr = plan.noise[i].data_ptr()
+            nstride = 0 if ps.shared else s.block_res * s.block_res
+        elif noise_mode == "random":
+            rnd = torch.randn([n, s.block_res, s.block_res], device=device) * layer.noise_strength
+            ps.keep_alive.append(rnd)
+            noise_ptr, nstride = rnd.data_ptr(), s.block_res * s.block_res
+        clamp = -1.0 if layer.conv_clamp is None else float(layer.conv_clamp)
+        # split-f16 layers hand activations over in H2 format (pre-multiplied by the consumer's styles).
+        # `x_h2` is this layer's complete H2 input if the previous layer produced it; `next_h2` is the
+        # consumer's input tensor this layer writes into directly when both ends are split-f16 kernels
+        # and nothing taps the fp32 activations in between (feature taps, blending, ToRGB, stop_after).
+        nxt = cfg.layers[i + 1] if i + 1 < len(cfg.layers) else None
+        at_block_end = s.up == 1
+        tapped = at_block_end and (block.is_last or res in return_features or res in blended_features
+                                   or stop_after == res)
+        me_h3 = self._h3_up2_eligible(s) if s.up == 2 else self._h3_eligible(s)
+        nxt_h3 = nxt is not None and (self._h3_eligible(nxt) if nxt.up == 1 else self._h3_up2_eligible(nxt))
+        in_fmt = self._operand_fmt(s)                       # 0 = H2 (hi/lo f16), 1 = f8 corrections
+        out_fmt = self._operand_fmt(nxt) if nxt_h3 else 0
+        geo_after = (self.geom_feature_channels[self.geom_feature_resolutions.index(res)]
+                     if at_block_end and res in self.geom_feature_resolutions else 0)
+        # (the f6 operand format is written by the f8 / f6 up=1 loops only: a producer on H2 operands -- c_in not a
+        #  multiple of 16 -- hands its output over in fp32 and the pack launch writes the consumer's operands)
+        fuse_out = (self.h2_handoff and me_h3 and nxt_h3 and not tapped and s.out_channels % 8 == 0
+                    and (out_fmt == 0 or (s.out_channels % 16 == 0 and geo_after % 16 == 0))
+                    and (out_fmt != 2 or (in_fmt != 0 and s.up == 1)))
+        y = next_h2 = None
+        ps.fused_rgb = None
+        if me_h3:
+            if x_h2 is None:
+                # producer was not a split-f16 kernel: (x ++ geometry) * styles -> H2 / f8 operands
+                evp = self._begin_event("pack_h2")
+                x_h2 = torch.empty(ops.h2_shape(n, s.in_channels, s.in_res, s.in_res), dtype=torch.float16,
+                                   device=device)
+                pack = (lib.nb_pack_h2_f32, lib.nb_pack_h2f8_f32, lib.nb_pack_h2f6_f32)[in_fmt]
+                _lib.check(pack(_p(x), c1, _p(x2), c2, _p(plan.styles[i]), _p(x_h2), n, s.in_res * s.in_res, stream),
+                           "pack_h2")
+                self._end_event(evp)
+            ev = self._begin_event(name)
+            wts = pk["w_f6"] if in_fmt == 2 else pk["w_f8"] if in_fmt else pk["w_h3"]
+            fuse_rgb = (self.fuse_torgb and block.is_last and s.up == 1 and s.out_channels <= 128
+                        and res not in blended_features)
+            targs = None
+            if fuse_rgb:
+                # last conv + ToRGB + compositing in one launch; the fp32 activations are only written
+                # when a caller taps them
+                tg = self._torgb_setup(plan, n, device, extra)
+                targs = self._torgb_args(plan, tg, s.out_channels)
+                if res in return_features or stop_after == res:
+                    y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+            elif fuse_out:
+                if at_block_end and res in ps.pre_h2:
+                    next_h2 = ps.pre_h2[res][0]                    # geometry channels are (being) packed into it
+                else:
+                    next_h2 = torch.empty(ops.h2_shape(n, nxt.in_channels, s.block_res, s.block_res),
+                                          dtype=torch.float16, device=device)
+            else:
+                y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+            nst = _p(plan.styles[i + 1]) if next_h2 is not None else None
+            c_next = nxt.in_channels if next_h2 is not None else 0
+            if s.up == 1:
+                _lib.check(lib.nb_modconv3x3_up1_h3_ex(
+                    _p(x_h2), s.in_channels, _p(wts), _p(plan.dcoefs[i]), noise_ptr, nstride, _p(layer.bias),
+                    _p(y), _p(next_h2), nst, c_next, c_next, None if targs is None else ctypes.byref(targs),
+                    in_fmt, out_fmt if next_h2 is not None else 0, n, s.in_res, s.in_res, s.out_channels, 0.2,
+                    layer.act_gain, clamp, stream), name)
+            else:
+                _lib.check(lib.nb_modconv3x3_up2_h3_ex(
+                    _p(x_h2), s.in_channels, _p(wts), _p(plan.dcoefs[i]), noise_ptr, nstride, _p(layer.bias),
+                    _p(y), _p(next_h2), nst, c_next, c_next, in_fmt, out_fmt if next_h2 is not None else 0, n,
+                    s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
+            if fuse_rgb:
+                ps.fused_rgb = self._torgb_finish(tg, extra)
+            self.layer_formats[name] = in_fmt
+            self.layer_kernels[name] = ("modconv3x3_up1_h3_kernel<%d>" % (2 if s.out_channels > 64 else 1)
+                                        if s.up == 1 else self._up2_h3_variant_name(in_fmt, n, s))
+            ps.keep_alive.append(x_h2)
+            self._end_event(ev)
+        elif self._small_h3_eligible(s) and c2 == 0 and x is not None:
+            # small conv1 layer: split-f16 products on 32 x 32 tiles with K split over the waves
+            ev = self._begin_event(name)
+            y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+            _lib.check(lib.nb_modconv3x3_up1_small_h3(
+                _p(x), c1, _p(pk["w_h3"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
+            self.layer_kernels[name] = "modconv3x3_up1_small_h3_kernel"
+            self._end_event(ev)
+        elif self._small_h3_up2_eligible(s) and c1 % 16 == 0 and c2 % 16 == 0 and x is not None:
+            # small conv0 layer: the FIR is folded into four per-phase 3x3 kernels (ops.fold_up2_fir), the
+            # phases run through the same small-tile split-f16 kernel
+            ev = self._begin_event(name)
+            y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+            _lib.check(lib.nb_modconv3x3_up2_small_h3(
+                _p(x), c1, _p(x2), c2, _p(pk["w_h3_up2"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr, nstride,
+                _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, 0.2, layer.act_gain, clamp, stream), name)
+            self.layer_kernels[name] = "modconv3x3_up1_small_h3_kernel"
+            self._end_event(ev)
+        else:
+            ev = self._begin_event(name)
+            y = torch.empty([n, s.out_channels, s.block_res, s.block_res], dtype=torch.float32, device=device)
+            _lib.check(lib.nb_modconv3x3_f32(
+                _p(x), c1, _p(x2), c2, _p(pk["wpk"]), _p(plan.styles[i]), _p(plan.dcoefs[i]), noise_ptr,
+                nstride, _p(layer.bias), _p(y), n, s.in_res, s.in_res, s.out_channels, s.up, 0.2,
+                layer.act_gain, clamp, stream), name)
+            self.layer_kernels[name] = self._variant_name(n, s)
+            self._end_event(ev)
+        ps.x_h2 = next_h2
+        ps.keep_alive += [x, x2]
+        ps.x, ps.x2 = y, None
+
+    def _finish_block(self, ps: "_Pass", block, res: int, specs) -> None:
+        """What follows a block's last layer (networks_modified.py:168-222): ToRGB of the last block, feature taps, blending, and the
+        geometry feature that is concatenated to the next block's input."""
+        opts, plan, n, device, lib, stream = ps.opts, ps.plan, ps.n, ps.device, _lib.lib(), ps.stream
+        extra, pre_h2 = opts.extra, ps.pre_h2
+        if block.is_last:
+            ps.img, triad = ps.fused_rgb if ps.fused_rgb is not None else self._torgb(plan, ps.x, n, stream, extra)
+            if ps.return_debug_data:
+                ps.debug_data.update(triad)
+        if res in ps.return_features:
+            ps.debug_data["features%d_preblend" % res] = ps.x
+        if res in ps.blended_features:
+            bf = ps.blended_features[res]
+            ps.x = ops.blend(bf.features.to(device=device, dtype=torch.float32),
+                             bf.alpha.to(device=device, dtype=torch.float32), ps.x)
+            if block.is_last:                                   # networks_modified.py:182-185
+                ps.img, triad = self._torgb(plan, ps.x, n, stream, extra)
+                ps.debug_data.update(triad)
+        if res in ps.return_features:
+            ps.debug_data["features%d" % res] = ps.x
+        if res not in self.geom_feature_resolutions:
+            return
+        x_h2 = ps.x_h2
+        g = ps.geom_feature[ps.geo_idx]
+        if g is None and x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
+            ps.geo_idx += 1                                     # the encoder wrote these channels into x_h2 itself
+            return
+        if g is None:                                           # (the producer did not take the hand-off after all)
+            g = ps.lazy_geom.plain()[ps.geo_idx]
+        ps.geo_idx += 1
+        if g.device != device:
+            raise RuntimeError(f"geom_feature is on {g.device} but the generator is on {device}")
+        x2 = g.to(torch.float32).contiguous()
+        _assert_shape(x2, [n, self.geom_feature_channels[self.geom_feature_resolutions.index(res)], res, res])
+        if x_h2 is not None and res in pre_h2 and x_h2 is pre_h2[res][0]:
+            if pre_h2[res][1] is not None and not ps.packs_waited:
+                # packed early on the side stream.  ONE wait, at the first consumer, for the LAST pack enqueued there (the
+                # stream runs them in order, and all of them are through long before this point: 131 us into a step whose
+                # first consumer starts at 168): a cross-stream wait costs ~6 us of idle chip each time, whether or not
+                # the event has fired (tools/trace_step_timeline.py)
+                last_ = getattr(plan, "pack_last_event", None)
+                covers_all = any(v[1] is last_ for v in pre_h2.values())        # (the last pack of THIS pass)
+                torch.cuda.current_stream(device).wait_event(last_ if covers_all else pre_h2[res][1])
+                ps.packs_waited = covers_all
+            ps.keep_alive.append(x2)
+            x2 = None
+        elif x_h2 is not None:
+            # the block's last layer already wrote its channels into the consumer's H2 input: add the
+            # geometry channels (x the consumer's styles) behind them
+            inext, snext = specs[f"synthesis.b{2 * res}.conv0"]
+            c_prod = snext.in_channels - x2.shape[1]
+            evp = self._begin_event("pack_h2")
+            part = (lib.nb_pack_h2_part_f32, lib.nb_pack_h2f8_part_f32, lib.nb_pack_h2f6_part_f32)[self._operand_fmt(snext)]
+            _lib.check(part(_p(x2), x2.shape[1], plan.styles[inext].data_ptr() + 4 * c_prod, snext.in_channels,
+                            _p(x_h2), (snext.in_channels + 7) // 8, c_prod // 8, n, res * res, stream),
+                       "pack_h2_part")
+            self._end_event(evp)
+            ps.keep_alive.append(x2)
+            x2 = None
+        ps.x2 = x2
 
     def _torgb_setup(self, plan: _Plan, n, dev, extra):
         """Allocate the ToRGB outputs and collect the launch arguments (shared by the standalone and fused forms)."""

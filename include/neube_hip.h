@@ -352,8 +352,8 @@ int nb_modconv3x3_up2_h3_ex(const void* x, int c_in, const void* wts, const floa
                             float alpha, float gain, float clamp, void* stream);
 
 /* Name of the kernel nb_modconv3x3_up2_h3 / _ex launches for this problem shape (the name rocprofv3 reports: the round-3 8-wave
- * kernel in one of its tile forms, the software-pipelined 8-wave kernel of csrc/nb_modconv_up2v.hip, or the one-wave-per-SIMD form
- * of csrc/nb_modconv_up2w.hip), so that a benchmark can attribute its per-launch timings to kernels.  in_fmt as in _ex. */
+ * kernel in one of its tile forms, or the software-pipelined 8-wave kernel of csrc/nb_modconv_up2v.hip), so that a benchmark can
+ * attribute its per-launch timings to kernels.  in_fmt as in _ex. */
 int nb_modconv3x3_up2_h3_variant(int in_fmt, int c_in, int c_out, int n, int h, int w, char* buf, int buflen);
 
 /* The same layer for SMALL images (csrc/nb_modconv_small.hip; the <= 64x64 conv1 layers): split-f16 products on

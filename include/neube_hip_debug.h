@@ -20,7 +20,7 @@ void nb_debug_set_up1_rows(int nbw);
  * round-3 loop, 1 = the software-pipelined loop.  tests/test_hip_f8.py asserts both bit-identical. */
 void nb_debug_set_up1_v2(int mode);
 /* ... its ping-pong form (round 5: waves 4-7 one segment behind waves 0-3, a load segment against a compute segment on every SIMD):
- * -1 = automatic (NB_UP1_PP, default ON since the end of round 5: launches -2.5 %, step +0.5 ... +1.0 %), 0 / 1 = off / on.  Bit-identical
+ * -1 = automatic (ON since the end of round 5: launches -2.5 %, step +0.5 ... +1.0 %), 0 / 1 = off / on.  Bit-identical
  * (tests/test_hip_f8.py). */
 void nb_debug_set_up1_pp(int mode);
 
@@ -39,11 +39,6 @@ void nb_debug_set_up2_tile(int tqh);
  * CU), 1 = 4 waves / 12 x 16 tiles / 2 stages (two per CU).  tests/test_hip_f8.py asserts both bit-identical. */
 void nb_debug_set_up2_pair(int mode);
 
-/* The one-wave-per-SIMD ("wide") form of the split-f16 up=2 kernel (csrc/nb_modconv_up2w.hip: 4 waves, 64 c_out x 12 x 16 quads,
- * 256 accumulator registers per wave): -1 = automatic (launches of >= 768 such workgroups), 0 = never, 1 = wherever the shape
- * allows (f8 operands, c_out % 64 == 0, w % 16 == 0).  tests/test_hip_f8.py asserts it bit-identical to the 8-wave kernel. */
-void nb_debug_set_up2_wide(int mode);
-
 /* The 8-wave split-f16 up=2 kernel with the software-pipelined K loop (csrc/nb_modconv_up2v.hip; f8 operands, 12 x 32 tiles):
  * -1 = automatic (every f8 launch that takes the 12-row tiles), 0 = never (the round-3 kernel), 1 = wherever the shape allows.
  * tests/test_hip_f8.py asserts the two bit-identical. */
@@ -51,6 +46,20 @@ void nb_debug_set_up2_v2(int mode);
 
 /* Tile form of nb_enc_conv3x3_h3: -1 = automatic, 0 = large tiles, 1 = small split-K tiles. */
 void nb_debug_set_enc_small(int mode);
+
+/* Feature-off bit mask of the conv kernels for same-box A/B runs (0 on the product path): 8 = no XCD-aware workgroup order,
+ * 32 = the round-3 order of the up=2 launches, ... (the uses of `p.dbg` in csrc/).  Until round 5 the launchers read the environment
+ * variable NB_DEBUG themselves; since round 6 the library reads NO environment variable -- tools/nb_debug_env.py maps the developer
+ * variables (NB_DEBUG, NB_STAGGER, NB_UP1_PP, NB_UP2_TQH, ...) onto these setters for the A/B scripts. */
+void nb_debug_set_flags(int flags);
+/* First-round stagger of the large split-f16 kernels: workgroup b sleeps (b % 8) * ticks s_sleep units before its prologue; 0 = off. */
+void nb_debug_set_stagger(int ticks);
+/* The 4-wave two-workgroups-per-CU form of the H2 up=1 kernel: -1 = automatic (images <= 32 x 32), 0 / 1 = never / always. */
+void nb_debug_set_up1_small(int mode);
+/* Workgroups the weight-gradient launches aim for (default 256 = one per CU; <= 0 restores it); tools/bench_wgrad.py. */
+void nb_debug_set_wgrad_wgs(int wgs);
+/* 1 = every nb_upfirdn2d_f32 call on the run-time-everything kernel (tests compare it with the specialised ones), 0 = automatic. */
+void nb_debug_set_upfirdn_generic(int on);
 
 /* Per-workgroup phase timestamps of the next split-f16 (resp. fp32 split-K) conv launches: buf = device pointer to
  * capacity_workgroups x 8 uint64 (s_memrealtime ticks; layout: tools/phase_times.py), NULL = off. */

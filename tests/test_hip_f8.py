@@ -166,12 +166,9 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for tqh in (12, 8, 5, "pair", "wide", "v2"):
-            if tqh == "wide" and not fmt:
-                continue                                  # (the wide form exists for f8 operands)
-            lib.nb_debug_set_up2_tile(12 if tqh == "pair" else 0 if tqh in ("wide", "v2") else tqh)
+        for tqh in (12, 8, 5, "pair", "v2"):
+            lib.nb_debug_set_up2_tile(12 if tqh == "pair" else 0 if tqh == "v2" else tqh)
             lib.nb_debug_set_up2_pair(1 if tqh == "pair" else 0)
-            lib.nb_debug_set_up2_wide(1 if tqh == "wide" else 0)
             lib.nb_debug_set_up2_v2(1 if tqh == "v2" else 0)        # (12 = the round-3 kernel on the same tiles)
             y = torch.empty([n, co, 2 * h, 2 * w], device="cuda")
             out = torch.zeros(ops.h2_shape(n, co, 2 * h, 2 * w), dtype=torch.float16, device="cuda")
@@ -185,17 +182,10 @@ def test_up2_tile_heights_agree(fmt, ci, co, h, w):
     finally:
         lib.nb_debug_set_up2_tile(0)
         lib.nb_debug_set_up2_pair(-1)
-        lib.nb_debug_set_up2_wide(-1)
         lib.nb_debug_set_up2_v2(-1)
     # the 8-wave kernel with the software-pipelined K loop (same tiles as 12; f8 and H2 operands)
     assert torch.equal(res[12][0], res["v2"][0])
     assert torch.equal(res[12][1], res["v2"][1])
-    if fmt:
-        pass
-        # the one-wave-per-SIMD form (64 c_out x 12 x 16 quads per workgroup; 26 and 32 rows end in ragged tiles whose waves
-        # multiply one or none of their two position blocks)
-        assert torch.equal(res[12][0], res["wide"][0])
-        assert torch.equal(res[12][1], res["wide"][1])
     assert torch.equal(res[12][0], res[5][0])
     assert torch.equal(res[12][1], res[5][1])
     assert torch.equal(res[12][0], res[8][0])                # 8-row tiles (launches that would end in a mostly empty round of 12-row tiles)

@@ -76,7 +76,9 @@ def test_bench_canvas_through_rccl_at_world_size_1(level):
     out = _one_line(r)
     _check_rccl(out["rccl"])
     assert out["n_gpus"] == 1 and "all_to_all_single (RCCL)" in out["parallelism"]
-    assert out["vs_reference_canvas"]["max_lsb"] <= 1 and out["vs_reference_canvas"]["bytes_differing"] < 5e-3
+    if level == 2:                       # (the fixture holds the whole reference canvas at level 2, strided rows only at level 0)
+        assert out["vs_reference_canvas"]["max_lsb"] <= 1 and out["vs_reference_canvas"]["bytes_differing"] < 5e-3
+    assert out["value"] > 0 and out["tiles"] == 12
     assert len(out["gather_wait_ms"]) == 1 and out["gather_wait_ms"][0] is not None and out["gather_wait_ms"][0] >= 0
     if level > 0:
         hb = out["halo_bytes_per_rank"][0]

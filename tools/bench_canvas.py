@@ -23,6 +23,8 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import config as cfgmod, weights as wmod, encoder as encmod, painting, launch  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 from brushstroke_engine_amd.networks import Generator  # noqa: E402
 
 

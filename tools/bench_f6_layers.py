@@ -4,6 +4,8 @@ import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib, ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 
 lib = _lib.lib()
 n = int(os.environ.get("NB_N", "32"))

@@ -1,6 +1,8 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 for split in (False, True):
     ops.WGRAD_SPLIT_F16 = split
     for (n, c, h) in ((8, 128, 128), (8, 64, 256), (8, 128, 64)):

@@ -6,7 +6,7 @@ set -e
 name=$1; src=$2; defs=$3
 root=$(git rev-parse --show-toplevel); cs=$root/brushstroke_engine_amd/csrc
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt"
-case $src in nb_modconv.hip|nb_ops.hip|nb_modconv_up2v.hip|nb_modconv_up2w.hip) FL="$FL -fno-slp-vectorize";; esac
+case $src in nb_modconv.hip|nb_ops.hip|nb_modconv_up2v.hip) FL="$FL -fno-slp-vectorize";; esac
 tmp=$(mktemp -d)
 /opt/rocm/bin/hipcc $FL $defs -c $cs/$src -o $tmp/variant.o
 others=$(ls $cs/build/*.o | grep -v "/$src\.")

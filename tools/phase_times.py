@@ -12,6 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib, ops  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 
 
 FMT = int(os.environ.get("NB_PHASE_FMT", "1" if os.environ.get("NB_PHASE_F8") == "1" else "0"))      # operand format: 0 H2, 1 f8, 2 f6

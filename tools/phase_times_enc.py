@@ -5,6 +5,8 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 dev = torch.device("cuda:0")
 lib = _lib.lib()
 lib.nb_debug_set_enc_timestamps.argtypes = [ctypes.c_void_p, ctypes.c_int]; lib.nb_debug_set_enc_timestamps.restype = None

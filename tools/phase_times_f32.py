@@ -3,6 +3,8 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib, ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 lib = _lib.lib()
 lib.nb_debug_set_timestamps_f32.argtypes = [ctypes.c_void_p, ctypes.c_int]; lib.nb_debug_set_timestamps_f32.restype = None
 for res in (4, 8, 16, 32, 64):

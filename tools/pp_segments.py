@@ -4,6 +4,8 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib, ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 lib = _lib.lib()
 lib.nb_debug_set_timestamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for ci, co, res in ((128, 128, 128), (64, 64, 256)):

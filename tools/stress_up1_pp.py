@@ -4,6 +4,8 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import _lib, ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 lib = _lib.lib()
 reps = int(os.environ.get("NB_REPS", "300"))
 S = torch.cuda.current_stream().cuda_stream

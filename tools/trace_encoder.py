@@ -5,6 +5,8 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import encoder as encmod, synthetic, config as cfgmod
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 dev = torch.device("cuda:0")
 R, B = int(os.environ.get("NB_R", "256")), int(os.environ.get("NB_B", "32"))
 enc = encmod.HipGeometryEncoder(encmod.random_encoder_state_dict(5), device=dev)

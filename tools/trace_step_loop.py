@@ -3,6 +3,8 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nb_debug_env; nb_debug_env.apply()          # developer NB_* switches -> the library's debug setters (it reads no environment itself)
 from brushstroke_engine_amd.networks import Generator
 dev = torch.device("cuda:0")
 cfg = cfgmod.style1_config(256)
