@@ -157,6 +157,9 @@ MODE_DTYPE = {
           "relative per product, ~5e-6 from an all-fp32 evaluation on pixels",
     "f8": "f16 hi x f16 hi MFMA + 2 block-scaled fp8 (e4m3) correction products per fp32 product, fp32 accumulate: ~2^-15 relative "
           "per product, ~1e-4 from an all-fp32 evaluation on pixels (north_star budget 1e-3)",
+    "f16": "f16 hi x f16 hi MFMA only in the four large launches (the f8 mode with its correction products skipped): plain single-f16 products, "
+           "~3e-3 from an all-fp32 evaluation on pixels -- OUTSIDE the 1e-3 budget: the reference's own shipped arithmetic for blocks >= 32^2 "
+           "(training/networks.py:634-638), a timing data point, NOT a parity mode",
     "f6": "f8 with fp6 (e2m3) correction products (per-pixel 16-channel block scales) in the two large up=2 launches: the round-5 experiment, "
           "not faster than f8 (profiles/r05_f6_ab.txt); everything else as f8",
 }
@@ -166,7 +169,8 @@ def scheme_ceiling(mode):
     """Matrix work a mode executes per algorithmic FLOP, at the nominal dense peaks."""
     return {"f32": PEAK_F32_MATRIX_TFLOPS, "h3": PEAK_F16_MATRIX_TFLOPS / 3,
             "f8": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS),
-            "f6": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS)}[mode]         # (priced as f8: most of its launches are)
+            "f6": 1 / (1 / PEAK_F16_MATRIX_TFLOPS + 2 / PEAK_FP8_MATRIX_TFLOPS),         # (priced as f8: most of its launches are)
+            "f16": PEAK_F16_MATRIX_TFLOPS}[mode]                                        # (priced at its four large launches: one f16 MFMA FLOP per algorithmic FLOP)
 
 
 def load_traffic(mode, res, batch):
@@ -185,8 +189,8 @@ def load_traffic(mode, res, batch):
         if stamp.get("source_digest") != _b.source_digest():
             return {}, "profiles/hbm_traffic.json was measured on other kernel sources (stale): not used"
         table = tj.get("modes", {}).get(mode)
-        if table is None and mode == "f6":
-            table = tj.get("modes", {}).get("f8")                      # (the same kernels; the f6 template forms read the same bytes)
+        if table is None and mode in ("f6", "f16"):
+            table = tj.get("modes", {}).get("f8")                      # (the same kernels; the f6 / hi-only template forms read the same bytes)
         if table is None and mode == "f8" and "modes" not in tj:
             table = {k: v for k, v in tj.items() if not k.startswith("_")}
         if table is None:
@@ -513,6 +517,9 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
                                     "what": "f16 MFMA FLOPs actually executed for the algorithmic ones (3 products per fp32 "
                                             "product; halo / block-rounding overhead of the up=2 kernel not included)"}
                                    if mode == "h3" else
+                                   {"tflops": round(achieved, 1), "frac": round(achieved / dom_peak, 4),
+                                    "what": "hi-only f16 products: one f16 MFMA FLOP per algorithmic FLOP"}
+                                   if mode == "f16" else
                                    {"f16_tflops": round(achieved, 1), "fp8_tflops": round(2 * achieved, 1),
                                     "frac": round(achieved / PEAK_F16_MATRIX_TFLOPS + 2 * achieved / PEAK_FP8_MATRIX_TFLOPS, 4),
                                     "what": "matrix work actually executed per algorithmic FLOP: 1 f16 MFMA FLOP (main product) + "
@@ -542,6 +549,8 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
                 "note": (("fp32 MFMA" if not split else
                           "split-f16 kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
                           if mode == "h3" else
+                          "hi-only f16 products: one f16 MFMA FLOP per algorithmic FLOP (NOT a parity mode: ~3e-3 from fp32)"
+                          if mode == "f16" else
                           "split-f16 + fp8-correction kernels spend 2 f16-MFMA-equivalents of matrix time per algorithmic fp32 FLOP: "
                           "frac (against the f16 peak) <= 1/2 by construction")
                          + ("; launch durations are from this mode's SINGLE-STREAM timed leg (value_single_stream: the same K steps "
@@ -670,6 +679,8 @@ def compact_line(out):
         modes[m] = {"value": r["value"], "ms_per_step": r["ms_per_step"], **_pick(r, ("value_single_stream", "streams")),
                     "roofline": _pick(r["roofline"], ("kernel", "achieved", "peak", "frac", "frac_of_sustained", "launch_ms")),
                     "parity": (r.get("parity") or {}).get("max_abs_rgba_vs_oracle")}
+        if m == "f16":
+            modes[m]["note"] = "reference's shipped arithmetic (plain f16 products); NOT a parity mode: outside the 1e-3 budget"
     c["modes"] = modes
     if out.get("rccl"):
         f = out["rccl"]
@@ -690,7 +701,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and with it the live parity of every mode)")
     ap.add_argument("--no-latency", action="store_true", help="skip the auxiliary legs: batch-1 hipGraph latency, three-steps-in-flight throughput")
-    ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f6", "f32"],
+    ap.add_argument("--conv-mode", default=None, choices=["h3", "f8", "f6", "f32", "f16"],
                     help="the PRIMARY arithmetic mode = top-level value; default: the library default (networks.DEFAULT_CONV_MODE = f8). "
                          "f8: f16 main product + two block-scaled fp8 correction products (pixels within 1e-4 of fp32; budget 1e-3); "
                          "h3: three f16 products on hi/lo-split operands (5e-6); f32: all layers on the fp32 MFMA kernels")
@@ -794,7 +805,8 @@ def main():
         args.conv_mode = DEFAULT_CONV_MODE
     if args.modes in (None, "all"):
         # (f6 -- the round-5 experiment, not faster and less accurate than f8 -- only on request: --modes f6 or all)
-        modes = (["f8", "h3", "f32", "f6"] if args.modes == "all" else ["f8", "h3", "f32"]) if (world == 1 or args.modes == "all") else [args.conv_mode]
+        # (f16: the reference's shipped precision, OUTSIDE the parity budget -- a timing data point, labelled so in `modes.f16.note`)
+        modes = (["f8", "h3", "f32", "f16", "f6"] if args.modes == "all" else ["f8", "h3", "f32", "f16"]) if (world == 1 or args.modes == "all") else [args.conv_mode]
     elif args.modes == "primary":
         modes = [args.conv_mode]
     else:

@@ -96,6 +96,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
         with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
             objs = list(ex.map(compile_one, SOURCES))
+        for old in os.listdir(objdir):                             # objects of sources that left the tree (tools/build_variant.sh links build/*.o)
+            if old.endswith(".o") and old.split(".hip.")[0] + ".hip" not in SOURCES:
+                os.remove(os.path.join(objdir, old))
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"] + objs + ["-o", tmp]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)

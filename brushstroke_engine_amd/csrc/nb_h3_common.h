@@ -38,6 +38,42 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int v6i __attribute__((ext_vector_type(6)));
 
+// The matrix instructions of the f8 K loops.  -DNB_MOCK16 (developer TIMING experiment, wrong results; tools/build_variant.sh, profiles/
+// r06_ab_mfma16.txt): every 32x32 instruction is replaced by TWO 16x16 instructions of half its MACs each on the same operand and
+// accumulator registers -- `v_mfma_f32_16x16x32_f16` (2 x 16 cycles for 32) and `v_mfma_scale_f32_16x16x128_f8f6f4` (2 x 32 for 64) --,
+// i.e. the instruction stream a 16x16-shaped body with the same 64 x 64 wave tile would execute (same fragment reads per MAC, same
+// LDS-DMA, same matrix cycles), to measure what the shape is worth in wall time (the clock the chip holds: MI355X_MICROARCH.md, DVFS
+// give-back item 7) BEFORE the operand layouts, pairings and epilogues of such a body are written.
+#ifdef NB_MOCK16
+__device__ __forceinline__ f32x16 nb_mock16_f16(h8 a, h8 b, f32x16 c, int q) {
+    f32x4 c0, c1;
+    const int o = (q & 1) * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c0[r] = c[o + r]; c1[r] = c[o + 4 + r]; }
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c[o + r] = c0[r]; c[o + 4 + r] = c1[r]; }
+    return c;
+}
+__device__ __forceinline__ f32x16 nb_mock16_fp8(i32x8 a, i32x8 b, f32x16 c, int sa, int sb, int q) {
+    f32x4 c0, c1;
+    const int o = (q & 1) * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c0[r] = c[o + r]; c1[r] = c[o + 4 + r]; }
+    c0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c0, 0, 0, 0, sa, 0, sb);
+    c1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c1, 0, 0, 0, sa, 0, sb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c[o + r] = c0[r]; c[o + 4 + r] = c1[r]; }
+    return c;
+}
+#define NB_MFMA_F16(a, b, c, q) nb_mock16_f16(a, b, c, q)
+#define NB_MFMA_FP8(a, b, c, sa, sb, q) nb_mock16_fp8(a, b, c, sa, sb, q)
+#else
+#define NB_MFMA_F16(a, b, c, q) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define NB_MFMA_FP8(a, b, c, sa, sb, q) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb)
+#endif
+
 // s_waitcnt vmcnt(N) as the BUILTIN, not inline assembly: the compiler's own wait bookkeeping (SIInsertWaitcnts) then sees
 // the LDS-DMA operations complete.  With asm waits it never does, keeps every LDS-DMA "pending" for the rest of the kernel and
 // -- because an LDS-DMA counts as a flat access that may touch LDS -- turns every wait for a fragment read into

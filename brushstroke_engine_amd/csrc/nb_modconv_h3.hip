@@ -91,8 +91,11 @@ __device__ __forceinline__ float nb_h3_act(float a, float dg, float nbg, float a
 // of the step's fragment reads and its LDS-DMA pieces, no matrix instruction -- and a COMPUTE segment -- the step's 18 MFMAs back to back,
 // every operand in registers --, waves 4-7 run one segment behind waves 0-3, a barrier after every segment: while one wave of a SIMD
 // computes, its partner loads.  Same per-accumulator order of products as the other f8 loops: bit-identical.
-template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false, bool F6 = false, bool PPK = false>
+// HO (with PPK, round 6): "hi only" -- the ping-pong f8 loop WITHOUT its correction products (plain single-f16 evaluation, ~3e-3 from
+// fp32: Generator(conv_mode="f16"), a timing data point at the reference's shipped precision, not a parity mode; see modconv3x3_up2v_kernel).
+template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false, bool F6 = false, bool PPK = false, bool HO = false>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
+    static_assert(!HO || PPK, "the hi-only form is a variant of the ping-pong f8 loop");
     static_assert(!F6 || (F8 && V2), "the f6 form is a variant of the software-pipelined f8 loop");
     static_assert(!PPK || (F8 && V2 && !F6), "the ping-pong form is a variant of the software-pipelined f8 loop");
     NB_TSTAMP(0);
@@ -456,16 +459,17 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 NB_SB;
             });
         };
-        auto mf_f16 = [&](h8 (&a)[MB], h8 (&b)[NBW]) {
-            return [&](auto mb_, auto nb_) {
+        // (q: which half of the accumulator tile the NB_MOCK16 timing build writes; unused otherwise)
+        auto mf_f16 = [&](h8 (&a)[MB], h8 (&b)[NBW], int q = 0) {
+            return [&, q](auto mb_, auto nb_) {
                 constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = NB_MFMA_F16(a[mb], b[nb], acc[mb][nb], q);
             };
         };
-        auto mf_fp8 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW]) {
-            return [&](auto mb_, auto nb_) {
+        auto mf_fp8 = [&](i32x8 (&a)[MB], i32x8 (&b)[NBW], int q = 0) {
+            return [&, q](auto mb_, auto nb_) {
                 constexpr int mb = decltype(mb_)::value, nb = decltype(nb_)::value;
-                acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mb], b[nb], acc[mb][nb], 0, 0, 0, sa, 0, sb);
+                if constexpr (!HO) acc[mb][nb] = NB_MFMA_FP8(a[mb], b[nb], acc[mb][nb], sa, sb, q);
             };
         };
         using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
@@ -507,11 +511,11 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 // (a piece costs the wave ~60 cycles of issue: behind a 64-cycle fp8 MFMA it is hidden, behind a 32-cycle f16 one the pipe waits)
                 constexpr int N1 = NDMA < NM ? NDMA : NM, R = NDMA - N1;
                 auto dma_r = [&](auto i_) { dma(std::integral_constant<int, decltype(i_)::value + N1>{}); };
-                group(std::integral_constant<int, 0>{}, mf_f16(ah0, bh0), [](auto) {});
-                group(std::integral_constant<int, 0>{}, mf_f16(ah1, bh1), [](auto) {});
-                group(std::integral_constant<int, N1>{}, mf_fp8(al01, bl01), dma);
-                group(std::integral_constant<int, ODD ? 0 : R>{}, mf_f16(ah2, bh2), dma_r);
-                if constexpr (ODD) group(std::integral_constant<int, R>{}, mf_fp8(al2, bl2), dma_r);
+                group(std::integral_constant<int, 0>{}, mf_f16(ah0, bh0, 0), [](auto) {});
+                group(std::integral_constant<int, 0>{}, mf_f16(ah1, bh1, 1), [](auto) {});
+                group(std::integral_constant<int, N1>{}, mf_fp8(al01, bl01, 0), dma);
+                group(std::integral_constant<int, ODD ? 0 : R>{}, mf_f16(ah2, bh2, 1), dma_r);
+                if constexpr (ODD) group(std::integral_constant<int, R>{}, mf_fp8(al2, bl2, 0), dma_r);
                 NB_SB;
             };
             const bool grp_b = wv >= 4;
@@ -1265,7 +1269,7 @@ static int launch_h3s(H3Params p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int MW, bool F8 = false, int NBW = 2, bool V2 = false, bool F6 = false, bool PP = false>
+template <int MW, bool F8 = false, int NBW = 2, bool V2 = false, bool F6 = false, bool PP = false, bool HO = false>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * NBW, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
@@ -1274,11 +1278,11 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
 }
@@ -1306,6 +1310,7 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
                           void* stream, const TorgbParams* tg = nullptr, int in_fmt = 0, int out_fmt = 0) {
     const bool f8 = in_fmt != 0, f6 = in_fmt == 2;          // (the f6 form is a variant of the f8 loop: same containers, same staging)
+    const bool hi_only = in_fmt == 3;                       // f8 containers, correction products skipped (conv_mode "f16": where the ping-pong loop runs)
     NB_REQUIRE(out_fmt == 0 || ((out_fmt == 1 || out_fmt == 2) && y_h2 && c_out % 16 == 0 && c_next % 16 == 0),
                "modconv3x3_up1_h3: f8 / f6 output needs an H2 destination and c_out, c_next %% 16 == 0");
     NB_REQUIRE(x_h2 && w_h3 && dcoefs && bias && (tg ? !y_h2 : ((y != nullptr) != (y_h2 != nullptr))), "modconv3x3_up1_h3: null pointer");
@@ -1360,6 +1365,7 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     }
     // the ping-pong form of that loop (full-height tiles): nb_debug_set_up1_pp
     const bool pp = (g_force_up1_pp >= 0 ? g_force_up1_pp : NB_UP1_PP_DEFAULT) != 0;
+    if (f8 && v2 && pp && hi_only) return c_out > 64 ? launch_h3<2, true, 2, true, false, true, true>(p, n, st) : launch_h3<1, true, 2, true, false, true, true>(p, n, st);
     if (f8 && v2 && pp) return c_out > 64 ? launch_h3<2, true, 2, true, false, true>(p, n, st) : launch_h3<1, true, 2, true, false, true>(p, n, st);
     if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 2, true>(p, n, st) : launch_h3<1, true, 2, true>(p, n, st);
     if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
@@ -1373,7 +1379,7 @@ extern "C" int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts,
                                       const float* next_styles, int next_stride, int c_next, const NbTorgbArgs* t, int in_fmt,
                                       int out_fmt, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
                                       void* stream) {
-    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 2, "modconv3x3_up1_h3: operand format must be 0 (H2), 1 (f8) or 2 (f6)");
+    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 3, "modconv3x3_up1_h3: operand format must be 0 (H2), 1 (f8), 2 (f6) or 3 (f8 containers, hi x hi products only)");
     if (!t)
         return nb_up1_h3_impl(x, c_in, wts, dcoefs, noise, noise_stride_n, bias, y_f32, y_h2, next_styles, next_stride, c_next,
                               n, h, w, c_out, alpha, gain, clamp, stream, nullptr, in_fmt, out_fmt);
@@ -2094,7 +2100,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
                           int64_t noise_stride_n, const float* bias, float* y, void* y_h2, const float* next_styles,
                           int next_stride, int c_next, int n, int h, int w, int c_out, float alpha, float gain, float clamp,
                           void* stream, int in_fmt = 0, int out_fmt = 0) {
-    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 2 && (out_fmt == 0 || out_fmt == 1), "modconv3x3_up2_h3: input operand format must be 0 (H2), 1 (f8) or 2 (f6), "
+    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 3 && (out_fmt == 0 || out_fmt == 1), "modconv3x3_up2_h3: input operand format must be 0 (H2), 1 (f8), 2 (f6) or 3 (f8, hi only), "
                "output format 0 or 1 (the up=2 epilogue does not write the f6 format)");
     NB_REQUIRE(in_fmt == 0 || c_in % 16 == 0, "modconv3x3_up2_h3: the f8 / f6 operand formats need c_in %% 16 == 0 (got %d)", c_in);
     NB_REQUIRE(out_fmt == 0 || (y_h2 && c_out % 16 == 0 && c_next % 16 == 0), "modconv3x3_up2_h3: f8 output needs an H2 destination and c_out, c_next %% 16 == 0");
@@ -2133,7 +2139,7 @@ static int nb_up2_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
 
 extern "C" int nb_modconv3x3_up2_h3_variant(int in_fmt, int c_in, int c_out, int n, int h, int w, char* buf, int buflen) {
     NB_REQUIRE(buf && buflen > 0, "modconv3x3_up2_h3_variant: bad buffer");
-    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 2 && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16 || w == 8), "modconv3x3_up2_h3_variant: bad shape");
+    NB_REQUIRE(in_fmt >= 0 && in_fmt <= 3 && n > 0 && c_in > 0 && c_out > 0 && h >= 8 && (w % 32 == 0 || w == 16 || w == 8), "modconv3x3_up2_h3_variant: bad shape");
     static const char* const names[] = {"modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel",
                                         "modconv3x3_up2_h3_kernel", "modconv3x3_up2_h3_kernel", "modconv3x3_up2v_kernel", "modconv3x3_up2_h3_kernel"};
     snprintf(buf, buflen, "%s", names[nb_up2_h3_select(in_fmt, c_in, c_out, n, h, w)]);

@@ -48,9 +48,15 @@ static_assert(NBLK <= NBJ * NW && KMIX * NW <= NXP && (KMIX + 1) * NW > NXP && N
 // scale per lane): lane half 0 takes the first tap of a pair, lane half 1 the second -- per-lane lo-slot addresses --, and the operand
 // tuple is the chunk's two lo slots as they stand (quad 0 = (cg 0, lo), quad 1 = (cg 1, lo): six dwords of fields, the scale dword =
 // the instruction's scale operand).  The lone tap 4: lane half 1 multiplies a zero slot on the weights side.
-template <bool F8, int OUTM, bool F6 = false>
+// HO (with F8, round 6): "hi only" -- the f8 loop WITHOUT its correction products: one f16 MFMA per tap on the hi halves, the plain
+// single-f16 evaluation (~3e-3 from fp32 end to end: outside the 1e-3 budget; the reference's own shipped arithmetic for its blocks
+// >= 32^2, training/networks.py:634-638).  Generator(conv_mode="f16"): a data point that separates the cost of the split scheme from
+// the cost of the kernel structure, NOT a parity mode.  Same staging, same fillers, same epilogue; the lo-fragment reads have no
+// consumer and are dropped by the compiler.
+template <bool F8, int OUTM, bool F6 = false, bool HO = false>
 __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Params p) {
     static_assert(!F6 || F8, "the f6 form is a variant of the f8 loop");
+    static_assert(!HO || (F8 && !F6), "the hi-only form is a variant of the f8 loop");
     NB_TSTAMP(0);
     if constexpr (OUTM == 2) nb_set_fp16_ovfl();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_v[];
@@ -476,11 +482,11 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
             nb_static_for<0, 2>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
                 f32x16& a_ = acc[j][ph];
-                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], Ba[j], a_, 0, 0, 0);
+                if constexpr (j < NBE) a_ = NB_MFMA_F16(ah[0], Ba[j], a_, 1);
                 NB_FENCE(); filler(std::integral_constant<int, 3 * j>{}); NB_FENCE();
-                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], Bb[j], a_, 0, 0, 0);
+                if constexpr (j < NBE) a_ = NB_MFMA_F16(ah[1], Bb[j], a_, 0);
                 NB_FENCE(); filler(std::integral_constant<int, 3 * j + 1>{}); NB_FENCE();
-                if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al, bl[j], a_, 0, 0, 0, sa_, 0, sb_);
+                if constexpr (j < NBE && !HO) a_ = NB_MFMA_FP8(al, bl[j], a_, sa_, sb_, 1);
                 NB_FENCE(); filler(std::integral_constant<int, 3 * j + 2>{}); NB_FENCE();
             });
         };
@@ -508,11 +514,11 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         nb_static_for<0, 2>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             f32x16& a_ = acc[j][3];
-            if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_m, bh0[j], a_, 0, 0, 0);
+            if constexpr (j < NBE) a_ = NB_MFMA_F16(ah_m, bh0[j], a_, 1);
             NB_FENCE();
             if constexpr (j == 0) { ah_a[0] = rA(7, 0, sa); ah_a[1] = rA(1, 0, sa); } else { set_lo(al_a, rA(7, 1, sa)); set_hi(al_a, rA(1, 1, sa)); }
             NB_FENCE();
-            if constexpr (j < NBE) a_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al_m, bl01[j], a_, 0, 0, 0, sa_, 0, sb_);
+            if constexpr (j < NBE && !HO) a_ = NB_MFMA_FP8(al_m, bl01[j], a_, sa_, sb_, 1);
             NB_FENCE();
             if constexpr (j == 0) dma(std::integral_constant<int, 5>{});
             NB_FENCE();
@@ -744,23 +750,23 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     }
 }
 
-template <bool F8, int OUTM, bool F6 = false>
+template <bool F8, int OUTM, bool F6 = false, bool HO = false>
 static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
     constexpr size_t lds_ring = (size_t)NST * STAGE * 16, lds_epi = (size_t)16 * NBLK * 32 * 16;
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM, F6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM, F6, HO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
-    hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM, F6>), grid, dim3(NT), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM, F6, HO>), grid, dim3(NT), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2v");
     return NB_OK;
 }
 
 // shapes this form takes: whole 16-channel chunks (f8 or H2 operands), 32-column tiles of 12 quad rows
-bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w) { return in_fmt >= 0 && in_fmt <= 2 && c_in % 16 == 0 && w % TQW == 0 && h >= 8; }
+bool nb_up2v_eligible(int in_fmt, int c_in, int h, int w) { return in_fmt >= 0 && in_fmt <= 3 && c_in % 16 == 0 && w % TQW == 0 && h >= 8; }
 
 // p as filled in by nb_up2_h3_impl (nb_modconv_h3.hip); tiles are set here
 int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long long* tstamps, int tstamps_cap) {
@@ -770,6 +776,7 @@ int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long
     p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     p.tstamps = (tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= tstamps_cap) ? tstamps : nullptr;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
+    if (in_fmt == 3) return outm == 2 ? nb_up2v_launch1<true, 2, false, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1, false, true>(p, n, stream) : nb_up2v_launch1<true, 0, false, true>(p, n, stream);
     if (in_fmt == 2) return outm == 2 ? nb_up2v_launch1<true, 2, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1, true>(p, n, stream) : nb_up2v_launch1<true, 0, true>(p, n, stream);
     if (in_fmt) return outm == 2 ? nb_up2v_launch1<true, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1>(p, n, stream) : nb_up2v_launch1<true, 0>(p, n, stream);
     return outm == 2 ? nb_up2v_launch1<false, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<false, 1>(p, n, stream) : nb_up2v_launch1<false, 0>(p, n, stream);

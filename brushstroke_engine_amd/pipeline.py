@@ -60,7 +60,7 @@ class TriadStepPipeline:
         """The tail may reuse the head's workspace only if every resumed layer computes its noise itself (large split-f16
         kernels); otherwise ``submit`` falls back to the unsplit call on the tail stream."""
         syn = self.G.synthesis
-        if not (syn.noise_in_kernel and syn.conv_mode in ("h3", "f8")):
+        if not (syn.noise_in_kernel and syn.conv_mode in ("h3", "f8", "f16")):
             return False
         syn._n, syn._h3_batch_ok = n, n >= syn.h3_min_batch
         syn._ensure_packed()

@@ -340,6 +340,11 @@ struct NbNoiseSrc {
 
 /* General forms of the two split-f16 convolutions.  in_fmt / out_fmt: 0 = H2 (hi/lo f16), 1 = "f8" (hi f16 + fp8
  * correction operands, above); the weights must be packed for in_fmt (nb_pack_conv_weight_h3 or the f8 layout).
+ * in_fmt 2 = "f6" (round-5 experiment: fp6 corrections, own weight layout).  in_fmt 3 (round 6) = f8 operands and weights with the
+ * correction products SKIPPED where the launch runs on the large throughput kernels (ping-pong up=1 loop, 12-row up=2 kernel;
+ * elsewhere it is in_fmt 1): a plain single-f16 evaluation, ~3e-3 from fp32 end to end -- the reference's own shipped arithmetic for
+ * blocks >= 32^2 (training/networks.py:634-638), outside this build's 1e-3 parity budget; Generator(conv_mode="f16"), a timing
+ * data point, not a parity mode.
  * Exactly one destination: y_f32 (fp32 NCHW; out_fmt ignored), y_h2 (the consumer's input tensor [n, c_next, ...] in
  * out_fmt, multiplied by next_styles), or -- up1 only, t != NULL -- the fused ToRGB outputs (y_f32 optional). */
 int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts, const float* dcoefs, const float* noise,

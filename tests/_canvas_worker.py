@@ -41,10 +41,11 @@ def main():
         else:
             assert r is None
         if level == 2:
-            hb = torch.tensor([helper.halo_bytes["sent"], helper.halo_bytes["received"]], dtype=torch.int64)
+            # (RCCL moves device tensors only; gloo takes either)
+            hb = torch.tensor([helper.halo_bytes["sent"], helper.halo_bytes["received"]], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
             allhb = [torch.zeros_like(hb) for _ in range(world)]
             dist.all_gather(allhb, hb)
-            res["lamali_halo_bytes"] = torch.stack(allhb).numpy()
+            res["lamali_halo_bytes"] = torch.stack(allhb).cpu().numpy()
             m = helper.mask.clone()
             dist.all_reduce(m, op=dist.ReduceOp.MAX)
             res["lamali_mask_sum"] = np.float64(m.sum().item())

@@ -82,16 +82,21 @@ def test_bench_line_carries_every_arithmetic_mode():
     r = _run(["--steps", "2", "--warmup", "1", "--res", "128", "--batch", "8", "--no-latency", "--cpu-seconds", "1"])
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_line(r.stdout)
-    assert set(out["modes"]) == {"f8", "h3", "f32"} and out["conv_mode"] == "f8"         # (f6, the round-5 experiment: only with --modes f6 / all)
+    # (f6, the round-5 experiment: only with --modes f6 / all; f16 = the reference's shipped precision, a timing data point)
+    assert set(out["modes"]) == {"f8", "h3", "f32", "f16"} and out["conv_mode"] == "f8"
+    assert "NOT a parity mode" in out["modes"]["f16"]["note"]
     # the headline is the library's concurrent schedule; the single-stream figure the roofline comes from rides along
     assert out["streams"] in (1, 3) and out["value_single_stream"] > 0 and out["modes"]["h3"]["value_single_stream"] > 0
     assert out["value"] == out["modes"]["f8"]["value"] and out["value_fp32_parity"] == out["modes"]["h3"]["value"]
     assert not out["dtype"].startswith("f32")
-    tol = {"f8": 3e-4, "h3": 2e-5, "f32": 2e-5, "f6": 6e-4}             # (f6: the round-5 experiment, tests/test_hip_f6.py)
+    # (f16 is NOT a parity mode: hi x hi products only in the large launches -- which at this test's R=128 / batch 8 are few, hence
+    #  the loose bound: the figure that matters is the R=256 one in the driver's line)
+    tol = {"f8": 3e-4, "h3": 2e-5, "f32": 2e-5, "f16": 3e-2}
     for m, rec in out["modes"].items():
         assert rec["value"] > 0 and rec["roofline"]["frac"] > 0
         assert rec["roofline"]["peak"] == (157.3 if m == "f32" else 2500.0)
         assert rec["parity"] <= tol[m], (m, rec["parity"])
+    assert out["modes"]["f16"]["parity"] >= out["modes"]["f8"]["parity"]
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] >= 1
     assert out["parity"]["max_abs_rgba_vs_oracle"] <= tol["f8"] and out["parity"]["tolerance"] == 1e-3
     # the full record (tables, per-layer times, explanatory strings) is in the detail file, same numbers

@@ -269,3 +269,41 @@ def test_generator_batch1_tiles_equal_forced_large_tiles():
     finally:
         lib.nb_debug_set_up1_rows(0); lib.nb_debug_set_up2_tile(0)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2]["uvs"], b[2]["uvs"])
+
+
+@pytest.mark.parametrize("up,ci,co,res,n", [(1, 128, 128, 64, 16), (1, 64, 64, 128, 8), (2, 128, 64, 128, 8), (2, 384, 128, 64, 32)])
+def test_hi_only_form_is_the_plain_f16_product(up, ci, co, res, n):
+    """in_fmt 3 (Generator(conv_mode="f16"), round 6): f8 operands and weights with the correction products skipped on the large
+    throughput kernels -- the output must be the convolution of the f16-ROUNDED operands (fp32 accumulation: ~1e-6 of the largest
+    output from a float64 evaluation of those rounded operands), i.e. a plain single-f16 evaluation, ~1e-3 relative away from the
+    f8 result (whose corrections restore the fp32 operands to ~2^-15)."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(up * 100 + ci + res)
+    hin = res if up == 1 else res // 2
+    lib = _lib.lib()
+    x = torch.from_numpy(rs.randn(n, ci, hin, hin).astype(np.float32)).cuda()
+    w = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    dco, bias = torch.ones(n, co, device="cuda"), torch.zeros(co, device="cuda")
+    S = torch.cuda.current_stream().cuda_stream
+    xh, wp = ops.pack_h2f8(x, st), ops.pack_conv_weight_h3f8(w)
+    out = {}
+    for fmt in (1, 3):
+        y = torch.empty([n, co, res, res], device="cuda")
+        if up == 1:
+            rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(), None, None,
+                                             0, 0, None, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
+        else:
+            rc = lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(), None, None,
+                                             0, 0, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
+        _lib.check(rc, "conv")
+        out[fmt] = y.cpu().double()
+    xr = (x * st[:, :, None, None]).half().float()                    # the hi halves as the pack rounds them
+    ref_hi = _conv_ref(xr, w.half().float(), torch.ones_like(st), up)
+    ref = _conv_ref(x, w, st, up)
+    scale = float(ref.abs().max())
+    e_hi = float((out[3] - ref_hi).abs().max()) / scale
+    e_f16 = float((out[3] - ref).abs().max()) / scale
+    e_f8 = float((out[1] - ref).abs().max()) / scale
+    print(f"[hi-only up{up} {ci}->{co}@{res}] vs rounded-operand float64 {e_hi:.1e}; vs fp32 operands: f16 {e_f16:.1e}, f8 {e_f8:.1e}")
+    assert e_hi <= 5e-6 and e_f8 <= 5e-5 and 5 * e_f8 < e_f16 < 5e-3
