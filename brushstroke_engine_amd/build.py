@@ -166,3 +166,59 @@ def disassembly(lib: str = LIB) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+
+
+def mfma_loop_spill_traffic(lib: str = LIB) -> dict:
+    """Scratch / SGPR-spill instructions INSIDE the matrix loops of every kernel of the built library, from its disassembly:
+    {kernel name: [(mfma, scratch, v_readlane + v_writelane) per innermost loop that holds MFMA instructions]}.
+    The persistent conv kernels of round 6 (a tile loop around the K loop) hold a few registers in scratch AROUND their K loops --
+    spilled before a tile's loop, reloaded behind it, a dozen instructions per 30-50 us tile --; what must stay clean is the K loop
+    itself, whose counted ``s_waitcnt vmcnt(N)`` would count a scratch access as one of its LDS-DMA pieces (tests/test_abi.py)."""
+    import re
+    import shutil
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin")
+    tmp = tempfile.mkdtemp(prefix="nbdis")
+    out = {}
+    try:
+        work = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, work)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", work], cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if ARCH not in f:
+                continue
+            dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            # functions: "<addr> <name>:" headers; instructions: "\tmnemonic operands // ADDR: encoding"
+            for m in re.finditer(r"^[0-9a-f]+ <([^>]+)>:\n(.*?)(?=^[0-9a-f]+ <[^>]+>:\n|\Z)", dis, flags=re.M | re.S):
+                name, body = m.group(1), m.group(2)
+                if "v_mfma" not in body:
+                    continue
+                ins = []                                  # (address, text)
+                for line in body.split("\n"):
+                    mm = re.match(r"^\s+(\S.*?)\s*//\s*([0-9A-F]+):", line)
+                    if mm:
+                        ins.append((int(mm.group(2), 16), mm.group(1)))
+                addr_index = {a: i for i, (a, _) in enumerate(ins)}
+                spans = []
+                for i, (a, t) in enumerate(ins):
+                    bm = re.match(r"s_c?branch\S*\s+(\d+)", t)
+                    if bm:                                # target = next pc + simm16 * 4
+                        off = int(bm.group(1))
+                        off = off - 65536 if off >= 32768 else off
+                        tgt = a + 4 + 4 * off
+                        if tgt <= a and tgt in addr_index:
+                            spans.append((addr_index[tgt], i))
+                inner = [sp for sp in set(spans) if not any(o != sp and o[0] >= sp[0] and o[1] <= sp[1] for o in spans)]
+                rows = []
+                for a0, a1 in sorted(inner):
+                    seg = [t for _, t in ins[a0:a1 + 1]]
+                    n_mf = sum(t.startswith("v_mfma") for t in seg)
+                    # a K loop: matrix instructions and no output stores.  (The tile loop's closing jump lands behind the steady-state
+                    # loops, so the stretch from there to the jump -- the last chunks' MFMAs, the whole epilogue -- looks innermost
+                    # too; it runs once per tile and is told apart by its stores.)
+                    if n_mf >= 8 and not any(t.startswith(("global_store", "buffer_store", "flat_store")) for t in seg):
+                        rows.append((n_mf, sum(t.startswith("scratch_") for t in seg), sum(t.startswith(("v_readlane", "v_writelane")) for t in seg)))
+                out[name] = rows
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

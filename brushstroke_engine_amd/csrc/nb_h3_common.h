@@ -380,4 +380,5 @@ struct H3Up2Params {
     float alpha, gain, clamp;
     unsigned long long* tstamps;
     _Float16* yh2; const float* next_styles; int next_stride, c8_next, out_f8;      // H2 output (see H3Params)
+    int items, items_x;     // up2v (persistent workgroups): items = tiles x slices x samples of the launch, items_x = per sample
 };

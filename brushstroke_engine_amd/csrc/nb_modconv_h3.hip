@@ -49,6 +49,7 @@ struct H3Params {
     long long noise_stride_n;
     int c8, nchunks, c_out, co_ld, h, w;
     int tiles_x, tiles_y, slices, dbg, stagger_ticks;
+    int items, items_x;            // persistent workgroups (8-wave kernel): items = tiles x slices x samples of the launch, items_x = per sample
     float alpha, gain, clamp;
     unsigned long long* tstamps;   // debug: per-workgroup phase timestamps (nb_debug_set_timestamps), else null
     // H2 output (y == null): the result, multiplied by the CONSUMER's styles, goes straight into the consumer's H2
@@ -120,68 +121,108 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
     const int wm = wv / NWN, wn = wv - wm * NWN;  // wave coordinates (c_out, pixel rows)
     const int H = p.h, W = p.w;
-    int b = blockIdx.x;
+    // PERSISTENT workgroups (round 6): gridDim.x = min(items, CUs); workgroup w renders items w, w + gridDim.x, ... of the list
+    // [sample][tile][c_out slice] (p.items of them, p.items_x per sample), and the NEXT tile's prologue -- its halo tile and first three
+    // weight sub-chunks, ~4 us of LDS-DMA round trip -- is issued BEFORE this tile's epilogue, which works straight from the
+    // accumulators (hand-off / fused ToRGB outputs) and leaves the staging LDS alone.
     // XCD-aware order (as in the up=2 kernel below): hardware workgroup ids go round-robin to the 8 XCDs, each with its own L2;
-    // renumbered, an XCD works on a contiguous run of the row-major tile list -- whole tile rows -- so that the halo columns
-    // and rows neighbouring tiles share are L2 hits instead of second HBM reads
-    if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
-    const int slice = b % p.slices; b /= p.slices;
-    const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
-    const int n = blockIdx.y;
-    const int y0 = tile_y * TH, x0 = tile_x * 32;
-    const int co0 = slice * CO_WG;
+    // renumbered, an XCD works on a contiguous run of a sample's row-major tile list -- whole tile rows -- so that the halo columns
+    // and rows neighbouring tiles share are L2 hits instead of second HBM reads (gridDim.x is a multiple of 8 whenever the per-sample
+    // list is, so a workgroup's items keep to its XCD)
+    typedef const __attribute__((address_space(4))) H3Params* kparams_t;
+    auto fresh_params = [&]() -> kparams_t {           // (per-tile reads of the launch parameters: not carried in registers across the K loop)
+        kparams_t q = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(q));
+        return q;
+    };
+    int n = 0, y0 = 0, x0 = 0, co0 = 0;
     const size_t HW8 = (size_t)H * W * 8;
-    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+    auto tile_coords = [&](unsigned l) {
+        kparams_t q_ = fresh_params();
+        const unsigned gx = (unsigned)q_->items_x;
+        unsigned b = l % gx;
+        const unsigned nn = l / gx;
+        if (gx % 8 == 0 && gridDim.x % 8 == 0 && !(q_->dbg & 8)) b = (b & 7) * (gx >> 3) + (b >> 3);
+        const int slice = b % q_->slices; b /= q_->slices;
+        const int tile_x = b % q_->tiles_x; const int tile_y = b / q_->tiles_x;
+        n = __builtin_amdgcn_readfirstlane((int)nn); y0 = __builtin_amdgcn_readfirstlane(tile_y * TH);
+        x0 = __builtin_amdgcn_readfirstlane(tile_x * 32); co0 = __builtin_amdgcn_readfirstlane(slice * CO_WG);
+    };
+    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    const unsigned total = (unsigned)p.items;
+    tile_coords(item);
 
-    // epilogue operands are fetched now, under the prologue DMA: per-channel demodulation / bias into LDS, the
+    // epilogue operands are fetched at the top of a tile, under the prologue DMA: per-channel demodulation / bias into LDS, the
     // lane's noise values into registers (fetching them in the epilogue costs ~10 us of exposed latency per tile)
     __shared__ __attribute__((aligned(16))) float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
-    if (tid < CO_WG) {
-        const int co = co0 + tid;
-        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] : 0.f;
-        s_bias[tid] = co < p.c_out ? p.bias[co] : 0.f;
-        s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
-    }
     __shared__ __attribute__((aligned(16))) float s_tw[3 * CO_WG];
     __shared__ float s_tcol[9], s_tcol01[9];
-    if (p.tg.c) nb_torgb_setup(p.tg, n, s_tw, s_tcol, s_tcol01, tid, 512, blockIdx.x == 0);
     float nzr[NBW];
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb)
-        nzr[nb] = p.noise ? p.noise[(size_t)n * p.noise_stride_n + (size_t)(y0 + wn * NBW + nb) * W + x0 + l31] : 0.f;
-    if (p.nsrc.const_t) {
-        // the lane's pixels (row y0 + wn NBW + nb, column x0 + l31): column parameters once, row parameters per row
-        float np0, np1, wy0, wy1;
-        int sy0;
-        nb_noise_np(p.nsrc, n, np0, np1);
-        nb_noise_axis(p.nsrc, x0 + l31, np1, sy0, wy0, wy1);
-        const float strength = p.nsrc.strength[0];
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            float wx0, wx1;
-            int sx0;
-            nb_noise_axis(p.nsrc, y0 + wn * NBW + nb, np0, sx0, wx0, wx1);
-            nzr[nb] = nb_noise_value(p.nsrc, strength, sx0, wx0, wx1, sy0, wy0, wy1);
+    int tg_n = -1;                                 // sample whose ToRGB tables (weights x styles) are in LDS
+    auto load_tile_tables = [&]() {
+        kparams_t q_ = fresh_params();
+        if (tid < CO_WG) {
+            const int co = co0 + tid, c_out = q_->c_out;
+            s_dco[tid] = co < c_out ? q_->dcoefs[(size_t)n * c_out + co] : 0.f;
+            s_bias[tid] = co < c_out ? q_->bias[co] : 0.f;
+            s_nst[tid] = (q_->yh2 && co < c_out) ? q_->next_styles[(size_t)n * q_->next_stride + co] : 0.f;
         }
-    }
+        if (p.tg.c && n != tg_n) { nb_torgb_setup(p.tg, n, s_tw, s_tcol, s_tcol01, tid, 512, item == 0); tg_n = n; }
+        const float* noise = q_->noise;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+            nzr[nb] = noise ? noise[(size_t)n * q_->noise_stride_n + (size_t)(y0 + wn * NBW + nb) * W + x0 + l31] : 0.f;
+        if (q_->nsrc.const_t) {
+            // the lane's pixels (row y0 + wn NBW + nb, column x0 + l31): column parameters once, row parameters per row
+            const NbNoiseSrcDev nsrc{q_->nsrc.const_t, q_->nsrc.lin, q_->nsrc.strength, q_->nsrc.norm_pos, q_->nsrc.positions, q_->nsrc.res, q_->nsrc.img_res};
+            float np0, np1, wy0, wy1;
+            int sy0;
+            nb_noise_np(nsrc, n, np0, np1);
+            nb_noise_axis(nsrc, x0 + l31, np1, sy0, wy0, wy1);
+            const float strength = nsrc.strength[0];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                float wx0, wx1;
+                int sx0;
+                nb_noise_axis(nsrc, y0 + wn * NBW + nb, np0, sx0, wx0, wx1);
+                nzr[nb] = nb_noise_value(nsrc, strength, sx0, wx0, wx1, sy0, wy0, wy1);
+            }
+        }
+    };
 
     // ---- DMA descriptors of this wave's activation pieces ----
     int xsp[NXPW], xpl[NXPW], xdst[NXPW];
+    const _Float16* xn = p.x;
 #pragma unroll
     for (int i = 0; i < NXPW; ++i) {
         int q = i * NW + wv;
         q = q < NXP ? q : NXP - 1;
         const int pl = q / PP, part = q - pl * PP;      // pl = cg_local*2 + hi/lo
-        const int e = part * 64 + lane;
-        xpl[i] = pl;
-        xdst[i] = pl * XPL + part * 64;
-        xsp[i] = -1;
-        if (e < SLOTS) {
-            const int r = e / TWP, c = e - r * TWP;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xsp[i] = (gy * W + gx) * 8;
-        }
+        xpl[i] = __builtin_amdgcn_readfirstlane(pl);
+        xdst[i] = __builtin_amdgcn_readfirstlane(pl * XPL + part * 64);
     }
+    // the CURRENT tile's per-lane sources (y0, x0, n as tile_coords left them; through an opaque statement: recomputed per tile)
+    auto piece_offsets = [&]() {
+        int y0_ = y0, x0_ = x0, lane_ = lane;
+        asm volatile("" : "+v"(y0_), "+v"(x0_), "+v"(lane_));
+        y0_ = __builtin_amdgcn_readfirstlane(y0_); x0_ = __builtin_amdgcn_readfirstlane(x0_);
+        kparams_t q_ = fresh_params();
+        xn = q_->x + (size_t)n * q_->c8 * 2 * HW8;
+#pragma unroll
+        for (int i = 0; i < NXPW; ++i) {
+            int q = i * NW + wv;
+            q = q < NXP ? q : NXP - 1;
+            const int part = q % PP;
+            const int e = part * 64 + lane_;
+            xsp[i] = -1;
+            if (e < SLOTS) {
+                const int r = e / TWP, c = e - r * TWP;
+                const int gy = y0_ - 1 + r, gx = x0_ - 1 + c;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) xsp[i] = (gy * W + gx) * 8;
+            }
+        }
+    };
+    piece_offsets();
     auto issue_x = [&](int c, h8* dst) {
 #pragma unroll
         for (int i = 0; i < NXPW; ++i) {
@@ -204,12 +245,6 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     };
 
     f32x16 acc[MB][NBW];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
     const int NC = p.nchunks, T = NC * 3;
     auto clampt = [&](int t) { return t < T ? t : T - 1; };
@@ -219,20 +254,27 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     const unsigned lds0_v2 = (unsigned)(uintptr_t)NB_LDS_PTR(smem_h3);
     const char* xs0_v2[NXPW];
     unsigned xst_v2[NXPW], wof_v2[NWPW];
+    auto piece_sources_v2 = [&]() {
+        kparams_t q_ = fresh_params();
+        int c0_ = co0, lane_ = lane;
+        asm volatile("" : "+v"(c0_), "+v"(lane_));
+        c0_ = __builtin_amdgcn_readfirstlane(c0_);
 #pragma unroll
-    for (int i = 0; i < NXPW; ++i) {
-        const bool in = xsp[i] >= 0;
-        xs0_v2[i] = in ? reinterpret_cast<const char*>(xn + (size_t)xpl[i] * HW8 + xsp[i]) : reinterpret_cast<const char*>(p.zeros);
-        xst_v2[i] = in ? (unsigned)(4 * HW8 * 2) : 0u;
-    }
+        for (int i = 0; i < NXPW; ++i) {
+            const bool in = xsp[i] >= 0;
+            xs0_v2[i] = in ? reinterpret_cast<const char*>(xn + (size_t)xpl[i] * HW8 + xsp[i]) : reinterpret_cast<const char*>(q_->zeros);
+            xst_v2[i] = in ? (unsigned)(4 * HW8 * 2) : 0u;
+        }
 #pragma unroll
-    for (int i = 0; i < NWPW; ++i) {
-        int q = i * NW + wv;
-        q = q < NWP ? q : NWP - 1;
-        const int e = q * 64 + lane;
-        const int row = e / CO_WG, j = e - row * CO_WG;
-        wof_v2[i] = (unsigned)(((size_t)row * p.co_ld + co0 + j) * 16);
-    }
+        for (int i = 0; i < NWPW; ++i) {
+            int q = i * NW + wv;
+            q = q < NWP ? q : NWP - 1;
+            const int e = q * 64 + lane_;
+            const int row = e / CO_WG, j = e - row * CO_WG;
+            wof_v2[i] = (unsigned)(((size_t)row * q_->co_ld + c0_ + j) * 16);
+        }
+    };
+    if constexpr (V2) piece_sources_v2();
     const size_t wstep_v2 = (size_t)12 * p.co_ld * 16;                 // bytes of one (chunk, tap row) weight sub-chunk
     constexpr int WRING_SLOT0 = 2 * 4 * XPL;
     auto issue_x_v2 = [&](auto ii, int c, int buf) {                   // piece ii of chunk c's halo tile into activation buffer buf
@@ -245,19 +287,32 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         q = q < NWP ? q : NWP - 1;
         nb_lds_dma16_s(reinterpret_cast<const char*>(p.wts) + (size_t)t * wstep_v2, wof_v2[i], lds0_v2 + (unsigned)(WRING_SLOT0 + slot * WSLOTS + q * 64) * 16u);
     };
-    // prologue: chunk 0's halo tile and the first three weight sub-chunks
-    if constexpr (V2) {
-        NB_TSTAMP(5);                              // (the hand-off epilogues leave slot 5 free: time that passes before the first LDS-DMA piece goes out)
-        nb_static_for<0, NXPW>([&](auto i) { issue_x_v2(i, 0, 0); });
-        nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, 0, 0); });
-        nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, clampt(1), 1); });
-        nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, clampt(2), 2); });
-    } else {
-    issue_x(0, xbuf);
-    issue_w(0, wring);
-    issue_w(clampt(1), wring + WSLOTS);
-    issue_w(clampt(2), wring + 2 * WSLOTS);
-    }
+    // a tile's prologue: chunk 0's halo tile and the first three weight sub-chunks
+    auto prologue_issue = [&]() {
+        if constexpr (V2) {
+            nb_static_for<0, NXPW>([&](auto i) { issue_x_v2(i, 0, 0); });
+            nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, 0, 0); });
+            nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, clampt(1), 1); });
+            nb_static_for<0, NWPW>([&](auto i) { issue_w_v2(i, clampt(2), 2); });
+        } else {
+            issue_x(0, xbuf);
+            issue_w(0, wring);
+            issue_w(clampt(1), wring + WSLOTS);
+            issue_w(clampt(2), wring + 2 * WSLOTS);
+        }
+    };
+    NB_TSTAMP(5);                              // (the hand-off epilogues leave slot 5 free: time that passes before the first LDS-DMA piece goes out)
+    prologue_issue();
+  for (;;) {                                   // one iteration per tile of this workgroup (see PERSISTENT above)
+#undef NB_TSTAMP
+#define NB_TSTAMP(k) do { if (p.tstamps && threadIdx.x == 0) { unsigned it_ = item; asm volatile("" : "+v"(it_)); p.tstamps[(size_t)it_ * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+    load_tile_tables();
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
     // step 0 needs the halo tile and sub-chunk 0 only: sub-chunks 1 and 2 may still be in flight (the loop's invariant)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -950,12 +1005,13 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     }
 #ifdef NB_PP_STAMPS
     if (p.tstamps && tid == 0) {
-        unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        unsigned long long* ts = p.tstamps + (size_t)item * 8;
         ts[6] = t_dma; ts[7] = t_bar;
     }
 #else
     if (p.tstamps && tid == 0) {
-        unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        unsigned it_ = item; asm volatile("" : "+v"(it_));
+        unsigned long long* ts = p.tstamps + (size_t)it_ * 8;
         ts[6] = t_dma; ts[7] = t_bar | ((__builtin_amdgcn_s_memtime() - t_loop0) << 32);
     }
 #endif
@@ -965,6 +1021,21 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     __builtin_amdgcn_s_barrier();
     NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
+    // ---- the NEXT tile's prologue goes out now, ahead of this tile's epilogue, where that epilogue works straight from the accumulators
+    //      (hand-off output; the fused ToRGB of a 64-channel layer): its ~4 us of LDS-DMA round trip then pass under the epilogue's
+    //      arithmetic and stores.  The fp32-output path stages its tile in the LDS the prologue fills: there the prologue follows it.
+    //      The epilogue keeps THIS tile's coordinates (e_*). ----
+    const int e_n = n, e_y0 = y0, e_x0 = x0, e_co0 = co0;
+    const unsigned item_next = __builtin_amdgcn_readfirstlane(item + gridDim.x);
+    const bool lds_free_epilogue = p.yh2 || (MW == 1 && p.tg.c && !p.y && p.c_out % 8 == 0);
+    const bool early = item_next < total && lds_free_epilogue && !(p.dbg & 64);      // (dbg & 64: no prefetch)
+    if (item_next < total) {
+        tile_coords(item_next);
+        piece_offsets();
+        if constexpr (V2) piece_sources_v2();
+        if (early) prologue_issue();
+    }
+    auto epilogue = [&]() {
 
     // ---- epilogue: *d, +noise, +bias, lrelu, gain, clamp -> fp32 NCHW; D[row = c_out, col = pixel] ----
     // The finished values go through LDS (the staging buffers are dead now) as an [c_out][pixel] image so that each
@@ -974,9 +1045,9 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     if (p.yh2) {
         const H3HandoffArgs ha_ = nb_handoff_args(p.yh2, p.c8_next, p.c_out, p.h, p.w, p.out_f8, p.dbg, p.alpha, p.gain, p.clamp);
         if constexpr (F8 && V2) {          // (the f6 output form exists for the software-pipelined f8 / f6 kernels only: the launcher checks)
-            if (p.out_f8 == 2) nb_up1_handoff_epilogue<MB, NBW, true>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
-            else nb_up1_handoff_epilogue<MB, NBW, false>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
-        } else nb_up1_handoff_epilogue<MB, NBW, false>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, co0, n, y0, x0, lh, l31);
+            if (p.out_f8 == 2) nb_up1_handoff_epilogue<MB, NBW, true>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, e_co0, e_n, e_y0, e_x0, lh, l31);
+            else nb_up1_handoff_epilogue<MB, NBW, false>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, e_co0, e_n, e_y0, e_x0, lh, l31);
+        } else nb_up1_handoff_epilogue<MB, NBW, false>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, e_co0, e_n, e_y0, e_x0, lh, l31);
         NB_TSTAMP(3);
         NB_TSTAMP(4);
         return;
@@ -1020,7 +1091,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                     nb_swap32(u0, u1);
                     a[k] = __builtin_bit_cast(float, u0) + __builtin_bit_cast(float, u1);
                 }
-                if (lh == 0) nb_torgb_pixel(p.tg, n, (y0 + wn * NBW + nb) * W + x0 + l31, a[0], a[1], a[2], s_tcol, s_tcol01);
+                if (lh == 0) nb_torgb_pixel(p.tg, e_n, (e_y0 + wn * NBW + nb) * W + e_x0 + l31, a[0], a[1], a[2], s_tcol, s_tcol01);
             }
             NB_TSTAMP(3);
             NB_TSTAMP(4);
@@ -1049,7 +1120,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         for (int pix = tid; pix < PIX_WG; pix += 512) {
             float a0, a1, a2;
             nb_torgb_dot(p.c_out, s_tw, [&](int ch) { return ot[ch * PIX_WG + pix]; }, a0, a1, a2);
-            nb_torgb_pixel(p.tg, n, (y0 + (pix >> 5)) * W + x0 + (pix & 31), a0, a1, a2, s_tcol, s_tcol01);
+            nb_torgb_pixel(p.tg, e_n, (e_y0 + (pix >> 5)) * W + e_x0 + (pix & 31), a0, a1, a2, s_tcol, s_tcol01);
         }
         if (!p.y) return;
     }
@@ -1057,19 +1128,29 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         constexpr int V4_PER_ROW = PIX_WG / 4;                   // float4 per c_out row
         for (int e = tid; e < CO_WG * V4_PER_ROW; e += 512) {
             const int col = e / V4_PER_ROW, q4 = e - col * V4_PER_ROW;
-            const int co = co0 + col;
+            const int co = e_co0 + col;
             if (co < p.c_out) {
                 const int trow = q4 >> 3, px = (q4 & 7) * 4;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(ot + col * PIX_WG + q4 * 4);
-                *reinterpret_cast<f32x4*>(p.y + ((size_t)n * p.c_out + co) * ((size_t)H * W) + (size_t)(y0 + trow) * W + x0 + px) = v;
+                *reinterpret_cast<f32x4*>(p.y + ((size_t)e_n * p.c_out + co) * ((size_t)H * W) + (size_t)(e_y0 + trow) * W + e_x0 + px) = v;
             }
         }
     }
     NB_TSTAMP(4);
-    if (p.tstamps) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        NB_TSTAMP(5);
-    }
+    };
+    epilogue();
+    if (item_next >= total) break;
+    item = item_next;
+    // every wave is through with the tile's tables (and, on the fp32-output path, with the staged tile)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    NB_TSTAMP(0);
+    if (!early) prologue_issue();
+  }
+#undef NB_TSTAMP
+#define NB_TSTAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (p.tstamps && threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1255,6 +1336,10 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
     }
 }
 
+static int g_up1_persist = -1;
+// developer / test hook: -1 / 1 = persistent workgroups of the 8-wave up=1 kernel (one per CU, next tile's prologue ahead of the epilogue), 0 = one per tile
+extern "C" void nb_debug_set_up1_persistent(int mode) { g_up1_persist = mode; }
+
 static int launch_h3s(H3Params p, int n, hipStream_t st) {
     constexpr size_t lds_stage = (size_t)2 * (4 * 320 + 12 * 64) * 16, lds_h2 = (size_t)2 * 256 * 72 * 2;
     const size_t lds = p.yh2 ? lds_h2 : lds_stage;
@@ -1276,12 +1361,21 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr size_t lds_stage = (size_t)(2 * 4 * XPL + 4 * 12 * CO_WG) * 16, lds_h2 = (size_t)2 * TH * 32 * (CO_WG + 8) * 2;
     const size_t lds = lds_stage > lds_h2 ? lds_stage : lds_h2;
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
+    p.items_x = p.tiles_x * p.tiles_y * p.slices; p.items = p.items_x * n;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
+    // persistent workgroups: one per CU (fewer items than CUs: one each), the next tile's prologue issued ahead of the current tile's
+    // epilogue; g_up1_persist == 0 (test hook): one workgroup per item, as until round 5
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        ncu = v;
+    }
+    dim3 grid(g_up1_persist != 0 && p.items > ncu ? ncu : p.items);
     hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;

@@ -65,89 +65,143 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lh = lane >> 5, l31 = lane & 31;
     const int H = p.h, W = p.w;
-    int b = blockIdx.x, n = blockIdx.y;
-    // XCD-aware order.  Hardware workgroup ids (x fastest, then y) go round-robin to the 8 XCDs, each with its own L2.  The whole
-    // grid -- [sample][tile][c_out slice] -- is renumbered so that an XCD works through a contiguous eighth of that list: the
-    // c_out slices of a tile (which re-read the same activations) run side by side on one XCD, its neighbours in the image
-    // (shared halo rows, shared 128-byte lines at the tile's left and right edge) right after them, and every XCD gets whole
-    // samples, i.e. the same mix of full and ragged tiles.  (dbg & 32: the round-3 order, per sample with a rotating XCD share --
+    // The per-tile set-up below reads its launch parameters through a LAUNDERED pointer to the kernarg segment: read through `p` they are
+    // loop invariants that the compiler keeps in ~40 SGPRs across the K loop (12 pointers of the epilogue tables and the noise source,
+    // the tile-list geometry ...), which spilled 112 SGPRs and 60 VGPRs; re-read per tile they cost a handful of scalar loads.
+    typedef const __attribute__((address_space(4))) H3Up2Params* kparams_t;
+    auto fresh_params = [&]() -> kparams_t {
+        kparams_t q = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(q));
+        return q;
+    };
+    // PERSISTENT workgroups (round 6): the launch has gridDim.x = min(items, CUs) workgroups and workgroup w renders items w, w + gridDim.x,
+    // ... of the list [sample][tile][c_out slice] (p.items of them, p.items_x per sample).  What that buys is the prologue: the first
+    // chunk of the NEXT tile is on its way (LDS-DMA) while this tile's epilogue runs -- a workgroup used to spend 4.4-5 of its 31-50 us
+    // waiting for that round trip with the matrix pipes idle, and one workgroup per CU (156 KB of LDS) means nobody else could use them.
+    // XCD-aware order.  Hardware workgroup ids go round-robin to the 8 XCDs, each with its own L2.  The whole list is renumbered so that
+    // an XCD works through a contiguous eighth of it: the c_out slices of a tile (which re-read the same activations) run side by side on
+    // one XCD, its neighbours in the image (shared halo rows, shared 128-byte lines at the tile's left and right edge) right after
+    // them, and every XCD gets whole samples, i.e. the same mix of full and ragged tiles; gridDim.x is a multiple of 8 whenever the
+    // list is, so a workgroup's items all sit on its own XCD.  (dbg & 32: the round-3 order, per sample with a rotating XCD share --
     // there 6 or 11 workgroups of a sample per XCD cut through the slices of a tile and the tile was fetched by two L2s.)
-    const unsigned total = gridDim.x * gridDim.y;
-    if (total % 8 == 0 && !(p.dbg & (8 | 32))) {
-        const unsigned l = b + gridDim.x * n;
-        const unsigned q = (l & 7) * (total >> 3) + (l >> 3);
-        n = q / gridDim.x; b = q - n * gridDim.x;
-    } else if (gridDim.x % 8 == 0 && !(p.dbg & 8)) b = (((b & 7) + n) & 7) * (gridDim.x >> 3) + (b >> 3);
-    const int slice = b % p.slices; b /= p.slices;
-    const int tile_x = b % p.tiles_x; const int tile_y = b / p.tiles_x;
-    const int I0 = tile_y * TQH, J0 = tile_x * TQW;
-    const int co0 = slice * CO_WG;
+    const unsigned total = (unsigned)p.items;
+    int n = 0, I0 = 0, J0 = 0, co0 = 0;
     const size_t HW8 = (size_t)H * W * 8;
-    const _Float16* xn = p.x + (size_t)n * p.c8 * 2 * HW8;
+    auto tile_coords = [&](unsigned l) {
+        kparams_t q_ = fresh_params();
+        const unsigned total = (unsigned)q_->items, gx = (unsigned)q_->items_x;
+        const int dbg = q_->dbg, slices = q_->slices, tiles_x = q_->tiles_x;
+        unsigned b = l % gx;
+        unsigned nn = l / gx;
+        if (total % 8 == 0 && gridDim.x % 8 == 0 && !(dbg & (8 | 32))) {
+            const unsigned q = (l & 7) * (total >> 3) + (l >> 3);
+            nn = q / gx; b = q - nn * gx;
+        } else if (gx % 8 == 0 && !(dbg & 8)) b = (((b & 7) + nn) & 7) * (gx >> 3) + (b >> 3);
+        const int slice = b % slices; b /= slices;
+        const int tile_x = b % tiles_x; const int tile_y = b / tiles_x;
+        // (uniform values: the divisions above run on the vector unit -- back into scalar registers)
+        n = __builtin_amdgcn_readfirstlane((int)nn); I0 = __builtin_amdgcn_readfirstlane(tile_y * TQH);
+        J0 = __builtin_amdgcn_readfirstlane(tile_x * TQW); co0 = __builtin_amdgcn_readfirstlane(slice * CO_WG);
+    };
+    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    tile_coords(item);
     const int nblk = wv < NBLK - (NBJ - 1) * NW ? NBJ : NBJ - 1;      // blocks wv, wv + 8 (< 15)
 
     __shared__ __attribute__((aligned(16))) float s_dco[CO_WG], s_bias[CO_WG], s_nst[CO_WG];
     __shared__ __attribute__((aligned(16))) float s_noise[2 * TQH * 2 * TQW];
-    if (tid < CO_WG) {
-        const int co = co0 + tid;
-        s_dco[tid] = co < p.c_out ? p.dcoefs[(size_t)n * p.c_out + co] * p.gain : 0.f;
-        s_bias[tid] = co < p.c_out ? p.bias[co] * p.gain : 0.f;
-        s_nst[tid] = (p.yh2 && co < p.c_out) ? p.next_styles[(size_t)n * p.next_stride + co] : 0.f;
-    }
+    // per-tile epilogue operands (written at the top of a tile's iteration: the previous tile's epilogue has passed its closing barrier)
+    auto load_channel_tables = [&]() {
+        kparams_t q_ = fresh_params();
+        if (tid < CO_WG) {
+            const int co = co0 + tid, c_out = q_->c_out;
+            const float gain = q_->gain;
+            s_dco[tid] = co < c_out ? q_->dcoefs[(size_t)n * c_out + co] * gain : 0.f;
+            s_bias[tid] = co < c_out ? q_->bias[co] * gain : 0.f;
+            s_nst[tid] = (q_->yh2 && co < c_out) ? q_->next_styles[(size_t)n * q_->next_stride + co] : 0.f;
+        }
+    };
     // ---- LDS-DMA pieces: position u = 8 k + wv of ONE list per chunk -- activation piece u (plane u / 9, 64 slots from
     //      (u % 9) 64; per-lane source, out-of-image slots read the zero page with stride 0, the ninth piece of a plane is
     //      partial: uniform lane mask) if u < 36, else weight piece u - 36 (64 slots = two rows of 32 c_out; uniform base + lane
     //      offset).  Every wave issues exactly NPC pieces per chunk: the waits below count them. ----
     const unsigned lds0 = (unsigned)(uintptr_t)NB_LDS_PTR(smem_v);
     const size_t wchunk = (size_t)WROWS * p.co_ld * 16;               // bytes of a chunk's weights
-    const char* xsrc0[KMIX + 1];
-    unsigned xstr[KMIX + 1];
+    const char* xsrc0[KMIX];
+    unsigned xstr[KMIX];
+    unsigned woff[NPC - KMIX - 1];                     // lane's byte offset within a chunk's weights (rounds > KMIX): slot e = q 64 + lane -> row e / 32, c_out e % 32
+    const char* msrc0 = nullptr;
+    unsigned mstr = 0;
+    // (wave-uniform, the same for every tile: kept in SCALAR registers -- computed through the vector unit's divisions they sat in vector
+    //  registers across the tile loop, ten of them spilled)
+    int xdst_s[KMIX + 1];
+    unsigned xmlo_s[KMIX + 1], xmhi_s[KMIX + 1];
 #pragma unroll
     for (int k = 0; k <= KMIX; ++k) {
-        int q = k * NW + wv;
-        q = q < NXP ? q : NXP - 1;
-        const int pl = q / PP, part = q - pl * PP;
-        const int e = part * 64 + lane;
-        xsrc0[k] = reinterpret_cast<const char*>(p.zeros);
-        xstr[k] = 0;
-        if (e < XPL) {
-            const int r = e / XS, c = e - r * XS;
-            const int gy = I0 - 1 + r, gx = J0 - 1 + c;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                xsrc0[k] = reinterpret_cast<const char*>(xn + (size_t)pl * HW8 + (size_t)(gy * W + gx) * 8);
-                xstr[k] = (unsigned)(4 * HW8 * 2);
-            }
-        }
-    }
-    auto xdst = [&](int k) { int q = k * NW + wv; q = q < NXP ? q : NXP - 1; const int pl = q / PP, part = q - pl * PP; return pl * XPL + part * 64; };
-    auto xmask = [&](int k) -> unsigned long long {
         int q = k * NW + wv; q = q < NXP ? q : NXP - 1;
-        return q % PP == PP - 1 ? (1ull << (XPL - (PP - 1) * 64)) - 1 : ~0ull;
-    };
-    // weight piece of list round k (k >= KMIX): q = 8 k + wv - 36 (clamped: the list's last two positions re-copy piece 17)
-    auto wq = [&](int k) { int q = k * NW + wv - NXP; return q < 0 ? 0 : (q < NWP ? q : NWP - 1); };
-    unsigned woff[NPC - KMIX];                         // lane's byte offset within a chunk's weights: slot e = q 64 + lane -> row e / 32, c_out e % 32
-#pragma unroll
-    for (int k = KMIX; k < NPC; ++k) {
-        const int e = wq(k) * 64 + lane;
-        woff[k - KMIX] = (unsigned)(((size_t)(e >> 5) * p.co_ld + co0 + (e & 31)) * 16);
+        const int pl = q / PP, part = q - pl * PP;
+        const unsigned long long m = part == PP - 1 ? (1ull << (XPL - (PP - 1) * 64)) - 1 : ~0ull;
+        xdst_s[k] = __builtin_amdgcn_readfirstlane(pl * XPL + part * 64);
+        xmlo_s[k] = __builtin_amdgcn_readfirstlane((unsigned)m); xmhi_s[k] = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
     }
+    auto xdst = [&](int k) { return xdst_s[k]; };
+    auto xmask = [&](int k) -> unsigned long long { return ((unsigned long long)xmhi_s[k] << 32) | xmlo_s[k]; };
+    // weight piece of list round k (k >= KMIX): q = 8 k + wv - 36 (clamped: the list's last two positions re-copy piece 17)
+    auto wq = [&](int k) { int q = k * NW + wv - NXP; return __builtin_amdgcn_readfirstlane(q < 0 ? 0 : (q < NWP ? q : NWP - 1)); };
     // the round of the list where the kind changes (waves 0-3: an activation piece, 4-7: a weight piece): ONE form for both --
     // per-lane source of chunk 0 and per-chunk stride, uniform destination and mask -- set up here, so that the K loop holds
     // neither a branch nor a select for it (a uniform `cond ? a : b` of two address computations compiles to a branch, the
     // branch splits the chunk into two basic blocks, and the compiler sinks MFMAs from the first into the second)
     const bool mix_isx = KMIX * NW + wv < NXP;
-    const char* msrc0 = mix_isx ? xsrc0[KMIX] : reinterpret_cast<const char*>(p.wts) + woff[0];
-    const unsigned mstr = mix_isx ? xstr[KMIX] : (unsigned)wchunk;
     const int mdst = mix_isx ? xdst(KMIX) : 4 * XPL + wq(KMIX) * 64;
     const unsigned long long mmask = mix_isx ? xmask(KMIX) : ~0ull;
+    // the per-lane sources of the CURRENT tile's pieces (I0, J0, n, co0 as tile_coords left them)
+    auto piece_sources = [&]() {
+        kparams_t q_ = fresh_params();
+        const char* zeros = reinterpret_cast<const char*>(q_->zeros);
+        const int co_ld = q_->co_ld;
+        const _Float16* xn = q_->x + (size_t)n * q_->c8 * 2 * HW8;        // (the sample's activations: not carried from tile to tile either)
+        // (I0, J0, co0 through an opaque statement: the sources are RECOMPUTED by the call behind the epilogue, not carried through it)
+        int i0_ = I0, j0_ = J0, c0_ = co0, lane_ = lane;             // (the lane too: slot row / column of a piece are tile-independent and would be hoisted -- ten spilled registers)
+        asm volatile("" : "+v"(i0_), "+v"(j0_), "+v"(c0_), "+v"(lane_));
+        i0_ = __builtin_amdgcn_readfirstlane(i0_); j0_ = __builtin_amdgcn_readfirstlane(j0_); c0_ = __builtin_amdgcn_readfirstlane(c0_);
+        // (round KMIX of the list -- an activation piece on waves 0-3, a weight piece on 4-7 -- only lives in msrc0 / mstr)
+        const char* xs_mix = zeros;
+        unsigned xt_mix = 0, wo_mix = 0;
+#pragma unroll
+        for (int k = 0; k <= KMIX; ++k) {
+            int q = k * NW + wv;
+            q = q < NXP ? q : NXP - 1;
+            const int pl = q / PP, part = q - pl * PP;
+            const int e = part * 64 + lane_;
+            const char* xs_ = zeros;
+            unsigned xt_ = 0;
+            if (e < XPL) {
+                const int r = e / XS, c = e - r * XS;
+                const int gy = i0_ - 1 + r, gxx = j0_ - 1 + c;
+                if (gy >= 0 && gy < H && gxx >= 0 && gxx < W) {
+                    xs_ = reinterpret_cast<const char*>(xn + (size_t)pl * HW8 + (size_t)(gy * W + gxx) * 8);
+                    xt_ = (unsigned)(4 * HW8 * 2);
+                }
+            }
+            if (k < KMIX) { xsrc0[k] = xs_; xstr[k] = xt_; } else { xs_mix = xs_; xt_mix = xt_; }
+        }
+#pragma unroll
+        for (int k = KMIX; k < NPC; ++k) {
+            const int e = wq(k) * 64 + lane_;
+            const unsigned wo_ = (unsigned)(((size_t)(e >> 5) * co_ld + c0_ + (e & 31)) * 16);
+            if (k > KMIX) woff[k - KMIX - 1] = wo_; else wo_mix = wo_;
+        }
+        msrc0 = mix_isx ? xs_mix : reinterpret_cast<const char*>(q_->wts) + wo_mix;
+        mstr = mix_isx ? xt_mix : (unsigned)wchunk;
+    };
+    piece_sources();
     auto issue_piece = [&](auto kk, int c, int stage_slot) {
         constexpr int k = decltype(kk)::value;
         if constexpr (k < KMIX) {
             nb_lds_dma16_m(xsrc0[k] + (size_t)c * xstr[k], lds0 + (unsigned)(stage_slot + xdst(k)) * 16u, xmask(k));
         } else if constexpr (k > KMIX) {
             const char* wbase = reinterpret_cast<const char*>(p.wts) + (size_t)c * wchunk;
-            nb_lds_dma16_s(wbase, woff[k - KMIX], lds0 + (unsigned)(stage_slot + 4 * XPL + wq(k) * 64) * 16u);
+            nb_lds_dma16_s(wbase, woff[k - KMIX - 1], lds0 + (unsigned)(stage_slot + 4 * XPL + wq(k) * 64) * 16u);
         } else {
             nb_lds_dma16_m(msrc0 + (size_t)c * mstr, lds0 + (unsigned)(stage_slot + mdst) * 16u, mmask);
         }
@@ -173,40 +227,7 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     if constexpr (F6) { if (tid == 0) s_zero6[0] = h8{}; }
 
     f32x16 acc[NBJ][4];
-#pragma unroll
-    for (int j = 0; j < NBJ; ++j)
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][ph][r] = 0.f;
-
-    // ---- prologue: chunks 0 and 1, and the two pieces of chunk 2 that the steady state issues under the previous chunk's last
-    //      group; the tile's noise values are computed / fetched while they are on their way ----
     const int NC = p.nchunks;
-    // (chunk 0 goes out alone and FIRST: a CU's LDS-DMA fill rate is ~25-35 GB/s, and pieces in flight together share it -- with
-    //  chunks 1 and 2 issued in the same breath the first MFMA waited 1.5 us longer for chunk 0)
-    nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 0, 0); });
-    for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
-        const int r = e / (2 * TQW), c = e - r * (2 * TQW);
-        const int oy = 2 * I0 + r, ox = 2 * J0 + c;
-        float v = (p.noise && oy < 2 * H) ? p.noise[(size_t)n * p.noise_stride_n + (size_t)oy * (2 * W) + ox] : 0.f;
-        if (p.nsrc.const_t && oy < 2 * H) {
-            float np0, np1, wx0, wx1, wy0, wy1;
-            int sx0, sy0;
-            nb_noise_np(p.nsrc, n, np0, np1);
-            nb_noise_axis(p.nsrc, oy, np0, sx0, wx0, wx1);
-            nb_noise_axis(p.nsrc, ox, np1, sy0, wy0, wy1);
-            v = nb_noise_value(p.nsrc, p.nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
-        }
-        s_noise[e] = v * p.gain;
-    }
-    if (NC > 1) nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 1, STAGE); });
-    if (NC > 2) nb_static_for<0, N4>([&](auto k) { issue_piece(k, 2, 2 * STAGE); });
-    if (NC > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + N4) : "memory");
-    else if (NC > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    NB_TSTAMP(1);
 
     // ---- fragment registers (loop-carried).  A: sets a / n (a tap pair: two hi fragments + ONE lo tuple), m (the lone tap 4, lo
     //      tuple = (tap 4 | zeros)).  B: hi fragments at input offsets 0, 1, XS, XS + 1; lo tuples bl01 = (offset 0 | offset 1) --
@@ -216,23 +237,28 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     i32x8 al_a, al_n, al_m;
     h8 bh0[NBJ], bh1[NBJ], bh2[NBJ], bh3[NBJ];
     i32x8 bl01[NBJ], bl23[NBJ];
-    ah_m = h8{}; al_a = i32x8{}; al_n = i32x8{}; al_m = i32x8{};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        ah_a[i] = h8{}; ah_n[i] = h8{};
-        bh0[i] = h8{}; bh1[i] = h8{}; bh2[i] = h8{}; bh3[i] = h8{}; bl01[i] = i32x8{}; bl23[i] = i32x8{};
-    }
     const int sa_ = lh ? 116 : 127, sb_ = lh ? 129 : 118;      // E8M0 block scales (see modconv3x3_up1_h3_kernel)
     // f6 operands: six registers + the scale dword each (A: pairs a / n, the lone tap m; B: positions (0 | 1) -- later (0 | XS) --, (XS | XS + 1))
-    v6i al6_a = v6i{}, al6_n = v6i{}, al6_m = v6i{}, bl6_01[NBJ], bl6_23[NBJ];
-    int sa6_a = 0, sa6_n = 0, sa6_m = 0, sb6_01[NBJ], sb6_23[NBJ];
-#pragma unroll
-    for (int i = 0; i < NBJ; ++i) { bl6_01[i] = v6i{}; bl6_23[i] = v6i{}; sb6_01[i] = 0; sb6_23[i] = 0; }
+    v6i al6_a, al6_n, al6_m, bl6_01[NBJ], bl6_23[NBJ];
+    int sa6_a, sa6_n, sa6_m, sb6_01[NBJ], sb6_23[NBJ];
     // H2 operands: separate lo fragments (no tuples): A sets a / n [tap of the pair], m; B lo at the four input offsets
     h8 hl_a[2], hl_n[2], hl_m, bl0[NBJ], bl1[NBJ], bl2[NBJ], bl3[NBJ];
-    hl_m = h8{};
+    // (cleared at the top of every tile: the ~100 fragment registers then are NOT values carried from one tile to the next -- and
+    //  through its epilogue, where the register file is full of accumulators and FIR operands)
+    auto zero_fragments = [&]() {
+        ah_m = h8{}; al_a = i32x8{}; al_n = i32x8{}; al_m = i32x8{};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { hl_a[i] = h8{}; hl_n[i] = h8{}; bl0[i] = h8{}; bl1[i] = h8{}; bl2[i] = h8{}; bl3[i] = h8{}; }
+        for (int i = 0; i < 2; ++i) {
+            ah_a[i] = h8{}; ah_n[i] = h8{};
+            bh0[i] = h8{}; bh1[i] = h8{}; bh2[i] = h8{}; bh3[i] = h8{}; bl01[i] = i32x8{}; bl23[i] = i32x8{};
+        }
+        al6_a = v6i{}; al6_n = v6i{}; al6_m = v6i{}; sa6_a = 0; sa6_n = 0; sa6_m = 0;
+#pragma unroll
+        for (int i = 0; i < NBJ; ++i) { bl6_01[i] = v6i{}; bl6_23[i] = v6i{}; sb6_01[i] = 0; sb6_23[i] = 0; }
+        hl_m = h8{};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { hl_a[i] = h8{}; hl_n[i] = h8{}; bl0[i] = h8{}; bl1[i] = h8{}; bl2[i] = h8{}; bl3[i] = h8{}; }
+    };
 
 #define NB_FENCE() __builtin_amdgcn_sched_barrier(0)
     auto set_lo = [](i32x8& t, const h8& v) { const i32x4 x = __builtin_bit_cast(i32x4, v); t[0] = x[0]; t[1] = x[1]; t[2] = x[2]; t[3] = x[3]; };
@@ -584,7 +610,55 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         if (c + 1 < NC) { chunk(std::integral_constant<int, 1>{}, nbe, c, ring + s * STAGE, ring + nxt(s) * STAGE, 0, 0); s = nxt(s); ++c; }
         chunk(std::integral_constant<int, 0>{}, nbe, c, ring + s * STAGE, nullptr, 0, 0);
     };
-    const unsigned long long t_loop0 = p.tstamps ? __builtin_amdgcn_s_memtime() : 0;
+    // ---- the first tile's chunk 0 (goes out alone and FIRST: a CU's LDS-DMA fill rate is ~25-35 GB/s, and pieces in flight together
+    //      share it -- with chunks 1 and 2 issued in the same breath the first MFMA waited 1.5 us longer for chunk 0) ----
+    nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 0, 0); });
+  for (;;) {                                            // one iteration per tile of this workgroup (see PERSISTENT above)
+#undef NB_TSTAMP
+// (the row address from a laundered copy of `item`: computed at the stamp, not carried in two vector registers across the K loop)
+#define NB_TSTAMP(k) do { if (p.tstamps && threadIdx.x == 0) { unsigned it_ = item; asm volatile("" : "+v"(it_)); p.tstamps[(size_t)it_ * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+    // ---- the tile's prologue: chunk 0 is on its way (the first tile's was issued above; a later tile's activations went out before
+    //      the previous tile's epilogue, its weights behind it); now chunk 1 and the two pieces of chunk 2 that the steady state
+    //      issues under the previous chunk's last group.  The tile's epilogue operands and noise values are written meanwhile. ----
+    load_channel_tables();
+    {
+        kparams_t q_ = fresh_params();
+        const float* noise = q_->noise;
+        const long long nstride = q_->noise_stride_n;
+        const float gain = q_->gain;
+        const NbNoiseSrcDev nsrc{q_->nsrc.const_t, q_->nsrc.lin, q_->nsrc.strength, q_->nsrc.norm_pos, q_->nsrc.positions, q_->nsrc.res, q_->nsrc.img_res};
+        for (int e = tid; e < 2 * TQH * 2 * TQW; e += NT) {
+            const int r = e / (2 * TQW), c = e - r * (2 * TQW);
+            const int oy = 2 * I0 + r, ox = 2 * J0 + c;
+            float v = (noise && oy < 2 * H) ? noise[(size_t)n * nstride + (size_t)oy * (2 * W) + ox] : 0.f;
+            if (nsrc.const_t && oy < 2 * H) {
+                float np0, np1, wx0, wx1, wy0, wy1;
+                int sx0, sy0;
+                nb_noise_np(nsrc, n, np0, np1);
+                nb_noise_axis(nsrc, oy, np0, sx0, wx0, wx1);
+                nb_noise_axis(nsrc, ox, np1, sy0, wy0, wy1);
+                v = nb_noise_value(nsrc, nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
+            }
+            s_noise[e] = v * gain;
+        }
+    }
+    if (NC > 1) nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 1, STAGE); });
+    if (NC > 2) nb_static_for<0, N4>([&](auto k) { issue_piece(k, 2, 2 * STAGE); });
+    // (vmcnt counts the previous tile's epilogue stores too -- older than every piece of this tile: "all but the youngest N" covers them)
+    if (NC > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + N4) : "memory");
+    else if (NC > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    NB_TSTAMP(1);
+
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][ph][r] = 0.f;
+    zero_fragments();
+    const unsigned t_loop0 = p.tstamps ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;      // (32 bits: a K loop is < 2^32 cycles)
     // position blocks of this wave that hold rows feeding stored pixels (see modconv3x3_up2_h3_kernel)
     const int nvalid_blk = (min(TQH, H - I0) + 2) * PW;
     int nbe_w = 0;
@@ -595,19 +669,47 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     else kloop(std::integral_constant<int, 0>{});
 #undef NB_FENCE
     if (p.tstamps && tid == 0) {
-        unsigned long long* ts = p.tstamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
-        ts[6] = 0; ts[7] = (__builtin_amdgcn_s_memtime() - t_loop0) << 32;
+        unsigned it_ = item; asm volatile("" : "+v"(it_));
+        unsigned long long* ts = p.tstamps + (size_t)it_ * 8;
+        ts[6] = 0; ts[7] = (unsigned long long)((unsigned)__builtin_amdgcn_s_memtime() - t_loop0) << 32;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain before the staging LDS is reused
     __builtin_amdgcn_s_barrier();
+    // (the K loop's per-lane piece sources end here: an opaque "definition" tells the compiler so -- piece_sources() rewrites them all
+    //  before their next use, but under a condition, and 21 registers would otherwise stay reserved through the epilogue)
+#pragma unroll
+    for (int k = 0; k < KMIX; ++k) { asm volatile("" : "=v"(xsrc0[k])); asm volatile("" : "=v"(xstr[k])); }
+#pragma unroll
+    for (int k = 0; k < NPC - KMIX - 1; ++k) asm volatile("" : "=v"(woff[k]));
+    asm volatile("" : "=v"(msrc0)); asm volatile("" : "=v"(mstr));
 
     NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
+    // ---- the NEXT tile's chunk 0, activations: into stage 0's activation planes (the first 33 600 bytes of the ring), which the
+    //      epilogue below leaves alone (its phase slots start behind them) -- they travel while the epilogue computes and stores.
+    //      The epilogue keeps THIS tile's coordinates (e_*); the coordinates and piece sources move on to the next tile. ----
+    const int e_n = n, e_I0 = I0, e_J0 = J0, e_co0 = co0;
+    const unsigned item_next = __builtin_amdgcn_readfirstlane(item + gridDim.x);
+    const bool has_next = item_next < total && !(p.dbg & 64);          // (dbg & 64: no prefetch -- the next tile's chunk 0 goes out after the epilogue)
+    if (item_next < total) {
+        tile_coords(item_next);
+        piece_sources();
+        if (has_next) {
+            nb_static_for<0, KMIX>([&](auto k) { issue_piece(k, 0, 0); });
+            if (mix_isx) issue_piece(std::integral_constant<int, KMIX>{}, 0, 0);
+        }
+    }
     // ---- epilogue: modconv3x3_up2_h3_kernel's, statement for statement (2 rounds of 16 c_out; comments there) ----
+    // (the lane / wave coordinates through an opaque statement: everything the epilogue derives from them -- slot addresses, quad
+    //  coordinates, channel offsets: ~45 per-lane values -- is the same for every tile, so the compiler would hoist it all out of the
+    //  tile loop and keep it in (spilled) registers across the K loop; recomputed per tile it is a few dozen integer instructions)
+    int l31e = l31, lhe = lh, wve = wv;
+    asm volatile("" : "+v"(l31e), "+v"(lhe), "+s"(wve));
     const int Wo = 2 * W, Ho = 2 * H;
     constexpr int nquads = TQH * TQW;
     constexpr int Y1P = NBLK * 32;
-    f32x4* y4 = reinterpret_cast<f32x4*>(smem_v);
+    // (the phase slots start behind stage 0's activation planes, where the next tile's first chunk is landing)
+    f32x4* y4 = reinterpret_cast<f32x4*>(smem_v + (size_t)4 * XPL * 16);
     const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
     unsigned long long te_w = 0, te_f = 0, te0 = 0;
 #pragma unroll
@@ -620,23 +722,23 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
 #pragma unroll
             for (int j = 0; j < NBJ; ++j) {
                 if (j >= nblk) continue;
-                const int pidx = (wv + NW * j) * 32 + l31;
+                const int pidx = (wve + NW * j) * 32 + l31e;
 #pragma unroll
                 for (int ph = 0; ph < 4; ++ph) {
                     const f32x16& a_ = acc[j][ph];
-                    y4[((gs * 2 + lh) * 4 + ph) * Y1P + pidx] = f32x4{a_[r0], a_[r0 + 1], a_[r0 + 2], a_[r0 + 3]};
+                    y4[((gs * 2 + lhe) * 4 + ph) * Y1P + pidx] = f32x4{a_[r0], a_[r0 + 1], a_[r0 + 2], a_[r0 + 3]};
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_w += t_ - te0; te0 = t_; }
         auto quad_item = [&](const int wi) {
-            const int hq = wi * 32 + l31;
+            const int hq = wi * 32 + l31e;
             const int gs = hq / nquads, qd = hq - gs * nquads;
             const int ti = qd / TQW, tj = qd - ti * TQW;
-            if (I0 + ti >= H) return;
-            const int c4 = 16 * R + 8 * gs + 4 * lh;  // the lane's four channels within the slice
-            const f32x4* ee = y4 + ((gs * 2 + lh) * 4) * Y1P + ti * PW + tj;
+            if (e_I0 + ti >= H) return;
+            const int c4 = 16 * R + 8 * gs + 4 * lhe;  // the lane's four channels within the slice
+            const f32x4* ee = y4 + ((gs * 2 + lhe) * 4) * Y1P + ti * PW + tj;
             const f32x4* eo = ee + 1 * Y1P;
             const f32x4* oe = ee + 2 * Y1P;
             const f32x4* oo = ee + 3 * Y1P;
@@ -656,7 +758,7 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                 vo[c][0] = fir4(o0, e0, o1, e1); vo[c][1] = fir4(e0, o1, e1, o2);
             }
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dco + c4), b4 = *reinterpret_cast<const f32x4*>(s_bias + c4);
-            const int qi = I0 + ti, qj = J0 + tj;
+            const int qi = e_I0 + ti, qj = e_J0 + tj;
             auto act4 = [&](f32x4 o, float nz) {
                 f32x4 t = __builtin_elementwise_fma(o, d4, b4 + nz);
                 const f32x4 ta = t * p.alpha;
@@ -679,9 +781,9 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                 if (qi < H && !(p.dbg & 1)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int co = co0 + c4 + i;
+                        const int co = e_co0 + c4 + i;
                         if (co < p.c_out) {
-                            float* dst = p.y + ((size_t)n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)(2 * qi) * Wo + 2 * qj;
+                            float* dst = p.y + ((size_t)e_n * p.c_out + co) * ((size_t)Ho * Wo) + (size_t)(2 * qi) * Wo + 2 * qj;
                             *reinterpret_cast<f32x2*>(dst) = f32x2{v[0][0][i], v[0][1][i]};
                             *reinterpret_cast<f32x2*>(dst + Wo) = f32x2{v[1][0][i], v[1][1][i]};
                         }
@@ -716,11 +818,11 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                         nb_swap32(ha[px][k], hb[px][k]);
                         nb_swap32(la[px][k], lb[px][k]);
                     }
-                const int cg = co0 / 8 + 2 * R + gs;
-                const int oy = 2 * qi + lh, ox = 2 * qj;
+                const int cg = e_co0 / 8 + 2 * R + gs;
+                const int oy = 2 * qi + lhe, ox = 2 * qj;
                 if (qi < H && cg * 8 < p.c_out && !(p.dbg & 1)) {
                     const size_t OHW8 = (size_t)Ho * Wo * 8;
-                    _Float16* yn = p.yh2 + ((size_t)n * p.c8_next + cg) * 2 * OHW8;
+                    _Float16* yn = p.yh2 + ((size_t)e_n * p.c8_next + cg) * 2 * OHW8;
                     const size_t opix8 = ((size_t)oy * Wo + ox) * 8;
 #pragma unroll
                     for (int px = 0; px < 2; ++px) {
@@ -728,7 +830,7 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                         if constexpr (OUTM == 1) {
                             *reinterpret_cast<u32x4*>(yn + OHW8 + opix8 + px * 8) = u32x4{la[px][0], la[px][1], lb[px][0], lb[px][1]};
                         } else {
-                            _Float16* lo_xl = p.yh2 + ((size_t)n * p.c8_next + (cg & ~1)) * 2 * OHW8 + OHW8 + opix8 + px * 8 + (cg & 1) * 4;
+                            _Float16* lo_xl = p.yh2 + ((size_t)e_n * p.c8_next + (cg & ~1)) * 2 * OHW8 + OHW8 + opix8 + px * 8 + (cg & 1) * 4;
                             *reinterpret_cast<u32x2*>(lo_xl) = u32x2{la[px][0], lb[px][0]};
                             *reinterpret_cast<u32x2*>(lo_xl + 2 * OHW8) = u32x2{la[px][1], lb[px][1]};
                         }
@@ -739,27 +841,59 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         constexpr int NWI = nquads * 2 / 32;          // 24 wave-iterations of 32 quads x both channel halves per round
         static_assert(nquads * 2 % 32 == 0 && NWI % NW == 0, "tile quads must fill whole waves");
 #pragma unroll
-        for (int k = 0; k < NWI / NW; ++k) quad_item(wv + k * NW);
+        for (int k = 0; k < NWI / NW; ++k) quad_item(wve + k * NW);
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_f += t_ - te0; }
     }
     NB_TSTAMP(4);
     if (p.tstamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         NB_TSTAMP(5);
-        if (threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + 3] = (te_w & 0x1fffff) | ((te_f & 0x1fffff) << 21);
+        if (threadIdx.x == 0) { unsigned it_ = item; asm volatile("" : "+v"(it_)); p.tstamps[(size_t)it_ * 8 + 3] = (te_w & 0x1fffff) | ((te_f & 0x1fffff) << 21); }
     }
+    if (item_next >= total) break;
+    // ---- on to the next tile: every wave has read its phase slots -- the rest of chunk 0 (its weights, which land on them) goes out ----
+    item = __builtin_amdgcn_readfirstlane(item_next);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    NB_TSTAMP(0);
+    piece_sources();            // (again: computed here, the 21 registers of per-lane sources are not alive through the epilogue)
+    if (has_next) {
+        if (!mix_isx) issue_piece(std::integral_constant<int, KMIX>{}, 0, 0);
+        nb_static_for<KMIX + 1, NPC>([&](auto k) { issue_piece(k, 0, 0); });
+    } else {
+        nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 0, 0); });
+    }
+  }
+#undef NB_TSTAMP
+#define NB_TSTAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (p.tstamps && threadIdx.x == 0) p.tstamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 }
+
+static int g_up2v_persist = -1;
+// developer / test hook: -1 / 1 = persistent workgroups (one per CU, next tile's first chunk prefetched under the epilogue), 0 = one workgroup per tile
+extern "C" void nb_debug_set_up2v_persistent(int mode) { g_up2v_persist = mode; }
 
 template <bool F8, int OUTM, bool F6 = false, bool HO = false>
 static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
-    constexpr size_t lds_ring = (size_t)NST * STAGE * 16, lds_epi = (size_t)16 * NBLK * 32 * 16;
+    // (epilogue phase slots behind stage 0's activation planes: 33 600 + 122 880 = 156 480 B, 384 more than the ring)
+    constexpr size_t lds_ring = (size_t)NST * STAGE * 16, lds_epi = (size_t)4 * XPL * 16 + (size_t)16 * NBLK * 32 * 16;
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM, F6, HO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(p.tiles_x * p.tiles_y * p.slices, n);
+    // persistent workgroups: one per CU (fewer items than CUs: one each), each walking its items with the next tile's first chunk
+    // prefetched under the current tile's epilogue; g_up2v_persist == 0 (test hook): one workgroup per item, as until round 5
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        ncu = v;
+    }
+    const int items = p.items;
+    dim3 grid(g_up2v_persist != 0 && items > ncu ? ncu : items);
     hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM, F6, HO>), grid, dim3(NT), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2v");
     return NB_OK;
@@ -774,7 +908,9 @@ int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long
     p.tiles_x = p.w / TQW;
     p.tiles_y = (p.h + TQH - 1) / TQH;
     p.slices = (p.c_out + CO_WG - 1) / CO_WG;
-    p.tstamps = (tstamps && (long long)p.tiles_x * p.tiles_y * p.slices * n <= tstamps_cap) ? tstamps : nullptr;
+    p.items_x = p.tiles_x * p.tiles_y * p.slices;
+    p.items = p.items_x * n;
+    p.tstamps = (tstamps && (long long)p.items <= tstamps_cap) ? tstamps : nullptr;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
     if (in_fmt == 3) return outm == 2 ? nb_up2v_launch1<true, 2, false, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1, false, true>(p, n, stream) : nb_up2v_launch1<true, 0, false, true>(p, n, stream);
     if (in_fmt == 2) return outm == 2 ? nb_up2v_launch1<true, 2, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1, true>(p, n, stream) : nb_up2v_launch1<true, 0, true>(p, n, stream);

@@ -44,6 +44,16 @@ void nb_debug_set_up2_pair(int mode);
  * tests/test_hip_f8.py asserts the two bit-identical. */
 void nb_debug_set_up2_v2(int mode);
 
+/* Workgroups of the 8-wave split-f16 up=1 kernel (round 6): -1 / 1 = persistent -- one per CU, each walking its share of the launch's
+ * tiles with the NEXT tile's prologue (halo tile + three weight sub-chunks) issued ahead of the current tile's epilogue --, 0 = one
+ * workgroup per tile.  tests/test_hip_f8.py asserts the two bit-identical. */
+void nb_debug_set_up1_persistent(int mode);
+
+/* Workgroups of the 12-row software-pipelined up=2 kernel (round 6): -1 / 1 = persistent -- one per CU, each walking its share of the
+ * launch's tiles with the NEXT tile's first chunk prefetched under the current tile's epilogue --, 0 = one workgroup per tile (the form
+ * of rounds 4-5).  tests/test_hip_f8.py asserts the two bit-identical. */
+void nb_debug_set_up2v_persistent(int mode);
+
 /* Tile form of nb_enc_conv3x3_h3: -1 = automatic, 0 = large tiles, 1 = small split-K tiles. */
 void nb_debug_set_enc_small(int mode);
 

@@ -119,15 +119,29 @@ def test_stampless_prebuilt_library_loads_with_warning(monkeypatch, tmp_path):
 
 def test_no_scratch_in_counted_wait_kernels(library):
     """The split-f16 and fp32-MFMA conv kernels keep several LDS-DMA operations in flight and wait on COUNTS
-    (``s_waitcnt vmcnt(N)``); register spills or other compiler-made scratch accesses inside them would sit in the same
-    counter.  The code-object metadata of the built library must show none (one long-standing exception is listed)."""
+    (``s_waitcnt vmcnt(N)``); register spills or other compiler-made scratch accesses inside their K loops would sit in the same
+    counter.  Two checks on the built library: (1) the code-object metadata shows no scratch at all -- except for the PERSISTENT
+    kernels of round 6 (a tile loop around the K loop: the 8-wave up=1 kernel and up2v), which may hold a few registers in scratch
+    AROUND the K loop (spilled before a tile's loop, reloaded behind it) -- and (2) the disassembly of EVERY kernel shows no scratch
+    instruction and no SGPR-spill lane traffic inside any matrix loop (innermost loops with >= 8 MFMA instructions)."""
     res = build.kernel_resources()
     assert len(res) >= 60
     known = {"modconv3x3_up1_small_h3_kernel"}          # no counted waits: weight fragments by plain loads, vmcnt(0) only
-    bad = {k: v for k, v in res.items() if (v["scratch_bytes"] or v["vgpr_spill"]) and not any(n in k for n in known)}
+    persistent = ("modconv3x3_up1_h3_kernel", "modconv3x3_up2v_kernel")
+    bad = {k: v for k, v in res.items() if (v["scratch_bytes"] or v["vgpr_spill"]) and not any(n in k for n in known)
+           and not (any(n in k for n in persistent) and v["vgpr_spill"] <= 40)}
     assert not bad, bad
     for k, v in res.items():
         assert v["vgpr"] <= 256 or "up2_h3" not in k, (k, v)
+    loops = build.mfma_loop_spill_traffic()
+    assert sum(len(v) for v in loops.values()) >= 40, "the disassembly walk found no matrix loops"
+    # (lane traffic: one v_readlane per six-step body of the round-3 H2 loop has been there since round 3)
+    hot = {k: v for k, v in loops.items() if any(sc or lanes > 2 for _, sc, lanes in v) and not any(n in k for n in known)}
+    assert not hot, hot
+    # ... and the walk sees the loops it is meant to guard: the steady-state bodies of the two persistent kernels
+    for name, n_mfma in (("modconv3x3_up1_h3_kernelILi2ELb1ELi2ELb1ELb0ELb1ELb0E", 108), ("modconv3x3_up2v_kernelILb1ELi2ELb0ELb0E", 28)):
+        rows = [v for k, v in loops.items() if name in k]
+        assert rows and any(r[0] == n_mfma for r in rows[0]), (name, rows)
 
 
 def test_no_packed_f32_high_dword_broadcast(library):

@@ -1,6 +1,8 @@
 """GPU parity of the "f8" conv mode (correction products of the split-f16 scheme on block-scaled fp8 MFMAs):
 kernels against float64 / the h3 kernels, the generator against the REFERENCE outputs (tests/golden/gen_r*.npz) and the
 tiled canvas against the reference-painted canvas.  north_star tolerance: 1e-3 max abs on pixels; asserted: 3e-4."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -288,6 +290,8 @@ def test_hi_only_form_is_the_plain_f16_product(up, ci, co, res, n):
     S = torch.cuda.current_stream().cuda_stream
     xh, wp = ops.pack_h2f8(x, st), ops.pack_conv_weight_h3f8(w)
     out = {}
+    if up == 2:
+        lib.nb_debug_set_up2_v2(1)              # (the 12-row software-pipelined kernel whatever the launch size: on other tile forms in_fmt 3 is in_fmt 1)
     for fmt in (1, 3):
         y = torch.empty([n, co, res, res], device="cuda")
         if up == 1:
@@ -296,8 +300,11 @@ def test_hi_only_form_is_the_plain_f16_product(up, ci, co, res, n):
         else:
             rc = lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), dco.data_ptr(), None, 0, bias.data_ptr(), y.data_ptr(), None, None,
                                              0, 0, fmt, 0, n, hin, hin, co, 1.0, 1.0, -1.0, S)
+        if rc != 0:
+            lib.nb_debug_set_up2_v2(-1)
         _lib.check(rc, "conv")
         out[fmt] = y.cpu().double()
+    lib.nb_debug_set_up2_v2(-1)
     xr = (x * st[:, :, None, None]).half().float()                    # the hi halves as the pack rounds them
     ref_hi = _conv_ref(xr, w.half().float(), torch.ones_like(st), up)
     ref = _conv_ref(x, w, st, up)
@@ -307,3 +314,120 @@ def test_hi_only_form_is_the_plain_f16_product(up, ci, co, res, n):
     e_f8 = float((out[1] - ref).abs().max()) / scale
     print(f"[hi-only up{up} {ci}->{co}@{res}] vs rounded-operand float64 {e_hi:.1e}; vs fp32 operands: f16 {e_f16:.1e}, f8 {e_f8:.1e}")
     assert e_hi <= 5e-6 and e_f8 <= 5e-5 and 5 * e_f8 < e_f16 < 5e-3
+
+
+@pytest.mark.parametrize("fmt,ci,co,h,w,n", [(1, 128, 64, 128, 128, 32), (1, 384, 128, 64, 64, 32), (0, 64, 64, 48, 32, 40), (1, 32, 32, 26, 64, 70), (1, 64, 96, 24, 32, 9)])
+def test_up2v_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h, w, n):
+    """The 12-row software-pipelined up=2 kernel runs as PERSISTENT workgroups since round 6 (one per CU, each walking its share of the
+    launch's tiles, the next tile's first chunk prefetched under the current tile's epilogue).  Same tiles, same per-tile arithmetic:
+    fp32 and hand-off outputs must be bit-identical to the one-workgroup-per-tile launch -- at BASELINE's two large shapes (11 and 6
+    tiles per workgroup), with ragged last tile rows, with more c_out slices than one, with fewer tiles than CUs (one each) and with a
+    tile count that is no multiple of 8 or of the CU count (no XCD renumbering, ragged shares)."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(ci + h + fmt)
+    x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32)).cuda()
+    wt = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    nst = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    dco = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32)).cuda()
+    noise = torch.from_numpy(rs.randn(n, 2 * h, 2 * w).astype(np.float32)).cuda()
+    xh = (ops.pack_h2f8 if fmt else ops.pack_h2)(x, st)
+    wp = (ops.pack_conv_weight_h3f8 if fmt else ops.pack_conv_weight_h3)(wt)
+    del x
+    lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    lib.nb_debug_set_up2v_persistent.argtypes, lib.nb_debug_set_up2v_persistent.restype = [ctypes.c_int], None
+    res = {}
+    try:
+        lib.nb_debug_set_up2_v2(1)
+        for mode in (0, 1):
+            lib.nb_debug_set_up2v_persistent(mode)
+            outs = []
+            for rep in range(2):                         # (twice: the second launch starts with the first one's data in the caches)
+                y = torch.full([n, co, 2 * h, 2 * w], float("nan"), device="cuda") if fmt == 0 or co <= 64 else None
+                out = torch.zeros(ops.h2_shape(n, co, 2 * h, 2 * w), dtype=torch.float16, device="cuda")
+                common = (dco.data_ptr(), noise.data_ptr(), 4 * h * w, bias.data_ptr())
+                if y is not None:
+                    _lib.check(lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, y.data_ptr(), None, None, 0, 0, fmt, 0,
+                                                           n, h, w, co, 0.2, 1.4142135, 256.0, S), "f32 out")
+                _lib.check(lib.nb_modconv3x3_up2_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, None, out.data_ptr(), nst.data_ptr(), co,
+                                                       co, fmt, fmt, n, h, w, co, 0.2, 1.4142135, 256.0, S), "hand-off out")
+                torch.cuda.synchronize()
+                outs.append((y, out))
+            res[mode] = outs
+    finally:
+        lib.nb_debug_set_up2v_persistent(-1)
+        lib.nb_debug_set_up2_v2(-1)
+    for rep in range(2):
+        for a, b in zip(res[0][rep], res[1][rep]):
+            if a is not None:
+                assert torch.equal(a, b)
+                assert bool(torch.isfinite(a.float()).all())
+
+
+@pytest.mark.parametrize("fmt,ci,co,h,w,n,out", [(1, 128, 128, 128, 128, 32, "handoff"), (1, 64, 64, 256, 256, 32, "torgb"), (1, 64, 64, 64, 64, 40, "f32"),
+                                                (0, 48, 64, 32, 64, 70, "handoff"), (1, 32, 192, 32, 32, 33, "handoff"), (1, 64, 64, 32, 64, 9, "torgb")])
+def test_up1_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h, w, n, out):
+    """The 8-wave up=1 kernel runs as PERSISTENT workgroups since round 6 (one per CU, each walking its share of the launch's tiles, the
+    next tile's prologue issued ahead of the current tile's epilogue where that epilogue works from the accumulators).  Same tiles, same
+    per-tile arithmetic: hand-off, fused-ToRGB and fp32 outputs must be bit-identical to the one-workgroup-per-tile launch -- at BASELINE's
+    two large shapes (8 and 16 tiles per workgroup), with several c_out slices, with item counts that are no multiple of 8 or of the CU
+    count, and with fewer items than CUs (one each)."""
+    from brushstroke_engine_amd import _lib, ops
+    rs = np.random.RandomState(ci + h + fmt)
+    x = torch.from_numpy(rs.randn(n, ci, h, w).astype(np.float32)).cuda()
+    wt = torch.from_numpy((rs.randn(co, ci, 3, 3) / np.sqrt(9 * ci)).astype(np.float32)).cuda()
+    st = torch.from_numpy(rs.uniform(0.5, 1.5, (n, ci)).astype(np.float32)).cuda()
+    nst = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    dco = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32)).cuda()
+    noise = torch.from_numpy(rs.randn(n, h, w).astype(np.float32)).cuda()
+    xh = (ops.pack_h2f8 if fmt else ops.pack_h2)(x, st)
+    wp = (ops.pack_conv_weight_h3f8 if fmt else ops.pack_conv_weight_h3)(wt)
+    del x
+    # fused ToRGB operands (the last layer's form: c_out <= 128, one slice)
+    tst = torch.from_numpy(rs.uniform(0.5, 1.5, (n, co + 9)).astype(np.float32)).cuda()
+    tw = torch.from_numpy((rs.randn(3, co) / np.sqrt(co)).astype(np.float32)).cuda()
+    tb, cb = torch.from_numpy(rs.randn(3).astype(np.float32)).cuda(), torch.from_numpy(rs.randn(9).astype(np.float32)).cuda()
+    lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    lib.nb_debug_set_up1_persistent.argtypes, lib.nb_debug_set_up1_persistent.restype = [ctypes.c_int], None
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.nb_debug_set_up1_persistent(mode)
+            outs = []
+            for rep in range(2):
+                common = (dco.data_ptr(), noise.data_ptr(), h * w, bias.data_ptr())
+                if out == "handoff":
+                    y = torch.zeros(ops.h2_shape(n, co, h, w), dtype=torch.float16, device="cuda")
+                    rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, None, y.data_ptr(), nst.data_ptr(), co, co, None,
+                                                     fmt, fmt, n, h, w, co, 0.2, 1.4142135, 256.0, S)
+                    got = (y,)
+                elif out == "f32":
+                    y = torch.full([n, co, h, w], float("nan"), device="cuda")
+                    rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, y.data_ptr(), None, None, 0, 0, None,
+                                                     fmt, 0, n, h, w, co, 0.2, 1.4142135, 256.0, S)
+                    got = (y,)
+                else:
+                    uvs = torch.full([n, 3, h, w], float("nan"), device="cuda")
+                    img = torch.full([n, 3, h, w], float("nan"), device="cuda")
+                    colors = torch.zeros([n, 3, 3], device="cuda")
+                    u8 = torch.zeros([n, h, w, 4], dtype=torch.uint8, device="cuda")
+                    t = _lib.NbTorgbArgs()
+                    t.styles, t.w, t.bias, t.color_bias = tst.data_ptr(), tw.data_ptr(), tb.data_ptr(), cb.data_ptr()
+                    t.logits, t.uvs, t.img, t.colors_out = None, uvs.data_ptr(), img.data_ptr(), colors.data_ptr()
+                    t.user_colors, t.sfactor, t.rgba_f32, t.rgba_u8 = None, None, None, u8.data_ptr()
+                    t.styles_stride_n, t.render_mode, t.clamp = co + 9, 0, 256.0
+                    rc = lib.nb_modconv3x3_up1_h3_ex(xh.data_ptr(), ci, wp.data_ptr(), *common, None, None, None, 0, 0, ctypes.byref(t),
+                                                     fmt, 0, n, h, w, co, 0.2, 1.4142135, 256.0, S)
+                    got = (uvs, img, colors, u8)
+                _lib.check(rc, "up1")
+                torch.cuda.synchronize()
+                outs.append(got)
+            res[mode] = outs
+    finally:
+        lib.nb_debug_set_up1_persistent(-1)
+    for rep in range(2):
+        for a, b in zip(res[0][rep], res[1][rep]):
+            assert torch.equal(a, b)
+            assert bool(torch.isfinite(a.float()).all())
