@@ -136,11 +136,13 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         return q;
     };
     int n = 0, y0 = 0, x0 = 0, co0 = 0;
+    bool sample_lead = false;                      // exactly one item per sample: it writes the sample's ToRGB colors
     const size_t HW8 = (size_t)H * W * 8;
     auto tile_coords = [&](unsigned l) {
         kparams_t q_ = fresh_params();
         const unsigned gx = (unsigned)q_->items_x;
         unsigned b = l % gx;
+        sample_lead = b == 0;
         const unsigned nn = l / gx;
         if (gx % 8 == 0 && gridDim.x % 8 == 0 && !(q_->dbg & 8)) b = (b & 7) * (gx >> 3) + (b >> 3);
         const int slice = b % q_->slices; b /= q_->slices;
@@ -167,7 +169,9 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             s_bias[tid] = co < c_out ? q_->bias[co] : 0.f;
             s_nst[tid] = (q_->yh2 && co < c_out) ? q_->next_styles[(size_t)n * q_->next_stride + co] : 0.f;
         }
-        if (p.tg.c && n != tg_n) { nb_torgb_setup(p.tg, n, s_tw, s_tcol, s_tcol01, tid, 512, item == 0); tg_n = n; }
+        // (weights x styles of the sample into LDS; the sample's lead item also writes its colors -- every item of the lead's sample
+        //  that this workgroup renders goes through here with the tables in place, so the lead must not be skipped)
+        if (p.tg.c && (n != tg_n || sample_lead)) { nb_torgb_setup(p.tg, n, s_tw, s_tcol, s_tcol01, tid, 512, sample_lead); tg_n = n; }
         const float* noise = q_->noise;
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)

@@ -431,3 +431,6 @@ def test_up1_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h, 
         for a, b in zip(res[0][rep], res[1][rep]):
             assert torch.equal(a, b)
             assert bool(torch.isfinite(a.float()).all())
+        if out == "torgb":                               # every sample's colors are written (by the sample's lead item), networks.py:462-466
+            want = torch.tanh(tst[:, :9] + cb[None, :]).reshape(n, 3, 3)
+            assert float((res[1][rep][2] - want).abs().max()) <= 1e-6
