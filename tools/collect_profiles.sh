@@ -2,10 +2,10 @@
 # Collect the round's judged artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1800 -- "bash tools/collect_profiles.sh r03 $(git rev-parse --short HEAD)"   (no git on the GPU box)
 # Writes gpurun_out/<tag>/...; copy what is to be judged into profiles/ (tools/copy_profiles.sh <tag>).
-TAG=${1:-r05}; GIT_HEAD=${2:-unknown}
+TAG=${1:-r06}; GIT_HEAD=${2:-unknown}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# the driver's command (one line carrying all three arithmetic modes), before anything else touches the GPU; it runs once more at the
+# the driver's command (one line carrying the arithmetic modes; `value` on the concurrent schedule, roofline on its single-stream leg), before anything else touches the GPU; it runs once more at the
 # very end, when the counter passes have written the traffic file for THESE kernel sources (a bench.py run right after the
 # rocprofv3 --pmc passes measured its auxiliary three-streams leg 19 % low, twice: the counters leave the clocks in a state of
 # their own for a while)
@@ -32,12 +32,18 @@ cd $R
 python tools/make_hbm_traffic.py $O/hbm_traffic.json "${GIT_HEAD:-unknown}" f8=$O/pmc_mem_f8.json h3=$O/pmc_mem_h3.json f32=$O/pmc_mem_f32.json > $O/hbm_traffic.log 2>&1
 cp $O/hbm_traffic.json $R/profiles/hbm_traffic.json
 NB_PHASE_FMT=1 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times.txt 2>&1
-NB_PHASE_FMT=2 NB_PHASE_H2OUT=1 python tools/phase_times.py > $O/phase_times_f6.txt 2>&1
 python tools/phase_times_enc.py > $O/phase_times_encoder.txt 2>&1
-# round 5: the large launches with f8 and f6 operands (same box, alternating), the ping-pong up=1 K loop against the software-pipelined one
-python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/f6_layers.txt
-(for pp in 0 1 0 1; do echo "== NB_UP1_PP=$pp"; NB_UP1_PP=$pp NB_LAYERS=0,1 NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up"; done) > $O/ab_up1_pingpong_layers.txt 2>&1
-bash tools/ab_env.sh NB_UP1_PP=0 2>&1 | grep f8 > $O/ab_up1_pingpong_step.txt    # (base = the variable set = ping-pong OFF, cur = the default = on)
+# round 6: launch times of the four large layers (40-launch loops), the persistent workgroups against one workgroup per tile (same box,
+# alternating: per-kernel ms of bench.py's calibration pass, both schedules' step rates; phase stamps of the up=1 launches), the number of
+# streams of the concurrent schedule, the first-round stagger (no-go)
+NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/large_layers.txt
+bash tools/ab_persist.sh > $O/ab_persistent.txt 2>&1
+bash tools/ab_streams.sh > $O/ab_streams.txt 2>&1
+PAIRS=2 bash tools/ab_env.sh NB_STAGGER=200 > $O/ab_stagger.txt 2>&1
+# the N > 1 code through RCCL at world size 1 (NB_FORCE_PG=1): bench.py, the lamali canvas, the training step
+NB_FORCE_PG=1 python bench.py --modes primary --no-cpu --no-latency --detail $O/rccl_world1_bench_detail.json > $O/rccl_world1_bench.json 2> $O/rccl_world1_bench.err
+NB_FORCE_PG=1 python tools/bench_lamali.py --steps 3 2> $O/rccl_world1_lamali.err | grep "^{" > $O/rccl_world1_lamali.json
+NB_FORCE_PG=1 python tools/bench_train.py --iters 8 --warmup 2 2> $O/rccl_world1_train.err | grep "^{" > $O/rccl_world1_train.json
 bash $R/tools/microbench/run_all.sh > $O/microbench.txt 2>&1
 python tools/latency_stroke.py > $O/latency_stroke.txt 2>&1
 NB_SUBS="1" NB_STEPS=40 bash tools/run_step_trace.sh > $O/step_trace.txt 2>&1

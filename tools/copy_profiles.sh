@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy a collection (gpurun_out/<tag>/, written by tools/collect_profiles.sh on the GPU box) into the tracked profiles/.
-TAG=${1:-r05}; S=gpurun_out/$TAG
+TAG=${1:-r06}; S=gpurun_out/$TAG
 for f in $S/*.json $S/*.txt $S/*.csv; do
   b=$(basename $f)
   case $b in smoke.txt|pmc_mem_*.json) continue;; esac
