@@ -1340,6 +1340,14 @@ __global__ __launch_bounds__(256, 2) void modconv3x3_up1_h3s_kernel(const H3Para
     }
 }
 
+#define NB_PERSIST_WGS_PER_CU 4
+// Workgroups per CU of the persistent launches (both large kernels).  1 would keep every workgroup resident from the start; with 4 a
+// workgroup still walks 2-4 tiles of the BASELINE launches (the prefetch pays from the second tile on) but CUs come free four times per
+// launch, which is what lets another stream's kernels in: same-box, 3 streams in flight, 18 415 (1) / 18 490 (2) / 18 577 (4) patches/s
+// against 18 311 with one workgroup per tile; on ONE stream all three give +2.8 % (profiles/r06_ab_persistent_grid.txt).
+int g_persist_wgs_per_cu = NB_PERSIST_WGS_PER_CU;
+// developer / test hook: <= 0 restores the default
+extern "C" void nb_debug_set_persistent_wgs_per_cu(int k) { g_persist_wgs_per_cu = k > 0 ? k : NB_PERSIST_WGS_PER_CU; }
 static int g_up1_persist = -1;
 // developer / test hook: -1 / 1 = persistent workgroups of the 8-wave up=1 kernel (one per CU, next tile's prologue ahead of the epilogue), 0 = one per tile
 extern "C" void nb_debug_set_up1_persistent(int mode) { g_up1_persist = mode; }
@@ -1379,7 +1387,8 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         ncu = v;
     }
-    dim3 grid(g_up1_persist != 0 && p.items > ncu ? ncu : p.items);
+    const long want = (long)ncu * g_persist_wgs_per_cu;                 // (workgroups per CU: see NB_PERSIST_WGS_PER_CU)
+    dim3 grid(g_up1_persist != 0 && p.items > want ? (unsigned)want : (unsigned)p.items);
     hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         asm volatile("" : "+s"(q));
         return q;
     };
-    // PERSISTENT workgroups (round 6): the launch has gridDim.x = min(items, CUs) workgroups and workgroup w renders items w, w + gridDim.x,
+    // PERSISTENT workgroups (round 6): the launch has gridDim.x = min(items, 4 x CUs) workgroups and workgroup w renders items w, w + gridDim.x,
     // ... of the list [sample][tile][c_out slice] (p.items of them, p.items_x per sample).  What that buys is the prologue: the first
     // chunk of the NEXT tile is on its way (LDS-DMA) while this tile's epilogue runs -- a workgroup used to spend 4.4-5 of its 31-50 us
     // waiting for that round trip with the matrix pipes idle, and one workgroup per CU (156 KB of LDS) means nobody else could use them.
@@ -870,6 +870,7 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     } while (0)
 }
 
+extern int g_persist_wgs_per_cu;
 static int g_up2v_persist = -1;
 // developer / test hook: -1 / 1 = persistent workgroups (one per CU, next tile's first chunk prefetched under the epilogue), 0 = one workgroup per tile
 extern "C" void nb_debug_set_up2v_persistent(int mode) { g_up2v_persist = mode; }
@@ -893,7 +894,8 @@ static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
         ncu = v;
     }
     const int items = p.items;
-    dim3 grid(g_up2v_persist != 0 && items > ncu ? ncu : items);
+    const long want = (long)ncu * g_persist_wgs_per_cu;                  // (workgroups per CU: NB_PERSIST_WGS_PER_CU in nb_modconv_h3.hip)
+    dim3 grid(g_up2v_persist != 0 && items > want ? (unsigned)want : (unsigned)items);
     hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM, F6, HO>), grid, dim3(NT), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2v");
     return NB_OK;

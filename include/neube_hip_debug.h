@@ -54,6 +54,11 @@ void nb_debug_set_up1_persistent(int mode);
  * of rounds 4-5).  tests/test_hip_f8.py asserts the two bit-identical. */
 void nb_debug_set_up2v_persistent(int mode);
 
+/* Workgroups per CU of the persistent launches (both kernels above): default 4 (<= 0 restores it) -- a workgroup walks 2-4 tiles of the
+ * BASELINE launches and CUs come free four times per launch for other streams' kernels; 1 = every workgroup resident from the start
+ * (`profiles/r06_ab_persistent_grid.txt`). */
+void nb_debug_set_persistent_wgs_per_cu(int k);
+
 /* Tile form of nb_enc_conv3x3_h3: -1 = automatic, 0 = large tiles, 1 = small split-K tiles. */
 void nb_debug_set_enc_small(int mode);
 

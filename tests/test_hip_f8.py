@@ -337,11 +337,13 @@ def test_up2v_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h,
     del x
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     lib.nb_debug_set_up2v_persistent.argtypes, lib.nb_debug_set_up2v_persistent.restype = [ctypes.c_int], None
+    lib.nb_debug_set_persistent_wgs_per_cu.argtypes, lib.nb_debug_set_persistent_wgs_per_cu.restype = [ctypes.c_int], None
     res = {}
     try:
         lib.nb_debug_set_up2_v2(1)
-        for mode in (0, 1):
-            lib.nb_debug_set_up2v_persistent(mode)
+        for mode in (0, 1, 2):                            # one workgroup per tile; persistent, 4 workgroups per CU (default); 1 per CU
+            lib.nb_debug_set_up2v_persistent(min(mode, 1))
+            lib.nb_debug_set_persistent_wgs_per_cu(1 if mode == 2 else 0)
             outs = []
             for rep in range(2):                         # (twice: the second launch starts with the first one's data in the caches)
                 y = torch.full([n, co, 2 * h, 2 * w], float("nan"), device="cuda") if fmt == 0 or co <= 64 else None
@@ -357,12 +359,14 @@ def test_up2v_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h,
             res[mode] = outs
     finally:
         lib.nb_debug_set_up2v_persistent(-1)
+        lib.nb_debug_set_persistent_wgs_per_cu(0)
         lib.nb_debug_set_up2_v2(-1)
     for rep in range(2):
-        for a, b in zip(res[0][rep], res[1][rep]):
-            if a is not None:
-                assert torch.equal(a, b)
-                assert bool(torch.isfinite(a.float()).all())
+        for mode in (1, 2):
+            for a, b in zip(res[0][rep], res[mode][rep]):
+                if a is not None:
+                    assert torch.equal(a, b)
+                    assert bool(torch.isfinite(a.float()).all())
 
 
 @pytest.mark.parametrize("fmt,ci,co,h,w,n,out", [(1, 128, 128, 128, 128, 32, "handoff"), (1, 64, 64, 256, 256, 32, "torgb"), (1, 64, 64, 64, 64, 40, "f32"),
@@ -391,10 +395,12 @@ def test_up1_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h, 
     tb, cb = torch.from_numpy(rs.randn(3).astype(np.float32)).cuda(), torch.from_numpy(rs.randn(9).astype(np.float32)).cuda()
     lib, S = _lib.lib(), torch.cuda.current_stream().cuda_stream
     lib.nb_debug_set_up1_persistent.argtypes, lib.nb_debug_set_up1_persistent.restype = [ctypes.c_int], None
+    lib.nb_debug_set_persistent_wgs_per_cu.argtypes, lib.nb_debug_set_persistent_wgs_per_cu.restype = [ctypes.c_int], None
     res = {}
     try:
-        for mode in (0, 1):
-            lib.nb_debug_set_up1_persistent(mode)
+        for mode in (0, 1, 2):                            # one workgroup per tile; persistent, 4 workgroups per CU (default); 1 per CU
+            lib.nb_debug_set_up1_persistent(min(mode, 1))
+            lib.nb_debug_set_persistent_wgs_per_cu(1 if mode == 2 else 0)
             outs = []
             for rep in range(2):
                 common = (dco.data_ptr(), noise.data_ptr(), h * w, bias.data_ptr())
@@ -427,10 +433,12 @@ def test_up1_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h, 
             res[mode] = outs
     finally:
         lib.nb_debug_set_up1_persistent(-1)
+        lib.nb_debug_set_persistent_wgs_per_cu(0)
     for rep in range(2):
-        for a, b in zip(res[0][rep], res[1][rep]):
-            assert torch.equal(a, b)
-            assert bool(torch.isfinite(a.float()).all())
+        for mode in (1, 2):
+            for a, b in zip(res[0][rep], res[mode][rep]):
+                assert torch.equal(a, b)
+                assert bool(torch.isfinite(a.float()).all())
         if out == "torgb":                               # every sample's colors are written (by the sample's lead item), networks.py:462-466
             want = torch.tanh(tst[:, :9] + cb[None, :]).reshape(n, 3, 3)
             assert float((res[1][rep][2] - want).abs().max()) <= 1e-6

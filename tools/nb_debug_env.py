@@ -21,6 +21,7 @@ SWITCHES = {
     "NB_UP2_V2": ("nb_debug_set_up2_v2", -1),
     "NB_UP2V_PERSIST": ("nb_debug_set_up2v_persistent", -1),
     "NB_UP1_PERSIST": ("nb_debug_set_up1_persistent", -1),
+    "NB_PERSIST_WGS": ("nb_debug_set_persistent_wgs_per_cu", 0),
     "NB_SMALL_WAVES": ("nb_debug_set_small_waves", 0),
     "NB_SMALL_BLOCKS": ("nb_debug_set_small_blocks", 0),
     "NB_ENC_SMALL": ("nb_debug_set_enc_small", -1),
