@@ -134,17 +134,17 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     // (wave-uniform, the same for every tile: kept in SCALAR registers -- computed through the vector unit's divisions they sat in vector
     //  registers across the tile loop, ten of them spilled)
     int xdst_s[KMIX + 1];
-    unsigned xmlo_s[KMIX + 1], xmhi_s[KMIX + 1];
+    unsigned xlast_bits = 0;                           // bit k: round k's activation piece is the partial ninth piece of its plane
 #pragma unroll
     for (int k = 0; k <= KMIX; ++k) {
         int q = k * NW + wv; q = q < NXP ? q : NXP - 1;
         const int pl = q / PP, part = q - pl * PP;
-        const unsigned long long m = part == PP - 1 ? (1ull << (XPL - (PP - 1) * 64)) - 1 : ~0ull;
         xdst_s[k] = __builtin_amdgcn_readfirstlane(pl * XPL + part * 64);
-        xmlo_s[k] = __builtin_amdgcn_readfirstlane((unsigned)m); xmhi_s[k] = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+        xlast_bits |= (part == PP - 1 ? 1u : 0u) << k;
     }
+    xlast_bits = __builtin_amdgcn_readfirstlane(xlast_bits);
     auto xdst = [&](int k) { return xdst_s[k]; };
-    auto xmask = [&](int k) -> unsigned long long { return ((unsigned long long)xmhi_s[k] << 32) | xmlo_s[k]; };
+    auto xmask = [&](int k) -> unsigned long long { return (xlast_bits >> k) & 1u ? (1ull << (XPL - (PP - 1) * 64)) - 1 : ~0ull; };
     // weight piece of list round k (k >= KMIX): q = 8 k + wv - 36 (clamped: the list's last two positions re-copy piece 17)
     auto wq = [&](int k) { int q = k * NW + wv - NXP; return __builtin_amdgcn_readfirstlane(q < 0 ? 0 : (q < NWP ? q : NWP - 1)); };
     // the round of the list where the kind changes (waves 0-3: an activation piece, 4-7: a weight piece): ONE form for both --
