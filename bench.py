@@ -797,6 +797,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
             dist.init_process_group(backend, timeout=tmo)
+        # RCCL prints its version banner to stdout through C stdio when the communicator comes up: bring that about NOW and flush, or
+        # the banner leaves the process at exit -- behind the JSON line, which must be the last line of stdout (launch.flush_c_stdio)
+        from brushstroke_engine_amd import launch as _launch0
+        _launch0.warm_up_communicator(dev)
 
     from brushstroke_engine_amd import config as cfgmod, weights as wmod, synthetic
     from brushstroke_engine_amd.networks import Generator, DEFAULT_CONV_MODE
@@ -925,14 +929,15 @@ def main():
             out["detail_file"] = os.path.relpath(detail_path, REPO)
         except OSError as e:
             out["detail_file"] = f"(not written: {e})"
-        if args.full_line:
-            print(json.dumps(out), flush=True)
-        else:
-            print(fit_line(compact_line(out)), flush=True)
+        final_line = json.dumps(out) if args.full_line else fit_line(compact_line(out))
     sampler.__exit__(None, None, None)
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+        _launch.flush_c_stdio()
+    if rank == 0:
+        # the LAST thing this job writes to stdout: after the process group is gone and every C-side buffer is out
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -58,6 +58,28 @@ def self_launch(script: str, argv: List[str], gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def flush_c_stdio() -> None:
+    """Flush the C library's stdio buffers of this process.  RCCL prints a version banner ("RCCL version : ...", five lines) to STDOUT
+    through C stdio when its first communicator comes up; into a pipe or a file that text sits in the C buffer until the process exits
+    -- i.e. it lands BEHIND the JSON line a benchmark printed from Python, and a reader of "the last line of stdout" finds the banner
+    (seen on the first RCCL run of this code, round 6).  Called right after the communicator exists, the banner goes out first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                   # noqa: BLE001
+        pass
+
+
+def warm_up_communicator(dev: torch.device) -> None:
+    """One tiny all-reduce so that the RCCL communicator (and its banner) exists now, then flush C stdio."""
+    if dist.is_available() and dist.is_initialized():
+        t = torch.zeros([1], device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.synchronize(dev)
+    flush_c_stdio()
+
+
 def init(timeout_s: int = 300) -> Tuple[int, int, torch.device, str]:
     """(rank, world, device, backend) of this process; creates the process group when world > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,6 +112,7 @@ def init(timeout_s: int = 300) -> Tuple[int, int, torch.device, str]:
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
             dist.init_process_group(backend, timeout=tmo)
+        warm_up_communicator(dev)
     return rank, world, dev, backend
 
 
@@ -157,3 +180,4 @@ def finish(world: int) -> None:
     if collective(world) and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()

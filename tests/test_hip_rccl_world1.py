@@ -39,6 +39,9 @@ def _one_line(r):
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    # the JSON line is the LAST line of stdout (the driver parses the last line): RCCL's version banner -- printed through C stdio when
+    # the communicator comes up, flushed at exit unless somebody flushes earlier -- must come before it (launch.flush_c_stdio)
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0], r.stdout[-1500:]
     return json.loads(lines[0])
 
 

@@ -46,6 +46,8 @@ def main():
                 sock.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        from brushstroke_engine_amd import launch as _launch
+        _launch.warm_up_communicator(dev)                # (RCCL's stdout banner out NOW, not behind the JSON line: launch.flush_c_stdio)
     cfg = cfgmod.style1_config(a.res)
     G = TrainableGenerator(cfg, wmod.random_state_dict(cfg, 0), dev)
     D = TrainableDiscriminator(random_discriminator_state_dict(a.res, 3, channel_base=16384, channel_max=128), a.res, 3,
