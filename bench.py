@@ -158,7 +158,7 @@ MODE_DTYPE = {
     "f8": "f16 hi x f16 hi MFMA + 2 block-scaled fp8 (e4m3) correction products per fp32 product, fp32 accumulate: ~2^-15 relative "
           "per product, ~1e-4 from an all-fp32 evaluation on pixels (north_star budget 1e-3)",
     "f16": "f16 hi x f16 hi MFMA only in the four large launches (the f8 mode with its correction products skipped): plain single-f16 products, "
-           "~3e-3 from an all-fp32 evaluation on pixels -- OUTSIDE the 1e-3 budget: the reference's own shipped arithmetic for blocks >= 32^2 "
+           "1.5e-3 ... 3e-3 from an all-fp32 evaluation on pixels -- OUTSIDE the 1e-3 budget: the reference's own shipped arithmetic for blocks >= 32^2 "
            "(training/networks.py:634-638), a timing data point, NOT a parity mode",
     "f6": "f8 with fp6 (e2m3) correction products (per-pixel 16-channel block scales) in the two large up=2 launches: the round-5 experiment, "
           "not faster than f8 (profiles/r05_f6_ab.txt); everything else as f8",
@@ -549,7 +549,7 @@ def measure_mode(G, mode, args, cfg, inputs, world, rank, dev, backend, gather, 
                 "note": (("fp32 MFMA" if not split else
                           "split-f16 kernels execute 3 f16 MFMA FLOPs per algorithmic fp32 FLOP: frac <= 1/3 by construction"
                           if mode == "h3" else
-                          "hi-only f16 products: one f16 MFMA FLOP per algorithmic FLOP (NOT a parity mode: ~3e-3 from fp32)"
+                          "hi-only f16 products: one f16 MFMA FLOP per algorithmic FLOP (NOT a parity mode: 1.5e-3 ... 3e-3 from fp32)"
                           if mode == "f16" else
                           "split-f16 + fp8-correction kernels spend 2 f16-MFMA-equivalents of matrix time per algorithmic fp32 FLOP: "
                           "frac (against the f16 peak) <= 1/2 by construction")

@@ -342,7 +342,7 @@ struct NbNoiseSrc {
  * correction operands, above); the weights must be packed for in_fmt (nb_pack_conv_weight_h3 or the f8 layout).
  * in_fmt 2 = "f6" (round-5 experiment: fp6 corrections, own weight layout).  in_fmt 3 (round 6) = f8 operands and weights with the
  * correction products SKIPPED where the launch runs on the large throughput kernels (ping-pong up=1 loop, 12-row up=2 kernel;
- * elsewhere it is in_fmt 1): a plain single-f16 evaluation, ~3e-3 from fp32 end to end -- the reference's own shipped arithmetic for
+ * elsewhere it is in_fmt 1): a plain single-f16 evaluation, 1.5e-3 ... 3e-3 from fp32 end to end -- the reference's own shipped arithmetic for
  * blocks >= 32^2 (training/networks.py:634-638), outside this build's 1e-3 parity budget; Generator(conv_mode="f16"), a timing
  * data point, not a parity mode.
  * Exactly one destination: y_f32 (fp32 NCHW; out_fmt ignored), y_h2 (the consumer's input tensor [n, c_next, ...] in
