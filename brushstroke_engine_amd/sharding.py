@@ -113,6 +113,13 @@ class TileGatherer:
         self.wait_host_ms = 0.0
         self._wait_events = []
         self._cuda = torch.device(device).type == "cuda"
+        # (timing events come from a pool created -- and recorded once -- up front: creating HIP events inside a timed region costs a
+        #  fresh process milliseconds; wait_ms(reset=True) hands them back)
+        self._event_pool = []
+        if self.timing and self._cuda and self.active and not torch.cuda.is_current_stream_capturing():
+            self._event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 48)]
+            for e in self._event_pool:
+                e.record()
 
     def wait_ms(self, reset: bool = True) -> dict:
         """{"host_ms", "stream_ms", "waits"} accumulated by finish() (synchronises the device when events are pending)."""
@@ -122,6 +129,8 @@ class TileGatherer:
             stream_ms = round(sum(a.elapsed_time(b) for a, b in self._wait_events), 4)
         out = {"host_ms": round(self.wait_host_ms, 4), "stream_ms": stream_ms, "waits": len(self._wait_events)}
         if reset:
+            for a, b in self._wait_events:
+                self._event_pool += [a, b]
             self.wait_host_ms, self._wait_events = 0.0, []
         return out
 
@@ -142,7 +151,8 @@ class TileGatherer:
             import time as _time
             ev = None
             if self._cuda and not torch.cuda.is_current_stream_capturing():
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev = ((self._event_pool.pop(), self._event_pool.pop()) if len(self._event_pool) >= 2 else
+                      (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
                 ev[0].record()
             t0 = _time.perf_counter()
             self._work.wait()
