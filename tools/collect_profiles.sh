@@ -40,6 +40,7 @@ NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/large_layers.tx
 bash tools/ab_persist.sh > $O/ab_persistent.txt 2>&1
 bash tools/ab_streams.sh > $O/ab_streams.txt 2>&1
 PAIRS=2 bash tools/ab_env.sh NB_STAGGER=200 > $O/ab_stagger.txt 2>&1
+python tools/stress_persistent.py > $O/stress_persistent.txt 2>&1           # race hunt: 2 400 persistent launches against the one-workgroup-per-tile results
 # the N > 1 code through RCCL at world size 1 (NB_FORCE_PG=1): bench.py, the lamali canvas, the training step
 NB_FORCE_PG=1 python bench.py --modes primary --no-cpu --no-latency --detail $O/rccl_world1_bench_detail.json > $O/rccl_world1_bench.json 2> $O/rccl_world1_bench.err
 NB_FORCE_PG=1 python tools/bench_lamali.py --steps 3 2> $O/rccl_world1_lamali.err | grep "^{" > $O/rccl_world1_lamali.json
