@@ -1,0 +1,8 @@
+# Same-box A/B of the persistent kernels' early fetch of the next tile's epilogue operands (NB_DEBUG bit 512 = at the top of the tile, as before).
+cd $GRAFT_REPO_ROOT
+for d in 0 512; do echo "== NB_DEBUG=$d"; NB_DEBUG=$d NB_PHASE_FMT=1 NB_PHASE_H2OUT=1 python tools/phase_times.py 2>&1 | grep -E "^up|prologue|k-loop|epilogue|inside the k-loop"; done
+for i in 1 2 3; do for d in 0 512; do NB_DEBUG=$d python bench.py --full-line --modes primary --no-cpu --no-latency 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); k = d['roofline']['calibration']['kernels']
+print('NB_DEBUG=$d:', round(d['value']), 'single', round(d['value_single_stream']), {n.replace('modconv3x3_','').replace('_kernel',''): round(v['ms_per_step'],4) for n,v in k.items() if 'up2v' in n or 'up1_h3' in n})
+"; done; done
