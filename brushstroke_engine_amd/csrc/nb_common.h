@@ -82,8 +82,8 @@ __device__ __forceinline__ void nb_noise_axis(const NbNoiseSrcDev& s, int idx, f
 }
 // noise of output pixel (row i, column j): the SOURCE COLUMN parameters (x0, wx0, wx1) come from row i, the source row
 // parameters (y0, wy0, wy1) from column j (the reference's grid transposes); const_t[x * res + y] = noise_const[y, x].
-// Two halves -- the four taps, then their weighted sum -- so that a caller can issue the taps early and combine late; the sum is ONE
-// piece of code for every caller (same contraction into fused multiply-adds: the results agree bit for bit).
+// Two halves -- the four taps, then their weighted sum -- so that a caller can issue the taps early and combine late (up2v: every tile
+// of a launch goes through the same two halves, so the results do not depend on which tile fetched early).
 __device__ __forceinline__ void nb_noise_taps(const NbNoiseSrcDev& s, int x0, int y0, float (&t)[4]) {
     const int r = s.res;
     auto tap = [&](int yi, int xi) -> float { return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? s.const_t[xi * r + yi] : 0.f; };
@@ -96,9 +96,16 @@ __device__ __forceinline__ float nb_noise_combine(const float (&t)[4], float str
     v += t[3] * (wx1 * wy1);
     return v * strength;
 }
+// (the one-call form keeps its own statement of the same sum: rewritten over nb_noise_taps / nb_noise_combine the SLP vectoriser paired its
+//  products into a swizzled v_pk_mul_f32 in the up=1 kernels -- the operand form tests/test_abi.py bans; callers that need the split
+//  use the two halves for ALL their tiles)
 __device__ __forceinline__ float nb_noise_value(const NbNoiseSrcDev& s, float strength, int x0, float wx0, float wx1, int y0, float wy0, float wy1) {
-    float t[4];
-    nb_noise_taps(s, x0, y0, t);
-    return nb_noise_combine(t, strength, wx0, wx1, wy0, wy1);
+    const int r = s.res;
+    auto tap = [&](int yi, int xi) -> float { return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? s.const_t[xi * r + yi] : 0.f; };
+    float v = tap(y0, x0) * (wx0 * wy0);
+    v += tap(y0, x0 + 1) * (wx1 * wy0);
+    v += tap(y0 + 1, x0) * (wx0 * wy1);
+    v += tap(y0 + 1, x0 + 1) * (wx1 * wy1);
+    return v * strength;
 }
 #endif

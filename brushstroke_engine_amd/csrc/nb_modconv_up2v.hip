@@ -638,7 +638,9 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                 nb_noise_np(nsrc, n, np0, np1);
                 nb_noise_axis(nsrc, oy, np0, sx0, wx0, wx1);
                 nb_noise_axis(nsrc, ox, np1, sy0, wy0, wy1);
-                v = nb_noise_value(nsrc, nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
+                float t4[4];
+                nb_noise_taps(nsrc, sx0, sy0, t4);
+                v = nb_noise_combine(t4, nsrc.strength[0], wx0, wx1, wy0, wy1);      // (the two halves, as next_fetch2 / 3 below)
             }
             s_noise[e] = v * gain;
         }
