@@ -39,6 +39,8 @@ python tools/phase_times_enc.py > $O/phase_times_encoder.txt 2>&1
 NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/large_layers.txt
 bash tools/ab_persist.sh > $O/ab_persistent.txt 2>&1
 bash tools/ab_streams.sh > $O/ab_streams.txt 2>&1
+bash tools/ab_wrap.sh > $O/ab_wrap.txt 2>&1                    # up=1 ping-pong loop: the next tile's prologue inside the K loop's last chunk (NB_DEBUG=128: off)
+bash tools/ab_early_tables.sh > $O/ab_early_tables.txt 2>&1    # up2v: the next tile's epilogue operands and noise under the epilogue (NB_DEBUG=512: off)
 PAIRS=2 bash tools/ab_env.sh NB_STAGGER=200 > $O/ab_stagger.txt 2>&1
 python tools/stress_persistent.py > $O/stress_persistent.txt 2>&1           # race hunt: 2 400 persistent launches against the one-workgroup-per-tile results
 # the N > 1 code through RCCL at world size 1 (NB_FORCE_PG=1): bench.py, the lamali canvas, the training step
