@@ -66,6 +66,7 @@ PROTOTYPES = {
     "nb_styles_noise_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "nb_demod_coefs_f32": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "nb_noise_f32": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "nb_norm_positions_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "nb_modconv3x3_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int64, vp, vp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp]),
     "nb_modconv3x3_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),

@@ -178,6 +178,7 @@ class _Plan:
         self.dcoefs = [torch.empty([n_max, c], dtype=torch.float32, device=device) for c in c_out[:-1]]
         self.noise = [torch.empty([n_max, s.block_res, s.block_res], dtype=torch.float32, device=device) for s in specs]
         self.max_res = max(s.block_res for s in specs)
+        self.npos_k = None                       # [n_max, 2] normalised positions for the layers that compute their noise themselves (on demand)
         descs = (_lib.NbLayerDesc * (len(specs) + 1))()
         for i, s in enumerate(specs):
             layer = syn.layer_module(s)
@@ -304,6 +305,7 @@ class _Pass:
     stream: int = 0
     npos: Optional[torch.Tensor] = None
     ipos: Optional[torch.Tensor] = None
+    npos_k: Optional[torch.Tensor] = None          # ipos normalised once per batch for the layers that compute their noise themselves
     shared: bool = False                     # constant noise without positions: one image for the whole batch
     inkernel_from: Optional[int] = None      # first layer (resolution order) from which every layer computes its noise itself
     pre_h2: dict = dataclasses.field(default_factory=dict)
@@ -361,6 +363,7 @@ class SynthesisNetwork(torch.nn.Module):
         self.early_geom_pack = True       # geometry channels of such inputs are packed at the start, on a side stream
         self.fuse_torgb = True            # last conv1 + ToRGB + compositing in one launch (split-f16 path)
         self.noise_in_kernel = True       # large split-f16 layers compute their (position-shifted) noise themselves
+        self.positions_once = True        # ... from positions normalised ONCE per batch (nb_norm_positions_f32) instead of per tile (batches > 8)
         self.layer_kernels: Dict[str, str] = {}
         self.layer_formats: Dict[str, int] = {}      # operand format each split-f16 layer last ran with (0 H2, 1 f8, 2 f6)
 
@@ -582,6 +585,14 @@ class SynthesisNetwork(torch.nn.Module):
             while k_ > 0 and elig[k_ - 1]:
                 k_ -= 1
             ps.inkernel_from = k_ if k_ < len(elig) else None
+            if self.positions_once and ps.inkernel_from is not None and ps.ipos is not None and n > 8 and not opts.prepare_only:
+                # those layers normalise the positions at the top of EVERY tile (nb_noise_np): from the integers that is four 64-bit modulo
+                # operations per lane and tile (44 us of a 1.93 ms step at batch 32); once per batch here, same function, same bits.
+                # (Batches <= 8 keep the integers: few tiles, and a launch costs more than it would save.)
+                if plan.npos_k is None:
+                    plan.npos_k = torch.empty([plan.n_max, 2], dtype=torch.float32, device=device)
+                _lib.check(_lib.lib().nb_norm_positions_f32(_p(ps.ipos), self.img_resolution, _p(plan.npos_k), n, ps.stream), "norm_positions")
+                ps.npos_k = plan.npos_k
 
     def _launch_styles_and_noise(self, ps: "_Pass") -> None:
         """Every layer's affine + demodulation coefficients (one launch) and the small layers' noise images (one launch), into the
@@ -752,7 +763,8 @@ class SynthesisNetwork(torch.nn.Module):
             raise AssertionError(f"{name}: got {c1}+{c2} input channels, expected {s.in_channels}")
         noise_ptr, nstride = None, 0
         if noise_mode == "const" and ps.inkernel_from is not None and i >= ps.inkernel_from:
-            nsrc = _lib.NbNoiseSrc(_p(pk["noise_const_t"]), _p(pk["noise_lin"]), _p(layer.noise_strength), _p(ps.npos), _p(ps.ipos),
+            nsrc = _lib.NbNoiseSrc(_p(pk["noise_const_t"]), _p(pk["noise_lin"]), _p(layer.noise_strength),
+                                   _p(ps.npos if ps.npos_k is None else ps.npos_k), _p(ps.ipos if ps.npos_k is None else None),
                                    s.block_res, self.img_resolution)
             ps.keep_alive.append(nsrc)
             noise_ptr, nstride = ctypes.addressof(nsrc), _lib.NB_NOISE_IN_KERNEL

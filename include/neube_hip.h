@@ -196,6 +196,12 @@ int nb_demod_coefs_f32(const float* styles, const float* wsq, float* dcoefs, int
 int nb_noise_f32(const NbLayerDesc* layers_dev, int n_layers, int max_res, const float* norm_pos,
                  const int64_t* positions, int img_resolution, int n, void* stream);
 
+/* The first step of that arithmetic on its own: positions [n,2] int64 -> norm_pos_out [n,2] float32 = ((p mod R) / (R - 1)), the values
+ * nb_noise_f32 derives internally (networks.py:371-374; same function, same bits).  For callers that hand NbNoiseSrc to the split-f16
+ * convolutions: those evaluate the normalisation at the top of every tile, and from `positions` that is four 64-bit modulo operations
+ * per lane and tile -- convert once per batch and pass `norm_pos`. */
+int nb_norm_positions_f32(const int64_t* positions, int img_resolution, float* norm_pos_out, int n, void* stream);
+
 /* Modulated 3x3 convolution + fused epilogue = SynthesisLayer.forward (networks.py:362-391) after
  * the affine:  y = clamp(lrelu(conv(x * s) * d + noise + bias, alpha) * gain, +-clamp)
  *   up = 1: cross-correlation, zero padding 1 (conv2d_resample.py:145-147)

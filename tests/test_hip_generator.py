@@ -293,6 +293,23 @@ def test_high_dynamic_range_fixture(dev, mode):
     assert e_ft <= {"f32": 2e-3, "h3": 2e-3, "f8": 0.25}[mode] and e_lg <= {"f32": 1e-3, "h3": 1e-3, "f8": 4e-3 * 10}[mode]
 
 
+def test_norm_positions_entry_point(dev):
+    """nb_norm_positions_f32 = the first step of the noise arithmetic on its own (networks.py:371-374: python-style modulo, float32
+    division): bit-identical to numpy's float32 evaluation, incl. negative, wrapped and large positions.  The generator converts a
+    batch's integer positions ONCE with it for the layers that compute their noise themselves (batches > 8); the bit-identity of
+    those layers with the noise-tensor path (which normalises inside nb_noise_f32) is test_noise_in_kernel_equals_noise_tensor."""
+    from brushstroke_engine_amd import _lib
+    rs = np.random.RandomState(3)
+    for R in (256, 128, 1000):
+        pos = rs.randint(-5000, 5000, size=(77, 2)).astype(np.int64)
+        pos[0], pos[1], pos[2], pos[3] = [0, R - 1], [-1, R], [2 ** 40 + 3, -(2 ** 40) - 3], [R * 7, -R * 7]
+        out = torch.full([77, 2], float("nan"), device=dev)
+        _lib.check(_lib.lib().nb_norm_positions_f32(torch.from_numpy(pos).to(dev).data_ptr(), R, out.data_ptr(), 77, torch.cuda.current_stream().cuda_stream), "np")
+        torch.cuda.synchronize()
+        want = (np.mod(pos, R).astype(np.float32) / np.float32(R - 1)).astype(np.float32)
+        assert np.array_equal(out.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("mode", ["h3", "f8"])
 @pytest.mark.parametrize("res,n", [(256, 32), (256, 1), (128, 5), (256, 3)])
 def test_noise_in_kernel_equals_noise_tensor(dev, mode, res, n):
