@@ -577,6 +577,15 @@ class SynthesisNetwork(torch.nn.Module):
                 _assert_shape(ps.npos, [n, 2])
                 ps.keep_alive.append(ps.npos)
             ps.shared = ps.npos is None and ps.ipos is None
+            if self.positions_once and ps.ipos is not None and n > 8:
+                # Integer positions -> normalised ones ONCE per batch (nb_norm_positions_f32: the function the kernels use, same bits).  The layers
+                # that compute their noise themselves normalise at the top of EVERY tile -- from the integers four 64-bit modulo operations
+                # per lane and tile, 44 us of a 1.93 ms step at batch 32 --, the noise launch once per block.  (Batches <= 8 keep the
+                # integers: few tiles, and a launch costs more than it would save.)
+                if plan.npos_k is None:
+                    plan.npos_k = torch.empty([plan.n_max, 2], dtype=torch.float32, device=device)
+                _lib.check(_lib.lib().nb_norm_positions_f32(_p(ps.ipos), self.img_resolution, _p(plan.npos_k), n, ps.stream), "norm_positions")
+                ps.npos_k = plan.npos_k
         # first layer (in resolution order) from which every layer runs on the large split-f16 kernels: those compute their
         # position-shifted noise in their own prologue.  Not with per-call noise buffers (their transposes do not exist).
         if (self.noise_in_kernel and opts.noise_mode == "const" and ps.table is plan.table and (ps.npos is not None or ps.ipos is not None)):
@@ -585,20 +594,14 @@ class SynthesisNetwork(torch.nn.Module):
             while k_ > 0 and elig[k_ - 1]:
                 k_ -= 1
             ps.inkernel_from = k_ if k_ < len(elig) else None
-            if self.positions_once and ps.inkernel_from is not None and ps.ipos is not None and n > 8 and not opts.prepare_only:
-                # those layers normalise the positions at the top of EVERY tile (nb_noise_np): from the integers that is four 64-bit modulo
-                # operations per lane and tile (44 us of a 1.93 ms step at batch 32); once per batch here, same function, same bits.
-                # (Batches <= 8 keep the integers: few tiles, and a launch costs more than it would save.)
-                if plan.npos_k is None:
-                    plan.npos_k = torch.empty([plan.n_max, 2], dtype=torch.float32, device=device)
-                _lib.check(_lib.lib().nb_norm_positions_f32(_p(ps.ipos), self.img_resolution, _p(plan.npos_k), n, ps.stream), "norm_positions")
-                ps.npos_k = plan.npos_k
 
     def _launch_styles_and_noise(self, ps: "_Pass") -> None:
         """Every layer's affine + demodulation coefficients (one launch) and the small layers' noise images (one launch), into the
         workspace slot -- unless an earlier pass of the same batch left them there."""
         cfg, opts, plan, n, lib, stream = self.cfg, ps.opts, ps.plan, ps.n, _lib.lib(), ps.stream
         table, npos, ipos, inkernel_from, noise_mode = ps.table, ps.npos, ps.ipos, ps.inkernel_from, opts.noise_mode
+        if ps.npos_k is not None:
+            npos, ipos = ps.npos_k, None         # (normalised once per batch, see _prepare_noise_sources)
         resume, stop_after = opts.resume, opts.stop_after
         if opts.prepared is not None:
             return                                  # styles, coefficients and noise images are in the workspace slot already
