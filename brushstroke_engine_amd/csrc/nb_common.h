@@ -69,36 +69,15 @@ __device__ __forceinline__ void nb_noise_np(const NbNoiseSrcDev& s, int n, float
         np1 = s.norm_pos[2 * n + 1];
     }
 }
-// bilinear parameters of one axis: output index idx -> first source index c0 and the two weights (nb_noise_axis_at: from the
-// value of lin[idx], for callers that fetched it ahead)
-__device__ __forceinline__ void nb_noise_axis_at(const NbNoiseSrcDev& s, float lin_idx, float np, int& c0, float& w0, float& w1) {
-    const float g = nb_fmod1(lin_idx + np) * 2.f - 1.f;
+// bilinear parameters of one axis: output index idx -> first source index c0 and the two weights
+__device__ __forceinline__ void nb_noise_axis(const NbNoiseSrcDev& s, int idx, float np, int& c0, float& w0, float& w1) {
+    const float g = nb_fmod1(s.lin[idx] + np) * 2.f - 1.f;
     const float cc = ((g + 1.f) / 2.f) * (float)(s.res - 1);
     const float f0 = floorf(cc);
     c0 = (int)f0; w1 = cc - f0; w0 = (f0 + 1.f) - cc;
 }
-__device__ __forceinline__ void nb_noise_axis(const NbNoiseSrcDev& s, int idx, float np, int& c0, float& w0, float& w1) {
-    nb_noise_axis_at(s, s.lin[idx], np, c0, w0, w1);
-}
 // noise of output pixel (row i, column j): the SOURCE COLUMN parameters (x0, wx0, wx1) come from row i, the source row
-// parameters (y0, wy0, wy1) from column j (the reference's grid transposes); const_t[x * res + y] = noise_const[y, x].
-// Two halves -- the four taps, then their weighted sum -- so that a caller can issue the taps early and combine late (up2v: every tile
-// of a launch goes through the same two halves, so the results do not depend on which tile fetched early).
-__device__ __forceinline__ void nb_noise_taps(const NbNoiseSrcDev& s, int x0, int y0, float (&t)[4]) {
-    const int r = s.res;
-    auto tap = [&](int yi, int xi) -> float { return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? s.const_t[xi * r + yi] : 0.f; };
-    t[0] = tap(y0, x0); t[1] = tap(y0, x0 + 1); t[2] = tap(y0 + 1, x0); t[3] = tap(y0 + 1, x0 + 1);
-}
-__device__ __forceinline__ float nb_noise_combine(const float (&t)[4], float strength, float wx0, float wx1, float wy0, float wy1) {
-    float v = t[0] * (wx0 * wy0);
-    v += t[1] * (wx1 * wy0);
-    v += t[2] * (wx0 * wy1);
-    v += t[3] * (wx1 * wy1);
-    return v * strength;
-}
-// (the one-call form keeps its own statement of the same sum: rewritten over nb_noise_taps / nb_noise_combine the SLP vectoriser paired its
-//  products into a swizzled v_pk_mul_f32 in the up=1 kernels -- the operand form tests/test_abi.py bans; callers that need the split
-//  use the two halves for ALL their tiles)
+// parameters (y0, wy0, wy1) from column j (the reference's grid transposes); const_t[x * res + y] = noise_const[y, x]
 __device__ __forceinline__ float nb_noise_value(const NbNoiseSrcDev& s, float strength, int x0, float wx0, float wx1, int y0, float wy0, float wy1) {
     const int r = s.res;
     auto tap = [&](int yi, int xi) -> float { return (yi >= 0 && yi < r && xi >= 0 && xi < r) ? s.const_t[xi * r + yi] : 0.f; };

@@ -305,38 +305,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             issue_w(clampt(2), wring + 2 * WSLOTS);
         }
     };
-    // WRAP (see the tile loop): the NEXT tile's activation piece sources, worked out at the top of a tile by all eight waves at once and
-    // parked in LDS behind the staging buffers (8 bytes per piece and lane: the source with NC chunk strides taken off, bit 0 = "in the
-    // image").  Inside the ping-pong loop the switch to them is NXPW LDS reads: the ~300 VALU instructions of the address arithmetic
-    // there cost their time TWICE (each wave group in its own segment, the other one waiting at the barrier: +3.8K cycles per tile).
-    unsigned long long* const next_src = reinterpret_cast<unsigned long long*>(smem_h3 + (size_t)(2 * 4 * XPL + 4 * WSLOTS) * 16);
-    auto stash_next_sources = [&](int n_, int y0_, int x0_) {
-        kparams_t q_ = fresh_params();
-        const _Float16* xn_ = q_->x + (size_t)n_ * q_->c8 * 2 * HW8;
-        const char* zeros_ = reinterpret_cast<const char*>(q_->zeros);
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
-#pragma unroll
-        for (int i = 0; i < NXPW; ++i) {
-            int q = i * NW + wv;
-            q = q < NXP ? q : NXP - 1;
-            const int e = (q % PP) * 64 + lane_;
-            const char* src = zeros_;
-            unsigned long long in = 0;
-            if (e < SLOTS) {
-                const int r = e / TWP, c = e - r * TWP;
-                const int gy = y0_ - 1 + r, gx = x0_ - 1 + c;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    src = reinterpret_cast<const char*>(xn_ + (size_t)xpl[i] * HW8 + (size_t)(gy * W + gx) * 8) - (size_t)NC * (4 * HW8 * 2);
-                    in = 1;
-                }
-            }
-            next_src[i * 512 + tid] = (unsigned long long)(uintptr_t)src | in;
-        }
-    };
     NB_TSTAMP(5);                              // (the hand-off epilogues leave slot 5 free: time that passes before the first LDS-DMA piece goes out)
     prologue_issue();
-    bool came_wrapped = false;                   // the tile before this one fetched this tile's prologue inside its K loop
   for (;;) {                                   // one iteration per tile of this workgroup (see PERSISTENT above)
 #undef NB_TSTAMP
 #define NB_TSTAMP(k) do { if (p.tstamps && threadIdx.x == 0) { unsigned it_ = item; asm volatile("" : "+v"(it_)); p.tstamps[(size_t)it_ * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
@@ -347,34 +317,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
-    // this tile's coordinates for its epilogue (the piece sources may move on to the next tile INSIDE the K loop, see `wrap`)
-    const int e_n = n, e_y0 = y0, e_x0 = x0, e_co0 = co0;
-    const unsigned item_next = __builtin_amdgcn_readfirstlane(item + gridDim.x);
-    const bool lds_free_epilogue = p.yh2 || (MW == 1 && p.tg.c && !p.y && p.c_out % 8 == 0);
-    // WRAP (ping-pong loop): the K loop's last three steps and its last chunk used to re-copy the last weight sub-chunk and halo tile
-    // (clamped indices: DMA traffic that only kept the counts uniform).  When the next tile of this workgroup has the same c_out slice, the
-    // step count is a multiple of the ring depth and the chunk count even, those very pieces fetch the NEXT tile's sub-chunks 0-2 (ring
-    // slots 0-2) and its first halo tile (buffer 0) instead: the next tile's prologue costs no issue slot, no set-up in front of the
-    // epilogue and no wait -- where the epilogue leaves the staging LDS alone.
-    bool wrap = false;
-    int w_n = 0, w_y0 = 0, w_x0 = 0;                // the next tile's coordinates, worked out HERE (three integer divisions: not inside the K loop)
-    bool w_lead = false;
-    if constexpr (PPK) {
-        if (item_next < total && lds_free_epilogue && T % 4 == 0 && NC % 2 == 0 && !(p.dbg & (64 | 128))) {
-            const int k_n = n, k_y0 = y0, k_x0 = x0, k_co0 = co0;
-            const bool k_lead = sample_lead;
-            tile_coords(item_next);
-            wrap = co0 == k_co0;
-            w_n = n; w_y0 = y0; w_x0 = x0; w_lead = sample_lead;
-            n = k_n; y0 = k_y0; x0 = k_x0; co0 = k_co0; sample_lead = k_lead;
-            if (wrap) stash_next_sources(w_n, w_y0, w_x0);
-        }
-    }
-    // step 0 needs the halo tile and sub-chunk 0 only: sub-chunks 1 and 2 may still be in flight (the loop's invariant).  After a
-    // wrapped tile the prologue pieces are OLDER than that tile's epilogue stores, so "all but the youngest" does not single them out:
-    // everything, then (they went out a whole epilogue ago)
-    if (came_wrapped) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
+    // step 0 needs the halo tile and sub-chunk 0 only: sub-chunks 1 and 2 may still be in flight (the loop's invariant)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWPW) : "memory");
     __builtin_amdgcn_s_barrier();
     NB_TSTAMP(1);
 
@@ -616,9 +560,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             auto comp_seg = [&](auto ky_, auto odd_, int t, int c) {
                 constexpr int KY = decltype(ky_)::value, ODD = decltype(odd_)::value;
                 constexpr int NDMA = NWPW + (KY == 0 ? NXPW : 0);
-                // (wrap: past the tile's end the indices run on into the next tile -- sub-chunk t + 3 - T of the same weights, "chunk NC" =
-                //  the next tile's chunk 0 through the piece sources switch_to_next_tile() has put in place; else clamped re-copies)
-                const int t3 = t + 3 < T ? t + 3 : (wrap ? t + 3 - T : T - 1), c1 = c + 1 < NC ? c + 1 : (wrap ? NC : NC - 1);
+                const int t3 = clampt(t + 3), c1 = c + 1 < NC ? c + 1 : NC - 1;
                 auto dma = [&](auto i_) {
                     constexpr int i = decltype(i_)::value;
                     if constexpr (i < NWPW) issue_w_v2(i_, t3, (t + 3) & 3);
@@ -668,23 +610,10 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                 t_bar += ((s2 - s1) & 0xffffffffull) | ((s4 - s3) << 32);          // (wait behind load | wait behind compute)
 #endif
             };
-            // the piece sources of the NEXT tile, biased by -NC chunk strides (issue_x_v2 adds c1 = NC of them): in place from the start of
-            // the tile's LAST chunk on -- whose own halo tile went out a chunk earlier
-            auto switch_to_next_tile = [&]() {
-                n = w_n; y0 = w_y0; x0 = w_x0; sample_lead = w_lead;          // (co0 is the same: that is what `wrap` means; so are the weight offsets)
-                typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_vu64;
-#pragma unroll
-                for (int i = 0; i < NXPW; ++i) {
-                    const unsigned long long v = ((lds_vu64)NB_LDS_PTR(next_src))[i * 512 + tid];
-                    xs0_v2[i] = reinterpret_cast<const char*>((uintptr_t)(v & ~1ull));
-                    xst_v2[i] = (v & 1) ? (unsigned)(4 * HW8 * 2) : 0u;
-                }
-            };
             auto pp_loop = [&](auto b_) {
                 int c = 0;
                 for (; c + 1 < NC; c += 2) {
                     pp_step(b_, K0{}, K0{}, 3 * c, c); pp_step(b_, K1{}, K1{}, 3 * c + 1, c); pp_step(b_, K2{}, K0{}, 3 * c + 2, c);
-                    if (wrap && c + 2 >= NC) switch_to_next_tile();
                     pp_step(b_, K0{}, K1{}, 3 * c + 3, c + 1); pp_step(b_, K1{}, K0{}, 3 * c + 4, c + 1); pp_step(b_, K2{}, K1{}, 3 * c + 5, c + 1);
                 }
                 if (c < NC) { pp_step(b_, K0{}, K0{}, 3 * c, c); pp_step(b_, K1{}, K1{}, 3 * c + 1, c); pp_step(b_, K2{}, K0{}, 3 * c + 2, c); }
@@ -1091,25 +1020,20 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     }
 #endif
     // drain the tail re-copies before the staging LDS is reused: every wave waits for ITS pieces, and the barrier makes
-    // sure no other wave's late piece lands on top of epilogue data (without it the outcome depended on DMA timing).
-    // Not after a wrapped K loop: what is in flight then is the NEXT tile's prologue, placed by the ring protocol where nobody reads
-    // any more, and the epilogue that follows does not touch the staging LDS -- the pieces land under it.
-    if (!wrap) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+    // sure no other wave's late piece lands on top of epilogue data (without it the outcome depended on DMA timing)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     NB_TSTAMP(2);
     if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.y[0] = 0.f; return; }      // ablation: main loop only
     // ---- the NEXT tile's prologue goes out now, ahead of this tile's epilogue, where that epilogue works straight from the accumulators
     //      (hand-off output; the fused ToRGB of a 64-channel layer): its ~4 us of LDS-DMA round trip then pass under the epilogue's
     //      arithmetic and stores.  The fp32-output path stages its tile in the LDS the prologue fills: there the prologue follows it.
     //      The epilogue keeps THIS tile's coordinates (e_*). ----
-    const bool early = wrap || (item_next < total && lds_free_epilogue && !(p.dbg & 64));      // (dbg & 64: no prefetch, 128: no wrap)
-    if (wrap) {
-        // (the next tile's prologue is in the LDS already: its coordinates and sources are in place, the bias comes off)
-#pragma unroll
-        for (int i = 0; i < NXPW; ++i) xs0_v2[i] += (size_t)NC * xst_v2[i];
-    } else if (item_next < total) {
+    const int e_n = n, e_y0 = y0, e_x0 = x0, e_co0 = co0;
+    const unsigned item_next = __builtin_amdgcn_readfirstlane(item + gridDim.x);
+    const bool lds_free_epilogue = p.yh2 || (MW == 1 && p.tg.c && !p.y && p.c_out % 8 == 0);
+    const bool early = item_next < total && lds_free_epilogue && !(p.dbg & 64);      // (dbg & 64: no prefetch)
+    if (item_next < total) {
         tile_coords(item_next);
         piece_offsets();
         if constexpr (V2) piece_sources_v2();
@@ -1221,7 +1145,6 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     epilogue();
     if (item_next >= total) break;
     item = item_next;
-    came_wrapped = wrap;
     // every wave is through with the tile's tables (and, on the fp32-output path, with the staged tile)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     NB_TSTAMP(0);
@@ -1448,10 +1371,7 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * NBW, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
     constexpr size_t lds_stage = (size_t)(2 * 4 * XPL + 4 * 12 * CO_WG) * 16, lds_h2 = (size_t)2 * TH * 32 * (CO_WG + 8) * 2;
-    // (ping-pong loop: + the next tile's piece sources, 8 bytes per activation piece and lane, behind the staging buffers -- live only where
-    //  the epilogue leaves the LDS alone, so the staged-output area may overlap them)
-    constexpr size_t lds_next = PP ? (size_t)((4 * (XPL / 64) + 7) / 8) * 512 * 8 : 0;
-    const size_t lds = lds_stage + lds_next > lds_h2 ? lds_stage + lds_next : lds_h2;
+    const size_t lds = lds_stage > lds_h2 ? lds_stage : lds_h2;
     p.tiles_x = p.w / 32; p.tiles_y = p.h / TH; p.slices = (p.c_out + CO_WG - 1) / CO_WG;
     p.items_x = p.tiles_x * p.tiles_y * p.slices; p.items = p.items_x * n;
     static bool attr_set = false;

@@ -613,7 +613,6 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     // ---- the first tile's chunk 0 (goes out alone and FIRST: a CU's LDS-DMA fill rate is ~25-35 GB/s, and pieces in flight together
     //      share it -- with chunks 1 and 2 issued in the same breath the first MFMA waited 1.5 us longer for chunk 0) ----
     nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 0, 0); });
-    bool tables_ready = false;                            // the previous tile's epilogue fetched this tile's epilogue operands and noise (below)
   for (;;) {                                            // one iteration per tile of this workgroup (see PERSISTENT above)
 #undef NB_TSTAMP
 // (the row address from a laundered copy of `item`: computed at the stamp, not carried in two vector registers across the K loop)
@@ -621,8 +620,8 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     // ---- the tile's prologue: chunk 0 is on its way (the first tile's was issued above; a later tile's activations went out before
     //      the previous tile's epilogue, its weights behind it); now chunk 1 and the two pieces of chunk 2 that the steady state
     //      issues under the previous chunk's last group.  The tile's epilogue operands and noise values are written meanwhile. ----
-    if (!tables_ready) {
-        load_channel_tables();
+    load_channel_tables();
+    {
         kparams_t q_ = fresh_params();
         const float* noise = q_->noise;
         const long long nstride = q_->noise_stride_n;
@@ -638,9 +637,7 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
                 nb_noise_np(nsrc, n, np0, np1);
                 nb_noise_axis(nsrc, oy, np0, sx0, wx0, wx1);
                 nb_noise_axis(nsrc, ox, np1, sy0, wy0, wy1);
-                float t4[4];
-                nb_noise_taps(nsrc, sx0, sy0, t4);
-                v = nb_noise_combine(t4, nsrc.strength[0], wx0, wx1, wy0, wy1);      // (the two halves, as next_fetch2 / 3 below)
+                v = nb_noise_value(nsrc, nsrc.strength[0], sx0, wx0, wx1, sy0, wy0, wy1);
             }
             s_noise[e] = v * gain;
         }
@@ -715,74 +712,6 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     f32x4* y4 = reinterpret_cast<f32x4*>(smem_v + (size_t)4 * XPL * 16);
     const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
     unsigned long long te_w = 0, te_f = 0, te0 = 0;
-    // ---- the NEXT tile's epilogue operands and noise values, fetched UNDER this epilogue.  At the top of a tile they cost two dependent
-    //      global-load latencies (sample position and the axis tables, then the four taps per value) with every matrix pipe of the CU
-    //      idle.  Here: first half of the chain behind round 0's slot writes (that round's accumulator halves are free registers),
-    //      the taps behind round 1's, the weighted sums after the last item; committed to LDS behind the closing barrier. ----
-    constexpr int NE = 2 * TQH * 2 * TQW / NT;        // noise values per lane (3)
-    static_assert(2 * TQH * 2 * TQW % NT == 0, "the tile's noise values fill whole rounds of the workgroup");
-    const bool early_tab = has_next && !(p.dbg & 512);          // (dbg & 512: fetch them at the top of the tile, as until round 6)
-    float nx_tab[3] = {0.f, 0.f, 0.f}, nx_v[NE], nx_lin[NE][2], nx_np[2] = {0.f, 0.f}, nx_strength = 0.f, nx_t[NE][4], nx_w[NE][4];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        nx_v[i] = 0.f; nx_lin[i][0] = nx_lin[i][1] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { nx_t[i][k] = 0.f; nx_w[i][k] = 0.f; }
-    }
-    auto nsrc_of = [](kparams_t q_) { return NbNoiseSrcDev{q_->nsrc.const_t, q_->nsrc.lin, q_->nsrc.strength, q_->nsrc.norm_pos, q_->nsrc.positions, q_->nsrc.res, q_->nsrc.img_res}; };
-    auto next_fetch1 = [&]() {                         // (n, I0, J0, co0 are the next tile's by now)
-        kparams_t q_ = fresh_params();
-        const float gain = q_->gain;
-        if (tid < CO_WG) {
-            const int co = co0 + tid, c_out = q_->c_out;
-            nx_tab[0] = co < c_out ? q_->dcoefs[(size_t)n * c_out + co] * gain : 0.f;
-            nx_tab[1] = co < c_out ? q_->bias[co] * gain : 0.f;
-            nx_tab[2] = (q_->yh2 && co < c_out) ? q_->next_styles[(size_t)n * q_->next_stride + co] : 0.f;
-        }
-        const float* noise = q_->noise;
-        const long long nstride = q_->noise_stride_n;
-        const NbNoiseSrcDev nsrc = nsrc_of(q_);
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * NT;
-            const int r = e / (2 * TQW), c = e - r * (2 * TQW);
-            const int oy = 2 * I0 + r, ox = 2 * J0 + c;
-            nx_v[i] = (noise && oy < 2 * H) ? noise[(size_t)n * nstride + (size_t)oy * (2 * W) + ox] : 0.f;
-            if (nsrc.const_t && oy < 2 * H) { nx_lin[i][0] = nsrc.lin[oy]; nx_lin[i][1] = nsrc.lin[ox]; }
-        }
-        if (nsrc.const_t) { nb_noise_np(nsrc, n, nx_np[0], nx_np[1]); nx_strength = nsrc.strength[0]; }
-    };
-    auto next_fetch2 = [&]() {
-        const NbNoiseSrcDev nsrc = nsrc_of(fresh_params());
-        if (!nsrc.const_t) return;
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * NT;
-            const int oy = 2 * I0 + e / (2 * TQW);
-            if (oy < 2 * H) {
-                int sx0, sy0;
-                nb_noise_axis_at(nsrc, nx_lin[i][0], nx_np[0], sx0, nx_w[i][0], nx_w[i][1]);
-                nb_noise_axis_at(nsrc, nx_lin[i][1], nx_np[1], sy0, nx_w[i][2], nx_w[i][3]);
-                nb_noise_taps(nsrc, sx0, sy0, nx_t[i]);
-            }
-        }
-    };
-    auto next_fetch3 = [&]() {                         // the weighted sums: what is carried over the closing barrier is NE + 3 registers
-        kparams_t q_ = fresh_params();
-        const float gain = q_->gain;
-        const bool in_kernel = q_->nsrc.const_t != nullptr;
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * NT;
-            const int oy = 2 * I0 + e / (2 * TQW);
-            if (in_kernel && oy < 2 * H) nx_v[i] = nb_noise_combine(nx_t[i], nx_strength, nx_w[i][0], nx_w[i][1], nx_w[i][2], nx_w[i][3]);
-            nx_v[i] *= gain;
-        }
-    };
-    auto issue_chunk0_weights = [&]() {
-        if (!mix_isx) issue_piece(std::integral_constant<int, KMIX>{}, 0, 0);
-        nb_static_for<KMIX + 1, NPC>([&](auto k) { issue_piece(k, 0, 0); });
-    };
 #pragma unroll
     for (int R = 0; R < 2; ++R) {
         if (p.tstamps) te0 = __builtin_amdgcn_s_memtime();
@@ -803,7 +732,6 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_w += t_ - te0; te0 = t_; }
-        if (early_tab) { if (R == 0) next_fetch1(); else next_fetch2(); }
         auto quad_item = [&](const int wi) {
             const int hq = wi * 32 + l31e;
             const int gs = hq / nquads, qd = hq - gs * nquads;
@@ -916,7 +844,6 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
         for (int k = 0; k < NWI / NW; ++k) quad_item(wve + k * NW);
         if (p.tstamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); te_f += t_ - te0; }
     }
-    if (early_tab) next_fetch3();
     NB_TSTAMP(4);
     if (p.tstamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -930,19 +857,10 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     NB_TSTAMP(0);
     piece_sources();            // (again: computed here, the 21 registers of per-lane sources are not alive through the epilogue)
     if (has_next) {
-        // (the rest of chunk 0: its weights land on the phase slots.  Sending them a third of a round earlier -- the last wave-iterations
-        //  of round 1 read the second c_out group's slots only -- takes one more barrier inside the round and measured +0.8 % per launch,
-        //  profiles/r06_ab_up2v_early.txt)
-        issue_chunk0_weights();
+        if (!mix_isx) issue_piece(std::integral_constant<int, KMIX>{}, 0, 0);
+        nb_static_for<KMIX + 1, NPC>([&](auto k) { issue_piece(k, 0, 0); });
     } else {
         nb_static_for<0, NPC>([&](auto k) { issue_piece(k, 0, 0); });
-    }
-    // the tile's epilogue operands and noise values, where the epilogue above fetched them (else: at the top of the tile)
-    tables_ready = early_tab;
-    if (early_tab) {
-        if (tid < CO_WG) { s_dco[tid] = nx_tab[0]; s_bias[tid] = nx_tab[1]; s_nst[tid] = nx_tab[2]; }
-#pragma unroll
-        for (int i = 0; i < NE; ++i) s_noise[tid + i * NT] = nx_v[i];
     }
   }
 #undef NB_TSTAMP

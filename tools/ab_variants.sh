@@ -1,0 +1,15 @@
+# Same-box A/B of library variants (csrc/libneube_<name>.so through NEUBE_LIB_PATH; "shipped" = the regular library), optionally with NB_DEBUG bits:
+#   bash tools/ab_variants.sh "midround newh3_oldv oldh3_newv shipped shipped:128 shipped:512"
+R=$(cd $(dirname $0)/.. && pwd); cd $R
+for i in 1 2 3; do
+  for v in $1; do
+    name=${v%%:*}; dbg=${v#*:}; [ "$dbg" = "$v" ] && dbg=0
+    if [ $name = shipped ]; then unset NEUBE_LIB_PATH; else export NEUBE_LIB_PATH=$R/brushstroke_engine_amd/csrc/libneube_$name.so; fi
+    NB_DEBUG=$dbg python bench.py --full-line --modes primary --no-cpu --no-latency 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); k = d['roofline']['calibration']['kernels']
+print('%-16s' % '$v', round(d['value']), 'patches/s (3 streams); one stream', round(d['value_single_stream']), {n.replace('modconv3x3_','').replace('_kernel',''): round(v['ms_per_step'],4) for n,v in k.items() if 'up2v' in n or 'up1_h3' in n})
+"
+  done
+done
+unset NEUBE_LIB_PATH
