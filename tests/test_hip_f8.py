@@ -371,8 +371,8 @@ def test_up2v_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h,
 
 @pytest.mark.parametrize("fmt,ci,co,h,w,n,out", [(1, 128, 128, 128, 128, 32, "handoff"), (1, 64, 64, 256, 256, 32, "torgb"), (1, 64, 64, 64, 64, 40, "f32"),
                                                 (0, 48, 64, 32, 64, 70, "handoff"), (1, 32, 192, 32, 32, 33, "handoff"), (1, 64, 64, 32, 64, 9, "torgb"),
-                                                # the wrap (next tile's prologue inside the K loop's last chunk) with several c_out slices: a workgroup's next
-                                                # item in the SAME slice (32 items per sample: stride 256 keeps the slice) and in ANOTHER one (12 per sample)
+                                                # several c_out slices: a workgroup's next item in the SAME slice (32 items per sample: stride 256 keeps the
+                                                # slice) and in ANOTHER one (12 per sample) -- the next tile's weights are the same pieces or other ones
                                                 (1, 128, 256, 64, 64, 24, "handoff"), (1, 64, 384, 32, 32, 40, "handoff")])
 def test_up1_persistent_workgroups_equal_one_workgroup_per_tile(fmt, ci, co, h, w, n, out):
     """The 8-wave up=1 kernel runs as PERSISTENT workgroups since round 6 (one per CU, each walking its share of the launch's tiles, the

@@ -1,5 +1,7 @@
 # Same-box A/B of library variants (csrc/libneube_<name>.so through NEUBE_LIB_PATH; "shipped" = the regular library), optionally with NB_DEBUG bits:
-#   bash tools/ab_variants.sh "midround newh3_oldv oldh3_newv shipped shipped:128 shipped:512"
+#   tools/build_variant_at.sh wrap e618c53 nb_modconv_h3.hip; tools/build_variant_at.sh early e618c53 nb_modconv_up2v.hip,nb_common.h
+#   gpurun -- 'bash tools/ab_variants.sh "shipped wrap early"'
+# (profiles/r06_ab_variants.txt: "midround" = the kernels shipped now, "shipped" there = wrap + early fetch, ":128" / ":512" their in-build switches)
 R=$(cd $(dirname $0)/.. && pwd); cd $R
 for i in 1 2 3; do
   for v in $1; do

@@ -39,8 +39,8 @@ python tools/phase_times_enc.py > $O/phase_times_encoder.txt 2>&1
 NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/large_layers.txt
 bash tools/ab_persist.sh > $O/ab_persistent.txt 2>&1
 bash tools/ab_streams.sh > $O/ab_streams.txt 2>&1
-bash tools/ab_wrap.sh > $O/ab_wrap.txt 2>&1                    # up=1 ping-pong loop: the next tile's prologue inside the K loop's last chunk (NB_DEBUG=128: off)
-bash tools/ab_early_tables.sh > $O/ab_early_tables.txt 2>&1
+# library-level A/B against the two features that were measured as gains by in-build switches and reverted (tools/build_variant_at.sh builds them from e618c53)
+[ -f brushstroke_engine_amd/csrc/libneube_wrap.so ] && bash tools/ab_variants.sh "shipped wrap early" 2>/dev/null | grep "patches/s" > $O/ab_variants.txt
 python tools/ab_positions_once.py 2>/dev/null | grep "per tile" > $O/ab_positions_once.txt     # integer positions normalised once per batch instead of at the top of every tile
 python tools/ab_noise_in_kernel.py 2>/dev/null | grep "noise images" > $O/ab_noise_in_kernel.txt  # the large layers' noise: computed in the kernels (default) against the noise launch's images    # up2v: the next tile's epilogue operands and noise under the epilogue (NB_DEBUG=512: off)
 PAIRS=2 bash tools/ab_env.sh NB_STAGGER=200 > $O/ab_stagger.txt 2>&1
