@@ -94,7 +94,12 @@ __device__ __forceinline__ float nb_h3_act(float a, float dg, float nbg, float a
 // computes, its partner loads.  Same per-accumulator order of products as the other f8 loops: bit-identical.
 // HO (with PPK, round 6): "hi only" -- the ping-pong f8 loop WITHOUT its correction products (plain single-f16 evaluation, ~3e-3 from
 // fp32: Generator(conv_mode="f16"), a timing data point at the reference's shipped precision, not a parity mode; see modconv3x3_up2v_kernel).
-template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false, bool F6 = false, bool PPK = false, bool HO = false>
+// PERSIST = false: the same body WITHOUT the tile loop (item_next is the list's end at compile time: no next tile, no prefetch, no carried state;
+// 208-210 instead of 256 registers, no spills) -- one workgroup per tile as until round 5.  DEFAULT for the ping-pong launches: against round 5's
+// kernels linked into the same library (profiles/r06_ab_variants*.txt) the persistent form is 4.4 % SLOWER at 64 channels (b256.conv1 + ToRGB:
+// 0.347 -> 0.362 ms per step), equal at 128, and costs the three-streams schedule 1.4 % -- while its own "one workgroup per tile" switch,
+// which kept the loop, had said -3 ... -4 %.  The persistent instantiation stays behind nb_debug_set_up1_persistent(1).
+template <int MW, bool F8 = false, int NBW_ = 2, bool V2 = false, bool F6 = false, bool PPK = false, bool HO = false, bool PERSIST = true>
 __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p) {
     static_assert(!HO || PPK, "the hi-only form is a variant of the ping-pong f8 loop");
     static_assert(!F6 || (F8 && V2), "the f6 form is a variant of the software-pipelined f8 loop");
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     //      arithmetic and stores.  The fp32-output path stages its tile in the LDS the prologue fills: there the prologue follows it.
     //      The epilogue keeps THIS tile's coordinates (e_*). ----
     const int e_n = n, e_y0 = y0, e_x0 = x0, e_co0 = co0;
-    const unsigned item_next = __builtin_amdgcn_readfirstlane(item + gridDim.x);
+    const unsigned item_next = PERSIST ? __builtin_amdgcn_readfirstlane(item + gridDim.x) : total;
     const bool lds_free_epilogue = p.yh2 || (MW == 1 && p.tg.c && !p.y && p.c_out % 8 == 0);
     const bool early = item_next < total && lds_free_epilogue && !(p.dbg & 64);      // (dbg & 64: no prefetch)
     if (item_next < total) {
@@ -1349,7 +1354,7 @@ int g_persist_wgs_per_cu = NB_PERSIST_WGS_PER_CU;
 // developer / test hook: <= 0 restores the default
 extern "C" void nb_debug_set_persistent_wgs_per_cu(int k) { g_persist_wgs_per_cu = k > 0 ? k : NB_PERSIST_WGS_PER_CU; }
 static int g_up1_persist = -1;
-// developer / test hook: -1 / 1 = persistent workgroups of the 8-wave up=1 kernel (one per CU, next tile's prologue ahead of the epilogue), 0 = one per tile
+// developer / test hook: 1 = persistent workgroups of the 8-wave up=1 kernel (next tile's prologue ahead of the epilogue), -1 (default) / 0 = one workgroup per tile
 extern "C" void nb_debug_set_up1_persistent(int mode) { g_up1_persist = mode; }
 
 static int launch_h3s(H3Params p, int n, hipStream_t st) {
@@ -1366,7 +1371,7 @@ static int launch_h3s(H3Params p, int n, hipStream_t st) {
     return NB_OK;
 }
 
-template <int MW, bool F8 = false, int NBW = 2, bool V2 = false, bool F6 = false, bool PP = false, bool HO = false>
+template <int MW, bool F8 = false, int NBW = 2, bool V2 = false, bool F6 = false, bool PP = false, bool HO = false, bool PERSIST = true>
 static int launch_h3(H3Params p, int n, hipStream_t st) {
     constexpr int NWN = 8 / MW, TH = NWN * NBW, CO_WG = MW * 64;
     constexpr int SLOTS = (TH + 2) * 34, XPL = ((SLOTS + 63) / 64) * 64;
@@ -1376,7 +1381,7 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
     p.items_x = p.tiles_x * p.tiles_y * p.slices; p.items = p.items_x * n;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // persistent workgroups: one per CU (fewer items than CUs: one each), the next tile's prologue issued ahead of the current tile's
@@ -1388,8 +1393,8 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
         ncu = v;
     }
     const long want = (long)ncu * g_persist_wgs_per_cu;                 // (workgroups per CU: see NB_PERSIST_WGS_PER_CU)
-    dim3 grid(g_up1_persist != 0 && p.items > want ? (unsigned)want : (unsigned)p.items);
-    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO>), grid, dim3(512), lds, st, p);
+    dim3 grid(PERSIST && g_up1_persist != 0 && p.items > want ? (unsigned)want : (unsigned)p.items);
+    hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO, PERSIST>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
 }
@@ -1472,8 +1477,17 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     }
     // the ping-pong form of that loop (full-height tiles): nb_debug_set_up1_pp
     const bool pp = (g_force_up1_pp >= 0 ? g_force_up1_pp : NB_UP1_PP_DEFAULT) != 0;
-    if (f8 && v2 && pp && hi_only) return c_out > 64 ? launch_h3<2, true, 2, true, false, true, true>(p, n, st) : launch_h3<1, true, 2, true, false, true, true>(p, n, st);
-    if (f8 && v2 && pp) return c_out > 64 ? launch_h3<2, true, 2, true, false, true>(p, n, st) : launch_h3<1, true, 2, true, false, true>(p, n, st);
+    // (persistent workgroups: automatic = NO, see the kernel's PERSIST; nb_debug_set_up1_persistent(1) = always: the tests and tools/stress_persistent.py
+    //  keep that form honest)
+    const bool persist = g_up1_persist > 0;
+    if (f8 && v2 && pp && hi_only) {
+        if (c_out > 64) return persist ? launch_h3<2, true, 2, true, false, true, true, true>(p, n, st) : launch_h3<2, true, 2, true, false, true, true, false>(p, n, st);
+        return persist ? launch_h3<1, true, 2, true, false, true, true, true>(p, n, st) : launch_h3<1, true, 2, true, false, true, true, false>(p, n, st);
+    }
+    if (f8 && v2 && pp) {
+        if (c_out > 64) return persist ? launch_h3<2, true, 2, true, false, true, false, true>(p, n, st) : launch_h3<2, true, 2, true, false, true, false, false>(p, n, st);
+        return persist ? launch_h3<1, true, 2, true, false, true, false, true>(p, n, st) : launch_h3<1, true, 2, true, false, true, false, false>(p, n, st);
+    }
     if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 2, true>(p, n, st) : launch_h3<1, true, 2, true>(p, n, st);
     if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
     if (v2) return c_out > 64 ? launch_h3<2, false, 2, true>(p, n, st) : launch_h3<1, false, 2, true>(p, n, st);

@@ -53,7 +53,9 @@ static_assert(NBLK <= NBJ * NW && KMIX * NW <= NXP && (KMIX + 1) * NW > NXP && N
 // >= 32^2, training/networks.py:634-638).  Generator(conv_mode="f16"): a data point that separates the cost of the split scheme from
 // the cost of the kernel structure, NOT a parity mode.  Same staging, same fillers, same epilogue; the lo-fragment reads have no
 // consumer and are dropped by the compiler.
-template <bool F8, int OUTM, bool F6 = false, bool HO = false>
+// PERSIST = false: the same body WITHOUT the tile loop (item_next is the list's end at compile time: no next tile, no prefetch, nothing carried) -- one
+// workgroup per tile, as until round 5 (see modconv3x3_up1_h3_kernel's PERSIST and profiles/r06_ab_variants.txt for why both exist).
+template <bool F8, int OUTM, bool F6 = false, bool HO = false, bool PERSIST = true>
 __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Params p) {
     static_assert(!F6 || F8, "the f6 form is a variant of the f8 loop");
     static_assert(!HO || (F8 && !F6), "the hi-only form is a variant of the f8 loop");
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
     //      epilogue below leaves alone (its phase slots start behind them) -- they travel while the epilogue computes and stores.
     //      The epilogue keeps THIS tile's coordinates (e_*); the coordinates and piece sources move on to the next tile. ----
     const int e_n = n, e_I0 = I0, e_J0 = J0, e_co0 = co0;
-    const unsigned item_next = __builtin_amdgcn_readfirstlane(item + gridDim.x);
+    const unsigned item_next = PERSIST ? __builtin_amdgcn_readfirstlane(item + gridDim.x) : total;
     const bool has_next = item_next < total && !(p.dbg & 64);          // (dbg & 64: no prefetch -- the next tile's chunk 0 goes out after the epilogue)
     if (item_next < total) {
         tile_coords(item_next);
@@ -871,18 +873,21 @@ __global__ __launch_bounds__(NT, 2) void modconv3x3_up2v_kernel(const H3Up2Param
 }
 
 extern int g_persist_wgs_per_cu;
+#ifndef NB_UP2V_PERSIST_DEFAULT
+#define NB_UP2V_PERSIST_DEFAULT 1          // (one stream: persistent 0.664-0.668 ms per step, round 5's kernel 0.667-0.672, the loop-less instantiation 0.679-0.686; three streams: equal)
+#endif
 static int g_up2v_persist = -1;
 // developer / test hook: -1 / 1 = persistent workgroups (one per CU, next tile's first chunk prefetched under the epilogue), 0 = one workgroup per tile
 extern "C" void nb_debug_set_up2v_persistent(int mode) { g_up2v_persist = mode; }
 
-template <bool F8, int OUTM, bool F6 = false, bool HO = false>
+template <bool F8, int OUTM, bool F6 = false, bool HO = false, bool PERSIST = true>
 static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
     // (epilogue phase slots behind stage 0's activation planes: 33 600 + 122 880 = 156 480 B, 384 more than the ring)
     constexpr size_t lds_ring = (size_t)NST * STAGE * 16, lds_epi = (size_t)4 * XPL * 16 + (size_t)16 * NBLK * 32 * 16;
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM, F6, HO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)modconv3x3_up2v_kernel<F8, OUTM, F6, HO, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // persistent workgroups: one per CU (fewer items than CUs: one each), each walking its items with the next tile's first chunk
@@ -895,8 +900,8 @@ static int nb_up2v_launch1(const H3Up2Params& p, int n, void* stream) {
     }
     const int items = p.items;
     const long want = (long)ncu * g_persist_wgs_per_cu;                  // (workgroups per CU: NB_PERSIST_WGS_PER_CU in nb_modconv_h3.hip)
-    dim3 grid(g_up2v_persist != 0 && items > want ? (unsigned)want : (unsigned)items);
-    hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM, F6, HO>), grid, dim3(NT), lds, (hipStream_t)stream, p);
+    dim3 grid(PERSIST && items > want ? (unsigned)want : (unsigned)items);
+    hipLaunchKernelGGL((modconv3x3_up2v_kernel<F8, OUTM, F6, HO, PERSIST>), grid, dim3(NT), lds, (hipStream_t)stream, p);
     NB_CHECK_LAUNCH("modconv3x3_up2v");
     return NB_OK;
 }
@@ -914,8 +919,16 @@ int nb_up2v_launch(H3Up2Params p, int n, int in_fmt, void* stream, unsigned long
     p.items = p.items_x * n;
     p.tstamps = (tstamps && (long long)p.items <= tstamps_cap) ? tstamps : nullptr;
     const int outm = p.yh2 ? (p.out_f8 ? 2 : 1) : 0;
-    if (in_fmt == 3) return outm == 2 ? nb_up2v_launch1<true, 2, false, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1, false, true>(p, n, stream) : nb_up2v_launch1<true, 0, false, true>(p, n, stream);
-    if (in_fmt == 2) return outm == 2 ? nb_up2v_launch1<true, 2, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1, true>(p, n, stream) : nb_up2v_launch1<true, 0, true>(p, n, stream);
-    if (in_fmt) return outm == 2 ? nb_up2v_launch1<true, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<true, 1>(p, n, stream) : nb_up2v_launch1<true, 0>(p, n, stream);
-    return outm == 2 ? nb_up2v_launch1<false, 2>(p, n, stream) : outm == 1 ? nb_up2v_launch1<false, 1>(p, n, stream) : nb_up2v_launch1<false, 0>(p, n, stream);
+    // (persistent workgroups: NB_UP2V_PERSIST_DEFAULT; nb_debug_set_up2v_persistent(0 / 1) = never / always)
+    const bool persist = g_up2v_persist >= 0 ? g_up2v_persist != 0 : NB_UP2V_PERSIST_DEFAULT != 0;
+    auto go = [&](auto f8_, auto f6_, auto ho_) {
+        constexpr bool F8_ = decltype(f8_)::value, F6_ = decltype(f6_)::value, HO_ = decltype(ho_)::value;
+        if (persist) return outm == 2 ? nb_up2v_launch1<F8_, 2, F6_, HO_, true>(p, n, stream) : outm == 1 ? nb_up2v_launch1<F8_, 1, F6_, HO_, true>(p, n, stream) : nb_up2v_launch1<F8_, 0, F6_, HO_, true>(p, n, stream);
+        return outm == 2 ? nb_up2v_launch1<F8_, 2, F6_, HO_, false>(p, n, stream) : outm == 1 ? nb_up2v_launch1<F8_, 1, F6_, HO_, false>(p, n, stream) : nb_up2v_launch1<F8_, 0, F6_, HO_, false>(p, n, stream);
+    };
+    using T = std::true_type; using F = std::false_type;
+    if (in_fmt == 3) return go(T{}, F{}, T{});
+    if (in_fmt == 2) return go(T{}, T{}, F{});
+    if (in_fmt) return go(T{}, F{}, F{});
+    return go(F{}, F{}, F{});
 }

@@ -39,7 +39,7 @@ for L in layers:                                         # references: one workg
     lib.nb_debug_set_up1_persistent(0); lib.nb_debug_set_up2v_persistent(0)
     run(L, L["out"][0], main)
 torch.cuda.synchronize()
-lib.nb_debug_set_up1_persistent(-1); lib.nb_debug_set_up2v_persistent(-1)
+lib.nb_debug_set_up1_persistent(1); lib.nb_debug_set_up2v_persistent(1)          # (the up=1 form is opt-in since the end of round 6)
 bad = 0
 for k in (0, 1):                                         # default (4 workgroups per CU), then every workgroup resident (1 per CU)
     lib.nb_debug_set_persistent_wgs_per_cu(k)
@@ -58,5 +58,6 @@ for k in (0, 1):                                         # default (4 workgroups
         bad += nb
         print(f"up{L['up']} {L['ci']}->{L['co']}@{L['res']} wgs/cu {'4 (default)' if k == 0 else 1}: {reps} persistent launches, {nb} differ from the one-workgroup-per-tile result", flush=True)
 lib.nb_debug_set_persistent_wgs_per_cu(0)
+lib.nb_debug_set_up1_persistent(-1); lib.nb_debug_set_up2v_persistent(-1)
 print("STRESS", "FAILED" if bad else "ok", bad)
 sys.exit(1 if bad else 0)
