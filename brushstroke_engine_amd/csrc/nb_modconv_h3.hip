@@ -1052,7 +1052,10 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
     // the accumulator registers directly, and whole 512-byte row segments per wave-instruction.
     constexpr int PIX_WG = TH * 32;
     if (p.yh2) {
-        const H3HandoffArgs ha_ = nb_handoff_args(p.yh2, p.c8_next, p.c_out, p.h, p.w, p.out_f8, p.dbg, p.alpha, p.gain, p.clamp);
+        // (the gain through a vector register of its own: see gain_t below)
+        float gain_h = p.gain;
+        asm volatile("" : "+v"(gain_h));
+        const H3HandoffArgs ha_ = nb_handoff_args(p.yh2, p.c8_next, p.c_out, p.h, p.w, p.out_f8, p.dbg, p.alpha, gain_h, p.clamp);
         if constexpr (F8 && V2) {          // (the f6 output form exists for the software-pipelined f8 / f6 kernels only: the launcher checks)
             if (p.out_f8 == 2) nb_up1_handoff_epilogue<MB, NBW, true>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, e_co0, e_n, e_y0, e_x0, lh, l31);
             else nb_up1_handoff_epilogue<MB, NBW, false>(ha_, acc, nzr, s_dco, s_bias, s_nst, wm * 64, wn * NBW, e_co0, e_n, e_y0, e_x0, lh, l31);
@@ -1068,9 +1071,13 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
             // (j = the four registers of a group, summed over (mb, g)), then the two lane halves meet through one
             // v_permlane32_swap per output.  No LDS image, no barrier.
             const float clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+            // (the gain through a vector register of its own: straight from the kernarg pair (alpha, gain) the packed `* gain` below broadcast
+            //  the pair's HIGH dword through op_sel:[1,0] in the loop-less instantiations -- the form tests/test_abi.py bans)
+            float gain_t = p.gain;
+            asm volatile("" : "+v"(gain_t));
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
-                const float nzg = nzr[nb] * p.gain;
+                const float nzg = nzr[nb] * gain_t;
                 f32x4 s0, s1, s2;
                 s0 = 0.f; s1 = 0.f; s2 = 0.f;
 #pragma unroll
@@ -1079,8 +1086,8 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
                     for (int g = 0; g < 4; ++g) {
                         const int col = mb * 32 + 8 * g + 4 * lh;
                         if (col < p.c_out) {
-                            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dco + col) * p.gain;
-                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + col) * p.gain + nzg;
+                            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dco + col) * gain_t;
+                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + col) * gain_t + nzg;
                             const f32x4 a4 = {acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]};
                             f32x4 t = __builtin_elementwise_fma(a4, d4, b4);
                             const f32x4 ta = t * p.alpha;
@@ -1108,17 +1115,21 @@ __global__ __launch_bounds__(512) void modconv3x3_up1_h3_kernel(const H3Params p
         }
     }
     float* ot = reinterpret_cast<float*>(smem_h3);               // [CO_WG][PIX_WG] floats (<= 128 KiB)
+    // (the gain through a vector register of its own: read from the kernarg pair (alpha, gain) the SLP vectoriser pairs the two `* gain` below
+    //  into a v_pk_mul_f32 with the gain broadcast through op_sel:[1,0] -- a swizzled packed form, see NB_NO_PACKED_F32 in nb_common.h)
+    float gain_v = p.gain;
+    asm volatile("" : "+v"(gain_v));
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int trow = wn * NBW + nb;
-        const float nzg = nzr[nb] * p.gain, clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+        const float nzg = nzr[nb] * gain_v, clampv = p.clamp >= 0.f ? p.clamp : __builtin_inff();
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // c_out within the workgroup
                 // (channels past c_out carry dco = bias = 0 and are never stored)
-                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_act(acc[mb][nb][r], s_dco[col] * p.gain, s_bias[col] * p.gain + nzg, p.alpha, clampv);
+                ot[col * PIX_WG + trow * 32 + l31] = nb_h3_act(acc[mb][nb][r], s_dco[col] * gain_v, s_bias[col] * gain_v + nzg, p.alpha, clampv);
             }
         }
     }
@@ -1393,7 +1404,7 @@ static int launch_h3(H3Params p, int n, hipStream_t st) {
         ncu = v;
     }
     const long want = (long)ncu * g_persist_wgs_per_cu;                 // (workgroups per CU: see NB_PERSIST_WGS_PER_CU)
-    dim3 grid(PERSIST && g_up1_persist != 0 && p.items > want ? (unsigned)want : (unsigned)p.items);
+    dim3 grid(PERSIST && p.items > want ? (unsigned)want : (unsigned)p.items);
     hipLaunchKernelGGL((modconv3x3_up1_h3_kernel<MW, F8, NBW, V2, F6, PP, HO, PERSIST>), grid, dim3(512), lds, st, p);
     NB_CHECK_LAUNCH("modconv3x3_up1_h3");
     return NB_OK;
@@ -1465,34 +1476,32 @@ static int nb_up1_h3_impl(const void* x_h2, int c_in, const void* w_h3, const fl
     //  with an odd number of channel groups keep the round-3 loop, whose last chunk reads the missing group from the zero page)
     const bool v2 = g_force_up1_v2 != 0 && (f8 || p.c8 % 2 == 0);
     NB_REQUIRE(out_fmt != 2 || (f8 && v2), "modconv3x3_up1_h3: the f6 output format is written by the software-pipelined f8 / f6 kernels only");
+    // Persistent workgroups: automatic = NO (see the kernel's PERSIST); nb_debug_set_up1_persistent(1) = always -- the tests and
+    // tools/stress_persistent.py keep that instantiation honest.  Half-height launches (< 160 workgroups) have nothing to walk: loop-less always.
+    const bool persist = g_up1_persist > 0;
+#define NB_H3_GO(MW, F8, NBW, V2, F6, PP, HO) \
+    (persist ? launch_h3<MW, F8, NBW, V2, F6, PP, HO, true>(p, n, st) : launch_h3<MW, F8, NBW, V2, F6, PP, HO, false>(p, n, st))
+#define NB_H3_GO1(MW, F8, NBW, V2, F6) launch_h3<MW, F8, NBW, V2, F6, false, false, false>(p, n, st)
     if (f6) {                                               // (the software-pipelined loop only)
-        if (half) return c_out > 64 ? launch_h3<2, true, 1, true, true>(p, n, st) : launch_h3<1, true, 1, true, true>(p, n, st);
-        return c_out > 64 ? launch_h3<2, true, 2, true, true>(p, n, st) : launch_h3<1, true, 2, true, true>(p, n, st);
+        if (half) return c_out > 64 ? NB_H3_GO1(2, true, 1, true, true) : NB_H3_GO1(1, true, 1, true, true);
+        return c_out > 64 ? NB_H3_GO(2, true, 2, true, true, false, false) : NB_H3_GO(1, true, 2, true, true, false, false);
     }
     if (half) {
-        if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 1, true>(p, n, st) : launch_h3<1, true, 1, true>(p, n, st);
-        if (f8) return c_out > 64 ? launch_h3<2, true, 1>(p, n, st) : launch_h3<1, true, 1>(p, n, st);
-        if (v2) return c_out > 64 ? launch_h3<2, false, 1, true>(p, n, st) : launch_h3<1, false, 1, true>(p, n, st);
-        return c_out > 64 ? launch_h3<2, false, 1>(p, n, st) : launch_h3<1, false, 1>(p, n, st);
+        if (f8 && v2) return c_out > 64 ? NB_H3_GO1(2, true, 1, true, false) : NB_H3_GO1(1, true, 1, true, false);
+        if (f8) return c_out > 64 ? NB_H3_GO1(2, true, 1, false, false) : NB_H3_GO1(1, true, 1, false, false);
+        if (v2) return c_out > 64 ? NB_H3_GO1(2, false, 1, true, false) : NB_H3_GO1(1, false, 1, true, false);
+        return c_out > 64 ? NB_H3_GO1(2, false, 1, false, false) : NB_H3_GO1(1, false, 1, false, false);
     }
     // the ping-pong form of that loop (full-height tiles): nb_debug_set_up1_pp
     const bool pp = (g_force_up1_pp >= 0 ? g_force_up1_pp : NB_UP1_PP_DEFAULT) != 0;
-    // (persistent workgroups: automatic = NO, see the kernel's PERSIST; nb_debug_set_up1_persistent(1) = always: the tests and tools/stress_persistent.py
-    //  keep that form honest)
-    const bool persist = g_up1_persist > 0;
-    if (f8 && v2 && pp && hi_only) {
-        if (c_out > 64) return persist ? launch_h3<2, true, 2, true, false, true, true, true>(p, n, st) : launch_h3<2, true, 2, true, false, true, true, false>(p, n, st);
-        return persist ? launch_h3<1, true, 2, true, false, true, true, true>(p, n, st) : launch_h3<1, true, 2, true, false, true, true, false>(p, n, st);
-    }
-    if (f8 && v2 && pp) {
-        if (c_out > 64) return persist ? launch_h3<2, true, 2, true, false, true, false, true>(p, n, st) : launch_h3<2, true, 2, true, false, true, false, false>(p, n, st);
-        return persist ? launch_h3<1, true, 2, true, false, true, false, true>(p, n, st) : launch_h3<1, true, 2, true, false, true, false, false>(p, n, st);
-    }
-    if (f8 && v2) return c_out > 64 ? launch_h3<2, true, 2, true>(p, n, st) : launch_h3<1, true, 2, true>(p, n, st);
-    if (f8) return c_out > 64 ? launch_h3<2, true>(p, n, st) : launch_h3<1, true>(p, n, st);
-    if (v2) return c_out > 64 ? launch_h3<2, false, 2, true>(p, n, st) : launch_h3<1, false, 2, true>(p, n, st);
-    if (c_out > 64) return launch_h3<2>(p, n, st);
-    return launch_h3<1>(p, n, st);
+    if (f8 && v2 && pp && hi_only) return c_out > 64 ? NB_H3_GO(2, true, 2, true, false, true, true) : NB_H3_GO(1, true, 2, true, false, true, true);
+    if (f8 && v2 && pp) return c_out > 64 ? NB_H3_GO(2, true, 2, true, false, true, false) : NB_H3_GO(1, true, 2, true, false, true, false);
+    if (f8 && v2) return c_out > 64 ? NB_H3_GO(2, true, 2, true, false, false, false) : NB_H3_GO(1, true, 2, true, false, false, false);
+    if (f8) return c_out > 64 ? NB_H3_GO(2, true, 2, false, false, false, false) : NB_H3_GO(1, true, 2, false, false, false, false);
+    if (v2) return c_out > 64 ? NB_H3_GO(2, false, 2, true, false, false, false) : NB_H3_GO(1, false, 2, true, false, false, false);
+    return c_out > 64 ? NB_H3_GO(2, false, 2, false, false, false, false) : NB_H3_GO(1, false, 2, false, false, false, false);
+#undef NB_H3_GO
+#undef NB_H3_GO1
 }
 
 extern "C" int nb_modconv3x3_up1_h3_ex(const void* x, int c_in, const void* wts, const float* dcoefs, const float* noise,

@@ -44,14 +44,15 @@ void nb_debug_set_up2_pair(int mode);
  * tests/test_hip_f8.py asserts the two bit-identical. */
 void nb_debug_set_up2_v2(int mode);
 
-/* Workgroups of the 8-wave split-f16 up=1 kernel (round 6): -1 / 1 = persistent -- one per CU, each walking its share of the launch's
- * tiles with the NEXT tile's prologue (halo tile + three weight sub-chunks) issued ahead of the current tile's epilogue --, 0 = one
- * workgroup per tile.  tests/test_hip_f8.py asserts the two bit-identical. */
+/* Workgroups of the 8-wave split-f16 up=1 kernel: 1 = persistent -- a few per CU, each walking its share of the launch's tiles with
+ * the NEXT tile's prologue (halo tile + three weight sub-chunks) issued ahead of the current tile's epilogue --, -1 (default) / 0 = one
+ * workgroup per tile, on a loop-less instantiation of the same kernel (template parameter PERSIST: against round 5's kernels in the
+ * same library the persistent form measured 4.4 % slower at 64 channels, equal at 128).  tests/test_hip_f8.py asserts the two bit-identical. */
 void nb_debug_set_up1_persistent(int mode);
 
-/* Workgroups of the 12-row software-pipelined up=2 kernel (round 6): -1 / 1 = persistent -- one per CU, each walking its share of the
- * launch's tiles with the NEXT tile's first chunk prefetched under the current tile's epilogue --, 0 = one workgroup per tile (the form
- * of rounds 4-5).  tests/test_hip_f8.py asserts the two bit-identical. */
+/* Workgroups of the 12-row software-pipelined up=2 kernel: -1 (default) / 1 = persistent -- a few per CU, each walking its share of the
+ * launch's tiles with the NEXT tile's first chunk prefetched under the current tile's epilogue --, 0 = one workgroup per tile on the
+ * loop-less instantiation (PERSIST = false).  tests/test_hip_f8.py asserts the two bit-identical. */
 void nb_debug_set_up2v_persistent(int mode);
 
 /* Workgroups per CU of the persistent launches (both kernels above): default 4 (<= 0 restores it) -- a workgroup walks 2-4 tiles of the
