@@ -40,7 +40,7 @@ NB_FMTS=1 python tools/bench_f6_layers.py 2>&1 | grep "^up" > $O/large_layers.tx
 bash tools/ab_persist.sh > $O/ab_persistent.txt 2>&1
 bash tools/ab_streams.sh > $O/ab_streams.txt 2>&1
 # library-level A/B against the two features that were measured as gains by in-build switches and reverted (tools/build_variant_at.sh builds them from e618c53)
-[ -f brushstroke_engine_amd/csrc/libneube_wrap.so ] && bash tools/ab_variants.sh "shipped wrap early" 2>/dev/null | grep "patches/s" > $O/ab_variants.txt
+[ -f brushstroke_engine_amd/csrc/libneube_r05k.so ] && bash tools/ab_variants.sh "shipped r05k wrap early" 2>/dev/null | grep "patches/s" > $O/ab_variants.txt      # (r05k: tools/build_variant_at.sh r05k c6a9fb7 nb_modconv_h3.hip,nb_modconv_up2v.hip,nb_modconv_up2w.hip,nb_h3_common.h,nb_common.h,nb_torgb.h)
 python tools/ab_positions_once.py 2>/dev/null | grep "per tile" > $O/ab_positions_once.txt     # integer positions normalised once per batch instead of at the top of every tile
 python tools/ab_noise_in_kernel.py 2>/dev/null | grep "noise images" > $O/ab_noise_in_kernel.txt  # the large layers' noise: computed in the kernels (default) against the noise launch's images    # up2v: the next tile's epilogue operands and noise under the epilogue (NB_DEBUG=512: off)
 PAIRS=2 bash tools/ab_env.sh NB_STAGGER=200 > $O/ab_stagger.txt 2>&1
