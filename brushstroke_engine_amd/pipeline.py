@@ -279,9 +279,11 @@ class ConcurrentTriadSteps:
         self.rr = self._rr[k]
         self.streams = k
 
-    def choose(self, z, geom_feature, positions, rounds: int = 3, steps: int = 6) -> int:
-        """1 or 3 streams for batches like this one: ``rounds`` interleaved pairs of ``steps`` steps each, best of each; three unless
-        they are more than 3 % slower HERE.  ~15 steps' worth of time; the figures stay in ``probe``."""
+    def choose(self, z, geom_feature, positions, rounds: int = 4, steps: int = 6) -> int:
+        """1 or 3 streams for batches like this one: ``rounds`` interleaved pairs of ``steps`` steps each, the MEDIAN of each; three if
+        that is at least 1 % faster HERE, else one.  (Until the end of round 6: best of each, three unless 3 % slower -- on one box of the
+        pool three streams ran bimodal, 17 300 or 19 800 patches/s from run to run against a steady 18 000 on one, and the best-of probe
+        kept choosing them.)  ~50 steps' worth of time; the figures stay in ``probe``."""
         import time
         times = {1: [], 3: []}
 
@@ -298,8 +300,8 @@ class ConcurrentTriadSteps:
         for _ in range(rounds):
             times[1].append(run(1, steps))
             times[3].append(run(3, steps))
-        best = {k: min(v) for k, v in times.items()}
-        pick = 1 if best[3] > 1.03 * best[1] else 3
+        best = {k: sorted(v)[len(v) // 2] if len(v) % 2 else 0.5 * (sorted(v)[len(v) // 2 - 1] + sorted(v)[len(v) // 2]) for k, v in times.items()}
+        pick = 3 if best[3] <= 0.99 * best[1] else 1
         self._set_streams(pick)
         self.probe = {"ms_per_step": {str(k): round(v, 4) for k, v in best.items()}, "chosen": pick, "batch": int(z.shape[0])}
         return pick
